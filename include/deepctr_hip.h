@@ -1,0 +1,265 @@
+/*
+ * deepctr_hip.h -- C ABI of libdeepctr_hip.so: the MI355X (gfx950) replacement for what
+ * TensorFlow-1.4's CPU op kernels do underneath the reference's tf.estimator
+ * `input_fn` / `model_fn` pair (lambdaji/tf_repos, the deep_ctr Model_pipeline scripts).
+ *
+ * The reference has NO native ABI for this path -- its boundary is Python
+ * (`input_fn(filenames, batch_size, num_epochs, perform_shuffle)` DeepFM.py:63 and
+ * `model_fn(features, labels, mode, params)` DeepFM.py:100, driven by tf.estimator.Estimator
+ * DeepFM.py:341-366).  This ABI is therefore defined by the build and sits under the
+ * TF-1.x-compatible Python surface in tf_repos_amd/ (see INTEGRATION.md for the binding).
+ * Every entry point cites the reference lines whose TF ops it replaces.
+ *
+ * Conventions: plain pointers + explicit sizes, no torch types.  Every function returns an
+ * int status (0 = DCTR_OK, <0 = error).  `stream` is a hipStream_t passed as void* (NULL =
+ * the null stream).  Pointers named d_* are device (HBM) pointers; h_* are host pointers.
+ * Step functions never allocate.  Floating point is IEEE binary32 throughout (dtype "f32").
+ */
+#ifndef DEEPCTR_HIP_H
+#define DEEPCTR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (mapped by the Python shim to the TF exception classes) ---------- */
+#define DCTR_OK                 0
+#define DCTR_ERR_INVALID_ARG   -1   /* tf.errors.InvalidArgumentError: bad shape/flag/OOB id   */
+#define DCTR_ERR_HIP           -2   /* a HIP runtime call failed (see dctr_last_error)          */
+#define DCTR_ERR_NOT_FOUND     -3   /* unknown parameter name                                   */
+#define DCTR_ERR_OUT_OF_RANGE  -4   /* tf.errors.OutOfRangeError: end of input                  */
+#define DCTR_ERR_PARSE         -5   /* StringToNumberOp / ragged line (InvalidArgumentError)    */
+#define DCTR_ERR_UNSUPPORTED   -6
+
+/* ---- enums ------------------------------------------------------------------------ */
+enum { DCTR_MODEL_DEEPFM = 0,  /* DeepFM.py   */
+       DCTR_MODEL_FNN    = 1,  /* PNN.py --model_type=FNN   */
+       DCTR_MODEL_IPNN   = 2,  /* PNN.py --model_type=Inner */
+       DCTR_MODEL_OPNN   = 3,  /* PNN.py --model_type=Outer */
+       DCTR_MODEL_NFM    = 4,  /* NFM.py      */
+       DCTR_MODEL_AFM    = 5,  /* AFM.py      */
+       DCTR_MODEL_DCN    = 6   /* DCN.py      */ };
+
+enum { DCTR_OPT_ADAM = 0, DCTR_OPT_ADAGRAD = 1, DCTR_OPT_MOMENTUM = 2, DCTR_OPT_FTRL = 3 }; /* DeepFM.py:204-211 */
+
+/* how the embedding/linear tables are stepped: the reference's loss adds l2_reg*l2_loss(table)
+ * (DeepFM.py:189-190) so TF densifies the table gradient and runs the optimizer over all V rows
+ * every step.  DENSE_EXACT reproduces that; TOUCHED_ROWS updates only rows present in the batch
+ * (a different, "lazy" semantics -- never used for parity claims). */
+enum { DCTR_TABLE_DENSE_EXACT = 0, DCTR_TABLE_TOUCHED_ROWS = 1 };
+
+/* reductions fused into the gather (which model consumes the scaled embeddings) */
+enum { DCTR_GATHER_RAW = 0,   /* e only                    (PNN.py:133-136, DCN.py:134-138, AFM.py:127-130) */
+       DCTR_GATHER_FM  = 1,   /* + y_v = FM second order   (DeepFM.py:133-135)                               */
+       DCTR_GATHER_BI  = 2    /* + bi[B,K] bi-interaction  (NFM.py:126-128)                                  */ };
+
+#define DCTR_MAX_LAYERS 8
+
+typedef struct dctr_config {
+    int32_t model;                       /* DCTR_MODEL_*                                         */
+    int32_t field_size;                  /* --field_size      DeepFM.py:42                        */
+    int32_t embedding_size;              /* --embedding_size  DeepFM.py:43 (multiple of 4)        */
+    int64_t feature_size;                /* --feature_size    DeepFM.py:41 (rows of the tables)   */
+    int32_t n_deep_layers;               /* --deep_layers     DeepFM.py:51                        */
+    int32_t deep_layers[DCTR_MAX_LAYERS];
+    float   keep_prob[DCTR_MAX_LAYERS];  /* --dropout = TF keep_prob, DeepFM.py:52,162            */
+    int32_t cross_layers;                /* --cross_layers    DCN.py:52                           */
+    int32_t n_attention_layers;          /* --attention_layers AFM.py:52                          */
+    int32_t attention_layers[DCTR_MAX_LAYERS];
+    float   l2_reg;                      /* --l2_reg          DeepFM.py:48                        */
+    float   learning_rate;               /* --learning_rate   DeepFM.py:47                        */
+    int32_t optimizer;                   /* DCTR_OPT_*        DeepFM.py:50,204-211                */
+    int32_t table_mode;                  /* DCTR_TABLE_*                                          */
+    int32_t batch_norm;                  /* --batch_norm      DeepFM.py:53 (0/1)                  */
+    float   batch_norm_decay;            /* --batch_norm_decay DeepFM.py:54                       */
+    int32_t max_batch;                   /* largest batch any step/predict call will pass         */
+    uint64_t seed;                       /* dropout RNG seed                                      */
+    /* row sharding: this handle owns rows {id : id % world == rank}, local row = id / world.
+     * world = 1 -> the whole table.  Only the table allocation + table ops look at these. */
+    int32_t shard_rank;
+    int32_t shard_world;
+    int32_t use_graph;                   /* capture the step into a hipGraph (1) or launch eagerly (0) */
+} dctr_config;
+
+typedef struct dctr_engine* dctr_handle;
+
+/* ---- library ------------------------------------------------------------------------- */
+int         dctr_version(void);
+const char* dctr_last_error(void);                       /* thread-local message for the last error */
+int         dctr_device_count(int* n);
+int         dctr_set_device(int dev);
+
+/* raw device memory helpers for hosts without torch */
+int dctr_malloc(void** d_ptr, size_t nbytes);
+int dctr_free(void* d_ptr);
+int dctr_memcpy_h2d(void* d_dst, const void* h_src, size_t nbytes, void* stream);
+int dctr_memcpy_d2h(void* h_dst, const void* d_src, size_t nbytes, void* stream);
+int dctr_memset(void* d_dst, int value, size_t nbytes, void* stream);
+int dctr_stream_sync(void* stream);
+
+/* ---- K1: libsvm text -> tensors.  Replaces decode_libsvm (DeepFM.py:65-81): string_split(' '),
+ * string_to_number(label,f32), string_split(':'), string_to_number(ids,i32 / vals,f32).  Host code
+ * (re-entrant).  Parses up to max_rows lines from h_text[0:nbytes); every line must carry exactly
+ * field_size id:val tokens (DeepFM.py:92,120-122).  *n_rows = lines parsed, *n_consumed = bytes
+ * consumed (whole lines only).  Errors: DCTR_ERR_PARSE (message names line/token). */
+int dctr_parse_libsvm(const char* h_text, size_t nbytes, int field_size, int64_t max_rows,
+                      int32_t* h_ids, float* h_vals, float* h_labels,
+                      int64_t* n_rows, size_t* n_consumed);
+
+/* ---- K2: embedding gather + value scale + fused reductions.
+ * Replaces embedding_lookup(FM_W)/multiply/reduce_sum (DeepFM.py:126-127), embedding_lookup(FM_V),
+ * multiply (DeepFM.py:130-132), and per `mode` the FM second-order term (DeepFM.py:133-135) or NFM's
+ * bi-interaction (NFM.py:126-128).
+ *   d_emb [rows,K] f32, d_lin [rows] f32 or NULL (DCN has none), d_ids [B,F] i32, d_vals [B,F] f32
+ *   d_e   [B, e_ld] f32 out: e[b, f*K+k] = emb[id,k]*val   (e_ld >= F*K, row stride in floats)
+ *   d_yw  [B] out (NULL if d_lin NULL): sum_f lin[id]*val
+ *   d_sum [B,K] out or NULL: S[b,k] = sum_f e[b,f,k]       (kept for the backward)
+ *   d_red      out: mode FM -> y_v [B]; mode BI -> bi [B,K]; RAW -> ignored
+ *   d_status   int32[2] device word: [0] != 0 if any id was outside [0, feature_size) -- the id that
+ *              failed is stored in [1]; rows for such ids read as 0.  TF's CPU gather raises
+ *              InvalidArgumentError; the host checks the word with dctr_check_ids.
+ * ids are GLOBAL ids; with shard_world>1 the caller passes local rows instead (see dctr_table_*). */
+int dctr_embed_gather_fwd(const float* d_emb, const float* d_lin, int64_t rows,
+                          const int32_t* d_ids, const float* d_vals,
+                          int B, int F, int K, int mode,
+                          float* d_e, int e_ld, float* d_yw, float* d_sum, float* d_red,
+                          int32_t* d_status, void* stream);
+
+/* ---- K8a: group the batch's ids (the IndexedSlices -> unsorted_segment_sum bookkeeping,
+ * SURVEY Appendix B item 2).  n = B*F entries, traversed field-major.  Workspace is owned by a
+ * dctr_group object so that step calls never allocate. */
+typedef struct dctr_group* dctr_group_t;
+int dctr_group_create(int64_t rows, int64_t max_entries, int K, dctr_group_t* g);
+int dctr_group_destroy(dctr_group_t g);
+/* after this call (all on `stream`): uniq[0:U) = distinct ids, seg_start[0:U], perm[0:n) entry
+ * indices (entry = f*B+b) grouped by unique id, slot[id] = u+1 for touched ids (0 elsewhere). */
+int dctr_group_ids(dctr_group_t g, const int32_t* d_ids, int B, int F, void* stream);
+int dctr_group_num_unique(dctr_group_t g, int32_t* h_U, void* stream);   /* syncs */
+/* any out pointer may be NULL.  d_counters: int32[2] = {U, total grouped entries}; d_gemb [cap,K] / d_glin [cap] are
+ * the compact gradient rows (row u <-> uniq[u]) zeroed by dctr_group_ids and filled by dctr_embed_scatter_bwd. */
+int dctr_group_buffers(dctr_group_t g, const int32_t** d_uniq, const int32_t** d_seg_start, const int32_t** d_cnt,
+                       const int32_t** d_perm, const int32_t** d_slot, const int32_t** d_counters,
+                       float** d_gemb, float** d_glin);
+
+/* ---- K8b: sparse dW_emb / dW_lin: per-unique-row sums of the batch's row gradients.
+ * Replaces the gradient of the two gathers (DeepFM.py:126,130) densified by UnsortedSegmentSum.
+ *   d_dE [B, de_ld]: gradient w.r.t. the scaled embeddings e (from the model's backward)
+ *   FM term fused (mode FM/BI): dE += coef[b,k]-style terms, see DESIGN.md "scatter"
+ *   d_dy [B]: dLoss/dlogit (for the linear table); NULL if no linear table
+ *   outputs (compact, row u <-> uniq[u]):  d_gemb [U,K], d_glin [U]  (zeroed by dctr_group_ids) */
+int dctr_embed_scatter_bwd(dctr_group_t g, const float* d_dE, int de_ld,
+                           const float* d_e, int e_ld, const float* d_sum, const float* d_coef,
+                           const float* d_dy, const float* d_vals,
+                           int B, int F, int K, int mode,
+                           float* d_gemb, float* d_glin, void* stream);
+
+/* ---- K9: optimizers (DeepFM.py:204-213), TF-1.4 update rules.
+ * `hyper`: Adam {lr, beta1, beta2, eps, t}; Adagrad {lr}; Momentum {lr, momentum}; Ftrl {lr}.
+ * slot0/slot1: Adam m/v, Adagrad accum/-, Momentum accum/-, Ftrl accum/linear.
+ * grad = sum_{s<n_partials} d_grad[s*partial_stride + i]  (+ l2*theta if l2 != 0). */
+int dctr_opt_dense(int kind, const float* hyper, float* d_theta, float* d_slot0, float* d_slot1,
+                   const float* d_grad, int n_partials, int64_t partial_stride, int64_t n, float l2,
+                   void* stream);
+/* tables: dense-exact streams all `rows` rows: grad = l2*theta + (slot[r] ? compact_grad[slot[r]-1] : 0)
+ * and clears slot[r]; touched-rows visits only uniq[0:U).  emb [rows,K] and lin [rows] (lin may be NULL). */
+int dctr_opt_table(int kind, const float* hyper, int table_mode, int64_t rows, int K,
+                   float* d_emb, float* d_emb_s0, float* d_emb_s1,
+                   float* d_lin, float* d_lin_s0, float* d_lin_s1,
+                   dctr_group_t g, float l2, float* d_sumsq /* [2] += sum emb^2, sum lin^2 (pre-update) or NULL */,
+                   void* stream);
+
+/* ---- K6: dense layers on the matrix cores (fp32-input MFMA, exact f32).
+ * Replaces contrib.layers.fully_connected (DeepFM.py:156-158,165-166): y = act(x W + b), W [in,out].
+ * fwd: Y[M,N] = epilogue(X[M,K] W[K,N] + b);  relu!=0 -> max(.,0);  keep<1 -> dropout with a
+ *      counter-based RNG keyed by (seed, element index) -- `x*floor(keep+U)/keep` [TF-1.4].
+ * bwd_data:  dX[M,K] = dY[M,N] W^T, then if d_act != NULL: dX *= (act>0)/keep_prev  (ReLU+dropout of the
+ *            producing layer; act is that layer's stored output)
+ * bwd_weights: dW[K,N] = X^T dY, db[N] = colsum(dY) */
+int dctr_fc_fwd(const float* d_x, int ldx, const float* d_w, const float* d_b, float* d_y, int ldy,
+                int M, int K, int N, int relu, float keep, uint64_t seed, void* stream);
+int dctr_fc_bwd_data(const float* d_dy, int lddy, const float* d_w, float* d_dx, int lddx,
+                     int M, int K, int N, const float* d_act, int ldact, float keep_prev, void* stream);
+int dctr_fc_bwd_weights(const float* d_x, int ldx, const float* d_dy, int lddy, float* d_dw, float* d_db,
+                        int M, int K, int N, float* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ---- K3/K5/K4: interaction layers ------------------------------------------------------ */
+/* PNN inner product (PNN.py:141-152): ip[b,p] = <e[b,i_p,:], e[b,j_p,:]>, pairs lexicographic i<j. */
+int dctr_pnn_inner_fwd(const float* d_e, int e_ld, int B, int F, int K, float* d_ip, int ip_ld, void* stream);
+/* dE[b,i,:] += sum_j dip[b,pair(i,j)] e[b,j,:]   (accumulates into d_dE) */
+int dctr_pnn_inner_bwd(const float* d_e, int e_ld, const float* d_dip, int dip_ld, int B, int F, int K,
+                       float* d_dE, int de_ld, void* stream);
+/* PNN outer product (PNN.py:154-167): op[b,p,a,c] = e[b,i_p,a] e[b,j_p,c], materialised [B, P*K*K]. */
+int dctr_pnn_outer_fwd(const float* d_e, int e_ld, int B, int F, int K, float* d_op, int64_t op_ld, void* stream);
+int dctr_pnn_outer_bwd(const float* d_e, int e_ld, const float* d_dop, int64_t dop_ld, int B, int F, int K,
+                       float* d_dE, int de_ld, void* stream);
+/* DCN cross network (DCN.py:140-145): x_{l+1} = x0*(x_l . w_l) + x_l + b_l, w,b [L,D].
+ * d_xs [L+1, B, D] keeps every x_l (x_0 copied in) and d_xlw [L,B] every x_l.w_l for the backward. */
+int dctr_dcn_cross_fwd(const float* d_x0, int x0_ld, const float* d_w, const float* d_b, int B, int D, int L,
+                       float* d_xs, float* d_xlw, void* stream);
+/* in: d_dxL [B,D] gradient w.r.t. x_L (row stride dxl_ld).  out: d_dx0 [B,D] (accumulated into, row stride
+ * dx0_ld), d_dw/d_db [L,D] (overwritten). */
+int dctr_dcn_cross_bwd(const float* d_xs, const float* d_xlw, const float* d_w, const float* d_dxL, int dxl_ld,
+                       int B, int D, int L, float* d_dx0, int dx0_ld, float* d_dw, float* d_db,
+                       float* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ---- K7: loss head.  y = bias + y_w + y_v + y_d (DeepFM.py:174-175, terms may be NULL);
+ * prob = sigmoid(y) (DeepFM.py:176); loss = mean xent (DeepFM.py:188, [TF-1.4] stable form);
+ * d_dy = (prob - label)*inv_batch (inv_batch = 1/global batch).  d_loss_sum accumulates sum_b xent (caller zeroes, divides by B). */
+int dctr_loss_head(const float* d_bias, const float* d_yw, const float* d_yv, const float* d_yd,
+                   const float* d_labels, int B, float inv_batch, float* d_y, float* d_prob, float* d_dy,
+                   float* d_loss_sum, void* stream);
+
+/* ---- K10: tf.metrics.auc (DeepFM.py:194), 200 thresholds [TF-1.4].  d_counts int64[4*200]
+ * = tp,fn,tn,fp per threshold, accumulated across calls; result computed on the host. */
+int dctr_auc_update(const float* d_labels, const float* d_prob, int B, int64_t* d_counts, void* stream);
+int dctr_auc_result(const int64_t* d_counts, float* h_auc, void* stream);
+
+/* ---- engine: owns parameters, optimizer slots, activations; one handle per GPU rank ------- */
+int dctr_create(const dctr_config* cfg, dctr_handle* h);
+int dctr_destroy(dctr_handle h);
+/* parameters by engine name ("emb", "linear", "bias", "mlp0/weights", ... -- tf_repos_amd.checkpoint
+ * maps them to the TF variable names fm_v/fm_w/fm_bias/... of SURVEY Appendix A) */
+int dctr_param_count(dctr_handle h, int* n);
+int dctr_param_info(dctr_handle h, int index, const char** name, int* rank, int64_t dims[4]);
+int dctr_param_set(dctr_handle h, const char* name, const float* h_src, size_t nbytes);
+int dctr_param_get(dctr_handle h, const char* name, float* h_dst, size_t nbytes);
+/* optimizer slots: which = 0/1 (see dctr_opt_dense) */
+int dctr_slot_get(dctr_handle h, const char* name, int which, float* h_dst, size_t nbytes);
+int dctr_slot_set(dctr_handle h, const char* name, int which, const float* h_src, size_t nbytes);
+int dctr_param_device_ptr(dctr_handle h, const char* name, float** d_ptr);
+int dctr_set_global_step(dctr_handle h, int64_t step);
+int dctr_get_global_step(dctr_handle h, int64_t* step);
+
+/* one optimizer step on one batch: forward, loss, backward, optimizer (DeepFM.py:125-213).
+ * d_ids/d_vals/d_labels are device pointers ([B,F] i32, [B,F] f32, [B] f32).  h_loss (may be NULL)
+ * receives the full loss of DeepFM.py:188-190 evaluated BEFORE the update; passing it forces a sync. */
+int dctr_train_step(dctr_handle h, const int32_t* d_ids, const float* d_vals, const float* d_labels,
+                    int B, float* h_loss, void* stream);
+/* forward only (mode PREDICT/EVAL: dropout off, BN moving stats): d_prob [B] (may be NULL), d_logit [B] (may be NULL) */
+int dctr_predict(dctr_handle h, const int32_t* d_ids, const float* d_vals, int B,
+                 float* d_prob, float* d_logit, void* stream);
+/* raises DCTR_ERR_INVALID_ARG if any id seen since the last check was out of range (syncs) */
+int dctr_check_ids(dctr_handle h, void* stream);
+/* named intermediates of the last forward, for parity tests ("e","y_w","y_v","bi","inner","x_cross","att") */
+int dctr_debug_tensor(dctr_handle h, const char* name, float** d_ptr, int64_t* n_elems, int* ld);
+
+/* split step for the row-sharded multi-GPU path.  The dense half consumes already
+ * gathered+scaled embeddings (received through all-to-all) and returns dE / dy for the owners. */
+int dctr_dense_fwd_bwd(dctr_handle h, const float* d_e, int e_ld, const float* d_yw, const float* d_labels,
+                       int B, int global_batch, float* d_dE, int de_ld, float* d_dy, float* d_loss_sum,
+                       int train, void* stream);
+int dctr_dense_grads(dctr_handle h, float** d_grads, int64_t* n);      /* flat dense-gradient arena (all-reduce it) */
+int dctr_dense_apply(dctr_handle h, void* stream);                     /* optimizer on the dense arena        */
+
+/* per-kernel timing hooks used by bench.py for the roofline objects: runs `iters` back-to-back
+ * launches of the named kernel on the engine's current buffers between two hipEvents recorded on
+ * `stream`, returns the average milliseconds per launch. */
+int dctr_time_kernel(dctr_handle h, const char* kernel, int iters, float* h_ms_per_launch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPCTR_HIP_H */

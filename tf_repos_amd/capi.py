@@ -1,0 +1,149 @@
+"""ctypes binding of libdeepctr_hip.so (the C ABI declared in include/deepctr_hip.h).
+
+This is the only module that touches the shared library.  There is NO CPU fallback: if the
+library is missing or a call fails, a Python exception is raised (TF-style classes from
+tf_repos_amd.errors).  torch is used by callers purely as a device-memory / stream provider:
+tensors cross the boundary as raw pointers (`tensor.data_ptr()`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from . import errors
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libdeepctr_hip.so")
+
+DCTR_OK = 0
+MODELS = {"deepfm": 0, "fnn": 1, "ipnn": 2, "opnn": 3, "nfm": 4, "afm": 5, "dcn": 6}
+OPTIMIZERS = {"Adam": 0, "Adagrad": 1, "Momentum": 2, "ftrl": 3}
+TABLE_MODES = {"dense_exact": 0, "touched_rows": 1}
+GATHER_RAW, GATHER_FM, GATHER_BI = 0, 1, 2
+MAX_LAYERS = 8
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("model", C.c_int32), ("field_size", C.c_int32), ("embedding_size", C.c_int32),
+        ("feature_size", C.c_int64), ("n_deep_layers", C.c_int32),
+        ("deep_layers", C.c_int32 * MAX_LAYERS), ("keep_prob", C.c_float * MAX_LAYERS),
+        ("cross_layers", C.c_int32), ("n_attention_layers", C.c_int32),
+        ("attention_layers", C.c_int32 * MAX_LAYERS), ("l2_reg", C.c_float),
+        ("learning_rate", C.c_float), ("optimizer", C.c_int32), ("table_mode", C.c_int32),
+        ("batch_norm", C.c_int32), ("batch_norm_decay", C.c_float), ("max_batch", C.c_int32),
+        ("seed", C.c_uint64), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
+        ("use_graph", C.c_int32),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+_P = C.c_void_p
+_SIGS = {
+    "dctr_version": ([], C.c_int),
+    "dctr_last_error": ([], C.c_char_p),
+    "dctr_device_count": ([C.POINTER(C.c_int)], C.c_int),
+    "dctr_set_device": ([C.c_int], C.c_int),
+    "dctr_malloc": ([C.POINTER(_P), C.c_size_t], C.c_int),
+    "dctr_free": ([_P], C.c_int),
+    "dctr_memcpy_h2d": ([_P, _P, C.c_size_t, _P], C.c_int),
+    "dctr_memcpy_d2h": ([_P, _P, C.c_size_t, _P], C.c_int),
+    "dctr_memset": ([_P, C.c_int, C.c_size_t, _P], C.c_int),
+    "dctr_stream_sync": ([_P], C.c_int),
+    "dctr_parse_libsvm": ([C.c_char_p, C.c_size_t, C.c_int, C.c_int64, _P, _P, _P,
+                           C.POINTER(C.c_int64), C.POINTER(C.c_size_t)], C.c_int),
+    "dctr_embed_gather_fwd": ([_P, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
+                               _P, C.c_int, _P, _P, _P, _P, _P], C.c_int),
+    "dctr_group_create": ([C.c_int64, C.c_int64, C.c_int, C.POINTER(_P)], C.c_int),
+    "dctr_group_destroy": ([_P], C.c_int),
+    "dctr_group_ids": ([_P, _P, C.c_int, C.c_int, _P], C.c_int),
+    "dctr_group_num_unique": ([_P, C.POINTER(C.c_int32), _P], C.c_int),
+    "dctr_group_buffers": ([_P] + [C.POINTER(_P)] * 8, C.c_int),
+    "dctr_embed_scatter_bwd": ([_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P,
+                                C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P], C.c_int),
+    "dctr_opt_dense": ([C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int64, C.c_int64, C.c_float, _P], C.c_int),
+    "dctr_opt_table": ([C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P,
+                        C.c_float, _P, _P], C.c_int),
+    "dctr_fc_fwd": ([_P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                     C.c_uint64, _P], C.c_int),
+    "dctr_fc_bwd_data": ([_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int,
+                          C.c_float, _P], C.c_int),
+    "dctr_fc_bwd_weights": ([_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P,
+                             C.c_size_t, _P], C.c_int),
+    "dctr_pnn_inner_fwd": ([_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P], C.c_int),
+    "dctr_pnn_inner_bwd": ([_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P], C.c_int),
+    "dctr_pnn_outer_fwd": ([_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P], C.c_int),
+    "dctr_pnn_outer_bwd": ([_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P], C.c_int),
+    "dctr_dcn_cross_fwd": ([_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P], C.c_int),
+    "dctr_dcn_cross_bwd": ([_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P,
+                            _P, C.c_size_t, _P], C.c_int),
+    "dctr_loss_head": ([_P, _P, _P, _P, _P, C.c_int, C.c_float, _P, _P, _P, _P, _P], C.c_int),
+    "dctr_auc_update": ([_P, _P, C.c_int, _P, _P], C.c_int),
+    "dctr_auc_result": ([_P, C.POINTER(C.c_float), _P], C.c_int),
+    "dctr_create": ([C.POINTER(Config), C.POINTER(_P)], C.c_int),
+    "dctr_destroy": ([_P], C.c_int),
+    "dctr_param_count": ([_P, C.POINTER(C.c_int)], C.c_int),
+    "dctr_param_info": ([_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int64 * 4)], C.c_int),
+    "dctr_param_set": ([_P, C.c_char_p, _P, C.c_size_t], C.c_int),
+    "dctr_param_get": ([_P, C.c_char_p, _P, C.c_size_t], C.c_int),
+    "dctr_slot_get": ([_P, C.c_char_p, C.c_int, _P, C.c_size_t], C.c_int),
+    "dctr_slot_set": ([_P, C.c_char_p, C.c_int, _P, C.c_size_t], C.c_int),
+    "dctr_param_device_ptr": ([_P, C.c_char_p, C.POINTER(_P)], C.c_int),
+    "dctr_set_global_step": ([_P, C.c_int64], C.c_int),
+    "dctr_get_global_step": ([_P, C.POINTER(C.c_int64)], C.c_int),
+    "dctr_train_step": ([_P, _P, _P, _P, C.c_int, C.POINTER(C.c_float), _P], C.c_int),
+    "dctr_predict": ([_P, _P, _P, C.c_int, _P, _P, _P], C.c_int),
+    "dctr_check_ids": ([_P, _P], C.c_int),
+    "dctr_debug_tensor": ([_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int)], C.c_int),
+}
+
+DECLARED_SYMBOLS = tuple(_SIGS)
+
+
+def lib() -> C.CDLL:
+    """Loads the HIP library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise errors.NotFoundError(
+                "libdeepctr_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(l, name)          # AttributeError if the ABI and the header drift apart
+            fn.argtypes = args
+            fn.restype = res
+        _lib = l
+    return _lib
+
+
+def last_error() -> str:
+    return (lib().dctr_last_error() or b"").decode()
+
+
+_EXC = {-1: errors.InvalidArgumentError, -2: errors.InternalError, -3: errors.NotFoundError,
+        -4: errors.OutOfRangeError, -5: errors.InvalidArgumentError, -6: errors.UnimplementedError}
+
+
+def check(rc: int) -> None:
+    if rc != DCTR_OK:
+        raise _EXC.get(rc, errors.InternalError)("%s (status %d)" % (last_error(), rc))
+
+
+def ptr(t) -> C.c_void_p:
+    """Raw device (or host) pointer of a torch tensor / numpy array / None."""
+    if t is None:
+        return C.c_void_p(0)
+    if hasattr(t, "data_ptr"):
+        return C.c_void_p(t.data_ptr())
+    if hasattr(t, "ctypes"):
+        return C.c_void_p(t.ctypes.data)
+    return C.c_void_p(int(t))
+
+
+def current_stream() -> C.c_void_p:
+    """The hipStream_t torch is currently launching on (so torch ops and our kernels order)."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

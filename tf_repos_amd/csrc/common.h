@@ -1,0 +1,67 @@
+// Shared helpers for libdeepctr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/deepctr_hip.h"
+
+namespace dctr {
+
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define DCTR_HIP_CHECK(expr)                                                                  \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            ::dctr::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                              __LINE__);                                                      \
+            return DCTR_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+#define DCTR_LAUNCH_CHECK()                                                                   \
+    do {                                                                                      \
+        hipError_t _e = hipGetLastError();                                                    \
+        if (_e != hipSuccess) {                                                               \
+            ::dctr::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e),      \
+                              __FILE__, __LINE__);                                            \
+            return DCTR_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+#define DCTR_REQUIRE(cond, ...)                                                               \
+    do {                                                                                      \
+        if (!(cond)) {                                                                        \
+            ::dctr::set_error(__VA_ARGS__);                                                   \
+            return DCTR_ERR_INVALID_ARG;                                                      \
+        }                                                                                     \
+    } while (0)
+
+#define DCTR_TRY(expr)                                                                        \
+    do {                                                                                      \
+        int _rc = (expr);                                                                     \
+        if (_rc != DCTR_OK) return _rc;                                                       \
+    } while (0)
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// counter-based RNG for dropout: one 32-bit hash per element, keyed by (seed, index).
+// u in [0,1): mask = floor(keep + u) = (u >= 1-keep)   [nn.dropout, TF-1.4]
+__device__ __forceinline__ uint32_t hash32(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return (uint32_t)x;
+}
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float keep) {
+    const float u = (float)(hash32(seed ^ (idx * 0x9E3779B97F4A7C15ULL)) >> 8) * (1.0f / 16777216.0f);
+    return (u >= 1.0f - keep) ? 1.0f / keep : 0.0f;
+}
+
+}  // namespace dctr

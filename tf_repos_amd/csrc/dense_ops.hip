@@ -1,0 +1,494 @@
+// K7 loss head, K9 optimizers, K10 streaming AUC, and the N=1 output layers (row dots).
+// All HBM-bound streaming kernels: float4 / 16-byte-per-lane coalesced accesses, grid-stride loops,
+// reductions in registers -> wave shuffles -> one atomic per block.
+#include "common.h"
+#include "ops.h"
+
+namespace dctr {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// ---- y[b] (+)= x[b,:] . w + bias : the [*,1] fully_connected layers (DeepFM.py:165-166, DCN.py:180-182,
+// AFM.py:147,160-161) and DCN's x_l . w_l (DCN.py:144).  One wave per row.
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, int M, int n,
+                                                    float* __restrict__ y, int accumulate) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * ldx;
+    float s = 0.f;
+    for (int j = lane; j < n; j += 64) s += xr[j] * w[j];
+    s = wave_sum(s);
+    if (lane == 0) {
+        if (bias != nullptr) s += bias[0];
+        y[row] = accumulate ? y[row] + s : s;
+    }
+}
+
+int rowdot(const float* x, int ldx, const float* w, const float* bias, int M, int n, float* y, int accumulate,
+           hipStream_t st) {
+    if (M <= 0) return DCTR_OK;
+    rowdot_kernel<<<ceil_div(M, 4), 256, 0, st>>>(x, ldx, w, bias, M, n, y, accumulate);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+// ---- dX[b,j] (+)= dy[b] * w[j], optionally masked by the producing layer's ReLU/dropout ((act>0)/keep)
+__global__ __launch_bounds__(256) void rank1_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ w, int M, int n,
+                                                       const float* __restrict__ act, int ldact, float inv_keep,
+                                                       float* __restrict__ dx, int lddx, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)M * n) return;
+    const int b = (int)(i / n), j = (int)(i - (int64_t)b * n);
+    float v = dy[b] * w[j];
+    if (act != nullptr) v = (act[(size_t)b * ldact + j] > 0.f) ? v * inv_keep : 0.f;
+    float* o = dx + (size_t)b * lddx + j;
+    *o = accumulate ? *o + v : v;
+}
+
+int rank1_bwd(const float* dy, const float* w, int M, int n, const float* act, int ldact, float keep, float* dx,
+              int lddx, int accumulate, hipStream_t st) {
+    if (M <= 0 || n <= 0) return DCTR_OK;
+    rank1_bwd_kernel<<<ceil_div((int64_t)M * n, 256), 256, 0, st>>>(dy, w, M, n, act, ldact, 1.0f / keep, dx, lddx, accumulate);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+// ---- column sums with an optional per-row scale: out[s][c] = sum_{r in split s} rs[r] * Y[r,c]
+__global__ __launch_bounds__(256) void colsum_scaled_kernel(const float* __restrict__ Y, int ldy, const float* __restrict__ rs,
+                                                           int M, int N, int rows_per_split, float* __restrict__ out,
+                                                           int64_t split_stride) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int rbeg = blockIdx.y * rows_per_split, rend = min(M, rbeg + rows_per_split);
+    float s = 0.f;
+    if (c < N) {
+        if (rs != nullptr)
+            for (int r = rbeg + rl; r < rend; r += 4) s += rs[r] * Y[(size_t)r * ldy + c];
+        else
+            for (int r = rbeg + rl; r < rend; r += 4) s += Y[(size_t)r * ldy + c];
+    }
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < N) {
+        const int x = threadIdx.x;
+        out[(size_t)blockIdx.y * split_stride + c] = red[0][x] + red[1][x] + red[2][x] + red[3][x];
+    }
+}
+
+int colsum_partials(const float* Y, int ldy, const float* rs, int M, int N, int splits, float* out,
+                    int64_t split_stride, hipStream_t st) {
+    if (N <= 0) return DCTR_OK;
+    dim3 grid(ceil_div(N, 64), splits), block(256);
+    colsum_scaled_kernel<<<grid, block, 0, st>>>(Y, ldy, rs, M, N, ceil_div(M, splits), out, split_stride);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+// ---- K7 loss head (DeepFM.py:174-176,188) -----------------------------------------------------
+__global__ __launch_bounds__(256) void loss_head_kernel(const float* __restrict__ bias, const float* __restrict__ yw,
+                                                       const float* __restrict__ yv, const float* __restrict__ yd,
+                                                       const float* __restrict__ labels, int B, float inv_batch,
+                                                       float* __restrict__ y_out, float* __restrict__ prob,
+                                                       float* __restrict__ dy, float* __restrict__ loss_sum) {
+    __shared__ float red[4];
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    float l = 0.f;
+    if (b < B) {
+        float y = 0.f;
+        if (bias) y += bias[0];
+        if (yw) y += yw[b];
+        if (yv) y += yv[b];
+        if (yd) y += yd[b];
+        // sigmoid via exp(-|y|): no overflow for large |y|
+        const float en = __expf(-fabsf(y));
+        const float p = (y >= 0.f) ? 1.0f / (1.0f + en) : en / (1.0f + en);
+        if (y_out) y_out[b] = y;
+        if (prob) prob[b] = p;
+        if (labels) {
+            const float z = labels[b];
+            // max(x,0) - x z + log1p(exp(-|x|))   [TF-1.4 sigmoid_cross_entropy_with_logits]
+            l = fmaxf(y, 0.f) - y * z + log1pf(expf(-fabsf(y)));
+            if (dy) dy[b] = (p - z) * inv_batch;
+        }
+    }
+    l = wave_sum(l);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_sum != nullptr && labels != nullptr) atomicAdd(loss_sum, red[0] + red[1] + red[2] + red[3]);
+}
+
+int loss_head(const float* bias, const float* yw, const float* yv, const float* yd, const float* labels, int B,
+              float inv_batch, float* y, float* prob, float* dy, float* loss_sum, hipStream_t st) {
+    if (B <= 0) return DCTR_OK;
+    loss_head_kernel<<<ceil_div(B, 256), 256, 0, st>>>(bias, yw, yv, yd, labels, B, inv_batch, y, prob, dy, loss_sum);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+// ---- K9 optimizers (DeepFM.py:204-211), TF-1.4 update rules ----------------------------------
+__device__ __forceinline__ void opt_update(int kind, const Hyper& h, float& th, float& s0, float& s1, float g) {
+    switch (kind) {
+        case DCTR_OPT_ADAM: {           // m,v ; theta -= lr_t m/(sqrt(v)+eps), lr_t = lr sqrt(1-b2^t)/(1-b1^t)
+            s0 = h.beta1 * s0 + (1.0f - h.beta1) * g;
+            s1 = h.beta2 * s1 + (1.0f - h.beta2) * g * g;
+            th = th - h.lr_t * s0 / (sqrtf(s1) + h.eps);
+        } break;
+        case DCTR_OPT_ADAGRAD: {        // accum += g^2 ; theta -= lr g / sqrt(accum)
+            s0 = s0 + g * g;
+            th = th - h.lr * g / sqrtf(s0);
+        } break;
+        case DCTR_OPT_MOMENTUM: {       // accum = mom*accum + g ; theta -= lr accum
+            s0 = h.momentum * s0 + g;
+            th = th - h.lr * s0;
+        } break;
+        case DCTR_OPT_FTRL: {           // lr_power = -0.5, l1 = l2 = 0: s0 = accum, s1 = linear
+            const float na = s0 + g * g;
+            const float sigma = (sqrtf(na) - sqrtf(s0)) / h.lr;
+            s1 = s1 + g - sigma * th;
+            th = -s1 / (sqrtf(na) / h.lr);
+            s0 = na;
+        } break;
+    }
+}
+
+__device__ __forceinline__ Hyper load_hyper(const Hyper* dev, const Hyper& val) { return dev ? *dev : val; }
+
+// dense arena: OPT_BLOCK elements per block; per-block metadata says where the gradient partials live
+template <int KIND>
+__global__ __launch_bounds__(256) void opt_dense_kernel(const Hyper* __restrict__ hdev, Hyper hval,
+                                                       float4* __restrict__ theta, float4* __restrict__ s0,
+                                                       float4* __restrict__ s1, const float* __restrict__ parts,
+                                                       const OptBlockMeta* __restrict__ meta, float4* __restrict__ gout,
+                                                       int apply, float* __restrict__ sumsq) {
+    const Hyper h = load_hyper(hdev, hval);
+    const OptBlockMeta m = meta[blockIdx.x];
+    const size_t i4 = (size_t)blockIdx.x * (OPT_BLOCK / 4) + threadIdx.x;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* p = reinterpret_cast<const float4*>(parts + m.part_off) + threadIdx.x;
+    for (int s = 0; s < m.n_part; ++s) {
+        const float4 q = p[(size_t)s * (m.part_stride / 4)];
+        g.x += q.x; g.y += q.y; g.z += q.z; g.w += q.w;
+    }
+    if (gout != nullptr) gout[i4] = g;       // reduced gradient (for the all-reduce in the multi-GPU path)
+    if (!apply) return;
+    float4 th = theta[i4];
+    if (m.l2 != 0.f) {
+        g.x += m.l2 * th.x; g.y += m.l2 * th.y; g.z += m.l2 * th.z; g.w += m.l2 * th.w;
+        if (sumsq != nullptr) {   // l2_loss term of the reported loss (DCN.py:199), pre-update values; padding is zero
+            float sq = wave_sum(th.x * th.x + th.y * th.y + th.z * th.z + th.w * th.w);
+            if ((threadIdx.x & 63) == 0) atomicAdd(sumsq, sq);
+        }
+    }
+    float4 a = s0[i4];
+    float4 b = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) ? s1[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    opt_update(KIND, h, th.x, a.x, b.x, g.x);
+    opt_update(KIND, h, th.y, a.y, b.y, g.y);
+    opt_update(KIND, h, th.z, a.z, b.z, g.z);
+    opt_update(KIND, h, th.w, a.w, b.w, g.w);
+    theta[i4] = th;
+    s0[i4] = a;
+    if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) s1[i4] = b;
+}
+
+int opt_dense_arena(int kind, const Hyper* hdev, const Hyper& hval, float* theta, float* s0, float* s1,
+                    const float* parts, const OptBlockMeta* meta, int n_blocks, float* gout, int apply, float* sumsq,
+                    hipStream_t st) {
+    if (n_blocks <= 0) return DCTR_OK;
+    float4* t4 = reinterpret_cast<float4*>(theta);
+    float4* a4 = reinterpret_cast<float4*>(s0);
+    float4* b4 = reinterpret_cast<float4*>(s1);
+    float4* g4 = reinterpret_cast<float4*>(gout);
+    switch (kind) {
+#define DCTR_K(KD) case KD: opt_dense_kernel<KD><<<n_blocks, 256, 0, st>>>(hdev, hval, t4, a4, b4, parts, meta, g4, apply, sumsq); break
+        DCTR_K(DCTR_OPT_ADAM); DCTR_K(DCTR_OPT_ADAGRAD); DCTR_K(DCTR_OPT_MOMENTUM); DCTR_K(DCTR_OPT_FTRL);
+#undef DCTR_K
+        default: set_error("unknown optimizer kind %d", kind); return DCTR_ERR_INVALID_ARG;
+    }
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+// plain flat variant for the op-level C ABI
+template <int KIND>
+__global__ __launch_bounds__(256) void opt_flat_kernel(const Hyper* __restrict__ hdev, Hyper hval, float* __restrict__ theta,
+                                                      float* __restrict__ s0, float* __restrict__ s1,
+                                                      const float* __restrict__ grad, int n_part, int64_t part_stride,
+                                                      int64_t n, float l2) {
+    const Hyper h = load_hyper(hdev, hval);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float g = 0.f;
+        for (int s = 0; s < n_part; ++s) g += grad[(size_t)s * part_stride + i];
+        float th = theta[i];
+        g += l2 * th;
+        float a = s0[i];
+        float b = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) ? s1[i] : 0.f;
+        opt_update(KIND, h, th, a, b, g);
+        theta[i] = th;
+        s0[i] = a;
+        if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) s1[i] = b;
+    }
+}
+
+int opt_dense_flat(int kind, const Hyper* hdev, const Hyper& hval, float* theta, float* s0, float* s1, const float* grad,
+                   int n_part, int64_t part_stride, int64_t n, float l2, hipStream_t st) {
+    if (n <= 0) return DCTR_OK;
+    const int grid = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
+    switch (kind) {
+#define DCTR_K(KD) case KD: opt_flat_kernel<KD><<<grid, 256, 0, st>>>(hdev, hval, theta, s0, s1, grad, n_part, part_stride, n, l2); break
+        DCTR_K(DCTR_OPT_ADAM); DCTR_K(DCTR_OPT_ADAGRAD); DCTR_K(DCTR_OPT_MOMENTUM); DCTR_K(DCTR_OPT_FTRL);
+#undef DCTR_K
+        default: set_error("unknown optimizer kind %d", kind); return DCTR_ERR_INVALID_ARG;
+    }
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+// tables.  DENSE: stream every row; grad = l2*theta + (slot[r] ? compact[slot[r]-1] : 0)  -- what TF does when the
+// IndexedSlices gradient meets the dense l2_loss gradient (DeepFM.py:189-190,213).  Also accumulates
+// sum(theta_old^2) so the l2 part of the reported loss is free.  TOUCHED: only rows uniq[0:U).
+template <int KIND, int KQ, bool DENSE>
+__global__ __launch_bounds__(256) void opt_table_emb_kernel(const Hyper* __restrict__ hdev, Hyper hval, int64_t rows,
+                                                           float4* __restrict__ emb, float4* __restrict__ s0,
+                                                           float4* __restrict__ s1, const int32_t* __restrict__ slot,
+                                                           const int32_t* __restrict__ uniq, const int32_t* __restrict__ counters,
+                                                           const float4* __restrict__ gemb, float l2,
+                                                           float* __restrict__ sumsq) {
+    const Hyper h = load_hyper(hdev, hval);
+    const int64_t n_items = DENSE ? rows : (int64_t)counters[0];
+    float sq = 0.f;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_items * KQ;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t item = t / KQ;
+        const int kq = (int)(t - item * KQ);
+        int64_t r;
+        int u;
+        if (DENSE) { r = item; u = slot[r] - 1; } else { u = (int)item; r = uniq[u]; }
+        const size_t i4 = (size_t)r * KQ + kq;
+        float4 th = emb[i4];
+        sq += th.x * th.x + th.y * th.y + th.z * th.z + th.w * th.w;
+        float4 g = make_float4(l2 * th.x, l2 * th.y, l2 * th.z, l2 * th.w);
+        if (u >= 0) {
+            const float4 q = gemb[(size_t)u * KQ + kq];
+            g.x += q.x; g.y += q.y; g.z += q.z; g.w += q.w;
+        }
+        float4 a = s0[i4];
+        float4 b = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) ? s1[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        opt_update(KIND, h, th.x, a.x, b.x, g.x);
+        opt_update(KIND, h, th.y, a.y, b.y, g.y);
+        opt_update(KIND, h, th.z, a.z, b.z, g.z);
+        opt_update(KIND, h, th.w, a.w, b.w, g.w);
+        emb[i4] = th;
+        s0[i4] = a;
+        if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) s1[i4] = b;
+    }
+    if (sumsq != nullptr) {
+        __shared__ float red[4];
+        sq = wave_sum(sq);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(sumsq, red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
+template <int KIND, bool DENSE>
+__global__ __launch_bounds__(256) void opt_table_lin_kernel(const Hyper* __restrict__ hdev, Hyper hval, int64_t rows,
+                                                           float* __restrict__ lin, float* __restrict__ s0,
+                                                           float* __restrict__ s1, const int32_t* __restrict__ slot,
+                                                           const int32_t* __restrict__ uniq, const int32_t* __restrict__ counters,
+                                                           const float* __restrict__ glin, float l2,
+                                                           float* __restrict__ sumsq) {
+    const Hyper h = load_hyper(hdev, hval);
+    const int64_t n_items = DENSE ? rows : (int64_t)counters[0];
+    float sq = 0.f;
+    for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < n_items;
+         item += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r;
+        int u;
+        if (DENSE) { r = item; u = slot[r] - 1; } else { u = (int)item; r = uniq[u]; }
+        float th = lin[r];
+        sq += th * th;
+        float g = l2 * th;
+        if (u >= 0) g += glin[u];
+        float a = s0[r];
+        float b = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) ? s1[r] : 0.f;
+        opt_update(KIND, h, th, a, b, g);
+        lin[r] = th;
+        s0[r] = a;
+        if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) s1[r] = b;
+    }
+    if (sumsq != nullptr) {
+        __shared__ float red[4];
+        sq = wave_sum(sq);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(sumsq, red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
+template <int KIND, bool DENSE>
+static int launch_table(const Hyper* hdev, const Hyper& hval, int64_t rows, int K, float* emb, float* e0, float* e1,
+                        float* lin, float* l0, float* l1, const int32_t* slot, const int32_t* uniq,
+                        const int32_t* counters, int64_t max_entries, const float* gemb, const float* glin, float l2,
+                        float* sumsq_emb, float* sumsq_lin, hipStream_t st) {
+    const int KQ = K / 4;
+    const int64_t items = DENSE ? rows : max_entries;
+    const int grid = (int)std::min<int64_t>(ceil_div(items * KQ, 256), 256 * 16);
+    float4* e4 = reinterpret_cast<float4*>(emb);
+    float4* a4 = reinterpret_cast<float4*>(e0);
+    float4* b4 = reinterpret_cast<float4*>(e1);
+    const float4* g4 = reinterpret_cast<const float4*>(gemb);
+    switch (KQ) {
+#define DCTR_T(Q) case Q: opt_table_emb_kernel<KIND, Q, DENSE><<<grid, 256, 0, st>>>(hdev, hval, rows, e4, a4, b4, slot, uniq, counters, g4, l2, sumsq_emb); break
+        DCTR_T(1); DCTR_T(2); DCTR_T(4); DCTR_T(8); DCTR_T(16); DCTR_T(32); DCTR_T(64);
+#undef DCTR_T
+        default: set_error("opt_table: K=%d unsupported", K); return DCTR_ERR_UNSUPPORTED;
+    }
+    if (lin != nullptr) {
+        const int gl = (int)std::min<int64_t>(ceil_div(items, 256), 256 * 8);
+        opt_table_lin_kernel<KIND, DENSE><<<gl, 256, 0, st>>>(hdev, hval, rows, lin, l0, l1, slot, uniq, counters, glin, l2, sumsq_lin);
+    }
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+int opt_table(int kind, const Hyper* hdev, const Hyper& hval, int table_mode, int64_t rows, int K, float* emb, float* e0,
+              float* e1, float* lin, float* l0, float* l1, const int32_t* slot, const int32_t* uniq,
+              const int32_t* counters, int64_t max_entries, const float* gemb, const float* glin, float l2,
+              float* sumsq_emb, float* sumsq_lin, hipStream_t st) {
+    const bool dense = table_mode == DCTR_TABLE_DENSE_EXACT;
+#define DCTR_K(KD)                                                                                                      \
+    case KD:                                                                                                            \
+        return dense ? launch_table<KD, true>(hdev, hval, rows, K, emb, e0, e1, lin, l0, l1, slot, uniq, counters,      \
+                                              max_entries, gemb, glin, l2, sumsq_emb, sumsq_lin, st)                    \
+                     : launch_table<KD, false>(hdev, hval, rows, K, emb, e0, e1, lin, l0, l1, slot, uniq, counters,     \
+                                               max_entries, gemb, glin, l2, sumsq_emb, sumsq_lin, st)
+    switch (kind) {
+        DCTR_K(DCTR_OPT_ADAM); DCTR_K(DCTR_OPT_ADAGRAD); DCTR_K(DCTR_OPT_MOMENTUM); DCTR_K(DCTR_OPT_FTRL);
+        default: set_error("unknown optimizer kind %d", kind); return DCTR_ERR_INVALID_ARG;
+    }
+#undef DCTR_K
+}
+
+// ---- per-step device state: global_step, Adam's lr_t, the dropout seed of this step.  Lives in device memory
+// so that a captured hipGraph sees fresh values on every replay.
+__global__ void step_state_kernel(StepState* s) {
+    s->t += 1;
+    const double t = (double)s->t;
+    Hyper& h = s->hyper;
+    h.lr_t = (float)((double)h.lr * sqrt(1.0 - pow((double)h.beta2, t)) / (1.0 - pow((double)h.beta1, t)));
+    s->seed_t = s->seed ^ ((uint64_t)s->t * 0xD1B54A32D192ED03ULL);
+}
+
+int step_state_advance(StepState* s, hipStream_t st) {
+    step_state_kernel<<<1, 1, 0, st>>>(s);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+// ---- K10 tf.metrics.auc: 200 thresholds, counts tp/fn/tn/fp with pred > thr [TF-1.4] ---------
+__global__ __launch_bounds__(256) void auc_update_kernel(const float* __restrict__ labels, const float* __restrict__ prob,
+                                                        int B, unsigned long long* __restrict__ counts) {
+    // one thread per threshold (200 of the 256 lanes), each walks the batch: B*200 compares, trivial
+    const int k = threadIdx.x;
+    if (k >= 200) return;
+    const float eps = 1e-7f;
+    float thr;
+    if (k == 0) thr = 0.0f - eps;
+    else if (k == 199) thr = 1.0f + eps;
+    else thr = (float)k * 1.0f / 199.0f;
+    const int chunk = (B + gridDim.x - 1) / gridDim.x;
+    const int b0 = blockIdx.x * chunk, b1 = min(B, b0 + chunk);
+    unsigned long long tp = 0, fn = 0, tn = 0, fp = 0;
+    for (int b = b0; b < b1; ++b) {
+        const bool pos = labels[b] != 0.f;
+        const bool gt = prob[b] > thr;
+        tp += (pos && gt); fn += (pos && !gt); fp += (!pos && gt); tn += (!pos && !gt);
+    }
+    if (b1 > b0) {
+        atomicAdd(&counts[0 * 200 + k], tp);
+        atomicAdd(&counts[1 * 200 + k], fn);
+        atomicAdd(&counts[2 * 200 + k], tn);
+        atomicAdd(&counts[3 * 200 + k], fp);
+    }
+}
+
+}  // namespace dctr
+
+using namespace dctr;
+
+static Hyper hyper_from_host(int kind, const float* hyper) {
+    Hyper h{};
+    h.lr = hyper[0];
+    h.beta1 = 0.9f; h.beta2 = 0.999f; h.eps = 1e-8f; h.momentum = 0.95f; h.lr_t = h.lr;
+    if (kind == DCTR_OPT_ADAM) {
+        h.beta1 = hyper[1]; h.beta2 = hyper[2]; h.eps = hyper[3];
+        const double t = (double)hyper[4];
+        h.lr_t = (float)((double)h.lr * sqrt(1.0 - pow((double)h.beta2, t)) / (1.0 - pow((double)h.beta1, t)));
+    } else if (kind == DCTR_OPT_MOMENTUM) {
+        h.momentum = hyper[1];
+    }
+    return h;
+}
+
+extern "C" {
+
+int dctr_loss_head(const float* d_bias, const float* d_yw, const float* d_yv, const float* d_yd, const float* d_labels,
+                   int B, float inv_batch, float* d_y, float* d_prob, float* d_dy, float* d_loss_sum, void* stream) {
+    return loss_head(d_bias, d_yw, d_yv, d_yd, d_labels, B, inv_batch, d_y, d_prob, d_dy, d_loss_sum, as_stream(stream));
+}
+
+int dctr_opt_dense(int kind, const float* hyper, float* d_theta, float* d_slot0, float* d_slot1, const float* d_grad,
+                   int n_partials, int64_t partial_stride, int64_t n, float l2, void* stream) {
+    DCTR_REQUIRE(hyper != nullptr, "hyper required");
+    const Hyper h = hyper_from_host(kind, hyper);
+    return opt_dense_flat(kind, nullptr, h, d_theta, d_slot0, d_slot1, d_grad, n_partials, partial_stride, n, l2, as_stream(stream));
+}
+
+int dctr_opt_table(int kind, const float* hyper, int table_mode, int64_t rows, int K, float* d_emb, float* d_emb_s0,
+                   float* d_emb_s1, float* d_lin, float* d_lin_s0, float* d_lin_s1, dctr_group_t g, float l2,
+                   float* d_sumsq, void* stream) {
+    DCTR_REQUIRE(hyper != nullptr && g != nullptr, "hyper and group required");
+    const Hyper h = hyper_from_host(kind, hyper);
+    const int32_t *uniq, *slot, *counters;
+    float *gemb, *glin;
+    DCTR_TRY(dctr_group_buffers(g, &uniq, nullptr, nullptr, nullptr, &slot, &counters, &gemb, &glin));
+    const int64_t max_entries = group_capacity(reinterpret_cast<Group*>(g));
+    return opt_table(kind, nullptr, h, table_mode, rows, K, d_emb, d_emb_s0, d_emb_s1, d_lin, d_lin_s0, d_lin_s1, slot,
+                     uniq, counters, max_entries, gemb, glin, l2, d_sumsq, d_sumsq ? d_sumsq + 1 : nullptr, as_stream(stream));
+}
+
+int dctr_auc_update(const float* d_labels, const float* d_prob, int B, int64_t* d_counts, void* stream) {
+    if (B <= 0) return DCTR_OK;
+    const int grid = std::max(1, std::min(256, B / 64));
+    auc_update_kernel<<<grid, 256, 0, as_stream(stream)>>>(d_labels, d_prob, B, reinterpret_cast<unsigned long long*>(d_counts));
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+int dctr_auc_result(const int64_t* d_counts, float* h_auc, void* stream) {
+    DCTR_REQUIRE(h_auc != nullptr, "null out pointer");
+    int64_t c[800];
+    DCTR_HIP_CHECK(hipMemcpyAsync(c, d_counts, sizeof(c), hipMemcpyDeviceToHost, as_stream(stream)));
+    DCTR_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+    // trapezoid over the ROC points, float32 arithmetic as tf.metrics.auc does [TF-1.4]
+    const float eps = 1e-6f;
+    float tpr[200], fpr[200];
+    for (int k = 0; k < 200; ++k) {
+        const float tp = (float)c[k], fn = (float)c[200 + k], tn = (float)c[400 + k], fp = (float)c[600 + k];
+        tpr[k] = (tp + eps) / (tp + fn + eps);
+        fpr[k] = fp / (fp + tn + eps);
+    }
+    float auc = 0.f;
+    for (int k = 0; k < 199; ++k) auc += (fpr[k] - fpr[k + 1]) * (tpr[k] + tpr[k + 1]) / 2.0f;
+    *h_auc = auc;
+    return DCTR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,624 @@
+// The engine: owns the tables, the dense-parameter arena, optimizer slots and activations of ONE rank, and runs
+// the whole model_fn step (DeepFM.py:125-213 and the PNN/NFM/DCN variants) as a fixed sequence of HIP kernels,
+// captured once per batch size into a hipGraph so a step costs one graph launch.
+//
+// HBM layout (all f32):
+//   tables    emb [rows,K] + 2 optimizer slots, linear [rows] + 2 slots      (rows = ceil((V - rank)/world))
+//   arena     every dense variable padded to OPT_BLOCK floats, one flat theta/slot0/slot1 triple
+//   parts     gradient partial slabs (split-K wgrad / column sums); the optimizer kernel sums them
+//   acts      x_in [B, Din_ld] (the scaled embeddings e are its first F*K columns), h_i [B,H_i], dh_i, ...
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "ops.h"
+
+namespace dctr {
+
+struct Param {
+    std::string name;
+    int rank = 1;
+    int64_t dims[4] = {1, 1, 1, 1};
+    int64_t n = 0;
+    bool is_table = false;
+    float* ptr = nullptr;        // device
+    float* s0 = nullptr;
+    float* s1 = nullptr;
+    int64_t arena_off = 0;       // dense params: offset in the arena
+    int64_t padded = 0;
+    int64_t part_off = 0;        // offset of the first partial slab in `parts`
+    int n_part = 1;
+    float l2 = 0.f;
+};
+
+struct Fc {
+    int in = 0, out = 0;
+    int w = -1, b = -1;          // indices into params
+    float keep = 1.f;
+    int splits = 1;
+};
+
+}  // namespace dctr
+
+using namespace dctr;
+
+struct dctr_engine {
+    dctr_config cfg{};
+    int F = 0, K = 0, P = 0, D = 0;      // D = F*K
+    int64_t rows = 0;
+    int MB = 0;
+    int Din = 0, Din_ld = 0;
+    std::vector<Param> params;
+    std::map<std::string, int> index;
+    std::vector<Fc> mlp;
+    int p_out_w = -1, p_out_b = -1, p_bias = -1, p_cross_w = -1, p_cross_b = -1;
+    int out_splits = 8;
+
+    // tables
+    float *emb = nullptr, *emb_s0 = nullptr, *emb_s1 = nullptr, *lin = nullptr, *lin_s0 = nullptr, *lin_s1 = nullptr;
+    Group* group = nullptr;
+    // arena
+    float *theta = nullptr, *as0 = nullptr, *as1 = nullptr, *gflat = nullptr, *parts = nullptr;
+    int64_t arena_n = 0, parts_n = 0;
+    OptBlockMeta* meta = nullptr;
+    int n_blocks = 0;
+    // state
+    StepState* state = nullptr;
+    StepState h_state{};
+    float* scalars = nullptr;     // [0] xent sum, [1] sumsq emb, [2] sumsq linear, [3] sumsq dense-l2 params
+    int32_t* status = nullptr;    // [2]
+    // activations
+    int32_t* ids = nullptr;
+    float *vals = nullptr, *labels = nullptr;
+    float *x_in = nullptr, *dx_in = nullptr, *e_buf = nullptr, *S = nullptr, *yw = nullptr, *yv = nullptr;
+    float *yd = nullptr, *y = nullptr, *prob = nullptr, *dy = nullptr;
+    std::vector<float*> h, dh;
+    float *xs = nullptr, *xlw = nullptr, *dxL = nullptr, *cross_scratch = nullptr;
+    float* e = nullptr;           // alias: where the scaled embeddings live
+    int e_ld = 0;
+    // graphs
+    std::map<int, hipGraphExec_t> train_graphs, predict_graphs;
+    int last_B = 0;
+
+    float* pp(int i) { return params[i].ptr; }
+    float* part(int i) { return parts + params[i].part_off; }
+};
+
+namespace {
+
+int add_param(dctr_engine* E, const std::string& name, std::initializer_list<int64_t> dims, bool table, int n_part, float l2) {
+    Param p;
+    p.name = name;
+    p.rank = (int)dims.size();
+    int i = 0;
+    p.n = 1;
+    for (auto d : dims) { p.dims[i++] = d; p.n *= d; }
+    p.is_table = table;
+    p.n_part = n_part;
+    p.l2 = l2;
+    E->index[name] = (int)E->params.size();
+    E->params.push_back(p);
+    return (int)E->params.size() - 1;
+}
+
+int gather_mode(const dctr_engine* E) {
+    switch (E->cfg.model) {
+        case DCTR_MODEL_DEEPFM: return DCTR_GATHER_FM;
+        case DCTR_MODEL_NFM: return DCTR_GATHER_BI;
+        default: return DCTR_GATHER_RAW;
+    }
+}
+
+template <typename T>
+int dmalloc(T** p, size_t n_elems, bool zero = true) {
+    DCTR_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n_elems, 4) * sizeof(T)));
+    if (zero) DCTR_HIP_CHECK(hipMemset(*p, 0, std::max<size_t>(n_elems, 4) * sizeof(T)));
+    return DCTR_OK;
+}
+
+// in-place dropout on an arbitrary-sign tensor (NFM's bi-interaction, NFM.py:136-137): mask recomputed from the counter RNG
+__global__ void dropout_inplace_kernel(float* __restrict__ x, int64_t n, float keep, const uint64_t* __restrict__ seed_ptr, uint64_t salt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    x[i] *= dropout_scale(*seed_ptr ^ salt, (uint64_t)i, keep);
+}
+
+int dropout_inplace(float* x, int64_t n, float keep, const uint64_t* seed_ptr, uint64_t salt, hipStream_t st) {
+    if (n <= 0 || keep >= 1.f) return DCTR_OK;
+    dropout_inplace_kernel<<<ceil_div(n, 256), 256, 0, st>>>(x, n, keep, seed_ptr, salt);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+int build(dctr_engine* E) {
+    const dctr_config& c = E->cfg;
+    DCTR_REQUIRE(c.model >= DCTR_MODEL_DEEPFM && c.model <= DCTR_MODEL_DCN, "unknown model %d", c.model);
+    DCTR_REQUIRE(c.model != DCTR_MODEL_AFM, "AFM is served by the attention engine (dctr_afm_*), not dctr_create");
+    DCTR_REQUIRE(c.field_size > 0 && c.feature_size > 0 && c.max_batch > 0, "field_size, feature_size, max_batch must be > 0");
+    DCTR_REQUIRE(c.embedding_size % 4 == 0 && c.embedding_size >= 4, "embedding_size must be a multiple of 4");
+    DCTR_REQUIRE(c.n_deep_layers >= 1 && c.n_deep_layers <= DCTR_MAX_LAYERS, "1..%d deep layers supported", DCTR_MAX_LAYERS);
+    DCTR_REQUIRE(c.shard_world >= 1 && c.shard_rank >= 0 && c.shard_rank < c.shard_world, "bad shard rank/world");
+    if (c.batch_norm) { set_error("batch_norm=True is not implemented in this engine yet"); return DCTR_ERR_UNSUPPORTED; }
+    for (int i = 0; i < c.n_deep_layers; ++i)
+        DCTR_REQUIRE(c.keep_prob[i] > 0.f && c.keep_prob[i] <= 1.f, "dropout keep_prob[%d]=%f must be in (0,1]", i, c.keep_prob[i]);
+    E->F = c.field_size; E->K = c.embedding_size; E->D = E->F * E->K; E->P = E->F * (E->F - 1) / 2; E->MB = c.max_batch;
+    E->rows = (c.feature_size - c.shard_rank + c.shard_world - 1) / c.shard_world;
+    const int F = E->F, K = E->K, D = E->D, P = E->P, MB = E->MB;
+    switch (c.model) {
+        case DCTR_MODEL_IPNN: E->Din = D + P; break;
+        case DCTR_MODEL_OPNN: E->Din = D + P * K * K; break;
+        case DCTR_MODEL_NFM: E->Din = K; break;
+        default: E->Din = D; break;
+    }
+    E->Din_ld = (int)round_up(E->Din, 4);
+    const bool has_lin = c.model != DCTR_MODEL_DCN;
+
+    // ---- parameters (engine names, tf_repos_amd.checkpoint maps them to TF names)
+    if (c.model == DCTR_MODEL_DCN) {
+        E->p_cross_b = add_param(E, "cross_b", {c.cross_layers, D}, false, 8, c.l2_reg);
+        E->p_cross_w = add_param(E, "cross_w", {c.cross_layers, D}, false, 8, c.l2_reg);
+    } else {
+        E->p_bias = add_param(E, "bias", {1}, false, E->out_splits, 0.f);
+        add_param(E, "linear", {E->rows}, true, 1, c.l2_reg);
+    }
+    add_param(E, "emb", {E->rows, K}, true, 1, c.l2_reg);
+    int d = E->Din;
+    for (int i = 0; i < c.n_deep_layers; ++i) {
+        Fc fc;
+        fc.in = d; fc.out = c.deep_layers[i]; fc.keep = c.keep_prob[i];
+        DCTR_REQUIRE(fc.out > 0, "deep layer widths must be positive (got %d)", fc.out);
+        fc.splits = choose_wgrad_splits(MB, fc.in, fc.out);
+        char nm[64];
+        snprintf(nm, sizeof(nm), "mlp%d/weights", i);
+        fc.w = add_param(E, nm, {fc.in, fc.out}, false, fc.splits, 0.f);
+        snprintf(nm, sizeof(nm), "mlp%d/biases", i);
+        fc.b = add_param(E, nm, {fc.out}, false, fc.splits, 0.f);
+        E->mlp.push_back(fc);
+        d = fc.out;
+    }
+    if (c.model == DCTR_MODEL_DCN) {
+        E->p_out_w = add_param(E, "out_layer/weights", {D + d, 1}, false, E->out_splits, 0.f);
+        E->p_out_b = add_param(E, "out_layer/biases", {1}, false, E->out_splits, 0.f);
+    } else {
+        E->p_out_w = add_param(E, "deep_out/weights", {d, 1}, false, E->out_splits, 0.f);
+        E->p_out_b = add_param(E, "deep_out/biases", {1}, false, E->out_splits, 0.f);
+    }
+
+    // ---- tables
+    DCTR_TRY(dmalloc(&E->emb, (size_t)E->rows * K));
+    DCTR_TRY(dmalloc(&E->emb_s0, (size_t)E->rows * K));
+    DCTR_TRY(dmalloc(&E->emb_s1, (size_t)E->rows * K));
+    if (has_lin) {
+        DCTR_TRY(dmalloc(&E->lin, (size_t)E->rows));
+        DCTR_TRY(dmalloc(&E->lin_s0, (size_t)E->rows));
+        DCTR_TRY(dmalloc(&E->lin_s1, (size_t)E->rows));
+    }
+    DCTR_TRY(group_create(E->rows, (int64_t)MB * F, K, &E->group));
+
+    // ---- dense arena + partial slabs + optimizer block metadata
+    int64_t off = 0, poff = 0;
+    for (auto& p : E->params) {
+        if (p.is_table) continue;
+        p.padded = round_up(p.n, OPT_BLOCK);
+        p.arena_off = off; off += p.padded;
+        p.part_off = poff; poff += p.padded * p.n_part;
+    }
+    // the global bias' gradient (sum_b dy) equals deep_out/biases' gradient: alias its slabs instead of recomputing
+    if (E->p_bias >= 0) { E->params[E->p_bias].part_off = E->params[E->p_out_b].part_off; E->params[E->p_bias].n_part = E->params[E->p_out_b].n_part; }
+    E->arena_n = off; E->parts_n = poff;
+    E->n_blocks = (int)(off / OPT_BLOCK);
+    DCTR_TRY(dmalloc(&E->theta, (size_t)off));
+    DCTR_TRY(dmalloc(&E->as0, (size_t)off));
+    DCTR_TRY(dmalloc(&E->as1, (size_t)off));
+    DCTR_TRY(dmalloc(&E->gflat, (size_t)off));
+    DCTR_TRY(dmalloc(&E->parts, (size_t)poff));
+    std::vector<OptBlockMeta> hm((size_t)E->n_blocks);
+    for (auto& p : E->params) {
+        if (p.is_table) {
+            const bool is_emb = p.name == "emb";
+            p.ptr = is_emb ? E->emb : E->lin; p.s0 = is_emb ? E->emb_s0 : E->lin_s0; p.s1 = is_emb ? E->emb_s1 : E->lin_s1;
+            continue;
+        }
+        p.ptr = E->theta + p.arena_off; p.s0 = E->as0 + p.arena_off; p.s1 = E->as1 + p.arena_off;
+        for (int64_t j = 0; j < p.padded / OPT_BLOCK; ++j) {
+            OptBlockMeta& m = hm[(size_t)(p.arena_off / OPT_BLOCK + j)];
+            m.part_off = p.part_off + j * OPT_BLOCK;
+            m.part_stride = p.padded;
+            m.n_part = p.n_part;
+            m.l2 = p.l2;
+        }
+    }
+    DCTR_TRY(dmalloc(&E->meta, hm.size(), false));
+    DCTR_HIP_CHECK(hipMemcpy(E->meta, hm.data(), hm.size() * sizeof(OptBlockMeta), hipMemcpyHostToDevice));
+
+    // ---- step state
+    StepState s{};
+    s.t = 0; s.seed = c.seed; s.seed_t = c.seed;
+    s.hyper.lr = c.learning_rate; s.hyper.beta1 = 0.9f; s.hyper.beta2 = 0.999f; s.hyper.eps = 1e-8f;   // DeepFM.py:205
+    s.hyper.momentum = 0.95f;                                                                          // DeepFM.py:209
+    s.hyper.lr_t = c.learning_rate;
+    E->h_state = s;
+    DCTR_TRY(dmalloc(&E->state, 1, false));
+    DCTR_HIP_CHECK(hipMemcpy(E->state, &s, sizeof(s), hipMemcpyHostToDevice));
+    DCTR_TRY(dmalloc(&E->scalars, 8));
+    DCTR_TRY(dmalloc(&E->status, 2));
+
+    // optimizer slot initial values (DeepFM.py:207 Adagrad 1e-8; Ftrl default accumulator 0.1 [TF-1.4])
+    if (c.optimizer == DCTR_OPT_ADAGRAD || c.optimizer == DCTR_OPT_FTRL) {
+        const float init = c.optimizer == DCTR_OPT_ADAGRAD ? 1e-8f : 0.1f;
+        auto fill = [&](float* p, size_t n) -> int {
+            if (!p || !n) return DCTR_OK;
+            std::vector<float> v(std::min<size_t>(n, (size_t)1 << 22), init);
+            for (size_t o = 0; o < n; o += v.size())
+                DCTR_HIP_CHECK(hipMemcpy(p + o, v.data(), std::min(v.size(), n - o) * sizeof(float), hipMemcpyHostToDevice));
+            return DCTR_OK;
+        };
+        DCTR_TRY(fill(E->emb_s0, (size_t)E->rows * K));
+        DCTR_TRY(fill(E->lin_s0, has_lin ? (size_t)E->rows : 0));
+        DCTR_TRY(fill(E->as0, (size_t)E->arena_n));
+    }
+
+    // ---- activations
+    DCTR_TRY(dmalloc(&E->ids, (size_t)MB * F));
+    DCTR_TRY(dmalloc(&E->vals, (size_t)MB * F));
+    DCTR_TRY(dmalloc(&E->labels, (size_t)MB));
+    DCTR_TRY(dmalloc(&E->x_in, (size_t)MB * E->Din_ld));
+    DCTR_TRY(dmalloc(&E->dx_in, (size_t)MB * E->Din_ld));
+    if (c.model == DCTR_MODEL_NFM) {
+        DCTR_TRY(dmalloc(&E->e_buf, (size_t)MB * D));
+        E->e = E->e_buf; E->e_ld = D;
+    } else {
+        E->e = E->x_in; E->e_ld = E->Din_ld;
+    }
+    DCTR_TRY(dmalloc(&E->S, (size_t)MB * K));
+    DCTR_TRY(dmalloc(&E->yw, (size_t)MB));
+    DCTR_TRY(dmalloc(&E->yv, (size_t)MB));
+    DCTR_TRY(dmalloc(&E->yd, (size_t)MB));
+    DCTR_TRY(dmalloc(&E->y, (size_t)MB));
+    DCTR_TRY(dmalloc(&E->prob, (size_t)MB));
+    DCTR_TRY(dmalloc(&E->dy, (size_t)MB));
+    for (auto& fc : E->mlp) {
+        float *a = nullptr, *g = nullptr;
+        DCTR_TRY(dmalloc(&a, (size_t)MB * fc.out));
+        DCTR_TRY(dmalloc(&g, (size_t)MB * fc.out));
+        E->h.push_back(a); E->dh.push_back(g);
+    }
+    if (c.model == DCTR_MODEL_DCN) {
+        const int L = c.cross_layers;
+        DCTR_REQUIRE(L >= 1 && L <= 16, "cross_layers must be in [1,16]");
+        DCTR_TRY(dmalloc(&E->xs, (size_t)(L + 1) * MB * D));
+        DCTR_TRY(dmalloc(&E->xlw, (size_t)L * MB));
+        DCTR_TRY(dmalloc(&E->dxL, (size_t)MB * D));
+        DCTR_TRY(dmalloc(&E->cross_scratch, (size_t)L * MB * D + (size_t)L * MB));
+    }
+    return DCTR_OK;
+}
+
+// ---- forward (train=true: dropout on, DeepFM.py:161-162) ------------------------------------------------
+int forward(dctr_engine* E, int B, bool train, hipStream_t st) {
+    const dctr_config& c = E->cfg;
+    const int F = E->F, K = E->K, D = E->D;
+    const int mode = gather_mode(E);
+    float* red = mode == DCTR_GATHER_FM ? E->yv : (mode == DCTR_GATHER_BI ? E->x_in : nullptr);
+    DCTR_TRY(embed_gather_fwd(E->emb, E->lin, E->rows, E->ids, E->vals, B, F, K, mode, E->e, E->e_ld, E->lin ? E->yw : nullptr,
+                              E->S, red, E->status, st));
+    const uint64_t* seedp = &E->state->seed_t;
+    if (c.model == DCTR_MODEL_IPNN) DCTR_TRY(pnn_inner_fwd(E->e, E->e_ld, B, F, K, E->x_in + D, E->Din_ld, st));
+    if (c.model == DCTR_MODEL_OPNN) DCTR_TRY(pnn_outer_fwd(E->e, E->e_ld, B, F, K, E->x_in + D, E->Din_ld, st));
+    if (c.model == DCTR_MODEL_NFM && train) DCTR_TRY(dropout_inplace(E->x_in, (int64_t)B * K, c.keep_prob[0], seedp, 0xB1ull, st));   // NFM.py:136-137
+    if (c.model == DCTR_MODEL_DCN)
+        DCTR_TRY(dcn_cross_fwd(E->x_in, E->Din_ld, E->pp(E->p_cross_w), E->pp(E->p_cross_b), B, D, c.cross_layers, E->xs, E->xlw, st));
+    const float* x = E->x_in;
+    int ldx = E->Din_ld;
+    for (size_t i = 0; i < E->mlp.size(); ++i) {
+        const Fc& fc = E->mlp[i];
+        DCTR_TRY(fc_fwd(x, ldx, E->pp(fc.w), E->pp(fc.b), E->h[i], fc.out, B, fc.in, fc.out, 1, train ? fc.keep : 1.f, seedp,
+                        0x1000ull + i, st));
+        x = E->h[i]; ldx = fc.out;
+    }
+    const int H = E->mlp.back().out;
+    const float* wout = E->pp(E->p_out_w);
+    if (c.model == DCTR_MODEL_DCN) {
+        // fc([x_L || mlp_out]) -> 1   (DCN.py:179-183); xs is laid out [L+1, B, D] for the current B
+        const float* xL = E->xs + (size_t)c.cross_layers * B * D;
+        DCTR_TRY(rowdot(xL, D, wout, E->pp(E->p_out_b), B, D, E->yd, 0, st));
+        DCTR_TRY(rowdot(E->h.back(), H, wout + D, nullptr, B, H, E->yd, 1, st));
+    } else {
+        DCTR_TRY(rowdot(E->h.back(), H, wout, E->pp(E->p_out_b), B, H, E->yd, 0, st));   // deep_out, DeepFM.py:165-167
+    }
+    return DCTR_OK;
+}
+
+int head(dctr_engine* E, int B, int global_batch, bool with_labels, hipStream_t st) {
+    const dctr_config& c = E->cfg;
+    const float* bias = E->p_bias >= 0 ? E->pp(E->p_bias) : nullptr;
+    const float* yw = E->lin ? E->yw : nullptr;
+    const float* yv = c.model == DCTR_MODEL_DEEPFM ? E->yv : nullptr;
+    return loss_head(bias, yw, yv, E->yd, with_labels ? E->labels : nullptr, B, 1.0f / (float)global_batch, E->y, E->prob,
+                     with_labels ? E->dy : nullptr, with_labels ? E->scalars : nullptr, st);
+}
+
+// ---- backward through head + MLP + interaction: leaves dL/de in dx_in (or the BI coefficient for NFM) ----------
+int backward_dense(dctr_engine* E, int B, hipStream_t st) {
+    const dctr_config& c = E->cfg;
+    const int F = E->F, K = E->K, D = E->D;
+    const int H = E->mlp.back().out;
+    const int nl = (int)E->mlp.size();
+    const float keep_last = E->mlp.back().keep;
+    const float* wout = E->pp(E->p_out_w);
+    const Param& pw = E->params[E->p_out_w];
+    const Param& pb = E->params[E->p_out_b];
+    // output layer: dW = h^T dy, db = sum dy   (also the global bias' gradient: aliased slabs)
+    DCTR_TRY(colsum_partials(E->dy, 1, nullptr, B, 1, pb.n_part, E->part(E->p_out_b), pb.padded, st));
+    if (c.model == DCTR_MODEL_DCN) {
+        const float* xL = E->xs + (size_t)c.cross_layers * B * D;
+        DCTR_TRY(colsum_partials(xL, D, E->dy, B, D, pw.n_part, E->part(E->p_out_w), pw.padded, st));
+        DCTR_TRY(colsum_partials(E->h.back(), H, E->dy, B, H, pw.n_part, E->part(E->p_out_w) + D, pw.padded, st));
+        DCTR_TRY(rank1_bwd(E->dy, wout, B, D, nullptr, 0, 1.f, E->dxL, D, 0, st));
+        DCTR_TRY(rank1_bwd(E->dy, wout + D, B, H, E->h.back(), H, keep_last, E->dh.back(), H, 0, st));
+    } else {
+        DCTR_TRY(colsum_partials(E->h.back(), H, E->dy, B, H, pw.n_part, E->part(E->p_out_w), pw.padded, st));
+        DCTR_TRY(rank1_bwd(E->dy, wout, B, H, E->h.back(), H, keep_last, E->dh.back(), H, 0, st));
+    }
+    for (int i = nl - 1; i >= 0; --i) {
+        const Fc& fc = E->mlp[i];
+        const float* x = i > 0 ? E->h[i - 1] : E->x_in;
+        const int ldx = i > 0 ? E->mlp[i - 1].out : E->Din_ld;
+        const Param& w = E->params[fc.w];
+        const Param& b = E->params[fc.b];
+        DCTR_TRY(fc_bwd_weights_partials(x, ldx, E->dh[i], fc.out, E->part(fc.w), w.padded, E->part(fc.b), b.padded, B, fc.in,
+                                         fc.out, fc.splits, st));
+        if (i > 0)
+            DCTR_TRY(fc_bwd_data(E->dh[i], fc.out, E->pp(fc.w), E->dh[i - 1], E->mlp[i - 1].out, B, fc.in, fc.out, E->h[i - 1],
+                                 E->mlp[i - 1].out, E->mlp[i - 1].keep, st));
+        else
+            DCTR_TRY(fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w), E->dx_in, E->Din_ld, B, fc.in, fc.out, nullptr, 0, 1.f, st));
+    }
+    const uint64_t* seedp = &E->state->seed_t;
+    if (c.model == DCTR_MODEL_IPNN) DCTR_TRY(pnn_inner_bwd(E->e, E->e_ld, E->dx_in + D, E->Din_ld, B, F, K, E->dx_in, E->Din_ld, st));
+    if (c.model == DCTR_MODEL_OPNN) DCTR_TRY(pnn_outer_bwd(E->e, E->e_ld, E->dx_in + D, E->Din_ld, B, F, K, E->dx_in, E->Din_ld, st));
+    if (c.model == DCTR_MODEL_NFM) DCTR_TRY(dropout_inplace(E->dx_in, (int64_t)B * K, c.keep_prob[0], seedp, 0xB1ull, st));
+    if (c.model == DCTR_MODEL_DCN) {
+        const Param& cw = E->params[E->p_cross_w];
+        DCTR_TRY(dcn_cross_bwd(E->xs, E->xlw, E->pp(E->p_cross_w), E->dxL, D, B, D, c.cross_layers, E->dx_in, E->Din_ld,
+                               E->part(E->p_cross_w), E->part(E->p_cross_b), cw.n_part, cw.padded, E->cross_scratch, st));
+    }
+    return DCTR_OK;
+}
+
+// ---- table side of the backward: group ids, segment-sum the row gradients, step the tables ------------------------
+int backward_tables(dctr_engine* E, int B, hipStream_t st) {
+    const dctr_config& c = E->cfg;
+    const int mode = gather_mode(E);
+    DCTR_TRY(group_ids(E->group, E->ids, B, E->F, st));
+    const float* dE = mode == DCTR_GATHER_BI ? nullptr : E->dx_in;
+    const float* coef = mode == DCTR_GATHER_FM ? E->dy : (mode == DCTR_GATHER_BI ? E->dx_in : nullptr);
+    DCTR_TRY(embed_scatter_bwd(E->group, dE, E->Din_ld, E->e, E->e_ld, E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F,
+                               E->K, mode, E->group->gemb, E->lin ? E->group->glin : nullptr, st));
+    DCTR_TRY(opt_table(c.optimizer, &E->state->hyper, E->h_state.hyper, c.table_mode, E->rows, E->K, E->emb, E->emb_s0, E->emb_s1,
+                       E->lin, E->lin_s0, E->lin_s1, E->group->slot, E->group->uniq, E->group->counters, E->group->max_entries,
+                       E->group->gemb, E->group->glin, c.l2_reg, E->scalars + 1, E->scalars + 2, st));
+    return DCTR_OK;
+}
+
+int record_train(dctr_engine* E, int B, hipStream_t st) {
+    DCTR_HIP_CHECK(hipMemsetAsync(E->scalars, 0, 8 * sizeof(float), st));
+    DCTR_TRY(step_state_advance(E->state, st));
+    DCTR_TRY(forward(E, B, true, st));
+    DCTR_TRY(head(E, B, B, true, st));
+    DCTR_TRY(backward_dense(E, B, st));
+    DCTR_TRY(backward_tables(E, B, st));
+    DCTR_TRY(opt_dense_arena(E->cfg.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->parts, E->meta,
+                             E->n_blocks, nullptr, 1, E->scalars + 3, st));
+    return DCTR_OK;
+}
+
+int record_predict(dctr_engine* E, int B, hipStream_t st) {
+    DCTR_TRY(forward(E, B, false, st));
+    DCTR_TRY(head(E, B, B, false, st));
+    return DCTR_OK;
+}
+
+int run_graph(dctr_engine* E, std::map<int, hipGraphExec_t>& cache, int B, bool train, hipStream_t st) {
+    if (!E->cfg.use_graph) return train ? record_train(E, B, st) : record_predict(E, B, st);
+    auto it = cache.find(B);
+    if (it == cache.end()) {
+        hipGraph_t graph = nullptr;
+        hipStream_t cs = nullptr;
+        DCTR_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        DCTR_HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        int rc = train ? record_train(E, B, cs) : record_predict(E, B, cs);
+        hipError_t e = hipStreamEndCapture(cs, &graph);
+        hipStreamDestroy(cs);
+        if (rc != DCTR_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) { set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return DCTR_ERR_HIP; }
+        hipGraphExec_t exec = nullptr;
+        DCTR_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        hipGraphDestroy(graph);
+        it = cache.emplace(B, exec).first;
+    }
+    DCTR_HIP_CHECK(hipGraphLaunch(it->second, st));
+    return DCTR_OK;
+}
+
+int stage_inputs(dctr_engine* E, const int32_t* ids, const float* vals, const float* labels, int B, hipStream_t st) {
+    DCTR_REQUIRE(B > 0 && B <= E->MB, "batch %d outside (0, max_batch=%d]", B, E->MB);
+    const size_t n = (size_t)B * E->F;
+    if (ids != E->ids) DCTR_HIP_CHECK(hipMemcpyAsync(E->ids, ids, n * 4, hipMemcpyDeviceToDevice, st));
+    if (vals != E->vals) DCTR_HIP_CHECK(hipMemcpyAsync(E->vals, vals, n * 4, hipMemcpyDeviceToDevice, st));
+    if (labels != nullptr && labels != E->labels)
+        DCTR_HIP_CHECK(hipMemcpyAsync(E->labels, labels, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    return DCTR_OK;
+}
+
+Param* find_param(dctr_engine* E, const char* name) {
+    auto it = E->index.find(name ? name : "");
+    if (it == E->index.end()) { set_error("no parameter named '%s'", name ? name : "(null)"); return nullptr; }
+    return &E->params[it->second];
+}
+
+}  // namespace
+
+extern "C" {
+
+int dctr_create(const dctr_config* cfg, dctr_handle* h) {
+    DCTR_REQUIRE(cfg != nullptr && h != nullptr, "null argument");
+    dctr_engine* E = new dctr_engine();
+    E->cfg = *cfg;
+    if (E->cfg.shard_world <= 0) { E->cfg.shard_world = 1; E->cfg.shard_rank = 0; }
+    const int rc = build(E);
+    if (rc != DCTR_OK) { dctr_destroy(E); return rc; }
+    *h = E;
+    return DCTR_OK;
+}
+
+int dctr_destroy(dctr_handle E) {
+    if (!E) return DCTR_OK;
+    for (auto& kv : E->train_graphs) hipGraphExecDestroy(kv.second);
+    for (auto& kv : E->predict_graphs) hipGraphExecDestroy(kv.second);
+    float* fl[] = {E->emb, E->emb_s0, E->emb_s1, E->lin, E->lin_s0, E->lin_s1, E->theta, E->as0, E->as1, E->gflat, E->parts,
+                   E->scalars, E->vals, E->labels, E->x_in, E->dx_in, E->e_buf, E->S, E->yw, E->yv, E->yd, E->y, E->prob, E->dy,
+                   E->xs, E->xlw, E->dxL, E->cross_scratch};
+    for (float* p : fl) if (p) hipFree(p);
+    for (float* p : E->h) hipFree(p);
+    for (float* p : E->dh) hipFree(p);
+    if (E->ids) hipFree(E->ids);
+    if (E->status) hipFree(E->status);
+    if (E->state) hipFree(E->state);
+    if (E->meta) hipFree(E->meta);
+    group_destroy(E->group);
+    delete E;
+    return DCTR_OK;
+}
+
+int dctr_param_count(dctr_handle E, int* n) {
+    DCTR_REQUIRE(E && n, "null argument");
+    *n = (int)E->params.size();
+    return DCTR_OK;
+}
+
+int dctr_param_info(dctr_handle E, int index, const char** name, int* rank, int64_t dims[4]) {
+    DCTR_REQUIRE(E && index >= 0 && index < (int)E->params.size(), "bad parameter index %d", index);
+    const Param& p = E->params[index];
+    if (name) *name = p.name.c_str();
+    if (rank) *rank = p.rank;
+    if (dims) for (int i = 0; i < 4; ++i) dims[i] = p.dims[i];
+    return DCTR_OK;
+}
+
+static int copy_param(dctr_handle E, const char* name, int which, void* host, size_t nbytes, bool to_device) {
+    DCTR_REQUIRE(E && host, "null argument");
+    Param* p = find_param(E, name);
+    if (!p) return DCTR_ERR_NOT_FOUND;
+    DCTR_REQUIRE(nbytes == (size_t)p->n * sizeof(float), "parameter '%s' holds %lld floats, caller passed %zu bytes", name,
+                 (long long)p->n, nbytes);
+    float* d = which < 0 ? p->ptr : (which == 0 ? p->s0 : p->s1);
+    DCTR_REQUIRE(d != nullptr, "parameter '%s' has no such slot", name);
+    DCTR_HIP_CHECK(hipDeviceSynchronize());
+    if (to_device) DCTR_HIP_CHECK(hipMemcpy(d, host, nbytes, hipMemcpyHostToDevice));
+    else DCTR_HIP_CHECK(hipMemcpy(host, d, nbytes, hipMemcpyDeviceToHost));
+    return DCTR_OK;
+}
+
+int dctr_param_set(dctr_handle h, const char* name, const float* h_src, size_t nbytes) {
+    return copy_param(h, name, -1, const_cast<float*>(h_src), nbytes, true);
+}
+int dctr_param_get(dctr_handle h, const char* name, float* h_dst, size_t nbytes) { return copy_param(h, name, -1, h_dst, nbytes, false); }
+int dctr_slot_get(dctr_handle h, const char* name, int which, float* h_dst, size_t nbytes) {
+    DCTR_REQUIRE(which == 0 || which == 1, "slot index must be 0 or 1");
+    return copy_param(h, name, which, h_dst, nbytes, false);
+}
+int dctr_slot_set(dctr_handle h, const char* name, int which, const float* h_src, size_t nbytes) {
+    DCTR_REQUIRE(which == 0 || which == 1, "slot index must be 0 or 1");
+    return copy_param(h, name, which, const_cast<float*>(h_src), nbytes, true);
+}
+int dctr_param_device_ptr(dctr_handle E, const char* name, float** d_ptr) {
+    DCTR_REQUIRE(E && d_ptr, "null argument");
+    Param* p = find_param(E, name);
+    if (!p) return DCTR_ERR_NOT_FOUND;
+    *d_ptr = p->ptr;
+    return DCTR_OK;
+}
+
+int dctr_set_global_step(dctr_handle E, int64_t step) {
+    DCTR_REQUIRE(E && step >= 0, "bad argument");
+    DCTR_HIP_CHECK(hipDeviceSynchronize());
+    E->h_state.t = step;
+    DCTR_HIP_CHECK(hipMemcpy(&E->state->t, &step, sizeof(step), hipMemcpyHostToDevice));
+    return DCTR_OK;
+}
+int dctr_get_global_step(dctr_handle E, int64_t* step) {
+    DCTR_REQUIRE(E && step, "null argument");
+    DCTR_HIP_CHECK(hipDeviceSynchronize());
+    DCTR_HIP_CHECK(hipMemcpy(step, &E->state->t, sizeof(*step), hipMemcpyDeviceToHost));
+    return DCTR_OK;
+}
+
+int dctr_train_step(dctr_handle E, const int32_t* d_ids, const float* d_vals, const float* d_labels, int B, float* h_loss,
+                    void* stream) {
+    DCTR_REQUIRE(E && d_ids && d_vals && d_labels, "null argument");
+    hipStream_t st = as_stream(stream);
+    DCTR_TRY(stage_inputs(E, d_ids, d_vals, d_labels, B, st));
+    DCTR_TRY(run_graph(E, E->train_graphs, B, true, st));
+    E->last_B = B;
+    if (h_loss) {
+        float sc[4];
+        DCTR_HIP_CHECK(hipMemcpyAsync(sc, E->scalars, sizeof(sc), hipMemcpyDeviceToHost, st));
+        DCTR_HIP_CHECK(hipStreamSynchronize(st));
+        // DeepFM.py:188-190: mean xent + l2_reg*(l2_loss(W) + l2_loss(V)), evaluated with the pre-update weights
+        *h_loss = sc[0] / (float)B + E->cfg.l2_reg * 0.5f * (sc[1] + sc[2] + sc[3]);
+    }
+    return DCTR_OK;
+}
+
+int dctr_predict(dctr_handle E, const int32_t* d_ids, const float* d_vals, int B, float* d_prob, float* d_logit, void* stream) {
+    DCTR_REQUIRE(E && d_ids && d_vals, "null argument");
+    hipStream_t st = as_stream(stream);
+    DCTR_TRY(stage_inputs(E, d_ids, d_vals, nullptr, B, st));
+    DCTR_TRY(run_graph(E, E->predict_graphs, B, false, st));
+    E->last_B = B;
+    if (d_prob) DCTR_HIP_CHECK(hipMemcpyAsync(d_prob, E->prob, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    if (d_logit) DCTR_HIP_CHECK(hipMemcpyAsync(d_logit, E->y, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    return DCTR_OK;
+}
+
+int dctr_check_ids(dctr_handle E, void* stream) {
+    DCTR_REQUIRE(E, "null handle");
+    int32_t s[2] = {0, 0};
+    DCTR_HIP_CHECK(hipMemcpyAsync(s, E->status, sizeof(s), hipMemcpyDeviceToHost, as_stream(stream)));
+    DCTR_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+    if (s[0] != 0) {
+        DCTR_HIP_CHECK(hipMemsetAsync(E->status, 0, sizeof(s), as_stream(stream)));
+        set_error("indices = %d is not in [0, %lld)", s[1], (long long)E->rows);   // GatherOp's message [TF-1.4]
+        return DCTR_ERR_INVALID_ARG;
+    }
+    return DCTR_OK;
+}
+
+int dctr_debug_tensor(dctr_handle E, const char* name, float** d_ptr, int64_t* n_elems, int* ld) {
+    DCTR_REQUIRE(E && name && d_ptr, "null argument");
+    const int B = E->last_B;
+    const std::string s(name);
+    float* p = nullptr;
+    int64_t n = 0;
+    int l = 1;
+    if (s == "e") { p = E->e; n = (int64_t)B * E->e_ld; l = E->e_ld; }
+    else if (s == "y_w") { p = E->yw; n = B; }
+    else if (s == "y_v") { p = E->yv; n = B; }
+    else if (s == "y_d") { p = E->yd; n = B; }
+    else if (s == "y") { p = E->y; n = B; }
+    else if (s == "prob") { p = E->prob; n = B; }
+    else if (s == "dy") { p = E->dy; n = B; }
+    else if (s == "sum") { p = E->S; n = (int64_t)B * E->K; l = E->K; }
+    else if (s == "x_in") { p = E->x_in; n = (int64_t)B * E->Din_ld; l = E->Din_ld; }
+    else if (s == "dx_in") { p = E->dx_in; n = (int64_t)B * E->Din_ld; l = E->Din_ld; }
+    else if (s == "x_cross" && E->xs) { p = E->xs + (size_t)E->cfg.cross_layers * B * E->D; n = (int64_t)B * E->D; l = E->D; }
+    else { set_error("no debug tensor named '%s'", name); return DCTR_ERR_NOT_FOUND; }
+    *d_ptr = p;
+    if (n_elems) *n_elems = n;
+    if (ld) *ld = l;
+    return DCTR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+// K2: embedding gather + value scale + fused first-order / FM second-order / bi-interaction.
+// Replaces tf.nn.embedding_lookup + tf.multiply + tf.reduce_sum/tf.square of
+// DeepFM.py:125-135, NFM.py:118-128, PNN.py:129-136, AFM.py:123-130, DCN.py:134-138.
+//
+// HBM-bound (<= 1 flop/byte).  Mapping: TPE = KQ*FS lanes per example, KQ = K/4 lanes cover one
+// table row as float4 (a 16-byte coalesced piece each), FS lane groups split the F fields, so every
+// lane keeps ~F/FS independent 16-byte row loads in flight and the per-example reductions over the
+// fields are register-local plus log2(FS) cross-lane steps.  No LDS: nothing is reused across lanes.
+#include "common.h"
+
+namespace dctr {
+
+template <int KQ, int FS, int MODE>
+__global__ __launch_bounds__(256) void gather_fwd_kernel(
+    const float4* __restrict__ emb, const float* __restrict__ lin, int64_t rows,
+    const int32_t* __restrict__ ids, const float* __restrict__ vals, int B, int F,
+    float* __restrict__ e_out, int e_ld, float* __restrict__ yw_out, float* __restrict__ sum_out,
+    float* __restrict__ red_out, int32_t* __restrict__ status) {
+    constexpr int TPE = KQ * FS;           // lanes per example (power of two, <= 64)
+    constexpr int EPB = 256 / TPE;         // examples per block
+    const int tid = threadIdx.x;
+    const int sub = tid % TPE;
+    const int kq = sub % KQ;
+    const int fs = sub / KQ;
+    const int b = blockIdx.x * EPB + tid / TPE;
+    const bool live = b < B;
+
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);   // sum_f e
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);   // sum_f e^2
+    float yw = 0.f;
+
+    if (live) {
+        const int32_t* idr = ids + (size_t)b * F;
+        const float* vr = vals + (size_t)b * F;
+        float4* er = reinterpret_cast<float4*>(e_out + (size_t)b * e_ld);
+        constexpr int U = 4;               // fields in flight per lane
+        for (int f0 = fs; f0 < F; f0 += FS * U) {
+            int32_t id[U];
+            float v[U];
+            float4 r[U];
+            float w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int f = f0 + u * FS;
+                id[u] = (f < F) ? idr[f] : 0;
+                v[u] = (f < F) ? vr[f] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int f = f0 + u * FS;
+                const bool ok = (f < F) && (id[u] >= 0) && ((int64_t)id[u] < rows);
+                if ((f < F) && !ok) {       // TF CPU gather: InvalidArgumentError [TF-1.4]
+                    atomicExch(&status[1], id[u]);
+                    atomicExch(&status[0], 1);
+                }
+                r[u] = ok ? emb[(size_t)id[u] * KQ + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
+                w[u] = (ok && lin != nullptr && kq == 0) ? lin[id[u]] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int f = f0 + u * FS;
+                if (f < F) {
+                    float4 e;
+                    e.x = r[u].x * v[u]; e.y = r[u].y * v[u]; e.z = r[u].z * v[u]; e.w = r[u].w * v[u];
+                    er[(size_t)f * KQ + kq] = e;
+                    s.x += e.x; s.y += e.y; s.z += e.z; s.w += e.w;
+                    q.x += e.x * e.x; q.y += e.y * e.y; q.z += e.z * e.z; q.w += e.w * e.w;
+                    yw += w[u] * v[u];
+                }
+            }
+        }
+    }
+    // reduce over the FS field groups (lanes sub, sub+KQ, ...)
+#pragma unroll
+    for (int off = KQ; off < TPE; off <<= 1) {
+        s.x += __shfl_xor(s.x, off); s.y += __shfl_xor(s.y, off);
+        s.z += __shfl_xor(s.z, off); s.w += __shfl_xor(s.w, off);
+        if (MODE != DCTR_GATHER_RAW) {
+            q.x += __shfl_xor(q.x, off); q.y += __shfl_xor(q.y, off);
+            q.z += __shfl_xor(q.z, off); q.w += __shfl_xor(q.w, off);
+        }
+        yw += __shfl_xor(yw, off);
+    }
+    float4 h;   // 0.5*(S^2 - Q) per component
+    h.x = 0.5f * (s.x * s.x - q.x); h.y = 0.5f * (s.y * s.y - q.y);
+    h.z = 0.5f * (s.z * s.z - q.z); h.w = 0.5f * (s.w * s.w - q.w);
+    float yv = h.x + h.y + h.z + h.w;
+    if (MODE == DCTR_GATHER_FM) {
+#pragma unroll
+        for (int off = 1; off < KQ; off <<= 1) yv += __shfl_xor(yv, off);
+    }
+    if (live && fs == 0) {
+        if (sum_out != nullptr) reinterpret_cast<float4*>(sum_out + (size_t)b * KQ * 4)[kq] = s;
+        if (MODE == DCTR_GATHER_BI) reinterpret_cast<float4*>(red_out + (size_t)b * KQ * 4)[kq] = h;
+        if (kq == 0) {
+            if (yw_out != nullptr) yw_out[b] = yw;
+            if (MODE == DCTR_GATHER_FM) red_out[b] = yv;
+        }
+    }
+}
+
+template <int KQ, int FS>
+static int launch_gather(const float* emb, const float* lin, int64_t rows, const int32_t* ids,
+                         const float* vals, int B, int F, int mode, float* e, int e_ld, float* yw,
+                         float* sum, float* red, int32_t* status, hipStream_t st) {
+    constexpr int EPB = 256 / (KQ * FS);
+    dim3 grid(ceil_div(B, EPB)), block(256);
+    const float4* emb4 = reinterpret_cast<const float4*>(emb);
+    switch (mode) {
+        case DCTR_GATHER_RAW:
+            gather_fwd_kernel<KQ, FS, DCTR_GATHER_RAW><<<grid, block, 0, st>>>(emb4, lin, rows, ids, vals, B, F, e, e_ld, yw, sum, red, status);
+            break;
+        case DCTR_GATHER_FM:
+            gather_fwd_kernel<KQ, FS, DCTR_GATHER_FM><<<grid, block, 0, st>>>(emb4, lin, rows, ids, vals, B, F, e, e_ld, yw, sum, red, status);
+            break;
+        case DCTR_GATHER_BI:
+            gather_fwd_kernel<KQ, FS, DCTR_GATHER_BI><<<grid, block, 0, st>>>(emb4, lin, rows, ids, vals, B, F, e, e_ld, yw, sum, red, status);
+            break;
+        default:
+            set_error("gather: bad mode %d", mode);
+            return DCTR_ERR_INVALID_ARG;
+    }
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+int embed_gather_fwd(const float* emb, const float* lin, int64_t rows, const int32_t* ids,
+                     const float* vals, int B, int F, int K, int mode, float* e, int e_ld, float* yw,
+                     float* sum, float* red, int32_t* status, hipStream_t st) {
+    DCTR_REQUIRE(K % 4 == 0 && K >= 4 && K <= 256, "embedding_size must be a multiple of 4 in [4,256], got %d", K);
+    DCTR_REQUIRE(e_ld % 4 == 0 && e_ld >= F * K, "gather: e_ld=%d must be a multiple of 4 and >= F*K=%d", e_ld, F * K);
+    DCTR_REQUIRE(status != nullptr, "gather: status word required");
+    DCTR_REQUIRE(mode == DCTR_GATHER_RAW || red != nullptr, "gather: reduction output required for mode %d", mode);
+    if (B <= 0) return DCTR_OK;
+    switch (K / 4) {
+        case 1:  return launch_gather<1, 16>(emb, lin, rows, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
+        case 2:  return launch_gather<2, 8>(emb, lin, rows, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
+        case 4:  return launch_gather<4, 4>(emb, lin, rows, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
+        case 8:  return launch_gather<8, 2>(emb, lin, rows, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
+        case 16: return launch_gather<16, 1>(emb, lin, rows, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
+        case 32: return launch_gather<32, 1>(emb, lin, rows, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
+        case 64: return launch_gather<64, 1>(emb, lin, rows, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
+        default:
+            set_error("embedding_size %d unsupported (K/4 must be a power of two <= 64)", K);
+            return DCTR_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace dctr
+
+extern "C" int dctr_embed_gather_fwd(const float* d_emb, const float* d_lin, int64_t rows,
+                                     const int32_t* d_ids, const float* d_vals, int B, int F, int K,
+                                     int mode, float* d_e, int e_ld, float* d_yw, float* d_sum,
+                                     float* d_red, int32_t* d_status, void* stream) {
+    return dctr::embed_gather_fwd(d_emb, d_lin, rows, d_ids, d_vals, B, F, K, mode, d_e, e_ld, d_yw,
+                                  d_sum, d_red, d_status, dctr::as_stream(stream));
+}

@@ -1,0 +1,276 @@
+// K6: dense layers on the matrix cores.  Exact-f32 GEMM built on v_mfma_f32_32x32x2_f32
+// (f32 in / f32 accumulate, bitwise an fmaf chain; 157 TF peak on gfx950).  bf16 MFMA would not hold
+// the 1e-4 logit tolerance over F*K-long dot products (SURVEY section 7 "hard parts").
+// Replaces contrib.layers.fully_connected forward (DeepFM.py:156-158,165-166) and the MatMul
+// gradients tf.gradients emits for it (DeepFM.py:213).
+//
+// One kernel template covers the three products of a layer:
+//   fwd      Y[M,N]  = X[M,K]  W[K,N]          A k-contiguous, B n-contiguous
+//   dgrad    dX[M,K] = dY[M,N] W[K,N]^T        A k-contiguous, B k-contiguous
+//   wgrad    dW[K,N] = X[M,K]^T dY[M,N]        A m-contiguous, B n-contiguous, split along the batch
+// Block tile 64x64x16, 4 waves (2x2), each wave one 32x32 accumulator (16 VGPRs).  Operands are
+// staged through LDS k-major (As[k][m], Bs[k][n]) so that the MFMA operand reads -- lane l needs
+// A[m = l&31][k = l>>5] -- are 32 consecutive floats per half-wave: conflict-free ds_read_b32.
+// Global loads are one float4 per thread per operand per k-step, double-buffered in LDS with the
+// next tile's loads issued before the current tile's MFMAs (one barrier per k-step).
+#include "common.h"
+#include "ops.h"
+
+namespace dctr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 64, BN = 64, BK = 16;
+
+enum { EPI_STORE = 0, EPI_BIAS_ACT = 1, EPI_MASK = 2 };
+
+struct Epilogue {
+    const float* bias;      // EPI_BIAS_ACT: [N] or null
+    int relu;               // EPI_BIAS_ACT
+    float keep;             // EPI_BIAS_ACT: dropout keep_prob of this layer (1 = off)
+    uint64_t seed;
+    const uint64_t* seed_ptr;   // if non-null the per-step seed is read from device memory (graph replay)
+    const float* act;       // EPI_MASK: stored output of the producing layer
+    int ldact;
+    float inv_keep;         // EPI_MASK: 1/keep of the producing layer
+    int64_t split_stride;   // EPI_STORE with gridDim.z>1: C + z*split_stride
+};
+
+// loads this thread's float4 piece of a [64 x 16] operand tile.
+// KC: memory is [mn][k] (k contiguous, ld = mn stride); thread -> (mn = t>>2, k = (t&3)*4 .. +3)
+// !KC: memory is [k][mn] (mn contiguous, ld = k stride);  thread -> (k = t>>4, mn = (t&15)*4 .. +3)
+template <bool KC>
+__device__ __forceinline__ float4 load_piece(const float* __restrict__ p, int ld, int mn0, int k0,
+                                             int MN, int Kend, bool vec, int t) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KC) {
+        const int mn = mn0 + (t >> 2), k = k0 + (t & 3) * 4;
+        if (mn < MN && k < Kend) {
+            const float* q = p + (size_t)mn * ld + k;
+            if (vec && k + 3 < Kend) {
+                v = *reinterpret_cast<const float4*>(q);
+            } else {
+                v.x = q[0];
+                if (k + 1 < Kend) v.y = q[1];
+                if (k + 2 < Kend) v.z = q[2];
+                if (k + 3 < Kend) v.w = q[3];
+            }
+        }
+    } else {
+        const int k = k0 + (t >> 4), mn = mn0 + (t & 15) * 4;
+        if (k < Kend && mn < MN) {
+            const float* q = p + (size_t)k * ld + mn;
+            if (vec && mn + 3 < MN) {
+                v = *reinterpret_cast<const float4*>(q);
+            } else {
+                v.x = q[0];
+                if (mn + 1 < MN) v.y = q[1];
+                if (mn + 2 < MN) v.z = q[2];
+                if (mn + 3 < MN) v.w = q[3];
+            }
+        }
+    }
+    return v;
+}
+
+template <bool KC, int LD>
+__device__ __forceinline__ void store_piece(float* __restrict__ s, float4 v, int t) {
+    if (KC) {
+        const int mn = t >> 2, k = (t & 3) * 4;
+        s[(k + 0) * LD + mn] = v.x;
+        s[(k + 1) * LD + mn] = v.y;
+        s[(k + 2) * LD + mn] = v.z;
+        s[(k + 3) * LD + mn] = v.w;
+    } else {
+        const int k = t >> 4, mn = (t & 15) * 4;
+        *reinterpret_cast<float4*>(&s[k * LD + mn]) = v;
+    }
+}
+
+template <bool A_KC, bool B_NC, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_mfma(
+    const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
+    float* __restrict__ Cm, int ldc, int M, int N, int K, int kchunk, bool vecA, bool vecB, Epilogue ep) {
+    constexpr int LDA = A_KC ? 66 : 68;      // 66: conflict-free transposing scalar writes; 68: 16B-aligned rows
+    constexpr int LDB = B_NC ? 68 : 66;
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * kchunk;
+    const int kend = min(K, kbeg + kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    float4 ra = load_piece<A_KC>(A, lda, m0, kbeg, M, kend, vecA, t);
+    float4 rb = load_piece<!B_NC>(Bm, ldb, n0, kbeg, N, kend, vecB, t);
+    store_piece<A_KC, LDA>(As[0], ra, t);
+    store_piece<!B_NC, LDB>(Bs[0], rb, t);
+    __syncthreads();
+
+    const int arow = wm * 32 + (lane & 31), bcol = wn * 32 + (lane & 31), khalf = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            ra = load_piece<A_KC>(A, lda, m0, kbeg + (kt + 1) * BK, M, kend, vecA, t);
+            rb = load_piece<!B_NC>(Bm, ldb, n0, kbeg + (kt + 1) * BK, N, kend, vecB, t);
+        }
+        const float* as = As[cur];
+        const float* bs = Bs[cur];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a = as[(kk + khalf) * LDA + arow];
+            const float b = bs[(kk + khalf) * LDB + bcol];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            store_piece<A_KC, LDA>(As[cur ^ 1], ra, t);
+            store_piece<!B_NC, LDB>(Bs[cur ^ 1], rb, t);
+        }
+        __syncthreads();
+    }
+
+    // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col >= N) return;
+    float* Cz = Cm + (EPI == EPI_STORE ? (size_t)blockIdx.z * ep.split_stride : 0);
+    float bias = 0.f;
+    uint64_t seed = 0;
+    if (EPI == EPI_BIAS_ACT) {
+        if (ep.bias != nullptr) bias = ep.bias[col];
+        seed = ep.seed ^ (ep.seed_ptr ? *ep.seed_ptr : 0ull);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= M) continue;
+        float v = acc[r];
+        if (EPI == EPI_BIAS_ACT) {
+            v += bias;
+            if (ep.relu) v = fmaxf(v, 0.f);
+            if (ep.keep < 1.0f) v *= dropout_scale(seed, (uint64_t)row * (uint64_t)N + col, ep.keep);
+        } else if (EPI == EPI_MASK) {
+            v = (ep.act[(size_t)row * ep.ldact + col] > 0.f) ? v * ep.inv_keep : 0.f;
+        }
+        Cz[(size_t)row * ldc + col] = v;
+    }
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <bool A_KC, bool B_NC, int EPI>
+static int launch_gemm(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
+                       int K, int splits, const Epilogue& ep, hipStream_t st) {
+    if (M <= 0 || N <= 0) return DCTR_OK;
+    const bool vecA = aligned16(A) && (lda % 4 == 0);
+    const bool vecB = aligned16(B) && (ldb % 4 == 0);
+    int kchunk = (int)round_up(ceil_div(K, splits), BK);
+    dim3 grid(ceil_div(N, BN), ceil_div(M, BM), splits), block(256);
+    gemm_f32_mfma<A_KC, B_NC, EPI><<<grid, block, 0, st>>>(A, lda, B, ldb, C, ldc, M, N, K, kchunk, vecA, vecB, ep);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+// ---- public (namespace-level) entry points used by the engine -------------------------------------
+int fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N,
+           int relu, float keep, const uint64_t* seed_ptr, uint64_t seed, hipStream_t st) {
+    Epilogue ep{};
+    ep.bias = b; ep.relu = relu; ep.keep = keep; ep.seed = seed; ep.seed_ptr = seed_ptr;
+    return launch_gemm<true, true, EPI_BIAS_ACT>(x, ldx, w, N, y, ldy, M, N, K, 1, ep, st);
+}
+
+int fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int K, int N,
+                const float* act, int ldact, float keep_prev, hipStream_t st) {
+    // dX[M,K] = dY[M,N] * W[K,N]^T : reduction over N; "B" = W^T[N,K] stored as W[K,N] => k(N)-contiguous
+    Epilogue ep{};
+    if (act != nullptr) {
+        ep.act = act; ep.ldact = ldact; ep.inv_keep = 1.0f / keep_prev;
+        return launch_gemm<true, false, EPI_MASK>(dy, lddy, w, N, dx, lddx, M, K, N, 1, ep, st);
+    }
+    return launch_gemm<true, false, EPI_STORE>(dy, lddy, w, N, dx, lddx, M, K, N, 1, ep, st);
+}
+
+// dW partials: out[s][K*N] for s < splits (split over the batch dimension M), db partials: outb[s][N]
+int fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int lddy, float* dw_part, int64_t dw_stride,
+                            float* db_part, int64_t db_stride, int M, int K, int N, int splits, hipStream_t st) {
+    Epilogue ep{};
+    ep.split_stride = dw_stride;
+    // C[K,N] = X^T[K,M] dY[M,N]: reduction over M.  A = X^T stored as X[M,K] => "m"(=K here)-contiguous
+    DCTR_TRY((launch_gemm<false, true, EPI_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st)));
+    if (db_part != nullptr) {
+        // any partition of the batch sums to the same total; it need not match the GEMM's k-chunking
+        DCTR_TRY(colsum_partials(dy, lddy, nullptr, M, N, splits, db_part, db_stride, st));
+    }
+    return DCTR_OK;
+}
+
+// generic sum of partial slabs: out[i] = sum_s part[s*stride + i]
+__global__ void sum_partials_kernel(const float* __restrict__ part, int64_t stride, int splits, int64_t n,
+                                    float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(size_t)k * stride + i];
+    out[i] = s;
+}
+
+int sum_partials(const float* part, int64_t stride, int splits, int64_t n, float* out, hipStream_t st) {
+    if (n <= 0) return DCTR_OK;
+    sum_partials_kernel<<<ceil_div(n, 256), 256, 0, st>>>(part, stride, splits, n, out);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+int choose_wgrad_splits(int M, int K, int N) {
+    const int tiles = ceil_div(K, BM) * ceil_div(N, BN);
+    int s = ceil_div(1024, tiles);                 // aim at ~4 blocks per CU
+    const int max_by_m = ceil_div(M, 4 * BK);      // keep >= 4 k-steps per split
+    if (s > max_by_m) s = max_by_m;
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+    return s;
+}
+
+}  // namespace dctr
+
+using namespace dctr;
+
+extern "C" {
+
+int dctr_fc_fwd(const float* d_x, int ldx, const float* d_w, const float* d_b, float* d_y, int ldy, int M,
+                int K, int N, int relu, float keep, uint64_t seed, void* stream) {
+    DCTR_REQUIRE(keep > 0.f && keep <= 1.f, "keep_prob must be in (0,1], got %f", keep);
+    return fc_fwd(d_x, ldx, d_w, d_b, d_y, ldy, M, K, N, relu, keep, nullptr, seed, as_stream(stream));
+}
+
+int dctr_fc_bwd_data(const float* d_dy, int lddy, const float* d_w, float* d_dx, int lddx, int M, int K, int N,
+                     const float* d_act, int ldact, float keep_prev, void* stream) {
+    return fc_bwd_data(d_dy, lddy, d_w, d_dx, lddx, M, K, N, d_act, ldact, keep_prev, as_stream(stream));
+}
+
+int dctr_fc_bwd_weights(const float* d_x, int ldx, const float* d_dy, int lddy, float* d_dw, float* d_db, int M,
+                        int K, int N, float* d_workspace, size_t workspace_bytes, void* stream) {
+    hipStream_t st = as_stream(stream);
+    int splits = choose_wgrad_splits(M, K, N);
+    const size_t per = ((size_t)K * N + N) * sizeof(float);
+    if (d_workspace == nullptr || workspace_bytes < per * 2) splits = 1;
+    else if ((size_t)splits * per > workspace_bytes) splits = (int)(workspace_bytes / per);
+    if (splits <= 1) {
+        DCTR_TRY(fc_bwd_weights_partials(d_x, ldx, d_dy, lddy, d_dw, 0, d_db, 0, M, K, N, 1, st));
+        return DCTR_OK;
+    }
+    float* wpart = d_workspace;
+    float* bpart = d_workspace + (size_t)splits * K * N;
+    DCTR_TRY(fc_bwd_weights_partials(d_x, ldx, d_dy, lddy, wpart, (int64_t)K * N, d_db ? bpart : nullptr, N, M, K, N, splits, st));
+    DCTR_TRY(sum_partials(wpart, (int64_t)K * N, splits, (int64_t)K * N, d_dw, st));
+    if (d_db) DCTR_TRY(sum_partials(bpart, N, splits, N, d_db, st));
+    return DCTR_OK;
+}
+
+}  // extern "C"

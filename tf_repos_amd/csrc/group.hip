@@ -1,0 +1,322 @@
+// K8: sparse table gradient = IndexedSlices -> unsorted_segment_sum of the gather gradients
+// (DeepFM.py:126,130 differentiated by optimizer.minimize DeepFM.py:213).
+//
+// Integer/byte work, HBM/L2-latency bound -- no sort, no GEMM reshaping:
+//   group_ids:  a direct-mapped slot word per table row groups the batch's B*F ids:
+//     count    slot[id] += multiplicity (wave-aggregated: lanes of a wave holding the same id issue
+//              ONE atomic; entries are walked field-major so Criteo's per-field hot ids -- the 13
+//              numeric ids hit by every example -- collapse to one atomic per wave)
+//     finalize per distinct id u: segment [seg_start[u], +cnt[u]) carved with one atomicAdd,
+//              slot[id] = u+1, compact gradient row u zeroed
+//     fill     perm[] = entry indices grouped by distinct id, seg_of[] = u per grouped position
+//   scatter:    walkers of K/4 lanes stride over runs of R grouped positions, accumulate row
+//              gradients in registers and flush once per (run, distinct id) with float atomics into
+//              the compact [U, K] buffer.  The FM / bi-interaction backward is fused here so dE never
+//              round-trips through HBM for those terms.
+#include "common.h"
+#include "ops.h"
+
+namespace dctr {
+
+
+__global__ void group_reset_kernel(int32_t* __restrict__ slot, const int32_t* __restrict__ uniq,
+                                   int32_t* __restrict__ counters, int n_max) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    const int U = counters[0];
+    if (u < U && u < n_max) slot[uniq[u]] = 0;
+}
+
+__global__ void group_zero_counters(int32_t* counters) {
+    counters[0] = 0;
+    counters[1] = 0;
+}
+
+// entry i <-> (f = i / B, b = i % B): field-major walk
+__global__ __launch_bounds__(256) void group_count_kernel(const int32_t* __restrict__ ids, int B, int F,
+                                                         int64_t rows, int32_t* __restrict__ slot,
+                                                         int32_t* __restrict__ uniq, int32_t* __restrict__ counters) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = B * F;
+    const int lane = threadIdx.x & 63;
+    int id = -1;
+    bool active = false;
+    if (i < n) {
+        const int f = i / B, b = i - f * B;
+        id = ids[(size_t)b * F + f];
+        active = (id >= 0) && ((int64_t)id < rows);
+    }
+    while (true) {
+        const unsigned long long m = __ballot(active);
+        if (m == 0ull) break;
+        const int leader = __ffsll((long long)m) - 1;
+        const int lid = __shfl(id, leader);
+        const bool same = active && (id == lid);
+        const unsigned long long sm = __ballot(same);
+        if (lane == leader) {
+            const int old = atomicAdd(&slot[lid], __popcll(sm));
+            if (old == 0) {
+                const int u = atomicAdd(&counters[0], 1);
+                uniq[u] = lid;
+            }
+        }
+        active = active && !same;
+    }
+}
+
+template <int KQ>
+__global__ __launch_bounds__(256) void group_finalize_kernel(int32_t* __restrict__ slot, const int32_t* __restrict__ uniq,
+                                                            int32_t* __restrict__ cnt, int32_t* __restrict__ seg_start,
+                                                            int32_t* __restrict__ cursor, int32_t* __restrict__ counters,
+                                                            float4* __restrict__ gemb, float* __restrict__ glin) {
+    // KQ lanes per distinct id (they zero the compact gradient row together)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int u = t / KQ, kq = t % KQ;
+    const int U = counters[0];
+    if (u >= U) return;
+    if (kq == 0) {
+        const int id = uniq[u];
+        const int c = slot[id];
+        const int s = atomicAdd(&counters[1], c);
+        cnt[u] = c;
+        seg_start[u] = s;
+        cursor[u] = s;
+        slot[id] = u + 1;
+        glin[u] = 0.f;
+    }
+    gemb[(size_t)u * KQ + kq] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ __launch_bounds__(256) void group_fill_kernel(const int32_t* __restrict__ ids, int B, int F, int64_t rows,
+                                                        const int32_t* __restrict__ slot, int32_t* __restrict__ cursor,
+                                                        int32_t* __restrict__ perm, int32_t* __restrict__ seg_of) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = B * F;
+    const int lane = threadIdx.x & 63;
+    int id = -1;
+    bool active = false;
+    if (i < n) {
+        const int f = i / B, b = i - f * B;
+        id = ids[(size_t)b * F + f];
+        active = (id >= 0) && ((int64_t)id < rows);
+    }
+    while (true) {
+        const unsigned long long m = __ballot(active);
+        if (m == 0ull) break;
+        const int leader = __ffsll((long long)m) - 1;
+        const int lid = __shfl(id, leader);
+        const bool same = active && (id == lid);
+        const unsigned long long sm = __ballot(same);
+        int u = 0, base = 0;
+        if (lane == leader) {
+            u = slot[lid] - 1;
+            base = atomicAdd(&cursor[u], __popcll(sm));
+        }
+        u = __shfl(u, leader);
+        base = __shfl(base, leader);
+        if (same) {
+            const int pos = base + __popcll(sm & ((1ull << lane) - 1ull));
+            perm[pos] = i;
+            seg_of[pos] = u;
+        }
+        active = active && !same;
+    }
+}
+
+constexpr int SCATTER_RUN = 16;   // grouped positions per walker
+
+template <int KQ, int MODE>
+__global__ __launch_bounds__(256) void scatter_bwd_kernel(
+    const int32_t* __restrict__ perm, const int32_t* __restrict__ seg_of, const int32_t* __restrict__ counters,
+    const float4* __restrict__ dE, int de_ld4, const float4* __restrict__ e, int e_ld4,
+    const float4* __restrict__ S, const float* __restrict__ coef, const float* __restrict__ dy,
+    const float* __restrict__ vals, int B, int F, float* __restrict__ gemb, float* __restrict__ glin) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = t / KQ, kq = t % KQ;
+    const int total = counters[1];
+    const int j0 = w * SCATTER_RUN;
+    if (j0 >= total) return;
+    const int jend = min(total, j0 + SCATTER_RUN);
+    int cur = -1;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float accl = 0.f;
+    for (int j = j0; j < jend; ++j) {
+        const int u = seg_of[j];
+        const int i = perm[j];
+        const int f = i / B, b = i - f * B;
+        if (u != cur) {
+            if (cur >= 0) {
+                float* g = gemb + ((size_t)cur * KQ + kq) * 4;
+                atomicAdd(g + 0, acc.x); atomicAdd(g + 1, acc.y); atomicAdd(g + 2, acc.z); atomicAdd(g + 3, acc.w);
+                if (kq == 0 && glin != nullptr) atomicAdd(glin + cur, accl);
+            }
+            cur = u;
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            accl = 0.f;
+        }
+        const float v = vals[(size_t)b * F + f];
+        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dE != nullptr) d = dE[(size_t)b * de_ld4 + (size_t)f * KQ + kq];
+        if (MODE == DCTR_GATHER_FM) {
+            // y_v = 0.5 sum_k[(sum_f e)^2 - sum_f e^2]  =>  d y_v / d e[b,f,k] = S[b,k] - e[b,f,k]   (DeepFM.py:133-135)
+            const float4 ee = e[(size_t)b * e_ld4 + (size_t)f * KQ + kq];
+            const float4 s = S[(size_t)b * KQ + kq];
+            const float c = coef[b];
+            d.x += c * (s.x - ee.x); d.y += c * (s.y - ee.y); d.z += c * (s.z - ee.z); d.w += c * (s.w - ee.w);
+        } else if (MODE == DCTR_GATHER_BI) {
+            // bi[b,k] = 0.5[(sum_f e)^2 - sum_f e^2]  =>  d e[b,f,k] = dbi[b,k] (S[b,k] - e[b,f,k])    (NFM.py:126-128)
+            const float4 ee = e[(size_t)b * e_ld4 + (size_t)f * KQ + kq];
+            const float4 s = S[(size_t)b * KQ + kq];
+            const float4 c = reinterpret_cast<const float4*>(coef)[(size_t)b * KQ + kq];
+            d.x += c.x * (s.x - ee.x); d.y += c.y * (s.y - ee.y); d.z += c.z * (s.z - ee.z); d.w += c.w * (s.w - ee.w);
+        }
+        acc.x += d.x * v; acc.y += d.y * v; acc.z += d.z * v; acc.w += d.w * v;
+        if (kq == 0 && dy != nullptr) accl += dy[b] * v;
+    }
+    if (cur >= 0) {
+        float* g = gemb + ((size_t)cur * KQ + kq) * 4;
+        atomicAdd(g + 0, acc.x); atomicAdd(g + 1, acc.y); atomicAdd(g + 2, acc.z); atomicAdd(g + 3, acc.w);
+        if (kq == 0 && glin != nullptr) atomicAdd(glin + cur, accl);
+    }
+}
+
+template <int KQ>
+static int launch_scatter(Group* g, const float* dE, int de_ld, const float* e, int e_ld, const float* S,
+                          const float* coef, const float* dy, const float* vals, int B, int F, int mode,
+                          float* gemb, float* glin, hipStream_t st) {
+    const int64_t n = (int64_t)B * F;
+    const int walkers = ceil_div(n, SCATTER_RUN);
+    dim3 grid(ceil_div((int64_t)walkers * KQ, 256)), block(256);
+#define DCTR_SC(MODE_)                                                                                         \
+    scatter_bwd_kernel<KQ, MODE_><<<grid, block, 0, st>>>(                                                     \
+        g->perm, g->seg_of, g->counters, reinterpret_cast<const float4*>(dE), de_ld / 4,                       \
+        reinterpret_cast<const float4*>(e), e_ld / 4, reinterpret_cast<const float4*>(S), coef, dy, vals, B, F, \
+        gemb, glin)
+    switch (mode) {
+        case DCTR_GATHER_RAW: DCTR_SC(DCTR_GATHER_RAW); break;
+        case DCTR_GATHER_FM:  DCTR_SC(DCTR_GATHER_FM); break;
+        case DCTR_GATHER_BI:  DCTR_SC(DCTR_GATHER_BI); break;
+        default: set_error("scatter: bad mode %d", mode); return DCTR_ERR_INVALID_ARG;
+    }
+#undef DCTR_SC
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+int group_create(int64_t rows, int64_t max_entries, int K, Group** out) {
+    DCTR_REQUIRE(rows > 0 && max_entries > 0 && K % 4 == 0 && K >= 4, "group_create: bad sizes rows=%lld n=%lld K=%d",
+                 (long long)rows, (long long)max_entries, K);
+    Group* g = new Group();
+    g->rows = rows; g->max_entries = max_entries; g->K = K;
+    const size_t n = (size_t)max_entries;
+    DCTR_HIP_CHECK(hipMalloc(&g->slot, (size_t)rows * 4));
+    DCTR_HIP_CHECK(hipMemset(g->slot, 0, (size_t)rows * 4));
+    DCTR_HIP_CHECK(hipMalloc(&g->uniq, n * 4));
+    DCTR_HIP_CHECK(hipMalloc(&g->cnt, n * 4));
+    DCTR_HIP_CHECK(hipMalloc(&g->seg_start, n * 4));
+    DCTR_HIP_CHECK(hipMalloc(&g->cursor, n * 4));
+    DCTR_HIP_CHECK(hipMalloc(&g->perm, n * 4));
+    DCTR_HIP_CHECK(hipMalloc(&g->seg_of, n * 4));
+    DCTR_HIP_CHECK(hipMalloc(&g->counters, 16));
+    DCTR_HIP_CHECK(hipMemset(g->counters, 0, 16));
+    DCTR_HIP_CHECK(hipMalloc(&g->gemb, n * K * 4));
+    DCTR_HIP_CHECK(hipMalloc(&g->glin, n * 4));
+    *out = g;
+    return DCTR_OK;
+}
+
+int group_destroy(Group* g) {
+    if (!g) return DCTR_OK;
+    hipFree(g->slot); hipFree(g->uniq); hipFree(g->cnt); hipFree(g->seg_start); hipFree(g->cursor);
+    hipFree(g->perm); hipFree(g->seg_of); hipFree(g->counters); hipFree(g->gemb); hipFree(g->glin);
+    delete g;
+    return DCTR_OK;
+}
+
+int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st) {
+    const int64_t n = (int64_t)B * F;
+    DCTR_REQUIRE(n <= g->max_entries, "group_ids: B*F=%lld exceeds capacity %lld", (long long)n, (long long)g->max_entries);
+    if (n <= 0) return DCTR_OK;
+    const int nb = ceil_div(n, 256);
+    group_reset_kernel<<<ceil_div(g->max_entries, 256), 256, 0, st>>>(g->slot, g->uniq, g->counters, (int)g->max_entries);
+    group_zero_counters<<<1, 1, 0, st>>>(g->counters);
+    group_count_kernel<<<nb, 256, 0, st>>>(ids, B, F, g->rows, g->slot, g->uniq, g->counters);
+    const int KQ = g->K / 4;
+    dim3 fgrid(ceil_div(n * KQ, 256));
+    float4* gemb4 = reinterpret_cast<float4*>(g->gemb);
+    switch (KQ) {
+#define DCTR_FIN(Q) case Q: group_finalize_kernel<Q><<<fgrid, 256, 0, st>>>(g->slot, g->uniq, g->cnt, g->seg_start, g->cursor, g->counters, gemb4, g->glin); break
+        DCTR_FIN(1); DCTR_FIN(2); DCTR_FIN(4); DCTR_FIN(8); DCTR_FIN(16); DCTR_FIN(32); DCTR_FIN(64);
+#undef DCTR_FIN
+        default: set_error("group: K=%d unsupported", g->K); return DCTR_ERR_UNSUPPORTED;
+    }
+    group_fill_kernel<<<nb, 256, 0, st>>>(ids, B, F, g->rows, g->slot, g->cursor, g->perm, g->seg_of);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+int embed_scatter_bwd(Group* g, const float* dE, int de_ld, const float* e, int e_ld, const float* S,
+                      const float* coef, const float* dy, const float* vals, int B, int F, int K, int mode,
+                      float* gemb, float* glin, hipStream_t st) {
+    DCTR_REQUIRE(K == g->K, "scatter: K=%d but group was created with K=%d", K, g->K);
+    DCTR_REQUIRE(dE == nullptr || de_ld % 4 == 0, "scatter: de_ld must be a multiple of 4");
+    DCTR_REQUIRE(mode == DCTR_GATHER_RAW || (e != nullptr && S != nullptr && coef != nullptr && e_ld % 4 == 0),
+                 "scatter: FM/BI modes need e, S and coef");
+    if (gemb == nullptr) gemb = g->gemb;
+    if (glin == nullptr && dy != nullptr) glin = g->glin;
+    switch (K / 4) {
+#define DCTR_L(Q) case Q: return launch_scatter<Q>(g, dE, de_ld, e, e_ld, S, coef, dy, vals, B, F, mode, gemb, glin, st)
+        DCTR_L(1); DCTR_L(2); DCTR_L(4); DCTR_L(8); DCTR_L(16); DCTR_L(32); DCTR_L(64);
+#undef DCTR_L
+        default: set_error("scatter: K=%d unsupported", K); return DCTR_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace dctr
+
+using namespace dctr;
+
+extern "C" {
+
+int dctr_group_create(int64_t rows, int64_t max_entries, int K, dctr_group_t* g) {
+    DCTR_REQUIRE(g != nullptr, "null out pointer");
+    Group* p = nullptr;
+    DCTR_TRY(group_create(rows, max_entries, K, &p));
+    *g = reinterpret_cast<dctr_group_t>(p);
+    return DCTR_OK;
+}
+int dctr_group_destroy(dctr_group_t g) { return group_destroy(reinterpret_cast<Group*>(g)); }
+int dctr_group_ids(dctr_group_t g, const int32_t* d_ids, int B, int F, void* stream) {
+    DCTR_REQUIRE(g != nullptr, "null group");
+    return group_ids(reinterpret_cast<Group*>(g), d_ids, B, F, as_stream(stream));
+}
+int dctr_group_num_unique(dctr_group_t g, int32_t* h_U, void* stream) {
+    DCTR_REQUIRE(g != nullptr && h_U != nullptr, "null pointer");
+    Group* p = reinterpret_cast<Group*>(g);
+    DCTR_HIP_CHECK(hipMemcpyAsync(h_U, p->counters, 4, hipMemcpyDeviceToHost, as_stream(stream)));
+    DCTR_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+    return DCTR_OK;
+}
+int dctr_group_buffers(dctr_group_t g, const int32_t** d_uniq, const int32_t** d_seg_start, const int32_t** d_cnt,
+                       const int32_t** d_perm, const int32_t** d_slot, const int32_t** d_counters,
+                       float** d_gemb, float** d_glin) {
+    DCTR_REQUIRE(g != nullptr, "null group");
+    Group* p = reinterpret_cast<Group*>(g);
+    if (d_uniq) *d_uniq = p->uniq;
+    if (d_seg_start) *d_seg_start = p->seg_start;
+    if (d_cnt) *d_cnt = p->cnt;
+    if (d_perm) *d_perm = p->perm;
+    if (d_slot) *d_slot = p->slot;
+    if (d_counters) *d_counters = p->counters;
+    if (d_gemb) *d_gemb = p->gemb;
+    if (d_glin) *d_glin = p->glin;
+    return DCTR_OK;
+}
+int dctr_embed_scatter_bwd(dctr_group_t g, const float* d_dE, int de_ld, const float* d_e, int e_ld,
+                           const float* d_sum, const float* d_coef, const float* d_dy, const float* d_vals, int B,
+                           int F, int K, int mode, float* d_gemb, float* d_glin, void* stream) {
+    DCTR_REQUIRE(g != nullptr, "null group");
+    return embed_scatter_bwd(reinterpret_cast<Group*>(g), d_dE, de_ld, d_e, e_ld, d_sum, d_coef, d_dy, d_vals, B, F, K,
+                             mode, d_gemb, d_glin, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,315 @@
+// K3 / K5: interaction layers between the gather and the MLP.
+//   PNN inner product  (PNN.py:141-153)  ip[b,p] = <e_i, e_j>, pairs (i<j) lexicographic
+//   PNN outer product  (PNN.py:154-167)  op[b,p,a,c] = e_i[a] e_j[c]  (materialised; reference marks it "NOT ready yet")
+//   DCN cross network  (DCN.py:140-145)  x_{l+1} = x0 (x_l . w_l) + x_l + b_l
+// All are <= 1 flop/byte per HBM byte: one example's F*K scaled-embedding tile is staged once in LDS
+// (or registers for DCN) and every pair / layer is computed from there.
+#include "common.h"
+#include "ops.h"
+
+namespace dctr {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__device__ __forceinline__ int pair_index(int i, int j, int F) {   // i < j
+    return i * F - (i * (i + 1)) / 2 + (j - i - 1);
+}
+
+// ---- inner product forward: one wave per example, e tile in LDS with row stride K+1 (bank-conflict-free
+// when lanes read different rows at the same k)
+__global__ __launch_bounds__(256) void pnn_inner_fwd_kernel(const float* __restrict__ e, int e_ld, int B, int F, int K,
+                                                           float* __restrict__ ip, int ip_ld) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    const int KS = K + 1;
+    float* t = smem + (size_t)wave * F * KS;
+    if (b < B) {
+        const float* er = e + (size_t)b * e_ld;
+        for (int x = lane; x < F * K; x += 64) t[(x / K) * KS + (x % K)] = er[x];
+    }
+    __syncthreads();
+    if (b >= B) return;
+    const int P = F * (F - 1) / 2;
+    // decode pair p -> (i,j) incrementally per lane
+    for (int p = lane; p < P; p += 64) {
+        // find i: largest i with i*F - i(i+1)/2 <= p
+        int i = 0, base = 0;
+        while (true) {
+            const int next = base + (F - 1 - i);
+            if (p < next) break;
+            base = next;
+            ++i;
+        }
+        const int j = i + 1 + (p - base);
+        const float* a = t + i * KS;
+        const float* c = t + j * KS;
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += a[k] * c[k];
+        ip[(size_t)b * ip_ld + p] = s;
+    }
+}
+
+int pnn_inner_fwd(const float* e, int e_ld, int B, int F, int K, float* ip, int ip_ld, hipStream_t st) {
+    if (B <= 0) return DCTR_OK;
+    const size_t lds = (size_t)4 * F * (K + 1) * sizeof(float);
+    DCTR_REQUIRE(lds <= 160 * 1024, "pnn_inner: F*K tile too large for LDS (F=%d K=%d)", F, K);
+    pnn_inner_fwd_kernel<<<ceil_div(B, 4), 256, lds, st>>>(e, e_ld, B, F, K, ip, ip_ld);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+// ---- inner product backward: dE[b,i,:] += sum_{j != i} dip[b,pair(i,j)] e[b,j,:]
+__global__ __launch_bounds__(256) void pnn_inner_bwd_kernel(const float* __restrict__ e, int e_ld, const float* __restrict__ dip,
+                                                           int dip_ld, int B, int F, int K, float* __restrict__ dE, int de_ld) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    const int P = F * (F - 1) / 2;
+    float* t = smem + (size_t)wave * (F * K + P);
+    float* g = t + F * K;
+    if (b < B) {
+        const float* er = e + (size_t)b * e_ld;
+        for (int x = lane; x < F * K; x += 64) t[x] = er[x];
+        const float* dr = dip + (size_t)b * dip_ld;
+        for (int x = lane; x < P; x += 64) g[x] = dr[x];
+    }
+    __syncthreads();
+    if (b >= B) return;
+    for (int x = lane; x < F * K; x += 64) {
+        const int i = x / K, k = x - i * K;
+        float s = 0.f;
+        for (int j = 0; j < i; ++j) s += g[pair_index(j, i, F)] * t[j * K + k];
+        for (int j = i + 1; j < F; ++j) s += g[pair_index(i, j, F)] * t[j * K + k];
+        dE[(size_t)b * de_ld + x] += s;
+    }
+}
+
+int pnn_inner_bwd(const float* e, int e_ld, const float* dip, int dip_ld, int B, int F, int K, float* dE, int de_ld,
+                  hipStream_t st) {
+    if (B <= 0) return DCTR_OK;
+    const int P = F * (F - 1) / 2;
+    const size_t lds = (size_t)4 * (F * K + P) * sizeof(float);
+    DCTR_REQUIRE(lds <= 160 * 1024, "pnn_inner_bwd: tile too large for LDS (F=%d K=%d)", F, K);
+    pnn_inner_bwd_kernel<<<ceil_div(B, 4), 256, lds, st>>>(e, e_ld, dip, dip_ld, B, F, K, dE, de_ld);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+// ---- outer product, materialised exactly as PNN.py:166 writes it: [B, P*K*K]
+__global__ __launch_bounds__(256) void pnn_outer_fwd_kernel(const float* __restrict__ e, int e_ld, int B, int F, int K,
+                                                           float* __restrict__ op, int64_t op_ld) {
+    const int b = blockIdx.y;
+    const int P = F * (F - 1) / 2;
+    const int64_t n = (int64_t)P * K * K;
+    const float* er = e + (size_t)b * e_ld;
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(x / (K * K));
+        const int r = (int)(x - (int64_t)p * K * K);
+        const int a = r / K, c = r - a * K;
+        int i = 0, base = 0;
+        while (true) {
+            const int next = base + (F - 1 - i);
+            if (p < next) break;
+            base = next;
+            ++i;
+        }
+        const int j = i + 1 + (p - base);
+        op[(size_t)b * op_ld + x] = er[i * K + a] * er[j * K + c];
+    }
+}
+
+int pnn_outer_fwd(const float* e, int e_ld, int B, int F, int K, float* op, int64_t op_ld, hipStream_t st) {
+    if (B <= 0) return DCTR_OK;
+    const int64_t n = (int64_t)F * (F - 1) / 2 * K * K;
+    dim3 grid((unsigned)std::min<int64_t>(ceil_div(n, 256), 1024), B);
+    pnn_outer_fwd_kernel<<<grid, 256, 0, st>>>(e, e_ld, B, F, K, op, op_ld);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+// dE[b,f,k] += sum_{j>f} sum_c dop[b,p(f,j),k,c] e[b,j,c]  +  sum_{i<f} sum_a dop[b,p(i,f),a,k] e[b,i,a]
+__global__ __launch_bounds__(256) void pnn_outer_bwd_kernel(const float* __restrict__ e, int e_ld, const float* __restrict__ dop,
+                                                           int64_t dop_ld, int B, int F, int K, float* __restrict__ dE, int de_ld) {
+    const int b = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= F * K) return;
+    const int f = x / K, k = x - f * K;
+    const float* er = e + (size_t)b * e_ld;
+    const float* dr = dop + (size_t)b * dop_ld;
+    float s = 0.f;
+    for (int j = f + 1; j < F; ++j) {
+        const float* d = dr + ((size_t)pair_index(f, j, F) * K + k) * K;
+        for (int c = 0; c < K; ++c) s += d[c] * er[j * K + c];
+    }
+    for (int i = 0; i < f; ++i) {
+        const float* d = dr + (size_t)pair_index(i, f, F) * K * K + k;
+        for (int a = 0; a < K; ++a) s += d[(size_t)a * K] * er[i * K + a];
+    }
+    dE[(size_t)b * de_ld + x] += s;
+}
+
+int pnn_outer_bwd(const float* e, int e_ld, const float* dop, int64_t dop_ld, int B, int F, int K, float* dE, int de_ld,
+                  hipStream_t st) {
+    if (B <= 0) return DCTR_OK;
+    dim3 grid(ceil_div(F * K, 256), B);
+    pnn_outer_bwd_kernel<<<grid, 256, 0, st>>>(e, e_ld, dop, dop_ld, B, F, K, dE, de_ld);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+// ---- DCN cross network.  One wave per example; x0 and x_l live in registers (NR = ceil(D/64) floats per lane);
+// all L layers are applied without leaving the CU.  xs[l] (l = 0..L) and s_l = x_l.w_l are kept for the backward.
+template <int NR>
+__global__ __launch_bounds__(256) void dcn_cross_fwd_kernel(const float* __restrict__ x0, int x0_ld, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, int B, int D, int L,
+                                                           float* __restrict__ xs, float* __restrict__ xlw) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float a0[NR], xl[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int d = lane + 64 * r;
+        a0[r] = (d < D) ? x0[(size_t)b * x0_ld + d] : 0.f;
+        xl[r] = a0[r];
+        if (d < D) xs[(size_t)b * D + d] = a0[r];
+    }
+    for (int l = 0; l < L; ++l) {
+        const float* wl = w + (size_t)l * D;
+        const float* bl = bias + (size_t)l * D;
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int d = lane + 64 * r;
+            if (d < D) s += xl[r] * wl[d];
+        }
+        s = wsum(s);
+        if (lane == 0) xlw[(size_t)l * B + b] = s;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int d = lane + 64 * r;
+            if (d < D) {
+                xl[r] = a0[r] * s + xl[r] + bl[d];
+                xs[((size_t)(l + 1) * B + b) * D + d] = xl[r];
+            }
+        }
+    }
+}
+
+int dcn_cross_fwd(const float* x0, int x0_ld, const float* w, const float* b, int B, int D, int L, float* xs,
+                  float* xlw, hipStream_t st) {
+    if (B <= 0) return DCTR_OK;
+    const int nr = ceil_div(D, 64);
+    dim3 grid(ceil_div(B, 4));
+    if (nr <= 10) dcn_cross_fwd_kernel<10><<<grid, 256, 0, st>>>(x0, x0_ld, w, b, B, D, L, xs, xlw);
+    else if (nr <= 20) dcn_cross_fwd_kernel<20><<<grid, 256, 0, st>>>(x0, x0_ld, w, b, B, D, L, xs, xlw);
+    else if (nr <= 40) dcn_cross_fwd_kernel<40><<<grid, 256, 0, st>>>(x0, x0_ld, w, b, B, D, L, xs, xlw);
+    else { set_error("dcn_cross: F*K=%d > 2560 unsupported", D); return DCTR_ERR_UNSUPPORTED; }
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+// backward per example (g = dL/dx_{l+1}):  t_l = g.x0 ; dx0 += g s_l ; g <- g + t_l w_l ; finally dx0 += g.
+// G[l] = dL/dx_{l+1} and T[l] = t_l are written to scratch; db_l = colsum(G[l]), dw_l = colsum(T[l] * xs[l]).
+template <int NR>
+__global__ __launch_bounds__(256) void dcn_cross_bwd_kernel(const float* __restrict__ xs, const float* __restrict__ xlw,
+                                                           const float* __restrict__ w, const float* __restrict__ dxL, int dxl_ld,
+                                                           int B, int D, int L, float* __restrict__ dx0, int dx0_ld,
+                                                           float* __restrict__ G, float* __restrict__ T) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float a0[NR], g[NR], acc0[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int d = lane + 64 * r;
+        a0[r] = (d < D) ? xs[(size_t)b * D + d] : 0.f;
+        g[r] = (d < D) ? dxL[(size_t)b * dxl_ld + d] : 0.f;
+        acc0[r] = 0.f;
+    }
+    for (int l = L - 1; l >= 0; --l) {
+        const float s = xlw[(size_t)l * B + b];
+        const float* wl = w + (size_t)l * D;
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) t += g[r] * a0[r];
+        t = wsum(t);
+        if (lane == 0) T[(size_t)l * B + b] = t;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int d = lane + 64 * r;
+            if (d < D) {
+                G[((size_t)l * B + b) * D + d] = g[r];
+                acc0[r] += g[r] * s;
+                g[r] += t * wl[d];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int d = lane + 64 * r;
+        if (d < D) dx0[(size_t)b * dx0_ld + d] += acc0[r] + g[r];
+    }
+}
+
+int dcn_cross_bwd(const float* xs, const float* xlw, const float* w, const float* dxL, int dxl_ld, int B, int D, int L,
+                  float* dx0, int dx0_ld, float* dw_part, float* db_part, int splits, int64_t part_stride,
+                  float* scratch, hipStream_t st) {
+    if (B <= 0) return DCTR_OK;
+    float* G = scratch;                          // [L,B,D]
+    float* T = scratch + (size_t)L * B * D;      // [L,B]
+    const int nr = ceil_div(D, 64);
+    dim3 grid(ceil_div(B, 4));
+    if (nr <= 10) dcn_cross_bwd_kernel<10><<<grid, 256, 0, st>>>(xs, xlw, w, dxL, dxl_ld, B, D, L, dx0, dx0_ld, G, T);
+    else if (nr <= 20) dcn_cross_bwd_kernel<20><<<grid, 256, 0, st>>>(xs, xlw, w, dxL, dxl_ld, B, D, L, dx0, dx0_ld, G, T);
+    else if (nr <= 40) dcn_cross_bwd_kernel<40><<<grid, 256, 0, st>>>(xs, xlw, w, dxL, dxl_ld, B, D, L, dx0, dx0_ld, G, T);
+    else { set_error("dcn_cross: F*K=%d > 2560 unsupported", D); return DCTR_ERR_UNSUPPORTED; }
+    DCTR_LAUNCH_CHECK();
+    for (int l = 0; l < L; ++l) {
+        // partial slabs: slab s of layer l at part + s*part_stride + l*D
+        DCTR_TRY(colsum_partials(G + (size_t)l * B * D, D, nullptr, B, D, splits, db_part + (size_t)l * D, part_stride, st));
+        DCTR_TRY(colsum_partials(xs + (size_t)l * B * D, D, T + (size_t)l * B, B, D, splits, dw_part + (size_t)l * D, part_stride, st));
+    }
+    return DCTR_OK;
+}
+
+}  // namespace dctr
+
+using namespace dctr;
+
+extern "C" {
+
+int dctr_pnn_inner_fwd(const float* d_e, int e_ld, int B, int F, int K, float* d_ip, int ip_ld, void* stream) {
+    return pnn_inner_fwd(d_e, e_ld, B, F, K, d_ip, ip_ld, as_stream(stream));
+}
+int dctr_pnn_inner_bwd(const float* d_e, int e_ld, const float* d_dip, int dip_ld, int B, int F, int K, float* d_dE,
+                       int de_ld, void* stream) {
+    return pnn_inner_bwd(d_e, e_ld, d_dip, dip_ld, B, F, K, d_dE, de_ld, as_stream(stream));
+}
+int dctr_pnn_outer_fwd(const float* d_e, int e_ld, int B, int F, int K, float* d_op, int64_t op_ld, void* stream) {
+    return pnn_outer_fwd(d_e, e_ld, B, F, K, d_op, op_ld, as_stream(stream));
+}
+int dctr_pnn_outer_bwd(const float* d_e, int e_ld, const float* d_dop, int64_t dop_ld, int B, int F, int K, float* d_dE,
+                       int de_ld, void* stream) {
+    return pnn_outer_bwd(d_e, e_ld, d_dop, dop_ld, B, F, K, d_dE, de_ld, as_stream(stream));
+}
+int dctr_dcn_cross_fwd(const float* d_x0, int x0_ld, const float* d_w, const float* d_b, int B, int D, int L,
+                       float* d_xs, float* d_xlw, void* stream) {
+    return dcn_cross_fwd(d_x0, x0_ld, d_w, d_b, B, D, L, d_xs, d_xlw, as_stream(stream));
+}
+int dctr_dcn_cross_bwd(const float* d_xs, const float* d_xlw, const float* d_w, const float* d_dxL, int dxl_ld, int B,
+                       int D, int L, float* d_dx0, int dx0_ld, float* d_dw, float* d_db, float* d_workspace,
+                       size_t workspace_bytes, void* stream) {
+    // workspace: G [L,B,D] + T [L,B]; single-slab column sums straight into d_dw / d_db ([L,D] each)
+    const size_t need = ((size_t)L * B * D + (size_t)L * B) * sizeof(float);
+    DCTR_REQUIRE(d_workspace != nullptr && workspace_bytes >= need, "dcn_cross_bwd: workspace of %zu bytes required", need);
+    return dcn_cross_bwd(d_xs, d_xlw, d_w, d_dxL, dxl_ld, B, D, L, d_dx0, dx0_ld, d_dw, d_db, 1, 0, d_workspace,
+                         as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+// Internal (namespace-level) declarations shared by the kernels' translation units and the engine.
+#pragma once
+#include "common.h"
+
+namespace dctr {
+
+// ---- optimizer scalars; a copy lives in device memory inside StepState so graphs replay correctly
+struct Hyper {
+    float lr, beta1, beta2, eps, lr_t, momentum;
+    float pad[2];
+};
+
+struct StepState {
+    int64_t t;          // global_step (number of optimizer steps applied so far)
+    uint64_t seed;      // base dropout seed
+    uint64_t seed_t;    // seed of the current step
+    Hyper hyper;
+};
+
+constexpr int OPT_BLOCK = 1024;   // elements of the dense arena handled by one optimizer block
+struct OptBlockMeta {
+    int64_t part_off;     // offset (floats) into the partial-gradient workspace for this block's first element
+    int64_t part_stride;  // distance (floats) between consecutive partial slabs
+    int32_t n_part;       // number of partial slabs to sum
+    float l2;             // l2_reg coefficient if this variable is in the loss via l2_loss (DCN.py:199), else 0
+};
+
+// ---- K8 grouping state (group.hip)
+struct Group {
+    int64_t rows = 0;
+    int64_t max_entries = 0;
+    int K = 0;
+    int32_t* slot = nullptr;      // [rows]   0 = untouched; count during grouping; u+1 afterwards
+    int32_t* uniq = nullptr;      // [max_entries]
+    int32_t* cnt = nullptr;       // [max_entries]
+    int32_t* seg_start = nullptr; // [max_entries]
+    int32_t* cursor = nullptr;    // [max_entries]
+    int32_t* perm = nullptr;      // [max_entries]
+    int32_t* seg_of = nullptr;    // [max_entries]
+    int32_t* counters = nullptr;  // [4]: 0 = U (distinct ids), 1 = total grouped entries
+    float* gemb = nullptr;        // [max_entries, K] compact gradient rows
+    float* glin = nullptr;        // [max_entries]
+};
+inline int64_t group_capacity(const Group* g) { return g->max_entries; }
+
+int group_create(int64_t rows, int64_t max_entries, int K, Group** out);
+int group_destroy(Group* g);
+int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st);
+int embed_scatter_bwd(Group* g, const float* dE, int de_ld, const float* e, int e_ld, const float* S,
+                      const float* coef, const float* dy, const float* vals, int B, int F, int K, int mode,
+                      float* gemb, float* glin, hipStream_t st);
+
+// ---- K2 (gather.hip)
+int embed_gather_fwd(const float* emb, const float* lin, int64_t rows, const int32_t* ids, const float* vals,
+                     int B, int F, int K, int mode, float* e, int e_ld, float* yw, float* sum, float* red,
+                     int32_t* status, hipStream_t st);
+
+// ---- K6 (gemm.hip)
+int fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N,
+           int relu, float keep, const uint64_t* seed_ptr, uint64_t seed, hipStream_t st);
+int fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int K, int N,
+                const float* act, int ldact, float keep_prev, hipStream_t st);
+int fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int lddy, float* dw_part, int64_t dw_stride,
+                            float* db_part, int64_t db_stride, int M, int K, int N, int splits, hipStream_t st);
+int sum_partials(const float* part, int64_t stride, int splits, int64_t n, float* out, hipStream_t st);
+int choose_wgrad_splits(int M, int K, int N);
+
+// ---- dense_ops.hip
+int rowdot(const float* x, int ldx, const float* w, const float* bias, int M, int n, float* y, int accumulate,
+           hipStream_t st);
+int rank1_bwd(const float* dy, const float* w, int M, int n, const float* act, int ldact, float keep, float* dx,
+              int lddx, int accumulate, hipStream_t st);
+int colsum_partials(const float* Y, int ldy, const float* rs, int M, int N, int splits, float* out,
+                    int64_t split_stride, hipStream_t st);
+int loss_head(const float* bias, const float* yw, const float* yv, const float* yd, const float* labels, int B,
+              float inv_batch, float* y, float* prob, float* dy, float* loss_sum, hipStream_t st);
+int opt_dense_arena(int kind, const Hyper* hdev, const Hyper& hval, float* theta, float* s0, float* s1,
+                    const float* parts, const OptBlockMeta* meta, int n_blocks, float* gout, int apply, float* sumsq,
+                    hipStream_t st);
+int opt_dense_flat(int kind, const Hyper* hdev, const Hyper& hval, float* theta, float* s0, float* s1, const float* grad,
+                   int n_part, int64_t part_stride, int64_t n, float l2, hipStream_t st);
+int opt_table(int kind, const Hyper* hdev, const Hyper& hval, int table_mode, int64_t rows, int K, float* emb, float* e0,
+              float* e1, float* lin, float* l0, float* l1, const int32_t* slot, const int32_t* uniq,
+              const int32_t* counters, int64_t max_entries, const float* gemb, const float* glin, float l2,
+              float* sumsq_emb, float* sumsq_lin, hipStream_t st);
+int step_state_advance(StepState* s, hipStream_t st);
+
+// ---- interact.hip
+int pnn_inner_fwd(const float* e, int e_ld, int B, int F, int K, float* ip, int ip_ld, hipStream_t st);
+int pnn_inner_bwd(const float* e, int e_ld, const float* dip, int dip_ld, int B, int F, int K, float* dE, int de_ld,
+                  hipStream_t st);
+int pnn_outer_fwd(const float* e, int e_ld, int B, int F, int K, float* op, int64_t op_ld, hipStream_t st);
+int pnn_outer_bwd(const float* e, int e_ld, const float* dop, int64_t dop_ld, int B, int F, int K, float* dE, int de_ld,
+                  hipStream_t st);
+int dcn_cross_fwd(const float* x0, int x0_ld, const float* w, const float* b, int B, int D, int L, float* xs,
+                  float* xlw, hipStream_t st);
+int dcn_cross_bwd(const float* xs, const float* xlw, const float* w, const float* dxL, int dxl_ld, int B, int D, int L,
+                  float* dx0, int dx0_ld, float* dw_part, float* db_part, int splits, int64_t part_stride,
+                  float* scratch, hipStream_t st);
+
+}  // namespace dctr

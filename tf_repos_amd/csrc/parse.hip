@@ -1,0 +1,156 @@
+// K1: libsvm text -> (ids i32 [n,F], vals f32 [n,F], labels f32 [n]).  Host code, re-entrant.
+// Replaces decode_libsvm (DeepFM.py:65-81; identical in DCN.py:68-84, PNN.py:67-83, NFM.py:65-76, AFM.py:64-80):
+//   string_split([line], ' ')          -> tokens, empty tokens dropped (skip_empty=True) [TF-1.4]
+//   string_to_number(token0, float32)  -> label
+//   string_split(tokens[1:], ':')      -> [F,2] strings
+//   string_to_number(col0, int32) / string_to_number(col1, float32)
+// string_to_number(float32) is a correctly rounded decimal->binary32 conversion.  Fast path: a plain decimal
+// with mantissa n < 2^29 and k <= 22 fractional digits converts as (float)((double)n / 10^k), which is
+// correctly rounded (the double quotient's 2^-53 relative error cannot cross a binary32 rounding boundary
+// for n < 2^29 -- see DESIGN.md "parser"); everything else goes through glibc strtof.
+#include <cerrno>
+#include <cstdlib>
+
+#include "common.h"
+
+namespace {
+
+const double kPow10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11,
+                           1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+// parses [p,e) completely as a float; returns false on malformed input
+bool parse_f32(const char* p, const char* e, float* out) {
+    if (p >= e) return false;
+    const char* q = p;
+    bool neg = false;
+    if (*q == '-' || *q == '+') { neg = (*q == '-'); ++q; }
+    uint64_t n = 0;
+    int digits = 0, frac = 0;
+    bool fast = true, any = false;
+    const char* r = q;
+    for (; r < e && *r >= '0' && *r <= '9'; ++r) { n = n * 10 + (uint64_t)(*r - '0'); ++digits; any = true; if (n >= (1ull << 29)) fast = false; if (digits > 18) break; }
+    if (r < e && *r == '.') {
+        ++r;
+        for (; r < e && *r >= '0' && *r <= '9'; ++r) { n = n * 10 + (uint64_t)(*r - '0'); ++digits; ++frac; any = true; if (n >= (1ull << 29)) fast = false; if (digits > 18) break; }
+    }
+    if (fast && any && r == e && frac <= 22) {
+        const double v = (double)n / kPow10[frac];
+        *out = (float)(neg ? -v : v);
+        return true;
+    }
+    // general path (exponents, inf/nan, long mantissas): glibc strtof on a NUL-terminated copy
+    char buf[128];
+    const size_t len = (size_t)(e - p);
+    if (len >= sizeof(buf)) return false;
+    memcpy(buf, p, len);
+    buf[len] = 0;
+    char* end = nullptr;
+    errno = 0;
+    const float v = strtof(buf, &end);
+    if (end != buf + len || end == buf) return false;
+    // TF's StringToNumber (strings::safe_strtof) rejects leading whitespace-only / trailing junk; accepts inf/nan
+    *out = v;
+    return true;
+}
+
+bool parse_i32(const char* p, const char* e, int32_t* out) {
+    if (p >= e) return false;
+    bool neg = false;
+    if (*p == '-' || *p == '+') { neg = (*p == '-'); ++p; }
+    if (p >= e) return false;
+    int64_t v = 0;
+    for (; p < e; ++p) {
+        if (*p < '0' || *p > '9') return false;
+        v = v * 10 + (*p - '0');
+        if (v > (int64_t)1 << 32) return false;
+    }
+    if (neg) v = -v;
+    if (v < INT32_MIN || v > INT32_MAX) return false;
+    *out = (int32_t)v;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int dctr_parse_libsvm(const char* h_text, size_t nbytes, int field_size, int64_t max_rows, int32_t* h_ids,
+                                 float* h_vals, float* h_labels, int64_t* n_rows, size_t* n_consumed) {
+    using namespace dctr;
+    DCTR_REQUIRE(h_text != nullptr && h_ids != nullptr && h_vals != nullptr && h_labels != nullptr && n_rows != nullptr,
+                 "null argument");
+    DCTR_REQUIRE(field_size > 0, "field_size must be > 0");
+    const char* p = h_text;
+    const char* end = h_text + nbytes;
+    int64_t row = 0;
+    size_t consumed = 0;
+    int64_t line_no = 0;
+    while (p < end && row < max_rows) {
+        const char* eol = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+        const char* le = eol ? eol : end;
+        const char* next = eol ? eol + 1 : end;
+        ++line_no;
+        const char* q = p;
+        if (le > q && le[-1] == '\r') --le;
+        // token 0: label
+        while (q < le && *q == ' ') ++q;
+        if (q == le) { p = next; consumed = (size_t)(p - h_text); continue; }   // empty line: TextLineDataset yields "", skipped here
+        const char* t = q;
+        while (q < le && *q != ' ') ++q;
+        float label;
+        if (!parse_f32(t, q, &label)) {
+            set_error("StringToNumberOp could not correctly convert string: %.*s (line %lld, label)", (int)(q - t), t, (long long)line_no);
+            return DCTR_ERR_PARSE;
+        }
+        int f = 0;
+        int32_t* ir = h_ids + (size_t)row * field_size;
+        float* vr = h_vals + (size_t)row * field_size;
+        while (true) {
+            while (q < le && *q == ' ') ++q;
+            if (q == le) break;
+            t = q;
+            while (q < le && *q != ' ') ++q;
+            // id:val with empty pieces dropped -> exactly two pieces
+            const char* a0 = t;
+            while (a0 < q && *a0 == ':') ++a0;
+            const char* a1 = a0;
+            while (a1 < q && *a1 != ':') ++a1;
+            const char* b0 = a1;
+            while (b0 < q && *b0 == ':') ++b0;
+            const char* b1 = b0;
+            while (b1 < q && *b1 != ':') ++b1;
+            const char* c0 = b1;
+            while (c0 < q && *c0 == ':') ++c0;
+            if (a0 == a1 || b0 == b1 || c0 != q) {
+                set_error("line %lld: token '%.*s' is not id:val (reshape of string_split(':') to [F,2] fails)", (long long)line_no,
+                          (int)(q - t), t);
+                return DCTR_ERR_PARSE;
+            }
+            if (f >= field_size) {
+                set_error("line %lld: more than field_size=%d id:val tokens (batch/reshape to [-1,%d] fails)", (long long)line_no,
+                          field_size, field_size);
+                return DCTR_ERR_PARSE;
+            }
+            if (!parse_i32(a0, a1, &ir[f])) {
+                set_error("StringToNumberOp could not correctly convert string: %.*s (line %lld, id)", (int)(a1 - a0), a0, (long long)line_no);
+                return DCTR_ERR_PARSE;
+            }
+            if (!parse_f32(b0, b1, &vr[f])) {
+                set_error("StringToNumberOp could not correctly convert string: %.*s (line %lld, value)", (int)(b1 - b0), b0, (long long)line_no);
+                return DCTR_ERR_PARSE;
+            }
+            ++f;
+        }
+        if (f != field_size) {
+            set_error("line %lld: %d id:val tokens, expected field_size=%d (batch/reshape to [-1,%d] fails)", (long long)line_no, f,
+                      field_size, field_size);
+            return DCTR_ERR_PARSE;
+        }
+        h_labels[row] = label;
+        ++row;
+        p = next;
+        consumed = (size_t)(p - h_text);
+    }
+    // swallow trailing blank lines so callers see end-of-input
+    *n_rows = row;
+    if (n_consumed) *n_consumed = consumed;
+    return DCTR_OK;
+}

@@ -1,0 +1,186 @@
+"""Python host for one engine handle (one GPU rank): thin, typed wrapper over the C ABI.
+
+Mirrors what tf.estimator holds for a `model_fn` (DeepFM.py:100-221): the variables, the
+optimizer slots, global_step, and the train / predict ops -- but every arithmetic op runs in
+libdeepctr_hip.so.  torch tensors are only device buffers whose raw pointers cross the ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import capi, errors
+
+
+@dataclass
+class EngineConfig:
+    """Field names follow the reference flags (DeepFM.py:34-60, DCN.py:52, AFM.py:52, PNN.py:61)."""
+    model: str = "deepfm"                      # deepfm | fnn | ipnn | opnn | nfm | dcn
+    field_size: int = 39
+    feature_size: int = 117581
+    embedding_size: int = 32
+    deep_layers: Sequence[int] = (256, 128, 64)
+    dropout: Sequence[float] = (0.5, 0.5, 0.5)  # TF keep_prob
+    cross_layers: int = 3
+    attention_layers: Sequence[int] = (256,)
+    l2_reg: float = 1e-4
+    learning_rate: float = 5e-4
+    optimizer: str = "Adam"
+    table_mode: str = "dense_exact"            # dense_exact (TF semantics) | touched_rows (lazy)
+    batch_norm: bool = False
+    batch_norm_decay: float = 0.9
+    max_batch: int = 4096
+    seed: int = 0
+    shard_rank: int = 0
+    shard_world: int = 1
+    use_graph: bool = True
+
+    def to_c(self) -> capi.Config:
+        if self.model not in capi.MODELS:
+            raise errors.InvalidArgumentError("unknown model %r" % self.model)
+        if self.optimizer not in capi.OPTIMIZERS:
+            # '--optimizer=GD' leaves `optimizer` unbound in the reference (DeepFM.py:204-213)
+            raise NameError("name 'optimizer' is not defined (optimizer=%r)" % self.optimizer)
+        c = capi.Config()
+        c.model = capi.MODELS[self.model]
+        c.field_size = self.field_size
+        c.embedding_size = self.embedding_size
+        c.feature_size = self.feature_size
+        layers = list(self.deep_layers)
+        keep = list(self.dropout)
+        if len(layers) > capi.MAX_LAYERS:
+            raise errors.InvalidArgumentError("at most %d deep layers" % capi.MAX_LAYERS)
+        c.n_deep_layers = len(layers)
+        for i, h in enumerate(layers):
+            c.deep_layers[i] = int(h)
+            c.keep_prob[i] = float(keep[i]) if i < len(keep) else 1.0
+        c.cross_layers = self.cross_layers
+        att = list(self.attention_layers)
+        c.n_attention_layers = len(att)
+        for i, a in enumerate(att[:capi.MAX_LAYERS]):
+            c.attention_layers[i] = int(a)
+        c.l2_reg = self.l2_reg
+        c.learning_rate = self.learning_rate
+        c.optimizer = capi.OPTIMIZERS[self.optimizer]
+        c.table_mode = capi.TABLE_MODES[self.table_mode]
+        c.batch_norm = int(self.batch_norm)
+        c.batch_norm_decay = self.batch_norm_decay
+        c.max_batch = self.max_batch
+        c.seed = self.seed
+        c.shard_rank = self.shard_rank
+        c.shard_world = self.shard_world
+        c.use_graph = int(self.use_graph)
+        return c
+
+
+class Engine:
+    def __init__(self, cfg: EngineConfig):
+        self.cfg = cfg
+        self._lib = capi.lib()
+        self._h = C.c_void_p()
+        ccfg = cfg.to_c()
+        capi.check(self._lib.dctr_create(C.byref(ccfg), C.byref(self._h)))
+        self._shapes = self._query_shapes()
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.dctr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- variables ---------------------------------------------------------------------------
+    def _query_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        n = C.c_int()
+        capi.check(self._lib.dctr_param_count(self._h, C.byref(n)))
+        out = {}
+        for i in range(n.value):
+            name = C.c_char_p()
+            rank = C.c_int()
+            dims = (C.c_int64 * 4)()
+            capi.check(self._lib.dctr_param_info(self._h, i, C.byref(name), C.byref(rank), C.byref(dims)))
+            out[name.value.decode()] = tuple(int(dims[k]) for k in range(rank.value))
+        return out
+
+    @property
+    def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        return dict(self._shapes)
+
+    def set_param(self, name: str, value) -> None:
+        a = np.ascontiguousarray(np.asarray(value, dtype=np.float32))
+        if tuple(a.shape) != self._shapes.get(name, None):
+            raise errors.InvalidArgumentError("shape mismatch for %s: %s vs %s" % (name, a.shape, self._shapes.get(name)))
+        capi.check(self._lib.dctr_param_set(self._h, name.encode(), capi.ptr(a), a.nbytes))
+
+    def get_param(self, name: str) -> np.ndarray:
+        a = np.empty(self._shapes[name], dtype=np.float32)
+        capi.check(self._lib.dctr_param_get(self._h, name.encode(), capi.ptr(a), a.nbytes))
+        return a
+
+    def set_params(self, params: Dict[str, "np.ndarray"]) -> None:
+        for k, v in params.items():
+            self.set_param(k, v.detach().cpu().numpy() if hasattr(v, "detach") else v)
+
+    def get_params(self) -> Dict[str, np.ndarray]:
+        return {k: self.get_param(k) for k in self._shapes}
+
+    def get_slot(self, name: str, which: int) -> np.ndarray:
+        a = np.empty(self._shapes[name], dtype=np.float32)
+        capi.check(self._lib.dctr_slot_get(self._h, name.encode(), which, capi.ptr(a), a.nbytes))
+        return a
+
+    def set_slot(self, name: str, which: int, value) -> None:
+        a = np.ascontiguousarray(np.asarray(value, dtype=np.float32))
+        capi.check(self._lib.dctr_slot_set(self._h, name.encode(), which, capi.ptr(a), a.nbytes))
+
+    @property
+    def global_step(self) -> int:
+        s = C.c_int64()
+        capi.check(self._lib.dctr_get_global_step(self._h, C.byref(s)))
+        return s.value
+
+    @global_step.setter
+    def global_step(self, v: int) -> None:
+        capi.check(self._lib.dctr_set_global_step(self._h, int(v)))
+
+    # -- ops ---------------------------------------------------------------------------------
+    def train_step(self, ids, vals, labels, want_loss: bool = True, stream=None) -> Optional[float]:
+        """ids int32 [B,F], vals f32 [B,F], labels f32 [B]: CUDA(HIP) torch tensors."""
+        B = int(labels.shape[0])
+        loss = C.c_float()
+        st = stream if stream is not None else capi.current_stream()
+        capi.check(self._lib.dctr_train_step(self._h, capi.ptr(ids), capi.ptr(vals), capi.ptr(labels), B,
+                                             C.byref(loss) if want_loss else None, st))
+        return loss.value if want_loss else None
+
+    def predict(self, ids, vals, out_prob=None, out_logit=None, stream=None):
+        B = int(ids.shape[0])
+        st = stream if stream is not None else capi.current_stream()
+        capi.check(self._lib.dctr_predict(self._h, capi.ptr(ids), capi.ptr(vals), B, capi.ptr(out_prob),
+                                          capi.ptr(out_logit), st))
+        return out_prob
+
+    def check_ids(self, stream=None) -> None:
+        st = stream if stream is not None else capi.current_stream()
+        capi.check(self._lib.dctr_check_ids(self._h, st))
+
+    def debug_tensor(self, name: str):
+        """Device view (torch) of a named intermediate of the last forward."""
+        import torch
+        p = C.c_void_p()
+        n = C.c_int64()
+        ld = C.c_int()
+        capi.check(self._lib.dctr_debug_tensor(self._h, name.encode(), C.byref(p), C.byref(n), C.byref(ld)))
+        host = np.empty(n.value, dtype=np.float32)
+        capi.check(self._lib.dctr_memcpy_d2h(capi.ptr(host), p, host.nbytes, None))
+        if ld.value > 1:
+            host = host.reshape(-1, ld.value)
+        return torch.from_numpy(host)
