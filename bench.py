@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""bench.py -- examples/sec of the DeepFM training step (BASELINE.json metric) on N MI355X GPUs of one node.
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], SURVEY 8d "c2"): DeepFM, 39 fields, vocab 1e6, emb_dim 16, batch 4096 per GPU
+(weak scaling), MLP 400-400-400 with keep_prob 0.5, Adam lr 5e-4, l2_reg 1e-4 (deep_ctr/README.md:49), f32 arithmetic,
+synthetic Criteo-shaped libsvm-equivalent tensors already resident in HBM, random-init N(0,0.01) weights.
+A "step" = forward + loss + backward + optimizer over one batch, table optimizer in DENSE-EXACT mode (what the
+reference's TF graph does: l2_loss on the tables makes the optimizer stream all V rows every step).
+Prints ONE JSON line (rank 0).  The `roofline` object is for the kernel that dominates the step; `cpu_baseline` is the
+torch-CPU restatement of the reference's TF-1.4 graph (oracle/, "port") timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F32_PEAK_TFS = 157.3  # f32-input MFMA peak
+
+WORKLOAD = dict(model="deepfm", field_size=39, feature_size=1_000_000, embedding_size=16, batch=4096,
+                deep_layers=(400, 400, 400), dropout=(0.5, 0.5, 0.5), l2_reg=1e-4, learning_rate=5e-4, optimizer="Adam")
+
+
+def cpu_baseline(w, seconds_budget=20.0):
+    """The oracle (torch-CPU restatement of the TF-1.4 graph, NOT TF) timed on the host cores: same model, same batch
+    shape, dense Adam over the full tables, on a bounded number of steps."""
+    import torch
+    from oracle import deepctr_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.Config(model=w["model"], field_size=w["field_size"], feature_size=w["feature_size"],
+                   embedding_size=w["embedding_size"], deep_layers=w["deep_layers"], dropout=w["dropout"],
+                   l2_reg=w["l2_reg"], learning_rate=w["learning_rate"], optimizer=w["optimizer"])
+    p = O.init_params(cfg, seed=1, scale=0.01)
+    opt = O.Optimizer(cfg, p)
+    B = w["batch"]
+    batches = [O.synth_batch(B, cfg.field_size, cfg.feature_size, seed=20260924 + i) for i in range(4)]
+    for i in range(2):
+        O.train_step(cfg, p, opt, *batches[i % 4])
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        O.train_step(cfg, p, opt, *batches[n % 4])
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 400:
+            break
+    return {"value": round(B * n / el, 1), "unit": "examples/sec", "cores": cores, "kind": "port",
+            "sample": "%d train steps of the same workload (batch %d) after 2 warm-up steps, torch-CPU fp32 restatement "
+                      "of the TF-1.4 graph (dense table gradient + dense Adam), %d threads" % (n, B, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--table-mode", default="dense_exact", choices=["dense_exact", "touched_rows"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--uniform-ids", action="store_true", help="uniform ids instead of Zipf (cache-worst case)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from tf_repos_amd.engine import Engine, EngineConfig
+    from tf_repos_amd.synth import synth_batch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    w = dict(WORKLOAD)
+    B = w["batch"]
+
+    if world > 1:
+        import torch.distributed as dist
+        from tf_repos_amd.distributed import ShardedTrainer
+        dist.init_process_group("nccl", device_id=dev)
+        trainer = ShardedTrainer(w, rank, world, dev, table_mode=args.table_mode)
+        step = trainer.train_step
+        barrier = dist.barrier
+    else:
+        eng = Engine(EngineConfig(model=w["model"], field_size=w["field_size"], feature_size=w["feature_size"],
+                                  embedding_size=w["embedding_size"], deep_layers=w["deep_layers"], dropout=w["dropout"],
+                                  l2_reg=w["l2_reg"], learning_rate=w["learning_rate"], optimizer=w["optimizer"],
+                                  table_mode=args.table_mode, max_batch=B, seed=1))
+        rng = np.random.default_rng(1)
+        for name, shp in eng.param_shapes.items():
+            eng.set_param(name, rng.normal(0, 0.01, size=shp).astype(np.float32))
+        step = lambda i, v, l: eng.train_step(i, v, l, want_loss=False)
+        barrier = lambda: None
+
+    nb = 8
+    batches = []
+    for i in range(nb):
+        ids, vals, labels = synth_batch(B, w["field_size"], w["feature_size"], seed=20260924 + 1 + rank * 1000 + i,
+                                        uniform_ids=args.uniform_ids)
+        batches.append((torch.from_numpy(ids).to(dev), torch.from_numpy(vals).to(dev), torch.from_numpy(labels).to(dev)))
+
+    for s in range(args.warmup):
+        step(*batches[s % nb])
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(*batches[s % nb])
+    barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "examples/sec DeepFM Criteo-39-field batch 4096", "value": round(B * world * args.steps / el, 1),
+            "unit": "examples/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * el / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic Criteo-shaped (Zipf categorical ids), random-init weights",
+            "config": {"workload": "DeepFM 39 fields, vocab 1e6, emb_dim 16, batch 4096/GPU, MLP 400-400-400 keep 0.5, Adam "
+                                   "(BASELINE configs[1])", "global_batch": B * world, "table_mode": args.table_mode,
+                       "parallelism": "single GPU" if world == 1 else "row-sharded tables (id %% %d) + data-parallel dense" % world,
+                       "ids": "uniform" if args.uniform_ids else "zipf"},
+        }
+    if world == 1:
+        # ---- per-stage timing (hipEvents around a graph of back-to-back launches, on torch's current stream)
+        F, K, V = w["field_size"], w["embedding_size"], w["feature_size"]
+        stages = {}
+        for name in ["embed_gather", "forward", "head", "backward_dense", "group_ids", "scatter", "opt_table", "opt_dense",
+                     "mlp0_fwd", "mlp0_dgrad", "mlp0_wgrad", "train_step"]:
+            stages[name] = eng.time_stage(name, iters=30)
+        gather_bytes = B * (F * (12 + 8 * K) + 8)                 # algorithmic bytes of the gather
+        table_bytes = 7 * V * (K + 1) * 4 + 4 * V                  # theta,m,v read + write, grad read, + slot word
+        mlp0_flops = 2.0 * B * (F * K) * w["deep_layers"][0]
+        kernels = {
+            "embed_gather_fwd": {"bound": "hbm", "ms": stages["embed_gather"], "achieved": gather_bytes / stages["embed_gather"] / 1e6,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+            "opt_table_dense_adam": {"bound": "hbm", "ms": stages["opt_table"], "achieved": table_bytes / stages["opt_table"] / 1e6,
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+            "mlp0_fwd_gemm": {"bound": "mfma", "ms": stages["mlp0_fwd"], "achieved": mlp0_flops / stages["mlp0_fwd"] / 1e9,
+                              "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s"},
+            "mlp0_dgrad_gemm": {"bound": "mfma", "ms": stages["mlp0_dgrad"], "achieved": mlp0_flops / stages["mlp0_dgrad"] / 1e9,
+                                "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s"},
+            "mlp0_wgrad_gemm": {"bound": "mfma", "ms": stages["mlp0_wgrad"], "achieved": mlp0_flops / stages["mlp0_wgrad"] / 1e9,
+                                "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s"},
+        }
+        for k in kernels.values():
+            k["frac"] = round(k["achieved"] / k["peak"], 4)
+            k["achieved"] = round(k["achieved"], 2)
+            k["ms"] = round(k["ms"], 5)
+        dom = "opt_table_dense_adam" if args.table_mode == "dense_exact" else "mlp0_fwd_gemm"
+        r = dict(kernels[dom])
+        r["kernel"] = dom
+        r["traffic"] = None
+        out["roofline"] = r
+        out["kernels"] = kernels
+        out["stage_ms"] = {k: round(v, 5) for k, v in stages.items()}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w)
+            out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -96,6 +96,7 @@ _SIGS = {
     "dctr_train_step": ([_P, _P, _P, _P, C.c_int, C.POINTER(C.c_float), _P], C.c_int),
     "dctr_predict": ([_P, _P, _P, C.c_int, _P, _P, _P], C.c_int),
     "dctr_check_ids": ([_P, _P], C.c_int),
+    "dctr_time_kernel": ([_P, C.c_char_p, C.c_int, C.POINTER(C.c_float), _P], C.c_int),
     "dctr_debug_tensor": ([_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int)], C.c_int),
 }
 

@@ -82,11 +82,84 @@ __global__ __launch_bounds__(256) void colsum_scaled_kernel(const float* __restr
     }
 }
 
+// float4 variant: 16 column groups (64 columns) x 16 row lanes per block, LDS reduction over the row lanes
+__global__ __launch_bounds__(256) void colsum_scaled_v4_kernel(const float* __restrict__ Y, int ldy, const float* __restrict__ rs,
+                                                              int M, int N, int rows_per_split, float* __restrict__ out,
+                                                              int64_t split_stride) {
+    __shared__ float4 red[16][17];
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cg * 4;
+    const int rbeg = blockIdx.y * rows_per_split, rend = min(M, rbeg + rows_per_split);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < N) {     // N % 4 == 0 on this path
+        for (int r = rbeg + rl; r < rend; r += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(Y + (size_t)r * ldy + c);
+            const float k = rs ? rs[r] : 1.0f;
+            s.x += k * v.x; s.y += k * v.y; s.z += k * v.z; s.w += k * v.w;
+        }
+    }
+    red[rl][cg] = s;
+    __syncthreads();
+    if (rl == 0 && c < N) {
+        float4 a = red[0][cg];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) { const float4 b = red[j][cg]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        *reinterpret_cast<float4*>(out + (size_t)blockIdx.y * split_stride + c) = a;
+    }
+}
+
 int colsum_partials(const float* Y, int ldy, const float* rs, int M, int N, int splits, float* out,
                     int64_t split_stride, hipStream_t st) {
     if (N <= 0) return DCTR_OK;
     dim3 grid(ceil_div(N, 64), splits), block(256);
-    colsum_scaled_kernel<<<grid, block, 0, st>>>(Y, ldy, rs, M, N, ceil_div(M, splits), out, split_stride);
+    const bool v4 = (N % 4 == 0) && (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && (split_stride % 4 == 0);
+    if (v4) colsum_scaled_v4_kernel<<<grid, block, 0, st>>>(Y, ldy, rs, M, N, ceil_div(M, splits), out, split_stride);
+    else colsum_scaled_kernel<<<grid, block, 0, st>>>(Y, ldy, rs, M, N, ceil_div(M, splits), out, split_stride);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+// ---- backward of a [n] -> 1 output layer in ONE pass over its input x [M,n]:
+//   dx[r,c]      = dy[r] * w[c]            (optionally masked by the producing ReLU/dropout: (x>0)/keep)
+//   dw_part[s,c] = sum_{r in block s} dy[r] * x[r,c]
+//   db_part[s]   = sum_{r in block s} dy[r]            (if requested)
+// grid = S row blocks; the optimizer kernel sums the S partial slabs.
+__global__ __launch_bounds__(256) void out_layer_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy,
+                                                           const float* __restrict__ w, int M, int n, int rows_per_block,
+                                                           int masked, float inv_keep, float* __restrict__ dx, int lddx,
+                                                           float* __restrict__ dw_part, int64_t dw_stride,
+                                                           float* __restrict__ db_part, int64_t db_stride) {
+    const int rbeg = blockIdx.x * rows_per_block, rend = min(M, rbeg + rows_per_block);
+    for (int c = threadIdx.x; c < n; c += 256) {
+        const float wc = w[c];
+        float acc = 0.f;
+        for (int r = rbeg; r < rend; ++r) {
+            const float d = dy[r];
+            const float xv = x[(size_t)r * ldx + c];
+            acc += d * xv;
+            if (dx != nullptr) {
+                float g = d * wc;
+                if (masked) g = xv > 0.f ? g * inv_keep : 0.f;
+                dx[(size_t)r * lddx + c] = g;
+            }
+        }
+        dw_part[(size_t)blockIdx.x * dw_stride + c] = acc;
+    }
+    if (db_part != nullptr && threadIdx.x < 64) {
+        float s = 0.f;
+        for (int r = rbeg + threadIdx.x; r < rend; r += 64) s += dy[r];
+        s = wave_sum(s);
+        if (threadIdx.x == 0) db_part[(size_t)blockIdx.x * db_stride] = s;
+    }
+}
+
+int out_layer_bwd(const float* x, int ldx, const float* dy, const float* w, int M, int n, int splits, int masked,
+                  float keep, float* dx, int lddx, float* dw_part, int64_t dw_stride, float* db_part, int64_t db_stride,
+                  hipStream_t st) {
+    if (M <= 0 || n <= 0) return DCTR_OK;
+    out_layer_bwd_kernel<<<splits, 256, 0, st>>>(x, ldx, dy, w, M, n, ceil_div(M, splits), masked, 1.0f / keep, dx, lddx,
+                                                  dw_part, dw_stride, db_part, db_stride);
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }
@@ -254,15 +327,18 @@ int opt_dense_flat(int kind, const Hyper* hdev, const Hyper& hval, float* theta,
 // IndexedSlices gradient meets the dense l2_loss gradient (DeepFM.py:189-190,213).  Also accumulates
 // sum(theta_old^2) so the l2 part of the reported loss is free.  TOUCHED: only rows uniq[0:U).
 template <int KIND, int KQ, bool DENSE>
-__global__ __launch_bounds__(256) void opt_table_emb_kernel(const Hyper* __restrict__ hdev, Hyper hval, int64_t rows,
-                                                           float4* __restrict__ emb, float4* __restrict__ s0,
-                                                           float4* __restrict__ s1, const int32_t* __restrict__ slot,
-                                                           const int32_t* __restrict__ uniq, const int32_t* __restrict__ counters,
-                                                           const float4* __restrict__ gemb, float l2,
-                                                           float* __restrict__ sumsq) {
+__global__ __launch_bounds__(256) void opt_table_kernel(const Hyper* __restrict__ hdev, Hyper hval, int64_t rows,
+                                                       float4* __restrict__ emb, float4* __restrict__ s0,
+                                                       float4* __restrict__ s1, float* __restrict__ lin,
+                                                       float* __restrict__ l0, float* __restrict__ l1,
+                                                       const int32_t* __restrict__ slot, const int32_t* __restrict__ uniq,
+                                                       const int32_t* __restrict__ counters, const float4* __restrict__ gemb,
+                                                       const float* __restrict__ glin, float l2, float* __restrict__ sumsq_emb,
+                                                       float* __restrict__ sumsq_lin) {
+    // KQ lanes per row (one float4 each); lane kq == 0 also steps the row's linear weight (same slot word, one launch)
     const Hyper h = load_hyper(hdev, hval);
     const int64_t n_items = DENSE ? rows : (int64_t)counters[0];
-    float sq = 0.f;
+    float sq = 0.f, sql = 0.f;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_items * KQ;
          t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t item = t / KQ;
@@ -272,14 +348,14 @@ __global__ __launch_bounds__(256) void opt_table_emb_kernel(const Hyper* __restr
         if (DENSE) { r = item; u = slot[r] - 1; } else { u = (int)item; r = uniq[u]; }
         const size_t i4 = (size_t)r * KQ + kq;
         float4 th = emb[i4];
+        float4 a = s0[i4];
+        float4 b = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) ? s1[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
         sq += th.x * th.x + th.y * th.y + th.z * th.z + th.w * th.w;
         float4 g = make_float4(l2 * th.x, l2 * th.y, l2 * th.z, l2 * th.w);
         if (u >= 0) {
             const float4 q = gemb[(size_t)u * KQ + kq];
             g.x += q.x; g.y += q.y; g.z += q.z; g.w += q.w;
         }
-        float4 a = s0[i4];
-        float4 b = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) ? s1[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
         opt_update(KIND, h, th.x, a.x, b.x, g.x);
         opt_update(KIND, h, th.y, a.y, b.y, g.y);
         opt_update(KIND, h, th.z, a.z, b.z, g.z);
@@ -287,48 +363,29 @@ __global__ __launch_bounds__(256) void opt_table_emb_kernel(const Hyper* __restr
         emb[i4] = th;
         s0[i4] = a;
         if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) s1[i4] = b;
+        if (kq == 0 && lin != nullptr) {
+            float lt = lin[r];
+            float la = l0[r];
+            float lb = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) ? l1[r] : 0.f;
+            sql += lt * lt;
+            float lg = l2 * lt;
+            if (u >= 0) lg += glin[u];
+            opt_update(KIND, h, lt, la, lb, lg);
+            lin[r] = lt;
+            l0[r] = la;
+            if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) l1[r] = lb;
+        }
     }
-    if (sumsq != nullptr) {
-        __shared__ float red[4];
+    if (sumsq_emb != nullptr) {
+        __shared__ float red[2][4];
         sq = wave_sum(sq);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+        sql = wave_sum(sql);
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sq; red[1][threadIdx.x >> 6] = sql; }
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(sumsq, red[0] + red[1] + red[2] + red[3]);
-    }
-}
-
-template <int KIND, bool DENSE>
-__global__ __launch_bounds__(256) void opt_table_lin_kernel(const Hyper* __restrict__ hdev, Hyper hval, int64_t rows,
-                                                           float* __restrict__ lin, float* __restrict__ s0,
-                                                           float* __restrict__ s1, const int32_t* __restrict__ slot,
-                                                           const int32_t* __restrict__ uniq, const int32_t* __restrict__ counters,
-                                                           const float* __restrict__ glin, float l2,
-                                                           float* __restrict__ sumsq) {
-    const Hyper h = load_hyper(hdev, hval);
-    const int64_t n_items = DENSE ? rows : (int64_t)counters[0];
-    float sq = 0.f;
-    for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < n_items;
-         item += (int64_t)gridDim.x * blockDim.x) {
-        int64_t r;
-        int u;
-        if (DENSE) { r = item; u = slot[r] - 1; } else { u = (int)item; r = uniq[u]; }
-        float th = lin[r];
-        sq += th * th;
-        float g = l2 * th;
-        if (u >= 0) g += glin[u];
-        float a = s0[r];
-        float b = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) ? s1[r] : 0.f;
-        opt_update(KIND, h, th, a, b, g);
-        lin[r] = th;
-        s0[r] = a;
-        if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) s1[r] = b;
-    }
-    if (sumsq != nullptr) {
-        __shared__ float red[4];
-        sq = wave_sum(sq);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
-        __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(sumsq, red[0] + red[1] + red[2] + red[3]);
+        if (threadIdx.x == 0) {
+            atomicAdd(sumsq_emb, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+            if (sumsq_lin != nullptr) atomicAdd(sumsq_lin, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        }
     }
 }
 
@@ -345,14 +402,10 @@ static int launch_table(const Hyper* hdev, const Hyper& hval, int64_t rows, int 
     float4* b4 = reinterpret_cast<float4*>(e1);
     const float4* g4 = reinterpret_cast<const float4*>(gemb);
     switch (KQ) {
-#define DCTR_T(Q) case Q: opt_table_emb_kernel<KIND, Q, DENSE><<<grid, 256, 0, st>>>(hdev, hval, rows, e4, a4, b4, slot, uniq, counters, g4, l2, sumsq_emb); break
+#define DCTR_T(Q) case Q: opt_table_kernel<KIND, Q, DENSE><<<grid, 256, 0, st>>>(hdev, hval, rows, e4, a4, b4, lin, l0, l1, slot, uniq, counters, g4, glin, l2, sumsq_emb, sumsq_lin); break
         DCTR_T(1); DCTR_T(2); DCTR_T(4); DCTR_T(8); DCTR_T(16); DCTR_T(32); DCTR_T(64);
 #undef DCTR_T
         default: set_error("opt_table: K=%d unsupported", K); return DCTR_ERR_UNSUPPORTED;
-    }
-    if (lin != nullptr) {
-        const int gl = (int)std::min<int64_t>(ceil_div(items, 256), 256 * 8);
-        opt_table_lin_kernel<KIND, DENSE><<<gl, 256, 0, st>>>(hdev, hval, rows, lin, l0, l1, slot, uniq, counters, glin, l2, sumsq_lin);
     }
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;

@@ -53,7 +53,7 @@ struct dctr_engine {
     std::map<std::string, int> index;
     std::vector<Fc> mlp;
     int p_out_w = -1, p_out_b = -1, p_bias = -1, p_cross_w = -1, p_cross_b = -1;
-    int out_splits = 8;
+    int out_splits = 128;
 
     // tables
     float *emb = nullptr, *emb_s0 = nullptr, *emb_s1 = nullptr, *lin = nullptr, *lin_s0 = nullptr, *lin_s1 = nullptr;
@@ -80,6 +80,9 @@ struct dctr_engine {
     // graphs
     std::map<int, hipGraphExec_t> train_graphs, predict_graphs;
     int last_B = 0;
+    hipStream_t s_group = nullptr, s_wgrad = nullptr;   // side streams of the step DAG
+    std::vector<hipEvent_t> events;
+    size_t ev_next = 0;
 
     float* pp(int i) { return params[i].ptr; }
     float* part(int i) { return parts + params[i].part_off; }
@@ -156,8 +159,8 @@ int build(dctr_engine* E) {
 
     // ---- parameters (engine names, tf_repos_amd.checkpoint maps them to TF names)
     if (c.model == DCTR_MODEL_DCN) {
-        E->p_cross_b = add_param(E, "cross_b", {c.cross_layers, D}, false, 8, c.l2_reg);
-        E->p_cross_w = add_param(E, "cross_w", {c.cross_layers, D}, false, 8, c.l2_reg);
+        E->p_cross_b = add_param(E, "cross_b", {c.cross_layers, D}, false, 32, c.l2_reg);
+        E->p_cross_w = add_param(E, "cross_w", {c.cross_layers, D}, false, 32, c.l2_reg);
     } else {
         E->p_bias = add_param(E, "bias", {1}, false, E->out_splits, 0.f);
         add_param(E, "linear", {E->rows}, true, 1, c.l2_reg);
@@ -259,6 +262,11 @@ int build(dctr_engine* E) {
         DCTR_TRY(fill(E->as0, (size_t)E->arena_n));
     }
 
+    DCTR_HIP_CHECK(hipStreamCreateWithFlags(&E->s_group, hipStreamNonBlocking));
+    DCTR_HIP_CHECK(hipStreamCreateWithFlags(&E->s_wgrad, hipStreamNonBlocking));
+    E->events.resize(64);
+    for (auto& ev : E->events) DCTR_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+
     // ---- activations
     DCTR_TRY(dmalloc(&E->ids, (size_t)MB * F));
     DCTR_TRY(dmalloc(&E->vals, (size_t)MB * F));
@@ -340,7 +348,17 @@ int head(dctr_engine* E, int B, int global_batch, bool with_labels, hipStream_t 
 }
 
 // ---- backward through head + MLP + interaction: leaves dL/de in dx_in (or the BI coefficient for NFM) ----------
-int backward_dense(dctr_engine* E, int B, hipStream_t st) {
+// records "to waits for everything enqueued on from so far" (works eagerly and under stream capture)
+int fork(dctr_engine* E, hipStream_t from, hipStream_t to) {
+    if (from == to) return DCTR_OK;
+    hipEvent_t ev = E->events[E->ev_next++ % E->events.size()];
+    DCTR_HIP_CHECK(hipEventRecord(ev, from));
+    DCTR_HIP_CHECK(hipStreamWaitEvent(to, ev, 0));
+    return DCTR_OK;
+}
+
+// st: critical path (dgrad chain); sw: side stream for the weight gradients (independent of the dgrad chain)
+int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
     const dctr_config& c = E->cfg;
     const int F = E->F, K = E->K, D = E->D;
     const int H = E->mlp.back().out;
@@ -349,17 +367,15 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st) {
     const float* wout = E->pp(E->p_out_w);
     const Param& pw = E->params[E->p_out_w];
     const Param& pb = E->params[E->p_out_b];
-    // output layer: dW = h^T dy, db = sum dy   (also the global bias' gradient: aliased slabs)
-    DCTR_TRY(colsum_partials(E->dy, 1, nullptr, B, 1, pb.n_part, E->part(E->p_out_b), pb.padded, st));
+    // output layer in one pass over h_last: dh = dy (x) w (masked), dW = h^T dy, db = sum dy (also the global bias' gradient)
     if (c.model == DCTR_MODEL_DCN) {
         const float* xL = E->xs + (size_t)c.cross_layers * B * D;
-        DCTR_TRY(colsum_partials(xL, D, E->dy, B, D, pw.n_part, E->part(E->p_out_w), pw.padded, st));
-        DCTR_TRY(colsum_partials(E->h.back(), H, E->dy, B, H, pw.n_part, E->part(E->p_out_w) + D, pw.padded, st));
-        DCTR_TRY(rank1_bwd(E->dy, wout, B, D, nullptr, 0, 1.f, E->dxL, D, 0, st));
-        DCTR_TRY(rank1_bwd(E->dy, wout + D, B, H, E->h.back(), H, keep_last, E->dh.back(), H, 0, st));
+        DCTR_TRY(out_layer_bwd(xL, D, E->dy, wout, B, D, pw.n_part, 0, 1.f, E->dxL, D, E->part(E->p_out_w), pw.padded, nullptr, 0, st));
+        DCTR_TRY(out_layer_bwd(E->h.back(), H, E->dy, wout + D, B, H, pw.n_part, 1, keep_last, E->dh.back(), H,
+                               E->part(E->p_out_w) + D, pw.padded, E->part(E->p_out_b), pb.padded, st));
     } else {
-        DCTR_TRY(colsum_partials(E->h.back(), H, E->dy, B, H, pw.n_part, E->part(E->p_out_w), pw.padded, st));
-        DCTR_TRY(rank1_bwd(E->dy, wout, B, H, E->h.back(), H, keep_last, E->dh.back(), H, 0, st));
+        DCTR_TRY(out_layer_bwd(E->h.back(), H, E->dy, wout, B, H, pw.n_part, 1, keep_last, E->dh.back(), H, E->part(E->p_out_w),
+                               pw.padded, E->part(E->p_out_b), pb.padded, st));
     }
     for (int i = nl - 1; i >= 0; --i) {
         const Fc& fc = E->mlp[i];
@@ -367,8 +383,9 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st) {
         const int ldx = i > 0 ? E->mlp[i - 1].out : E->Din_ld;
         const Param& w = E->params[fc.w];
         const Param& b = E->params[fc.b];
+        DCTR_TRY(fork(E, st, sw));      // dh[i] is complete on st
         DCTR_TRY(fc_bwd_weights_partials(x, ldx, E->dh[i], fc.out, E->part(fc.w), w.padded, E->part(fc.b), b.padded, B, fc.in,
-                                         fc.out, fc.splits, st));
+                                         fc.out, fc.splits, sw));
         if (i > 0)
             DCTR_TRY(fc_bwd_data(E->dh[i], fc.out, E->pp(fc.w), E->dh[i - 1], E->mlp[i - 1].out, B, fc.in, fc.out, E->h[i - 1],
                                  E->mlp[i - 1].out, E->mlp[i - 1].keep, st));
@@ -387,11 +404,10 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st) {
     return DCTR_OK;
 }
 
-// ---- table side of the backward: group ids, segment-sum the row gradients, step the tables ------------------------
-int backward_tables(dctr_engine* E, int B, hipStream_t st) {
+// ---- table side of the backward: segment-sum the row gradients (ids already grouped), step the tables ------------
+int scatter_and_step_tables(dctr_engine* E, int B, hipStream_t st) {
     const dctr_config& c = E->cfg;
     const int mode = gather_mode(E);
-    DCTR_TRY(group_ids(E->group, E->ids, B, E->F, st));
     const float* dE = mode == DCTR_GATHER_BI ? nullptr : E->dx_in;
     const float* coef = mode == DCTR_GATHER_FM ? E->dy : (mode == DCTR_GATHER_BI ? E->dx_in : nullptr);
     DCTR_TRY(embed_scatter_bwd(E->group, dE, E->Din_ld, E->e, E->e_ld, E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F,
@@ -402,15 +418,25 @@ int backward_tables(dctr_engine* E, int B, hipStream_t st) {
     return DCTR_OK;
 }
 
+// The step as a small DAG over three streams (captured into one hipGraph):
+//   st : state -> gather -> MLP fwd -> head -> dgrad chain -> interaction bwd -> [join grouping] scatter -> table optimizer
+//   sg : grouping of the batch's ids (depends only on the inputs; hidden under the MLP)
+//   sw : weight gradients (each waits for its layer's dY) -> dense optimizer (runs beside scatter + table optimizer)
 int record_train(dctr_engine* E, int B, hipStream_t st) {
+    hipStream_t sg = E->s_group, sw = E->s_wgrad;
     DCTR_HIP_CHECK(hipMemsetAsync(E->scalars, 0, 8 * sizeof(float), st));
     DCTR_TRY(step_state_advance(E->state, st));
+    DCTR_TRY(fork(E, st, sg));
+    DCTR_TRY(group_ids(E->group, E->ids, B, E->F, sg));
     DCTR_TRY(forward(E, B, true, st));
     DCTR_TRY(head(E, B, B, true, st));
-    DCTR_TRY(backward_dense(E, B, st));
-    DCTR_TRY(backward_tables(E, B, st));
+    DCTR_TRY(backward_dense(E, B, st, sw));
+    DCTR_TRY(fork(E, st, sw));          // cross-network / output-layer partials are written on st
     DCTR_TRY(opt_dense_arena(E->cfg.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->parts, E->meta,
-                             E->n_blocks, nullptr, 1, E->scalars + 3, st));
+                             E->n_blocks, nullptr, 1, E->scalars + 3, sw));
+    DCTR_TRY(fork(E, sg, st));
+    DCTR_TRY(scatter_and_step_tables(E, B, st));
+    DCTR_TRY(fork(E, sw, st));
     return DCTR_OK;
 }
 
@@ -488,6 +514,9 @@ int dctr_destroy(dctr_handle E) {
     if (E->state) hipFree(E->state);
     if (E->meta) hipFree(E->meta);
     group_destroy(E->group);
+    for (auto& ev : E->events) if (ev) hipEventDestroy(ev);
+    if (E->s_group) hipStreamDestroy(E->s_group);
+    if (E->s_wgrad) hipStreamDestroy(E->s_wgrad);
     delete E;
     return DCTR_OK;
 }
@@ -618,6 +647,85 @@ int dctr_debug_tensor(dctr_handle E, const char* name, float** d_ptr, int64_t* n
     *d_ptr = p;
     if (n_elems) *n_elems = n;
     if (ld) *ld = l;
+    return DCTR_OK;
+}
+
+// Times one stage of the step on the engine's current buffers (last batch): `iters` back-to-back executions are
+// captured into a graph (so the host launch rate does not bound the measurement) and bracketed by two hipEvents
+// recorded on `stream`.  Stages mutate state exactly as a step does (the optimizer stages do update weights).
+int dctr_time_kernel(dctr_handle E, const char* kernel, int iters, float* h_ms_per_launch, void* stream) {
+    DCTR_REQUIRE(E && kernel && h_ms_per_launch && iters > 0, "bad argument");
+    DCTR_REQUIRE(E->last_B > 0, "run a train step first: stages are timed on the last batch's buffers");
+    hipStream_t st = as_stream(stream);
+    const int B = E->last_B;
+    const std::string s(kernel);
+    const dctr_config& c = E->cfg;
+    auto stage = [&](hipStream_t cs) -> int {
+        if (s == "embed_gather") {
+            const int mode = gather_mode(E);
+            float* red = mode == DCTR_GATHER_FM ? E->yv : (mode == DCTR_GATHER_BI ? E->x_in : nullptr);
+            return embed_gather_fwd(E->emb, E->lin, E->rows, E->ids, E->vals, B, E->F, E->K, mode, E->e, E->e_ld,
+                                    E->lin ? E->yw : nullptr, E->S, red, E->status, cs);
+        }
+        if (s == "forward") return forward(E, B, true, cs);
+        if (s == "head") return head(E, B, B, true, cs);
+        if (s == "backward_dense") return backward_dense(E, B, cs, cs);
+        if (s == "group_ids") return group_ids(E->group, E->ids, B, E->F, cs);
+        if (s == "scatter") {
+            const int mode = gather_mode(E);
+            const float* dE = mode == DCTR_GATHER_BI ? nullptr : E->dx_in;
+            const float* coef = mode == DCTR_GATHER_FM ? E->dy : (mode == DCTR_GATHER_BI ? E->dx_in : nullptr);
+            return embed_scatter_bwd(E->group, dE, E->Din_ld, E->e, E->e_ld, E->S, coef, E->lin ? E->dy : nullptr, E->vals, B,
+                                     E->F, E->K, mode, E->group->gemb, E->lin ? E->group->glin : nullptr, cs);
+        }
+        if (s == "opt_table")
+            return opt_table(c.optimizer, &E->state->hyper, E->h_state.hyper, c.table_mode, E->rows, E->K, E->emb, E->emb_s0,
+                             E->emb_s1, E->lin, E->lin_s0, E->lin_s1, E->group->slot, E->group->uniq, E->group->counters,
+                             E->group->max_entries, E->group->gemb, E->group->glin, c.l2_reg, E->scalars + 1, E->scalars + 2, cs);
+        if (s == "opt_dense")
+            return opt_dense_arena(c.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->parts, E->meta,
+                                   E->n_blocks, nullptr, 1, E->scalars + 3, cs);
+        if (s == "mlp0_fwd" || s == "mlp0_dgrad" || s == "mlp0_wgrad") {
+            const Fc& fc = E->mlp[0];
+            if (s == "mlp0_fwd")
+                return fc_fwd(E->x_in, E->Din_ld, E->pp(fc.w), E->pp(fc.b), E->h[0], fc.out, B, fc.in, fc.out, 1, fc.keep,
+                              &E->state->seed_t, 0x1000ull, cs);
+            if (s == "mlp0_dgrad")
+                return fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w), E->dx_in, E->Din_ld, B, fc.in, fc.out, nullptr, 0, 1.f, cs);
+            return fc_bwd_weights_partials(E->x_in, E->Din_ld, E->dh[0], fc.out, E->part(fc.w), E->params[fc.w].padded,
+                                           E->part(fc.b), E->params[fc.b].padded, B, fc.in, fc.out, fc.splits, cs);
+        }
+        if (s == "train_step") return record_train(E, B, cs);
+        set_error("unknown stage '%s'", kernel);
+        return DCTR_ERR_NOT_FOUND;
+    };
+    hipGraph_t graph = nullptr;
+    hipStream_t cs = nullptr;
+    DCTR_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    DCTR_HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+    int rc = DCTR_OK;
+    for (int i = 0; i < iters && rc == DCTR_OK; ++i) rc = stage(cs);
+    hipError_t e = hipStreamEndCapture(cs, &graph);
+    hipStreamDestroy(cs);
+    if (rc != DCTR_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) { set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return DCTR_ERR_HIP; }
+    hipGraphExec_t exec = nullptr;
+    DCTR_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    hipGraphDestroy(graph);
+    hipEvent_t e0, e1;
+    DCTR_HIP_CHECK(hipEventCreate(&e0));
+    DCTR_HIP_CHECK(hipEventCreate(&e1));
+    DCTR_HIP_CHECK(hipGraphLaunch(exec, st));          // warm-up replay
+    DCTR_HIP_CHECK(hipStreamSynchronize(st));
+    DCTR_HIP_CHECK(hipEventRecord(e0, st));
+    DCTR_HIP_CHECK(hipGraphLaunch(exec, st));
+    DCTR_HIP_CHECK(hipEventRecord(e1, st));
+    DCTR_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    DCTR_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipGraphExecDestroy(exec);
+    *h_ms_per_launch = ms / (float)iters;
     return DCTR_OK;
 }
 

@@ -13,6 +13,8 @@
 // A[m = l&31][k = l>>5] -- are 32 consecutive floats per half-wave: conflict-free ds_read_b32.
 // Global loads are one float4 per thread per operand per k-step, double-buffered in LDS with the
 // next tile's loads issued before the current tile's MFMAs (one barrier per k-step).
+#include <type_traits>
+
 #include "common.h"
 #include "ops.h"
 
@@ -20,7 +22,8 @@ namespace dctr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 64, BN = 64, BK = 16;
+constexpr int BM = 64, BN = 64, BK = 16;   // BK = NH 16-wide halves: one float4 piece per thread per half
+constexpr int NH = BK / 16;
 
 enum { EPI_STORE = 0, EPI_BIAS_ACT = 1, EPI_MASK = 2 };
 
@@ -34,6 +37,8 @@ struct Epilogue {
     int ldact;
     float inv_keep;         // EPI_MASK: 1/keep of the producing layer
     int64_t split_stride;   // EPI_STORE with gridDim.z>1: C + z*split_stride
+    float* colsum;          // wgrad only: column sums of B (= dY) per k-split -> bias-gradient partial slabs
+    int64_t colsum_stride;
 };
 
 // loads this thread's float4 piece of a [64 x 16] operand tile.
@@ -87,58 +92,166 @@ __device__ __forceinline__ void store_piece(float* __restrict__ s, float4 v, int
     }
 }
 
+constexpr int H16 = BK / 2;    // MFMAs (k-pairs) per BK tile
+
 template <bool A_KC, bool B_NC, int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(
     const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
-    float* __restrict__ Cm, int ldc, int M, int N, int K, int kchunk, bool vecA, bool vecB, Epilogue ep) {
+    float* __restrict__ Cm, int ldc, int M, int N, int K, int kchunk, bool vecA, bool vecB, Epilogue ep, int abl) {
     constexpr int LDA = A_KC ? 66 : 68;      // 66: conflict-free transposing scalar writes; 68: 16B-aligned rows
     constexpr int LDB = B_NC ? 68 : 66;
-    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+    constexpr int ABUF = BK * LDA, BBUF = BK * LDB;
+    __shared__ __attribute__((aligned(16))) float smem[2 * ABUF + 2 * BBUF];
+    float* const As0 = smem;
+    float* const As1 = smem + ABUF;
+    float* const Bs0 = smem + 2 * ABUF;
+    float* const Bs1 = smem + 2 * ABUF + BBUF;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: hardware places linear block id b on XCD b % 8; remapping gives every XCD a contiguous run of
+    // tiles (n fastest) so the blocks that share an A row-panel / the whole B panel hit the same 4 MiB L2.  Pure speed
+    // choice: any placement computes the same result.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int nwg = gridDim.x * gridDim.y;
+        const int b = blockIdx.y * gridDim.x + blockIdx.x;
+        const int q = nwg / 8, r = nwg % 8, xcd = b % 8, idx = b / 8;
+        const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;     // bijective for any nwg
+        bx = lb % gridDim.x;
+        by = lb / gridDim.x;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = blockIdx.z * kchunk;
     const int kend = min(K, kbeg + kchunk);
     const int nk = (kend - kbeg + BK - 1) / BK;
+    // a wave whose 32x32 output tile lies entirely outside C still stages operands but skips its MFMAs
+    const bool wave_live = (m0 + wm * 32 < M) && (n0 + wn * 32 < N);
+
+    // NACC accumulator chains over k.  A dependent v_mfma_f32_32x32x2_f32 chain already issues every 64 cycles
+    // (tools/mfma_rate.hip: 140 TF from one wave per SIMD with one accumulator), so one chain is enough and keeps
+    // the VGPR count at 3+ waves per SIMD.
+    constexpr int NACC = 1;
+    f32x16 accs[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accs[a][i] = 0.f;
+
+    // per-thread constant LDS offsets: fragment reads (lane -> A[m = lane&31][k = lane>>5]) and staging writes
+    const int rdA = (lane >> 5) * LDA + wm * 32 + (lane & 31);
+    const int rdB = (lane >> 5) * LDB + wn * 32 + (lane & 31);
+    // bias gradient for free: the blocks of the first row of tiles also sum their dY tiles (already in LDS) over k
+    const bool do_colsum = (EPI == EPI_STORE) && !A_KC && B_NC && ep.colsum != nullptr && by == 0 && t < BN;
+    float csum = 0.f;
+
+    // Software pipeline (one barrier per BK=32 k-step, MFMAs never wait on LDS or HBM):
+    //   global registers hold tile kt+1 (kt+2 after the barrier), LDS holds tile kt+1 in the other buffer, the fragment
+    //   registers hold tile kt; the fragments of tile kt+1 are read while tile kt's 16 MFMAs run.  The k-loop is
+    //   unrolled by two so buffers and fragment sets alternate by name (no copies, immediate LDS offsets).
+    // Interior blocks (all tiles full, 16-byte aligned operands) run the FAST instantiation without any bounds checks.
+    auto mainloop = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        // FAST: per-thread global pointers advanced by a constant per 16-wide k-half
+        const float* gA = A_KC ? A + (size_t)(m0 + (t >> 2)) * lda + kbeg + (t & 3) * 4
+                               : A + (size_t)(kbeg + (t >> 4)) * lda + m0 + (t & 15) * 4;
+        const float* gB = !B_NC ? Bm + (size_t)(n0 + (t >> 2)) * ldb + kbeg + (t & 3) * 4
+                                : Bm + (size_t)(kbeg + (t >> 4)) * ldb + n0 + (t & 15) * 4;
+        const size_t stepA = A_KC ? 16 : (size_t)16 * lda;
+        const size_t stepB = !B_NC ? 16 : (size_t)16 * ldb;
+        float4 ra[NH], rb[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) ra[h] = rb[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto gload = [&](int kt) {       // tile kt -> global registers
+            const int k0 = kbeg + kt * BK;
+            if (FAST) {
+                const float* pa = gA + (size_t)(NH * kt) * stepA;
+                const float* pb = gB + (size_t)(NH * kt) * stepB;
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    if (h == 0 || k0 + 16 * h < kend) {    // wave-uniform: only the last tile of a k-range may be partly empty
+                        ra[h] = *reinterpret_cast<const float4*>(pa + h * stepA);
+                        rb[h] = *reinterpret_cast<const float4*>(pb + h * stepB);
+                    } else {
+                        ra[h] = rb[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    ra[h] = load_piece<A_KC>(A, lda, m0, k0 + 16 * h, M, kend, vecA, t);
+                    rb[h] = load_piece<!B_NC>(Bm, ldb, n0, k0 + 16 * h, N, kend, vecB, t);
+                }
+            }
+        };
+        auto lstore = [&](float* as, float* bs) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                store_piece<A_KC, LDA>(as + 16 * h * LDA, ra[h], t);
+                store_piece<!B_NC, LDB>(bs + 16 * h * LDB, rb[h], t);
+            }
+        };
+        auto lread = [&](const float* as, const float* bs, float (&fa)[H16], float (&fb)[H16]) {
+            const float* pa = as + rdA;
+            const float* pb = bs + rdB;
+#pragma unroll
+            for (int j = 0; j < H16; ++j) { fa[j] = pa[2 * j * LDA]; fb[j] = pb[2 * j * LDB]; }
+        };
+        auto colsum = [&](const float* bs) {
+            if (do_colsum) {
+#pragma unroll
+                for (int kk = 0; kk < BK; ++kk) csum += bs[kk * LDB + t];
+            }
+        };
+        // one k-step: tile kt's fragments are in (fa,fb); tile kt+1 goes registers -> (asn,bsn) -> (na,nb)
+        auto step = [&](int kt, float* asn, float* bsn, float (&fa)[H16], float (&fb)[H16], float (&na)[H16], float (&nb)[H16]) {
+            const bool more = kt + 1 < nk;
+            if (more && abl < 1) lstore(asn, bsn);
+            if (abl < 3) __syncthreads();
+            if (kt + 2 < nk && abl < 1) gload(kt + 2);
+            if (more && abl < 2) lread(asn, bsn, na, nb);
+            if (more && abl >= 2) {
+#pragma unroll
+                for (int j = 0; j < H16; ++j) { na[j] = fa[j]; nb[j] = fb[j]; }
+            }
+            if (wave_live) {
+#pragma unroll
+                for (int j = 0; j < H16; ++j) accs[j % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb[j], accs[j % NACC], 0, 0, 0);
+            }
+            if (more) colsum(bsn);
+        };
+        float f0a[H16], f0b[H16], f1a[H16], f1b[H16];
+        if (nk > 0) {
+            gload(0);
+            lstore(As0, Bs0);
+            if (nk > 1) gload(1);
+        }
+        __syncthreads();
+        lread(As0, Bs0, f0a, f0b);
+        colsum(Bs0);
+        for (int kt = 0; kt < nk; kt += 2) {
+            step(kt, As1, Bs1, f0a, f0b, f1a, f1b);
+            if (kt + 1 < nk) step(kt + 1, As0, Bs0, f1a, f1b, f0a, f0b);
+        }
+    };
+    const bool fast_all = vecA && vecB && (m0 + BM <= M) && (n0 + BN <= N) && ((kend - kbeg) % 16 == 0);
+    if (fast_all) mainloop(std::true_type{});
+    else mainloop(std::false_type{});
 
     f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-
-    float4 ra = load_piece<A_KC>(A, lda, m0, kbeg, M, kend, vecA, t);
-    float4 rb = load_piece<!B_NC>(Bm, ldb, n0, kbeg, N, kend, vecB, t);
-    store_piece<A_KC, LDA>(As[0], ra, t);
-    store_piece<!B_NC, LDB>(Bs[0], rb, t);
-    __syncthreads();
-
-    const int arow = wm * 32 + (lane & 31), bcol = wn * 32 + (lane & 31), khalf = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            ra = load_piece<A_KC>(A, lda, m0, kbeg + (kt + 1) * BK, M, kend, vecA, t);
-            rb = load_piece<!B_NC>(Bm, ldb, n0, kbeg + (kt + 1) * BK, N, kend, vecB, t);
-        }
-        const float* as = As[cur];
-        const float* bs = Bs[cur];
+    for (int i = 0; i < 16; ++i) {
+        float s = accs[0][i];
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const float a = as[(kk + khalf) * LDA + arow];
-            const float b = bs[(kk + khalf) * LDB + bcol];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            store_piece<A_KC, LDA>(As[cur ^ 1], ra, t);
-            store_piece<!B_NC, LDB>(Bs[cur ^ 1], rb, t);
-        }
-        __syncthreads();
+        for (int a = 1; a < NACC; ++a) s += accs[a][i];
+        acc[i] = s;
     }
 
+    if (do_colsum && n0 + t < N) ep.colsum[(size_t)blockIdx.z * ep.colsum_stride + n0 + t] = csum;
     // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col = n0 + wn * 32 + (lane & 31);
-    if (col >= N) return;
+    if (col >= N || !wave_live) return;
     float* Cz = Cm + (EPI == EPI_STORE ? (size_t)blockIdx.z * ep.split_stride : 0);
     float bias = 0.f;
     uint64_t seed = 0;
@@ -146,19 +259,23 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(
         if (ep.bias != nullptr) bias = ep.bias[col];
         seed = ep.seed ^ (ep.seed_ptr ? *ep.seed_ptr : 0ull);
     }
+    const int rbase = m0 + wm * 32 + 4 * (lane >> 5);
+    float* crow = Cz + (size_t)rbase * ldc + col;
+    const float* arow_p = (EPI == EPI_MASK) ? ep.act + (size_t)rbase * ep.ldact + col : nullptr;
+    const bool rows_full = m0 + BM <= M;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= M) continue;
+        const int roff = (r & 3) + 8 * (r >> 2);
+        if (!rows_full && rbase + roff >= M) continue;
         float v = acc[r];
         if (EPI == EPI_BIAS_ACT) {
             v += bias;
             if (ep.relu) v = fmaxf(v, 0.f);
-            if (ep.keep < 1.0f) v *= dropout_scale(seed, (uint64_t)row * (uint64_t)N + col, ep.keep);
+            if (ep.keep < 1.0f) v *= dropout_scale(seed, (uint64_t)(rbase + roff) * (uint64_t)N + col, ep.keep);
         } else if (EPI == EPI_MASK) {
-            v = (ep.act[(size_t)row * ep.ldact + col] > 0.f) ? v * ep.inv_keep : 0.f;
+            v = (arow_p[(size_t)roff * ep.ldact] > 0.f) ? v * ep.inv_keep : 0.f;
         }
-        Cz[(size_t)row * ldc + col] = v;
+        crow[(size_t)roff * ldc] = v;
     }
 }
 
@@ -172,7 +289,9 @@ static int launch_gemm(const float* A, int lda, const float* B, int ldb, float* 
     const bool vecB = aligned16(B) && (ldb % 4 == 0);
     int kchunk = (int)round_up(ceil_div(K, splits), BK);
     dim3 grid(ceil_div(N, BN), ceil_div(M, BM), splits), block(256);
-    gemm_f32_mfma<A_KC, B_NC, EPI><<<grid, block, 0, st>>>(A, lda, B, ldb, C, ldc, M, N, K, kchunk, vecA, vecB, ep);
+    static const int dyn_lds = getenv("DCTR_GEMM_DYN_LDS") ? atoi(getenv("DCTR_GEMM_DYN_LDS")) : 0;   // occupancy experiments
+    static const int abl = getenv("DCTR_GEMM_ABLATE") ? atoi(getenv("DCTR_GEMM_ABLATE")) : 0;          // ablation experiments (wrong results!)
+    gemm_f32_mfma<A_KC, B_NC, EPI><<<grid, block, dyn_lds, st>>>(A, lda, B, ldb, C, ldc, M, N, K, kchunk, vecA, vecB, ep, abl);
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }
@@ -201,12 +320,10 @@ int fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int lddy, 
                             float* db_part, int64_t db_stride, int M, int K, int N, int splits, hipStream_t st) {
     Epilogue ep{};
     ep.split_stride = dw_stride;
+    ep.colsum = db_part;            // db = column sums of dY, fused into the first row of tiles
+    ep.colsum_stride = db_stride;
     // C[K,N] = X^T[K,M] dY[M,N]: reduction over M.  A = X^T stored as X[M,K] => "m"(=K here)-contiguous
     DCTR_TRY((launch_gemm<false, true, EPI_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st)));
-    if (db_part != nullptr) {
-        // any partition of the batch sums to the same total; it need not match the GEMM's k-chunking
-        DCTR_TRY(colsum_partials(dy, lddy, nullptr, M, N, splits, db_part, db_stride, st));
-    }
     return DCTR_OK;
 }
 

@@ -31,6 +31,31 @@ __global__ void group_zero_counters(int32_t* counters) {
     counters[1] = 0;
 }
 
+// Wave-level grouping of equal ids without memory traffic: for every lane, the lowest lane of the wave holding the
+// same id (its "leader"), the number of lanes sharing the id and this lane's rank among them.  The loop runs once
+// per DISTINCT id in the wave and only does ballots/shuffles; the atomics are issued afterwards by all leaders at
+// once, so their latencies overlap instead of serialising.
+struct WaveGroup { int leader; int count; int rank; };
+__device__ __forceinline__ WaveGroup wave_group(int id, bool valid, int lane) {
+    WaveGroup g{lane, 0, 0};
+    bool pending = valid;
+    while (true) {
+        const unsigned long long m = __ballot(pending);
+        if (m == 0ull) break;
+        const int leader = __ffsll((long long)m) - 1;
+        const int lid = __shfl(id, leader);
+        const bool same = pending && (id == lid);
+        const unsigned long long sm = __ballot(same);
+        if (same) {
+            g.leader = leader;
+            g.count = __popcll(sm);
+            g.rank = __popcll(sm & ((1ull << lane) - 1ull));
+        }
+        pending = pending && !same;
+    }
+    return g;
+}
+
 // entry i <-> (f = i / B, b = i % B): field-major walk
 __global__ __launch_bounds__(256) void group_count_kernel(const int32_t* __restrict__ ids, int B, int F,
                                                          int64_t rows, int32_t* __restrict__ slot,
@@ -39,27 +64,23 @@ __global__ __launch_bounds__(256) void group_count_kernel(const int32_t* __restr
     const int n = B * F;
     const int lane = threadIdx.x & 63;
     int id = -1;
-    bool active = false;
+    bool valid = false;
     if (i < n) {
         const int f = i / B, b = i - f * B;
         id = ids[(size_t)b * F + f];
-        active = (id >= 0) && ((int64_t)id < rows);
+        valid = (id >= 0) && ((int64_t)id < rows);
     }
-    while (true) {
-        const unsigned long long m = __ballot(active);
-        if (m == 0ull) break;
-        const int leader = __ffsll((long long)m) - 1;
-        const int lid = __shfl(id, leader);
-        const bool same = active && (id == lid);
-        const unsigned long long sm = __ballot(same);
-        if (lane == leader) {
-            const int old = atomicAdd(&slot[lid], __popcll(sm));
-            if (old == 0) {
-                const int u = atomicAdd(&counters[0], 1);
-                uniq[u] = lid;
-            }
-        }
-        active = active && !same;
+    const WaveGroup g = wave_group(id, valid, lane);
+    bool first = false;     // this wave is the first to touch the id
+    if (valid && g.leader == lane) first = atomicAdd(&slot[id], g.count) == 0;
+    // compact-slot allocation: one atomic per wave for all of its newly seen ids
+    const unsigned long long fm = __ballot(first);
+    if (fm != 0ull) {
+        int base = 0;
+        const int head = __ffsll((long long)fm) - 1;
+        if (lane == head) base = atomicAdd(&counters[0], __popcll(fm));
+        base = __shfl(base, head);
+        if (first) uniq[base + __popcll(fm & ((1ull << lane) - 1ull))] = id;
     }
 }
 
@@ -93,32 +114,21 @@ __global__ __launch_bounds__(256) void group_fill_kernel(const int32_t* __restri
     const int n = B * F;
     const int lane = threadIdx.x & 63;
     int id = -1;
-    bool active = false;
+    bool valid = false;
     if (i < n) {
         const int f = i / B, b = i - f * B;
         id = ids[(size_t)b * F + f];
-        active = (id >= 0) && ((int64_t)id < rows);
+        valid = (id >= 0) && ((int64_t)id < rows);
     }
-    while (true) {
-        const unsigned long long m = __ballot(active);
-        if (m == 0ull) break;
-        const int leader = __ffsll((long long)m) - 1;
-        const int lid = __shfl(id, leader);
-        const bool same = active && (id == lid);
-        const unsigned long long sm = __ballot(same);
-        int u = 0, base = 0;
-        if (lane == leader) {
-            u = slot[lid] - 1;
-            base = atomicAdd(&cursor[u], __popcll(sm));
-        }
-        u = __shfl(u, leader);
-        base = __shfl(base, leader);
-        if (same) {
-            const int pos = base + __popcll(sm & ((1ull << lane) - 1ull));
-            perm[pos] = i;
-            seg_of[pos] = u;
-        }
-        active = active && !same;
+    const WaveGroup g = wave_group(id, valid, lane);
+    int u = 0, base = 0;
+    if (valid) u = slot[id] - 1;
+    if (valid && g.leader == lane) base = atomicAdd(&cursor[u], g.count);
+    base = __shfl(base, g.leader);
+    if (valid) {
+        const int pos = base + g.rank;
+        perm[pos] = i;
+        seg_of[pos] = u;
     }
 }
 

@@ -72,6 +72,9 @@ int rank1_bwd(const float* dy, const float* w, int M, int n, const float* act, i
               int lddx, int accumulate, hipStream_t st);
 int colsum_partials(const float* Y, int ldy, const float* rs, int M, int N, int splits, float* out,
                     int64_t split_stride, hipStream_t st);
+int out_layer_bwd(const float* x, int ldx, const float* dy, const float* w, int M, int n, int splits, int masked,
+                  float keep, float* dx, int lddx, float* dw_part, int64_t dw_stride, float* db_part, int64_t db_stride,
+                  hipStream_t st);
 int loss_head(const float* bias, const float* yw, const float* yv, const float* yd, const float* labels, int B,
               float inv_batch, float* y, float* prob, float* dy, float* loss_sum, hipStream_t st);
 int opt_dense_arena(int kind, const Hyper* hdev, const Hyper& hval, float* theta, float* s0, float* s1,

@@ -172,6 +172,13 @@ class Engine:
         st = stream if stream is not None else capi.current_stream()
         capi.check(self._lib.dctr_check_ids(self._h, st))
 
+    def time_stage(self, stage: str, iters: int = 50, stream=None) -> float:
+        """Average milliseconds per execution of one stage of the step (hipEvents around a graph of `iters` launches)."""
+        ms = C.c_float()
+        st = stream if stream is not None else capi.current_stream()
+        capi.check(self._lib.dctr_time_kernel(self._h, stage.encode(), iters, C.byref(ms), st))
+        return ms.value
+
     def debug_tensor(self, name: str):
         """Device view (torch) of a named intermediate of the last forward."""
         import torch
