@@ -82,10 +82,14 @@ def main():
     w = dict(WORKLOAD)
     B = w["batch"]
 
-    if world > 1:
+    sharded = world > 1 or bool(os.environ.get("DCTR_FORCE_SHARDED"))     # the env var exercises the RCCL path on one GPU
+    if sharded:
         import torch.distributed as dist
         from tf_repos_amd.distributed import ShardedTrainer
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         trainer = ShardedTrainer(w, rank, world, dev, table_mode=args.table_mode)
         step = trainer.train_step
         barrier = dist.barrier
@@ -117,7 +121,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -135,7 +139,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else "row-sharded tables (id %% %d) + data-parallel dense" % world,
                        "ids": "uniform" if args.uniform_ids else "zipf"},
         }
-    if world == 1:
+    if not sharded:
         # ---- per-stage timing (hipEvents around a graph of back-to-back launches, on torch's current stream)
         F, K, V = w["field_size"], w["embedding_size"], w["feature_size"]
         stages = {}
@@ -173,7 +177,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
         dist.destroy_process_group()
 

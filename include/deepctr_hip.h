@@ -246,13 +246,42 @@ int dctr_check_ids(dctr_handle h, void* stream);
 /* named intermediates of the last forward, for parity tests ("e","y_w","y_v","bi","inner","x_cross","att") */
 int dctr_debug_tensor(dctr_handle h, const char* name, float** d_ptr, int64_t* n_elems, int* ld);
 
-/* split step for the row-sharded multi-GPU path.  The dense half consumes already
- * gathered+scaled embeddings (received through all-to-all) and returns dE / dy for the owners. */
-int dctr_dense_fwd_bwd(dctr_handle h, const float* d_e, int e_ld, const float* d_yw, const float* d_labels,
-                       int B, int global_batch, float* d_dE, int de_ld, float* d_dy, float* d_loss_sum,
-                       int train, void* stream);
-int dctr_dense_grads(dctr_handle h, float** d_grads, int64_t* n);      /* flat dense-gradient arena (all-reduce it) */
-int dctr_dense_apply(dctr_handle h, void* stream);                     /* optimizer on the dense arena        */
+/* ---- row-sharded multi-GPU path: owner(id) = id % world, local row = id / world.  There is no reference
+ * call site -- this replaces the async parameter-server push/pull of set_dist_env (DeepFM.py:237-282) with a
+ * synchronous step whose only exchanges are three all-to-alls (distinct rows out, rows back, row gradients back) and
+ * one all-reduce of the dense gradients, all issued by the host through torch.distributed (RCCL).
+ * Requester side, on a dctr_group_t created over the GLOBAL id space (rows = feature_size):
+ *   dctr_group_ids -> dctr_route_unique -> [all-to-all rows] -> dctr_entry_index -> dctr_sharded_forward_backward
+ *   -> dctr_sharded_row_grads -> dctr_permute_unique_rows -> [all-to-all grads] ;  owner side: dctr_table_* below. */
+/* d_counts int32[2*world]: [0:world) distinct ids per owner (the all-to-all send split sizes), rest is scratch.
+ * d_send_rows [U] local rows grouped by owner; d_upos [U] position of distinct id u in that send order. */
+int dctr_route_unique(dctr_group_t g, int world, int32_t* d_send_rows, int32_t* d_upos, int32_t* d_counts, void* stream);
+/* d_idx[i] = position (in send order) of entry i's id, -1 for ids outside [0, rows): the `ids` of a gather whose
+ * table is the buffer of rows received back from the owners */
+int dctr_entry_index(dctr_group_t g, const int32_t* d_ids, int n, const int32_t* d_upos, int32_t* d_idx, void* stream);
+/* d_dst[d_pos[u], :] = d_src[u, :] for the group's U distinct ids (K = 1 for the linear gradients) */
+int dctr_permute_unique_rows(dctr_group_t g, const float* d_src, const int32_t* d_pos, int K, float* d_dst, void* stream);
+/* owner side: raw rows of this rank's shard (no value scaling): d_out_emb [n,K], d_out_lin [n] (NULL without linear table) */
+int dctr_table_gather_rows(dctr_handle h, const int32_t* d_rows, int n, float* d_out_emb, float* d_out_lin, void* stream);
+/* owner side: segment-sum the received row gradients (a row may arrive from several ranks) and step the shard's tables
+ * with the configured optimizer / table_mode */
+int dctr_table_apply_grads(dctr_handle h, const int32_t* d_rows, int n, const float* d_gemb, const float* d_glin, void* stream);
+/* requester side */
+int dctr_step_begin(dctr_handle h, void* stream);                 /* zero the loss scalars, advance global_step / Adam lr_t / dropout seed */
+/* forward (+ backward through head, MLP, interaction when train != 0) on rows received from the owners:
+ * d_rows [n_rows,K], d_lin [n_rows] are the table the gather reads, d_idx [B,F] its ids (dctr_entry_index).
+ * The logit gradient is (prob - label)/global_batch so that summing dense gradients over ranks gives the mean. */
+int dctr_sharded_forward_backward(dctr_handle h, const float* d_rows, const float* d_lin, int n_rows, const int32_t* d_idx,
+                                  const float* d_vals, const float* d_labels, int B, int global_batch, int train, void* stream);
+/* per-distinct-id gradients of this rank's batch into g's compact buffers (dctr_group_buffers: d_gemb [U,K], d_glin [U]) */
+int dctr_sharded_row_grads(dctr_handle h, dctr_group_t g, int B, void* stream);
+/* dense gradients: reduce the partial slabs into one flat array (all-reduce it in place), then apply the optimizer */
+int dctr_dense_grads(dctr_handle h, float** d_flat, int64_t* n, void* stream);
+int dctr_dense_apply(dctr_handle h, void* stream);
+/* [0] sum_b xent of this rank's batch, [1] sum emb^2, [2] sum linear^2 (this shard, pre-update), [3] sum of l2-regularised dense params^2 */
+int dctr_read_scalars(dctr_handle h, float h_out[4], void* stream);
+/* prob / logit of the last forward (device pointers into the engine's buffers, valid until the next call) */
+int dctr_last_outputs(dctr_handle h, float** d_prob, float** d_logit);
 
 /* per-kernel timing hooks used by bench.py for the roofline objects: runs `iters` back-to-back
  * launches of the named kernel on the engine's current buffers between two hipEvents recorded on

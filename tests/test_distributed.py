@@ -1,0 +1,132 @@
+"""Multi-GPU path.  CPU: the exchange protocol over gloo with world_size 2.  GPU: two ranks sharing one
+MI355X (gloo + host staging) must reproduce the single-rank engine on the same global batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+# ------------------------------------------------------------------------------------------------- CPU / gloo
+def _exchange_worker(rank, world, port, ret):
+    from tf_repos_amd.distributed import Comm, ShardExchange
+    _init(rank, world, port)
+    try:
+        V, K = 101, 4
+        table = np.arange(V * K, dtype=np.float32).reshape(V, K)            # row r = [4r, 4r+1, ...]
+        shard = torch.from_numpy(table[rank::world].copy())
+        grad_acc = torch.zeros_like(shard)
+        rng = np.random.default_rng(10 + rank)
+        uniq = np.unique(rng.integers(0, V, size=40)).astype(np.int64)       # this rank's distinct ids
+        dest = uniq % world
+        order = np.argsort(dest, kind="stable")
+        send_ids = uniq[order]
+        send_rows = torch.from_numpy((send_ids // world).astype(np.int32))
+        counts = [int((dest == d).sum()) for d in range(world)]
+        x = ShardExchange(Comm())
+        rows_back, = x.request_rows(send_rows, counts, lambda rows: [shard[rows.long()]])
+        assert np.array_equal(rows_back.numpy(), table[send_ids]), "rows came back in the wrong order"
+
+        def apply(rows, g):
+            grad_acc.index_add_(0, rows.long(), g)
+        x.return_grads([torch.ones(len(send_ids), K) * (rank + 1)], apply)
+        # every rank's contribution must land on the owner's rows exactly once
+        all_ids = [None] * world
+        dist.all_gather_object(all_ids, send_ids)
+        expect = np.zeros((V, K), np.float32)
+        for r, ids_r in enumerate(all_ids):
+            expect[ids_r] += r + 1
+        assert np.array_equal(grad_acc.numpy(), expect[rank::world])
+        t = torch.tensor([float(rank + 1)])
+        Comm().all_reduce_sum(t)
+        assert float(t) == sum(range(1, world + 1))
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_protocol_gloo_world2():
+    world = 2
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_exchange_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert [ret.get(r) for r in range(world)] == ["ok"] * world
+
+
+# ------------------------------------------------------------------------------------------------- GPU
+def _shard_worker(rank, world, port, model, ret):
+    from oracle import deepctr_oracle as O
+    from tf_repos_amd.distributed import ShardedTrainer
+    _init(rank, world, port)
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+        F, V, K, Bg = 39, 2003, 8, 128
+        w = dict(model=model, field_size=F, feature_size=V, embedding_size=K, batch=Bg // world, deep_layers=(32, 16),
+                 dropout=(1.0, 1.0), cross_layers=2, l2_reg=1e-3, learning_rate=1e-2, optimizer="Adam")
+        ocfg = O.Config(model=model, field_size=F, feature_size=V, embedding_size=K, deep_layers=(32, 16), dropout=(1.0, 1.0),
+                        cross_layers=2, l2_reg=1e-3, learning_rate=1e-2, optimizer="Adam")
+        params = {k: v.numpy() for k, v in O.init_params(ocfg, seed=5, scale=0.05).items()}
+        tr = ShardedTrainer(w, rank, world, dev, params=params)
+        losses = []
+        for step in range(3):
+            ids, vals, labels = O.synth_batch(Bg, F, V, seed=300 + step)
+            sl = slice(rank * (Bg // world), (rank + 1) * (Bg // world))
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a[sl])).to(dev)
+            losses.append(tr.train_step(t(ids), t(vals), t(labels), want_loss=True))
+        full = tr.gather_full_params()
+        ids, vals, labels = O.synth_batch(Bg, F, V, seed=999)
+        prob = tr.predict(t(ids), t(vals)).cpu().numpy()
+        if rank == 0:
+            ret["params"] = full
+            ret["losses"] = losses
+        ret["prob%d" % rank] = prob
+        tr.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["deepfm", "dcn", "nfm"])
+def test_two_ranks_equal_one_rank(model, dev):
+    from oracle import deepctr_oracle as O
+    from tests.util import dev_batch, make_pair
+    world = 2
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_shard_worker, args=(world, _free_port(), model, ret), nprocs=world, join=True)
+        got, losses = dict(ret["params"]), list(ret["losses"])
+        probs = np.concatenate([ret["prob0"], ret["prob1"]])
+    F, V, K, Bg = 39, 2003, 8, 128
+    ocfg, params, eng = make_pair(model, B=Bg, F=F, V=V, K=K, layers=(32, 16), cross=2, opt="Adam", l2=1e-3, lr=1e-2, seed=4)
+    ref_losses = []
+    for step in range(3):
+        ids, vals, labels = O.synth_batch(Bg, F, V, seed=300 + step)
+        ref_losses.append(eng.train_step(*dev_batch(ids, vals, labels, dev)))
+    one = eng.get_params()
+    for k in one:
+        assert np.abs(one[k] - got[k]).max() <= 1e-6, k           # tolerance: N ranks == 1 rank within 1e-6
+    assert np.allclose(losses, ref_losses, rtol=1e-5, atol=1e-6)
+    ids, vals, labels = O.synth_batch(Bg, F, V, seed=999)
+    d = dev_batch(ids, vals, labels, dev)
+    p1 = torch.empty(Bg, device=dev)
+    eng.predict(d[0], d[1], p1, None)
+    assert np.abs(p1.cpu().numpy() - probs).max() <= 1e-6
+    eng.close()

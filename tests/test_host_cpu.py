@@ -1,0 +1,141 @@
+"""CPU-side tests (no GPU): the C ABI exports what the header declares, the host parser (K1) matches the oracle and
+glibc strtof bit-for-bit, and the oracle's own formulas are self-consistent."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+from hypothesis import given, settings, strategies as st
+
+from oracle import deepctr_oracle as O
+from tf_repos_amd import capi, errors
+from tf_repos_amd.input_pipeline import parse_libsvm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# the only concrete 39-field sample in the reference: deep_fm_serving_client.cpp:42-45
+SERVING_IDS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 555, 1078, 17797, 26190, 26341, 28570, 35361, 35613, 35984, 48424,
+               51364, 64053, 65964, 66206, 71628, 84088, 84119, 86889, 88280, 88283, 100288, 100300, 102447, 109932, 111823]
+SERVING_VALS = [0.05, 0.006633, 0.05, 0, 0.021594, 0.008, 0.15, 0.04, 0.362, 0.1, 0.2, 0, 0.04] + [1.0] * 26
+
+
+def test_library_exports_every_symbol_the_header_declares():
+    hdr = open(os.path.join(ROOT, "include", "deepctr_hip.h")).read()
+    declared = set(re.findall(r"\b(dctr_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"dctr_config", "dctr_engine", "dctr_group"}
+    lib = capi.lib()          # binds every symbol in capi._SIGS or raises
+    for name in sorted(declared):
+        assert hasattr(lib, name), "header declares %s but libdeepctr_hip.so does not export it" % name
+    assert declared == set(capi.DECLARED_SYMBOLS), declared ^ set(capi.DECLARED_SYMBOLS)
+    assert lib.dctr_version() >= 100
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libdeepctr_hip.so")
+    with pytest.raises(errors.NotFoundError):
+        capi.lib()
+
+
+def test_parser_matches_oracle_on_criteo_shaped_text():
+    ids, vals, labels = O.synth_batch(257, 39, 117581, seed=3)
+    text = O.to_libsvm(ids, vals, labels)
+    pi, pv, pl = parse_libsvm(text, 39)
+    oi, ov, ol = O.parse_libsvm(text, 39)
+    assert np.array_equal(pi, oi) and np.array_equal(pi, ids)
+    assert np.array_equal(pv.view(np.uint32), ov.view(np.uint32))        # bit-exact floats
+    assert np.array_equal(pl, ol)
+
+
+def test_parser_reference_comment_line_and_serving_sample():
+    # the libsvm line in the comment at DeepFM.py:62 has 27 tokens (not 39): parses with field_size=27, ragged for 39
+    line = ("1 1:0.5 2:0.03519 3:1 4:0.02567 7:0.03708 8:0.01705 9:0.06296 10:0.18185 11:0.02497 12:1 14:0.02565 15:0.03267 "
+            "17:0.0247 18:0.03158 20:1 22:1 23:0.13169 24:0.02933 27:0.18159 31:0.0177 34:0.02888 38:1 51:1 63:1 132:1 164:1 236:1\n")
+    i, v, l = parse_libsvm(line, 27)
+    assert i.shape == (1, 27) and i[0, -1] == 236 and l[0] == 1.0 and v[0, 1] == np.float32(0.03519)
+    with pytest.raises(errors.InvalidArgumentError):
+        parse_libsvm(line, 39)
+    s = "0 " + " ".join("%d:%s" % (a, repr(b)) for a, b in zip(SERVING_IDS, SERVING_VALS)) + "\n"
+    i, v, l = parse_libsvm(s, 39)
+    assert list(i[0]) == SERVING_IDS and np.array_equal(v[0], np.array(SERVING_VALS, np.float32))
+
+
+@pytest.mark.parametrize("bad", ["1 1:0.5 2:\n", "1 1:0.5 x:2\n", "1 1:0.5 2:3:4\n", "abc 1:1 2:2\n", "1 1:0.5 2:1e\n", "1 3000000000:1 2:1\n"])
+def test_parser_rejects_malformed_lines(bad):
+    with pytest.raises(errors.InvalidArgumentError):
+        parse_libsvm(bad, 2)
+
+
+def test_parser_skips_empty_tokens_and_blank_lines():
+    i, v, l = parse_libsvm("\n1  1:2   3:4 \n\n0 5:6 7:8\n", 2)
+    assert i.tolist() == [[1, 3], [5, 7]] and v.tolist() == [[2.0, 4.0], [6.0, 8.0]] and l.tolist() == [1.0, 0.0]
+    i, v, l = parse_libsvm("", 2)
+    assert i.shape == (0, 2)
+
+
+_float_text = st.one_of(
+    st.floats(allow_nan=False, allow_infinity=False, width=64).map(lambda x: "%.17g" % x),
+    st.floats(min_value=0, max_value=1).map(lambda x: ("%.6f" % x).rstrip("0").rstrip(".") or "0"),
+    st.floats(allow_nan=False, allow_infinity=False, width=32).map(lambda x: "%.9g" % x),
+    st.integers(min_value=0, max_value=10 ** 12).map(lambda n: "0.%012d" % n),
+    st.tuples(st.integers(0, 10 ** 9), st.integers(0, 12)).map(lambda t: ("%d" % t[0])[:-t[1] or None] + "." + ("%d" % t[0])[-t[1]:] if t[1] else "%d" % t[0]),
+)
+
+
+@settings(max_examples=400, deadline=None)
+@given(_float_text)
+def test_float_parse_is_correctly_rounded_like_glibc_strtof(tok):
+    libc = C.CDLL(None)
+    libc.strtof.restype = C.c_float
+    want = np.float32(libc.strtof(tok.encode(), None))
+    _, v, _ = parse_libsvm("0 7:%s\n" % tok, 1)
+    assert v[0, 0].view(np.uint32) == want.view(np.uint32) or (np.isnan(v[0, 0]) and np.isnan(want)), tok
+
+
+def test_oracle_deepfm_matches_closed_form_and_fp64_shadow():
+    cfg = O.Config(model="deepfm", field_size=39, feature_size=117581, embedding_size=8, deep_layers=(16, 8), dropout=(1, 1))
+    p = O.init_params(cfg, seed=2, scale=0.05)
+    ids = np.array([SERVING_IDS], dtype=np.int64)
+    vals = np.array([SERVING_VALS], dtype=np.float32)
+    out = O.forward(cfg, p, ids, vals)
+    e = p["emb"].numpy()[ids[0]] * vals[0][:, None]
+    yv = 0.5 * ((e.sum(0) ** 2) - (e ** 2).sum(0)).sum()
+    pairs = sum(float(e[i] @ e[j]) for i in range(39) for j in range(i + 1, 39))      # FM identity: sum_{i<j} <e_i,e_j>
+    assert abs(float(out["y_v"][0]) - yv) < 1e-6 and abs(yv - pairs) < 1e-5
+    p64 = {k: v.double() for k, v in p.items()}
+    out64 = O.forward(cfg, p64, ids, vals.astype(np.float64))
+    assert abs(float(out["y"][0]) - float(out64["y"][0])) < 1e-5
+
+
+def test_oracle_optimizers_one_step_closed_form():
+    for kind, expect in [("Adam", lambda th, g, lr: th - lr * np.sign(g) * (1 / (1 + 1e-8 / np.abs(g)))),
+                         ("Momentum", lambda th, g, lr: th - lr * g),
+                         ("Adagrad", lambda th, g, lr: th - lr * g / np.sqrt(1e-8 + g * g))]:
+        cfg = O.Config(model="fnn", field_size=2, feature_size=5, embedding_size=4, deep_layers=(4,), dropout=(1,), optimizer=kind,
+                       learning_rate=0.1)
+        p = O.init_params(cfg, seed=1, scale=0.1)
+        th0 = p["mlp0/weights"].clone().numpy()
+        opt = O.Optimizer(cfg, p)
+        g = {k: torch.full_like(v, 0.25) for k, v in p.items()}
+        opt.step(p, g)
+        np.testing.assert_allclose(p["mlp0/weights"].numpy(), expect(th0, 0.25, 0.1), rtol=1e-5, atol=1e-7)
+
+
+def test_oracle_streaming_auc():
+    a = O.StreamingAUC()
+    rng = np.random.default_rng(0)
+    lab = (rng.random(5000) < 0.3).astype(np.float32)
+    pred = np.clip(0.3 * lab + 0.7 * rng.random(5000), 0, 1).astype(np.float32)
+    a.update(lab[:2000], pred[:2000])
+    a.update(lab[2000:], pred[2000:])
+    from sklearn.metrics import roc_auc_score
+    assert abs(a.result() - roc_auc_score(lab, pred)) < 2e-3        # 200-threshold trapezoid vs exact AUC
+
+
+def test_out_of_range_ids_raise_in_the_oracle():
+    cfg = O.Config(model="deepfm", field_size=2, feature_size=5, embedding_size=4, deep_layers=(4,), dropout=(1,))
+    p = O.init_params(cfg)
+    with pytest.raises(IndexError):
+        O.forward(cfg, p, np.array([[1, 5]]), np.ones((1, 2), np.float32))

@@ -96,6 +96,18 @@ _SIGS = {
     "dctr_train_step": ([_P, _P, _P, _P, C.c_int, C.POINTER(C.c_float), _P], C.c_int),
     "dctr_predict": ([_P, _P, _P, C.c_int, _P, _P, _P], C.c_int),
     "dctr_check_ids": ([_P, _P], C.c_int),
+    "dctr_route_unique": ([_P, C.c_int, _P, _P, _P, _P], C.c_int),
+    "dctr_entry_index": ([_P, _P, C.c_int, _P, _P, _P], C.c_int),
+    "dctr_permute_unique_rows": ([_P, _P, _P, C.c_int, _P, _P], C.c_int),
+    "dctr_table_gather_rows": ([_P, _P, C.c_int, _P, _P, _P], C.c_int),
+    "dctr_table_apply_grads": ([_P, _P, C.c_int, _P, _P, _P], C.c_int),
+    "dctr_step_begin": ([_P, _P], C.c_int),
+    "dctr_sharded_forward_backward": ([_P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P], C.c_int),
+    "dctr_sharded_row_grads": ([_P, _P, C.c_int, _P], C.c_int),
+    "dctr_dense_grads": ([_P, C.POINTER(_P), C.POINTER(C.c_int64), _P], C.c_int),
+    "dctr_dense_apply": ([_P, _P], C.c_int),
+    "dctr_read_scalars": ([_P, C.POINTER(C.c_float * 4), _P], C.c_int),
+    "dctr_last_outputs": ([_P, C.POINTER(_P), C.POINTER(_P)], C.c_int),
     "dctr_time_kernel": ([_P, C.c_char_p, C.c_int, C.POINTER(C.c_float), _P], C.c_int),
     "dctr_debug_tensor": ([_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int)], C.c_int),
 }

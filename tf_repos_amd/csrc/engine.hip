@@ -62,6 +62,8 @@ struct dctr_engine {
     float *theta = nullptr, *as0 = nullptr, *as1 = nullptr, *gflat = nullptr, *parts = nullptr;
     int64_t arena_n = 0, parts_n = 0;
     OptBlockMeta* meta = nullptr;
+    OptBlockMeta* meta_flat = nullptr;
+    float* ones = nullptr;        // [max_batch*F*world] of 1.0f: the `vals` of raw row gathers / gradient segment sums
     int n_blocks = 0;
     // state
     StepState* state = nullptr;
@@ -197,7 +199,7 @@ int build(dctr_engine* E) {
         DCTR_TRY(dmalloc(&E->lin_s0, (size_t)E->rows));
         DCTR_TRY(dmalloc(&E->lin_s1, (size_t)E->rows));
     }
-    DCTR_TRY(group_create(E->rows, (int64_t)MB * F, K, &E->group));
+    DCTR_TRY(group_create(E->rows, (int64_t)MB * F * c.shard_world, K, &E->group));   // owner side may receive rows from every rank
 
     // ---- dense arena + partial slabs + optimizer block metadata
     int64_t off = 0, poff = 0;
@@ -234,6 +236,16 @@ int build(dctr_engine* E) {
     }
     DCTR_TRY(dmalloc(&E->meta, hm.size(), false));
     DCTR_HIP_CHECK(hipMemcpy(E->meta, hm.data(), hm.size() * sizeof(OptBlockMeta), hipMemcpyHostToDevice));
+    // second metadata table: gradients already reduced into the flat arena (after the all-reduce of the sharded path)
+    std::vector<OptBlockMeta> hf(hm);
+    for (size_t j = 0; j < hf.size(); ++j) { hf[j].part_off = (int64_t)j * OPT_BLOCK; hf[j].part_stride = 0; hf[j].n_part = 1; }
+    DCTR_TRY(dmalloc(&E->meta_flat, hf.size(), false));
+    DCTR_HIP_CHECK(hipMemcpy(E->meta_flat, hf.data(), hf.size() * sizeof(OptBlockMeta), hipMemcpyHostToDevice));
+    {
+        std::vector<float> ones((size_t)MB * F * c.shard_world, 1.0f);
+        DCTR_TRY(dmalloc(&E->ones, ones.size(), false));
+        DCTR_HIP_CHECK(hipMemcpy(E->ones, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
 
     // ---- step state
     StepState s{};
@@ -304,12 +316,15 @@ int build(dctr_engine* E) {
 }
 
 // ---- forward (train=true: dropout on, DeepFM.py:161-162) ------------------------------------------------
-int forward(dctr_engine* E, int B, bool train, hipStream_t st) {
+// the gather reads (emb, lin, rows, ids): the engine's own tables, or -- in the row-sharded path -- the buffer of rows
+// received from their owners with ids = positions in that buffer
+int forward_from(dctr_engine* E, const float* emb, const float* lin, int64_t rows, const int32_t* ids, int B, bool train,
+                 hipStream_t st) {
     const dctr_config& c = E->cfg;
     const int F = E->F, K = E->K, D = E->D;
     const int mode = gather_mode(E);
     float* red = mode == DCTR_GATHER_FM ? E->yv : (mode == DCTR_GATHER_BI ? E->x_in : nullptr);
-    DCTR_TRY(embed_gather_fwd(E->emb, E->lin, E->rows, E->ids, E->vals, B, F, K, mode, E->e, E->e_ld, E->lin ? E->yw : nullptr,
+    DCTR_TRY(embed_gather_fwd(emb, lin, rows, ids, E->vals, B, F, K, mode, E->e, E->e_ld, lin ? E->yw : nullptr,
                               E->S, red, E->status, st));
     const uint64_t* seedp = &E->state->seed_t;
     if (c.model == DCTR_MODEL_IPNN) DCTR_TRY(pnn_inner_fwd(E->e, E->e_ld, B, F, K, E->x_in + D, E->Din_ld, st));
@@ -336,6 +351,10 @@ int forward(dctr_engine* E, int B, bool train, hipStream_t st) {
         DCTR_TRY(rowdot(E->h.back(), H, wout, E->pp(E->p_out_b), B, H, E->yd, 0, st));   // deep_out, DeepFM.py:165-167
     }
     return DCTR_OK;
+}
+
+int forward(dctr_engine* E, int B, bool train, hipStream_t st) {
+    return forward_from(E, E->emb, E->lin, E->rows, E->ids, B, train, st);
 }
 
 int head(dctr_engine* E, int B, int global_batch, bool with_labels, hipStream_t st) {
@@ -513,6 +532,8 @@ int dctr_destroy(dctr_handle E) {
     if (E->status) hipFree(E->status);
     if (E->state) hipFree(E->state);
     if (E->meta) hipFree(E->meta);
+    if (E->meta_flat) hipFree(E->meta_flat);
+    if (E->ones) hipFree(E->ones);
     group_destroy(E->group);
     for (auto& ev : E->events) if (ev) hipEventDestroy(ev);
     if (E->s_group) hipStreamDestroy(E->s_group);
@@ -647,6 +668,94 @@ int dctr_debug_tensor(dctr_handle E, const char* name, float** d_ptr, int64_t* n
     *d_ptr = p;
     if (n_elems) *n_elems = n;
     if (ld) *ld = l;
+    return DCTR_OK;
+}
+
+// ---- row-sharded path (declared in deepctr_hip.h under "row-sharded multi-GPU path") ---------------------------------
+int dctr_table_gather_rows(dctr_handle E, const int32_t* d_rows, int n, float* d_out_emb, float* d_out_lin, void* stream) {
+    DCTR_REQUIRE(E && d_rows && d_out_emb, "null argument");
+    DCTR_REQUIRE(n >= 0 && (int64_t)n <= (int64_t)E->MB * E->F * E->cfg.shard_world, "too many rows requested (%d)", n);
+    if (n == 0) return DCTR_OK;
+    // B = n examples of one field each, value 1: e_out [n,K] = raw rows, yw = raw linear weights
+    return embed_gather_fwd(E->emb, E->lin, E->rows, d_rows, E->ones, n, 1, E->K, DCTR_GATHER_RAW, d_out_emb, E->K,
+                            (E->lin && d_out_lin) ? d_out_lin : nullptr, nullptr, nullptr, E->status, as_stream(stream));
+}
+
+int dctr_table_apply_grads(dctr_handle E, const int32_t* d_rows, int n, const float* d_gemb, const float* d_glin, void* stream) {
+    DCTR_REQUIRE(E && (n == 0 || (d_rows && d_gemb)), "null argument");
+    DCTR_REQUIRE(n >= 0 && (int64_t)n <= E->group->max_entries, "too many rows (%d)", n);
+    hipStream_t st = as_stream(stream);
+    const dctr_config& c = E->cfg;
+    if (n > 0) {
+        DCTR_TRY(group_ids(E->group, d_rows, n, 1, st));
+        DCTR_TRY(embed_scatter_bwd(E->group, d_gemb, E->K, nullptr, 0, nullptr, nullptr, (E->lin && d_glin) ? d_glin : nullptr,
+                                   E->ones, n, 1, E->K, DCTR_GATHER_RAW, E->group->gemb, E->lin ? E->group->glin : nullptr, st));
+    } else {
+        DCTR_TRY(group_ids(E->group, E->ids, 0, 1, st));
+    }
+    return opt_table(c.optimizer, &E->state->hyper, E->h_state.hyper, c.table_mode, E->rows, E->K, E->emb, E->emb_s0, E->emb_s1,
+                     E->lin, E->lin_s0, E->lin_s1, E->group->slot, E->group->uniq, E->group->counters, E->group->max_entries,
+                     E->group->gemb, E->group->glin, c.l2_reg, E->scalars + 1, E->scalars + 2, st);
+}
+
+int dctr_step_begin(dctr_handle E, void* stream) {
+    DCTR_REQUIRE(E, "null handle");
+    DCTR_HIP_CHECK(hipMemsetAsync(E->scalars, 0, 8 * sizeof(float), as_stream(stream)));
+    return step_state_advance(E->state, as_stream(stream));
+}
+
+int dctr_sharded_forward_backward(dctr_handle E, const float* d_rows, const float* d_lin, int n_rows, const int32_t* d_idx,
+                                  const float* d_vals, const float* d_labels, int B, int global_batch, int train, void* stream) {
+    DCTR_REQUIRE(E && d_rows && d_idx && d_vals, "null argument");
+    DCTR_REQUIRE(B > 0 && B <= E->MB && global_batch >= B, "bad batch sizes B=%d global=%d", B, global_batch);
+    DCTR_REQUIRE(!train || d_labels, "labels required for training");
+    hipStream_t st = as_stream(stream);
+    const size_t n = (size_t)B * E->F;
+    if (d_vals != E->vals) DCTR_HIP_CHECK(hipMemcpyAsync(E->vals, d_vals, n * 4, hipMemcpyDeviceToDevice, st));
+    if (d_labels && d_labels != E->labels) DCTR_HIP_CHECK(hipMemcpyAsync(E->labels, d_labels, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    DCTR_TRY(forward_from(E, d_rows, E->lin ? d_lin : nullptr, n_rows, d_idx, B, train != 0, st));
+    DCTR_TRY(head(E, B, global_batch, d_labels != nullptr, st));
+    if (train) DCTR_TRY(backward_dense(E, B, st, st));
+    E->last_B = B;
+    return DCTR_OK;
+}
+
+int dctr_sharded_row_grads(dctr_handle E, dctr_group_t g, int B, void* stream) {
+    DCTR_REQUIRE(E && g, "null argument");
+    Group* G = reinterpret_cast<Group*>(g);
+    const int mode = gather_mode(E);
+    const float* dE = mode == DCTR_GATHER_BI ? nullptr : E->dx_in;
+    const float* coef = mode == DCTR_GATHER_FM ? E->dy : (mode == DCTR_GATHER_BI ? E->dx_in : nullptr);
+    return embed_scatter_bwd(G, dE, E->Din_ld, E->e, E->e_ld, E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F, E->K, mode,
+                             G->gemb, E->lin ? G->glin : nullptr, as_stream(stream));
+}
+
+int dctr_dense_grads(dctr_handle E, float** d_flat, int64_t* n, void* stream) {
+    DCTR_REQUIRE(E && d_flat && n, "null argument");
+    DCTR_TRY(opt_dense_arena(E->cfg.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->parts, E->meta,
+                             E->n_blocks, E->gflat, 0, nullptr, as_stream(stream)));
+    *d_flat = E->gflat;
+    *n = E->arena_n;
+    return DCTR_OK;
+}
+
+int dctr_dense_apply(dctr_handle E, void* stream) {
+    DCTR_REQUIRE(E, "null handle");
+    return opt_dense_arena(E->cfg.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->gflat, E->meta_flat,
+                           E->n_blocks, nullptr, 1, E->scalars + 3, as_stream(stream));
+}
+
+int dctr_read_scalars(dctr_handle E, float h_out[4], void* stream) {
+    DCTR_REQUIRE(E && h_out, "null argument");
+    DCTR_HIP_CHECK(hipMemcpyAsync(h_out, E->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, as_stream(stream)));
+    DCTR_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+    return DCTR_OK;
+}
+
+int dctr_last_outputs(dctr_handle E, float** d_prob, float** d_logit) {
+    DCTR_REQUIRE(E, "null handle");
+    if (d_prob) *d_prob = E->prob;
+    if (d_logit) *d_logit = E->y;
     return DCTR_OK;
 }
 

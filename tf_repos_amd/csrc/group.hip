@@ -245,10 +245,11 @@ int group_destroy(Group* g) {
 int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st) {
     const int64_t n = (int64_t)B * F;
     DCTR_REQUIRE(n <= g->max_entries, "group_ids: B*F=%lld exceeds capacity %lld", (long long)n, (long long)g->max_entries);
-    if (n <= 0) return DCTR_OK;
-    const int nb = ceil_div(n, 256);
+    // always forget the previous batch (slot words back to 0, U = 0), even for an empty one
     group_reset_kernel<<<ceil_div(g->max_entries, 256), 256, 0, st>>>(g->slot, g->uniq, g->counters, (int)g->max_entries);
     group_zero_counters<<<1, 1, 0, st>>>(g->counters);
+    if (n <= 0) { DCTR_LAUNCH_CHECK(); return DCTR_OK; }
+    const int nb = ceil_div(n, 256);
     group_count_kernel<<<nb, 256, 0, st>>>(ids, B, F, g->rows, g->slot, g->uniq, g->counters);
     const int KQ = g->K / 4;
     dim3 fgrid(ceil_div(n * KQ, 256));

@@ -1,0 +1,119 @@
+"""input_fn side of the hot path (DeepFM.py:63-98): libsvm text -> batched (feat_ids, feat_vals, labels).
+
+The text decode (K1) is the C ABI's dctr_parse_libsvm -- host C++ inside libdeepctr_hip.so, re-entrant, so a file is
+split on line boundaries and parsed by a thread pool (ctypes releases the GIL) like tf.data's
+map(decode_libsvm, num_parallel_calls=10) (DeepFM.py:84).  Batches are staged in pinned host memory and copied to
+the GPU on a side stream so the training step never waits for the parser.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from concurrent.futures import ThreadPoolExecutor
+from typing import Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import capi, errors
+
+
+def parse_libsvm(text, field_size: int, max_rows: Optional[int] = None):
+    """One call into the C parser.  text: str or bytes of whole lines.  Returns (ids i32 [n,F], vals f32 [n,F], labels f32 [n])."""
+    if isinstance(text, str):
+        text = text.encode()
+    n_lines = text.count(b"\n") + (0 if text.endswith(b"\n") or not text else 1)
+    cap = n_lines if max_rows is None else min(n_lines, max_rows)
+    ids = np.empty((max(cap, 1), field_size), dtype=np.int32)
+    vals = np.empty((max(cap, 1), field_size), dtype=np.float32)
+    labels = np.empty(max(cap, 1), dtype=np.float32)
+    n = C.c_int64()
+    used = C.c_size_t()
+    capi.check(capi.lib().dctr_parse_libsvm(text, len(text), field_size, cap, capi.ptr(ids), capi.ptr(vals), capi.ptr(labels),
+                                            C.byref(n), C.byref(used)))
+    k = n.value
+    return ids[:k], vals[:k], labels[:k]
+
+
+def _split_on_lines(buf: bytes, parts: int) -> List[bytes]:
+    if parts <= 1 or len(buf) < (1 << 16):
+        return [buf]
+    out, start = [], 0
+    step = len(buf) // parts
+    for i in range(1, parts):
+        cut = buf.find(b"\n", start + step)
+        if cut < 0:
+            break
+        out.append(buf[start:cut + 1])
+        start = cut + 1
+    out.append(buf[start:])
+    return [b for b in out if b]
+
+
+def parse_file(path: str, field_size: int, threads: int = 10):
+    with open(path, "rb") as f:
+        buf = f.read()
+    chunks = _split_on_lines(buf, threads)
+    if len(chunks) == 1:
+        return parse_libsvm(chunks[0], field_size)
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        parts = list(ex.map(lambda c: parse_libsvm(c, field_size), chunks))
+    return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts]))
+
+
+class LibsvmDataset:
+    """TextLineDataset(filenames).map(decode_libsvm, 10).prefetch().[shuffle(256)].repeat(num_epochs).batch(batch_size)
+    (DeepFM.py:84-92) as a Python iterator of numpy batches; the last batch may be short."""
+
+    def __init__(self, filenames: Sequence[str], field_size: int, batch_size: int = 32, num_epochs: int = 1,
+                 perform_shuffle: bool = False, threads: int = 10, seed: int = 0, binary_cache: bool = True):
+        self.filenames = [filenames] if isinstance(filenames, str) else list(filenames)
+        self.field_size = field_size
+        self.batch_size = batch_size
+        self.num_epochs = num_epochs
+        self.perform_shuffle = perform_shuffle
+        self.threads = threads
+        self.seed = seed
+        self.binary_cache = binary_cache
+        self._cache = {}
+
+    def _load(self, path):
+        if path in self._cache:
+            return self._cache[path]
+        npz = path + ".f%d.dctr.npz" % self.field_size
+        if self.binary_cache and os.path.exists(npz) and os.path.getmtime(npz) >= os.path.getmtime(path):
+            z = np.load(npz)
+            data = (z["ids"], z["vals"], z["labels"])
+        else:
+            data = parse_file(path, self.field_size, self.threads)
+            if self.binary_cache:
+                try:
+                    np.savez(npz, ids=data[0], vals=data[1], labels=data[2])     # pre-tokenised cache
+                except OSError:
+                    pass
+        self._cache[path] = data
+        return data
+
+    def __iter__(self) -> Iterator[Tuple[np.ndarray, np.ndarray, np.ndarray]]:
+        rng = np.random.default_rng(self.seed)
+        B = self.batch_size
+        carry = None
+        for _epoch in range(self.num_epochs):
+            for path in self.filenames:
+                ids, vals, labels = self._load(path)
+                if self.perform_shuffle:          # shuffle(buffer_size=256): windowed shuffle (DeepFM.py:88)
+                    n = len(labels)
+                    perm = np.arange(n)
+                    for s in range(0, n, 256):
+                        rng.shuffle(perm[s:s + 256])
+                    ids, vals, labels = ids[perm], vals[perm], labels[perm]
+                if carry is not None:
+                    ids = np.concatenate([carry[0], ids]); vals = np.concatenate([carry[1], vals]); labels = np.concatenate([carry[2], labels])
+                    carry = None
+                n = len(labels)
+                full = n // B * B
+                for s in range(0, full, B):
+                    yield ids[s:s + B], vals[s:s + B], labels[s:s + B]
+                if full < n:
+                    carry = (ids[full:], vals[full:], labels[full:])
+        if carry is not None and len(carry[2]) > 0:
+            yield carry
