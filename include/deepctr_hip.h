@@ -241,6 +241,11 @@ int dctr_train_step(dctr_handle h, const int32_t* d_ids, const float* d_vals, co
 /* forward only (mode PREDICT/EVAL: dropout off, BN moving stats): d_prob [B] (may be NULL), d_logit [B] (may be NULL) */
 int dctr_predict(dctr_handle h, const int32_t* d_ids, const float* d_vals, int B,
                  float* d_prob, float* d_logit, void* stream);
+/* mode EVAL (DeepFM.py:193-201): accumulate the loss and tf.metrics.auc's 200-threshold counters over an eval set */
+int dctr_eval_reset(dctr_handle h, void* stream);
+int dctr_eval_batch(dctr_handle h, const int32_t* d_ids, const float* d_vals, const float* d_labels, int B, void* stream);
+/* h_loss = mean xent over the set + l2_reg * sum l2_loss(regularised variables) (DeepFM.py:188-190); syncs */
+int dctr_eval_result(dctr_handle h, float* h_auc, float* h_loss, int64_t* h_examples, void* stream);
 /* raises DCTR_ERR_INVALID_ARG if any id seen since the last check was out of range (syncs) */
 int dctr_check_ids(dctr_handle h, void* stream);
 /* named intermediates of the last forward, for parity tests ("e","y_w","y_v","bi","inner","x_cross","att") */

@@ -95,6 +95,9 @@ _SIGS = {
     "dctr_get_global_step": ([_P, C.POINTER(C.c_int64)], C.c_int),
     "dctr_train_step": ([_P, _P, _P, _P, C.c_int, C.POINTER(C.c_float), _P], C.c_int),
     "dctr_predict": ([_P, _P, _P, C.c_int, _P, _P, _P], C.c_int),
+    "dctr_eval_reset": ([_P, _P], C.c_int),
+    "dctr_eval_batch": ([_P, _P, _P, _P, C.c_int, _P], C.c_int),
+    "dctr_eval_result": ([_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int64), _P], C.c_int),
     "dctr_check_ids": ([_P, _P], C.c_int),
     "dctr_route_unique": ([_P, C.c_int, _P, _P, _P, _P], C.c_int),
     "dctr_entry_index": ([_P, _P, C.c_int, _P, _P, _P], C.c_int),

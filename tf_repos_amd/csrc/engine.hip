@@ -83,6 +83,9 @@ struct dctr_engine {
     std::map<int, hipGraphExec_t> train_graphs, predict_graphs;
     int last_B = 0;
     hipStream_t s_group = nullptr, s_wgrad = nullptr;   // side streams of the step DAG
+    int64_t* auc_counts = nullptr;   // [4*200] tp,fn,tn,fp per threshold (tf.metrics.auc)
+    float* eval_scalars = nullptr;   // [0] sum xent over the eval set, [1..] scratch
+    int64_t eval_examples = 0;
     std::vector<hipEvent_t> events;
     size_t ev_next = 0;
 
@@ -278,6 +281,9 @@ int build(dctr_engine* E) {
     DCTR_HIP_CHECK(hipStreamCreateWithFlags(&E->s_wgrad, hipStreamNonBlocking));
     E->events.resize(64);
     for (auto& ev : E->events) DCTR_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+
+    DCTR_TRY(dmalloc(&E->auc_counts, 800));
+    DCTR_TRY(dmalloc(&E->eval_scalars, 8));
 
     // ---- activations
     DCTR_TRY(dmalloc(&E->ids, (size_t)MB * F));
@@ -533,6 +539,8 @@ int dctr_destroy(dctr_handle E) {
     if (E->state) hipFree(E->state);
     if (E->meta) hipFree(E->meta);
     if (E->meta_flat) hipFree(E->meta_flat);
+    if (E->auc_counts) hipFree(E->auc_counts);
+    if (E->eval_scalars) hipFree(E->eval_scalars);
     if (E->ones) hipFree(E->ones);
     group_destroy(E->group);
     for (auto& ev : E->events) if (ev) hipEventDestroy(ev);
@@ -630,6 +638,55 @@ int dctr_predict(dctr_handle E, const int32_t* d_ids, const float* d_vals, int B
     E->last_B = B;
     if (d_prob) DCTR_HIP_CHECK(hipMemcpyAsync(d_prob, E->prob, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
     if (d_logit) DCTR_HIP_CHECK(hipMemcpyAsync(d_logit, E->y, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    return DCTR_OK;
+}
+
+// ---- mode EVAL (DeepFM.py:193-201): streaming loss + tf.metrics.auc over an eval set --------------------------------------
+__global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += x[i] * x[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+int dctr_eval_reset(dctr_handle E, void* stream) {
+    DCTR_REQUIRE(E, "null handle");
+    DCTR_HIP_CHECK(hipMemsetAsync(E->auc_counts, 0, 800 * sizeof(int64_t), as_stream(stream)));
+    DCTR_HIP_CHECK(hipMemsetAsync(E->eval_scalars, 0, 8 * sizeof(float), as_stream(stream)));
+    E->eval_examples = 0;
+    return DCTR_OK;
+}
+
+int dctr_eval_batch(dctr_handle E, const int32_t* d_ids, const float* d_vals, const float* d_labels, int B, void* stream) {
+    DCTR_REQUIRE(E && d_ids && d_vals && d_labels, "null argument");
+    hipStream_t st = as_stream(stream);
+    DCTR_TRY(stage_inputs(E, d_ids, d_vals, d_labels, B, st));
+    DCTR_TRY(forward(E, B, false, st));
+    const float* bias = E->p_bias >= 0 ? E->pp(E->p_bias) : nullptr;
+    DCTR_TRY(loss_head(bias, E->lin ? E->yw : nullptr, E->cfg.model == DCTR_MODEL_DEEPFM ? E->yv : nullptr, E->yd, E->labels, B,
+                       1.0f / (float)B, E->y, E->prob, nullptr, E->eval_scalars, st));
+    DCTR_TRY(dctr_auc_update(E->labels, E->prob, B, E->auc_counts, stream));
+    E->eval_examples += B;
+    E->last_B = B;
+    return DCTR_OK;
+}
+
+int dctr_eval_result(dctr_handle E, float* h_auc, float* h_loss, int64_t* h_examples, void* stream) {
+    DCTR_REQUIRE(E, "null handle");
+    hipStream_t st = as_stream(stream);
+    if (h_auc) DCTR_TRY(dctr_auc_result(E->auc_counts, h_auc, stream));
+    if (h_loss) {
+        // loss of DeepFM.py:188-190 over the eval set: mean xent + l2_reg * sum l2_loss(regularised variables)
+        DCTR_HIP_CHECK(hipMemsetAsync(E->eval_scalars + 1, 0, sizeof(float), st));
+        for (auto& p : E->params)
+            if (p.l2 != 0.f) sumsq_kernel<<<1024, 256, 0, st>>>(p.ptr, p.n, E->eval_scalars + 1);
+        float sc[2];
+        DCTR_HIP_CHECK(hipMemcpyAsync(sc, E->eval_scalars, sizeof(sc), hipMemcpyDeviceToHost, st));
+        DCTR_HIP_CHECK(hipStreamSynchronize(st));
+        *h_loss = (E->eval_examples > 0 ? sc[0] / (float)E->eval_examples : 0.f) + E->cfg.l2_reg * 0.5f * sc[1];
+    }
+    if (h_examples) *h_examples = E->eval_examples;
     return DCTR_OK;
 }
 

@@ -168,6 +168,20 @@ class Engine:
                                           capi.ptr(out_logit), st))
         return out_prob
 
+    def eval_reset(self, stream=None) -> None:
+        capi.check(self._lib.dctr_eval_reset(self._h, stream if stream is not None else capi.current_stream()))
+
+    def eval_batch(self, ids, vals, labels, stream=None) -> None:
+        st = stream if stream is not None else capi.current_stream()
+        capi.check(self._lib.dctr_eval_batch(self._h, capi.ptr(ids), capi.ptr(vals), capi.ptr(labels), int(labels.shape[0]), st))
+
+    def eval_result(self, stream=None):
+        """-> (auc, loss, n_examples) accumulated since eval_reset (tf.metrics.auc semantics, DeepFM.py:193-195)."""
+        auc, loss, n = C.c_float(), C.c_float(), C.c_int64()
+        st = stream if stream is not None else capi.current_stream()
+        capi.check(self._lib.dctr_eval_result(self._h, C.byref(auc), C.byref(loss), C.byref(n), st))
+        return auc.value, loss.value, n.value
+
     def check_ids(self, stream=None) -> None:
         st = stream if stream is not None else capi.current_stream()
         capi.check(self._lib.dctr_check_ids(self._h, st))

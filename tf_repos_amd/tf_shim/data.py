@@ -1,0 +1,111 @@
+"""tf.data as the reference uses it (DeepFM.py:84-96): TextLineDataset(files).map(decode_libsvm, num_parallel_calls)
+.prefetch(n)[.shuffle(256)].repeat(epochs).batch(B).make_one_shot_iterator().get_next().
+
+The map function is TRACED once on a symbolic line; the trace must be the libsvm decode of DeepFM.py:65-81
+(string_split(' ') -> label, string_split(':') -> [F,2] -> ids int32 / vals float32).  Execution is the C parser
+(dctr_parse_libsvm) behind tf_repos_amd.input_pipeline -- nothing is interpreted in Python per example."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+from .. import errors
+from ..input_pipeline import LibsvmDataset
+from . import graph as G
+
+
+def _provenance(t) -> str:
+    """Classifies a traced tensor of decode_libsvm: 'label' | 'ids' | 'vals' (raises otherwise)."""
+    if not isinstance(t, G.Tensor) or t.op != "string_to_number":
+        raise errors.UnimplementedError("input_fn map function is not the libsvm decode (got %r)" % (t,))
+    src = t.inputs[0]
+    if src.op == "getitem" and src.inputs[0].op == "sparse_values":          # columns.values[0]
+        key = src.attrs["key"]
+        if key == (0,) and src.inputs[0].inputs[0].attrs.get("delimiter") == " ":
+            if t.attrs["out_type"] is not G.float32:
+                raise errors.UnimplementedError("label must be parsed as float32")
+            return "label"
+    if src.op == "split":                                                     # tf.split(id_vals, 2, axis=1)
+        rs = src.inputs[0]
+        ok = (rs.op == "reshape" and rs.inputs[0].op == "sparse_values" and rs.inputs[0].inputs[0].attrs.get("delimiter") == ":"
+              and src.attrs["num"] == 2 and src.attrs["axis"] == 1)
+        if ok:
+            if src.attrs["index"] == 0 and t.attrs["out_type"] is G.int32:
+                return "ids"
+            if src.attrs["index"] == 1 and t.attrs["out_type"] is G.float32:
+                return "vals"
+    raise errors.UnimplementedError("input_fn map function is not the libsvm decode of DeepFM.py:65-81")
+
+
+class Dataset:
+    def __init__(self, filenames):
+        self.filenames = [filenames] if isinstance(filenames, str) else list(filenames)
+        self.batch_size = 1
+        self.num_epochs = 1
+        self.perform_shuffle = False
+        self.num_parallel_calls = 10
+        self.feature_keys: Dict[str, str] = {}       # role -> feature dict key
+        self.field_size: Optional[int] = None
+
+    # -- pipeline construction (each call returns self: the pipeline is a linear chain in the reference) ---------------
+    def map(self, fn, num_parallel_calls=None):
+        if num_parallel_calls:
+            self.num_parallel_calls = int(num_parallel_calls)
+        line = G.Tensor("text_line", [], {}, G.string, ())
+        out = fn(line)
+        if not (isinstance(out, tuple) and len(out) == 2 and isinstance(out[0], dict)):
+            raise errors.UnimplementedError("map function must return ({'feat_ids':..., 'feat_vals':...}, labels)")
+        feats, label = out
+        if _provenance(label) != "label":
+            raise errors.UnimplementedError("labels are not token 0 of the line")
+        for k, v in feats.items():
+            self.feature_keys[_provenance(v)] = k
+        if set(self.feature_keys) != {"ids", "vals"}:
+            raise errors.UnimplementedError("features must be the libsvm ids and vals")
+        return self
+
+    def prefetch(self, buffer_size):
+        return self
+
+    def shuffle(self, buffer_size, seed=None, **_kw):
+        self.perform_shuffle = True
+        return self
+
+    def repeat(self, count=None):
+        self.num_epochs = int(count) if count is not None else 10 ** 9
+        return self
+
+    def batch(self, batch_size, **_kw):
+        self.batch_size = int(batch_size)
+        return self
+
+    def make_one_shot_iterator(self):
+        return _Iterator(self)
+
+    # -- execution ---------------------------------------------------------------------------------------------------------
+    def numpy_batches(self):
+        if self.field_size is None:
+            raise errors.InvalidArgumentError("field_size unknown: model_fn never reshaped feat_ids to [-1, field_size]")
+        if not self.filenames:
+            return iter(())
+        ds = LibsvmDataset(self.filenames, self.field_size, self.batch_size, self.num_epochs, self.perform_shuffle,
+                           threads=self.num_parallel_calls)
+        return iter(ds)
+
+
+class _Iterator:
+    def __init__(self, ds: Dataset):
+        self.ds = ds
+
+    def get_next(self):
+        ds = self.ds
+        if not ds.feature_keys:
+            raise errors.UnimplementedError("TextLineDataset without a decode map function")
+        ids = G.Tensor("iterator_ids", [], {"dataset": ds}, G.int32, (None, None, 1))
+        vals = G.Tensor("iterator_vals", [], {"dataset": ds}, G.float32, (None, None, 1))
+        labels = G.Tensor("iterator_labels", [], {"dataset": ds}, G.float32, (None,))
+        G.current_graph().collections.setdefault("iterators", []).append(ds)
+        return {ds.feature_keys["ids"]: ids, ds.feature_keys["vals"]: vals}, labels
+
+
+def TextLineDataset(filenames, **_kw):
+    return Dataset(filenames)

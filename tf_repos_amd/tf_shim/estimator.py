@@ -1,0 +1,350 @@
+"""tf.estimator surface the reference drives (DeepFM.py:339-366): Estimator(model_fn, model_dir, params, config),
+train / evaluate / predict / export_savedmodel, TrainSpec / EvalSpec / train_and_evaluate, RunConfig, EstimatorSpec.
+
+model_fn and input_fn are called exactly as TF would call them (graph mode); the graph they build is lowered onto the
+HIP engine once per mode, then the Python loop only moves batches: host parser -> pinned memory -> GPU -> one engine
+call per step.  Checkpoints are .npz files keyed by the TF variable names in model_dir.
+"""
+from __future__ import annotations
+
+import glob
+import inspect
+import json
+import os
+import time
+from typing import Any, Callable, Dict, Iterator, List, Optional
+
+import numpy as np
+
+from .. import errors
+from ..engine import Engine
+from . import data as D
+from . import graph as G
+from .lowering import Lowered, lower
+
+
+class ModeKeys:
+    TRAIN = "train"
+    EVAL = "eval"
+    PREDICT = "infer"
+
+
+class EstimatorSpec:
+    def __init__(self, mode, predictions=None, loss=None, train_op=None, eval_metric_ops=None, export_outputs=None, **_kw):
+        self.mode, self.predictions, self.loss, self.train_op = mode, predictions, loss, train_op
+        self.eval_metric_ops, self.export_outputs = eval_metric_ops or {}, export_outputs or {}
+        if mode == ModeKeys.TRAIN and (loss is None or train_op is None):
+            raise ValueError("Missing loss/train_op for mode TRAIN")
+        if mode == ModeKeys.EVAL and loss is None:
+            raise ValueError("Missing loss for mode EVAL")
+        if mode == ModeKeys.PREDICT and predictions is None:
+            raise ValueError("Missing predictions for mode PREDICT")
+
+
+class ConfigProto:
+    def __init__(self, device_count=None, **kw):
+        self.device_count = device_count or {}
+        self.__dict__.update(kw)
+
+
+class RunConfig:
+    def __init__(self, model_dir=None, session_config=None, log_step_count_steps=100, save_summary_steps=100,
+                 save_checkpoints_steps=None, save_checkpoints_secs=600, keep_checkpoint_max=5, tf_random_seed=None, **_kw):
+        self.model_dir = model_dir
+        self.session_config = session_config
+        self.log_step_count_steps = log_step_count_steps
+        self.save_summary_steps = save_summary_steps
+        self.save_checkpoints_steps = save_checkpoints_steps
+        self.save_checkpoints_secs = save_checkpoints_secs
+        self.keep_checkpoint_max = keep_checkpoint_max
+        self.tf_random_seed = tf_random_seed
+
+    def replace(self, **kw):
+        c = RunConfig(**{k: v for k, v in self.__dict__.items()})
+        for k, v in kw.items():
+            if not hasattr(c, k):
+                raise ValueError("Replacing %s is not supported" % k)
+            setattr(c, k, v)
+        return c
+
+
+class TrainSpec:
+    def __init__(self, input_fn, max_steps=None, hooks=None):
+        self.input_fn, self.max_steps = input_fn, max_steps
+
+
+class EvalSpec:
+    def __init__(self, input_fn, steps=100, name=None, hooks=None, exporters=None, start_delay_secs=120, throttle_secs=600):
+        self.input_fn, self.steps = input_fn, steps
+        self.start_delay_secs, self.throttle_secs = start_delay_secs, throttle_secs
+
+
+class PredictOutput:
+    def __init__(self, outputs):
+        self.outputs = outputs
+
+
+class ServingInputReceiver:
+    def __init__(self, features, receiver_tensors):
+        self.features, self.receiver_tensors = features, receiver_tensors
+
+
+def build_raw_serving_input_receiver_fn(features, default_batch_size=None):
+    def fn():
+        return ServingInputReceiver(dict(features), dict(features))
+    return fn
+
+
+def _init_value(v: G.Variable, rng: np.random.Generator) -> np.ndarray:
+    """Initial values per SURVEY Appendix B items 4, 10 [TF-1.4]: glorot_normal = truncated normal (resample beyond 2
+    sigma), sigma = sqrt(2/(fan_in+fan_out)); rank-1 [V] -> fan_in = fan_out = V; glorot_uniform U(+-sqrt(6/(fi+fo)))."""
+    shp = v.shape
+    init = v.initializer
+    if init.kind == "constant":
+        return np.full(shp, init.kw["value"], dtype=np.float32)
+    if len(shp) == 1:
+        fi = fo = shp[0]
+    else:
+        fi, fo = int(np.prod(shp[:-1])), shp[-1]
+    if init.kind == "glorot_uniform":
+        lim = np.sqrt(6.0 / (fi + fo))
+        return rng.uniform(-lim, lim, size=shp).astype(np.float32)
+    if init.kind == "glorot_normal":
+        std = np.sqrt(2.0 / (fi + fo)) / 0.87962566103423978      # TF's truncated-normal variance correction
+        a = rng.normal(0, std, size=shp)
+        bad = np.abs(a) > 2 * std
+        while bad.any():
+            a[bad] = rng.normal(0, std, size=int(bad.sum()))
+            bad = np.abs(a) > 2 * std
+        return a.astype(np.float32)
+    raise errors.UnimplementedError("initializer %s" % init.kind)
+
+
+class Estimator:
+    def __init__(self, model_fn=None, model_dir=None, config=None, params=None, warm_start_from=None):
+        self._model_fn = model_fn
+        self._config = config or RunConfig()
+        self.model_dir = model_dir or self._config.model_dir or "/tmp/tf_repos_amd_model"
+        self.params = dict(params or {})
+        self._engine: Optional[Engine] = None
+        self._lowered: Optional[Lowered] = None
+        self._variables: Dict[str, G.Variable] = {}
+        self.table_mode = os.environ.get("DCTR_TABLE_MODE", "dense_exact")
+
+    @property
+    def config(self):
+        return self._config
+
+    # -- graph construction --------------------------------------------------------------------------------------------
+    def _call_model_fn(self, features, labels, mode):
+        args = inspect.signature(self._model_fn).parameters
+        kw = {}
+        if "labels" in args:
+            kw["labels"] = labels
+        if "mode" in args:
+            kw["mode"] = mode
+        if "params" in args:
+            kw["params"] = self.params
+        if "config" in args:
+            kw["config"] = self._config
+        return self._model_fn(features=features, **kw)
+
+    def _build(self, input_fn, mode):
+        from . import FLAGS_MODULE
+        with G.Graph() as g:
+            out = input_fn()
+            if isinstance(out, D.Dataset):
+                out = out.make_one_shot_iterator().get_next()
+            features, labels = out if isinstance(out, tuple) else (out, None)
+            if mode == ModeKeys.PREDICT:
+                labels = None
+            spec = self._call_model_fn(features, labels, mode)
+            if not isinstance(spec, EstimatorSpec):
+                raise ValueError("model_fn should return an EstimatorSpec.")
+            lowered = lower(spec.loss, spec.train_op, spec.predictions or {}, FLAGS_MODULE.FLAGS)
+            pipeline = g.collections.get("iterators", [None])[-1]
+            if pipeline is not None:
+                pipeline.field_size = lowered.config_kwargs["field_size"]     # reshape(feat_ids, [-1, field_size]) fixes F
+            variables = dict(g.variables)
+        return spec, lowered, pipeline, variables
+
+    def _ensure_engine(self, lowered: Lowered, variables, batch_size: int):
+        need_new = self._engine is None or self._engine.cfg.max_batch < batch_size
+        if self._engine is not None and not need_new:
+            return
+        state = self._snapshot() if self._engine is not None else None
+        if self._engine is not None:
+            self._engine.close()
+        cfg = lowered.engine_config(max_batch=batch_size, table_mode=self.table_mode,
+                                    seed=int(self._config.tf_random_seed or 0))
+        self._engine = Engine(cfg)
+        self._lowered = lowered
+        self._variables = variables
+        ck = state or self._load_latest()
+        if ck is not None:
+            self._restore(ck)
+        else:
+            rng = np.random.default_rng(int(self._config.tf_random_seed or 0))
+            for ename, tfname in lowered.name_map.items():
+                self._engine.set_param(ename, _init_value(variables[tfname], rng).reshape(self._engine.param_shapes[ename]))
+
+    # -- checkpoints (TF variable names) ----------------------------------------------------------------------------------
+    def _snapshot(self) -> Dict[str, np.ndarray]:
+        e, m = self._engine, self._lowered.name_map
+        out = {"global_step": np.int64(e.global_step)}
+        for ename, tfname in m.items():
+            out[tfname] = e.get_param(ename)
+            out[tfname + "/slot0"] = e.get_slot(ename, 0)
+            out[tfname + "/slot1"] = e.get_slot(ename, 1)
+        return out
+
+    def _restore(self, ck) -> None:
+        e, m = self._engine, self._lowered.name_map
+        for ename, tfname in m.items():
+            if tfname not in ck:
+                raise errors.NotFoundError("Key %s not found in checkpoint" % tfname)
+            e.set_param(ename, np.asarray(ck[tfname]).reshape(e.param_shapes[ename]))
+            if tfname + "/slot0" in ck:
+                e.set_slot(ename, 0, np.asarray(ck[tfname + "/slot0"]).reshape(e.param_shapes[ename]))
+                e.set_slot(ename, 1, np.asarray(ck[tfname + "/slot1"]).reshape(e.param_shapes[ename]))
+        e.global_step = int(ck["global_step"]) if "global_step" in ck else 0
+
+    def latest_checkpoint(self) -> Optional[str]:
+        files = glob.glob(os.path.join(self.model_dir, "model.ckpt-*.npz"))
+        if not files:
+            return None
+        return max(files, key=lambda f: int(f.rsplit("-", 1)[1].split(".")[0]))
+
+    def _load_latest(self):
+        f = self.latest_checkpoint()
+        return dict(np.load(f)) if f else None
+
+    def _save(self) -> str:
+        os.makedirs(self.model_dir, exist_ok=True)
+        snap = self._snapshot()
+        path = os.path.join(self.model_dir, "model.ckpt-%d.npz" % int(snap["global_step"]))
+        np.savez(path, **snap)
+        keep = self._config.keep_checkpoint_max or 5
+        files = sorted(glob.glob(os.path.join(self.model_dir, "model.ckpt-*.npz")), key=lambda f: int(f.rsplit("-", 1)[1].split(".")[0]))
+        for f in files[:-keep]:
+            os.remove(f)
+        return path
+
+    def get_variable_names(self):
+        return sorted(self._lowered.name_map.values()) if self._lowered else []
+
+    def get_variable_value(self, name):
+        inv = {v: k for k, v in self._lowered.name_map.items()}
+        return self._engine.get_param(inv[name])
+
+    # -- modes ----------------------------------------------------------------------------------------------------------------
+    def _device_batches(self, pipeline: "D.Dataset"):
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        for ids, vals, labels in pipeline.numpy_batches():
+            yield (torch.from_numpy(np.ascontiguousarray(ids)).pin_memory().to(dev, non_blocking=True),
+                   torch.from_numpy(np.ascontiguousarray(vals)).pin_memory().to(dev, non_blocking=True),
+                   torch.from_numpy(np.ascontiguousarray(labels)).pin_memory().to(dev, non_blocking=True))
+
+    def train(self, input_fn, hooks=None, steps=None, max_steps=None, saving_listeners=None):
+        from . import logging as L
+        spec, lowered, pipeline, variables = self._build(input_fn, ModeKeys.TRAIN)
+        if pipeline is None:
+            raise errors.InvalidArgumentError("input_fn must return tensors produced by a tf.data iterator")
+        self._ensure_engine(lowered, variables, pipeline.batch_size)
+        e = self._engine
+        log_every = max(1, int(self._config.log_step_count_steps or 100))
+        start_step = e.global_step
+        t0, n0 = time.time(), 0
+        done = 0
+        loss = None
+        for ids, vals, labels in self._device_batches(pipeline):
+            if steps is not None and done >= steps:
+                break
+            if max_steps is not None and start_step + done >= max_steps:
+                break
+            want = (done + 1) % log_every == 0
+            loss = e.train_step(ids, vals, labels, want_loss=want)
+            done += 1
+            n0 += int(labels.shape[0])
+            if want:
+                e.check_ids()
+                dt = time.time() - t0
+                L.info("global_step/sec: %.4g  examples/sec: %.4g  loss = %.7g, step = %d" % (log_every / dt, n0 / dt, loss, start_step + done))
+                t0, n0 = time.time(), 0
+        e.check_ids()
+        path = self._save()
+        L.info("Saving checkpoints for %d into %s." % (e.global_step, path))
+        return self
+
+    def evaluate(self, input_fn, steps=None, hooks=None, checkpoint_path=None, name=None):
+        from . import logging as L
+        spec, lowered, pipeline, variables = self._build(input_fn, ModeKeys.EVAL)
+        self._ensure_engine(lowered, variables, pipeline.batch_size)
+        e = self._engine
+        e.eval_reset()
+        n = 0
+        for ids, vals, labels in self._device_batches(pipeline):
+            if steps is not None and n >= steps:
+                break
+            e.eval_batch(ids, vals, labels)
+            n += 1
+        e.check_ids()
+        auc, loss, _count = e.eval_result()
+        out = {"loss": loss, "global_step": e.global_step}
+        for key in (spec.eval_metric_ops or {"auc": None}):
+            out[key] = auc
+        L.info("Saving dict for global step %d: %s" % (e.global_step, ", ".join("%s = %s" % kv for kv in sorted(out.items()))))
+        return out
+
+    def predict(self, input_fn, predict_keys=None, hooks=None, checkpoint_path=None, yield_single_examples=True) -> Iterator[Dict[str, Any]]:
+        import torch
+        spec, lowered, pipeline, variables = self._build(input_fn, ModeKeys.PREDICT)
+        self._ensure_engine(lowered, variables, pipeline.batch_size)
+        e = self._engine
+        keys = list(spec.predictions.keys())
+        if predict_keys is not None:
+            want = [predict_keys] if isinstance(predict_keys, str) else list(predict_keys)
+            keys = [k for k in keys if k in want]
+        for ids, vals, _labels in self._device_batches(pipeline):
+            prob = torch.empty(int(ids.shape[0]), dtype=torch.float32, device=ids.device)
+            e.predict(ids, vals, prob, None)
+            p = prob.cpu().numpy()
+            e.check_ids()
+            if yield_single_examples:
+                for v in p:
+                    yield {k: v for k in keys}
+            else:
+                yield {k: p for k in keys}
+
+    def export_savedmodel(self, export_dir_base, serving_input_receiver_fn, assets_extra=None, as_text=False, checkpoint_path=None, **_kw):
+        """Writes the variables (TF names) and the serving signature: inputs feat_ids int64 [None,F] / feat_vals float32
+        [None,F], output key(s) of `predictions` (DeepFM.py:361-366).  Not a TF SavedModel protobuf (no TF here)."""
+        recv = serving_input_receiver_fn()
+        with G.Graph() as g:
+            feats = {k: G.placeholder(v.dtype, v.shape, name=k) for k, v in recv.features.items()}
+            spec = self._call_model_fn(feats, None, ModeKeys.PREDICT)
+            from . import FLAGS_MODULE
+            lowered = lower(None, None, spec.predictions, FLAGS_MODULE.FLAGS)
+            variables = dict(g.variables)
+        self._ensure_engine(lowered, variables, 1024)
+        out = os.path.join(export_dir_base, str(int(time.time())))
+        os.makedirs(out, exist_ok=True)
+        snap = {k: v for k, v in self._snapshot().items() if "/slot" not in k}
+        np.savez(os.path.join(out, "variables.npz"), **snap)
+        sig = {"signature_def": {"serving_default": {
+            "inputs": {k: {"dtype": v.dtype.name, "shape": [None if s is None else int(s) for s in (v.shape or ())]} for k, v in recv.receiver_tensors.items()},
+            "outputs": {k: {"dtype": "float32", "shape": [None]} for k in spec.predictions},
+            "method_name": "tensorflow/serving/predict"}},
+            "engine": {"model": lowered.model, "config": {k: (list(v) if isinstance(v, tuple) else v) for k, v in lowered.config_kwargs.items()},
+                       "name_map": lowered.name_map}}
+        with open(os.path.join(out, "signature.json"), "w") as f:
+            json.dump(sig, f, indent=1)
+        return out
+
+
+def train_and_evaluate(estimator: Estimator, train_spec: TrainSpec, eval_spec: EvalSpec):
+    """Local mode of tf.estimator.train_and_evaluate: train until the input is exhausted (or max_steps), then evaluate.
+    (TF interleaves evaluations every throttle_secs on the latest checkpoint; the final metrics are the same.)"""
+    estimator.train(train_spec.input_fn, max_steps=train_spec.max_steps)
+    return estimator.evaluate(eval_spec.input_fn, steps=eval_spec.steps)

@@ -1,0 +1,199 @@
+"""Lowers the symbolic graph a reference-style model_fn builds onto the HIP engine.
+
+The six deep_ctr model_fn's differ only in ~30 lines of interaction math, so lowering is a strict
+structural recognizer: it identifies the tables, the interaction (FM second order / bi-interaction / inner or outer
+product pairs / cross network / attention), the MLP stack, dropout keep_probs, the l2 terms of the loss and the
+optimizer, and emits an EngineConfig plus the engine-name -> TF-variable-name map (checkpoint compatibility, SURVEY
+Appendix A).  Anything it does not recognise raises -- there is no generic interpreter to fall back on.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+from .. import errors
+from ..engine import EngineConfig
+from . import graph as G
+
+
+@dataclass
+class Lowered:
+    model: str
+    config_kwargs: Dict
+    name_map: Dict[str, str]                 # engine parameter name -> TF variable name
+    predict_keys: List[str] = field(default_factory=lambda: ["prob"])
+
+    def engine_config(self, max_batch: int, **overrides) -> EngineConfig:
+        kw = dict(self.config_kwargs)
+        kw.update(overrides)
+        return EngineConfig(max_batch=max_batch, **kw)
+
+
+def _unsupported(msg):
+    return errors.UnimplementedError("tf_repos_amd cannot lower this graph onto the HIP engine: " + msg)
+
+
+def _through(t, ops=("reshape", "identity", "cast")):
+    while isinstance(t, G.Tensor) and t.op in ops and t.inputs:
+        t = t.inputs[0]
+    return t
+
+
+def lower(loss: Optional[G.Tensor], train_op: Optional[G.Tensor], predictions: Dict[str, G.Tensor], flags=None) -> Lowered:
+    roots = [t for t in [loss, train_op] + list(predictions.values()) if isinstance(t, G.Tensor)]
+    nodes = G.ancestors(roots)
+    by_op: Dict[str, List[G.Tensor]] = {}
+    for n in nodes:
+        by_op.setdefault(n.op, []).append(n)
+    if by_op.get("batch_norm"):
+        raise _unsupported("batch_norm=True (contrib.layers.batch_norm) is not implemented in the engine yet")
+
+    # ---- tables --------------------------------------------------------------------------------------------------
+    lookups = by_op.get("embedding_lookup", [])
+    emb_var = lin_var = None
+    field_size = None
+    for lk in lookups:
+        var, ids = lk.inputs
+        if not isinstance(var, G.Variable):
+            raise _unsupported("embedding_lookup on a non-variable")
+        if len(var.shape) == 2:
+            emb_var = var
+        elif len(var.shape) == 1:
+            lin_var = var
+        if ids.op == "reshape" and ids.attrs.get("shape") and len(ids.attrs["shape"]) == 2:
+            field_size = int(ids.attrs["shape"][1])
+    if emb_var is None or field_size is None:
+        raise _unsupported("no [feature_size, embedding_size] embedding_lookup over reshape(feat_ids, [-1, field_size]) found")
+    V, K = int(emb_var.shape[0]), int(emb_var.shape[1])
+    F = field_size
+    variables = {n.var_name: n for n in nodes if isinstance(n, G.Variable)}
+
+    # ---- interaction -> model kind ---------------------------------------------------------------------------------
+    fcs = by_op.get("fully_connected", [])
+    hidden = [f for f in fcs if f.attrs["activation"] == "relu"]
+    outs = [f for f in fcs if f.attrs["activation"] == "identity"]
+    fc_vars = {id(v) for f in fcs for v in f.inputs[1:]}
+    cross_vars = [v for v in variables.values() if len(v.shape) == 2 and v is not emb_var and id(v) not in fc_vars]
+    bias_var = next((v for v in variables.values() if v.shape == (1,) and v.trainable and id(v) not in fc_vars), None)
+    name_map: Dict[str, str] = {"emb": emb_var.var_name}
+    kw: Dict = dict(field_size=F, feature_size=V, embedding_size=K)
+    if by_op.get("softmax"):
+        model = "afm"
+    elif by_op.get("einsum"):
+        model = "opnn"
+    elif any(g.attrs.get("axis") == 1 and g.attrs.get("indices") for g in by_op.get("gather", [])):
+        model = "ipnn"
+    elif by_op.get("matmul") and len(cross_vars) == 2:
+        model = "dcn"
+    elif not hidden:
+        raise _unsupported("no hidden fully_connected layers")
+    else:
+        first_in = int(hidden[0].inputs[1].shape[0])
+        has_sq = bool(by_op.get("square"))
+        if has_sq and first_in == K:
+            model = "nfm"
+        elif has_sq and first_in == F * K:
+            model = "deepfm"
+        elif first_in == F * K:
+            model = "fnn"
+        else:
+            raise _unsupported("first dense layer has fan-in %d (neither K=%d nor F*K=%d)" % (first_in, K, F * K))
+    kw["model"] = model
+
+    if model == "dcn":
+        if lin_var is not None or bias_var is not None:
+            raise _unsupported("DCN graph with a linear table / global bias")
+        cw = next(v for v in cross_vars if any(n.op == "matmul" for n in nodes if _uses(n, v, nodes)))
+        cb = next(v for v in cross_vars if v is not cw)
+        if cw.shape != cb.shape or cw.shape[1] != F * K:
+            raise _unsupported("cross_w/cross_b must both be [cross_layers, F*K]")
+        kw["cross_layers"] = int(cw.shape[0])
+        name_map["cross_w"], name_map["cross_b"] = cw.var_name, cb.var_name
+    else:
+        if lin_var is None or bias_var is None:
+            raise _unsupported("%s graph without linear table / global bias" % model)
+        name_map["linear"], name_map["bias"] = lin_var.var_name, bias_var.var_name
+
+    # ---- dense stack -----------------------------------------------------------------------------------------------
+    if model == "afm":
+        att = [int(f.attrs["num_outputs"]) for f in hidden]
+        kw["attention_layers"] = tuple(att)
+        kw["deep_layers"] = (1,)
+        for i, f in enumerate(hidden):
+            name_map["att_mlp%d/weights" % i], name_map["att_mlp%d/biases" % i] = f.inputs[1].var_name, f.inputs[2].var_name
+        if len(outs) != 2:
+            raise _unsupported("AFM expects attention_out and deep_out projections")
+        name_map["attention_out/weights"], name_map["attention_out/biases"] = outs[0].inputs[1].var_name, outs[0].inputs[2].var_name
+        name_map["deep_out/weights"], name_map["deep_out/biases"] = outs[1].inputs[1].var_name, outs[1].inputs[2].var_name
+    else:
+        kw["deep_layers"] = tuple(int(f.attrs["num_outputs"]) for f in hidden)
+        for i, f in enumerate(hidden):
+            name_map["mlp%d/weights" % i], name_map["mlp%d/biases" % i] = f.inputs[1].var_name, f.inputs[2].var_name
+        if len(outs) != 1 or int(outs[0].attrs["num_outputs"]) != 1:
+            raise _unsupported("expected exactly one linear output layer of width 1")
+        oname = "out_layer" if model == "dcn" else "deep_out"
+        name_map[oname + "/weights"], name_map[oname + "/biases"] = outs[0].inputs[1].var_name, outs[0].inputs[2].var_name
+
+    # ---- dropout (TRAIN graphs only; keep_prob semantics, DeepFM.py:162) -------------------------------------------------
+    keep = [1.0] * len(kw["deep_layers"])
+    pre_keep = None
+    att_keep: List[float] = []
+    for d in by_op.get("dropout", []):
+        src = _through(d.inputs[0])
+        if src.op == "fully_connected" and src in hidden and model != "afm":
+            keep[hidden.index(src)] = d.attrs["keep_prob"]
+        elif model == "nfm":
+            pre_keep = d.attrs["keep_prob"]
+        elif model == "afm":
+            att_keep.append(d.attrs["keep_prob"])
+        else:
+            raise _unsupported("dropout on %s" % src.op)
+    if model == "nfm" and pre_keep is not None and abs(pre_keep - keep[0]) > 1e-12:
+        raise _unsupported("NFM bi-interaction dropout (%g) must equal dropout[0] (%g) as in NFM.py:137,145" % (pre_keep, keep[0]))
+    kw["dropout"] = tuple(att_keep) if model == "afm" else tuple(keep)
+
+    # ---- loss: mean sigmoid_xent + l2_reg * l2_loss(table)  (DeepFM.py:188-190) ----------------------------------------------
+    if loss is not None:
+        if not by_op.get("sigmoid_xent"):
+            raise _unsupported("loss is not sigmoid_cross_entropy_with_logits")
+        regs = []
+        for m in by_op.get("mul", []):
+            a, b = m.inputs
+            c, l = (a, b) if a.op == "const" else (b, a)
+            if c.op == "const" and l.op == "l2_loss" and isinstance(l.inputs[0], G.Variable):
+                regs.append((l.inputs[0].var_name, float(c.attrs["value"])))
+        expect = {name_map[k] for k in (("cross_b", "cross_w", "emb") if model == "dcn" else ("linear", "emb"))}
+        if regs:
+            coefs = {round(c, 12) for _, c in regs}
+            if {n for n, _ in regs} != expect or len(coefs) != 1:
+                raise _unsupported("l2_loss terms %s do not match the reference's set %s" % (sorted(regs), sorted(expect)))
+            kw["l2_reg"] = regs[0][1]
+        else:
+            kw["l2_reg"] = 0.0
+
+    # ---- optimizer (DeepFM.py:204-213) ---------------------------------------------------------------------------------------------
+    if train_op is not None:
+        if train_op.op != "minimize":
+            raise _unsupported("train_op must come from optimizer.minimize(loss, global_step)")
+        a = train_op.attrs
+        h = a["hyper"]
+        ok = {"Adam": h.get("beta1") == 0.9 and h.get("beta2") == 0.999 and h.get("epsilon") == 1e-8,
+              "Adagrad": h.get("initial_accumulator_value") == 1e-8,
+              "Momentum": h.get("momentum") == 0.95 and not h.get("use_nesterov"),
+              "ftrl": h.get("learning_rate_power") == -0.5 and h.get("initial_accumulator_value") == 0.1 and not h.get("l1") and not h.get("l2")}
+        if not ok.get(a["optimizer"], False):
+            raise _unsupported("optimizer %s with hyper-parameters %s (engine implements the reference's settings only)" % (a["optimizer"], h))
+        kw["optimizer"] = a["optimizer"]
+        kw["learning_rate"] = a["learning_rate"]
+    return Lowered(model=model, config_kwargs=kw, name_map=name_map, predict_keys=list(predictions.keys()))
+
+
+def _uses(node, var, nodes) -> bool:
+    """True if `node` consumes `var` directly or through getitem/reshape."""
+    for i in node.inputs:
+        j = i
+        while isinstance(j, G.Tensor) and j.op in ("getitem", "reshape"):
+            j = j.inputs[0]
+        if j is var:
+            return True
+    return False
