@@ -10,7 +10,7 @@ from tests.util import dev_batch, make_pair
 
 pytestmark = pytest.mark.gpu
 
-MODELS = ["deepfm", "fnn", "ipnn", "nfm", "dcn"]
+MODELS = ["deepfm", "fnn", "ipnn", "nfm", "dcn", "afm"]
 
 
 @pytest.mark.parametrize("model", MODELS + ["opnn"])

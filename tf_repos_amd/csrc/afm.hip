@@ -1,0 +1,249 @@
+// K3/K4 for AFM (AFM.py:127-162): pairwise element-wise products of the F scaled embeddings, a one-hidden-layer
+// attention MLP over the P = F(F-1)/2 pairs, softmax over the pairs, attention-weighted pooling, fc K -> 1.
+//
+//   pp[b,p,:]  = e[b,i_p,:] * e[b,j_p,:]                       AFM.py:134-138 (pairs lexicographic i<j)
+//   ah         = relu(pp W_a + b_a)   [B*P, A]                 AFM.py:142-145   -> fp32 MFMA GEMM (gemm.hip)
+//   s          = ah w_o + b_o         [B*P]                    AFM.py:147
+//   att        = softmax_p(s)         [B,P]                    AFM.py:151  (+ dropout[0] in TRAIN, :152-153)
+//   y_emb[b,:] = sum_p att[b,p] pp[b,p,:]   (+ dropout[1])     AFM.py:156-158
+//   y_deep     = y_emb w_d + b_d                               AFM.py:160-162
+// This first version materialises pp and ah in HBM (B*P*(K+A) floats: 3.1 GB each at B=4096, K=A=256 -- fits the
+// 288 GB part with room to spare) so that the attention layer is one large GEMM; the flash-style fusion that keeps
+// pp/ah on chip is listed as next work in DESIGN.md.
+#include "common.h"
+#include "engine.h"
+#include "ops.h"
+
+namespace dctr {
+
+__device__ __forceinline__ float wsum64(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float wmax64(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// pp4[(b*P + p)*KQ + kq] = e4[b,i_p,kq] * e4[b,j_p,kq]
+__global__ __launch_bounds__(256) void afm_pair_fwd_kernel(const float4* __restrict__ e, int e_ld4, const int16_t* __restrict__ pi,
+                                                          const int16_t* __restrict__ pj, int B, int P, int KQ,
+                                                          float4* __restrict__ pp) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)B * P * KQ;
+    if (t >= n) return;
+    const int kq = (int)(t % KQ);
+    const int64_t bp = t / KQ;
+    const int p = (int)(bp % P), b = (int)(bp / P);
+    const float4 a = e[(size_t)b * e_ld4 + (size_t)pi[p] * KQ + kq];
+    const float4 c = e[(size_t)b * e_ld4 + (size_t)pj[p] * KQ + kq];
+    pp[t] = make_float4(a.x * c.x, a.y * c.y, a.z * c.z, a.w * c.w);
+}
+
+// one block per example: softmax over the P scores, attention dropout, pooling over the pairs, y_emb dropout
+__global__ __launch_bounds__(256) void afm_pool_fwd_kernel(const float* __restrict__ sc, const float* __restrict__ pp, int P, int K,
+                                                          float keep_att, float keep_emb, const uint64_t* __restrict__ seed_ptr,
+                                                          int train, float* __restrict__ att, float* __restrict__ yemb) {
+    extern __shared__ float sm[];        // [P] attention weights (after dropout)
+    __shared__ float red[4];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float* s = sc + (size_t)b * P;
+    float m = -3.0e38f;
+    for (int p = t; p < P; p += 256) m = fmaxf(m, s[p]);
+    m = wmax64(m);
+    if ((t & 63) == 0) red[t >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float z = 0.f;
+    for (int p = t; p < P; p += 256) { const float ex = expf(s[p] - m); sm[p] = ex; z += ex; }
+    z = wsum64(z);
+    if ((t & 63) == 0) red[t >> 6] = z;
+    __syncthreads();
+    z = red[0] + red[1] + red[2] + red[3];
+    const float inv = 1.0f / z;
+    const uint64_t seed = (train && (keep_att < 1.f || keep_emb < 1.f)) ? *seed_ptr : 0ull;
+    for (int p = t; p < P; p += 256) {
+        const float a = sm[p] * inv;
+        att[(size_t)b * P + p] = a;                                            // softmax output (before dropout): kept for the backward
+        sm[p] = (train && keep_att < 1.f) ? a * dropout_scale(seed ^ 0xA0ull, (uint64_t)b * P + p, keep_att) : a;
+    }
+    __syncthreads();
+    const float* ppb = pp + (size_t)b * P * K;
+    for (int k = t; k < K; k += 256) {
+        float acc = 0.f;
+        for (int p = 0; p < P; ++p) acc += sm[p] * ppb[(size_t)p * K + k];
+        if (train && keep_emb < 1.f) acc *= dropout_scale(seed ^ 0xA1ull, (uint64_t)b * K + k, keep_emb);
+        yemb[(size_t)b * K + k] = acc;
+    }
+}
+
+// backward of dropout[1] -> pooling -> dropout[0] -> softmax.  in: dyemb_post [B,K]; out: dsc [B,P], dpp [B,P,K]
+__global__ __launch_bounds__(256) void afm_pool_bwd_kernel(const float* __restrict__ dy_post, const float* __restrict__ pp,
+                                                          const float* __restrict__ att, int P, int K, float keep_att, float keep_emb,
+                                                          const uint64_t* __restrict__ seed_ptr, float* __restrict__ dsc,
+                                                          float* __restrict__ dpp) {
+    extern __shared__ float sm[];        // [K] dyemb (pre-dropout gradient) | [P] da | [P] a' (post-dropout attention)
+    __shared__ float red[4];
+    float* dye = sm;
+    float* da = sm + K;
+    float* ad = sm + K + P;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint64_t seed = (keep_att < 1.f || keep_emb < 1.f) ? *seed_ptr : 0ull;
+    for (int k = t; k < K; k += 256) {
+        float g = dy_post[(size_t)b * K + k];
+        if (keep_emb < 1.f) g *= dropout_scale(seed ^ 0xA1ull, (uint64_t)b * K + k, keep_emb);
+        dye[k] = g;
+    }
+    __syncthreads();
+    const float* ppb = pp + (size_t)b * P * K;
+    const float* ab = att + (size_t)b * P;
+    float part = 0.f;                                          // sum_q att[q] * da[q]
+    for (int p = wave; p < P; p += 4) {
+        float s = 0.f;
+        for (int k = lane; k < K; k += 64) s += dye[k] * ppb[(size_t)p * K + k];
+        s = wsum64(s);                                         // d a'[p]
+        const float msk = keep_att < 1.f ? dropout_scale(seed ^ 0xA0ull, (uint64_t)b * P + p, keep_att) : 1.f;
+        const float d = s * msk;                               // d att[p]
+        if (lane == 0) { da[p] = d; ad[p] = ab[p] * msk; part += ab[p] * d; }
+    }
+    part = wsum64(part);
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    for (int p = t; p < P; p += 256) dsc[(size_t)b * P + p] = ab[p] * (da[p] - tot);      // softmax backward
+    float* dppb = dpp + (size_t)b * P * K;
+    for (int p = wave; p < P; p += 4) {
+        const float a = ad[p];
+        for (int k = lane; k < K; k += 64) dppb[(size_t)p * K + k] = a * dye[k];
+    }
+}
+
+// dE[b,i,:] = sum_{j != i} (g1 + g2)[b,pair(i,j),:] * e[b,j,:]
+__global__ __launch_bounds__(256) void afm_pair_bwd_kernel(const float* __restrict__ e, int e_ld, const float* __restrict__ g1,
+                                                          const float* __restrict__ g2, int F, int K, int P, float* __restrict__ dE,
+                                                          int de_ld) {
+    const int b = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= F * K) return;
+    const int i = x / K, k = x - i * K;
+    const float* eb = e + (size_t)b * e_ld;
+    const float* a = g1 + (size_t)b * P * K;
+    const float* c = g2 + (size_t)b * P * K;
+    float s = 0.f;
+    for (int j = 0; j < i; ++j) {
+        const size_t p = (size_t)(j * F - (j * (j + 1)) / 2 + (i - j - 1)) * K + k;
+        s += (a[p] + c[p]) * eb[j * K + k];
+    }
+    for (int j = i + 1; j < F; ++j) {
+        const size_t p = (size_t)(i * F - (i * (i + 1)) / 2 + (j - i - 1)) * K + k;
+        s += (a[p] + c[p]) * eb[j * K + k];
+    }
+    dE[(size_t)b * de_ld + x] = s;
+}
+
+}  // namespace dctr
+
+using namespace dctr;
+
+int afm_declare_params(dctr_engine* E) {
+    auto add = engine_add_param;
+    const dctr_config& c = E->cfg;
+    DCTR_REQUIRE(c.n_attention_layers == 1, "AFM: exactly one attention layer is supported (got %d)", c.n_attention_layers);
+    E->A = c.attention_layers[0];
+    DCTR_REQUIRE(E->A > 0, "AFM: attention layer width must be > 0");
+    E->keep_att = c.keep_prob[0] > 0.f ? c.keep_prob[0] : 1.f;
+    E->keep_emb = c.keep_prob[1] > 0.f ? c.keep_prob[1] : 1.f;
+    const int K = E->K, A = E->A;
+    E->att_splits = choose_wgrad_splits(E->MB * E->P, K, A);
+    E->p_att_w = add(E, "att_mlp0/weights", {K, A}, false, E->att_splits, 0.f);
+    E->p_att_b = add(E, "att_mlp0/biases", {A}, false, E->att_splits, 0.f);
+    E->p_ao_w = add(E, "attention_out/weights", {A, 1}, false, E->ao_splits, 0.f);
+    E->p_ao_b = add(E, "attention_out/biases", {1}, false, E->ao_splits, 0.f);
+    E->p_out_w = add(E, "deep_out/weights", {K, 1}, false, E->out_splits, 0.f);
+    E->p_out_b = add(E, "deep_out/biases", {1}, false, E->out_splits, 0.f);
+    return DCTR_OK;
+}
+
+template <typename T>
+static int dm(T** p, size_t n) {
+    DCTR_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 4) * sizeof(T)));
+    DCTR_HIP_CHECK(hipMemset(*p, 0, std::max<size_t>(n, 4) * sizeof(T)));
+    return DCTR_OK;
+}
+
+int afm_alloc(dctr_engine* E) {
+    const size_t MB = E->MB, P = E->P, K = E->K, A = E->A;
+    DCTR_TRY(dm(&E->pairp, MB * P * K));
+    DCTR_TRY(dm(&E->dpairp, MB * P * K));
+    DCTR_TRY(dm(&E->dpairp2, MB * P * K));
+    DCTR_TRY(dm(&E->ah, MB * P * A));
+    DCTR_TRY(dm(&E->dah, MB * P * A));
+    DCTR_TRY(dm(&E->sc, MB * P));
+    DCTR_TRY(dm(&E->dsc, MB * P));
+    DCTR_TRY(dm(&E->att, MB * P));
+    DCTR_TRY(dm(&E->dE_buf, MB * E->D));
+    std::vector<int16_t> pi, pj;
+    for (int i = 0; i < E->F - 1; ++i)
+        for (int j = i + 1; j < E->F; ++j) { pi.push_back((int16_t)i); pj.push_back((int16_t)j); }
+    DCTR_TRY(dm(&E->pair_i, pi.size()));
+    DCTR_TRY(dm(&E->pair_j, pj.size()));
+    DCTR_HIP_CHECK(hipMemcpy(E->pair_i, pi.data(), pi.size() * 2, hipMemcpyHostToDevice));
+    DCTR_HIP_CHECK(hipMemcpy(E->pair_j, pj.data(), pj.size() * 2, hipMemcpyHostToDevice));
+    return DCTR_OK;
+}
+
+void afm_free(dctr_engine* E) {
+    float* fl[] = {E->pairp, E->dpairp, E->dpairp2, E->ah, E->dah, E->sc, E->dsc, E->att, E->dE_buf};
+    for (float* p : fl) if (p) hipFree(p);
+    if (E->pair_i) hipFree(E->pair_i);
+    if (E->pair_j) hipFree(E->pair_j);
+}
+
+// after the gather (mode RAW + linear) has filled E->e / E->yw
+int afm_forward(dctr_engine* E, int B, bool train, hipStream_t st) {
+    const int F = E->F, K = E->K, P = E->P, A = E->A, KQ = K / 4;
+    const int64_t n4 = (int64_t)B * P * KQ;
+    afm_pair_fwd_kernel<<<ceil_div(n4, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(E->e), E->e_ld / 4, E->pair_i, E->pair_j, B,
+                                                            P, KQ, reinterpret_cast<float4*>(E->pairp));
+    DCTR_LAUNCH_CHECK();
+    (void)F;
+    DCTR_TRY(fc_fwd(E->pairp, K, E->pp(E->p_att_w), E->pp(E->p_att_b), E->ah, A, B * P, K, A, 1, 1.f, nullptr, 0, st));
+    DCTR_TRY(rowdot(E->ah, A, E->pp(E->p_ao_w), E->pp(E->p_ao_b), B * P, A, E->sc, 0, st));
+    afm_pool_fwd_kernel<<<B, 256, (size_t)P * sizeof(float), st>>>(E->sc, E->pairp, P, K, E->keep_att, E->keep_emb, &E->state->seed_t,
+                                                                   train ? 1 : 0, E->att, E->x_in);
+    DCTR_LAUNCH_CHECK();
+    DCTR_TRY(rowdot(E->x_in, E->Din_ld, E->pp(E->p_out_w), E->pp(E->p_out_b), B, K, E->yd, 0, st));
+    return DCTR_OK;
+}
+
+// leaves dL/de in E->dE_buf; dense-gradient partial slabs in E->parts
+int afm_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
+    const int F = E->F, K = E->K, P = E->P, A = E->A;
+    const Param& pw = E->params[E->p_out_w];
+    const Param& pb = E->params[E->p_out_b];
+    // deep_out (K -> 1): d y_emb(post-dropout) = dy (x) w_d into dx_in; dW/db partial slabs
+    DCTR_TRY(out_layer_bwd(E->x_in, E->Din_ld, E->dy, E->pp(E->p_out_w), B, K, pw.n_part, 0, 1.f, E->dx_in, E->Din_ld,
+                           E->part(E->p_out_w), pw.padded, E->part(E->p_out_b), pb.padded, st));
+    afm_pool_bwd_kernel<<<B, 256, (size_t)(K + 2 * P) * sizeof(float), st>>>(E->dx_in, E->pairp, E->att, P, K, E->keep_att, E->keep_emb,
+                                                                             &E->state->seed_t, E->dsc, E->dpairp);
+    DCTR_LAUNCH_CHECK();
+    // attention_out (A -> 1) over the B*P rows: d ah = dsc (x) w_o masked by relu, dW_o / db_o partial slabs
+    const Param& aw = E->params[E->p_ao_w];
+    const Param& ab = E->params[E->p_ao_b];
+    DCTR_TRY(out_layer_bwd(E->ah, A, E->dsc, E->pp(E->p_ao_w), B * P, A, aw.n_part, 1, 1.f, E->dah, A, E->part(E->p_ao_w), aw.padded,
+                           E->part(E->p_ao_b), ab.padded, st));
+    // attention layer: wgrad on the side stream, dgrad on the critical path
+    DCTR_TRY(fork(E, st, sw));
+    const Param& w = E->params[E->p_att_w];
+    const Param& b = E->params[E->p_att_b];
+    DCTR_TRY(fc_bwd_weights_partials(E->pairp, K, E->dah, A, E->part(E->p_att_w), w.padded, E->part(E->p_att_b), b.padded, B * P, K, A,
+                                     E->att_splits, sw));
+    DCTR_TRY(fc_bwd_data(E->dah, A, E->pp(E->p_att_w), E->dpairp2, K, B * P, K, A, nullptr, 0, 1.f, st));
+    dim3 grid(ceil_div(F * K, 256), B);
+    afm_pair_bwd_kernel<<<grid, 256, 0, st>>>(E->e, E->e_ld, E->dpairp, E->dpairp2, F, K, P, E->dE_buf, E->D);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}

@@ -1,0 +1,113 @@
+// Engine state shared by engine.hip (MLP-family models) and afm.hip (attention model).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "ops.h"
+
+namespace dctr {
+
+struct Param {
+    std::string name;
+    int rank = 1;
+    int64_t dims[4] = {1, 1, 1, 1};
+    int64_t n = 0;
+    bool is_table = false;
+    float* ptr = nullptr;        // device
+    float* s0 = nullptr;
+    float* s1 = nullptr;
+    int64_t arena_off = 0;       // dense params: offset in the arena
+    int64_t padded = 0;
+    int64_t part_off = 0;        // offset of the first partial slab in `parts`
+    int n_part = 1;
+    float l2 = 0.f;
+};
+
+struct Fc {
+    int in = 0, out = 0;
+    int w = -1, b = -1;          // indices into params
+    float keep = 1.f;
+    int splits = 1;
+};
+
+}  // namespace dctr
+
+using dctr::Param;
+using dctr::Fc;
+using dctr::Group;
+using dctr::OptBlockMeta;
+using dctr::StepState;
+
+struct dctr_engine {
+    dctr_config cfg{};
+    int F = 0, K = 0, P = 0, D = 0;      // D = F*K
+    int64_t rows = 0;
+    int MB = 0;
+    int Din = 0, Din_ld = 0;
+    std::vector<Param> params;
+    std::map<std::string, int> index;
+    std::vector<Fc> mlp;
+    int p_out_w = -1, p_out_b = -1, p_bias = -1, p_cross_w = -1, p_cross_b = -1;
+    int out_splits = 128;
+
+    // tables
+    float *emb = nullptr, *emb_s0 = nullptr, *emb_s1 = nullptr, *lin = nullptr, *lin_s0 = nullptr, *lin_s1 = nullptr;
+    Group* group = nullptr;
+    // arena
+    float *theta = nullptr, *as0 = nullptr, *as1 = nullptr, *gflat = nullptr, *parts = nullptr;
+    int64_t arena_n = 0, parts_n = 0;
+    OptBlockMeta* meta = nullptr;
+    OptBlockMeta* meta_flat = nullptr;
+    float* ones = nullptr;        // [max_batch*F*world] of 1.0f: the `vals` of raw row gathers / gradient segment sums
+    int n_blocks = 0;
+    // state
+    StepState* state = nullptr;
+    StepState h_state{};
+    float* scalars = nullptr;     // [0] xent sum, [1] sumsq emb, [2] sumsq linear, [3] sumsq dense-l2 params
+    int32_t* status = nullptr;    // [2]
+    // activations
+    int32_t* ids = nullptr;
+    float *vals = nullptr, *labels = nullptr;
+    float *x_in = nullptr, *dx_in = nullptr, *e_buf = nullptr, *S = nullptr, *yw = nullptr, *yv = nullptr;
+    float *yd = nullptr, *y = nullptr, *prob = nullptr, *dy = nullptr;
+    std::vector<float*> h, dh;
+    float *xs = nullptr, *xlw = nullptr, *dxL = nullptr, *cross_scratch = nullptr;
+    float* e = nullptr;           // alias: where the scaled embeddings live
+    int e_ld = 0;
+    // graphs
+    std::map<int, hipGraphExec_t> train_graphs, predict_graphs;
+    int last_B = 0;
+    hipStream_t s_group = nullptr, s_wgrad = nullptr;   // side streams of the step DAG
+    int64_t* auc_counts = nullptr;   // [4*200] tp,fn,tn,fp per threshold (tf.metrics.auc)
+    float* eval_scalars = nullptr;   // [0] sum xent over the eval set, [1..] scratch
+    int64_t eval_examples = 0;
+    std::vector<hipEvent_t> events;
+    size_t ev_next = 0;
+
+    // AFM (afm.hip)
+    int A = 0;                       // attention layer width
+    int p_att_w = -1, p_att_b = -1, p_ao_w = -1, p_ao_b = -1;
+    int att_splits = 1, ao_splits = 1024;
+    float keep_att = 1.f, keep_emb = 1.f;
+    float *pairp = nullptr, *dpairp = nullptr, *dpairp2 = nullptr, *ah = nullptr, *dah = nullptr, *sc = nullptr, *dsc = nullptr,
+          *att = nullptr, *dE_buf = nullptr;
+    int16_t *pair_i = nullptr, *pair_j = nullptr;
+    // where dL/de lives for the table backward (dx_in for the MLP-family models, dE_buf for AFM)
+    float* dE = nullptr;
+    int dE_ld = 0;
+
+    float* pp(int i) { return params[i].ptr; }
+    float* part(int i) { return parts + params[i].part_off; }
+};
+
+
+// shared between engine.hip and afm.hip
+int engine_add_param(dctr_engine* E, const std::string& name, std::initializer_list<int64_t> dims, bool table, int n_part, float l2);
+int fork(dctr_engine* E, hipStream_t from, hipStream_t to);
+int afm_declare_params(dctr_engine* E);
+int afm_alloc(dctr_engine* E);
+void afm_free(dctr_engine* E);
+int afm_forward(dctr_engine* E, int B, bool train, hipStream_t st);
+int afm_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t sw);

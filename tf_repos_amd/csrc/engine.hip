@@ -13,89 +13,11 @@
 
 #include "common.h"
 #include "ops.h"
-
-namespace dctr {
-
-struct Param {
-    std::string name;
-    int rank = 1;
-    int64_t dims[4] = {1, 1, 1, 1};
-    int64_t n = 0;
-    bool is_table = false;
-    float* ptr = nullptr;        // device
-    float* s0 = nullptr;
-    float* s1 = nullptr;
-    int64_t arena_off = 0;       // dense params: offset in the arena
-    int64_t padded = 0;
-    int64_t part_off = 0;        // offset of the first partial slab in `parts`
-    int n_part = 1;
-    float l2 = 0.f;
-};
-
-struct Fc {
-    int in = 0, out = 0;
-    int w = -1, b = -1;          // indices into params
-    float keep = 1.f;
-    int splits = 1;
-};
-
-}  // namespace dctr
+#include "engine.h"
 
 using namespace dctr;
 
-struct dctr_engine {
-    dctr_config cfg{};
-    int F = 0, K = 0, P = 0, D = 0;      // D = F*K
-    int64_t rows = 0;
-    int MB = 0;
-    int Din = 0, Din_ld = 0;
-    std::vector<Param> params;
-    std::map<std::string, int> index;
-    std::vector<Fc> mlp;
-    int p_out_w = -1, p_out_b = -1, p_bias = -1, p_cross_w = -1, p_cross_b = -1;
-    int out_splits = 128;
-
-    // tables
-    float *emb = nullptr, *emb_s0 = nullptr, *emb_s1 = nullptr, *lin = nullptr, *lin_s0 = nullptr, *lin_s1 = nullptr;
-    Group* group = nullptr;
-    // arena
-    float *theta = nullptr, *as0 = nullptr, *as1 = nullptr, *gflat = nullptr, *parts = nullptr;
-    int64_t arena_n = 0, parts_n = 0;
-    OptBlockMeta* meta = nullptr;
-    OptBlockMeta* meta_flat = nullptr;
-    float* ones = nullptr;        // [max_batch*F*world] of 1.0f: the `vals` of raw row gathers / gradient segment sums
-    int n_blocks = 0;
-    // state
-    StepState* state = nullptr;
-    StepState h_state{};
-    float* scalars = nullptr;     // [0] xent sum, [1] sumsq emb, [2] sumsq linear, [3] sumsq dense-l2 params
-    int32_t* status = nullptr;    // [2]
-    // activations
-    int32_t* ids = nullptr;
-    float *vals = nullptr, *labels = nullptr;
-    float *x_in = nullptr, *dx_in = nullptr, *e_buf = nullptr, *S = nullptr, *yw = nullptr, *yv = nullptr;
-    float *yd = nullptr, *y = nullptr, *prob = nullptr, *dy = nullptr;
-    std::vector<float*> h, dh;
-    float *xs = nullptr, *xlw = nullptr, *dxL = nullptr, *cross_scratch = nullptr;
-    float* e = nullptr;           // alias: where the scaled embeddings live
-    int e_ld = 0;
-    // graphs
-    std::map<int, hipGraphExec_t> train_graphs, predict_graphs;
-    int last_B = 0;
-    hipStream_t s_group = nullptr, s_wgrad = nullptr;   // side streams of the step DAG
-    int64_t* auc_counts = nullptr;   // [4*200] tp,fn,tn,fp per threshold (tf.metrics.auc)
-    float* eval_scalars = nullptr;   // [0] sum xent over the eval set, [1..] scratch
-    int64_t eval_examples = 0;
-    std::vector<hipEvent_t> events;
-    size_t ev_next = 0;
-
-    float* pp(int i) { return params[i].ptr; }
-    float* part(int i) { return parts + params[i].part_off; }
-};
-
-namespace {
-
-int add_param(dctr_engine* E, const std::string& name, std::initializer_list<int64_t> dims, bool table, int n_part, float l2) {
+int engine_add_param(dctr_engine* E, const std::string& name, std::initializer_list<int64_t> dims, bool table, int n_part, float l2) {
     Param p;
     p.name = name;
     p.rank = (int)dims.size();
@@ -108,6 +30,21 @@ int add_param(dctr_engine* E, const std::string& name, std::initializer_list<int
     E->index[name] = (int)E->params.size();
     E->params.push_back(p);
     return (int)E->params.size() - 1;
+}
+
+// records "to waits for everything enqueued on from so far" (works eagerly and under stream capture)
+int fork(dctr_engine* E, hipStream_t from, hipStream_t to) {
+    if (from == to) return DCTR_OK;
+    hipEvent_t ev = E->events[E->ev_next++ % E->events.size()];
+    DCTR_HIP_CHECK(hipEventRecord(ev, from));
+    DCTR_HIP_CHECK(hipStreamWaitEvent(to, ev, 0));
+    return DCTR_OK;
+}
+
+namespace {
+
+static int add_param(dctr_engine* E, const std::string& name, std::initializer_list<int64_t> dims, bool table, int n_part, float l2) {
+    return engine_add_param(E, name, dims, table, n_part, l2);
 }
 
 int gather_mode(const dctr_engine* E) {
@@ -142,13 +79,13 @@ int dropout_inplace(float* x, int64_t n, float keep, const uint64_t* seed_ptr, u
 int build(dctr_engine* E) {
     const dctr_config& c = E->cfg;
     DCTR_REQUIRE(c.model >= DCTR_MODEL_DEEPFM && c.model <= DCTR_MODEL_DCN, "unknown model %d", c.model);
-    DCTR_REQUIRE(c.model != DCTR_MODEL_AFM, "AFM is served by the attention engine (dctr_afm_*), not dctr_create");
     DCTR_REQUIRE(c.field_size > 0 && c.feature_size > 0 && c.max_batch > 0, "field_size, feature_size, max_batch must be > 0");
     DCTR_REQUIRE(c.embedding_size % 4 == 0 && c.embedding_size >= 4, "embedding_size must be a multiple of 4");
-    DCTR_REQUIRE(c.n_deep_layers >= 1 && c.n_deep_layers <= DCTR_MAX_LAYERS, "1..%d deep layers supported", DCTR_MAX_LAYERS);
+    const bool afm = c.model == DCTR_MODEL_AFM;
+    DCTR_REQUIRE(afm || (c.n_deep_layers >= 1 && c.n_deep_layers <= DCTR_MAX_LAYERS), "1..%d deep layers supported", DCTR_MAX_LAYERS);
     DCTR_REQUIRE(c.shard_world >= 1 && c.shard_rank >= 0 && c.shard_rank < c.shard_world, "bad shard rank/world");
     if (c.batch_norm) { set_error("batch_norm=True is not implemented in this engine yet"); return DCTR_ERR_UNSUPPORTED; }
-    for (int i = 0; i < c.n_deep_layers; ++i)
+    for (int i = 0; i < (afm ? 2 : c.n_deep_layers); ++i)
         DCTR_REQUIRE(c.keep_prob[i] > 0.f && c.keep_prob[i] <= 1.f, "dropout keep_prob[%d]=%f must be in (0,1]", i, c.keep_prob[i]);
     E->F = c.field_size; E->K = c.embedding_size; E->D = E->F * E->K; E->P = E->F * (E->F - 1) / 2; E->MB = c.max_batch;
     E->rows = (c.feature_size - c.shard_rank + c.shard_world - 1) / c.shard_world;
@@ -157,6 +94,7 @@ int build(dctr_engine* E) {
         case DCTR_MODEL_IPNN: E->Din = D + P; break;
         case DCTR_MODEL_OPNN: E->Din = D + P * K * K; break;
         case DCTR_MODEL_NFM: E->Din = K; break;
+        case DCTR_MODEL_AFM: E->Din = K; break;
         default: E->Din = D; break;
     }
     E->Din_ld = (int)round_up(E->Din, 4);
@@ -172,7 +110,8 @@ int build(dctr_engine* E) {
     }
     add_param(E, "emb", {E->rows, K}, true, 1, c.l2_reg);
     int d = E->Din;
-    for (int i = 0; i < c.n_deep_layers; ++i) {
+    if (afm) DCTR_TRY(afm_declare_params(E));
+    for (int i = 0; i < (afm ? 0 : c.n_deep_layers); ++i) {
         Fc fc;
         fc.in = d; fc.out = c.deep_layers[i]; fc.keep = c.keep_prob[i];
         DCTR_REQUIRE(fc.out > 0, "deep layer widths must be positive (got %d)", fc.out);
@@ -185,7 +124,9 @@ int build(dctr_engine* E) {
         E->mlp.push_back(fc);
         d = fc.out;
     }
-    if (c.model == DCTR_MODEL_DCN) {
+    if (afm) {
+        // output layer declared by afm_declare_params
+    } else if (c.model == DCTR_MODEL_DCN) {
         E->p_out_w = add_param(E, "out_layer/weights", {D + d, 1}, false, E->out_splits, 0.f);
         E->p_out_b = add_param(E, "out_layer/biases", {1}, false, E->out_splits, 0.f);
     } else {
@@ -291,11 +232,16 @@ int build(dctr_engine* E) {
     DCTR_TRY(dmalloc(&E->labels, (size_t)MB));
     DCTR_TRY(dmalloc(&E->x_in, (size_t)MB * E->Din_ld));
     DCTR_TRY(dmalloc(&E->dx_in, (size_t)MB * E->Din_ld));
-    if (c.model == DCTR_MODEL_NFM) {
+    if (c.model == DCTR_MODEL_NFM || afm) {
         DCTR_TRY(dmalloc(&E->e_buf, (size_t)MB * D));
         E->e = E->e_buf; E->e_ld = D;
     } else {
         E->e = E->x_in; E->e_ld = E->Din_ld;
+    }
+    E->dE = E->dx_in; E->dE_ld = E->Din_ld;
+    if (afm) {
+        DCTR_TRY(afm_alloc(E));
+        E->dE = E->dE_buf; E->dE_ld = D;
     }
     DCTR_TRY(dmalloc(&E->S, (size_t)MB * K));
     DCTR_TRY(dmalloc(&E->yw, (size_t)MB));
@@ -332,6 +278,7 @@ int forward_from(dctr_engine* E, const float* emb, const float* lin, int64_t row
     float* red = mode == DCTR_GATHER_FM ? E->yv : (mode == DCTR_GATHER_BI ? E->x_in : nullptr);
     DCTR_TRY(embed_gather_fwd(emb, lin, rows, ids, E->vals, B, F, K, mode, E->e, E->e_ld, lin ? E->yw : nullptr,
                               E->S, red, E->status, st));
+    if (c.model == DCTR_MODEL_AFM) return afm_forward(E, B, train, st);
     const uint64_t* seedp = &E->state->seed_t;
     if (c.model == DCTR_MODEL_IPNN) DCTR_TRY(pnn_inner_fwd(E->e, E->e_ld, B, F, K, E->x_in + D, E->Din_ld, st));
     if (c.model == DCTR_MODEL_OPNN) DCTR_TRY(pnn_outer_fwd(E->e, E->e_ld, B, F, K, E->x_in + D, E->Din_ld, st));
@@ -373,18 +320,10 @@ int head(dctr_engine* E, int B, int global_batch, bool with_labels, hipStream_t 
 }
 
 // ---- backward through head + MLP + interaction: leaves dL/de in dx_in (or the BI coefficient for NFM) ----------
-// records "to waits for everything enqueued on from so far" (works eagerly and under stream capture)
-int fork(dctr_engine* E, hipStream_t from, hipStream_t to) {
-    if (from == to) return DCTR_OK;
-    hipEvent_t ev = E->events[E->ev_next++ % E->events.size()];
-    DCTR_HIP_CHECK(hipEventRecord(ev, from));
-    DCTR_HIP_CHECK(hipStreamWaitEvent(to, ev, 0));
-    return DCTR_OK;
-}
-
 // st: critical path (dgrad chain); sw: side stream for the weight gradients (independent of the dgrad chain)
 int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
     const dctr_config& c = E->cfg;
+    if (c.model == DCTR_MODEL_AFM) return afm_backward(E, B, st, sw);
     const int F = E->F, K = E->K, D = E->D;
     const int H = E->mlp.back().out;
     const int nl = (int)E->mlp.size();
@@ -433,9 +372,9 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
 int scatter_and_step_tables(dctr_engine* E, int B, hipStream_t st) {
     const dctr_config& c = E->cfg;
     const int mode = gather_mode(E);
-    const float* dE = mode == DCTR_GATHER_BI ? nullptr : E->dx_in;
+    const float* dE = mode == DCTR_GATHER_BI ? nullptr : E->dE;
     const float* coef = mode == DCTR_GATHER_FM ? E->dy : (mode == DCTR_GATHER_BI ? E->dx_in : nullptr);
-    DCTR_TRY(embed_scatter_bwd(E->group, dE, E->Din_ld, E->e, E->e_ld, E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F,
+    DCTR_TRY(embed_scatter_bwd(E->group, dE, E->dE_ld, E->e, E->e_ld, E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F,
                                E->K, mode, E->group->gemb, E->lin ? E->group->glin : nullptr, st));
     DCTR_TRY(opt_table(c.optimizer, &E->state->hyper, E->h_state.hyper, c.table_mode, E->rows, E->K, E->emb, E->emb_s0, E->emb_s1,
                        E->lin, E->lin_s0, E->lin_s1, E->group->slot, E->group->uniq, E->group->counters, E->group->max_entries,
@@ -543,6 +482,7 @@ int dctr_destroy(dctr_handle E) {
     if (E->eval_scalars) hipFree(E->eval_scalars);
     if (E->ones) hipFree(E->ones);
     group_destroy(E->group);
+    afm_free(E);
     for (auto& ev : E->events) if (ev) hipEventDestroy(ev);
     if (E->s_group) hipStreamDestroy(E->s_group);
     if (E->s_wgrad) hipStreamDestroy(E->s_wgrad);
@@ -781,9 +721,9 @@ int dctr_sharded_row_grads(dctr_handle E, dctr_group_t g, int B, void* stream) {
     DCTR_REQUIRE(E && g, "null argument");
     Group* G = reinterpret_cast<Group*>(g);
     const int mode = gather_mode(E);
-    const float* dE = mode == DCTR_GATHER_BI ? nullptr : E->dx_in;
+    const float* dE = mode == DCTR_GATHER_BI ? nullptr : E->dE;
     const float* coef = mode == DCTR_GATHER_FM ? E->dy : (mode == DCTR_GATHER_BI ? E->dx_in : nullptr);
-    return embed_scatter_bwd(G, dE, E->Din_ld, E->e, E->e_ld, E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F, E->K, mode,
+    return embed_scatter_bwd(G, dE, E->dE_ld, E->e, E->e_ld, E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F, E->K, mode,
                              G->gemb, E->lin ? G->glin : nullptr, as_stream(stream));
 }
 

@@ -97,7 +97,7 @@ constexpr int H16 = BK / 2;    // MFMAs (k-pairs) per BK tile
 template <bool A_KC, bool B_NC, int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(
     const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
-    float* __restrict__ Cm, int ldc, int M, int N, int K, int kchunk, bool vecA, bool vecB, Epilogue ep, int abl) {
+    float* __restrict__ Cm, int ldc, int M, int N, int K, int kchunk, bool vecA, bool vecB, Epilogue ep, int abl, int nx) {
     constexpr int LDA = A_KC ? 66 : 68;      // 66: conflict-free transposing scalar writes; 68: 16B-aligned rows
     constexpr int LDB = B_NC ? 68 : 66;
     constexpr int ABUF = BK * LDA, BBUF = BK * LDB;
@@ -113,14 +113,15 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(
     // XCD-aware tile order: hardware places linear block id b on XCD b % 8; remapping gives every XCD a contiguous run of
     // tiles (n fastest) so the blocks that share an A row-panel / the whole B panel hit the same 4 MiB L2.  Pure speed
     // choice: any placement computes the same result.
-    int bx = blockIdx.x, by = blockIdx.y;
+    // (1-D grid of nx*ny tiles: the m-tile count of the attention GEMMs exceeds the 65535 limit of gridDim.y)
+    int bx, by;
     {
-        const int nwg = gridDim.x * gridDim.y;
-        const int b = blockIdx.y * gridDim.x + blockIdx.x;
+        const int nwg = gridDim.x;
+        const int b = blockIdx.x;
         const int q = nwg / 8, r = nwg % 8, xcd = b % 8, idx = b / 8;
         const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;     // bijective for any nwg
-        bx = lb % gridDim.x;
-        by = lb / gridDim.x;
+        bx = lb % nx;
+        by = lb / nx;
     }
     const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = blockIdx.z * kchunk;
@@ -288,10 +289,11 @@ static int launch_gemm(const float* A, int lda, const float* B, int ldb, float* 
     const bool vecA = aligned16(A) && (lda % 4 == 0);
     const bool vecB = aligned16(B) && (ldb % 4 == 0);
     int kchunk = (int)round_up(ceil_div(K, splits), BK);
-    dim3 grid(ceil_div(N, BN), ceil_div(M, BM), splits), block(256);
+    const int nx = ceil_div(N, BN);
+    dim3 grid((unsigned)((int64_t)nx * ceil_div(M, BM)), 1, splits), block(256);
     static const int dyn_lds = getenv("DCTR_GEMM_DYN_LDS") ? atoi(getenv("DCTR_GEMM_DYN_LDS")) : 0;   // occupancy experiments
     static const int abl = getenv("DCTR_GEMM_ABLATE") ? atoi(getenv("DCTR_GEMM_ABLATE")) : 0;          // ablation experiments (wrong results!)
-    gemm_f32_mfma<A_KC, B_NC, EPI><<<grid, block, dyn_lds, st>>>(A, lda, B, ldb, C, ldc, M, N, K, kchunk, vecA, vecB, ep, abl);
+    gemm_f32_mfma<A_KC, B_NC, EPI><<<grid, block, dyn_lds, st>>>(A, lda, B, ldb, C, ldc, M, N, K, kchunk, vecA, vecB, ep, abl, nx);
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }

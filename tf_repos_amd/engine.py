@@ -56,6 +56,7 @@ class EngineConfig:
         c.n_deep_layers = len(layers)
         for i, h in enumerate(layers):
             c.deep_layers[i] = int(h)
+        for i in range(capi.MAX_LAYERS):        # AFM reads keep_prob[0..1] = attention / pooled-embedding dropout (AFM.py:153,158)
             c.keep_prob[i] = float(keep[i]) if i < len(keep) else 1.0
         c.cross_layers = self.cross_layers
         att = list(self.attention_layers)
