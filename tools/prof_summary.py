@@ -1,0 +1,40 @@
+"""Summarises rocprofv3 outputs (rocpd sqlite: *_results.db) into the text files committed under profiles/.
+
+    python tools/prof_summary.py stats  <results.db>            # per-kernel calls / total / average (like --stats)
+    python tools/prof_summary.py pmc    <results.db> [...]      # per-kernel mean counter values (one db per --pmc pass)
+"""
+import collections
+import sqlite3
+import sys
+
+
+def stats(path):
+    cur = sqlite3.connect(path).cursor()
+    rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+    print("%-92s %8s %14s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "%"))
+    for name, calls, tot, avg, pct in rows:
+        print("%-92s %8d %14.0f %12.1f %7.2f" % (name[:92], calls, tot, avg, pct))
+
+
+def pmc(paths):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for path in paths:
+        cur = sqlite3.connect(path).cursor()
+        cols = [d[0] for d in cur.execute("select * from counters_collection limit 1").description]
+        ki, ci, vi = cols.index("kernel_name"), cols.index("counter_name"), cols.index("value")
+        di = cols.index("dispatch_id") if "dispatch_id" in cols else None
+        per = collections.defaultdict(float)
+        for r in cur.execute("select * from counters_collection"):
+            per[(r[ki], r[ci], r[di] if di is not None else 0)] += r[vi]      # sum over XCDs / instances of one dispatch
+        for (k, c, _d), v in per.items():
+            agg[k][c].append(v)
+    print("%-80s %s" % ("kernel", "mean counter value per dispatch"))
+    for k, d in sorted(agg.items()):
+        print("%-80s %s" % (k[:80], "  ".join("%s=%.4g (n=%d)" % (c, sum(v) / len(v), len(v)) for c, v in sorted(d.items()))))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2])
+    else:
+        pmc(sys.argv[2:])
