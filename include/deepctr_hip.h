@@ -57,6 +57,7 @@ enum { DCTR_GATHER_RAW = 0,   /* e only                    (PNN.py:133-136, DCN.
        DCTR_GATHER_BI  = 2    /* + bi[B,K] bi-interaction  (NFM.py:126-128)                                  */ };
 
 #define DCTR_MAX_LAYERS 8
+#define DCTR_INPUT_SLOTS 8     /* engine-owned input staging sets, see dctr_input_slot */
 
 typedef struct dctr_config {
     int32_t model;                       /* DCTR_MODEL_*                                         */
@@ -168,7 +169,7 @@ int dctr_opt_dense(int kind, const float* hyper, float* d_theta, float* d_slot0,
 int dctr_opt_table(int kind, const float* hyper, int table_mode, int64_t rows, int K,
                    float* d_emb, float* d_emb_s0, float* d_emb_s1,
                    float* d_lin, float* d_lin_s0, float* d_lin_s1,
-                   dctr_group_t g, float l2, float* d_sumsq /* [2] += sum emb^2, sum lin^2 (pre-update) or NULL */,
+                   dctr_group_t g, float l2, float* d_sumsq /* [128] or NULL: 64 shards += sum emb^2, next 64 shards += sum lin^2 (pre-update) */,
                    void* stream);
 
 /* ---- K6: dense layers on the matrix cores (fp32-input MFMA, exact f32).
@@ -238,6 +239,11 @@ int dctr_get_global_step(dctr_handle h, int64_t* step);
  * receives the full loss of DeepFM.py:188-190 evaluated BEFORE the update; passing it forces a sync. */
 int dctr_train_step(dctr_handle h, const int32_t* d_ids, const float* d_vals, const float* d_labels,
                     int B, float* h_loss, void* stream);
+/* Engine-owned input staging: DCTR_INPUT_SLOTS sets of ([max_batch,F] i32, [max_batch,F] f32, [max_batch] f32) device
+ * buffers.  A caller that writes a batch straight into slot k (e.g. the H2D copy of the input pipeline) and passes those
+ * same pointers to dctr_train_step / dctr_predict / dctr_eval_batch pays no staging copy; any other pointers are copied
+ * device-to-device into slot 0 first. */
+int dctr_input_slot(dctr_handle h, int slot, int32_t** d_ids, float** d_vals, float** d_labels);
 /* forward only (mode PREDICT/EVAL: dropout off, BN moving stats): d_prob [B] (may be NULL), d_logit [B] (may be NULL) */
 int dctr_predict(dctr_handle h, const int32_t* d_ids, const float* d_vals, int B,
                  float* d_prob, float* d_logit, void* stream);

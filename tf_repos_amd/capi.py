@@ -22,6 +22,7 @@ OPTIMIZERS = {"Adam": 0, "Adagrad": 1, "Momentum": 2, "ftrl": 3}
 TABLE_MODES = {"dense_exact": 0, "touched_rows": 1}
 GATHER_RAW, GATHER_FM, GATHER_BI = 0, 1, 2
 MAX_LAYERS = 8
+INPUT_SLOTS = 8
 
 
 class Config(C.Structure):
@@ -98,6 +99,7 @@ _SIGS = {
     "dctr_eval_reset": ([_P, _P], C.c_int),
     "dctr_eval_batch": ([_P, _P, _P, _P, C.c_int, _P], C.c_int),
     "dctr_eval_result": ([_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int64), _P], C.c_int),
+    "dctr_input_slot": ([_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)], C.c_int),
     "dctr_check_ids": ([_P, _P], C.c_int),
     "dctr_route_unique": ([_P, C.c_int, _P, _P, _P, _P], C.c_int),
     "dctr_entry_index": ([_P, _P, C.c_int, _P, _P, _P], C.c_int),

@@ -154,12 +154,73 @@ __global__ __launch_bounds__(256) void out_layer_bwd_kernel(const float* __restr
     }
 }
 
+// float4 variant: 128 column groups x 2 row lanes per block, 4 rows in flight per thread
+__global__ __launch_bounds__(256) void out_layer_bwd_v4_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy,
+                                                              const float* __restrict__ w, int M, int n, int rows_per_block,
+                                                              int masked, float inv_keep, float* __restrict__ dx, int lddx,
+                                                              float* __restrict__ dw_part, int64_t dw_stride,
+                                                              float* __restrict__ db_part, int64_t db_stride) {
+    __shared__ float4 red[128];
+    const int rbeg = blockIdx.x * rows_per_block, rend = min(M, rbeg + rows_per_block);
+    const int cg = threadIdx.x & 127, rl = threadIdx.x >> 7;
+    for (int c0 = 0; c0 < n; c0 += 512) {
+        const int c = c0 + cg * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < n) {
+            const float4 wc = *reinterpret_cast<const float4*>(w + c);
+            for (int r = rbeg + rl; r < rend; r += 8) {
+                float4 xv[4];
+                float d[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int rr = r + 2 * u;
+                    d[u] = rr < rend ? dy[rr] : 0.f;
+                    xv[u] = rr < rend ? *reinterpret_cast<const float4*>(x + (size_t)rr * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int rr = r + 2 * u;
+                    acc.x += d[u] * xv[u].x; acc.y += d[u] * xv[u].y; acc.z += d[u] * xv[u].z; acc.w += d[u] * xv[u].w;
+                    if (dx != nullptr && rr < rend) {
+                        float4 g = make_float4(d[u] * wc.x, d[u] * wc.y, d[u] * wc.z, d[u] * wc.w);
+                        if (masked) {
+                            g.x = xv[u].x > 0.f ? g.x * inv_keep : 0.f; g.y = xv[u].y > 0.f ? g.y * inv_keep : 0.f;
+                            g.z = xv[u].z > 0.f ? g.z * inv_keep : 0.f; g.w = xv[u].w > 0.f ? g.w * inv_keep : 0.f;
+                        }
+                        *reinterpret_cast<float4*>(dx + (size_t)rr * lddx + c) = g;
+                    }
+                }
+            }
+        }
+        if (rl == 1) red[cg] = acc;
+        __syncthreads();
+        if (rl == 0 && c < n) {
+            const float4 o = red[cg];
+            *reinterpret_cast<float4*>(dw_part + (size_t)blockIdx.x * dw_stride + c) = make_float4(acc.x + o.x, acc.y + o.y, acc.z + o.z, acc.w + o.w);
+        }
+        __syncthreads();
+    }
+    if (db_part != nullptr && threadIdx.x < 64) {
+        float s = 0.f;
+        for (int r = rbeg + threadIdx.x; r < rend; r += 64) s += dy[r];
+        s = wave_sum(s);
+        if (threadIdx.x == 0) db_part[(size_t)blockIdx.x * db_stride] = s;
+    }
+}
+
 int out_layer_bwd(const float* x, int ldx, const float* dy, const float* w, int M, int n, int splits, int masked,
                   float keep, float* dx, int lddx, float* dw_part, int64_t dw_stride, float* db_part, int64_t db_stride,
                   hipStream_t st) {
     if (M <= 0 || n <= 0) return DCTR_OK;
-    out_layer_bwd_kernel<<<splits, 256, 0, st>>>(x, ldx, dy, w, M, n, ceil_div(M, splits), masked, 1.0f / keep, dx, lddx,
-                                                  dw_part, dw_stride, db_part, db_stride);
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool v4 = n % 4 == 0 && ldx % 4 == 0 && (dx == nullptr || lddx % 4 == 0) && dw_stride % 4 == 0 && al(x) && al(w) && al(dw_part) &&
+                    (dx == nullptr || al(dx));
+    if (v4)
+        out_layer_bwd_v4_kernel<<<splits, 256, 0, st>>>(x, ldx, dy, w, M, n, ceil_div(M, splits), masked, 1.0f / keep, dx, lddx,
+                                                         dw_part, dw_stride, db_part, db_stride);
+    else
+        out_layer_bwd_kernel<<<splits, 256, 0, st>>>(x, ldx, dy, w, M, n, ceil_div(M, splits), masked, 1.0f / keep, dx, lddx,
+                                                      dw_part, dw_stride, db_part, db_stride);
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }
@@ -245,9 +306,15 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const Hyper* __restrict_
     const size_t i4 = (size_t)blockIdx.x * (OPT_BLOCK / 4) + threadIdx.x;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4* p = reinterpret_cast<const float4*>(parts + m.part_off) + threadIdx.x;
-    for (int s = 0; s < m.n_part; ++s) {
-        const float4 q = p[(size_t)s * (m.part_stride / 4)];
-        g.x += q.x; g.y += q.y; g.z += q.z; g.w += q.w;
+    const size_t ps4 = (size_t)(m.part_stride / 4);
+    // eight slab loads in flight per round: under a concurrent table-optimizer stream a load takes microseconds, and a
+    // one-at-a-time loop made this kernel 15 dependent round trips long
+    for (int s0 = 0; s0 < m.n_part; s0 += 8) {
+        float4 q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = (s0 + j < m.n_part) ? p[(size_t)(s0 + j) * ps4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { g.x += q[j].x; g.y += q[j].y; g.z += q[j].z; g.w += q[j].w; }
     }
     if (gout != nullptr) gout[i4] = g;       // reduced gradient (for the all-reduce in the multi-GPU path)
     if (!apply) return;
@@ -256,7 +323,7 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const Hyper* __restrict_
         g.x += m.l2 * th.x; g.y += m.l2 * th.y; g.z += m.l2 * th.z; g.w += m.l2 * th.w;
         if (sumsq != nullptr) {   // l2_loss term of the reported loss (DCN.py:199), pre-update values; padding is zero
             float sq = wave_sum(th.x * th.x + th.y * th.y + th.z * th.z + th.w * th.w);
-            if ((threadIdx.x & 63) == 0) atomicAdd(sumsq, sq);
+            if ((threadIdx.x & 63) == 0) atomicAdd(sumsq + (blockIdx.x & (SUMSQ_SHARDS - 1)), sq);
         }
     }
     float4 a = s0[i4];
@@ -326,6 +393,17 @@ int opt_dense_flat(int kind, const Hyper* hdev, const Hyper& hval, float* theta,
 // tables.  DENSE: stream every row; grad = l2*theta + (slot[r] ? compact[slot[r]-1] : 0)  -- what TF does when the
 // IndexedSlices gradient meets the dense l2_loss gradient (DeepFM.py:189-190,213).  Also accumulates
 // sum(theta_old^2) so the l2 part of the reported loss is free.  TOUCHED: only rows uniq[0:U).
+__device__ __forceinline__ float4 ntload4(const float4* p) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void ntstore4(float4* p, float4 x) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    v4 v; v.x = x.x; v.y = x.y; v.z = x.z; v.w = x.w;
+    __builtin_nontemporal_store(v, reinterpret_cast<v4*>(p));
+}
+
 template <int KIND, int KQ, bool DENSE>
 __global__ __launch_bounds__(256) void opt_table_kernel(const Hyper* __restrict__ hdev, Hyper hval, int64_t rows,
                                                        float4* __restrict__ emb, float4* __restrict__ s0,
@@ -334,7 +412,7 @@ __global__ __launch_bounds__(256) void opt_table_kernel(const Hyper* __restrict_
                                                        const int32_t* __restrict__ slot, const int32_t* __restrict__ uniq,
                                                        const int32_t* __restrict__ counters, const float4* __restrict__ gemb,
                                                        const float* __restrict__ glin, float l2, float* __restrict__ sumsq_emb,
-                                                       float* __restrict__ sumsq_lin) {
+                                                       float* __restrict__ sumsq_lin, int nt) {
     // KQ lanes per row (one float4 each); lane kq == 0 also steps the row's linear weight (same slot word, one launch)
     const Hyper h = load_hyper(hdev, hval);
     const int64_t n_items = DENSE ? rows : (int64_t)counters[0];
@@ -347,9 +425,14 @@ __global__ __launch_bounds__(256) void opt_table_kernel(const Hyper* __restrict_
         int u;
         if (DENSE) { r = item; u = slot[r] - 1; } else { u = (int)item; r = uniq[u]; }
         const size_t i4 = (size_t)r * KQ + kq;
-        float4 th = emb[i4];
-        float4 a = s0[i4];
-        float4 b = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) ? s1[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 th, a, b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nt) {
+            th = ntload4(emb + i4); a = ntload4(s0 + i4);
+            if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) b = ntload4(s1 + i4);
+        } else {
+            th = emb[i4]; a = s0[i4];
+            if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) b = s1[i4];
+        }
         sq += th.x * th.x + th.y * th.y + th.z * th.z + th.w * th.w;
         float4 g = make_float4(l2 * th.x, l2 * th.y, l2 * th.z, l2 * th.w);
         if (u >= 0) {
@@ -360,9 +443,13 @@ __global__ __launch_bounds__(256) void opt_table_kernel(const Hyper* __restrict_
         opt_update(KIND, h, th.y, a.y, b.y, g.y);
         opt_update(KIND, h, th.z, a.z, b.z, g.z);
         opt_update(KIND, h, th.w, a.w, b.w, g.w);
-        emb[i4] = th;
-        s0[i4] = a;
-        if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) s1[i4] = b;
+        if (nt) {
+            ntstore4(emb + i4, th); ntstore4(s0 + i4, a);
+            if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) ntstore4(s1 + i4, b);
+        } else {
+            emb[i4] = th; s0[i4] = a;
+            if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) s1[i4] = b;
+        }
         if (kq == 0 && lin != nullptr) {
             float lt = lin[r];
             float la = l0[r];
@@ -383,9 +470,58 @@ __global__ __launch_bounds__(256) void opt_table_kernel(const Hyper* __restrict_
         if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sq; red[1][threadIdx.x >> 6] = sql; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            atomicAdd(sumsq_emb, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-            if (sumsq_lin != nullptr) atomicAdd(sumsq_lin, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+            atomicAdd(sumsq_emb + (blockIdx.x & (SUMSQ_SHARDS - 1)), red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+            if (sumsq_lin != nullptr) atomicAdd(sumsq_lin + (blockIdx.x & (SUMSQ_SHARDS - 1)), red[1][0] + red[1][1] + red[1][2] + red[1][3]);
         }
+    }
+}
+
+// dense-exact step of the [rows] linear table, 4 rows per thread (16-byte accesses on all seven streams)
+template <int KIND>
+__global__ __launch_bounds__(256) void opt_lin_dense_kernel(const Hyper* __restrict__ hdev, Hyper hval, int64_t rows,
+                                                           float* __restrict__ lin, float* __restrict__ l0, float* __restrict__ l1,
+                                                           const int32_t* __restrict__ slot, const float* __restrict__ glin, float l2,
+                                                           float* __restrict__ sumsq) {
+    const Hyper h = load_hyper(hdev, hval);
+    const int64_t n4 = rows / 4;
+    float sq = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 th = reinterpret_cast<float4*>(lin)[i];
+        float4 a = reinterpret_cast<float4*>(l0)[i];
+        float4 b = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) ? reinterpret_cast<float4*>(l1)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int4 sl = reinterpret_cast<const int4*>(slot)[i];
+        sq += th.x * th.x + th.y * th.y + th.z * th.z + th.w * th.w;
+        float4 g = make_float4(l2 * th.x, l2 * th.y, l2 * th.z, l2 * th.w);
+        if (sl.x) g.x += glin[sl.x - 1];
+        if (sl.y) g.y += glin[sl.y - 1];
+        if (sl.z) g.z += glin[sl.z - 1];
+        if (sl.w) g.w += glin[sl.w - 1];
+        opt_update(KIND, h, th.x, a.x, b.x, g.x);
+        opt_update(KIND, h, th.y, a.y, b.y, g.y);
+        opt_update(KIND, h, th.z, a.z, b.z, g.z);
+        opt_update(KIND, h, th.w, a.w, b.w, g.w);
+        reinterpret_cast<float4*>(lin)[i] = th;
+        reinterpret_cast<float4*>(l0)[i] = a;
+        if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) reinterpret_cast<float4*>(l1)[i] = b;
+    }
+    // the rows % 4 tail
+    const int64_t r = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) {
+        float th = lin[r], a = l0[r], b = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) ? l1[r] : 0.f;
+        sq += th * th;
+        float g = l2 * th;
+        const int u = slot[r] - 1;
+        if (u >= 0) g += glin[u];
+        opt_update(KIND, h, th, a, b, g);
+        lin[r] = th; l0[r] = a;
+        if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) l1[r] = b;
+    }
+    if (sumsq != nullptr) {
+        __shared__ float red[4];
+        sq = wave_sum(sq);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(sumsq + (blockIdx.x & (SUMSQ_SHARDS - 1)), red[0] + red[1] + red[2] + red[3]);
     }
 }
 
@@ -393,19 +529,31 @@ template <int KIND, bool DENSE>
 static int launch_table(const Hyper* hdev, const Hyper& hval, int64_t rows, int K, float* emb, float* e0, float* e1,
                         float* lin, float* l0, float* l1, const int32_t* slot, const int32_t* uniq,
                         const int32_t* counters, int64_t max_entries, const float* gemb, const float* glin, float l2,
-                        float* sumsq_emb, float* sumsq_lin, hipStream_t st) {
+                        float* sumsq_emb, float* sumsq_lin, hipStream_t st, hipStream_t st_lin) {
     const int KQ = K / 4;
+    // dense mode: the linear table gets its own vectorised kernel (on st_lin, beside the embedding pass); touched-rows
+    // mode keeps it fused (lane kq == 0 of each visited row)
+    float* lin_f = lin; float* l0_f = l0; float* l1_f = l1;
+    const bool split_lin = DENSE && lin != nullptr && ((reinterpret_cast<uintptr_t>(lin) | reinterpret_cast<uintptr_t>(l0) |
+                                                       reinterpret_cast<uintptr_t>(l1) | reinterpret_cast<uintptr_t>(slot)) & 15) == 0;
+    if (split_lin) { lin = nullptr; l0 = nullptr; l1 = nullptr; }
     const int64_t items = DENSE ? rows : max_entries;
-    const int grid = (int)std::min<int64_t>(ceil_div(items * KQ, 256), 256 * 16);
+    static const int gmul = getenv("DCTR_OPT_GRID") ? atoi(getenv("DCTR_OPT_GRID")) : 8;
+    static const int nt = getenv("DCTR_OPT_NT") ? atoi(getenv("DCTR_OPT_NT")) : 0;
+    const int grid = (int)std::min<int64_t>(ceil_div(items * KQ, 256), 256 * gmul);
     float4* e4 = reinterpret_cast<float4*>(emb);
     float4* a4 = reinterpret_cast<float4*>(e0);
     float4* b4 = reinterpret_cast<float4*>(e1);
     const float4* g4 = reinterpret_cast<const float4*>(gemb);
     switch (KQ) {
-#define DCTR_T(Q) case Q: opt_table_kernel<KIND, Q, DENSE><<<grid, 256, 0, st>>>(hdev, hval, rows, e4, a4, b4, lin, l0, l1, slot, uniq, counters, g4, glin, l2, sumsq_emb, sumsq_lin); break
+#define DCTR_T(Q) case Q: opt_table_kernel<KIND, Q, DENSE><<<grid, 256, 0, st>>>(hdev, hval, rows, e4, a4, b4, lin, l0, l1, slot, uniq, counters, g4, glin, l2, sumsq_emb, sumsq_lin, nt); break
         DCTR_T(1); DCTR_T(2); DCTR_T(4); DCTR_T(8); DCTR_T(16); DCTR_T(32); DCTR_T(64);
 #undef DCTR_T
         default: set_error("opt_table: K=%d unsupported", K); return DCTR_ERR_UNSUPPORTED;
+    }
+    if (split_lin) {
+        const int gl = (int)std::min<int64_t>(ceil_div(rows / 4 + 1, 256), 2048);
+        opt_lin_dense_kernel<KIND><<<gl, 256, 0, st_lin>>>(hdev, hval, rows, lin_f, l0_f, l1_f, slot, glin, l2, sumsq_lin);
     }
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
@@ -414,14 +562,15 @@ static int launch_table(const Hyper* hdev, const Hyper& hval, int64_t rows, int 
 int opt_table(int kind, const Hyper* hdev, const Hyper& hval, int table_mode, int64_t rows, int K, float* emb, float* e0,
               float* e1, float* lin, float* l0, float* l1, const int32_t* slot, const int32_t* uniq,
               const int32_t* counters, int64_t max_entries, const float* gemb, const float* glin, float l2,
-              float* sumsq_emb, float* sumsq_lin, hipStream_t st) {
+              float* sumsq_emb, float* sumsq_lin, hipStream_t st, hipStream_t st_lin) {
     const bool dense = table_mode == DCTR_TABLE_DENSE_EXACT;
+    if (st_lin == nullptr) st_lin = st;
 #define DCTR_K(KD)                                                                                                      \
     case KD:                                                                                                            \
         return dense ? launch_table<KD, true>(hdev, hval, rows, K, emb, e0, e1, lin, l0, l1, slot, uniq, counters,      \
-                                              max_entries, gemb, glin, l2, sumsq_emb, sumsq_lin, st)                    \
+                                              max_entries, gemb, glin, l2, sumsq_emb, sumsq_lin, st, st_lin)            \
                      : launch_table<KD, false>(hdev, hval, rows, K, emb, e0, e1, lin, l0, l1, slot, uniq, counters,     \
-                                               max_entries, gemb, glin, l2, sumsq_emb, sumsq_lin, st)
+                                               max_entries, gemb, glin, l2, sumsq_emb, sumsq_lin, st, st_lin)
     switch (kind) {
         DCTR_K(DCTR_OPT_ADAM); DCTR_K(DCTR_OPT_ADAGRAD); DCTR_K(DCTR_OPT_MOMENTUM); DCTR_K(DCTR_OPT_FTRL);
         default: set_error("unknown optimizer kind %d", kind); return DCTR_ERR_INVALID_ARG;
@@ -514,7 +663,7 @@ int dctr_opt_table(int kind, const float* hyper, int table_mode, int64_t rows, i
     DCTR_TRY(dctr_group_buffers(g, &uniq, nullptr, nullptr, nullptr, &slot, &counters, &gemb, &glin));
     const int64_t max_entries = group_capacity(reinterpret_cast<Group*>(g));
     return opt_table(kind, nullptr, h, table_mode, rows, K, d_emb, d_emb_s0, d_emb_s1, d_lin, d_lin_s0, d_lin_s1, slot,
-                     uniq, counters, max_entries, gemb, glin, l2, d_sumsq, d_sumsq ? d_sumsq + 1 : nullptr, as_stream(stream));
+                     uniq, counters, max_entries, gemb, glin, l2, d_sumsq, d_sumsq ? d_sumsq + SUMSQ_SHARDS : nullptr, as_stream(stream), nullptr);
 }
 
 int dctr_auc_update(const float* d_labels, const float* d_prob, int B, int64_t* d_counts, void* stream) {

@@ -68,7 +68,11 @@ struct dctr_engine {
     float* scalars = nullptr;     // [0] xent sum, [1] sumsq emb, [2] sumsq linear, [3] sumsq dense-l2 params
     int32_t* status = nullptr;    // [2]
     // activations
-    int32_t* ids = nullptr;
+    int32_t* ids = nullptr;       // current input slot (aliases slot_*[cur_slot])
+    int32_t* slot_ids[DCTR_INPUT_SLOTS] = {};
+    float* slot_vals[DCTR_INPUT_SLOTS] = {};
+    float* slot_labels[DCTR_INPUT_SLOTS] = {};
+    int cur_slot = 0;
     float *vals = nullptr, *labels = nullptr;
     float *x_in = nullptr, *dx_in = nullptr, *e_buf = nullptr, *S = nullptr, *yw = nullptr, *yv = nullptr;
     float *yd = nullptr, *y = nullptr, *prob = nullptr, *dy = nullptr;

@@ -200,7 +200,7 @@ int build(dctr_engine* E) {
     E->h_state = s;
     DCTR_TRY(dmalloc(&E->state, 1, false));
     DCTR_HIP_CHECK(hipMemcpy(E->state, &s, sizeof(s), hipMemcpyHostToDevice));
-    DCTR_TRY(dmalloc(&E->scalars, 8));
+    DCTR_TRY(dmalloc(&E->scalars, 4 * SUMSQ_SHARDS));   // [0] xent sum; [64..127] emb^2 shards; [128..191] linear^2; [192..255] dense l2 params
     DCTR_TRY(dmalloc(&E->status, 2));
 
     // optimizer slot initial values (DeepFM.py:207 Adagrad 1e-8; Ftrl default accumulator 0.1 [TF-1.4])
@@ -227,9 +227,14 @@ int build(dctr_engine* E) {
     DCTR_TRY(dmalloc(&E->eval_scalars, 8));
 
     // ---- activations
-    DCTR_TRY(dmalloc(&E->ids, (size_t)MB * F));
-    DCTR_TRY(dmalloc(&E->vals, (size_t)MB * F));
-    DCTR_TRY(dmalloc(&E->labels, (size_t)MB));
+    // DCTR_INPUT_SLOTS sets of input staging buffers: a caller that fills a slot directly (dctr_input_slot) pays no copy,
+    // and each slot has its own captured graph, so batches can be staged while earlier steps run
+    for (int k = 0; k < DCTR_INPUT_SLOTS; ++k) {
+        DCTR_TRY(dmalloc(&E->slot_ids[k], (size_t)MB * F));
+        DCTR_TRY(dmalloc(&E->slot_vals[k], (size_t)MB * F));
+        DCTR_TRY(dmalloc(&E->slot_labels[k], (size_t)MB));
+    }
+    E->ids = E->slot_ids[0]; E->vals = E->slot_vals[0]; E->labels = E->slot_labels[0];
     DCTR_TRY(dmalloc(&E->x_in, (size_t)MB * E->Din_ld));
     DCTR_TRY(dmalloc(&E->dx_in, (size_t)MB * E->Din_ld));
     if (c.model == DCTR_MODEL_NFM || afm) {
@@ -270,14 +275,19 @@ int build(dctr_engine* E) {
 // ---- forward (train=true: dropout on, DeepFM.py:161-162) ------------------------------------------------
 // the gather reads (emb, lin, rows, ids): the engine's own tables, or -- in the row-sharded path -- the buffer of rows
 // received from their owners with ids = positions in that buffer
-int forward_from(dctr_engine* E, const float* emb, const float* lin, int64_t rows, const int32_t* ids, int B, bool train,
-                 hipStream_t st) {
+int gather_from(dctr_engine* E, const float* emb, const float* lin, int64_t rows, const int32_t* ids, int B, hipStream_t st) {
     const dctr_config& c = E->cfg;
     const int F = E->F, K = E->K, D = E->D;
     const int mode = gather_mode(E);
     float* red = mode == DCTR_GATHER_FM ? E->yv : (mode == DCTR_GATHER_BI ? E->x_in : nullptr);
     DCTR_TRY(embed_gather_fwd(emb, lin, rows, ids, E->vals, B, F, K, mode, E->e, E->e_ld, lin ? E->yw : nullptr,
                               E->S, red, E->status, st));
+    return DCTR_OK;
+}
+
+int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st) {
+    const dctr_config& c = E->cfg;
+    const int F = E->F, K = E->K, D = E->D;
     if (c.model == DCTR_MODEL_AFM) return afm_forward(E, B, train, st);
     const uint64_t* seedp = &E->state->seed_t;
     if (c.model == DCTR_MODEL_IPNN) DCTR_TRY(pnn_inner_fwd(E->e, E->e_ld, B, F, K, E->x_in + D, E->Din_ld, st));
@@ -306,8 +316,11 @@ int forward_from(dctr_engine* E, const float* emb, const float* lin, int64_t row
     return DCTR_OK;
 }
 
+int forward_gather(dctr_engine* E, int B, hipStream_t st) { return gather_from(E, E->emb, E->lin, E->rows, E->ids, B, st); }
+
 int forward(dctr_engine* E, int B, bool train, hipStream_t st) {
-    return forward_from(E, E->emb, E->lin, E->rows, E->ids, B, train, st);
+    DCTR_TRY(forward_gather(E, B, st));
+    return forward_rest(E, B, train, st);
 }
 
 int head(dctr_engine* E, int B, int global_batch, bool with_labels, hipStream_t st) {
@@ -369,16 +382,18 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
 }
 
 // ---- table side of the backward: segment-sum the row gradients (ids already grouped), step the tables ------------
-int scatter_and_step_tables(dctr_engine* E, int B, hipStream_t st) {
+int scatter_and_step_tables(dctr_engine* E, int B, hipStream_t st, hipStream_t st_lin = nullptr) {
     const dctr_config& c = E->cfg;
     const int mode = gather_mode(E);
     const float* dE = mode == DCTR_GATHER_BI ? nullptr : E->dE;
     const float* coef = mode == DCTR_GATHER_FM ? E->dy : (mode == DCTR_GATHER_BI ? E->dx_in : nullptr);
     DCTR_TRY(embed_scatter_bwd(E->group, dE, E->dE_ld, E->e, E->e_ld, E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F,
                                E->K, mode, E->group->gemb, E->lin ? E->group->glin : nullptr, st));
+    if (st_lin != nullptr && st_lin != st) DCTR_TRY(fork(E, st, st_lin));        // the compact gradients are complete on st
     DCTR_TRY(opt_table(c.optimizer, &E->state->hyper, E->h_state.hyper, c.table_mode, E->rows, E->K, E->emb, E->emb_s0, E->emb_s1,
                        E->lin, E->lin_s0, E->lin_s1, E->group->slot, E->group->uniq, E->group->counters, E->group->max_entries,
-                       E->group->gemb, E->group->glin, c.l2_reg, E->scalars + 1, E->scalars + 2, st));
+                       E->group->gemb, E->group->glin, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, st, st_lin));
+    if (st_lin != nullptr && st_lin != st) DCTR_TRY(fork(E, st_lin, st));
     return DCTR_OK;
 }
 
@@ -388,18 +403,22 @@ int scatter_and_step_tables(dctr_engine* E, int B, hipStream_t st) {
 //   sw : weight gradients (each waits for its layer's dY) -> dense optimizer (runs beside scatter + table optimizer)
 int record_train(dctr_engine* E, int B, hipStream_t st) {
     hipStream_t sg = E->s_group, sw = E->s_wgrad;
-    DCTR_HIP_CHECK(hipMemsetAsync(E->scalars, 0, 8 * sizeof(float), st));
-    DCTR_TRY(step_state_advance(E->state, st));
-    DCTR_TRY(fork(E, st, sg));
+    // per-step state (loss scalars, global_step, Adam lr_t, dropout seed) off the critical path: the gather does not need it
+    DCTR_TRY(fork(E, st, sw));
+    DCTR_HIP_CHECK(hipMemsetAsync(E->scalars, 0, 4 * SUMSQ_SHARDS * sizeof(float), sw));
+    DCTR_TRY(step_state_advance(E->state, sw));
+    DCTR_TRY(forward_gather(E, B, st));
+    DCTR_TRY(fork(E, st, sg));              // grouping starts after the gather (its atomics slow a concurrent gather 4x)
     DCTR_TRY(group_ids(E->group, E->ids, B, E->F, sg));
-    DCTR_TRY(forward(E, B, true, st));
+    DCTR_TRY(fork(E, sw, st));
+    DCTR_TRY(forward_rest(E, B, true, st));
     DCTR_TRY(head(E, B, B, true, st));
     DCTR_TRY(backward_dense(E, B, st, sw));
     DCTR_TRY(fork(E, st, sw));          // cross-network / output-layer partials are written on st
     DCTR_TRY(opt_dense_arena(E->cfg.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->parts, E->meta,
-                             E->n_blocks, nullptr, 1, E->scalars + 3, sw));
+                             E->n_blocks, nullptr, 1, E->scalars + 3 * SUMSQ_SHARDS, sw));
     DCTR_TRY(fork(E, sg, st));
-    DCTR_TRY(scatter_and_step_tables(E, B, st));
+    DCTR_TRY(scatter_and_step_tables(E, B, st, sg));       // the grouping stream is idle by now: linear table beside the embedding table
     DCTR_TRY(fork(E, sw, st));
     return DCTR_OK;
 }
@@ -412,7 +431,8 @@ int record_predict(dctr_engine* E, int B, hipStream_t st) {
 
 int run_graph(dctr_engine* E, std::map<int, hipGraphExec_t>& cache, int B, bool train, hipStream_t st) {
     if (!E->cfg.use_graph) return train ? record_train(E, B, st) : record_predict(E, B, st);
-    auto it = cache.find(B);
+    const int key = B * DCTR_INPUT_SLOTS + E->cur_slot;        // input pointers are baked into the graph
+    auto it = cache.find(key);
     if (it == cache.end()) {
         hipGraph_t graph = nullptr;
         hipStream_t cs = nullptr;
@@ -426,7 +446,7 @@ int run_graph(dctr_engine* E, std::map<int, hipGraphExec_t>& cache, int B, bool 
         hipGraphExec_t exec = nullptr;
         DCTR_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         hipGraphDestroy(graph);
-        it = cache.emplace(B, exec).first;
+        it = cache.emplace(key, exec).first;
     }
     DCTR_HIP_CHECK(hipGraphLaunch(it->second, st));
     return DCTR_OK;
@@ -435,10 +455,30 @@ int run_graph(dctr_engine* E, std::map<int, hipGraphExec_t>& cache, int B, bool 
 int stage_inputs(dctr_engine* E, const int32_t* ids, const float* vals, const float* labels, int B, hipStream_t st) {
     DCTR_REQUIRE(B > 0 && B <= E->MB, "batch %d outside (0, max_batch=%d]", B, E->MB);
     const size_t n = (size_t)B * E->F;
+    // the caller's buffers ARE one of the input slots: select it, nothing to copy
+    int slot = 0;
+    for (int k = 0; k < DCTR_INPUT_SLOTS; ++k)
+        if (ids == E->slot_ids[k] && vals == E->slot_vals[k] && (labels == nullptr || labels == E->slot_labels[k])) slot = k;
+    E->cur_slot = slot;
+    E->ids = E->slot_ids[slot]; E->vals = E->slot_vals[slot]; E->labels = E->slot_labels[slot];
     if (ids != E->ids) DCTR_HIP_CHECK(hipMemcpyAsync(E->ids, ids, n * 4, hipMemcpyDeviceToDevice, st));
     if (vals != E->vals) DCTR_HIP_CHECK(hipMemcpyAsync(E->vals, vals, n * 4, hipMemcpyDeviceToDevice, st));
     if (labels != nullptr && labels != E->labels)
         DCTR_HIP_CHECK(hipMemcpyAsync(E->labels, labels, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    return DCTR_OK;
+}
+
+// [0] xent sum, [1] sum emb^2, [2] sum linear^2, [3] sum of l2-regularised dense params^2 (shards summed on the host); syncs
+int read_scalars(dctr_engine* E, float out[4], hipStream_t st) {
+    float raw[4 * SUMSQ_SHARDS];
+    DCTR_HIP_CHECK(hipMemcpyAsync(raw, E->scalars, sizeof(raw), hipMemcpyDeviceToHost, st));
+    DCTR_HIP_CHECK(hipStreamSynchronize(st));
+    out[0] = raw[0];
+    for (int k = 1; k < 4; ++k) {
+        double s = 0.0;
+        for (int j = 0; j < SUMSQ_SHARDS; ++j) s += raw[k * SUMSQ_SHARDS + j];
+        out[k] = (float)s;
+    }
     return DCTR_OK;
 }
 
@@ -468,12 +508,12 @@ int dctr_destroy(dctr_handle E) {
     for (auto& kv : E->train_graphs) hipGraphExecDestroy(kv.second);
     for (auto& kv : E->predict_graphs) hipGraphExecDestroy(kv.second);
     float* fl[] = {E->emb, E->emb_s0, E->emb_s1, E->lin, E->lin_s0, E->lin_s1, E->theta, E->as0, E->as1, E->gflat, E->parts,
-                   E->scalars, E->vals, E->labels, E->x_in, E->dx_in, E->e_buf, E->S, E->yw, E->yv, E->yd, E->y, E->prob, E->dy,
+                   E->scalars, E->x_in, E->dx_in, E->e_buf, E->S, E->yw, E->yv, E->yd, E->y, E->prob, E->dy,
                    E->xs, E->xlw, E->dxL, E->cross_scratch};
     for (float* p : fl) if (p) hipFree(p);
     for (float* p : E->h) hipFree(p);
     for (float* p : E->dh) hipFree(p);
-    if (E->ids) hipFree(E->ids);
+    for (int k = 0; k < DCTR_INPUT_SLOTS; ++k) { if (E->slot_ids[k]) hipFree(E->slot_ids[k]); if (E->slot_vals[k]) hipFree(E->slot_vals[k]); if (E->slot_labels[k]) hipFree(E->slot_labels[k]); }
     if (E->status) hipFree(E->status);
     if (E->state) hipFree(E->state);
     if (E->meta) hipFree(E->meta);
@@ -562,8 +602,7 @@ int dctr_train_step(dctr_handle E, const int32_t* d_ids, const float* d_vals, co
     E->last_B = B;
     if (h_loss) {
         float sc[4];
-        DCTR_HIP_CHECK(hipMemcpyAsync(sc, E->scalars, sizeof(sc), hipMemcpyDeviceToHost, st));
-        DCTR_HIP_CHECK(hipStreamSynchronize(st));
+        DCTR_TRY(read_scalars(E, sc, st));
         // DeepFM.py:188-190: mean xent + l2_reg*(l2_loss(W) + l2_loss(V)), evaluated with the pre-update weights
         *h_loss = sc[0] / (float)B + E->cfg.l2_reg * 0.5f * (sc[1] + sc[2] + sc[3]);
     }
@@ -630,6 +669,14 @@ int dctr_eval_result(dctr_handle E, float* h_auc, float* h_loss, int64_t* h_exam
     return DCTR_OK;
 }
 
+int dctr_input_slot(dctr_handle E, int slot, int32_t** d_ids, float** d_vals, float** d_labels) {
+    DCTR_REQUIRE(E && slot >= 0 && slot < DCTR_INPUT_SLOTS, "slot must be in [0,%d)", DCTR_INPUT_SLOTS);
+    if (d_ids) *d_ids = E->slot_ids[slot];
+    if (d_vals) *d_vals = E->slot_vals[slot];
+    if (d_labels) *d_labels = E->slot_labels[slot];
+    return DCTR_OK;
+}
+
 int dctr_check_ids(dctr_handle E, void* stream) {
     DCTR_REQUIRE(E, "null handle");
     int32_t s[2] = {0, 0};
@@ -692,12 +739,12 @@ int dctr_table_apply_grads(dctr_handle E, const int32_t* d_rows, int n, const fl
     }
     return opt_table(c.optimizer, &E->state->hyper, E->h_state.hyper, c.table_mode, E->rows, E->K, E->emb, E->emb_s0, E->emb_s1,
                      E->lin, E->lin_s0, E->lin_s1, E->group->slot, E->group->uniq, E->group->counters, E->group->max_entries,
-                     E->group->gemb, E->group->glin, c.l2_reg, E->scalars + 1, E->scalars + 2, st);
+                     E->group->gemb, E->group->glin, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, st);
 }
 
 int dctr_step_begin(dctr_handle E, void* stream) {
     DCTR_REQUIRE(E, "null handle");
-    DCTR_HIP_CHECK(hipMemsetAsync(E->scalars, 0, 8 * sizeof(float), as_stream(stream)));
+    DCTR_HIP_CHECK(hipMemsetAsync(E->scalars, 0, 4 * SUMSQ_SHARDS * sizeof(float), as_stream(stream)));
     return step_state_advance(E->state, as_stream(stream));
 }
 
@@ -710,7 +757,8 @@ int dctr_sharded_forward_backward(dctr_handle E, const float* d_rows, const floa
     const size_t n = (size_t)B * E->F;
     if (d_vals != E->vals) DCTR_HIP_CHECK(hipMemcpyAsync(E->vals, d_vals, n * 4, hipMemcpyDeviceToDevice, st));
     if (d_labels && d_labels != E->labels) DCTR_HIP_CHECK(hipMemcpyAsync(E->labels, d_labels, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
-    DCTR_TRY(forward_from(E, d_rows, E->lin ? d_lin : nullptr, n_rows, d_idx, B, train != 0, st));
+    DCTR_TRY(gather_from(E, d_rows, E->lin ? d_lin : nullptr, n_rows, d_idx, B, st));
+    DCTR_TRY(forward_rest(E, B, train != 0, st));
     DCTR_TRY(head(E, B, global_batch, d_labels != nullptr, st));
     if (train) DCTR_TRY(backward_dense(E, B, st, st));
     E->last_B = B;
@@ -739,14 +787,12 @@ int dctr_dense_grads(dctr_handle E, float** d_flat, int64_t* n, void* stream) {
 int dctr_dense_apply(dctr_handle E, void* stream) {
     DCTR_REQUIRE(E, "null handle");
     return opt_dense_arena(E->cfg.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->gflat, E->meta_flat,
-                           E->n_blocks, nullptr, 1, E->scalars + 3, as_stream(stream));
+                           E->n_blocks, nullptr, 1, E->scalars + 3 * SUMSQ_SHARDS, as_stream(stream));
 }
 
 int dctr_read_scalars(dctr_handle E, float h_out[4], void* stream) {
     DCTR_REQUIRE(E && h_out, "null argument");
-    DCTR_HIP_CHECK(hipMemcpyAsync(h_out, E->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, as_stream(stream)));
-    DCTR_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
-    return DCTR_OK;
+    return read_scalars(E, h_out, as_stream(stream));
 }
 
 int dctr_last_outputs(dctr_handle E, float** d_prob, float** d_logit) {
@@ -787,10 +833,10 @@ int dctr_time_kernel(dctr_handle E, const char* kernel, int iters, float* h_ms_p
         if (s == "opt_table")
             return opt_table(c.optimizer, &E->state->hyper, E->h_state.hyper, c.table_mode, E->rows, E->K, E->emb, E->emb_s0,
                              E->emb_s1, E->lin, E->lin_s0, E->lin_s1, E->group->slot, E->group->uniq, E->group->counters,
-                             E->group->max_entries, E->group->gemb, E->group->glin, c.l2_reg, E->scalars + 1, E->scalars + 2, cs);
+                             E->group->max_entries, E->group->gemb, E->group->glin, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, cs);
         if (s == "opt_dense")
             return opt_dense_arena(c.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->parts, E->meta,
-                                   E->n_blocks, nullptr, 1, E->scalars + 3, cs);
+                                   E->n_blocks, nullptr, 1, E->scalars + 3 * SUMSQ_SHARDS, cs);
         if (s == "mlp0_fwd" || s == "mlp0_dgrad" || s == "mlp0_wgrad") {
             const Fc& fc = E->mlp[0];
             if (s == "mlp0_fwd")

@@ -19,16 +19,22 @@
 namespace dctr {
 
 
+// forget the previous batch: slot words of its distinct ids back to 0; the last block to finish also zeroes the counters
+// (ticket in counters[3]) so that no separate one-thread launch is needed
 __global__ void group_reset_kernel(int32_t* __restrict__ slot, const int32_t* __restrict__ uniq,
                                    int32_t* __restrict__ counters, int n_max) {
+    __shared__ int last;
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     const int U = counters[0];
     if (u < U && u < n_max) slot[uniq[u]] = 0;
-}
-
-__global__ void group_zero_counters(int32_t* counters) {
-    counters[0] = 0;
-    counters[1] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) last = (atomicAdd(&counters[3], 1) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        counters[0] = 0;
+        counters[1] = 0;
+        counters[3] = 0;
+    }
 }
 
 // Wave-level grouping of equal ids without memory traffic: for every lane, the lowest lane of the wave holding the
@@ -73,38 +79,69 @@ __global__ __launch_bounds__(256) void group_count_kernel(const int32_t* __restr
     const WaveGroup g = wave_group(id, valid, lane);
     bool first = false;     // this wave is the first to touch the id
     if (valid && g.leader == lane) first = atomicAdd(&slot[id], g.count) == 0;
-    // compact-slot allocation: one atomic per wave for all of its newly seen ids
+    // compact-slot allocation: ONE atomic on the shared counter per 256-thread block (a single word sustains only ~90
+    // atomics/us, so one per wave -- 2500 per batch -- cost more than everything else in this kernel)
+    __shared__ int wcount[4];
+    __shared__ int bbase;
+    const int wave = threadIdx.x >> 6;
     const unsigned long long fm = __ballot(first);
-    if (fm != 0ull) {
-        int base = 0;
-        const int head = __ffsll((long long)fm) - 1;
-        if (lane == head) base = atomicAdd(&counters[0], __popcll(fm));
-        base = __shfl(base, head);
-        if (first) uniq[base + __popcll(fm & ((1ull << lane) - 1ull))] = id;
+    if (lane == 0) wcount[wave] = __popcll(fm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        bbase = tot ? atomicAdd(&counters[0], tot) : 0;
+    }
+    __syncthreads();
+    if (first) {
+        int base = bbase;
+        for (int w = 0; w < wave; ++w) base += wcount[w];
+        uniq[base + __popcll(fm & ((1ull << lane) - 1ull))] = id;
     }
 }
 
-template <int KQ>
-__global__ __launch_bounds__(256) void group_finalize_kernel(int32_t* __restrict__ slot, const int32_t* __restrict__ uniq,
+// one thread per distinct id: carve its segment of the grouped-entry array (one atomic per block on the running total)
+__global__ __launch_bounds__(256) void group_segments_kernel(int32_t* __restrict__ slot, const int32_t* __restrict__ uniq,
                                                             int32_t* __restrict__ cnt, int32_t* __restrict__ seg_start,
                                                             int32_t* __restrict__ cursor, int32_t* __restrict__ counters,
-                                                            float4* __restrict__ gemb, float* __restrict__ glin) {
-    // KQ lanes per distinct id (they zero the compact gradient row together)
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int u = t / KQ, kq = t % KQ;
+                                                            float* __restrict__ glin) {
+    __shared__ int wsum[4];
+    __shared__ int bbase;
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int U = counters[0];
-    if (u >= U) return;
-    if (kq == 0) {
-        const int id = uniq[u];
-        const int c = slot[id];
-        const int s = atomicAdd(&counters[1], c);
+    int c = 0, id = 0;
+    if (u < U) { id = uniq[u]; c = slot[id]; }
+    // inclusive scan of c within the wave
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        bbase = tot ? atomicAdd(&counters[1], tot) : 0;
+    }
+    __syncthreads();
+    if (u < U) {
+        int s = bbase + incl - c;
+        for (int w = 0; w < wave; ++w) s += wsum[w];
         cnt[u] = c;
         seg_start[u] = s;
         cursor[u] = s;
         slot[id] = u + 1;
         glin[u] = 0.f;
     }
-    gemb[(size_t)u * KQ + kq] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// zero the compact gradient rows of the U distinct ids (KQ float4 lanes per row)
+template <int KQ>
+__global__ __launch_bounds__(256) void group_finalize_kernel(const int32_t* __restrict__ counters, float4* __restrict__ gemb) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t / KQ >= counters[0]) return;
+    gemb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 __global__ __launch_bounds__(256) void group_fill_kernel(const int32_t* __restrict__ ids, int B, int F, int64_t rows,
@@ -137,6 +174,7 @@ constexpr int SCATTER_RUN = 16;   // grouped positions per walker
 template <int KQ, int MODE>
 __global__ __launch_bounds__(256) void scatter_bwd_kernel(
     const int32_t* __restrict__ perm, const int32_t* __restrict__ seg_of, const int32_t* __restrict__ counters,
+    const int32_t* __restrict__ seg_start, const int32_t* __restrict__ cnt,
     const float4* __restrict__ dE, int de_ld4, const float4* __restrict__ e, int e_ld4,
     const float4* __restrict__ S, const float* __restrict__ coef, const float* __restrict__ dy,
     const float* __restrict__ vals, int B, int F, float* __restrict__ gemb, float* __restrict__ glin) {
@@ -147,18 +185,28 @@ __global__ __launch_bounds__(256) void scatter_bwd_kernel(
     if (j0 >= total) return;
     const int jend = min(total, j0 + SCATTER_RUN);
     int cur = -1;
+    bool inside = false;          // the current segment started inside this run
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float accl = 0.f;
+    // a segment that lies entirely inside the run (the common case: most ids occur once per batch) is written with plain
+    // 16-byte stores; only segments that straddle runs use float atomics on the pre-zeroed compact row
+    auto flush = [&](bool whole) {
+        float* g = gemb + ((size_t)cur * KQ + kq) * 4;
+        if (whole) {
+            *reinterpret_cast<float4*>(g) = acc;
+            if (kq == 0 && glin != nullptr) glin[cur] = accl;
+        } else {
+            atomicAdd(g + 0, acc.x); atomicAdd(g + 1, acc.y); atomicAdd(g + 2, acc.z); atomicAdd(g + 3, acc.w);
+            if (kq == 0 && glin != nullptr) atomicAdd(glin + cur, accl);
+        }
+    };
     for (int j = j0; j < jend; ++j) {
         const int u = seg_of[j];
         const int i = perm[j];
         const int f = i / B, b = i - f * B;
         if (u != cur) {
-            if (cur >= 0) {
-                float* g = gemb + ((size_t)cur * KQ + kq) * 4;
-                atomicAdd(g + 0, acc.x); atomicAdd(g + 1, acc.y); atomicAdd(g + 2, acc.z); atomicAdd(g + 3, acc.w);
-                if (kq == 0 && glin != nullptr) atomicAdd(glin + cur, accl);
-            }
+            if (cur >= 0) flush(inside);                      // ended by a key change: it ended inside the run
+            inside = (j > j0) || (seg_start[u] == j0);
             cur = u;
             acc = make_float4(0.f, 0.f, 0.f, 0.f);
             accl = 0.f;
@@ -182,11 +230,7 @@ __global__ __launch_bounds__(256) void scatter_bwd_kernel(
         acc.x += d.x * v; acc.y += d.y * v; acc.z += d.z * v; acc.w += d.w * v;
         if (kq == 0 && dy != nullptr) accl += dy[b] * v;
     }
-    if (cur >= 0) {
-        float* g = gemb + ((size_t)cur * KQ + kq) * 4;
-        atomicAdd(g + 0, acc.x); atomicAdd(g + 1, acc.y); atomicAdd(g + 2, acc.z); atomicAdd(g + 3, acc.w);
-        if (kq == 0 && glin != nullptr) atomicAdd(glin + cur, accl);
-    }
+    if (cur >= 0) flush(inside && (seg_start[cur] + cnt[cur] <= jend));
 }
 
 template <int KQ>
@@ -198,7 +242,7 @@ static int launch_scatter(Group* g, const float* dE, int de_ld, const float* e, 
     dim3 grid(ceil_div((int64_t)walkers * KQ, 256)), block(256);
 #define DCTR_SC(MODE_)                                                                                         \
     scatter_bwd_kernel<KQ, MODE_><<<grid, block, 0, st>>>(                                                     \
-        g->perm, g->seg_of, g->counters, reinterpret_cast<const float4*>(dE), de_ld / 4,                       \
+        g->perm, g->seg_of, g->counters, g->seg_start, g->cnt, reinterpret_cast<const float4*>(dE), de_ld / 4,                       \
         reinterpret_cast<const float4*>(e), e_ld / 4, reinterpret_cast<const float4*>(S), coef, dy, vals, B, F, \
         gemb, glin)
     switch (mode) {
@@ -247,15 +291,15 @@ int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st) {
     DCTR_REQUIRE(n <= g->max_entries, "group_ids: B*F=%lld exceeds capacity %lld", (long long)n, (long long)g->max_entries);
     // always forget the previous batch (slot words back to 0, U = 0), even for an empty one
     group_reset_kernel<<<ceil_div(g->max_entries, 256), 256, 0, st>>>(g->slot, g->uniq, g->counters, (int)g->max_entries);
-    group_zero_counters<<<1, 1, 0, st>>>(g->counters);
     if (n <= 0) { DCTR_LAUNCH_CHECK(); return DCTR_OK; }
     const int nb = ceil_div(n, 256);
     group_count_kernel<<<nb, 256, 0, st>>>(ids, B, F, g->rows, g->slot, g->uniq, g->counters);
+    group_segments_kernel<<<nb, 256, 0, st>>>(g->slot, g->uniq, g->cnt, g->seg_start, g->cursor, g->counters, g->glin);
     const int KQ = g->K / 4;
     dim3 fgrid(ceil_div(n * KQ, 256));
     float4* gemb4 = reinterpret_cast<float4*>(g->gemb);
     switch (KQ) {
-#define DCTR_FIN(Q) case Q: group_finalize_kernel<Q><<<fgrid, 256, 0, st>>>(g->slot, g->uniq, g->cnt, g->seg_start, g->cursor, g->counters, gemb4, g->glin); break
+#define DCTR_FIN(Q) case Q: group_finalize_kernel<Q><<<fgrid, 256, 0, st>>>(g->counters, gemb4); break
         DCTR_FIN(1); DCTR_FIN(2); DCTR_FIN(4); DCTR_FIN(8); DCTR_FIN(16); DCTR_FIN(32); DCTR_FIN(64);
 #undef DCTR_FIN
         default: set_error("group: K=%d unsupported", g->K); return DCTR_ERR_UNSUPPORTED;

@@ -17,6 +17,9 @@ struct StepState {
     Hyper hyper;
 };
 
+// sum-of-squares outputs (the l2_loss part of the reported loss) are SUMSQ_SHARDS-way sharded by block index: thousands of
+// blocks adding to ONE word serialise at ~90 atomics/us and used to cost more than the streaming pass itself
+constexpr int SUMSQ_SHARDS = 64;
 constexpr int OPT_BLOCK = 1024;   // elements of the dense arena handled by one optimizer block
 struct OptBlockMeta {
     int64_t part_off;     // offset (floats) into the partial-gradient workspace for this block's first element
@@ -85,7 +88,7 @@ int opt_dense_flat(int kind, const Hyper* hdev, const Hyper& hval, float* theta,
 int opt_table(int kind, const Hyper* hdev, const Hyper& hval, int table_mode, int64_t rows, int K, float* emb, float* e0,
               float* e1, float* lin, float* l0, float* l1, const int32_t* slot, const int32_t* uniq,
               const int32_t* counters, int64_t max_entries, const float* gemb, const float* glin, float l2,
-              float* sumsq_emb, float* sumsq_lin, hipStream_t st);
+              float* sumsq_emb, float* sumsq_lin, hipStream_t st, hipStream_t st_lin = nullptr);
 int step_state_advance(StepState* s, hipStream_t st);
 
 // ---- interact.hip

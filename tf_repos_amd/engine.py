@@ -169,6 +169,23 @@ class Engine:
                                           capi.ptr(out_logit), st))
         return out_prob
 
+    def input_slot(self, slot: int):
+        """Zero-copy torch views (ids i32 [max_batch,F], vals f32 [max_batch,F], labels f32 [max_batch]) of engine-owned
+        input staging set `slot`; batches written there are consumed by train_step/predict without a staging copy."""
+        import torch
+        pi, pv, pl = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        capi.check(self._lib.dctr_input_slot(self._h, slot, C.byref(pi), C.byref(pv), C.byref(pl)))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        MB, F = self.cfg.max_batch, self.cfg.field_size
+
+        def view(ptr, shape, typestr):
+            class _A:
+                pass
+            a = _A()
+            a.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr.value, False), "version": 2}
+            return torch.as_tensor(a, device=dev)
+        return view(pi, (MB, F), "<i4"), view(pv, (MB, F), "<f4"), view(pl, (MB,), "<f4")
+
     def eval_reset(self, stream=None) -> None:
         capi.check(self._lib.dctr_eval_reset(self._h, stream if stream is not None else capi.current_stream()))
 

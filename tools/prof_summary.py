@@ -33,7 +33,28 @@ def pmc(paths):
         print("%-80s %s" % (k[:80], "  ".join("%s=%.4g (n=%d)" % (c, sum(v) / len(v), len(v)) for c, v in sorted(d.items()))))
 
 
+def timeline(path, anchor="step_state_kernel", which=40):
+    """Start offset / duration of every kernel between two consecutive launches of `anchor` (one training step)."""
+    cur = sqlite3.connect(path).cursor()
+    cols = [d[0] for d in cur.execute("select * from kernels limit 1").description]
+    ni, si, ei = cols.index("name"), cols.index("start"), cols.index("end")
+    qi = cols.index("queue_id") if "queue_id" in cols else (cols.index("stream_id") if "stream_id" in cols else None)
+    rows = sorted(cur.execute("select * from kernels"), key=lambda r: r[si])
+    marks = [i for i, r in enumerate(rows) if anchor in r[ni]]
+    if len(marks) < which + 2:
+        which = max(0, len(marks) - 2)
+    a, b = marks[which], marks[which + 1]
+    t0 = rows[a][si]
+    print("one step: %d kernels, %.1f us from first start to last end" % (b - a, (max(r[ei] for r in rows[a:b]) - t0) / 1e3))
+    print("%10s %10s %6s  %s" % ("start_us", "dur_us", "queue", "kernel"))
+    for r in rows[a:b]:
+        print("%10.1f %10.1f %6s  %s" % ((r[si] - t0) / 1e3, (r[ei] - r[si]) / 1e3, r[qi] if qi is not None else "-", r[ni][:70]))
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "timeline":
+        timeline(sys.argv[2])
+        sys.exit(0)
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
     else:

@@ -14,7 +14,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o $TAG -- python $R
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_sq -o $TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> $OUT/pmc_sq.err
 cd $R
 python tools/prof_summary.py stats $OUT/trace/${TAG}_results.db > $OUT/${TAG}_kernel_stats.txt 2>&1
+python tools/prof_summary.py timeline $OUT/trace/${TAG}_results.db > $OUT/${TAG}_step_timeline.txt 2>&1
 python tools/prof_summary.py pmc $OUT/pmc_fetch/${TAG}_results.db $OUT/pmc_write/${TAG}_results.db > $OUT/${TAG}_pmc_traffic.txt 2>&1
 python tools/prof_summary.py pmc $OUT/pmc_sq/${TAG}_results.db > $OUT/${TAG}_pmc_sq.txt 2>&1
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
-head -30 $OUT/${TAG}_kernel_stats.txt; cat $OUT/${TAG}_pmc_traffic.txt | head -40
+cat $OUT/${TAG}_step_timeline.txt | head -60
