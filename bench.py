@@ -106,7 +106,8 @@ def main():
         eng = Engine(EngineConfig(model=w["model"], field_size=w["field_size"], feature_size=w["feature_size"],
                                   embedding_size=w["embedding_size"], deep_layers=w["deep_layers"], dropout=w["dropout"],
                                   l2_reg=w["l2_reg"], learning_rate=w["learning_rate"], optimizer=w["optimizer"],
-                                  table_mode=args.table_mode, max_batch=B, seed=1))
+                                  table_mode=args.table_mode, max_batch=B, seed=1,
+                                  use_graph=os.environ.get("DCTR_USE_GRAPH", "0") == "1"))
         rng = np.random.default_rng(1)
         for name, shp in eng.param_shapes.items():
             eng.set_param(name, rng.normal(0, 0.01, size=shp).astype(np.float32))

@@ -215,8 +215,7 @@ int afm_forward(dctr_engine* E, int B, bool train, hipStream_t st) {
     afm_pool_fwd_kernel<<<B, 256, (size_t)P * sizeof(float), st>>>(E->sc, E->pairp, P, K, E->keep_att, E->keep_emb, &E->state->seed_t,
                                                                    train ? 1 : 0, E->att, E->x_in);
     DCTR_LAUNCH_CHECK();
-    DCTR_TRY(rowdot(E->x_in, E->Din_ld, E->pp(E->p_out_w), E->pp(E->p_out_b), B, K, E->yd, 0, st));
-    return DCTR_OK;
+    return DCTR_OK;      // the fc(K -> 1) output layer is fused into the head kernel
 }
 
 // leaves dL/de in E->dE_buf; dense-gradient partial slabs in E->parts

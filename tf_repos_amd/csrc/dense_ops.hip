@@ -258,6 +258,181 @@ __global__ __launch_bounds__(256) void loss_head_kernel(const float* __restrict_
     if (threadIdx.x == 0 && loss_sum != nullptr && labels != nullptr) atomicAdd(loss_sum, red[0] + red[1] + red[2] + red[3]);
 }
 
+// ---- fused output layer + loss head: y_d = x1[b,:].w1 (+ x2[b,:].w2) + b_out, then the loss head of DeepFM.py:174-176,188.
+// One wave per example (4 per block); the xent sum goes to one of SUMSQ_SHARDS shards (a thousand blocks on one word would
+// serialise).  Replaces three launches (rowdot, rowdot, loss_head) on the critical path between forward and backward.
+__global__ __launch_bounds__(256) void head_fused_kernel(const float* __restrict__ x1, int ld1, const float* __restrict__ w1, int n1,
+                                                        const float* __restrict__ x2, int ld2, const float* __restrict__ w2, int n2,
+                                                        const float* __restrict__ b_out, const float* __restrict__ bias,
+                                                        const float* __restrict__ yw, const float* __restrict__ yv,
+                                                        const float* __restrict__ labels, int B, float inv_batch,
+                                                        float* __restrict__ yd_out, float* __restrict__ y_out, float* __restrict__ prob,
+                                                        float* __restrict__ dy, float* __restrict__ loss_shards) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    float l = 0.f;
+    if (b < B) {
+        float s = 0.f;
+        const float* r1 = x1 + (size_t)b * ld1;
+        for (int j = lane; j < n1; j += 64) s += r1[j] * w1[j];
+        if (x2 != nullptr) {
+            const float* r2 = x2 + (size_t)b * ld2;
+            for (int j = lane; j < n2; j += 64) s += r2[j] * w2[j];
+        }
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float ydv = s + (b_out ? b_out[0] : 0.f);
+            float y = ydv;
+            if (bias) y += bias[0];
+            if (yw) y += yw[b];
+            if (yv) y += yv[b];
+            const float en = __expf(-fabsf(y));
+            const float p = (y >= 0.f) ? 1.0f / (1.0f + en) : en / (1.0f + en);
+            yd_out[b] = ydv;
+            y_out[b] = y;
+            prob[b] = p;
+            if (labels) {
+                const float z = labels[b];
+                l = fmaxf(y, 0.f) - y * z + log1pf(expf(-fabsf(y)));
+                if (dy) dy[b] = (p - z) * inv_batch;
+            }
+        }
+    }
+    if (lane == 0) red[wave] = l;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_shards != nullptr && labels != nullptr)
+        atomicAdd(loss_shards + (blockIdx.x & (SUMSQ_SHARDS - 1)), red[0] + red[1] + red[2] + red[3]);
+}
+
+int head_fused(const float* x1, int ld1, const float* w1, int n1, const float* x2, int ld2, const float* w2, int n2,
+               const float* b_out, const float* bias, const float* yw, const float* yv, const float* labels, int B, float inv_batch,
+               float* yd, float* y, float* prob, float* dy, float* loss_shards, hipStream_t st) {
+    if (B <= 0) return DCTR_OK;
+    head_fused_kernel<<<ceil_div(B, 4), 256, 0, st>>>(x1, ld1, w1, n1, x2, ld2, w2, n2, b_out, bias, yw, yv, labels, B, inv_batch, yd, y,
+                                                      prob, dy, loss_shards);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+// ---- TRAIN: output layer forward + loss head + output layer backward in ONE launch.  A block owns `rows_per_block`
+// examples: phase 1 (one wave per example) computes logit / prob / xent / dy into LDS, phase 2 (128 float4 column groups x 2
+// row lanes) re-reads the block's rows of x (L2-resident) for dX = dy (x) w [masked] and the dW partial slab.
+struct HeadSeg { const float* x; int ld; const float* w; int n; int masked; float* dx; int lddx; };
+
+__global__ __launch_bounds__(256) void head_out_bwd_kernel(HeadSeg s1, HeadSeg s2, const float* __restrict__ b_out,
+                                                          const float* __restrict__ bias, const float* __restrict__ yw,
+                                                          const float* __restrict__ yv, const float* __restrict__ labels, int B,
+                                                          float inv_batch, float inv_keep, int rows_per_block,
+                                                          float* __restrict__ yd_out, float* __restrict__ y_out, float* __restrict__ prob,
+                                                          float* __restrict__ dy_out, float* __restrict__ loss_shards,
+                                                          float* __restrict__ dw_part, int64_t dw_stride, float* __restrict__ db_part,
+                                                          int64_t db_stride) {
+    __shared__ float dys[64];
+    __shared__ float4 red[128];
+    __shared__ float lred[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rbeg = blockIdx.x * rows_per_block, rend = min(B, rbeg + rows_per_block);
+    float lsum = 0.f;
+    // phase 1: 8 lanes per example, 32 examples at a time, float4 loads -> all of the block's dot products in flight together
+    for (int rb = rbeg; rb < rend; rb += 32) {
+        const int r = rb + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+        float s = 0.f;
+        if (r < rend) {
+            const float* r1 = s1.x + (size_t)r * s1.ld;
+            for (int j = sub * 4; j < s1.n; j += 32) {
+                const float4 a = *reinterpret_cast<const float4*>(r1 + j);
+                const float4 w = *reinterpret_cast<const float4*>(s1.w + j);
+                s += a.x * w.x + a.y * w.y + a.z * w.z + a.w * w.w;
+            }
+            if (s2.x != nullptr) {
+                const float* r2 = s2.x + (size_t)r * s2.ld;
+                for (int j = sub * 4; j < s2.n; j += 32) {
+                    const float4 a = *reinterpret_cast<const float4*>(r2 + j);
+                    const float4 w = *reinterpret_cast<const float4*>(s2.w + j);
+                    s += a.x * w.x + a.y * w.y + a.z * w.z + a.w * w.w;
+                }
+            }
+        }
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+        if (r < rend && sub == 0) {
+            const float ydv = s + (b_out ? b_out[0] : 0.f);
+            float y = ydv;
+            if (bias) y += bias[0];
+            if (yw) y += yw[r];
+            if (yv) y += yv[r];
+            const float en = __expf(-fabsf(y));
+            const float p = (y >= 0.f) ? 1.0f / (1.0f + en) : en / (1.0f + en);
+            const float z = labels[r];
+            lsum += fmaxf(y, 0.f) - y * z + log1pf(expf(-fabsf(y)));
+            const float d = (p - z) * inv_batch;
+            yd_out[r] = ydv; y_out[r] = y; prob[r] = p; dy_out[r] = d;
+            dys[r - rbeg] = d;
+        }
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) lred[wave] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(loss_shards + (blockIdx.x & (SUMSQ_SHARDS - 1)), lred[0] + lred[1] + lred[2] + lred[3]);
+        float s = 0.f;
+        for (int r = 0; r < rend - rbeg; ++r) s += dys[r];
+        db_part[(size_t)blockIdx.x * db_stride] = s;
+    }
+    const int cg = threadIdx.x & 127, rl = threadIdx.x >> 7;
+    int col_off = 0;
+#pragma unroll
+    for (int seg = 0; seg < 2; ++seg) {
+        const HeadSeg& g = seg == 0 ? s1 : s2;
+        if (g.x == nullptr) break;
+        for (int c0 = 0; c0 < g.n; c0 += 512) {
+            const int c = c0 + cg * 4;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < g.n) {
+                const float4 wc = *reinterpret_cast<const float4*>(g.w + c);
+                for (int r = rbeg + rl; r < rend; r += 2) {
+                    const float d = dys[r - rbeg];
+                    const float4 xv = *reinterpret_cast<const float4*>(g.x + (size_t)r * g.ld + c);
+                    acc.x += d * xv.x; acc.y += d * xv.y; acc.z += d * xv.z; acc.w += d * xv.w;
+                    float4 o = make_float4(d * wc.x, d * wc.y, d * wc.z, d * wc.w);
+                    if (g.masked) {
+                        o.x = xv.x > 0.f ? o.x * inv_keep : 0.f; o.y = xv.y > 0.f ? o.y * inv_keep : 0.f;
+                        o.z = xv.z > 0.f ? o.z * inv_keep : 0.f; o.w = xv.w > 0.f ? o.w * inv_keep : 0.f;
+                    }
+                    *reinterpret_cast<float4*>(g.dx + (size_t)r * g.lddx + c) = o;
+                }
+            }
+            if (rl == 1) red[cg] = acc;
+            __syncthreads();
+            if (rl == 0 && c < g.n) {
+                const float4 o = red[cg];
+                *reinterpret_cast<float4*>(dw_part + (size_t)blockIdx.x * dw_stride + col_off + c) =
+                    make_float4(acc.x + o.x, acc.y + o.y, acc.z + o.z, acc.w + o.w);
+            }
+            __syncthreads();
+        }
+        col_off += g.n;
+    }
+}
+
+// returns DCTR_ERR_UNSUPPORTED (without setting an error) when the shapes do not meet the float4 alignment rules
+int head_out_bwd(const float* x1, int ld1, const float* w1, int n1, int masked1, float* dx1, int lddx1,
+                 const float* x2, int ld2, const float* w2, int n2, int masked2, float* dx2, int lddx2,
+                 const float* b_out, const float* bias, const float* yw, const float* yv, const float* labels, int B, float inv_batch,
+                 float keep, int splits, float* yd, float* y, float* prob, float* dy, float* loss_shards, float* dw_part,
+                 int64_t dw_stride, float* db_part, int64_t db_stride, hipStream_t st) {
+    auto ok = [](const void* p, int ld, int n) { return p == nullptr || ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 4 == 0 && n % 4 == 0); };
+    const int rpb = ceil_div(B, splits);
+    if (B <= 0 || rpb > 64 || !ok(x1, ld1, n1) || !ok(dx1, lddx1, n1) || !ok(w1, 4, n1) || !ok(x2, ld2, n2) || !ok(dx2, lddx2, n2) ||
+        !ok(w2, 4, n2) || dw_stride % 4 != 0 || (reinterpret_cast<uintptr_t>(dw_part) & 15) != 0)
+        return DCTR_ERR_UNSUPPORTED;
+    HeadSeg s1{x1, ld1, w1, n1, masked1, dx1, lddx1}, s2{x2, ld2, w2, n2, masked2, dx2, lddx2};
+    head_out_bwd_kernel<<<splits, 256, 0, st>>>(s1, s2, b_out, bias, yw, yv, labels, B, inv_batch, 1.0f / keep, rpb, yd, y, prob, dy,
+                                                loss_shards, dw_part, dw_stride, db_part, db_stride);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
 int loss_head(const float* bias, const float* yw, const float* yv, const float* yd, const float* labels, int B,
               float inv_batch, float* y, float* prob, float* dy, float* loss_sum, hipStream_t st) {
     if (B <= 0) return DCTR_OK;
@@ -580,7 +755,9 @@ int opt_table(int kind, const Hyper* hdev, const Hyper& hval, int table_mode, in
 
 // ---- per-step device state: global_step, Adam's lr_t, the dropout seed of this step.  Lives in device memory
 // so that a captured hipGraph sees fresh values on every replay.
-__global__ void step_state_kernel(StepState* s) {
+__global__ void step_state_kernel(StepState* s, float* zero, int n_zero) {
+    for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero[i] = 0.f;     // the step's loss scalars
+    if (threadIdx.x != 0) return;
     s->t += 1;
     const double t = (double)s->t;
     Hyper& h = s->hyper;
@@ -588,8 +765,8 @@ __global__ void step_state_kernel(StepState* s) {
     s->seed_t = s->seed ^ ((uint64_t)s->t * 0xD1B54A32D192ED03ULL);
 }
 
-int step_state_advance(StepState* s, hipStream_t st) {
-    step_state_kernel<<<1, 1, 0, st>>>(s);
+int step_state_advance(StepState* s, float* zero, int n_zero, hipStream_t st) {
+    step_state_kernel<<<1, 256, 0, st>>>(s, zero, n_zero);
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }

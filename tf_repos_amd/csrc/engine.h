@@ -73,6 +73,7 @@ struct dctr_engine {
     float* slot_vals[DCTR_INPUT_SLOTS] = {};
     float* slot_labels[DCTR_INPUT_SLOTS] = {};
     int cur_slot = 0;
+    bool head_did_out_bwd = false;   // the fused head kernel already produced the output layer's backward
     float *vals = nullptr, *labels = nullptr;
     float *x_in = nullptr, *dx_in = nullptr, *e_buf = nullptr, *S = nullptr, *yw = nullptr, *yv = nullptr;
     float *yd = nullptr, *y = nullptr, *prob = nullptr, *dy = nullptr;

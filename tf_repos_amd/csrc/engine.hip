@@ -200,7 +200,7 @@ int build(dctr_engine* E) {
     E->h_state = s;
     DCTR_TRY(dmalloc(&E->state, 1, false));
     DCTR_HIP_CHECK(hipMemcpy(E->state, &s, sizeof(s), hipMemcpyHostToDevice));
-    DCTR_TRY(dmalloc(&E->scalars, 4 * SUMSQ_SHARDS));   // [0] xent sum; [64..127] emb^2 shards; [128..191] linear^2; [192..255] dense l2 params
+    DCTR_TRY(dmalloc(&E->scalars, 4 * SUMSQ_SHARDS));   // [0..63] xent shards; [64..127] emb^2 shards; [128..191] linear^2; [192..255] dense l2 params
     DCTR_TRY(dmalloc(&E->status, 2));
 
     // optimizer slot initial values (DeepFM.py:207 Adagrad 1e-8; Ftrl default accumulator 0.1 [TF-1.4])
@@ -224,7 +224,7 @@ int build(dctr_engine* E) {
     for (auto& ev : E->events) DCTR_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 
     DCTR_TRY(dmalloc(&E->auc_counts, 800));
-    DCTR_TRY(dmalloc(&E->eval_scalars, 8));
+    DCTR_TRY(dmalloc(&E->eval_scalars, 2 * SUMSQ_SHARDS));   // [0..63] xent shards over the eval set, [64] sum of squares scratch
 
     // ---- activations
     // DCTR_INPUT_SLOTS sets of input staging buffers: a caller that fills a slot directly (dctr_input_slot) pays no copy,
@@ -303,17 +303,7 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st) {
                         0x1000ull + i, st));
         x = E->h[i]; ldx = fc.out;
     }
-    const int H = E->mlp.back().out;
-    const float* wout = E->pp(E->p_out_w);
-    if (c.model == DCTR_MODEL_DCN) {
-        // fc([x_L || mlp_out]) -> 1   (DCN.py:179-183); xs is laid out [L+1, B, D] for the current B
-        const float* xL = E->xs + (size_t)c.cross_layers * B * D;
-        DCTR_TRY(rowdot(xL, D, wout, E->pp(E->p_out_b), B, D, E->yd, 0, st));
-        DCTR_TRY(rowdot(E->h.back(), H, wout + D, nullptr, B, H, E->yd, 1, st));
-    } else {
-        DCTR_TRY(rowdot(E->h.back(), H, wout, E->pp(E->p_out_b), B, H, E->yd, 0, st));   // deep_out, DeepFM.py:165-167
-    }
-    return DCTR_OK;
+    return DCTR_OK;     // the [H -> 1] output layer is fused into the head kernel (head())
 }
 
 int forward_gather(dctr_engine* E, int B, hipStream_t st) { return gather_from(E, E->emb, E->lin, E->rows, E->ids, B, st); }
@@ -323,18 +313,63 @@ int forward(dctr_engine* E, int B, bool train, hipStream_t st) {
     return forward_rest(E, B, train, st);
 }
 
-int head(dctr_engine* E, int B, int global_batch, bool with_labels, hipStream_t st) {
+// output layer ([H -> 1], DeepFM.py:165-167; DCN's fc([x_L || mlp_out]), DCN.py:179-183; AFM's fc(K -> 1), AFM.py:160-162) fused
+// with logit / sigmoid / xent / dy.  `loss_shards`: SUMSQ_SHARDS floats receiving the xent sum.
+int head(dctr_engine* E, int B, int global_batch, bool with_labels, hipStream_t st, float* loss_shards = nullptr, bool fuse_out_bwd = false) {
     const dctr_config& c = E->cfg;
     const float* bias = E->p_bias >= 0 ? E->pp(E->p_bias) : nullptr;
     const float* yw = E->lin ? E->yw : nullptr;
     const float* yv = c.model == DCTR_MODEL_DEEPFM ? E->yv : nullptr;
-    return loss_head(bias, yw, yv, E->yd, with_labels ? E->labels : nullptr, B, 1.0f / (float)global_batch, E->y, E->prob,
-                     with_labels ? E->dy : nullptr, with_labels ? E->scalars : nullptr, st);
+    const float* wout = E->pp(E->p_out_w);
+    const float *x1, *x2 = nullptr, *w2 = nullptr;
+    int ld1, n1, ld2 = 0, n2 = 0;
+    if (c.model == DCTR_MODEL_AFM) {
+        x1 = E->x_in; ld1 = E->Din_ld; n1 = E->K;
+    } else if (c.model == DCTR_MODEL_DCN) {
+        x1 = E->xs + (size_t)c.cross_layers * B * E->D; ld1 = E->D; n1 = E->D;      // xs is laid out [L+1, B, D] for the current B
+        x2 = E->h.back(); ld2 = E->mlp.back().out; n2 = ld2; w2 = wout + E->D;
+    } else {
+        x1 = E->h.back(); ld1 = E->mlp.back().out; n1 = ld1;
+    }
+    if (loss_shards == nullptr) loss_shards = E->scalars;
+    E->head_did_out_bwd = false;
+    if (fuse_out_bwd && with_labels && c.model != DCTR_MODEL_AFM) {
+        // one launch for output layer forward + loss head + output layer backward (dh_last / dxL, dW and db partial slabs)
+        const Param& pw = E->params[E->p_out_w];
+        const Param& pb = E->params[E->p_out_b];
+        const float keep_last = E->mlp.back().keep;
+        int rc;
+        if (c.model == DCTR_MODEL_DCN)
+            rc = head_out_bwd(x1, ld1, wout, n1, 0, E->dxL, E->D, x2, ld2, w2, n2, 1, E->dh.back(), ld2, E->pp(E->p_out_b), bias, yw, yv,
+                              E->labels, B, 1.0f / (float)global_batch, keep_last, pw.n_part, E->yd, E->y, E->prob, E->dy, loss_shards,
+                              E->part(E->p_out_w), pw.padded, E->part(E->p_out_b), pb.padded, st);
+        else
+            rc = head_out_bwd(x1, ld1, wout, n1, 1, E->dh.back(), ld1, nullptr, 0, nullptr, 0, 0, nullptr, 0, E->pp(E->p_out_b), bias, yw, yv,
+                              E->labels, B, 1.0f / (float)global_batch, keep_last, pw.n_part, E->yd, E->y, E->prob, E->dy, loss_shards,
+                              E->part(E->p_out_w), pw.padded, E->part(E->p_out_b), pb.padded, st);
+        if (rc == DCTR_OK) { E->head_did_out_bwd = true; return DCTR_OK; }
+        if (rc != DCTR_ERR_UNSUPPORTED) return rc;
+    }
+    return head_fused(x1, ld1, wout, n1, x2, ld2, w2, n2, E->pp(E->p_out_b), bias, yw, yv, with_labels ? E->labels : nullptr, B,
+                      1.0f / (float)global_batch, E->yd, E->y, E->prob, with_labels ? E->dy : nullptr,
+                      with_labels ? loss_shards : nullptr, st);
 }
 
 // ---- backward through head + MLP + interaction: leaves dL/de in dx_in (or the BI coefficient for NFM) ----------
 // st: critical path (dgrad chain); sw: side stream for the weight gradients (independent of the dgrad chain)
-int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
+// optimizer over the arena blocks of parameters [first, last] (inclusive, consecutive in the arena)
+int opt_dense_range(dctr_engine* E, int p_first, int p_last, hipStream_t st) {
+    const Param& a = E->params[p_first];
+    const Param& b = E->params[p_last];
+    const int64_t off = a.arena_off;
+    const int nb = (int)((b.arena_off + b.padded - off) / OPT_BLOCK);
+    return opt_dense_arena(E->cfg.optimizer, &E->state->hyper, E->h_state.hyper, E->theta + off, E->as0 + off, E->as1 + off, E->parts,
+                           E->meta + off / OPT_BLOCK, nb, nullptr, 1, E->scalars + 3 * SUMSQ_SHARDS, st);
+}
+
+// fused_opt: step each MLP layer's weights on the side stream as soon as BOTH its wgrad (same stream) and its dgrad (which
+// still reads the old weights, other stream) are done -- the dense optimizer then costs nothing at the end of the step
+int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool fused_opt = false) {
     const dctr_config& c = E->cfg;
     if (c.model == DCTR_MODEL_AFM) return afm_backward(E, B, st, sw);
     const int F = E->F, K = E->K, D = E->D;
@@ -345,7 +380,9 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
     const Param& pw = E->params[E->p_out_w];
     const Param& pb = E->params[E->p_out_b];
     // output layer in one pass over h_last: dh = dy (x) w (masked), dW = h^T dy, db = sum dy (also the global bias' gradient)
-    if (c.model == DCTR_MODEL_DCN) {
+    if (E->head_did_out_bwd) {
+        // already done inside the fused head kernel
+    } else if (c.model == DCTR_MODEL_DCN) {
         const float* xL = E->xs + (size_t)c.cross_layers * B * D;
         DCTR_TRY(out_layer_bwd(xL, D, E->dy, wout, B, D, pw.n_part, 0, 1.f, E->dxL, D, E->part(E->p_out_w), pw.padded, nullptr, 0, st));
         DCTR_TRY(out_layer_bwd(E->h.back(), H, E->dy, wout + D, B, H, pw.n_part, 1, keep_last, E->dh.back(), H,
@@ -368,6 +405,10 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
                                  E->mlp[i - 1].out, E->mlp[i - 1].keep, st));
         else
             DCTR_TRY(fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w), E->dx_in, E->Din_ld, B, fc.in, fc.out, nullptr, 0, 1.f, st));
+        if (fused_opt) {
+            DCTR_TRY(fork(E, st, sw));          // dgrad_i (reader of the old W_i) is complete
+            DCTR_TRY(opt_dense_range(E, fc.w, fc.b, sw));
+        }
     }
     const uint64_t* seedp = &E->state->seed_t;
     if (c.model == DCTR_MODEL_IPNN) DCTR_TRY(pnn_inner_bwd(E->e, E->e_ld, E->dx_in + D, E->Din_ld, B, F, K, E->dx_in, E->Din_ld, st));
@@ -405,18 +446,39 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     hipStream_t sg = E->s_group, sw = E->s_wgrad;
     // per-step state (loss scalars, global_step, Adam lr_t, dropout seed) off the critical path: the gather does not need it
     DCTR_TRY(fork(E, st, sw));
-    DCTR_HIP_CHECK(hipMemsetAsync(E->scalars, 0, 4 * SUMSQ_SHARDS * sizeof(float), sw));
-    DCTR_TRY(step_state_advance(E->state, sw));
+    DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, sw));
     DCTR_TRY(forward_gather(E, B, st));
     DCTR_TRY(fork(E, st, sg));              // grouping starts after the gather (its atomics slow a concurrent gather 4x)
     DCTR_TRY(group_ids(E->group, E->ids, B, E->F, sg));
     DCTR_TRY(fork(E, sw, st));
     DCTR_TRY(forward_rest(E, B, true, st));
-    DCTR_TRY(head(E, B, B, true, st));
-    DCTR_TRY(backward_dense(E, B, st, sw));
+    DCTR_TRY(head(E, B, B, true, st, nullptr, true));
+    const bool fused_opt = E->cfg.model != DCTR_MODEL_AFM;
+    if (fused_opt && E->head_did_out_bwd) {
+        // the output layer (and the global bias, whose gradient aliases the output bias' slabs) is final right after the fused
+        // head kernel: step it now, beside the MLP backward, instead of at the end of the step beside the scatter
+        DCTR_TRY(fork(E, st, sw));
+        DCTR_TRY(opt_dense_range(E, E->p_out_w, E->p_out_b, sw));
+        if (E->p_bias >= 0) DCTR_TRY(opt_dense_range(E, E->p_bias, E->p_bias, sw));
+    }
+    const bool out_done = fused_opt && E->head_did_out_bwd;
+    DCTR_TRY(backward_dense(E, B, st, sw, fused_opt));
     DCTR_TRY(fork(E, st, sw));          // cross-network / output-layer partials are written on st
-    DCTR_TRY(opt_dense_arena(E->cfg.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->parts, E->meta,
-                             E->n_blocks, nullptr, 1, E->scalars + 3 * SUMSQ_SHARDS, sw));
+    if (fused_opt) {
+        // what is left of the dense arena: cross_w / cross_b (DCN), and the output layer + bias if they were not stepped above
+        for (int i = 0; i < (int)E->params.size(); ++i) {
+            const Param& p = E->params[i];
+            if (p.is_table) continue;
+            bool is_mlp = false;
+            for (auto& fc : E->mlp) is_mlp = is_mlp || i == fc.w || i == fc.b;
+            if (is_mlp) continue;
+            if (out_done && (i == E->p_out_w || i == E->p_out_b || i == E->p_bias)) continue;
+            DCTR_TRY(opt_dense_range(E, i, i, sw));
+        }
+    } else {
+        DCTR_TRY(opt_dense_arena(E->cfg.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->parts, E->meta,
+                                 E->n_blocks, nullptr, 1, E->scalars + 3 * SUMSQ_SHARDS, sw));
+    }
     DCTR_TRY(fork(E, sg, st));
     DCTR_TRY(scatter_and_step_tables(E, B, st, sg));       // the grouping stream is idle by now: linear table beside the embedding table
     DCTR_TRY(fork(E, sw, st));
@@ -473,8 +535,7 @@ int read_scalars(dctr_engine* E, float out[4], hipStream_t st) {
     float raw[4 * SUMSQ_SHARDS];
     DCTR_HIP_CHECK(hipMemcpyAsync(raw, E->scalars, sizeof(raw), hipMemcpyDeviceToHost, st));
     DCTR_HIP_CHECK(hipStreamSynchronize(st));
-    out[0] = raw[0];
-    for (int k = 1; k < 4; ++k) {
+    for (int k = 0; k < 4; ++k) {
         double s = 0.0;
         for (int j = 0; j < SUMSQ_SHARDS; ++j) s += raw[k * SUMSQ_SHARDS + j];
         out[k] = (float)s;
@@ -632,7 +693,7 @@ __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __re
 int dctr_eval_reset(dctr_handle E, void* stream) {
     DCTR_REQUIRE(E, "null handle");
     DCTR_HIP_CHECK(hipMemsetAsync(E->auc_counts, 0, 800 * sizeof(int64_t), as_stream(stream)));
-    DCTR_HIP_CHECK(hipMemsetAsync(E->eval_scalars, 0, 8 * sizeof(float), as_stream(stream)));
+    DCTR_HIP_CHECK(hipMemsetAsync(E->eval_scalars, 0, 2 * SUMSQ_SHARDS * sizeof(float), as_stream(stream)));
     E->eval_examples = 0;
     return DCTR_OK;
 }
@@ -642,9 +703,7 @@ int dctr_eval_batch(dctr_handle E, const int32_t* d_ids, const float* d_vals, co
     hipStream_t st = as_stream(stream);
     DCTR_TRY(stage_inputs(E, d_ids, d_vals, d_labels, B, st));
     DCTR_TRY(forward(E, B, false, st));
-    const float* bias = E->p_bias >= 0 ? E->pp(E->p_bias) : nullptr;
-    DCTR_TRY(loss_head(bias, E->lin ? E->yw : nullptr, E->cfg.model == DCTR_MODEL_DEEPFM ? E->yv : nullptr, E->yd, E->labels, B,
-                       1.0f / (float)B, E->y, E->prob, nullptr, E->eval_scalars, st));
+    DCTR_TRY(head(E, B, B, true, st, E->eval_scalars));      // dy is written too (unused in EVAL)
     DCTR_TRY(dctr_auc_update(E->labels, E->prob, B, E->auc_counts, stream));
     E->eval_examples += B;
     E->last_B = B;
@@ -657,13 +716,15 @@ int dctr_eval_result(dctr_handle E, float* h_auc, float* h_loss, int64_t* h_exam
     if (h_auc) DCTR_TRY(dctr_auc_result(E->auc_counts, h_auc, stream));
     if (h_loss) {
         // loss of DeepFM.py:188-190 over the eval set: mean xent + l2_reg * sum l2_loss(regularised variables)
-        DCTR_HIP_CHECK(hipMemsetAsync(E->eval_scalars + 1, 0, sizeof(float), st));
+        DCTR_HIP_CHECK(hipMemsetAsync(E->eval_scalars + SUMSQ_SHARDS, 0, sizeof(float), st));
         for (auto& p : E->params)
-            if (p.l2 != 0.f) sumsq_kernel<<<1024, 256, 0, st>>>(p.ptr, p.n, E->eval_scalars + 1);
-        float sc[2];
+            if (p.l2 != 0.f) sumsq_kernel<<<256, 256, 0, st>>>(p.ptr, p.n, E->eval_scalars + SUMSQ_SHARDS);
+        float sc[SUMSQ_SHARDS + 1];
         DCTR_HIP_CHECK(hipMemcpyAsync(sc, E->eval_scalars, sizeof(sc), hipMemcpyDeviceToHost, st));
         DCTR_HIP_CHECK(hipStreamSynchronize(st));
-        *h_loss = (E->eval_examples > 0 ? sc[0] / (float)E->eval_examples : 0.f) + E->cfg.l2_reg * 0.5f * sc[1];
+        double xent = 0.0;
+        for (int j = 0; j < SUMSQ_SHARDS; ++j) xent += sc[j];
+        *h_loss = (E->eval_examples > 0 ? (float)(xent / (double)E->eval_examples) : 0.f) + E->cfg.l2_reg * 0.5f * sc[SUMSQ_SHARDS];
     }
     if (h_examples) *h_examples = E->eval_examples;
     return DCTR_OK;
@@ -744,8 +805,7 @@ int dctr_table_apply_grads(dctr_handle E, const int32_t* d_rows, int n, const fl
 
 int dctr_step_begin(dctr_handle E, void* stream) {
     DCTR_REQUIRE(E, "null handle");
-    DCTR_HIP_CHECK(hipMemsetAsync(E->scalars, 0, 4 * SUMSQ_SHARDS * sizeof(float), as_stream(stream)));
-    return step_state_advance(E->state, as_stream(stream));
+    return step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, as_stream(stream));
 }
 
 int dctr_sharded_forward_backward(dctr_handle E, const float* d_rows, const float* d_lin, int n_rows, const int32_t* d_idx,
@@ -760,7 +820,7 @@ int dctr_sharded_forward_backward(dctr_handle E, const float* d_rows, const floa
     DCTR_TRY(gather_from(E, d_rows, E->lin ? d_lin : nullptr, n_rows, d_idx, B, st));
     DCTR_TRY(forward_rest(E, B, train != 0, st));
     DCTR_TRY(head(E, B, global_batch, d_labels != nullptr, st));
-    if (train) DCTR_TRY(backward_dense(E, B, st, st));
+    if (train) { E->head_did_out_bwd = false; DCTR_TRY(backward_dense(E, B, st, st)); }
     E->last_B = B;
     return DCTR_OK;
 }
@@ -820,7 +880,7 @@ int dctr_time_kernel(dctr_handle E, const char* kernel, int iters, float* h_ms_p
                                     E->lin ? E->yw : nullptr, E->S, red, E->status, cs);
         }
         if (s == "forward") return forward(E, B, true, cs);
-        if (s == "head") return head(E, B, B, true, cs);
+        if (s == "head") return head(E, B, B, true, cs, nullptr, true);
         if (s == "backward_dense") return backward_dense(E, B, cs, cs);
         if (s == "group_ids") return group_ids(E->group, E->ids, B, E->F, cs);
         if (s == "scatter") {

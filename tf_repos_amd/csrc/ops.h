@@ -89,7 +89,15 @@ int opt_table(int kind, const Hyper* hdev, const Hyper& hval, int table_mode, in
               float* e1, float* lin, float* l0, float* l1, const int32_t* slot, const int32_t* uniq,
               const int32_t* counters, int64_t max_entries, const float* gemb, const float* glin, float l2,
               float* sumsq_emb, float* sumsq_lin, hipStream_t st, hipStream_t st_lin = nullptr);
-int step_state_advance(StepState* s, hipStream_t st);
+int step_state_advance(StepState* s, float* zero, int n_zero, hipStream_t st);
+int head_out_bwd(const float* x1, int ld1, const float* w1, int n1, int masked1, float* dx1, int lddx1,
+                 const float* x2, int ld2, const float* w2, int n2, int masked2, float* dx2, int lddx2,
+                 const float* b_out, const float* bias, const float* yw, const float* yv, const float* labels, int B, float inv_batch,
+                 float keep, int splits, float* yd, float* y, float* prob, float* dy, float* loss_shards, float* dw_part,
+                 int64_t dw_stride, float* db_part, int64_t db_stride, hipStream_t st);
+int head_fused(const float* x1, int ld1, const float* w1, int n1, const float* x2, int ld2, const float* w2, int n2,
+               const float* b_out, const float* bias, const float* yw, const float* yv, const float* labels, int B, float inv_batch,
+               float* yd, float* y, float* prob, float* dy, float* loss_shards, hipStream_t st);
 
 // ---- interact.hip
 int pnn_inner_fwd(const float* e, int e_ld, int B, int F, int K, float* ip, int ip_ld, hipStream_t st);

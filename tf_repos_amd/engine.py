@@ -36,7 +36,8 @@ class EngineConfig:
     seed: int = 0
     shard_rank: int = 0
     shard_world: int = 1
-    use_graph: bool = True
+    use_graph: bool = False                    # False: eager launches on 3 HIP streams (measured faster: each stream keeps its own
+                                               # hardware queue); True: one captured hipGraph per (batch size, input slot)
 
     def to_c(self) -> capi.Config:
         if self.model not in capi.MODELS:
