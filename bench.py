@@ -66,6 +66,24 @@ def cpu_baseline(w, seconds_budget=18.0):
                       "gradient + dense Adam over all rows), %d threads = best of {8,16,32} on a %d-core host" % (n, B, best_nt, cores)}
 
 
+def pmc_traffic_bytes(kernel_substr):
+    """HBM bytes per launch of a kernel from the committed PMC summary (collected by tools/profile_round.sh in separate
+    --pmc passes; a live bench run cannot sample counters).  None when the summary is absent."""
+    import re
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.txt")
+    if not os.path.exists(path):
+        return None
+    f = w = 0.0
+    for line in open(path):
+        if kernel_substr in line:
+            mf = re.search(r"FETCH_SIZE=([0-9.e+]+)", line)
+            mw = re.search(r"WRITE_SIZE=([0-9.e+]+)", line)
+            if mf and mw:
+                f += float(mf.group(1))
+                w += float(mw.group(1))
+    return int((2 * f + w) * 1024) if (f or w) else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,7 +182,10 @@ def main():
                      "mlp0_fwd", "mlp0_dgrad", "mlp0_wgrad", "train_step"]:
             stages[name] = eng.time_stage(name, iters=30)
         gather_bytes = B * (F * (12 + 8 * K) + 8)                 # algorithmic bytes of the gather
-        table_bytes = 7 * V * (K + 1) * 4 + 4 * V                  # theta,m,v read + write, grad read, + slot word
+        # dense-exact table step as implemented: theta,m,v read + write (6 streams) + the 4-byte slot word per row; the per-row
+        # gradient is NOT a dense stream here (only the ~U touched rows read a compact gradient row), so SURVEY 8d's 7-stream
+        # figure (7*V*(K+1)*4 = 476 MB) would flatter the kernel -- 6 streams (412 MB) is what the algorithm must move
+        table_bytes = 6 * V * (K + 1) * 4 + 4 * V
         mlp0_flops = 2.0 * B * (F * K) * w["deep_layers"][0]
         kernels = {
             "embed_gather_fwd": {"bound": "hbm", "ms": stages["embed_gather"], "achieved": gather_bytes / stages["embed_gather"] / 1e6,
@@ -185,7 +206,8 @@ def main():
         dom = "opt_table_dense_adam" if args.table_mode == "dense_exact" else "mlp0_fwd_gemm"
         r = dict(kernels[dom])
         r["kernel"] = dom
-        r["traffic"] = None
+        r["traffic"] = pmc_traffic_bytes("opt_table_kernel") if dom == "opt_table_dense_adam" else None
+        r["traffic_source"] = "profiles/r01_pmc_traffic.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts 1/2 of 16-B/lane streams; MI355X_MICROARCH.md HBM section)"
         out["roofline"] = r
         out["kernels"] = kernels
         out["stage_ms"] = {k: round(v, 5) for k, v in stages.items()}
