@@ -118,7 +118,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         trainer = ShardedTrainer(w, rank, world, dev, table_mode=args.table_mode)
-        step = trainer.train_step
+        step = lambda i, v, l, nxt: trainer.train_step(i, v, l, next_ids=nxt)      # routes the next batch's ids a step ahead
         barrier = dist.barrier
     else:
         eng = Engine(EngineConfig(model=w["model"], field_size=w["field_size"], feature_size=w["feature_size"],
@@ -129,7 +129,7 @@ def main():
         rng = np.random.default_rng(1)
         for name, shp in eng.param_shapes.items():
             eng.set_param(name, rng.normal(0, 0.01, size=shp).astype(np.float32))
-        step = lambda i, v, l: eng.train_step(i, v, l, want_loss=False)
+        step = lambda i, v, l, nxt: eng.train_step(i, v, l, want_loss=False)
         barrier = lambda: None
 
     nb = 8
@@ -147,12 +147,12 @@ def main():
         batches.append(t)
 
     for s in range(args.warmup):
-        step(*batches[s % nb])
+        step(*batches[s % nb], batches[(s + 1) % nb][0])
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        step(*batches[s % nb])
+        step(*batches[(args.warmup + s) % nb], batches[(args.warmup + s + 1) % nb][0])
     barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0

@@ -261,31 +261,36 @@ int dctr_debug_tensor(dctr_handle h, const char* name, float** d_ptr, int64_t* n
  * call site -- this replaces the async parameter-server push/pull of set_dist_env (DeepFM.py:237-282) with a
  * synchronous step whose only exchanges are three all-to-alls (distinct rows out, rows back, row gradients back) and
  * one all-reduce of the dense gradients, all issued by the host through torch.distributed (RCCL).
+ * Rows and row gradients cross the fabric as PACKED records of K+4 floats: K embedding floats | linear weight | 3 pad
+ * (16-byte aligned; one all-to-all per direction covers both tables).
  * Requester side, on a dctr_group_t created over the GLOBAL id space (rows = feature_size):
- *   dctr_group_ids -> dctr_route_unique -> [all-to-all rows] -> dctr_entry_index -> dctr_sharded_forward_backward
- *   -> dctr_sharded_row_grads -> dctr_permute_unique_rows -> [all-to-all grads] ;  owner side: dctr_table_* below. */
+ *   dctr_group_ids -> dctr_route_unique -> [all-to-all local rows] -> dctr_entry_index            (routing: depends only on
+ *                                                                                                  the ids, may run a step ahead)
+ *   [all-to-all packed rows] -> dctr_sharded_forward_backward -> dctr_sharded_pack_row_grads -> [all-to-all packed grads]
+ * Owner side: dctr_table_group_rows (with the routing) / dctr_table_gather_packed / dctr_table_apply_packed. */
 /* d_counts int32[2*world]: [0:world) distinct ids per owner (the all-to-all send split sizes), rest is scratch.
  * d_send_rows [U] local rows grouped by owner; d_upos [U] position of distinct id u in that send order. */
 int dctr_route_unique(dctr_group_t g, int world, int32_t* d_send_rows, int32_t* d_upos, int32_t* d_counts, void* stream);
 /* d_idx[i] = position (in send order) of entry i's id, -1 for ids outside [0, rows): the `ids` of a gather whose
  * table is the buffer of rows received back from the owners */
 int dctr_entry_index(dctr_group_t g, const int32_t* d_ids, int n, const int32_t* d_upos, int32_t* d_idx, void* stream);
-/* d_dst[d_pos[u], :] = d_src[u, :] for the group's U distinct ids (K = 1 for the linear gradients) */
-int dctr_permute_unique_rows(dctr_group_t g, const float* d_src, const int32_t* d_pos, int K, float* d_dst, void* stream);
-/* owner side: raw rows of this rank's shard (no value scaling): d_out_emb [n,K], d_out_lin [n] (NULL without linear table) */
-int dctr_table_gather_rows(dctr_handle h, const int32_t* d_rows, int n, float* d_out_emb, float* d_out_lin, void* stream);
-/* owner side: segment-sum the received row gradients (a row may arrive from several ranks) and step the shard's tables
- * with the configured optimizer / table_mode */
-int dctr_table_apply_grads(dctr_handle h, const int32_t* d_rows, int n, const float* d_gemb, const float* d_glin, void* stream);
-/* requester side */
-int dctr_step_begin(dctr_handle h, void* stream);                 /* zero the loss scalars, advance global_step / Adam lr_t / dropout seed */
-/* forward (+ backward through head, MLP, interaction when train != 0) on rows received from the owners:
- * d_rows [n_rows,K], d_lin [n_rows] are the table the gather reads, d_idx [B,F] its ids (dctr_entry_index).
- * The logit gradient is (prob - label)/global_batch so that summing dense gradients over ranks gives the mean. */
-int dctr_sharded_forward_backward(dctr_handle h, const float* d_rows, const float* d_lin, int n_rows, const int32_t* d_idx,
+/* owner side: packed raw rows of this rank's shard: d_out [n, K+4] */
+int dctr_table_gather_packed(dctr_handle h, const int32_t* d_rows, int n, float* d_out, void* stream);
+/* owner side: group the n local rows requested by all ranks (a row may be requested by several) into grouping state
+ * `which` (0 or 1: two states, so the rows of step t+1 can be grouped while step t still uses its own) */
+int dctr_table_group_rows(dctr_handle h, int which, const int32_t* d_rows, int n, void* stream);
+/* owner side: segment-sum the n received packed row gradients d_grads [n, K+4] (same order as the rows given to
+ * dctr_table_group_rows(which)) and step the shard's tables with the configured optimizer / table_mode */
+int dctr_table_apply_packed(dctr_handle h, int which, int n, const float* d_grads, void* stream);
+/* requester side: forward (+ backward through head, MLP, interaction when train != 0) on the packed rows received from
+ * the owners: d_rows [n_rows, K+4] is the table the gather reads, d_idx [B,F] its ids (dctr_entry_index).  train != 0
+ * also advances global_step / Adam lr_t / the dropout seed and zeroes the loss scalars.  The logit gradient is
+ * (prob - label)/global_batch so that summing dense gradients over ranks gives the mean. */
+int dctr_sharded_forward_backward(dctr_handle h, const float* d_rows, int n_rows, const int32_t* d_idx,
                                   const float* d_vals, const float* d_labels, int B, int global_batch, int train, void* stream);
-/* per-distinct-id gradients of this rank's batch into g's compact buffers (dctr_group_buffers: d_gemb [U,K], d_glin [U]) */
-int dctr_sharded_row_grads(dctr_handle h, dctr_group_t g, int B, void* stream);
+/* per-distinct-id gradients of this rank's batch (segment sum into g's compact buffers), packed in send order:
+ * d_out[d_upos[u]] = { gemb[u,:], glin[u], 0,0,0 }, d_out [U, K+4] */
+int dctr_sharded_pack_row_grads(dctr_handle h, dctr_group_t g, int B, const int32_t* d_upos, float* d_out, void* stream);
 /* dense gradients: reduce the partial slabs into one flat array (all-reduce it in place), then apply the optimizer */
 int dctr_dense_grads(dctr_handle h, float** d_flat, int64_t* n, void* stream);
 int dctr_dense_apply(dctr_handle h, void* stream);
@@ -293,6 +298,37 @@ int dctr_dense_apply(dctr_handle h, void* stream);
 int dctr_read_scalars(dctr_handle h, float h_out[4], void* stream);
 /* prob / logit of the last forward (device pointers into the engine's buffers, valid until the next call) */
 int dctr_last_outputs(dctr_handle h, float** d_prob, float** d_logit);
+
+/* ---- native driver of the row-sharded step: the sequence above, including its collectives, enqueued from C++ on three
+ * HIP streams (rows/gradients on the caller's stream, routing of the NEXT batch and the dense all-reduce on two internal
+ * ones).  Stands where the TF-1.x distributed runtime stands for the reference (tf.train.Server / replica_device_setter
+ * behind set_dist_env, DeepFM.py:237-282): one process per GPU, rendezvous supplied by the host. */
+typedef struct dctr_dist* dctr_dist_t;
+/* Collective transport.  `channel` selects an independent communicator: 0 = rows/gradients (caller's stream), 1 = routing,
+ * 2 = dense all-reduce; calls on one channel are issued in the same order on every rank.  All pointers are device
+ * pointers; counts are per peer, in records; the call only ENQUEUES on `stream`.  Return DCTR_OK or an error code. */
+typedef struct {
+    void* ctx;
+    int (*all_gather_i32)(void* ctx, int channel, const int32_t* d_send, int n, int32_t* d_recv /* [world*n] */, void* stream);
+    int (*all_to_all)(void* ctx, int channel, const void* d_send, const int64_t* send_counts, void* d_recv,
+                      const int64_t* recv_counts, int64_t record_bytes, void* stream);
+    int (*all_reduce_f32)(void* ctx, int channel, float* d_buf, int64_t n, void* stream);   /* sum, in place */
+} dctr_transport;
+#define DCTR_RCCL_ID_BYTES 128
+/* rank 0: one ncclUniqueId (128 bytes) per channel -- call 3 times, hand the 384 bytes to every rank (any host-side
+ * rendezvous: torch.distributed store, MPI, a file).  rccl_path: librccl to load when the process has none yet (may be NULL). */
+int dctr_rccl_unique_id(const char* rccl_path, char* id128);
+/* RCCL transport over xGMI: ids = 3 * DCTR_RCCL_ID_BYTES bytes from rank 0.  Collective: every rank calls it. */
+int dctr_dist_create_rccl(dctr_handle h, int rank, int world, const char* ids, const char* rccl_path, dctr_dist_t* out);
+/* caller-supplied transport (tests: ranks sharing a GPU, staged over gloo) */
+int dctr_dist_create(dctr_handle h, int rank, int world, const dctr_transport* t, dctr_dist_t* out);
+int dctr_dist_destroy(dctr_dist_t d);
+/* one synchronous step on this rank's B examples (global batch = B * world).  d_next_ids/next_B (optional): the ids the NEXT
+ * call will be given -- they are routed while this step runs; they must have been written before this call and stay
+ * untouched until that call.  h_loss (optional): the global loss (mean xent + l2 terms); asking for it synchronises. */
+int dctr_dist_train_step(dctr_dist_t d, const int32_t* d_ids, const float* d_vals, const float* d_labels, int B,
+                         const int32_t* d_next_ids, int next_B, float* h_loss, void* stream);
+int dctr_dist_predict(dctr_dist_t d, const int32_t* d_ids, const float* d_vals, int B, float* d_prob, void* stream);
 
 /* per-kernel timing hooks used by bench.py for the roofline objects: runs `iters` back-to-back
  * launches of the named kernel on the engine's current buffers between two hipEvents recorded on

@@ -41,12 +41,12 @@ def _exchange_worker(rank, world, port, ret):
         send_rows = torch.from_numpy((send_ids // world).astype(np.int32))
         counts = [int((dest == d).sum()) for d in range(world)]
         x = ShardExchange(Comm())
-        rows_back, = x.request_rows(send_rows, counts, lambda rows: [shard[rows.long()]])
+        r = x.route(send_rows, counts)
+        assert r.send_counts == counts and r.n_send == len(send_ids)
+        rows_back = x.fetch(r, shard[r.recv_rows.long()])
         assert np.array_equal(rows_back.numpy(), table[send_ids]), "rows came back in the wrong order"
-
-        def apply(rows, g):
-            grad_acc.index_add_(0, rows.long(), g)
-        x.return_grads([torch.ones(len(send_ids), K) * (rank + 1)], apply)
+        g = x.return_grads(r, torch.ones(len(send_ids), K) * (rank + 1))
+        grad_acc.index_add_(0, r.recv_rows.long(), g)
         # every rank's contribution must land on the owner's rows exactly once
         all_ids = [None] * world
         dist.all_gather_object(all_ids, send_ids)
@@ -71,7 +71,7 @@ def test_exchange_protocol_gloo_world2():
 
 
 # ------------------------------------------------------------------------------------------------- GPU
-def _shard_worker(rank, world, port, model, ret):
+def _shard_worker(rank, world, port, model, overlap, driver, ret):
     from oracle import deepctr_oracle as O
     from tf_repos_amd.distributed import ShardedTrainer
     _init(rank, world, port)
@@ -84,13 +84,16 @@ def _shard_worker(rank, world, port, model, ret):
         ocfg = O.Config(model=model, field_size=F, feature_size=V, embedding_size=K, deep_layers=(32, 16), dropout=(1.0, 1.0),
                         cross_layers=2, l2_reg=1e-3, learning_rate=1e-2, optimizer="Adam")
         params = {k: v.numpy() for k, v in O.init_params(ocfg, seed=5, scale=0.05).items()}
-        tr = ShardedTrainer(w, rank, world, dev, params=params)
+        tr = ShardedTrainer(w, rank, world, dev, params=params, overlap=overlap, driver=driver)
         losses = []
+        sl = slice(rank * (Bg // world), (rank + 1) * (Bg // world))
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a[sl])).to(dev)
+        batches = [tuple(t(a) for a in O.synth_batch(Bg, F, V, seed=300 + step)) for step in range(3)]
+        torch.cuda.synchronize()
         for step in range(3):
-            ids, vals, labels = O.synth_batch(Bg, F, V, seed=300 + step)
-            sl = slice(rank * (Bg // world), (rank + 1) * (Bg // world))
-            t = lambda a: torch.from_numpy(np.ascontiguousarray(a[sl])).to(dev)
-            losses.append(tr.train_step(t(ids), t(vals), t(labels), want_loss=True))
+            # with overlap, the next batch's ids are routed on the side stream while this step runs
+            nxt = batches[step + 1][0] if (overlap and step + 1 < 3) else None
+            losses.append(tr.train_step(*batches[step], want_loss=True, next_ids=nxt))
         full = tr.gather_full_params()
         ids, vals, labels = O.synth_batch(Bg, F, V, seed=999)
         prob = tr.predict(t(ids), t(vals)).cpu().numpy()
@@ -104,14 +107,15 @@ def _shard_worker(rank, world, port, model, ret):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model", ["deepfm", "dcn", "nfm"])
-def test_two_ranks_equal_one_rank(model, dev):
+@pytest.mark.parametrize("model,overlap,driver", [("deepfm", False, "python"), ("deepfm", True, "python"), ("deepfm", True, "native"),
+                                                  ("dcn", True, "native"), ("nfm", False, "native")])
+def test_two_ranks_equal_one_rank(model, overlap, driver, dev):
     from oracle import deepctr_oracle as O
     from tests.util import dev_batch, make_pair
     world = 2
     with mp.Manager() as m:
         ret = m.dict()
-        mp.spawn(_shard_worker, args=(world, _free_port(), model, ret), nprocs=world, join=True)
+        mp.spawn(_shard_worker, args=(world, _free_port(), model, overlap, driver, ret), nprocs=world, join=True)
         got, losses = dict(ret["params"]), list(ret["losses"])
         probs = np.concatenate([ret["prob0"], ret["prob1"]])
     F, V, K, Bg = 39, 2003, 8, 128

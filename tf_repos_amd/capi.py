@@ -103,19 +103,36 @@ _SIGS = {
     "dctr_check_ids": ([_P, _P], C.c_int),
     "dctr_route_unique": ([_P, C.c_int, _P, _P, _P, _P], C.c_int),
     "dctr_entry_index": ([_P, _P, C.c_int, _P, _P, _P], C.c_int),
-    "dctr_permute_unique_rows": ([_P, _P, _P, C.c_int, _P, _P], C.c_int),
-    "dctr_table_gather_rows": ([_P, _P, C.c_int, _P, _P, _P], C.c_int),
-    "dctr_table_apply_grads": ([_P, _P, C.c_int, _P, _P, _P], C.c_int),
-    "dctr_step_begin": ([_P, _P], C.c_int),
-    "dctr_sharded_forward_backward": ([_P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P], C.c_int),
-    "dctr_sharded_row_grads": ([_P, _P, C.c_int, _P], C.c_int),
+    "dctr_table_gather_packed": ([_P, _P, C.c_int, _P, _P], C.c_int),
+    "dctr_table_group_rows": ([_P, C.c_int, _P, C.c_int, _P], C.c_int),
+    "dctr_table_apply_packed": ([_P, C.c_int, C.c_int, _P, _P], C.c_int),
+    "dctr_sharded_forward_backward": ([_P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P], C.c_int),
+    "dctr_sharded_pack_row_grads": ([_P, _P, C.c_int, _P, _P, _P], C.c_int),
     "dctr_dense_grads": ([_P, C.POINTER(_P), C.POINTER(C.c_int64), _P], C.c_int),
     "dctr_dense_apply": ([_P, _P], C.c_int),
     "dctr_read_scalars": ([_P, C.POINTER(C.c_float * 4), _P], C.c_int),
     "dctr_last_outputs": ([_P, C.POINTER(_P), C.POINTER(_P)], C.c_int),
     "dctr_time_kernel": ([_P, C.c_char_p, C.c_int, C.POINTER(C.c_float), _P], C.c_int),
     "dctr_debug_tensor": ([_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int)], C.c_int),
+    "dctr_rccl_unique_id": ([C.c_char_p, C.c_char_p], C.c_int),
+    "dctr_dist_create_rccl": ([_P, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(_P)], C.c_int),
+    "dctr_dist_create": ([_P, C.c_int, C.c_int, _P, C.POINTER(_P)], C.c_int),
+    "dctr_dist_destroy": ([_P], C.c_int),
+    "dctr_dist_train_step": ([_P, _P, _P, _P, C.c_int, _P, C.c_int, C.POINTER(C.c_float), _P], C.c_int),
+    "dctr_dist_predict": ([_P, _P, _P, C.c_int, _P, _P], C.c_int),
 }
+
+RCCL_ID_BYTES = 128
+# dctr_transport (include/deepctr_hip.h): collective callbacks for the native sharded-step driver
+ALL_GATHER_I32_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
+ALL_TO_ALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64),
+                            C.c_int64, C.c_void_p)
+ALL_REDUCE_F32_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class Transport(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("all_gather_i32", ALL_GATHER_I32_FN), ("all_to_all", ALL_TO_ALL_FN),
+                ("all_reduce_f32", ALL_REDUCE_F32_FN)]
 
 DECLARED_SYMBOLS = tuple(_SIGS)
 

@@ -55,6 +55,7 @@ struct dctr_engine {
     // tables
     float *emb = nullptr, *emb_s0 = nullptr, *emb_s1 = nullptr, *lin = nullptr, *lin_s0 = nullptr, *lin_s1 = nullptr;
     Group* group = nullptr;
+    Group* group_alt = nullptr;     // second owner-side grouping state of the row-sharded path (created on first use)
     // arena
     float *theta = nullptr, *as0 = nullptr, *as1 = nullptr, *gflat = nullptr, *parts = nullptr;
     int64_t arena_n = 0, parts_n = 0;

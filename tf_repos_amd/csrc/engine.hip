@@ -269,6 +269,7 @@ int build(dctr_engine* E) {
         DCTR_TRY(dmalloc(&E->dxL, (size_t)MB * D));
         DCTR_TRY(dmalloc(&E->cross_scratch, (size_t)L * MB * D + (size_t)L * MB));
     }
+    DCTR_HIP_CHECK(hipDeviceSynchronize());     // the zero-fills above ran on the null stream; callers use non-blocking streams
     return DCTR_OK;
 }
 
@@ -276,8 +277,7 @@ int build(dctr_engine* E) {
 // the gather reads (emb, lin, rows, ids): the engine's own tables, or -- in the row-sharded path -- the buffer of rows
 // received from their owners with ids = positions in that buffer
 int gather_from(dctr_engine* E, const float* emb, const float* lin, int64_t rows, const int32_t* ids, int B, hipStream_t st) {
-    const dctr_config& c = E->cfg;
-    const int F = E->F, K = E->K, D = E->D;
+    const int F = E->F, K = E->K;
     const int mode = gather_mode(E);
     float* red = mode == DCTR_GATHER_FM ? E->yv : (mode == DCTR_GATHER_BI ? E->x_in : nullptr);
     DCTR_TRY(embed_gather_fwd(emb, lin, rows, ids, E->vals, B, F, K, mode, E->e, E->e_ld, lin ? E->yw : nullptr,
@@ -582,6 +582,7 @@ int dctr_destroy(dctr_handle E) {
     if (E->auc_counts) hipFree(E->auc_counts);
     if (E->eval_scalars) hipFree(E->eval_scalars);
     if (E->ones) hipFree(E->ones);
+    if (E->group_alt) group_destroy(E->group_alt);
     group_destroy(E->group);
     afm_free(E);
     for (auto& ev : E->events) if (ev) hipEventDestroy(ev);
@@ -777,62 +778,88 @@ int dctr_debug_tensor(dctr_handle E, const char* name, float** d_ptr, int64_t* n
 }
 
 // ---- row-sharded path (declared in deepctr_hip.h under "row-sharded multi-GPU path") ---------------------------------
-int dctr_table_gather_rows(dctr_handle E, const int32_t* d_rows, int n, float* d_out_emb, float* d_out_lin, void* stream) {
-    DCTR_REQUIRE(E && d_rows && d_out_emb, "null argument");
-    DCTR_REQUIRE(n >= 0 && (int64_t)n <= (int64_t)E->MB * E->F * E->cfg.shard_world, "too many rows requested (%d)", n);
-    if (n == 0) return DCTR_OK;
-    // B = n examples of one field each, value 1: e_out [n,K] = raw rows, yw = raw linear weights
-    return embed_gather_fwd(E->emb, E->lin, E->rows, d_rows, E->ones, n, 1, E->K, DCTR_GATHER_RAW, d_out_emb, E->K,
-                            (E->lin && d_out_lin) ? d_out_lin : nullptr, nullptr, nullptr, E->status, as_stream(stream));
+// Rows and row gradients travel as packed [K+4]-float records (shard.hip).  The owner keeps TWO grouping states so that the rows
+// of step t+1 can be grouped (dctr_table_group_rows, on a side stream) while step t still uses its own.
+static Group* owner_group(dctr_engine* E, int which) {
+    if (which == 0) return E->group;
+    if (E->group_alt == nullptr && group_create(E->rows, E->group->max_entries, E->K, &E->group_alt) != DCTR_OK) return nullptr;
+    return E->group_alt;
 }
 
-int dctr_table_apply_grads(dctr_handle E, const int32_t* d_rows, int n, const float* d_gemb, const float* d_glin, void* stream) {
-    DCTR_REQUIRE(E && (n == 0 || (d_rows && d_gemb)), "null argument");
-    DCTR_REQUIRE(n >= 0 && (int64_t)n <= E->group->max_entries, "too many rows (%d)", n);
+int dctr_table_gather_packed(dctr_handle E, const int32_t* d_rows, int n, float* d_out, void* stream) {
+    DCTR_REQUIRE(E && (n == 0 || (d_rows && d_out)), "null argument");
+    DCTR_REQUIRE(n >= 0 && (int64_t)n <= E->group->max_entries, "too many rows requested (%d)", n);
+    return pack_table_rows(E->emb, E->lin, E->rows, E->K, d_rows, n, d_out, E->status, as_stream(stream));
+}
+
+int dctr_table_group_rows(dctr_handle E, int which, const int32_t* d_rows, int n, void* stream) {
+    DCTR_REQUIRE(E && (which == 0 || which == 1) && (n == 0 || d_rows), "bad argument");
+    Group* G = owner_group(E, which);
+    DCTR_REQUIRE(G != nullptr, "owner group allocation failed");
+    DCTR_REQUIRE(n >= 0 && (int64_t)n <= G->max_entries, "too many rows (%d)", n);
+    return group_ids(G, n > 0 ? d_rows : E->ids, n, 1, as_stream(stream));
+}
+
+int dctr_table_apply_packed(dctr_handle E, int which, int n, const float* d_grads, void* stream) {
+    DCTR_REQUIRE(E && (which == 0 || which == 1) && (n == 0 || d_grads), "bad argument");
+    Group* G = owner_group(E, which);
+    DCTR_REQUIRE(G != nullptr, "owner group allocation failed");
+    DCTR_REQUIRE(n >= 0 && (int64_t)n <= G->max_entries, "too many rows (%d)", n);
     hipStream_t st = as_stream(stream);
     const dctr_config& c = E->cfg;
-    if (n > 0) {
-        DCTR_TRY(group_ids(E->group, d_rows, n, 1, st));
-        DCTR_TRY(embed_scatter_bwd(E->group, d_gemb, E->K, nullptr, 0, nullptr, nullptr, (E->lin && d_glin) ? d_glin : nullptr,
-                                   E->ones, n, 1, E->K, DCTR_GATHER_RAW, E->group->gemb, E->lin ? E->group->glin : nullptr, st));
-    } else {
-        DCTR_TRY(group_ids(E->group, E->ids, 0, 1, st));
-    }
+    const int P = E->K + 4;
+    if (n > 0)      // n "examples" of one field each, value 1: dE = the record's K gradient floats, dy = its linear-weight gradient
+        DCTR_TRY(embed_scatter_bwd(G, d_grads, P, nullptr, 0, nullptr, nullptr, E->lin ? d_grads + E->K : nullptr, E->ones, n, 1, E->K,
+                                   DCTR_GATHER_RAW, G->gemb, E->lin ? G->glin : nullptr, st, P));
     return opt_table(c.optimizer, &E->state->hyper, E->h_state.hyper, c.table_mode, E->rows, E->K, E->emb, E->emb_s0, E->emb_s1,
-                     E->lin, E->lin_s0, E->lin_s1, E->group->slot, E->group->uniq, E->group->counters, E->group->max_entries,
-                     E->group->gemb, E->group->glin, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, st);
+                     E->lin, E->lin_s0, E->lin_s1, G->slot, G->uniq, G->counters, G->max_entries, G->gemb, G->glin, c.l2_reg,
+                     E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, st);
 }
 
-int dctr_step_begin(dctr_handle E, void* stream) {
-    DCTR_REQUIRE(E, "null handle");
-    return step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, as_stream(stream));
-}
-
-int dctr_sharded_forward_backward(dctr_handle E, const float* d_rows, const float* d_lin, int n_rows, const int32_t* d_idx,
-                                  const float* d_vals, const float* d_labels, int B, int global_batch, int train, void* stream) {
+// forward (+ backward when train) of one rank's examples against the packed rows received from their owners.  Training also
+// advances the step state (global_step, lr_t, dropout seed; zeroes the loss scalars).  Weight gradients run on the engine's
+// side stream beside the dgrad chain; everything is joined back into `stream` before returning.
+int dctr_sharded_forward_backward(dctr_handle E, const float* d_rows, int n_rows, const int32_t* d_idx, const float* d_vals,
+                                  const float* d_labels, int B, int global_batch, int train, void* stream) {
     DCTR_REQUIRE(E && d_rows && d_idx && d_vals, "null argument");
     DCTR_REQUIRE(B > 0 && B <= E->MB && global_batch >= B, "bad batch sizes B=%d global=%d", B, global_batch);
     DCTR_REQUIRE(!train || d_labels, "labels required for training");
-    hipStream_t st = as_stream(stream);
+    hipStream_t st = as_stream(stream), sw = E->s_wgrad;
     const size_t n = (size_t)B * E->F;
+    const int P = E->K + 4;
+    if (train) {
+        DCTR_TRY(fork(E, st, sw));
+        DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, sw));
+    }
     if (d_vals != E->vals) DCTR_HIP_CHECK(hipMemcpyAsync(E->vals, d_vals, n * 4, hipMemcpyDeviceToDevice, st));
     if (d_labels && d_labels != E->labels) DCTR_HIP_CHECK(hipMemcpyAsync(E->labels, d_labels, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
-    DCTR_TRY(gather_from(E, d_rows, E->lin ? d_lin : nullptr, n_rows, d_idx, B, st));
+    const int mode = gather_mode(E);
+    float* red = mode == DCTR_GATHER_FM ? E->yv : (mode == DCTR_GATHER_BI ? E->x_in : nullptr);
+    DCTR_TRY(embed_gather_strided(d_rows, P, E->lin ? d_rows + E->K : nullptr, P, n_rows, d_idx, E->vals, B, E->F, E->K, mode, E->e,
+                                  E->e_ld, E->lin ? E->yw : nullptr, E->S, red, E->status, st));
+    if (train) DCTR_TRY(fork(E, sw, st));
     DCTR_TRY(forward_rest(E, B, train != 0, st));
-    DCTR_TRY(head(E, B, global_batch, d_labels != nullptr, st));
-    if (train) { E->head_did_out_bwd = false; DCTR_TRY(backward_dense(E, B, st, st)); }
+    DCTR_TRY(head(E, B, global_batch, d_labels != nullptr, st, nullptr, train != 0));
+    if (train) {
+        DCTR_TRY(backward_dense(E, B, st, sw, false));
+        DCTR_TRY(fork(E, sw, st));
+    }
     E->last_B = B;
     return DCTR_OK;
 }
 
-int dctr_sharded_row_grads(dctr_handle E, dctr_group_t g, int B, void* stream) {
-    DCTR_REQUIRE(E && g, "null argument");
+// per-distinct-id gradients of this rank's examples (segment sum into g's compact rows), packed in send order:
+// d_out[upos[u]] = { gemb[u, :], glin[u], 0, 0, 0 }
+int dctr_sharded_pack_row_grads(dctr_handle E, dctr_group_t g, int B, const int32_t* d_upos, float* d_out, void* stream) {
+    DCTR_REQUIRE(E && g && d_upos && d_out, "null argument");
     Group* G = reinterpret_cast<Group*>(g);
+    hipStream_t st = as_stream(stream);
     const int mode = gather_mode(E);
     const float* dE = mode == DCTR_GATHER_BI ? nullptr : E->dE;
     const float* coef = mode == DCTR_GATHER_FM ? E->dy : (mode == DCTR_GATHER_BI ? E->dx_in : nullptr);
-    return embed_scatter_bwd(G, dE, E->dE_ld, E->e, E->e_ld, E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F, E->K, mode,
-                             G->gemb, E->lin ? G->glin : nullptr, as_stream(stream));
+    DCTR_TRY(embed_scatter_bwd(G, dE, E->dE_ld, E->e, E->e_ld, E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F, E->K, mode,
+                               G->gemb, E->lin ? G->glin : nullptr, st));
+    return pack_unique_grads(G, E->lin ? G->glin : nullptr, d_upos, d_out, st);
 }
 
 int dctr_dense_grads(dctr_handle E, float** d_flat, int64_t* n, void* stream) {

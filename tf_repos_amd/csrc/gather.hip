@@ -12,7 +12,7 @@ namespace dctr {
 
 template <int KQ, int FS, int MODE>
 __global__ __launch_bounds__(256) void gather_fwd_kernel(
-    const float4* __restrict__ emb, const float* __restrict__ lin, int64_t rows,
+    const float4* __restrict__ emb, const float* __restrict__ lin, int64_t rows, int emb_ld4, int lin_ld,
     const int32_t* __restrict__ ids, const float* __restrict__ vals, int B, int F,
     float* __restrict__ e_out, int e_ld, float* __restrict__ yw_out, float* __restrict__ sum_out,
     float* __restrict__ red_out, int32_t* __restrict__ status) {
@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(
                     atomicExch(&status[1], id[u]);
                     atomicExch(&status[0], 1);
                 }
-                r[u] = ok ? emb[(size_t)id[u] * KQ + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
-                w[u] = (ok && lin != nullptr && kq == 0) ? lin[id[u]] : 0.f;
+                r[u] = ok ? emb[(size_t)id[u] * emb_ld4 + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
+                w[u] = (ok && lin != nullptr && kq == 0) ? lin[(size_t)id[u] * lin_ld] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(
 }
 
 template <int KQ, int FS>
-static int launch_gather(const float* emb, const float* lin, int64_t rows, const int32_t* ids,
+static int launch_gather(const float* emb, const float* lin, int64_t rows, int emb_ld, int lin_ld, const int32_t* ids,
                          const float* vals, int B, int F, int mode, float* e, int e_ld, float* yw,
                          float* sum, float* red, int32_t* status, hipStream_t st) {
     constexpr int EPB = 256 / (KQ * FS);
@@ -108,13 +108,13 @@ static int launch_gather(const float* emb, const float* lin, int64_t rows, const
     const float4* emb4 = reinterpret_cast<const float4*>(emb);
     switch (mode) {
         case DCTR_GATHER_RAW:
-            gather_fwd_kernel<KQ, FS, DCTR_GATHER_RAW><<<grid, block, 0, st>>>(emb4, lin, rows, ids, vals, B, F, e, e_ld, yw, sum, red, status);
+            gather_fwd_kernel<KQ, FS, DCTR_GATHER_RAW><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status);
             break;
         case DCTR_GATHER_FM:
-            gather_fwd_kernel<KQ, FS, DCTR_GATHER_FM><<<grid, block, 0, st>>>(emb4, lin, rows, ids, vals, B, F, e, e_ld, yw, sum, red, status);
+            gather_fwd_kernel<KQ, FS, DCTR_GATHER_FM><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status);
             break;
         case DCTR_GATHER_BI:
-            gather_fwd_kernel<KQ, FS, DCTR_GATHER_BI><<<grid, block, 0, st>>>(emb4, lin, rows, ids, vals, B, F, e, e_ld, yw, sum, red, status);
+            gather_fwd_kernel<KQ, FS, DCTR_GATHER_BI><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status);
             break;
         default:
             set_error("gather: bad mode %d", mode);
@@ -124,26 +124,34 @@ static int launch_gather(const float* emb, const float* lin, int64_t rows, const
     return DCTR_OK;
 }
 
-int embed_gather_fwd(const float* emb, const float* lin, int64_t rows, const int32_t* ids,
+// emb_ld / lin_ld: row strides (floats) of the table being read -- K and 1 for the engine's own tables, K+4 for the packed
+// [row | linear weight | pad] buffer of rows received from their owners in the row-sharded path
+int embed_gather_strided(const float* emb, int emb_ld, const float* lin, int lin_ld, int64_t rows, const int32_t* ids,
                      const float* vals, int B, int F, int K, int mode, float* e, int e_ld, float* yw,
                      float* sum, float* red, int32_t* status, hipStream_t st) {
     DCTR_REQUIRE(K % 4 == 0 && K >= 4 && K <= 256, "embedding_size must be a multiple of 4 in [4,256], got %d", K);
+    DCTR_REQUIRE(emb_ld % 4 == 0 && emb_ld >= K && lin_ld >= 1, "gather: bad table strides emb_ld=%d lin_ld=%d", emb_ld, lin_ld);
     DCTR_REQUIRE(e_ld % 4 == 0 && e_ld >= F * K, "gather: e_ld=%d must be a multiple of 4 and >= F*K=%d", e_ld, F * K);
     DCTR_REQUIRE(status != nullptr, "gather: status word required");
     DCTR_REQUIRE(mode == DCTR_GATHER_RAW || red != nullptr, "gather: reduction output required for mode %d", mode);
     if (B <= 0) return DCTR_OK;
     switch (K / 4) {
-        case 1:  return launch_gather<1, 16>(emb, lin, rows, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
-        case 2:  return launch_gather<2, 8>(emb, lin, rows, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
-        case 4:  return launch_gather<4, 4>(emb, lin, rows, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
-        case 8:  return launch_gather<8, 2>(emb, lin, rows, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
-        case 16: return launch_gather<16, 1>(emb, lin, rows, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
-        case 32: return launch_gather<32, 1>(emb, lin, rows, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
-        case 64: return launch_gather<64, 1>(emb, lin, rows, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
+        case 1:  return launch_gather<1, 16>(emb, lin, rows, emb_ld, lin_ld, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
+        case 2:  return launch_gather<2, 8>(emb, lin, rows, emb_ld, lin_ld, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
+        case 4:  return launch_gather<4, 4>(emb, lin, rows, emb_ld, lin_ld, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
+        case 8:  return launch_gather<8, 2>(emb, lin, rows, emb_ld, lin_ld, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
+        case 16: return launch_gather<16, 1>(emb, lin, rows, emb_ld, lin_ld, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
+        case 32: return launch_gather<32, 1>(emb, lin, rows, emb_ld, lin_ld, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
+        case 64: return launch_gather<64, 1>(emb, lin, rows, emb_ld, lin_ld, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
         default:
             set_error("embedding_size %d unsupported (K/4 must be a power of two <= 64)", K);
             return DCTR_ERR_UNSUPPORTED;
     }
+}
+
+int embed_gather_fwd(const float* emb, const float* lin, int64_t rows, const int32_t* ids, const float* vals, int B, int F, int K,
+                     int mode, float* e, int e_ld, float* yw, float* sum, float* red, int32_t* status, hipStream_t st) {
+    return embed_gather_strided(emb, K, lin, 1, rows, ids, vals, B, F, K, mode, e, e_ld, yw, sum, red, status, st);
 }
 
 }  // namespace dctr

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void scatter_bwd_kernel(
     const int32_t* __restrict__ seg_start, const int32_t* __restrict__ cnt,
     const float4* __restrict__ dE, int de_ld4, const float4* __restrict__ e, int e_ld4,
     const float4* __restrict__ S, const float* __restrict__ coef, const float* __restrict__ dy,
-    const float* __restrict__ vals, int B, int F, float* __restrict__ gemb, float* __restrict__ glin) {
+    const float* __restrict__ vals, int B, int F, float* __restrict__ gemb, float* __restrict__ glin, int dy_ld) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int w = t / KQ, kq = t % KQ;
     const int total = counters[1];
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void scatter_bwd_kernel(
             d.x += c.x * (s.x - ee.x); d.y += c.y * (s.y - ee.y); d.z += c.z * (s.z - ee.z); d.w += c.w * (s.w - ee.w);
         }
         acc.x += d.x * v; acc.y += d.y * v; acc.z += d.z * v; acc.w += d.w * v;
-        if (kq == 0 && dy != nullptr) accl += dy[b] * v;
+        if (kq == 0 && dy != nullptr) accl += dy[(size_t)b * dy_ld] * v;
     }
     if (cur >= 0) flush(inside && (seg_start[cur] + cnt[cur] <= jend));
 }
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void scatter_bwd_kernel(
 template <int KQ>
 static int launch_scatter(Group* g, const float* dE, int de_ld, const float* e, int e_ld, const float* S,
                           const float* coef, const float* dy, const float* vals, int B, int F, int mode,
-                          float* gemb, float* glin, hipStream_t st) {
+                          float* gemb, float* glin, int dy_ld, hipStream_t st) {
     const int64_t n = (int64_t)B * F;
     const int walkers = ceil_div(n, SCATTER_RUN);
     dim3 grid(ceil_div((int64_t)walkers * KQ, 256)), block(256);
@@ -244,7 +244,7 @@ static int launch_scatter(Group* g, const float* dE, int de_ld, const float* e, 
     scatter_bwd_kernel<KQ, MODE_><<<grid, block, 0, st>>>(                                                     \
         g->perm, g->seg_of, g->counters, g->seg_start, g->cnt, reinterpret_cast<const float4*>(dE), de_ld / 4,                       \
         reinterpret_cast<const float4*>(e), e_ld / 4, reinterpret_cast<const float4*>(S), coef, dy, vals, B, F, \
-        gemb, glin)
+        gemb, glin, dy_ld)
     switch (mode) {
         case DCTR_GATHER_RAW: DCTR_SC(DCTR_GATHER_RAW); break;
         case DCTR_GATHER_FM:  DCTR_SC(DCTR_GATHER_FM); break;
@@ -274,6 +274,8 @@ int group_create(int64_t rows, int64_t max_entries, int K, Group** out) {
     DCTR_HIP_CHECK(hipMemset(g->counters, 0, 16));
     DCTR_HIP_CHECK(hipMalloc(&g->gemb, n * K * 4));
     DCTR_HIP_CHECK(hipMalloc(&g->glin, n * 4));
+    // the memsets above run on the null stream and may still be pending: a first use on a non-blocking stream must not overtake them
+    DCTR_HIP_CHECK(hipDeviceSynchronize());
     *out = g;
     return DCTR_OK;
 }
@@ -311,7 +313,7 @@ int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st) {
 
 int embed_scatter_bwd(Group* g, const float* dE, int de_ld, const float* e, int e_ld, const float* S,
                       const float* coef, const float* dy, const float* vals, int B, int F, int K, int mode,
-                      float* gemb, float* glin, hipStream_t st) {
+                      float* gemb, float* glin, hipStream_t st, int dy_ld) {
     DCTR_REQUIRE(K == g->K, "scatter: K=%d but group was created with K=%d", K, g->K);
     DCTR_REQUIRE(dE == nullptr || de_ld % 4 == 0, "scatter: de_ld must be a multiple of 4");
     DCTR_REQUIRE(mode == DCTR_GATHER_RAW || (e != nullptr && S != nullptr && coef != nullptr && e_ld % 4 == 0),
@@ -319,7 +321,7 @@ int embed_scatter_bwd(Group* g, const float* dE, int de_ld, const float* e, int 
     if (gemb == nullptr) gemb = g->gemb;
     if (glin == nullptr && dy != nullptr) glin = g->glin;
     switch (K / 4) {
-#define DCTR_L(Q) case Q: return launch_scatter<Q>(g, dE, de_ld, e, e_ld, S, coef, dy, vals, B, F, mode, gemb, glin, st)
+#define DCTR_L(Q) case Q: return launch_scatter<Q>(g, dE, de_ld, e, e_ld, S, coef, dy, vals, B, F, mode, gemb, glin, dy_ld, st)
         DCTR_L(1); DCTR_L(2); DCTR_L(4); DCTR_L(8); DCTR_L(16); DCTR_L(32); DCTR_L(64);
 #undef DCTR_L
         default: set_error("scatter: K=%d unsupported", K); return DCTR_ERR_UNSUPPORTED;

@@ -51,12 +51,21 @@ int group_destroy(Group* g);
 int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st);
 int embed_scatter_bwd(Group* g, const float* dE, int de_ld, const float* e, int e_ld, const float* S,
                       const float* coef, const float* dy, const float* vals, int B, int F, int K, int mode,
-                      float* gemb, float* glin, hipStream_t st);
+                      float* gemb, float* glin, hipStream_t st, int dy_ld = 1);   // dy_ld: stride (floats) between examples in dy
 
 // ---- K2 (gather.hip)
 int embed_gather_fwd(const float* emb, const float* lin, int64_t rows, const int32_t* ids, const float* vals,
                      int B, int F, int K, int mode, float* e, int e_ld, float* yw, float* sum, float* red,
                      int32_t* status, hipStream_t st);
+
+int embed_gather_strided(const float* emb, int emb_ld, const float* lin, int lin_ld, int64_t rows, const int32_t* ids,
+                         const float* vals, int B, int F, int K, int mode, float* e, int e_ld, float* yw, float* sum, float* red,
+                         int32_t* status, hipStream_t st);
+
+// ---- shard.hip: packed [K+4]-float row records for the row-sharded exchange
+int pack_table_rows(const float* emb, const float* lin, int64_t rows, int K, const int32_t* rows_idx, int n, float* out,
+                    int32_t* status, hipStream_t st);
+int pack_unique_grads(const Group* g, const float* glin, const int32_t* upos, float* out, hipStream_t st);
 
 // ---- K6 (gemm.hip)
 int fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N,

@@ -8,16 +8,29 @@
 
 namespace dctr {
 
-// counts[d] = number of distinct ids owned by rank d; one atomic per (wave, destination)
+// counts[d] = number of distinct ids owned by rank d.  Per-wave ballots, summed per block in LDS: one atomic per (block,
+// destination) -- thousands of waves adding to `world` words would serialise at ~90 atomics/us per word
+constexpr int ROUTE_WAVES = 4;      // 256-thread blocks
+constexpr int ROUTE_MAX_WORLD = 64;
+
 __global__ __launch_bounds__(256) void route_count_kernel(const int32_t* __restrict__ uniq, const int32_t* __restrict__ counters,
                                                          int world, int32_t* __restrict__ counts) {
+    __shared__ int32_t wc[ROUTE_WAVES][ROUTE_MAX_WORLD];
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     const int U = counters[0];
-    const int lane = threadIdx.x & 63;
+    if ((int)(blockIdx.x * blockDim.x) >= U) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int dest = (u < U) ? uniq[u] % world : -1;
     for (int d = 0; d < world; ++d) {
         const unsigned long long m = __ballot(dest == d);
-        if (m != 0ull && lane == __ffsll((long long)m) - 1) atomicAdd(&counts[d], __popcll(m));
+        if (lane == 0) wc[wave][d] = __popcll(m);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < world) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < ROUTE_WAVES; ++w) tot += wc[w][threadIdx.x];
+        if (tot) atomicAdd(&counts[threadIdx.x], tot);
     }
 }
 
@@ -25,25 +38,35 @@ __global__ __launch_bounds__(256) void route_count_kernel(const int32_t* __restr
 __global__ __launch_bounds__(256) void route_fill_kernel(const int32_t* __restrict__ uniq, const int32_t* __restrict__ counters,
                                                         int world, const int32_t* __restrict__ counts, int32_t* __restrict__ cursor,
                                                         int32_t* __restrict__ send_rows, int32_t* __restrict__ upos) {
+    __shared__ int32_t wc[ROUTE_WAVES][ROUTE_MAX_WORLD];    // per-wave counts, then per-wave bases in the send buffer
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     const int U = counters[0];
-    const int lane = threadIdx.x & 63;
+    if ((int)(blockIdx.x * blockDim.x) >= U) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int id = (u < U) ? uniq[u] : -1;
     const int dest = (u < U) ? id % world : -1;
+    unsigned long long mine = 0ull;
     for (int d = 0; d < world; ++d) {
         const unsigned long long m = __ballot(dest == d);
-        if (m == 0ull) continue;
-        const int head = __ffsll((long long)m) - 1;
-        int base = 0;
-        if (lane == head) base = atomicAdd(&cursor[d], __popcll(m));
-        base = __shfl(base, head);
-        if (dest == d) {
-            int off = 0;
-            for (int j = 0; j < d; ++j) off += counts[j];
-            const int pos = off + base + __popcll(m & ((1ull << lane) - 1ull));
-            send_rows[pos] = id / world;
-            upos[u] = pos;
-        }
+        if (dest == d) mine = m;
+        if (lane == 0) wc[wave][d] = __popcll(m);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < world) {
+        const int d = threadIdx.x;
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < ROUTE_WAVES; ++w) tot += wc[w][d];
+        int base = tot ? atomicAdd(&cursor[d], tot) : 0;
+        for (int j = 0; j < d; ++j) base += counts[j];      // start of destination d's range
+#pragma unroll
+        for (int w = 0; w < ROUTE_WAVES; ++w) { const int c = wc[w][d]; wc[w][d] = base; base += c; }
+    }
+    __syncthreads();
+    if (dest >= 0) {
+        const int pos = wc[wave][dest] + __popcll(mine & ((1ull << lane) - 1ull));
+        send_rows[pos] = id / world;
+        upos[u] = pos;
     }
 }
 
@@ -56,19 +79,58 @@ __global__ __launch_bounds__(256) void entry_index_kernel(const int32_t* __restr
     idx[i] = (id >= 0 && (int64_t)id < rows) ? upos[slot[id] - 1] : -1;     // -1 trips the gather's range check
 }
 
-// dst[pos[u], :] = src[u, :] for u < U (U read from device memory)
-__global__ __launch_bounds__(256) void permute_rows_kernel(const float4* __restrict__ src, const int32_t* __restrict__ pos,
-                                                          const int32_t* __restrict__ counters, int kq_per_row, float4* __restrict__ dst) {
+// Rows cross the fabric PACKED: one [K+4]-float record per row = K embedding floats | linear weight | 3 pad floats, so each
+// direction of the exchange is ONE all-to-all of 16-byte-aligned records (K=16: 80 B) instead of one per table.
+
+// owner side: out[i] = { emb[rows_idx[i], :], lin[rows_idx[i]], 0, 0, 0 }
+__global__ __launch_bounds__(256) void pack_table_rows_kernel(const float4* __restrict__ emb, const float* __restrict__ lin,
+                                                             int64_t rows, const int32_t* __restrict__ rows_idx, int n, int KQ,
+                                                             float4* __restrict__ out, int32_t* __restrict__ status) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int u = (int)(t / kq_per_row), kq = (int)(t % kq_per_row);
-    if (u >= counters[0]) return;
-    dst[(size_t)pos[u] * kq_per_row + kq] = src[(size_t)u * kq_per_row + kq];
+    const int Q = KQ + 1;
+    const int i = (int)(t / Q), q = (int)(t % Q);
+    if (i >= n) return;
+    const int r = rows_idx[i];
+    const bool ok = r >= 0 && (int64_t)r < rows;
+    if (!ok && q == 0) { atomicExch(&status[1], r); atomicExch(&status[0], 1); }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+        if (q < KQ) v = emb[(size_t)r * KQ + q];
+        else if (lin != nullptr) v.x = lin[r];
+    }
+    out[(size_t)i * Q + q] = v;
 }
-__global__ __launch_bounds__(256) void permute_scalars_kernel(const float* __restrict__ src, const int32_t* __restrict__ pos,
-                                                             const int32_t* __restrict__ counters, float* __restrict__ dst) {
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+
+// requester side: out[upos[u]] = { gemb[u, :], glin[u], 0, 0, 0 } for u < U (U read from device memory)
+__global__ __launch_bounds__(256) void pack_unique_grads_kernel(const float4* __restrict__ gemb, const float* __restrict__ glin,
+                                                               const int32_t* __restrict__ upos, const int32_t* __restrict__ counters,
+                                                               int KQ, float4* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Q = KQ + 1;
+    const int u = (int)(t / Q), q = (int)(t % Q);
     if (u >= counters[0]) return;
-    dst[pos[u]] = src[u];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < KQ) v = gemb[(size_t)u * KQ + q];
+    else if (glin != nullptr) v.x = glin[u];
+    out[(size_t)upos[u] * Q + q] = v;
+}
+
+int pack_table_rows(const float* emb, const float* lin, int64_t rows, int K, const int32_t* rows_idx, int n, float* out,
+                    int32_t* status, hipStream_t st) {
+    if (n <= 0) return DCTR_OK;
+    const int KQ = K / 4;
+    pack_table_rows_kernel<<<ceil_div((int64_t)n * (KQ + 1), 256), 256, 0, st>>>(reinterpret_cast<const float4*>(emb), lin, rows, rows_idx,
+                                                                               n, KQ, reinterpret_cast<float4*>(out), status);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+int pack_unique_grads(const Group* g, const float* glin, const int32_t* upos, float* out, hipStream_t st) {
+    const int KQ = g->K / 4;
+    pack_unique_grads_kernel<<<ceil_div(g->max_entries * (KQ + 1), 256), 256, 0, st>>>(reinterpret_cast<const float4*>(g->gemb), glin, upos,
+                                                                                      g->counters, KQ, reinterpret_cast<float4*>(out));
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
 }
 
 }  // namespace dctr
@@ -95,21 +157,6 @@ int dctr_entry_index(dctr_group_t g, const int32_t* d_ids, int n, const int32_t*
     Group* p = reinterpret_cast<Group*>(g);
     if (n <= 0) return DCTR_OK;
     entry_index_kernel<<<ceil_div(n, 256), 256, 0, as_stream(stream)>>>(d_ids, n, p->rows, p->slot, d_upos, d_idx);
-    DCTR_LAUNCH_CHECK();
-    return DCTR_OK;
-}
-
-int dctr_permute_unique_rows(dctr_group_t g, const float* d_src, const int32_t* d_pos, int K, float* d_dst, void* stream) {
-    DCTR_REQUIRE(g != nullptr && d_src && d_pos && d_dst && (K == 1 || K % 4 == 0), "bad argument");
-    Group* p = reinterpret_cast<Group*>(g);
-    hipStream_t st = as_stream(stream);
-    if (K == 1) {
-        permute_scalars_kernel<<<ceil_div(p->max_entries, 256), 256, 0, st>>>(d_src, d_pos, p->counters, d_dst);
-    } else {
-        const int kq = K / 4;
-        permute_rows_kernel<<<ceil_div(p->max_entries * kq, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(d_src), d_pos, p->counters,
-                                                                                kq, reinterpret_cast<float4*>(d_dst));
-    }
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }
