@@ -174,22 +174,22 @@ def main():
                        "parallelism": "single GPU" if world == 1 else "row-sharded tables (id %% %d) + data-parallel dense" % world,
                        "ids": "uniform" if args.uniform_ids else "zipf"},
         }
-    if not sharded:
+    if rank == 0:
         # ---- per-stage timing (hipEvents around a graph of back-to-back launches, on torch's current stream)
         F, K, V = w["field_size"], w["embedding_size"], w["feature_size"]
-        stages = {}
-        for name in ["embed_gather", "forward", "head", "backward_dense", "group_ids", "scatter", "opt_table", "opt_dense",
-                     "mlp0_fwd", "mlp0_dgrad", "mlp0_wgrad", "train_step"]:
-            stages[name] = eng.time_stage(name, iters=30)
+        e = trainer.eng if sharded else eng
+        rows = (V + world - 1) // world                            # rows of this rank's table shard
+        names = ["opt_table", "mlp0_fwd", "mlp0_dgrad", "mlp0_wgrad"]
+        if not sharded:
+            names = ["embed_gather", "forward", "head", "backward_dense", "group_ids", "scatter", "opt_dense", "train_step"] + names
+        stages = {name: e.time_stage(name, iters=30) for name in names}
         gather_bytes = B * (F * (12 + 8 * K) + 8)                 # algorithmic bytes of the gather
         # dense-exact table step as implemented: theta,m,v read + write (6 streams) + the 4-byte slot word per row; the per-row
         # gradient is NOT a dense stream here (only the ~U touched rows read a compact gradient row), so SURVEY 8d's 7-stream
         # figure (7*V*(K+1)*4 = 476 MB) would flatter the kernel -- 6 streams (412 MB) is what the algorithm must move
-        table_bytes = 6 * V * (K + 1) * 4 + 4 * V
+        table_bytes = 6 * rows * (K + 1) * 4 + 4 * rows
         mlp0_flops = 2.0 * B * (F * K) * w["deep_layers"][0]
         kernels = {
-            "embed_gather_fwd": {"bound": "hbm", "ms": stages["embed_gather"], "achieved": gather_bytes / stages["embed_gather"] / 1e6,
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s"},
             "opt_table_dense_adam": {"bound": "hbm", "ms": stages["opt_table"], "achieved": table_bytes / stages["opt_table"] / 1e6,
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s"},
             "mlp0_fwd_gemm": {"bound": "mfma", "ms": stages["mlp0_fwd"], "achieved": mlp0_flops / stages["mlp0_fwd"] / 1e9,
@@ -199,19 +199,23 @@ def main():
             "mlp0_wgrad_gemm": {"bound": "mfma", "ms": stages["mlp0_wgrad"], "achieved": mlp0_flops / stages["mlp0_wgrad"] / 1e9,
                                 "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s"},
         }
+        if not sharded:
+            kernels["embed_gather_fwd"] = {"bound": "hbm", "ms": stages["embed_gather"], "achieved": gather_bytes / stages["embed_gather"] / 1e6,
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s"}
         for k in kernels.values():
             k["frac"] = round(k["achieved"] / k["peak"], 4)
             k["achieved"] = round(k["achieved"], 2)
             k["ms"] = round(k["ms"], 5)
-        dom = "opt_table_dense_adam" if args.table_mode == "dense_exact" else "mlp0_fwd_gemm"
+        # the dominant kernel: the dense-exact table optimizer on one GPU; once the table is sharded 8 ways, the first MLP GEMM
+        dom = "opt_table_dense_adam" if (args.table_mode == "dense_exact" and stages["opt_table"] >= stages["mlp0_fwd"]) else "mlp0_fwd_gemm"
         r = dict(kernels[dom])
         r["kernel"] = dom
-        r["traffic"] = pmc_traffic_bytes("opt_table_kernel") if dom == "opt_table_dense_adam" else None
+        r["traffic"] = pmc_traffic_bytes("opt_table_kernel") if (dom == "opt_table_dense_adam" and not sharded) else None
         r["traffic_source"] = "profiles/r01_pmc_traffic.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts 1/2 of 16-B/lane streams; MI355X_MICROARCH.md HBM section)"
         out["roofline"] = r
         out["kernels"] = kernels
         out["stage_ms"] = {k: round(v, 5) for k, v in stages.items()}
-        if not args.no_cpu_baseline:
+        if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     if rank == 0:

@@ -218,8 +218,8 @@ int fetch_and_forward(dctr_dist* D, RouteState& r, const float* vals, const floa
     const int64_t rec = (int64_t)(E->K + 4) * sizeof(float);
     DCTR_TRY(dctr_table_gather_packed(E, r.recv_rows, (int)r.n_recv, D->rows_out, M));
     DCTR_TRY(D->t.all_to_all(D->t.ctx, 0, D->rows_out, r.rcnt.data(), D->rows_back, r.scnt.data(), rec, M));
-    // n_rows = capacity: every index entry_index produced is either < n_send or -1
-    return dctr_sharded_forward_backward(E, D->rows_back, (int)r.n_send, r.idx, vals, labels, B, B * D->world, train ? 1 : 0, M);
+    // weight gradients stay un-joined on the engine's side stream: the dense update continues there (train_step)
+    return sharded_forward_backward(E, D->rows_back, (int)r.n_send, r.idx, vals, labels, B, B * D->world, train, false, M);
 }
 
 int dense_update(dctr_dist* D, hipStream_t s) {
@@ -255,8 +255,11 @@ int dist_alloc(dctr_dist* D) {
     DCTR_HIP_CHECK(hipMalloc(&D->send_grads, D->cap * P * 4));
     DCTR_HIP_CHECK(hipMalloc(&D->recv_grads, D->cap_owner * P * 4));
     DCTR_HIP_CHECK(hipMalloc(&D->d_loss, 4 * sizeof(float)));
-    DCTR_HIP_CHECK(hipStreamCreateWithFlags(&D->s_route, hipStreamNonBlocking));
-    DCTR_HIP_CHECK(hipStreamCreateWithFlags(&D->s_dense, hipStreamNonBlocking));
+    // no streams of its own: the GPU has 4 hardware queues by default and more streams than queues serialise against each
+    // other (measured: a 4th/5th stream landed on the main stream's queue; GPU_MAX_HW_QUEUES=8 was 2.3x SLOWER).  The routing
+    // runs on the engine's grouping stream (idle in the sharded step), the dense update continues on its wgrad stream.
+    D->s_route = E->s_group;
+    D->s_dense = E->s_wgrad;
     DCTR_HIP_CHECK(hipEventCreateWithFlags(&D->ev_start, hipEventDisableTiming));
     DCTR_HIP_CHECK(hipEventCreateWithFlags(&D->ev_fb, hipEventDisableTiming));
     DCTR_HIP_CHECK(hipEventCreateWithFlags(&D->ev_dense, hipEventDisableTiming));
@@ -335,8 +338,6 @@ int dctr_dist_destroy(dctr_dist_t D) {
         if (r.done) hipEventDestroy(r.done);
     }
     hipFree(D->rows_out); hipFree(D->rows_back); hipFree(D->send_grads); hipFree(D->recv_grads); hipFree(D->d_loss);
-    if (D->s_route) hipStreamDestroy(D->s_route);
-    if (D->s_dense) hipStreamDestroy(D->s_dense);
     if (D->ev_start) hipEventDestroy(D->ev_start);
     if (D->ev_fb) hipEventDestroy(D->ev_fb);
     if (D->ev_dense) hipEventDestroy(D->ev_dense);
@@ -363,10 +364,14 @@ int dctr_dist_train_step(dctr_dist_t D, const int32_t* d_ids, const float* d_val
     if (prefetch) DCTR_TRY(prefetch_begin(D, d_next_ids, next_B));
     DCTR_TRY(fetch_and_forward(D, r, d_vals, d_labels, B, true, M));
     // dense side, beside the gradient exchange (the logit gradient already carries 1/global_batch: sum over ranks = mean)
-    hipStream_t sd = D->overlap ? D->s_dense : M;
-    if (sd != M) {
-        DCTR_HIP_CHECK(hipEventRecord(D->ev_fb, M));
-        DCTR_HIP_CHECK(hipStreamWaitEvent(sd, D->ev_fb, 0));
+    // (the side stream already holds the weight gradients; it still needs the output-layer / cross-network partials from M)
+    hipStream_t sd = D->s_dense;
+    DCTR_HIP_CHECK(hipEventRecord(D->ev_fb, M));
+    DCTR_HIP_CHECK(hipStreamWaitEvent(sd, D->ev_fb, 0));
+    if (!D->overlap) {          // serial variant: everything back on M before going on
+        DCTR_HIP_CHECK(hipEventRecord(D->ev_dense, sd));
+        DCTR_HIP_CHECK(hipStreamWaitEvent(M, D->ev_dense, 0));
+        sd = M;
     }
     DCTR_TRY(dense_update(D, sd));
     if (sd != M) DCTR_HIP_CHECK(hipEventRecord(D->ev_dense, sd));

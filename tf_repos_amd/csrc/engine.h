@@ -112,6 +112,9 @@ struct dctr_engine {
 // shared between engine.hip and afm.hip
 int engine_add_param(dctr_engine* E, const std::string& name, std::initializer_list<int64_t> dims, bool table, int n_part, float l2);
 int fork(dctr_engine* E, hipStream_t from, hipStream_t to);
+// row-sharded path (engine.hip), used by the native step driver (dist.hip)
+int sharded_forward_backward(dctr_engine* E, const float* d_rows, int n_rows, const int32_t* d_idx, const float* d_vals,
+                             const float* d_labels, int B, int global_batch, bool train, bool join_wgrad, hipStream_t st);
 int afm_declare_params(dctr_engine* E);
 int afm_alloc(dctr_engine* E);
 void afm_free(dctr_engine* E);

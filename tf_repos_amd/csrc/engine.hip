@@ -218,8 +218,21 @@ int build(dctr_engine* E) {
         DCTR_TRY(fill(E->as0, (size_t)E->arena_n));
     }
 
-    DCTR_HIP_CHECK(hipStreamCreateWithFlags(&E->s_group, hipStreamNonBlocking));
-    DCTR_HIP_CHECK(hipStreamCreateWithFlags(&E->s_wgrad, hipStreamNonBlocking));
+    {
+        // The runtime multiplexes streams onto 4 hardware queues PER PRIORITY LEVEL, and which queue a stream lands on depends on
+        // how many other streams the process (torch, RCCL) has touched before: side streams that share the main stream's queue
+        // silently serialise behind it.  Giving each side stream its own priority level gives it a queue of its own:
+        // grouping / routing = low (background work hidden under the GEMMs), weight gradients + dense update = high.
+        int least = 0, greatest = 0;
+        DCTR_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        auto prio = [&](const char* env, int dflt) {
+            const char* v = getenv(env);
+            if (v == nullptr) return dflt;
+            return v[0] == 'h' ? greatest : (v[0] == 'l' ? least : 0);
+        };
+        DCTR_HIP_CHECK(hipStreamCreateWithPriority(&E->s_group, hipStreamNonBlocking, prio("DCTR_PRIO_GROUP", least)));
+        DCTR_HIP_CHECK(hipStreamCreateWithPriority(&E->s_wgrad, hipStreamNonBlocking, prio("DCTR_PRIO_WGRAD", greatest)));
+    }
     E->events.resize(64);
     for (auto& ev : E->events) DCTR_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 
@@ -816,15 +829,18 @@ int dctr_table_apply_packed(dctr_handle E, int which, int n, const float* d_grad
                      E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, st);
 }
 
+}  // extern "C"
+
 // forward (+ backward when train) of one rank's examples against the packed rows received from their owners.  Training also
 // advances the step state (global_step, lr_t, dropout seed; zeroes the loss scalars).  Weight gradients run on the engine's
-// side stream beside the dgrad chain; everything is joined back into `stream` before returning.
-int dctr_sharded_forward_backward(dctr_handle E, const float* d_rows, int n_rows, const int32_t* d_idx, const float* d_vals,
-                                  const float* d_labels, int B, int global_batch, int train, void* stream) {
+// side stream beside the dgrad chain; join_wgrad: wait for them on `stream` before returning (the native driver instead
+// keeps using the side stream for the dense all-reduce + optimizer and joins at the end of the step).
+int sharded_forward_backward(dctr_engine* E, const float* d_rows, int n_rows, const int32_t* d_idx, const float* d_vals,
+                             const float* d_labels, int B, int global_batch, bool train, bool join_wgrad, hipStream_t st) {
     DCTR_REQUIRE(E && d_rows && d_idx && d_vals, "null argument");
     DCTR_REQUIRE(B > 0 && B <= E->MB && global_batch >= B, "bad batch sizes B=%d global=%d", B, global_batch);
     DCTR_REQUIRE(!train || d_labels, "labels required for training");
-    hipStream_t st = as_stream(stream), sw = E->s_wgrad;
+    hipStream_t sw = E->s_wgrad;
     const size_t n = (size_t)B * E->F;
     const int P = E->K + 4;
     if (train) {
@@ -838,14 +854,21 @@ int dctr_sharded_forward_backward(dctr_handle E, const float* d_rows, int n_rows
     DCTR_TRY(embed_gather_strided(d_rows, P, E->lin ? d_rows + E->K : nullptr, P, n_rows, d_idx, E->vals, B, E->F, E->K, mode, E->e,
                                   E->e_ld, E->lin ? E->yw : nullptr, E->S, red, E->status, st));
     if (train) DCTR_TRY(fork(E, sw, st));
-    DCTR_TRY(forward_rest(E, B, train != 0, st));
-    DCTR_TRY(head(E, B, global_batch, d_labels != nullptr, st, nullptr, train != 0));
+    DCTR_TRY(forward_rest(E, B, train, st));
+    DCTR_TRY(head(E, B, global_batch, d_labels != nullptr, st, nullptr, train));
     if (train) {
         DCTR_TRY(backward_dense(E, B, st, sw, false));
-        DCTR_TRY(fork(E, sw, st));
+        if (join_wgrad) DCTR_TRY(fork(E, sw, st));
     }
     E->last_B = B;
     return DCTR_OK;
+}
+
+extern "C" {
+
+int dctr_sharded_forward_backward(dctr_handle E, const float* d_rows, int n_rows, const int32_t* d_idx, const float* d_vals,
+                                  const float* d_labels, int B, int global_batch, int train, void* stream) {
+    return sharded_forward_backward(E, d_rows, n_rows, d_idx, d_vals, d_labels, B, global_batch, train != 0, true, as_stream(stream));
 }
 
 // per-distinct-id gradients of this rank's examples (segment sum into g's compact rows), packed in send order:
