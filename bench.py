@@ -202,7 +202,11 @@ def main():
         if not sharded:
             kernels["embed_gather_fwd"] = {"bound": "hbm", "ms": stages["embed_gather"], "achieved": gather_bytes / stages["embed_gather"] / 1e6,
                                            "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        copy_gbps = e.measure_copy_bandwidth(1 << 30, 20)          # this box's measured HBM roofline (1 GiB float4 copy, read + write)
+        out["hbm_measured_copy_GBps"] = round(copy_gbps, 1)
         for k in kernels.values():
+            if k["bound"] == "hbm":
+                k["frac_of_measured_copy"] = round(k["achieved"] / copy_gbps, 4)
             k["frac"] = round(k["achieved"] / k["peak"], 4)
             k["achieved"] = round(k["achieved"], 2)
             k["ms"] = round(k["ms"], 5)

@@ -114,6 +114,7 @@ _SIGS = {
     "dctr_last_outputs": ([_P, C.POINTER(_P), C.POINTER(_P)], C.c_int),
     "dctr_time_kernel": ([_P, C.c_char_p, C.c_int, C.POINTER(C.c_float), _P], C.c_int),
     "dctr_debug_tensor": ([_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int)], C.c_int),
+    "dctr_measure_copy_bw": ([C.c_size_t, C.c_int, C.POINTER(C.c_float), _P], C.c_int),
     "dctr_rccl_unique_id": ([C.c_char_p, C.c_char_p], C.c_int),
     "dctr_dist_create_rccl": ([_P, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(_P)], C.c_int),
     "dctr_dist_create": ([_P, C.c_int, C.c_int, _P, C.POINTER(_P)], C.c_int),

@@ -14,7 +14,38 @@ const char* get_error() { return g_err; }
 
 using namespace dctr;
 
+// streaming float4 copy: the "measured HBM roofline" the gather / optimizer fractions are quoted against
+__global__ __launch_bounds__(256) void copy_f4_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+
 extern "C" {
+
+int dctr_measure_copy_bw(size_t nbytes, int iters, float* h_gbps, void* stream) {
+    DCTR_REQUIRE(h_gbps != nullptr && nbytes >= (1u << 20) && iters > 0, "bad argument");
+    hipStream_t st = as_stream(stream);
+    const size_t n4 = nbytes / 16;
+    float4 *a = nullptr, *b = nullptr;
+    DCTR_HIP_CHECK(hipMalloc(&a, n4 * 16));
+    if (hipMalloc(&b, n4 * 16) != hipSuccess) { hipFree(a); set_error("copy probe: out of memory"); return DCTR_ERR_HIP; }
+    hipMemsetAsync(a, 0, n4 * 16, st);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int grid = 256 * 8;                   // 8 resident blocks per CU, grid-stride
+    copy_f4_kernel<<<grid, 256, 0, st>>>(a, b, n4);       // warm-up
+    hipEventRecord(e0, st);
+    for (int i = 0; i < iters; ++i) copy_f4_kernel<<<grid, 256, 0, st>>>(a, b, n4);
+    hipEventRecord(e1, st);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(a); hipFree(b);
+    if (e != hipSuccess) { set_error("copy probe failed: %s", hipGetErrorString(e)); return DCTR_ERR_HIP; }
+    *h_gbps = (float)(2.0 * (double)(n4 * 16) * iters / ((double)ms * 1e6));     // read + write bytes per second / 1e9
+    return DCTR_OK;
+}
 
 int dctr_version(void) { return 100; }
 const char* dctr_last_error(void) { return get_error(); }

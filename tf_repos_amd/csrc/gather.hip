@@ -10,7 +10,7 @@
 
 namespace dctr {
 
-template <int KQ, int FS, int MODE>
+template <int KQ, int FS, int MODE, int U>
 __global__ __launch_bounds__(256) void gather_fwd_kernel(
     const float4* __restrict__ emb, const float* __restrict__ lin, int64_t rows, int emb_ld4, int lin_ld,
     const int32_t* __restrict__ ids, const float* __restrict__ vals, int B, int F,
@@ -33,7 +33,6 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(
         const int32_t* idr = ids + (size_t)b * F;
         const float* vr = vals + (size_t)b * F;
         float4* er = reinterpret_cast<float4*>(e_out + (size_t)b * e_ld);
-        constexpr int U = 4;               // fields in flight per lane
         for (int f0 = fs; f0 < F; f0 += FS * U) {
             int32_t id[U];
             float v[U];
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(
     }
 }
 
-template <int KQ, int FS>
+template <int KQ, int FS, int U = 4>
 static int launch_gather(const float* emb, const float* lin, int64_t rows, int emb_ld, int lin_ld, const int32_t* ids,
                          const float* vals, int B, int F, int mode, float* e, int e_ld, float* yw,
                          float* sum, float* red, int32_t* status, hipStream_t st) {
@@ -108,13 +107,13 @@ static int launch_gather(const float* emb, const float* lin, int64_t rows, int e
     const float4* emb4 = reinterpret_cast<const float4*>(emb);
     switch (mode) {
         case DCTR_GATHER_RAW:
-            gather_fwd_kernel<KQ, FS, DCTR_GATHER_RAW><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status);
+            gather_fwd_kernel<KQ, FS, DCTR_GATHER_RAW, U><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status);
             break;
         case DCTR_GATHER_FM:
-            gather_fwd_kernel<KQ, FS, DCTR_GATHER_FM><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status);
+            gather_fwd_kernel<KQ, FS, DCTR_GATHER_FM, U><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status);
             break;
         case DCTR_GATHER_BI:
-            gather_fwd_kernel<KQ, FS, DCTR_GATHER_BI><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status);
+            gather_fwd_kernel<KQ, FS, DCTR_GATHER_BI, U><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status);
             break;
         default:
             set_error("gather: bad mode %d", mode);
@@ -135,18 +134,23 @@ int embed_gather_strided(const float* emb, int emb_ld, const float* lin, int lin
     DCTR_REQUIRE(status != nullptr, "gather: status word required");
     DCTR_REQUIRE(mode == DCTR_GATHER_RAW || red != nullptr, "gather: reduction output required for mode %d", mode);
     if (B <= 0) return DCTR_OK;
+    // lanes per example = KQ*FS; U = row loads in flight per lane.  FS*U is chosen >= 39 (Criteo's F) with one trip through the
+    // field loop where it fits: the gather is a latency-bound random read, so what matters is how many 16-byte row pieces are in
+    // flight (measured on c2, cache-resident table: <4,4,4> 6.2 us, <4,8,5> 5.2 us, <4,16,3> 5.7 us)
+#define DCTR_G(Q, FS_, U_) return launch_gather<Q, FS_, U_>(emb, lin, rows, emb_ld, lin_ld, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st)
     switch (K / 4) {
-        case 1:  return launch_gather<1, 16>(emb, lin, rows, emb_ld, lin_ld, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
-        case 2:  return launch_gather<2, 8>(emb, lin, rows, emb_ld, lin_ld, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
-        case 4:  return launch_gather<4, 4>(emb, lin, rows, emb_ld, lin_ld, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
-        case 8:  return launch_gather<8, 2>(emb, lin, rows, emb_ld, lin_ld, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
-        case 16: return launch_gather<16, 1>(emb, lin, rows, emb_ld, lin_ld, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
-        case 32: return launch_gather<32, 1>(emb, lin, rows, emb_ld, lin_ld, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
-        case 64: return launch_gather<64, 1>(emb, lin, rows, emb_ld, lin_ld, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st);
+        case 1:  DCTR_G(1, 16, 3);
+        case 2:  DCTR_G(2, 8, 5);
+        case 4:  DCTR_G(4, 8, 5);
+        case 8:  DCTR_G(8, 4, 5);
+        case 16: DCTR_G(16, 4, 5);
+        case 32: DCTR_G(32, 2, 4);
+        case 64: DCTR_G(64, 1, 4);
         default:
             set_error("embedding_size %d unsupported (K/4 must be a power of two <= 64)", K);
             return DCTR_ERR_UNSUPPORTED;
     }
+#undef DCTR_G
 }
 
 int embed_gather_fwd(const float* emb, const float* lin, int64_t rows, const int32_t* ids, const float* vals, int B, int F, int K,

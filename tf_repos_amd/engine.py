@@ -212,6 +212,14 @@ class Engine:
         capi.check(self._lib.dctr_time_kernel(self._h, stage.encode(), iters, C.byref(ms), st))
         return ms.value
 
+    @staticmethod
+    def measure_copy_bandwidth(nbytes: int = 1 << 30, iters: int = 20, stream=None) -> float:
+        """GB/s (read + write) of a streaming float4 copy: the measured HBM roofline of this box."""
+        g = C.c_float()
+        st = stream if stream is not None else capi.current_stream()
+        capi.check(capi.lib().dctr_measure_copy_bw(int(nbytes), int(iters), C.byref(g), st))
+        return g.value
+
     def debug_tensor(self, name: str):
         """Device view (torch) of a named intermediate of the last forward."""
         import torch
