@@ -41,7 +41,12 @@ enum { DCTR_MODEL_DEEPFM = 0,  /* DeepFM.py   */
        DCTR_MODEL_OPNN   = 3,  /* PNN.py --model_type=Outer */
        DCTR_MODEL_NFM    = 4,  /* NFM.py      */
        DCTR_MODEL_AFM    = 5,  /* AFM.py      */
-       DCTR_MODEL_DCN    = 6   /* DCN.py      */ };
+       DCTR_MODEL_DCN    = 6,  /* DCN.py      */
+       /* canned estimators of wide_n_deep.py:113-151 over its feature columns (:92-105): field_size categorical
+        * (identity) columns share one stacked table, dense_size numeric columns enter as dense inputs */
+       DCTR_MODEL_WIDE   = 7,  /* --model_type=wide         LinearClassifier            */
+       DCTR_MODEL_DEEP   = 8,  /* --model_type=deep         DNNClassifier               */
+       DCTR_MODEL_WND    = 9   /* --model_type=wide_n_deep  DNNLinearCombinedClassifier */ };
 
 enum { DCTR_OPT_ADAM = 0, DCTR_OPT_ADAGRAD = 1, DCTR_OPT_MOMENTUM = 2, DCTR_OPT_FTRL = 3 }; /* DeepFM.py:204-211 */
 
@@ -83,6 +88,11 @@ typedef struct dctr_config {
     int32_t shard_rank;
     int32_t shard_world;
     int32_t use_graph;                   /* capture the step into a hipGraph (1) or launch eagerly (0) */
+    /* canned-estimator models only (DCTR_MODEL_WIDE/DEEP/WND); zero for the model_fn models */
+    int32_t dense_size;                  /* numeric_column count (13, wide_n_deep.py:55,94): dense inputs [B,dense_size]  */
+    int32_t lin_optimizer;               /* DCTR_OPT_* of the linear side (TF default Ftrl); `optimizer` drives the DNN side */
+    float   lin_learning_rate;
+    int32_t loss_sum;                    /* 1: loss (and its gradient) is the SUM over the batch [TF-1.4 canned heads], 0: mean */
 } dctr_config;
 
 typedef struct dctr_engine* dctr_handle;
@@ -243,7 +253,13 @@ int dctr_train_step(dctr_handle h, const int32_t* d_ids, const float* d_vals, co
  * buffers.  A caller that writes a batch straight into slot k (e.g. the H2D copy of the input pipeline) and passes those
  * same pointers to dctr_train_step / dctr_predict / dctr_eval_batch pays no staging copy; any other pointers are copied
  * device-to-device into slot 0 first. */
+/* canned-estimator models: the dense (numeric-column) inputs [B, dense_size] f32 of the NEXT train/predict/eval call; the
+ * buffer is read in place and must stay valid until that call's work has finished */
+int dctr_set_dense_input(dctr_handle h, const float* d_dense);
 int dctr_input_slot(dctr_handle h, int slot, int32_t** d_ids, float** d_vals, float** d_labels);
+/* canned-estimator models: the dense (numeric-column) inputs [B, dense_size] f32 of the NEXT train/predict/eval call; the
+ * buffer is read in place and must stay valid until that call's work has finished */
+int dctr_set_dense_input(dctr_handle h, const float* d_dense);
 /* forward only (mode PREDICT/EVAL: dropout off, BN moving stats): d_prob [B] (may be NULL), d_logit [B] (may be NULL) */
 int dctr_predict(dctr_handle h, const int32_t* d_ids, const float* d_vals, int B,
                  float* d_prob, float* d_logit, void* stream);

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libdeepctr_hip.so")
 
 DCTR_OK = 0
-MODELS = {"deepfm": 0, "fnn": 1, "ipnn": 2, "opnn": 3, "nfm": 4, "afm": 5, "dcn": 6}
+MODELS = {"deepfm": 0, "fnn": 1, "ipnn": 2, "opnn": 3, "nfm": 4, "afm": 5, "dcn": 6, "wide": 7, "deep": 8, "wide_n_deep": 9}
 OPTIMIZERS = {"Adam": 0, "Adagrad": 1, "Momentum": 2, "ftrl": 3}
 TABLE_MODES = {"dense_exact": 0, "touched_rows": 1}
 GATHER_RAW, GATHER_FM, GATHER_BI = 0, 1, 2
@@ -35,7 +35,8 @@ class Config(C.Structure):
         ("learning_rate", C.c_float), ("optimizer", C.c_int32), ("table_mode", C.c_int32),
         ("batch_norm", C.c_int32), ("batch_norm_decay", C.c_float), ("max_batch", C.c_int32),
         ("seed", C.c_uint64), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
-        ("use_graph", C.c_int32),
+        ("use_graph", C.c_int32), ("dense_size", C.c_int32), ("lin_optimizer", C.c_int32),
+        ("lin_learning_rate", C.c_float), ("loss_sum", C.c_int32),
     ]
 
 
@@ -114,6 +115,7 @@ _SIGS = {
     "dctr_last_outputs": ([_P, C.POINTER(_P), C.POINTER(_P)], C.c_int),
     "dctr_time_kernel": ([_P, C.c_char_p, C.c_int, C.POINTER(C.c_float), _P], C.c_int),
     "dctr_debug_tensor": ([_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int)], C.c_int),
+    "dctr_set_dense_input": ([_P, _P], C.c_int),
     "dctr_measure_copy_bw": ([C.c_size_t, C.c_int, C.POINTER(C.c_float), _P], C.c_int),
     "dctr_rccl_unique_id": ([C.c_char_p, C.c_char_p], C.c_int),
     "dctr_dist_create_rccl": ([_P, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(_P)], C.c_int),

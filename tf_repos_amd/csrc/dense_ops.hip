@@ -1,6 +1,7 @@
 // K7 loss head, K9 optimizers, K10 streaming AUC, and the N=1 output layers (row dots).
 // All HBM-bound streaming kernels: float4 / 16-byte-per-lane coalesced accesses, grid-stride loops,
 // reductions in registers -> wave shuffles -> one atomic per block.
+#include "opt_rules.h"
 #include "common.h"
 #include "ops.h"
 
@@ -442,32 +443,6 @@ int loss_head(const float* bias, const float* yw, const float* yv, const float* 
 }
 
 // ---- K9 optimizers (DeepFM.py:204-211), TF-1.4 update rules ----------------------------------
-__device__ __forceinline__ void opt_update(int kind, const Hyper& h, float& th, float& s0, float& s1, float g) {
-    switch (kind) {
-        case DCTR_OPT_ADAM: {           // m,v ; theta -= lr_t m/(sqrt(v)+eps), lr_t = lr sqrt(1-b2^t)/(1-b1^t)
-            s0 = h.beta1 * s0 + (1.0f - h.beta1) * g;
-            s1 = h.beta2 * s1 + (1.0f - h.beta2) * g * g;
-            th = th - h.lr_t * s0 / (sqrtf(s1) + h.eps);
-        } break;
-        case DCTR_OPT_ADAGRAD: {        // accum += g^2 ; theta -= lr g / sqrt(accum)
-            s0 = s0 + g * g;
-            th = th - h.lr * g / sqrtf(s0);
-        } break;
-        case DCTR_OPT_MOMENTUM: {       // accum = mom*accum + g ; theta -= lr accum
-            s0 = h.momentum * s0 + g;
-            th = th - h.lr * s0;
-        } break;
-        case DCTR_OPT_FTRL: {           // lr_power = -0.5, l1 = l2 = 0: s0 = accum, s1 = linear
-            const float na = s0 + g * g;
-            const float sigma = (sqrtf(na) - sqrtf(s0)) / h.lr;
-            s1 = s1 + g - sigma * th;
-            th = -s1 / (sqrtf(na) / h.lr);
-            s0 = na;
-        } break;
-    }
-}
-
-__device__ __forceinline__ Hyper load_hyper(const Hyper* dev, const Hyper& val) { return dev ? *dev : val; }
 
 // dense arena: OPT_BLOCK elements per block; per-block metadata says where the gradient partials live
 template <int KIND>
@@ -760,8 +735,10 @@ __global__ void step_state_kernel(StepState* s, float* zero, int n_zero) {
     if (threadIdx.x != 0) return;
     s->t += 1;
     const double t = (double)s->t;
-    Hyper& h = s->hyper;
-    h.lr_t = (float)((double)h.lr * sqrt(1.0 - pow((double)h.beta2, t)) / (1.0 - pow((double)h.beta1, t)));
+    for (Hyper* hp : {&s->hyper, &s->hyper_lin}) {
+        Hyper& h = *hp;
+        h.lr_t = (float)((double)h.lr * sqrt(1.0 - pow((double)h.beta2, t)) / (1.0 - pow((double)h.beta1, t)));
+    }
     s->seed_t = s->seed ^ ((uint64_t)s->t * 0xD1B54A32D192ED03ULL);
 }
 

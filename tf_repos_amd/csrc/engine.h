@@ -92,6 +92,12 @@ struct dctr_engine {
     std::vector<hipEvent_t> events;
     size_t ev_next = 0;
 
+    // canned-estimator models (wide_n_deep.py): dense numeric inputs + a linear side with its own optimizer
+    bool wnd = false, wnd_wide = false, wnd_deep = false;
+    int n_dense = 0;
+    const float* dense = nullptr;    // [B, n_dense] inputs of the next call (dctr_set_dense_input), caller-owned
+    int p_lin_dense = -1;
+
     // AFM (afm.hip)
     int A = 0;                       // attention layer width
     int p_att_w = -1, p_att_b = -1, p_ao_w = -1, p_ao_b = -1;

@@ -15,6 +15,7 @@ struct StepState {
     uint64_t seed;      // base dropout seed
     uint64_t seed_t;    // seed of the current step
     Hyper hyper;
+    Hyper hyper_lin;    // canned-estimator models: the linear side's optimizer (wide_n_deep.py:144-149); else a copy of hyper
 };
 
 // sum-of-squares outputs (the l2_loss part of the reported loss) are SUMSQ_SHARDS-way sharded by block index: thousands of
@@ -107,6 +108,11 @@ int head_out_bwd(const float* x1, int ld1, const float* w1, int n1, int masked1,
 int head_fused(const float* x1, int ld1, const float* w1, int n1, const float* x2, int ld2, const float* w2, int n2,
                const float* b_out, const float* bias, const float* yw, const float* yv, const float* labels, int B, float inv_batch,
                float* yd, float* y, float* prob, float* dy, float* loss_shards, hipStream_t st);
+
+// ---- wnd.hip: dense (numeric-column) inputs and the linear side of the canned-estimator models
+int wnd_dense_fwd(const float* dense, int nd, const float* wd, int B, float* x_in, int ldx, int col0, float* yw, hipStream_t st);
+int opt_lin_touched(int kind, const Hyper* hdev, const Hyper& hval, float* lin, float* l0, float* l1, const int32_t* uniq,
+                    const int32_t* counters, int64_t max_entries, const float* glin, hipStream_t st);
 
 // ---- interact.hip
 int pnn_inner_fwd(const float* e, int e_ld, int B, int F, int K, float* ip, int ip_ld, hipStream_t st);

@@ -1,0 +1,34 @@
+// K9 optimizer update rules (DeepFM.py:204-211), TF-1.4 semantics; shared by dense_ops.hip and wnd.hip.
+#pragma once
+#include "ops.h"
+
+namespace dctr {
+
+__device__ __forceinline__ void opt_update(int kind, const Hyper& h, float& th, float& s0, float& s1, float g) {
+    switch (kind) {
+        case DCTR_OPT_ADAM: {           // m,v ; theta -= lr_t m/(sqrt(v)+eps), lr_t = lr sqrt(1-b2^t)/(1-b1^t)
+            s0 = h.beta1 * s0 + (1.0f - h.beta1) * g;
+            s1 = h.beta2 * s1 + (1.0f - h.beta2) * g * g;
+            th = th - h.lr_t * s0 / (sqrtf(s1) + h.eps);
+        } break;
+        case DCTR_OPT_ADAGRAD: {        // accum += g^2 ; theta -= lr g / sqrt(accum)
+            s0 = s0 + g * g;
+            th = th - h.lr * g / sqrtf(s0);
+        } break;
+        case DCTR_OPT_MOMENTUM: {       // accum = mom*accum + g ; theta -= lr accum
+            s0 = h.momentum * s0 + g;
+            th = th - h.lr * s0;
+        } break;
+        case DCTR_OPT_FTRL: {           // lr_power = -0.5, l1 = l2 = 0: s0 = accum, s1 = linear
+            const float na = s0 + g * g;
+            const float sigma = (sqrtf(na) - sqrtf(s0)) / h.lr;
+            s1 = s1 + g - sigma * th;
+            th = -s1 / (sqrtf(na) / h.lr);
+            s0 = na;
+        } break;
+    }
+}
+
+__device__ __forceinline__ Hyper load_hyper(const Hyper* dev, const Hyper& val) { return dev ? *dev : val; }
+
+}  // namespace dctr

@@ -36,6 +36,12 @@ class EngineConfig:
     seed: int = 0
     shard_rank: int = 0
     shard_world: int = 1
+    # canned estimators of wide_n_deep.py (model = wide | deep | wide_n_deep): field_size categorical identity columns over
+    # one stacked table, dense_size numeric columns as dense inputs, a linear side with its own optimizer, summed loss
+    dense_size: int = 0
+    lin_optimizer: str = "ftrl"
+    lin_learning_rate: float = 0.005
+    loss_sum: bool = False
     use_graph: bool = False                    # False: eager launches on 3 HIP streams (measured faster: each stream keeps its own
                                                # hardware queue); True: one captured hipGraph per (batch size, input slot)
 
@@ -75,6 +81,10 @@ class EngineConfig:
         c.shard_rank = self.shard_rank
         c.shard_world = self.shard_world
         c.use_graph = int(self.use_graph)
+        c.dense_size = int(self.dense_size)
+        c.lin_optimizer = capi.OPTIMIZERS[self.lin_optimizer]
+        c.lin_learning_rate = float(self.lin_learning_rate)
+        c.loss_sum = int(self.loss_sum)
         return c
 
 
@@ -154,8 +164,13 @@ class Engine:
         capi.check(self._lib.dctr_set_global_step(self._h, int(v)))
 
     # -- ops ---------------------------------------------------------------------------------
-    def train_step(self, ids, vals, labels, want_loss: bool = True, stream=None) -> Optional[float]:
-        """ids int32 [B,F], vals f32 [B,F], labels f32 [B]: CUDA(HIP) torch tensors."""
+    def _set_dense(self, dense) -> None:
+        if dense is not None:
+            capi.check(self._lib.dctr_set_dense_input(self._h, capi.ptr(dense)))
+
+    def train_step(self, ids, vals, labels, want_loss: bool = True, stream=None, dense=None) -> Optional[float]:
+        """ids int32 [B,F], vals f32 [B,F], labels f32 [B] (dense f32 [B,dense_size] for the canned models): device tensors."""
+        self._set_dense(dense)
         B = int(labels.shape[0])
         loss = C.c_float()
         st = stream if stream is not None else capi.current_stream()
@@ -163,7 +178,8 @@ class Engine:
                                              C.byref(loss) if want_loss else None, st))
         return loss.value if want_loss else None
 
-    def predict(self, ids, vals, out_prob=None, out_logit=None, stream=None):
+    def predict(self, ids, vals, out_prob=None, out_logit=None, stream=None, dense=None):
+        self._set_dense(dense)
         B = int(ids.shape[0])
         st = stream if stream is not None else capi.current_stream()
         capi.check(self._lib.dctr_predict(self._h, capi.ptr(ids), capi.ptr(vals), B, capi.ptr(out_prob),
@@ -190,7 +206,8 @@ class Engine:
     def eval_reset(self, stream=None) -> None:
         capi.check(self._lib.dctr_eval_reset(self._h, stream if stream is not None else capi.current_stream()))
 
-    def eval_batch(self, ids, vals, labels, stream=None) -> None:
+    def eval_batch(self, ids, vals, labels, stream=None, dense=None) -> None:
+        self._set_dense(dense)
         st = stream if stream is not None else capi.current_stream()
         capi.check(self._lib.dctr_eval_batch(self._h, capi.ptr(ids), capi.ptr(vals), capi.ptr(labels), int(labels.shape[0]), st))
 
