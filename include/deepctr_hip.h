@@ -120,6 +120,13 @@ int dctr_parse_libsvm(const char* h_text, size_t nbytes, int field_size, int64_t
                       int32_t* h_ids, float* h_vals, float* h_labels,
                       int64_t* n_rows, size_t* n_consumed);
 
+/* CSV text -> column tensors.  Replaces tf.decode_csv(line, record_defaults) (wide_n_deep.py:67-73; defaults :59-64):
+ * kinds[c] = 0 float / 1 int32 column; an empty field takes its column's default; float (int) columns land in order of
+ * appearance in h_f [rows, n_float] (h_i [rows, n_int]).  Same whole-lines / n_consumed contract as dctr_parse_libsvm. */
+int dctr_parse_csv(const char* h_text, size_t nbytes, int n_cols, const int8_t* kinds, const float* f_defaults,
+                   const int32_t* i_defaults, int64_t max_rows, float* h_f, int32_t* h_i, int64_t* n_rows,
+                   size_t* n_consumed);
+
 /* ---- K2: embedding gather + value scale + fused reductions.
  * Replaces embedding_lookup(FM_W)/multiply/reduce_sum (DeepFM.py:126-127), embedding_lookup(FM_V),
  * multiply (DeepFM.py:130-132), and per `mode` the FM second-order term (DeepFM.py:133-135) or NFM's

@@ -154,3 +154,66 @@ extern "C" int dctr_parse_libsvm(const char* h_text, size_t nbytes, int field_si
     if (n_consumed) *n_consumed = consumed;
     return DCTR_OK;
 }
+
+// CSV text -> column tensors.  Replaces tf.decode_csv(line, record_defaults) of wide_n_deep.py:67-73 (record_defaults
+// wide_n_deep.py:59-64: one float label, 13 float columns, 26 int columns): fields split on ',', an EMPTY field takes its
+// column's default, float columns go through the same correctly rounded conversion as string_to_number, int columns must be
+// plain base-10 int32 [TF-1.4 DecodeCSVOp: "Field i is not a valid int32/float"].  Quoted fields are not used by the
+// reference's data and are rejected.  kinds[c]: 0 = float column, 1 = int32 column; float / int columns are written in order
+// of appearance into h_f [rows, n_float] / h_i [rows, n_int].  Host code, re-entrant.
+extern "C" int dctr_parse_csv(const char* h_text, size_t nbytes, int n_cols, const int8_t* kinds, const float* f_defaults,
+                              const int32_t* i_defaults, int64_t max_rows, float* h_f, int32_t* h_i, int64_t* n_rows,
+                              size_t* n_consumed) {
+    using namespace dctr;
+    DCTR_REQUIRE(h_text != nullptr && kinds != nullptr && n_rows != nullptr && n_cols > 0, "bad argument");
+    int nf = 0, ni = 0;
+    for (int c = 0; c < n_cols; ++c) (kinds[c] == 0 ? nf : ni) += 1;
+    DCTR_REQUIRE((nf == 0 || (h_f != nullptr && f_defaults != nullptr)) && (ni == 0 || (h_i != nullptr && i_defaults != nullptr)), "null output");
+    const char* p = h_text;
+    const char* end = h_text + nbytes;
+    int64_t row = 0, line_no = 0;
+    size_t consumed = 0;
+    while (p < end && row < max_rows) {
+        const char* eol = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+        const char* le = eol ? eol : end;
+        const char* next = eol ? eol + 1 : end;
+        ++line_no;
+        if (le > p && le[-1] == '\r') --le;
+        if (le == p) { p = next; consumed = (size_t)(p - h_text); continue; }
+        float* fr = h_f + (size_t)row * nf;
+        int32_t* ir = h_i + (size_t)row * ni;
+        int c = 0, fc = 0, ic = 0;
+        const char* q = p;
+        while (true) {
+            const char* t = q;
+            while (q < le && *q != ',') ++q;
+            if (c >= n_cols) { set_error("Expect %d fields but have more in record (line %lld)", n_cols, (long long)line_no); return DCTR_ERR_PARSE; }
+            if (t < q && *t == '"') { set_error("line %lld: quoted CSV fields are not supported", (long long)line_no); return DCTR_ERR_PARSE; }
+            if (kinds[c] == 0) {
+                if (t == q) fr[fc] = f_defaults[fc];
+                else if (!parse_f32(t, q, &fr[fc])) {
+                    set_error("Field %d in record is not a valid float: %.*s (line %lld)", c, (int)(q - t), t, (long long)line_no);
+                    return DCTR_ERR_PARSE;
+                }
+                ++fc;
+            } else {
+                if (t == q) ir[ic] = i_defaults[ic];
+                else if (!parse_i32(t, q, &ir[ic])) {
+                    set_error("Field %d in record is not a valid int32: %.*s (line %lld)", c, (int)(q - t), t, (long long)line_no);
+                    return DCTR_ERR_PARSE;
+                }
+                ++ic;
+            }
+            ++c;
+            if (q == le) break;
+            ++q;                    // skip the comma; a trailing comma yields one more (empty) field
+        }
+        if (c != n_cols) { set_error("Expect %d fields but have %d in record (line %lld)", n_cols, c, (long long)line_no); return DCTR_ERR_PARSE; }
+        ++row;
+        p = next;
+        consumed = (size_t)(p - h_text);
+    }
+    *n_rows = row;
+    if (n_consumed) *n_consumed = consumed;
+    return DCTR_OK;
+}

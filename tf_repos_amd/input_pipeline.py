@@ -117,3 +117,67 @@ class LibsvmDataset:
                     carry = (ids[full:], vals[full:], labels[full:])
         if carry is not None and len(carry[2]) > 0:
             yield carry
+
+
+def parse_csv(text, kinds: Sequence[int], f_defaults: Sequence[float], i_defaults: Sequence[int], max_rows: Optional[int] = None):
+    """One call into the C CSV decoder (dctr_parse_csv = tf.decode_csv, wide_n_deep.py:67-73).  kinds[c]: 0 float / 1 int32.
+    Returns (floats f32 [n, n_float], ints i32 [n, n_int]) with the columns of each kind in order of appearance."""
+    if isinstance(text, str):
+        text = text.encode()
+    n_lines = text.count(b"\n") + (0 if text.endswith(b"\n") or not text else 1)
+    cap = n_lines if max_rows is None else min(n_lines, max_rows)
+    k = np.asarray(kinds, dtype=np.int8)
+    nf, ni = int((k == 0).sum()), int((k == 1).sum())
+    fd = np.asarray(list(f_defaults) or [0.0], dtype=np.float32)
+    idf = np.asarray(list(i_defaults) or [0], dtype=np.int32)
+    out_f = np.empty((max(cap, 1), max(nf, 1)), dtype=np.float32)
+    out_i = np.empty((max(cap, 1), max(ni, 1)), dtype=np.int32)
+    n = C.c_int64()
+    used = C.c_size_t()
+    capi.check(capi.lib().dctr_parse_csv(text, len(text), len(k), capi.ptr(k), capi.ptr(fd), capi.ptr(idf), cap, capi.ptr(out_f),
+                                         capi.ptr(out_i), C.byref(n), C.byref(used)))
+    return out_f[:n.value, :nf], out_i[:n.value, :ni]
+
+
+class CsvDataset:
+    """TextLineDataset(filenames).map(parse_csv, 10).prefetch().repeat(num_epochs).batch(batch_size) (wide_n_deep.py:66-89) as
+    an iterator of numpy batches (floats [b, n_float], ints [b, n_int]); files are decoded by a thread pool of C calls."""
+
+    def __init__(self, filenames: Sequence[str], kinds: Sequence[int], f_defaults: Sequence[float], i_defaults: Sequence[int],
+                 batch_size: int = 1, num_epochs: int = 1, threads: int = 10):
+        self.filenames = [filenames] if isinstance(filenames, str) else list(filenames)
+        self.kinds, self.f_defaults, self.i_defaults = list(kinds), list(f_defaults), list(i_defaults)
+        self.batch_size, self.num_epochs, self.threads = batch_size, num_epochs, threads
+        self._cache = {}
+
+    def _load(self, path):
+        if path not in self._cache:
+            with open(path, "rb") as f:
+                buf = f.read()
+            chunks = _split_on_lines(buf, self.threads)
+            fn = lambda c: parse_csv(c, self.kinds, self.f_defaults, self.i_defaults)
+            if len(chunks) == 1:
+                parts = [fn(chunks[0])]
+            else:
+                with ThreadPoolExecutor(max_workers=self.threads) as ex:
+                    parts = list(ex.map(fn, chunks))
+            self._cache[path] = (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]))
+        return self._cache[path]
+
+    def __iter__(self):
+        B = self.batch_size
+        carry = None
+        for _epoch in range(self.num_epochs):
+            for path in self.filenames:
+                f, i = self._load(path)
+                if carry is not None:
+                    f = np.concatenate([carry[0], f]); i = np.concatenate([carry[1], i])
+                    carry = None
+                n = len(f)
+                full = n // B * B
+                for s in range(0, full, B):
+                    yield f[s:s + B], i[s:s + B]
+                if full < n:
+                    carry = (f[full:], i[full:])
+        if carry is not None and len(carry[0]) > 0:
+            yield carry

@@ -12,6 +12,7 @@ import sys
 import types
 
 from .. import errors as _errors
+from . import canned as _canned
 from . import data as _data
 from . import estimator as _est
 from . import flags as FLAGS_MODULE
@@ -47,10 +48,16 @@ def build_module():
     tf.metrics = _mod("tensorflow.metrics", auc=_g.metrics_auc)
     tf.data = _mod("tensorflow.data", TextLineDataset=_data.TextLineDataset)
     export = _mod("tensorflow.estimator.export", PredictOutput=_est.PredictOutput, ServingInputReceiver=_est.ServingInputReceiver,
-                  build_raw_serving_input_receiver_fn=_est.build_raw_serving_input_receiver_fn)
+                  build_raw_serving_input_receiver_fn=_est.build_raw_serving_input_receiver_fn,
+                  build_parsing_serving_input_receiver_fn=_canned.build_parsing_serving_input_receiver_fn)
     tf.estimator = _mod("tensorflow.estimator", Estimator=_est.Estimator, EstimatorSpec=_est.EstimatorSpec, ModeKeys=_est.ModeKeys,
                         RunConfig=_est.RunConfig, TrainSpec=_est.TrainSpec, EvalSpec=_est.EvalSpec,
-                        train_and_evaluate=_est.train_and_evaluate, export=export)
+                        train_and_evaluate=_est.train_and_evaluate, export=export,
+                        LinearClassifier=_canned.LinearClassifier, DNNClassifier=_canned.DNNClassifier,
+                        DNNLinearCombinedClassifier=_canned.DNNLinearCombinedClassifier)
+    tf.feature_column = _mod("tensorflow.feature_column", numeric_column=_canned.numeric_column,
+                             categorical_column_with_identity=_canned.categorical_column_with_identity,
+                             embedding_column=_canned.embedding_column, make_parse_example_spec=_canned.make_parse_example_spec)
     tf.ConfigProto = _est.ConfigProto
     sigc = _mod("tensorflow.saved_model.signature_constants", DEFAULT_SERVING_SIGNATURE_DEF_KEY="serving_default")
     tf.saved_model = _mod("tensorflow.saved_model", signature_constants=sigc)
@@ -67,7 +74,7 @@ def install(force: bool = False):
         raise RuntimeError("a real tensorflow is already imported")
     tf = build_module()
     sys.modules["tensorflow"] = tf
-    for sub in ("nn", "contrib", "train", "metrics", "data", "estimator", "saved_model", "app"):
+    for sub in ("nn", "contrib", "train", "metrics", "data", "estimator", "saved_model", "app", "feature_column"):
         sys.modules["tensorflow." + sub] = getattr(tf, sub)
     sys.modules["tensorflow.contrib.layers"] = tf.contrib.layers
     sys.modules["tensorflow.estimator.export"] = tf.estimator.export

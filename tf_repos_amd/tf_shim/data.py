@@ -9,7 +9,7 @@ from __future__ import annotations
 from typing import Dict, List, Optional, Sequence
 
 from .. import errors
-from ..input_pipeline import LibsvmDataset
+from ..input_pipeline import CsvDataset, LibsvmDataset
 from . import graph as G
 
 
@@ -45,6 +45,8 @@ class Dataset:
         self.num_parallel_calls = 10
         self.feature_keys: Dict[str, str] = {}       # role -> feature dict key
         self.field_size: Optional[int] = None
+        # CSV pipelines (wide_n_deep.py:66-89): column kinds/defaults of decode_csv, feature key -> column, label column
+        self.csv: Optional[Dict] = None
 
     # -- pipeline construction (each call returns self: the pipeline is a linear chain in the reference) ---------------
     def map(self, fn, num_parallel_calls=None):
@@ -55,6 +57,8 @@ class Dataset:
         if not (isinstance(out, tuple) and len(out) == 2 and isinstance(out[0], dict)):
             raise errors.UnimplementedError("map function must return ({'feat_ids':..., 'feat_vals':...}, labels)")
         feats, label = out
+        if isinstance(label, G.Tensor) and label.op == "decode_csv":
+            return self._map_csv(feats, label)
         if _provenance(label) != "label":
             raise errors.UnimplementedError("labels are not token 0 of the line")
         for k, v in feats.items():
@@ -62,6 +66,40 @@ class Dataset:
         if set(self.feature_keys) != {"ids", "vals"}:
             raise errors.UnimplementedError("features must be the libsvm ids and vals")
         return self
+
+    def _map_csv(self, feats, label):
+        """map(parse_csv): columns = tf.decode_csv(line, record_defaults); features = dict(zip(names, columns)); labels = pop."""
+        cols = dict(feats)
+        n = label.attrs["n"]
+        by_index = {label.attrs["index"]: ("__label__", label)}
+        for k, v in cols.items():
+            if not (isinstance(v, G.Tensor) and v.op == "decode_csv" and v.inputs[0] is label.inputs[0]):
+                raise errors.UnimplementedError("feature %r is not a decode_csv column of the same record" % k)
+            by_index[v.attrs["index"]] = (k, v)
+        if sorted(by_index) != list(range(n)):
+            raise errors.UnimplementedError("every decode_csv column must be either the label or a feature")
+        kinds = [0 if by_index[i][1].dtype is G.float32 else 1 for i in range(n)]
+        self.csv = {"kinds": kinds,
+                    "f_defaults": [float(by_index[i][1].attrs["default"][0]) for i in range(n) if kinds[i] == 0],
+                    "i_defaults": [int(by_index[i][1].attrs["default"][0]) for i in range(n) if kinds[i] == 1],
+                    "names": [by_index[i][0] for i in range(n)], "label_index": label.attrs["index"]}
+        if kinds[self.csv["label_index"]] != 0:
+            raise errors.UnimplementedError("the label column must be a float column")
+        return self
+
+    def csv_batches(self):
+        """numpy batches (floats [b, n_float], ints [b, n_int]); column names per kind in self.csv_float_names / csv_int_names"""
+        c = self.csv
+        return iter(CsvDataset(self.filenames, c["kinds"], c["f_defaults"], c["i_defaults"], self.batch_size, self.num_epochs,
+                               threads=self.num_parallel_calls)) if self.filenames else iter(())
+
+    @property
+    def csv_float_names(self):
+        return [n for n, k in zip(self.csv["names"], self.csv["kinds"]) if k == 0]
+
+    @property
+    def csv_int_names(self):
+        return [n for n, k in zip(self.csv["names"], self.csv["kinds"]) if k == 1]
 
     def prefetch(self, buffer_size):
         return self
@@ -98,6 +136,12 @@ class _Iterator:
 
     def get_next(self):
         ds = self.ds
+        if ds.csv is not None:
+            feats = {n: G.Tensor("iterator_csv", [], {"dataset": ds, "column": n}, G.float32 if k == 0 else G.int32, (None,))
+                     for n, k in zip(ds.csv["names"], ds.csv["kinds"]) if n != "__label__"}
+            labels = G.Tensor("iterator_labels", [], {"dataset": ds}, G.float32, (None,))
+            G.current_graph().collections.setdefault("iterators", []).append(ds)
+            return feats, labels
         if not ds.feature_keys:
             raise errors.UnimplementedError("TextLineDataset without a decode map function")
         ids = G.Tensor("iterator_ids", [], {"dataset": ds}, G.int32, (None, None, 1))
