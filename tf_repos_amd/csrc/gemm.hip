@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(
         }
         __syncthreads();
         lread(As0, Bs0, f0a, f0b);
-        colsum(Bs0);
+        if (nk > 0) colsum(Bs0);        // (an empty k-split -- splits*kchunk may overshoot -- has nothing staged: LDS is garbage)
         for (int kt = 0; kt < nk; kt += 2) {
             step(kt, As1, Bs1, f0a, f0b, f1a, f1b);
             if (kt + 1 < nk) step(kt + 1, As0, Bs0, f1a, f1b, f0a, f0b);
