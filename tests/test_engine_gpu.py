@@ -95,3 +95,62 @@ def test_graph_and_eager_agree_and_ragged_last_batch(dev):
         eng.close()
     for k in res[0]:
         assert np.abs(res[0][k] - res[1][k]).max() <= 1e-6, k
+
+
+@pytest.mark.parametrize("model,opt", [("deepfm", "Momentum"), ("deepfm", "Adagrad"), ("nfm", "Momentum"), ("dcn", "Momentum"), ("ipnn", "Adagrad")])
+def test_batch_norm_matches_oracle(model, opt, dev):
+    """--batch_norm=True (run.sh:17 uses it for NFM): contrib batch_norm after each hidden ReLU (DeepFM.py:159-160,231-235):
+    batch statistics + moving-average update in TRAIN, moving statistics in EVAL/PREDICT.
+    Not Adam here: BN makes the loss invariant to a shift of its input, so the gradient of a bias whose units are active for the
+    whole batch is EXACTLY zero in exact arithmetic and ~1e-9 rounding noise in f32 -- Adam divides by sqrt(v)+1e-8 and turns
+    that noise into O(lr/100) steps on either side (the f32 oracle differs from its own f64 shadow the same way)."""
+    from tf_repos_amd.engine import Engine, EngineConfig
+    F, V, B, K = 39, 3000, 128, 8
+    ocfg = O.Config(model=model, field_size=F, feature_size=V, embedding_size=K, deep_layers=(32, 16), dropout=(1.0, 1.0), cross_layers=2,
+                    l2_reg=1e-3, learning_rate=1e-2, optimizer=opt, batch_norm=True, batch_norm_decay=0.9)
+    params = O.init_params(ocfg, seed=3, scale=0.05)
+    rng = np.random.default_rng(0)
+    for k in params:          # non-trivial BN parameters / statistics
+        if k.endswith(("gamma", "moving_variance")):
+            params[k] = torch.from_numpy(rng.uniform(0.5, 1.5, size=tuple(params[k].shape)).astype(np.float32))
+        if k.endswith(("beta", "moving_mean")):
+            params[k] = torch.from_numpy(rng.normal(0, 0.1, size=tuple(params[k].shape)).astype(np.float32))
+    eng = Engine(EngineConfig(model=model, field_size=F, feature_size=V, embedding_size=K, deep_layers=(32, 16), dropout=(1.0, 1.0),
+                              cross_layers=2, l2_reg=1e-3, learning_rate=1e-2, optimizer=opt, batch_norm=True, batch_norm_decay=0.9,
+                              max_batch=B, use_graph=False))
+    assert set(eng.param_shapes) == set(params)
+    eng.set_params(params)
+    ids, vals, labels = O.synth_batch(B, F, V, seed=5)
+    d = dev_batch(ids, vals, labels, dev)
+    logit = torch.empty(B, device=dev)
+    prob = torch.empty(B, device=dev)
+    eng.predict(d[0], d[1], prob, logit)                                   # inference: moving statistics
+    ref = O.forward(ocfg, params, ids, vals, train=False)
+    assert np.abs(logit.cpu().numpy() - ref["y"].numpy()).max() <= 1e-4
+    oopt = O.Optimizer(ocfg, params)
+    for step in range(3):
+        ids, vals, labels = O.synth_batch(B, F, V, seed=200 + step)
+        ref_loss, _ = O.train_step(ocfg, params, oopt, ids, vals, labels)
+        loss = eng.train_step(*dev_batch(ids, vals, labels, dev))
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (step, loss, ref_loss)
+    got = eng.get_params()
+    for name, refv in params.items():
+        assert np.abs(got[name] - refv.numpy()).max() <= 2e-5, name         # includes moving_mean / moving_variance; BN divides by the batch std, which amplifies f32 rounding ~10x
+    eng.close()
+
+
+def test_batch_norm_with_dropout_runs_and_freezes_moving_stats_under_ftrl(dev):
+    from tf_repos_amd.engine import Engine, EngineConfig
+    F, V, B, K = 39, 3000, 64, 8
+    eng = Engine(EngineConfig(model="deepfm", field_size=F, feature_size=V, embedding_size=K, deep_layers=(32, 16), dropout=(0.5, 0.5),
+                              l2_reg=1e-3, learning_rate=1e-2, optimizer="ftrl", batch_norm=True, batch_norm_decay=0.5, max_batch=B))
+    rng = np.random.default_rng(1)
+    for name, shp in eng.param_shapes.items():
+        eng.set_param(name, np.ones(shp, np.float32) if name.endswith(("gamma", "moving_variance")) else rng.normal(0, 0.05, size=shp).astype(np.float32))
+    ids, vals, labels = O.synth_batch(B, F, V, seed=9)
+    loss = eng.train_step(*dev_batch(ids, vals, labels, dev))
+    assert np.isfinite(loss)
+    mv = eng.get_param("bn_0/moving_variance")
+    mm = eng.get_param("bn_0/moving_mean")
+    assert np.all(mv > 0.4) and np.all(mv < 1.0) and np.abs(mm).max() > 0         # moved by the moving average only, not zeroed by Ftrl
+    eng.close()

@@ -67,9 +67,10 @@ def test_reference_quirks_surface_unchanged():
     with pytest.raises(UnboundLocalError):
         _trace(mod, PARAMS)
     mod = load_reference_module(os.path.join(REF, "NFM.py"))
-    shim.FLAGS_MODULE.FLAGS.batch_norm = True
-    with pytest.raises(errors.UnimplementedError):
-        _trace(mod, PARAMS)
+    shim.FLAGS_MODULE.FLAGS.batch_norm = True           # run.sh:17 trains NFM with --batch_norm=True
+    _spec, low, _pipe, _vars = _trace(mod, PARAMS)
+    assert low.config_kwargs["batch_norm"] is True and low.config_kwargs["batch_norm_decay"] == 0.9
+    assert low.name_map["bn_0/moving_variance"].endswith("bn_0/moving_variance") and low.name_map["bn_1/beta"].endswith("bn_1/beta")
 
 
 def _load_example():

@@ -453,6 +453,7 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const Hyper* __restrict_
                                                        int apply, float* __restrict__ sumsq) {
     const Hyper h = load_hyper(hdev, hval);
     const OptBlockMeta m = meta[blockIdx.x];
+    if (m.n_part < 0) return;       // not trainable (BN moving statistics)
     const size_t i4 = (size_t)blockIdx.x * (OPT_BLOCK / 4) + threadIdx.x;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4* p = reinterpret_cast<const float4*>(parts + m.part_off) + threadIdx.x;

@@ -23,6 +23,7 @@ struct Param {
     int64_t part_off = 0;        // offset of the first partial slab in `parts`
     int n_part = 1;
     float l2 = 0.f;
+    bool frozen = false;         // not trainable (BN moving statistics): the optimizer skips its blocks
 };
 
 struct Fc {
@@ -30,6 +31,8 @@ struct Fc {
     int w = -1, b = -1;          // indices into params
     float keep = 1.f;
     int splits = 1;
+    int bn_beta = -1, bn_gamma = -1, bn_mm = -1, bn_mv = -1;   // batch_norm after this layer's ReLU (DeepFM.py:159-160)
+    int last = -1;               // last parameter index of this layer (biases, or the BN moving variance)
 };
 
 }  // namespace dctr
@@ -79,6 +82,9 @@ struct dctr_engine {
     float *x_in = nullptr, *dx_in = nullptr, *e_buf = nullptr, *S = nullptr, *yw = nullptr, *yv = nullptr;
     float *yd = nullptr, *y = nullptr, *prob = nullptr, *dy = nullptr;
     std::vector<float*> h, dh;
+    bool bn = false;
+    std::vector<float*> hbn, bn_stats;   // batch_norm: normalised (+dropout) layer outputs, batch mean / invstd per layer
+    float* bn_scratch = nullptr;
     float *xs = nullptr, *xlw = nullptr, *dxL = nullptr, *cross_scratch = nullptr;
     float* e = nullptr;           // alias: where the scaled embeddings live
     int e_ld = 0;

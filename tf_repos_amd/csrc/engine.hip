@@ -95,7 +95,12 @@ int build(dctr_engine* E) {
     const bool no_mlp = afm || c.model == DCTR_MODEL_WIDE;
     DCTR_REQUIRE(no_mlp || (c.n_deep_layers >= 1 && c.n_deep_layers <= DCTR_MAX_LAYERS), "1..%d deep layers supported", DCTR_MAX_LAYERS);
     DCTR_REQUIRE(c.shard_world >= 1 && c.shard_rank >= 0 && c.shard_rank < c.shard_world, "bad shard rank/world");
-    if (c.batch_norm) { set_error("batch_norm=True is not implemented in this engine yet"); return DCTR_ERR_UNSUPPORTED; }
+    E->bn = c.batch_norm != 0;
+    if (E->bn) {
+        DCTR_REQUIRE(c.model != DCTR_MODEL_AFM && c.model < DCTR_MODEL_WIDE, "batch_norm is implemented for the MLP-family models");
+        DCTR_REQUIRE(c.shard_world == 1, "batch_norm with row-sharded tables would need synchronised statistics: not implemented");
+        DCTR_REQUIRE(c.batch_norm_decay >= 0.f && c.batch_norm_decay <= 1.f, "batch_norm_decay must be in [0,1]");
+    }
     for (int i = 0; i < (afm ? 2 : (no_mlp ? 0 : c.n_deep_layers)); ++i)
         DCTR_REQUIRE(c.keep_prob[i] > 0.f && c.keep_prob[i] <= 1.f, "dropout keep_prob[%d]=%f must be in (0,1]", i, c.keep_prob[i]);
     E->F = c.field_size; E->K = c.embedding_size; E->D = E->F * E->K; E->P = E->F * (E->F - 1) / 2; E->MB = c.max_batch;
@@ -133,6 +138,15 @@ int build(dctr_engine* E) {
         fc.w = add_param(E, nm, {fc.in, fc.out}, false, fc.splits, 0.f);
         snprintf(nm, sizeof(nm), "mlp%d/biases", i);
         fc.b = add_param(E, nm, {fc.out}, false, fc.splits, 0.f);
+        fc.last = fc.b;
+        if (E->bn) {        // variable names of contrib.layers.batch_norm under scope bn_%d (DeepFM.py:160,231-235)
+            snprintf(nm, sizeof(nm), "bn_%d/beta", i);            fc.bn_beta = add_param(E, nm, {fc.out}, false, 1, 0.f);
+            snprintf(nm, sizeof(nm), "bn_%d/gamma", i);           fc.bn_gamma = add_param(E, nm, {fc.out}, false, 1, 0.f);
+            snprintf(nm, sizeof(nm), "bn_%d/moving_mean", i);     fc.bn_mm = add_param(E, nm, {fc.out}, false, 1, 0.f);
+            snprintf(nm, sizeof(nm), "bn_%d/moving_variance", i); fc.bn_mv = add_param(E, nm, {fc.out}, false, 1, 0.f);
+            E->params[fc.bn_mm].frozen = E->params[fc.bn_mv].frozen = true;
+            fc.last = fc.bn_mv;
+        }
         E->mlp.push_back(fc);
         d = fc.out;
     }
@@ -186,7 +200,7 @@ int build(dctr_engine* E) {
             OptBlockMeta& m = hm[(size_t)(p.arena_off / OPT_BLOCK + j)];
             m.part_off = p.part_off + j * OPT_BLOCK;
             m.part_stride = p.padded;
-            m.n_part = p.n_part;
+            m.n_part = p.frozen ? -1 : p.n_part;        // n_part < 0: the optimizer leaves the block alone
             m.l2 = p.l2;
         }
     }
@@ -194,7 +208,7 @@ int build(dctr_engine* E) {
     DCTR_HIP_CHECK(hipMemcpy(E->meta, hm.data(), hm.size() * sizeof(OptBlockMeta), hipMemcpyHostToDevice));
     // second metadata table: gradients already reduced into the flat arena (after the all-reduce of the sharded path)
     std::vector<OptBlockMeta> hf(hm);
-    for (size_t j = 0; j < hf.size(); ++j) { hf[j].part_off = (int64_t)j * OPT_BLOCK; hf[j].part_stride = 0; hf[j].n_part = 1; }
+    for (size_t j = 0; j < hf.size(); ++j) { hf[j].part_off = (int64_t)j * OPT_BLOCK; hf[j].part_stride = 0; hf[j].n_part = hf[j].n_part < 0 ? -1 : 1; }
     DCTR_TRY(dmalloc(&E->meta_flat, hf.size(), false));
     DCTR_HIP_CHECK(hipMemcpy(E->meta_flat, hf.data(), hf.size() * sizeof(OptBlockMeta), hipMemcpyHostToDevice));
     {
@@ -288,6 +302,17 @@ int build(dctr_engine* E) {
         DCTR_TRY(dmalloc(&a, (size_t)MB * fc.out));
         DCTR_TRY(dmalloc(&g, (size_t)MB * fc.out));
         E->h.push_back(a); E->dh.push_back(g);
+        if (E->bn) {
+            float *z = nullptr, *sx = nullptr;
+            DCTR_TRY(dmalloc(&z, (size_t)MB * fc.out));
+            DCTR_TRY(dmalloc(&sx, (size_t)2 * fc.out));
+            E->hbn.push_back(z); E->bn_stats.push_back(sx);
+        }
+    }
+    if (E->bn) {
+        int hmax = 0;
+        for (auto& fc : E->mlp) hmax = std::max(hmax, fc.out);
+        DCTR_TRY(dmalloc(&E->bn_scratch, (size_t)bn_scratch_floats(hmax)));
     }
     if (c.model == DCTR_MODEL_DCN) {
         const int L = c.cross_layers;
@@ -330,9 +355,16 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st) {
     int ldx = E->Din_ld;
     for (size_t i = 0; i < E->mlp.size(); ++i) {
         const Fc& fc = E->mlp[i];
-        DCTR_TRY(fc_fwd(x, ldx, E->pp(fc.w), E->pp(fc.b), E->h[i], fc.out, B, fc.in, fc.out, 1, train ? fc.keep : 1.f, seedp,
-                        0x1000ull + i, st));
+        // relu(x W + b) [-> batch_norm] -> dropout (DeepFM.py:156-162): without BN the dropout rides in the GEMM epilogue
+        DCTR_TRY(fc_fwd(x, ldx, E->pp(fc.w), E->pp(fc.b), E->h[i], fc.out, B, fc.in, fc.out, 1, (train && !E->bn) ? fc.keep : 1.f,
+                        seedp, 0x1000ull + i, st));
         x = E->h[i]; ldx = fc.out;
+        if (E->bn) {
+            DCTR_TRY(bn_forward(E->h[i], fc.out, B, fc.out, train, 1e-3f, c.batch_norm_decay, E->pp(fc.bn_gamma), E->pp(fc.bn_beta),
+                                E->pp(fc.bn_mm), E->pp(fc.bn_mv), fc.keep, seedp, 0x1000ull + i, E->bn_stats[i], E->bn_scratch,
+                                E->hbn[i], fc.out, st));
+            x = E->hbn[i];
+        }
     }
     return DCTR_OK;     // the [H -> 1] output layer is fused into the head kernel (head())
 }
@@ -365,10 +397,11 @@ int head(dctr_engine* E, int B, int global_batch, bool with_labels, hipStream_t 
         x1 = E->x_in; ld1 = E->Din_ld; n1 = E->K;
     } else if (c.model == DCTR_MODEL_DCN) {
         x1 = E->xs + (size_t)c.cross_layers * B * E->D; ld1 = E->D; n1 = E->D;      // xs is laid out [L+1, B, D] for the current B
-        x2 = E->h.back(); ld2 = E->mlp.back().out; n2 = ld2; w2 = wout + E->D;
+        x2 = E->bn ? E->hbn.back() : E->h.back(); ld2 = E->mlp.back().out; n2 = ld2; w2 = wout + E->D;
     } else {
-        x1 = E->h.back(); ld1 = E->mlp.back().out; n1 = ld1;
+        x1 = E->bn ? E->hbn.back() : E->h.back(); ld1 = E->mlp.back().out; n1 = ld1;
     }
+    const int mask_last = E->bn ? 0 : 1;        // with BN the layer's ReLU/dropout backward happens in bn_backward
     if (loss_shards == nullptr) loss_shards = E->scalars;
     E->head_did_out_bwd = false;
 
@@ -379,11 +412,11 @@ int head(dctr_engine* E, int B, int global_batch, bool with_labels, hipStream_t 
         const float keep_last = E->mlp.back().keep;
         int rc;
         if (c.model == DCTR_MODEL_DCN)
-            rc = head_out_bwd(x1, ld1, wout, n1, 0, E->dxL, E->D, x2, ld2, w2, n2, 1, E->dh.back(), ld2, E->pp(E->p_out_b), bias, yw, yv,
+            rc = head_out_bwd(x1, ld1, wout, n1, 0, E->dxL, E->D, x2, ld2, w2, n2, mask_last, E->dh.back(), ld2, E->pp(E->p_out_b), bias, yw, yv,
                               E->labels, B, 1.0f / (float)global_batch, keep_last, pw.n_part, E->yd, E->y, E->prob, E->dy, loss_shards,
                               E->part(E->p_out_w), pw.padded, E->part(E->p_out_b), pb.padded, st);
         else
-            rc = head_out_bwd(x1, ld1, wout, n1, 1, E->dh.back(), ld1, nullptr, 0, nullptr, 0, 0, nullptr, 0, E->pp(E->p_out_b), bias, yw, yv,
+            rc = head_out_bwd(x1, ld1, wout, n1, mask_last, E->dh.back(), ld1, nullptr, 0, nullptr, 0, 0, nullptr, 0, E->pp(E->p_out_b), bias, yw, yv,
                               E->labels, B, 1.0f / (float)global_batch, keep_last, pw.n_part, E->yd, E->y, E->prob, E->dy, loss_shards,
                               E->part(E->p_out_w), pw.padded, E->part(E->p_out_b), pb.padded, st);
         if (rc == DCTR_OK) { E->head_did_out_bwd = true; return DCTR_OK; }
@@ -426,29 +459,33 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
     } else if (c.model == DCTR_MODEL_DCN) {
         const float* xL = E->xs + (size_t)c.cross_layers * B * D;
         DCTR_TRY(out_layer_bwd(xL, D, E->dy, wout, B, D, pw.n_part, 0, 1.f, E->dxL, D, E->part(E->p_out_w), pw.padded, nullptr, 0, st));
-        DCTR_TRY(out_layer_bwd(E->h.back(), H, E->dy, wout + D, B, H, pw.n_part, 1, keep_last, E->dh.back(), H,
+        DCTR_TRY(out_layer_bwd(E->bn ? E->hbn.back() : E->h.back(), H, E->dy, wout + D, B, H, pw.n_part, E->bn ? 0 : 1, keep_last, E->dh.back(), H,
                                E->part(E->p_out_w) + D, pw.padded, E->part(E->p_out_b), pb.padded, st));
     } else {
-        DCTR_TRY(out_layer_bwd(E->h.back(), H, E->dy, wout, B, H, pw.n_part, 1, keep_last, E->dh.back(), H, E->part(E->p_out_w),
+        DCTR_TRY(out_layer_bwd(E->bn ? E->hbn.back() : E->h.back(), H, E->dy, wout, B, H, pw.n_part, E->bn ? 0 : 1, keep_last, E->dh.back(), H, E->part(E->p_out_w),
                                pw.padded, E->part(E->p_out_b), pb.padded, st));
     }
+    const uint64_t* bn_seedp = &E->state->seed_t;
     for (int i = nl - 1; i >= 0; --i) {
         const Fc& fc = E->mlp[i];
-        const float* x = i > 0 ? E->h[i - 1] : E->x_in;
+        const float* x = i > 0 ? (E->bn ? E->hbn[i - 1] : E->h[i - 1]) : E->x_in;
         const int ldx = i > 0 ? E->mlp[i - 1].out : E->Din_ld;
         const Param& w = E->params[fc.w];
         const Param& b = E->params[fc.b];
+        if (E->bn)      // dh[i] holds dL/d(layer output): dropout mask, BN backward, ReLU mask -> dL/d(pre-activation), in place
+            DCTR_TRY(bn_backward(E->dh[i], fc.out, E->h[i], fc.out, B, fc.out, E->bn_stats[i], E->pp(fc.bn_gamma), fc.keep, bn_seedp,
+                                 0x1000ull + i, E->bn_scratch, E->part(fc.bn_beta), E->part(fc.bn_gamma), E->dh[i], fc.out, st));
         DCTR_TRY(fork(E, st, sw));      // dh[i] is complete on st
         DCTR_TRY(fc_bwd_weights_partials(x, ldx, E->dh[i], fc.out, E->part(fc.w), w.padded, E->part(fc.b), b.padded, B, fc.in,
                                          fc.out, fc.splits, sw));
         if (i > 0)
-            DCTR_TRY(fc_bwd_data(E->dh[i], fc.out, E->pp(fc.w), E->dh[i - 1], E->mlp[i - 1].out, B, fc.in, fc.out, E->h[i - 1],
-                                 E->mlp[i - 1].out, E->mlp[i - 1].keep, st));
+            DCTR_TRY(fc_bwd_data(E->dh[i], fc.out, E->pp(fc.w), E->dh[i - 1], E->mlp[i - 1].out, B, fc.in, fc.out,
+                                 E->bn ? nullptr : E->h[i - 1], E->mlp[i - 1].out, E->bn ? 1.f : E->mlp[i - 1].keep, st));
         else
             DCTR_TRY(fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w), E->dx_in, E->Din_ld, B, fc.in, fc.out, nullptr, 0, 1.f, st));
         if (fused_opt) {
             DCTR_TRY(fork(E, st, sw));          // dgrad_i (reader of the old W_i) is complete
-            DCTR_TRY(opt_dense_range(E, fc.w, fc.b, sw));
+            DCTR_TRY(opt_dense_range(E, fc.w, fc.last, sw));
         }
     }
     const uint64_t* seedp = &E->state->seed_t;
@@ -555,7 +592,7 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
             const Param& p = E->params[i];
             if (p.is_table) continue;
             bool is_mlp = false;
-            for (auto& fc : E->mlp) is_mlp = is_mlp || i == fc.w || i == fc.b;
+            for (auto& fc : E->mlp) is_mlp = is_mlp || (i >= fc.w && i <= fc.last);
             if (is_mlp) continue;
             if (out_done && (i == E->p_out_w || i == E->p_out_b || i == E->p_bias)) continue;
             DCTR_TRY(opt_dense_range(E, i, i, sw));
@@ -668,6 +705,9 @@ int dctr_destroy(dctr_handle E) {
     if (E->eval_scalars) hipFree(E->eval_scalars);
     if (E->ones) hipFree(E->ones);
     if (E->group_alt) group_destroy(E->group_alt);
+    for (float* p : E->hbn) hipFree(p);
+    for (float* p : E->bn_stats) hipFree(p);
+    if (E->bn_scratch) hipFree(E->bn_scratch);
     group_destroy(E->group);
     afm_free(E);
     for (auto& ev : E->events) if (ev) hipEventDestroy(ev);
@@ -918,7 +958,7 @@ int dctr_table_apply_packed(dctr_handle E, int which, int n, const float* d_grad
 int sharded_forward_backward(dctr_engine* E, const float* d_rows, int n_rows, const int32_t* d_idx, const float* d_vals,
                              const float* d_labels, int B, int global_batch, bool train, bool join_wgrad, hipStream_t st) {
     DCTR_REQUIRE(E && d_rows && d_idx && d_vals, "null argument");
-    DCTR_REQUIRE(!E->wnd, "canned-estimator models are not row-sharded");
+    DCTR_REQUIRE(!E->wnd && !E->bn, "canned-estimator models / batch_norm are not row-sharded");
     DCTR_REQUIRE(B > 0 && B <= E->MB && global_batch >= B, "bad batch sizes B=%d global=%d", B, global_batch);
     DCTR_REQUIRE(!train || d_labels, "labels required for training");
     hipStream_t sw = E->s_wgrad;

@@ -114,6 +114,15 @@ int wnd_dense_fwd(const float* dense, int nd, const float* wd, int B, float* x_i
 int opt_lin_touched(int kind, const Hyper* hdev, const Hyper& hval, float* lin, float* l0, float* l1, const int32_t* uniq,
                     const int32_t* counters, int64_t max_entries, const float* glin, hipStream_t st);
 
+// ---- bn.hip: contrib.layers.batch_norm after each hidden layer's ReLU, then dropout (DeepFM.py:159-162, 231-235)
+int bn_forward(const float* y, int ldy, int B, int H, bool train, float eps, float decay, const float* gamma, const float* beta,
+               float* mm, float* mv, float keep, const uint64_t* seed_ptr, uint64_t salt, float* stats, float* scratch, float* out,
+               int ldo, hipStream_t st);
+int bn_backward(const float* dout, int ldd, const float* y, int ldy, int B, int H, const float* stats, const float* gamma, float keep,
+                const uint64_t* seed_ptr, uint64_t salt, float* scratch, float* dbeta, float* dgamma, float* dpre, int ldp,
+                hipStream_t st);
+int bn_scratch_floats(int H);
+
 // ---- interact.hip
 int pnn_inner_fwd(const float* e, int e_ld, int B, int F, int K, float* ip, int ip_ld, hipStream_t st);
 int pnn_inner_bwd(const float* e, int e_ld, const float* dip, int dip_ld, int B, int F, int K, float* dE, int de_ld,

@@ -45,8 +45,7 @@ def lower(loss: Optional[G.Tensor], train_op: Optional[G.Tensor], predictions: D
     by_op: Dict[str, List[G.Tensor]] = {}
     for n in nodes:
         by_op.setdefault(n.op, []).append(n)
-    if by_op.get("batch_norm"):
-        raise _unsupported("batch_norm=True (contrib.layers.batch_norm) is not implemented in the engine yet")
+    bn_ops = by_op.get("batch_norm", [])
 
     # ---- tables --------------------------------------------------------------------------------------------------
     lookups = by_op.get("embedding_lookup", [])
@@ -116,6 +115,8 @@ def lower(loss: Optional[G.Tensor], train_op: Optional[G.Tensor], predictions: D
 
     # ---- dense stack -----------------------------------------------------------------------------------------------
     if model == "afm":
+        if bn_ops:
+            raise _unsupported("batch_norm=True in the AFM graph is not implemented in the engine")
         att = [int(f.attrs["num_outputs"]) for f in hidden]
         kw["attention_layers"] = tuple(att)
         kw["deep_layers"] = (1,)
@@ -129,6 +130,22 @@ def lower(loss: Optional[G.Tensor], train_op: Optional[G.Tensor], predictions: D
         kw["deep_layers"] = tuple(int(f.attrs["num_outputs"]) for f in hidden)
         for i, f in enumerate(hidden):
             name_map["mlp%d/weights" % i], name_map["mlp%d/biases" % i] = f.inputs[1].var_name, f.inputs[2].var_name
+        if bn_ops:
+            # batch_norm_layer(x_deep, train_phase, scope_bn='bn_%d') after every hidden layer (DeepFM.py:159-160, 231-235)
+            decays = set()
+            for i, f in enumerate(hidden):
+                mine = [b for b in bn_ops if _through(b.inputs[0]) is f]
+                if len(mine) != 1:
+                    raise _unsupported("expected one batch_norm on the output of hidden layer %d" % i)
+                b = mine[0]
+                if not (b.attrs["center"] and b.attrs["scale"]) or abs(b.attrs["epsilon"] - 1e-3) > 1e-12:
+                    raise _unsupported("batch_norm must use center=True, scale=True, epsilon=0.001 (DeepFM.py:232-233)")
+                decays.add(float(b.attrs["decay"]))
+                for nm, v in zip(("beta", "gamma", "moving_mean", "moving_variance"), b.inputs[1:]):
+                    name_map["bn_%d/%s" % (i, nm)] = v.var_name
+            if len(decays) != 1:
+                raise _unsupported("batch_norm layers with different decays")
+            kw["batch_norm"], kw["batch_norm_decay"] = True, decays.pop()
         if len(outs) != 1 or int(outs[0].attrs["num_outputs"]) != 1:
             raise _unsupported("expected exactly one linear output layer of width 1")
         oname = "out_layer" if model == "dcn" else "deep_out"
@@ -140,6 +157,8 @@ def lower(loss: Optional[G.Tensor], train_op: Optional[G.Tensor], predictions: D
     att_keep: List[float] = []
     for d in by_op.get("dropout", []):
         src = _through(d.inputs[0])
+        if src.op == "batch_norm":
+            src = _through(src.inputs[0])
         if src.op == "fully_connected" and src in hidden and model != "afm":
             keep[hidden.index(src)] = d.attrs["keep_prob"]
         elif model == "nfm":
