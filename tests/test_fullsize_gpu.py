@@ -86,7 +86,9 @@ def test_c2_checksums_and_grouping(dev):
     order = np.argsort(uniq)
     ref_rows = np.zeros((len(uniq_np), K), dtype=np.float64)
     np.add.at(ref_rows, np.searchsorted(uniq_np, ids.reshape(-1)), (dE.reshape(B, F, K) * vals[:, :, None]).reshape(-1, K).astype(np.float64))
-    assert np.abs(gemb[:U.value].cpu().numpy()[order] - ref_rows).max() <= 5e-5      # hot ids sum 4096 terms in f32
+    # hot ids sum 4096 N(0,1) terms in f32 (|row sum| ~ 60, summation order varies with the atomics): 3e-6 relative to the
+    # sum of magnitudes of the terms
+    assert np.abs(gemb[:U.value].cpu().numpy()[order] - ref_rows).max() <= 3e-4
     capi.check(lib.dctr_group_destroy(g))
 
 

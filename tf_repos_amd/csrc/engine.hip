@@ -183,7 +183,11 @@ int build(dctr_engine* E) {
     if (E->p_bias >= 0 && E->p_out_b >= 0) { E->params[E->p_bias].part_off = E->params[E->p_out_b].part_off; E->params[E->p_bias].n_part = E->params[E->p_out_b].n_part; }
     E->arena_n = off; E->parts_n = poff;
     E->n_blocks = (int)(off / OPT_BLOCK);
-    DCTR_TRY(dmalloc(&E->theta, (size_t)off));
+    // readable slack behind the arena: the MLP GEMMs run their edge tiles unchecked (gemm.hip `over`) and may read up to
+    // GEMM_SLACK_ROWS rows past a weight matrix -- normally the next parameters, past the last one this padding
+    size_t wslack = 0;
+    for (auto& fc : E->mlp) wslack = std::max(wslack, (size_t)GEMM_SLACK_ROWS * (size_t)std::max(fc.out, fc.in));
+    DCTR_TRY(dmalloc(&E->theta, (size_t)off + wslack));
     DCTR_TRY(dmalloc(&E->as0, (size_t)off));
     DCTR_TRY(dmalloc(&E->as1, (size_t)off));
     DCTR_TRY(dmalloc(&E->gflat, (size_t)off));
@@ -277,8 +281,8 @@ int build(dctr_engine* E) {
         DCTR_TRY(dmalloc(&E->slot_labels[k], (size_t)MB));
     }
     E->ids = E->slot_ids[0]; E->vals = E->slot_vals[0]; E->labels = E->slot_labels[0];
-    DCTR_TRY(dmalloc(&E->x_in, (size_t)MB * E->Din_ld));
-    DCTR_TRY(dmalloc(&E->dx_in, (size_t)MB * E->Din_ld));
+    DCTR_TRY(dmalloc(&E->x_in, (size_t)(MB + GEMM_SLACK_ROWS) * E->Din_ld));      // (+ slack rows: see gemm.hip `over`)
+    DCTR_TRY(dmalloc(&E->dx_in, (size_t)(MB + GEMM_SLACK_ROWS) * E->Din_ld));
     if (c.model == DCTR_MODEL_NFM || afm) {
         DCTR_TRY(dmalloc(&E->e_buf, (size_t)MB * D));
         E->e = E->e_buf; E->e_ld = D;
@@ -299,12 +303,12 @@ int build(dctr_engine* E) {
     DCTR_TRY(dmalloc(&E->dy, (size_t)MB));
     for (auto& fc : E->mlp) {
         float *a = nullptr, *g = nullptr;
-        DCTR_TRY(dmalloc(&a, (size_t)MB * fc.out));
-        DCTR_TRY(dmalloc(&g, (size_t)MB * fc.out));
+        DCTR_TRY(dmalloc(&a, (size_t)(MB + GEMM_SLACK_ROWS) * fc.out));
+        DCTR_TRY(dmalloc(&g, (size_t)(MB + GEMM_SLACK_ROWS) * fc.out));
         E->h.push_back(a); E->dh.push_back(g);
         if (E->bn) {
             float *z = nullptr, *sx = nullptr;
-            DCTR_TRY(dmalloc(&z, (size_t)MB * fc.out));
+            DCTR_TRY(dmalloc(&z, (size_t)(MB + GEMM_SLACK_ROWS) * fc.out));
             DCTR_TRY(dmalloc(&sx, (size_t)2 * fc.out));
             E->hbn.push_back(z); E->bn_stats.push_back(sx);
         }
@@ -357,7 +361,7 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st) {
         const Fc& fc = E->mlp[i];
         // relu(x W + b) [-> batch_norm] -> dropout (DeepFM.py:156-162): without BN the dropout rides in the GEMM epilogue
         DCTR_TRY(fc_fwd(x, ldx, E->pp(fc.w), E->pp(fc.b), E->h[i], fc.out, B, fc.in, fc.out, 1, (train && !E->bn) ? fc.keep : 1.f,
-                        seedp, 0x1000ull + i, st));
+                        seedp, 0x1000ull + i, st, 1));
         x = E->h[i]; ldx = fc.out;
         if (E->bn) {
             DCTR_TRY(bn_forward(E->h[i], fc.out, B, fc.out, train, 1e-3f, c.batch_norm_decay, E->pp(fc.bn_gamma), E->pp(fc.bn_beta),
@@ -477,12 +481,12 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
                                  0x1000ull + i, E->bn_scratch, E->part(fc.bn_beta), E->part(fc.bn_gamma), E->dh[i], fc.out, st));
         DCTR_TRY(fork(E, st, sw));      // dh[i] is complete on st
         DCTR_TRY(fc_bwd_weights_partials(x, ldx, E->dh[i], fc.out, E->part(fc.w), w.padded, E->part(fc.b), b.padded, B, fc.in,
-                                         fc.out, fc.splits, sw));
+                                         fc.out, fc.splits, sw, 1));
         if (i > 0)
             DCTR_TRY(fc_bwd_data(E->dh[i], fc.out, E->pp(fc.w), E->dh[i - 1], E->mlp[i - 1].out, B, fc.in, fc.out,
-                                 E->bn ? nullptr : E->h[i - 1], E->mlp[i - 1].out, E->bn ? 1.f : E->mlp[i - 1].keep, st));
+                                 E->bn ? nullptr : E->h[i - 1], E->mlp[i - 1].out, E->bn ? 1.f : E->mlp[i - 1].keep, st, 1));
         else
-            DCTR_TRY(fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w), E->dx_in, E->Din_ld, B, fc.in, fc.out, nullptr, 0, 1.f, st));
+            DCTR_TRY(fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w), E->dx_in, E->Din_ld, B, fc.in, fc.out, nullptr, 0, 1.f, st, 1));
         if (fused_opt) {
             DCTR_TRY(fork(E, st, sw));          // dgrad_i (reader of the old W_i) is complete
             DCTR_TRY(opt_dense_range(E, fc.w, fc.last, sw));
@@ -1072,11 +1076,11 @@ int dctr_time_kernel(dctr_handle E, const char* kernel, int iters, float* h_ms_p
             const Fc& fc = E->mlp[0];
             if (s == "mlp0_fwd")
                 return fc_fwd(E->x_in, E->Din_ld, E->pp(fc.w), E->pp(fc.b), E->h[0], fc.out, B, fc.in, fc.out, 1, fc.keep,
-                              &E->state->seed_t, 0x1000ull, cs);
+                              &E->state->seed_t, 0x1000ull, cs, 1);
             if (s == "mlp0_dgrad")
-                return fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w), E->dx_in, E->Din_ld, B, fc.in, fc.out, nullptr, 0, 1.f, cs);
+                return fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w), E->dx_in, E->Din_ld, B, fc.in, fc.out, nullptr, 0, 1.f, cs, 1);
             return fc_bwd_weights_partials(E->x_in, E->Din_ld, E->dh[0], fc.out, E->part(fc.w), E->params[fc.w].padded,
-                                           E->part(fc.b), E->params[fc.b].padded, B, fc.in, fc.out, fc.splits, cs);
+                                           E->part(fc.b), E->params[fc.b].padded, B, fc.in, fc.out, fc.splits, cs, 1);
         }
         if (s == "train_step") return record_train(E, B, cs);
         set_error("unknown stage '%s'", kernel);

@@ -70,11 +70,13 @@ int pack_unique_grads(const Group* g, const float* glin, const int32_t* upos, fl
 
 // ---- K6 (gemm.hip)
 int fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N,
-           int relu, float keep, const uint64_t* seed_ptr, uint64_t seed, hipStream_t st);
+           int relu, float keep, const uint64_t* seed_ptr, uint64_t seed, hipStream_t st, int over = 0);
 int fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int K, int N,
-                const float* act, int ldact, float keep_prev, hipStream_t st);
+                const float* act, int ldact, float keep_prev, hipStream_t st, int over = 0);
 int fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int lddy, float* dw_part, int64_t dw_stride,
-                            float* db_part, int64_t db_stride, int M, int K, int N, int splits, hipStream_t st);
+                            float* db_part, int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, int over = 0);
+// `over` = 1: both operands are followed by GEMM_SLACK_ROWS rows (64 * ld floats) of readable memory, edge tiles may over-read
+constexpr int GEMM_SLACK_ROWS = 64;
 int sum_partials(const float* part, int64_t stride, int splits, int64_t n, float* out, hipStream_t st);
 int choose_wgrad_splits(int M, int K, int N);
 
