@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) void opt_table_kernel(const Hyper* __restrict_
                                                        const int32_t* __restrict__ slot, const int32_t* __restrict__ uniq,
                                                        const int32_t* __restrict__ counters, const float4* __restrict__ gemb,
                                                        const float* __restrict__ glin, float l2, float* __restrict__ sumsq_emb,
-                                                       float* __restrict__ sumsq_lin, int nt) {
+                                                       float* __restrict__ sumsq_lin, int nt, int untouched_only) {
     // KQ lanes per row (one float4 each); lane kq == 0 also steps the row's linear weight (same slot word, one launch)
     const Hyper h = load_hyper(hdev, hval);
     const int64_t n_items = DENSE ? rows : (int64_t)counters[0];
@@ -575,6 +575,7 @@ __global__ __launch_bounds__(256) void opt_table_kernel(const Hyper* __restrict_
         int64_t r;
         int u;
         if (DENSE) { r = item; u = slot[r] - 1; } else { u = (int)item; r = uniq[u]; }
+        if (DENSE && untouched_only && u >= 0) continue;    // the batch's rows are stepped later, once their gradients exist
         const size_t i4 = (size_t)r * KQ + kq;
         float4 th, a, b = make_float4(0.f, 0.f, 0.f, 0.f);
         if (nt) {
@@ -627,12 +628,59 @@ __global__ __launch_bounds__(256) void opt_table_kernel(const Hyper* __restrict_
     }
 }
 
+// Background pass over the rows the batch does NOT touch (gradient = l2*theta), meant to run UNDER the MLP GEMMs: a small grid
+// (a wave or two per SIMD, so the GEMM blocks still find their wave slots) with UNR independent row pieces in flight per lane
+// to keep the HBM pipe full from few waves.
+template <int KIND, int KQ, int UNR>
+__global__ __launch_bounds__(256) void opt_table_untouched_kernel(const Hyper* __restrict__ hdev, Hyper hval, int64_t rows,
+                                                                 float4* __restrict__ emb, float4* __restrict__ s0,
+                                                                 float4* __restrict__ s1, const int32_t* __restrict__ slot, float l2,
+                                                                 float* __restrict__ sumsq_emb) {
+    const Hyper h = load_hyper(hdev, hval);
+    constexpr bool TWO = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL);
+    const int64_t n = rows * KQ;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float sq = 0.f;
+    for (int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t0 < n; t0 += stride * UNR) {
+        float4 th[UNR], a[UNR], b[UNR];
+        bool live[UNR];
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            const int64_t t = t0 + j * stride;
+            live[j] = t < n && slot[t / KQ] == 0;
+            if (live[j]) {
+                th[j] = emb[t]; a[j] = s0[t];
+                b[j] = TWO ? s1[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            if (!live[j]) continue;
+            const int64_t t = t0 + j * stride;
+            sq += th[j].x * th[j].x + th[j].y * th[j].y + th[j].z * th[j].z + th[j].w * th[j].w;
+            opt_update(KIND, h, th[j].x, a[j].x, b[j].x, l2 * th[j].x);
+            opt_update(KIND, h, th[j].y, a[j].y, b[j].y, l2 * th[j].y);
+            opt_update(KIND, h, th[j].z, a[j].z, b[j].z, l2 * th[j].z);
+            opt_update(KIND, h, th[j].w, a[j].w, b[j].w, l2 * th[j].w);
+            emb[t] = th[j]; s0[t] = a[j];
+            if (TWO) s1[t] = b[j];
+        }
+    }
+    if (sumsq_emb != nullptr) {
+        __shared__ float red[4];
+        sq = wave_sum(sq);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(sumsq_emb + (blockIdx.x & (SUMSQ_SHARDS - 1)), red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
 // dense-exact step of the [rows] linear table, 4 rows per thread (16-byte accesses on all seven streams)
 template <int KIND>
 __global__ __launch_bounds__(256) void opt_lin_dense_kernel(const Hyper* __restrict__ hdev, Hyper hval, int64_t rows,
                                                            float* __restrict__ lin, float* __restrict__ l0, float* __restrict__ l1,
                                                            const int32_t* __restrict__ slot, const float* __restrict__ glin, float l2,
-                                                           float* __restrict__ sumsq) {
+                                                           float* __restrict__ sumsq, int untouched_only) {
     const Hyper h = load_hyper(hdev, hval);
     const int64_t n4 = rows / 4;
     float sq = 0.f;
@@ -641,16 +689,24 @@ __global__ __launch_bounds__(256) void opt_lin_dense_kernel(const Hyper* __restr
         float4 a = reinterpret_cast<float4*>(l0)[i];
         float4 b = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) ? reinterpret_cast<float4*>(l1)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         const int4 sl = reinterpret_cast<const int4*>(slot)[i];
-        sq += th.x * th.x + th.y * th.y + th.z * th.z + th.w * th.w;
-        float4 g = make_float4(l2 * th.x, l2 * th.y, l2 * th.z, l2 * th.w);
-        if (sl.x) g.x += glin[sl.x - 1];
-        if (sl.y) g.y += glin[sl.y - 1];
-        if (sl.z) g.z += glin[sl.z - 1];
-        if (sl.w) g.w += glin[sl.w - 1];
-        opt_update(KIND, h, th.x, a.x, b.x, g.x);
-        opt_update(KIND, h, th.y, a.y, b.y, g.y);
-        opt_update(KIND, h, th.z, a.z, b.z, g.z);
-        opt_update(KIND, h, th.w, a.w, b.w, g.w);
+        if (untouched_only) {
+            // rows of the batch keep their values (written back unchanged: the touched pass is ordered after this one)
+            if (!sl.x) { sq += th.x * th.x; opt_update(KIND, h, th.x, a.x, b.x, l2 * th.x); }
+            if (!sl.y) { sq += th.y * th.y; opt_update(KIND, h, th.y, a.y, b.y, l2 * th.y); }
+            if (!sl.z) { sq += th.z * th.z; opt_update(KIND, h, th.z, a.z, b.z, l2 * th.z); }
+            if (!sl.w) { sq += th.w * th.w; opt_update(KIND, h, th.w, a.w, b.w, l2 * th.w); }
+        } else {
+            sq += th.x * th.x + th.y * th.y + th.z * th.z + th.w * th.w;
+            float4 g = make_float4(l2 * th.x, l2 * th.y, l2 * th.z, l2 * th.w);
+            if (sl.x) g.x += glin[sl.x - 1];
+            if (sl.y) g.y += glin[sl.y - 1];
+            if (sl.z) g.z += glin[sl.z - 1];
+            if (sl.w) g.w += glin[sl.w - 1];
+            opt_update(KIND, h, th.x, a.x, b.x, g.x);
+            opt_update(KIND, h, th.y, a.y, b.y, g.y);
+            opt_update(KIND, h, th.z, a.z, b.z, g.z);
+            opt_update(KIND, h, th.w, a.w, b.w, g.w);
+        }
         reinterpret_cast<float4*>(lin)[i] = th;
         reinterpret_cast<float4*>(l0)[i] = a;
         if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) reinterpret_cast<float4*>(l1)[i] = b;
@@ -658,14 +714,16 @@ __global__ __launch_bounds__(256) void opt_lin_dense_kernel(const Hyper* __restr
     // the rows % 4 tail
     const int64_t r = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r < rows) {
-        float th = lin[r], a = l0[r], b = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) ? l1[r] : 0.f;
-        sq += th * th;
-        float g = l2 * th;
         const int u = slot[r] - 1;
-        if (u >= 0) g += glin[u];
-        opt_update(KIND, h, th, a, b, g);
-        lin[r] = th; l0[r] = a;
-        if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) l1[r] = b;
+        if (!(untouched_only && u >= 0)) {
+            float th = lin[r], a = l0[r], b = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) ? l1[r] : 0.f;
+            sq += th * th;
+            float g = l2 * th;
+            if (u >= 0) g += glin[u];
+            opt_update(KIND, h, th, a, b, g);
+            lin[r] = th; l0[r] = a;
+            if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) l1[r] = b;
+        }
     }
     if (sumsq != nullptr) {
         __shared__ float red[4];
@@ -680,7 +738,7 @@ template <int KIND, bool DENSE>
 static int launch_table(const Hyper* hdev, const Hyper& hval, int64_t rows, int K, float* emb, float* e0, float* e1,
                         float* lin, float* l0, float* l1, const int32_t* slot, const int32_t* uniq,
                         const int32_t* counters, int64_t max_entries, const float* gemb, const float* glin, float l2,
-                        float* sumsq_emb, float* sumsq_lin, hipStream_t st, hipStream_t st_lin) {
+                        float* sumsq_emb, float* sumsq_lin, hipStream_t st, hipStream_t st_lin, int untouched_only) {
     const int KQ = K / 4;
     // dense mode: the linear table gets its own vectorised kernel (on st_lin, beside the embedding pass); touched-rows
     // mode keeps it fused (lane kq == 0 of each visited row)
@@ -696,15 +754,37 @@ static int launch_table(const Hyper* hdev, const Hyper& hval, int64_t rows, int 
     float4* a4 = reinterpret_cast<float4*>(e0);
     float4* b4 = reinterpret_cast<float4*>(e1);
     const float4* g4 = reinterpret_cast<const float4*>(gemb);
+    if (DENSE && untouched_only) {
+        static const int bg = getenv("DCTR_OPT_BG_GRID") ? atoi(getenv("DCTR_OPT_BG_GRID")) : 2;     // blocks per CU of the background pass
+        const int g2 = (int)std::min<int64_t>(ceil_div(items * KQ, 256 * 4), 256 * bg);
+        switch (KQ) {
+#define DCTR_U(Q) case Q: opt_table_untouched_kernel<KIND, Q, 4><<<g2, 256, 0, st>>>(hdev, hval, rows, e4, a4, b4, slot, l2, sumsq_emb); break
+            DCTR_U(1); DCTR_U(2); DCTR_U(4); DCTR_U(8); DCTR_U(16); DCTR_U(32); DCTR_U(64);
+#undef DCTR_U
+            default: set_error("opt_table: K=%d unsupported", K); return DCTR_ERR_UNSUPPORTED;
+        }
+        if (lin_f != nullptr) {
+            if (split_lin) {
+                const int gl = (int)std::min<int64_t>(ceil_div(rows / 4 + 1, 256), 256 * bg);
+                opt_lin_dense_kernel<KIND><<<gl, 256, 0, st>>>(hdev, hval, rows, lin_f, l0_f, l1_f, slot, glin, l2, sumsq_lin, 1);
+            } else {
+                // (unaligned linear table: the generic kernel, embedding side disabled, is not available -- fall through)
+                set_error("opt_table: unaligned linear table in the split dense pass");
+                return DCTR_ERR_UNSUPPORTED;
+            }
+        }
+        DCTR_LAUNCH_CHECK();
+        return DCTR_OK;
+    }
     switch (KQ) {
-#define DCTR_T(Q) case Q: opt_table_kernel<KIND, Q, DENSE><<<grid, 256, 0, st>>>(hdev, hval, rows, e4, a4, b4, lin, l0, l1, slot, uniq, counters, g4, glin, l2, sumsq_emb, sumsq_lin, nt); break
+#define DCTR_T(Q) case Q: opt_table_kernel<KIND, Q, DENSE><<<grid, 256, 0, st>>>(hdev, hval, rows, e4, a4, b4, lin, l0, l1, slot, uniq, counters, g4, glin, l2, sumsq_emb, sumsq_lin, nt, untouched_only); break
         DCTR_T(1); DCTR_T(2); DCTR_T(4); DCTR_T(8); DCTR_T(16); DCTR_T(32); DCTR_T(64);
 #undef DCTR_T
         default: set_error("opt_table: K=%d unsupported", K); return DCTR_ERR_UNSUPPORTED;
     }
     if (split_lin) {
         const int gl = (int)std::min<int64_t>(ceil_div(rows / 4 + 1, 256), 2048);
-        opt_lin_dense_kernel<KIND><<<gl, 256, 0, st_lin>>>(hdev, hval, rows, lin_f, l0_f, l1_f, slot, glin, l2, sumsq_lin);
+        opt_lin_dense_kernel<KIND><<<gl, 256, 0, st_lin>>>(hdev, hval, rows, lin_f, l0_f, l1_f, slot, glin, l2, sumsq_lin, untouched_only);
     }
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
@@ -713,15 +793,20 @@ static int launch_table(const Hyper* hdev, const Hyper& hval, int64_t rows, int 
 int opt_table(int kind, const Hyper* hdev, const Hyper& hval, int table_mode, int64_t rows, int K, float* emb, float* e0,
               float* e1, float* lin, float* l0, float* l1, const int32_t* slot, const int32_t* uniq,
               const int32_t* counters, int64_t max_entries, const float* gemb, const float* glin, float l2,
-              float* sumsq_emb, float* sumsq_lin, hipStream_t st, hipStream_t st_lin) {
-    const bool dense = table_mode == DCTR_TABLE_DENSE_EXACT;
+              float* sumsq_emb, float* sumsq_lin, hipStream_t st, hipStream_t st_lin, int pass) {
+    // pass (dense-exact only): OPT_PASS_ALL = every row in one sweep; OPT_PASS_UNTOUCHED = rows the batch does not touch
+    // (gradient = l2*theta: needs the grouping, not the backward pass); OPT_PASS_TOUCHED = the batch's distinct rows (the
+    // touched-rows kernel computes the same l2*theta + segment sum).  UNTOUCHED then TOUCHED == ALL, row for row.
+    const bool dense = table_mode == DCTR_TABLE_DENSE_EXACT && pass != OPT_PASS_TOUCHED;
+    const int untouched_only = (dense && pass == OPT_PASS_UNTOUCHED) ? 1 : 0;
+    if (table_mode != DCTR_TABLE_DENSE_EXACT && pass == OPT_PASS_UNTOUCHED) return DCTR_OK;
     if (st_lin == nullptr) st_lin = st;
 #define DCTR_K(KD)                                                                                                      \
     case KD:                                                                                                            \
         return dense ? launch_table<KD, true>(hdev, hval, rows, K, emb, e0, e1, lin, l0, l1, slot, uniq, counters,      \
-                                              max_entries, gemb, glin, l2, sumsq_emb, sumsq_lin, st, st_lin)            \
+                                              max_entries, gemb, glin, l2, sumsq_emb, sumsq_lin, st, st_lin, untouched_only) \
                      : launch_table<KD, false>(hdev, hval, rows, K, emb, e0, e1, lin, l0, l1, slot, uniq, counters,     \
-                                               max_entries, gemb, glin, l2, sumsq_emb, sumsq_lin, st, st_lin)
+                                               max_entries, gemb, glin, l2, sumsq_emb, sumsq_lin, st, st_lin, 0)
     switch (kind) {
         DCTR_K(DCTR_OPT_ADAM); DCTR_K(DCTR_OPT_ADAGRAD); DCTR_K(DCTR_OPT_MOMENTUM); DCTR_K(DCTR_OPT_FTRL);
         default: set_error("unknown optimizer kind %d", kind); return DCTR_ERR_INVALID_ARG;

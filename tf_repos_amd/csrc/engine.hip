@@ -505,19 +505,31 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
 }
 
 // ---- table side of the backward: segment-sum the row gradients (ids already grouped), step the tables ------------
-int scatter_and_step_tables(dctr_engine* E, int B, hipStream_t st, hipStream_t st_lin = nullptr) {
+int scatter_and_step_tables(dctr_engine* E, int B, hipStream_t st, hipStream_t st_lin = nullptr, int pass = OPT_PASS_ALL) {
     const dctr_config& c = E->cfg;
     const int mode = gather_mode(E);
     const float* dE = mode == DCTR_GATHER_BI ? nullptr : E->dE;
     const float* coef = mode == DCTR_GATHER_FM ? E->dy : (mode == DCTR_GATHER_BI ? E->dx_in : nullptr);
     DCTR_TRY(embed_scatter_bwd(E->group, dE, E->dE_ld, E->e, E->e_ld, E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F,
                                E->K, mode, E->group->gemb, E->lin ? E->group->glin : nullptr, st));
+    if (pass == OPT_PASS_TOUCHED) st_lin = nullptr;     // the touched-rows kernel steps the linear weights in the same launch
     if (st_lin != nullptr && st_lin != st) DCTR_TRY(fork(E, st, st_lin));        // the compact gradients are complete on st
     DCTR_TRY(opt_table(c.optimizer, &E->state->hyper, E->h_state.hyper, c.table_mode, E->rows, E->K, E->emb, E->emb_s0, E->emb_s1,
                        E->lin, E->lin_s0, E->lin_s1, E->group->slot, E->group->uniq, E->group->counters, E->group->max_entries,
-                       E->group->gemb, E->group->glin, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, st, st_lin));
+                       E->group->gemb, E->group->glin, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, st, st_lin,
+                       pass));
     if (st_lin != nullptr && st_lin != st) DCTR_TRY(fork(E, st_lin, st));
     return DCTR_OK;
+}
+
+// dense-exact tables: the rows the batch does NOT touch have gradient l2*theta, which depends on nothing this step computes --
+// their optimizer step (90 % of the table pass) runs right after the grouping, under the MLP GEMMs, instead of at the end
+int step_untouched_rows(dctr_engine* E, hipStream_t st) {
+    const dctr_config& c = E->cfg;
+    return opt_table(c.optimizer, &E->state->hyper, E->h_state.hyper, c.table_mode, E->rows, E->K, E->emb, E->emb_s0, E->emb_s1,
+                     E->lin, E->lin_s0, E->lin_s1, E->group->slot, E->group->uniq, E->group->counters, E->group->max_entries,
+                     E->group->gemb, E->group->glin, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, st, nullptr,
+                     OPT_PASS_UNTOUCHED);
 }
 
 // The step as a small DAG over three streams (captured into one hipGraph):
@@ -574,18 +586,25 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     DCTR_TRY(fork(E, st, sw));
     DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, sw));
     DCTR_TRY(forward_gather(E, B, st));
+    DCTR_TRY(fork(E, sw, st));              // (before the fork below: sg's table pass needs this step's lr_t and zeroed scalars)
     DCTR_TRY(fork(E, st, sg));              // grouping starts after the gather (its atomics slow a concurrent gather 4x)
     DCTR_TRY(group_ids(E->group, E->ids, B, E->F, sg));
-    DCTR_TRY(fork(E, sw, st));
+    static const bool no_split = getenv("DCTR_NO_SPLIT_TABLE") != nullptr;      // A/B knob
+    const bool split_table = E->cfg.table_mode == DCTR_TABLE_DENSE_EXACT && !no_split;
+    static const bool bg_late = getenv("DCTR_BG_LATE") != nullptr;              // A/B knob: background table pass beside the backward
+    if (split_table && !bg_late) DCTR_TRY(step_untouched_rows(E, sg));
     DCTR_TRY(forward_rest(E, B, true, st));
     DCTR_TRY(head(E, B, B, true, st, nullptr, true));
     const bool fused_opt = E->cfg.model != DCTR_MODEL_AFM;
     if (fused_opt && E->head_did_out_bwd) {
         // the output layer (and the global bias, whose gradient aliases the output bias' slabs) is final right after the fused
         // head kernel: step it now, beside the MLP backward, instead of at the end of the step beside the scatter
-        DCTR_TRY(fork(E, st, sw));
-        DCTR_TRY(opt_dense_range(E, E->p_out_w, E->p_out_b, sw));
-        if (E->p_bias >= 0) DCTR_TRY(opt_dense_range(E, E->p_bias, E->p_bias, sw));
+        // (on the grouping stream, idle since the MLP forward: on the wgrad stream these two latency-bound launches -- 128 slabs
+        //  summed by one block each, ~35 us -- would delay the whole weight-gradient chain behind them)
+        DCTR_TRY(fork(E, st, sg));
+        if (split_table && bg_late) DCTR_TRY(step_untouched_rows(E, sg));
+        DCTR_TRY(opt_dense_range(E, E->p_out_w, E->p_out_b, sg));
+        if (E->p_bias >= 0) DCTR_TRY(opt_dense_range(E, E->p_bias, E->p_bias, sg));
     }
     const bool out_done = fused_opt && E->head_did_out_bwd;
     DCTR_TRY(backward_dense(E, B, st, sw, fused_opt));
@@ -606,7 +625,8 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
                                  E->n_blocks, nullptr, 1, E->scalars + 3 * SUMSQ_SHARDS, sw));
     }
     DCTR_TRY(fork(E, sg, st));
-    DCTR_TRY(scatter_and_step_tables(E, B, st, sg));       // the grouping stream is idle by now: linear table beside the embedding table
+    if (split_table) DCTR_TRY(scatter_and_step_tables(E, B, st, nullptr, OPT_PASS_TOUCHED));
+    else DCTR_TRY(scatter_and_step_tables(E, B, st, sg));  // the grouping stream is idle by now: linear table beside the embedding table
     DCTR_TRY(fork(E, sw, st));
     return DCTR_OK;
 }

@@ -100,7 +100,8 @@ int opt_dense_flat(int kind, const Hyper* hdev, const Hyper& hval, float* theta,
 int opt_table(int kind, const Hyper* hdev, const Hyper& hval, int table_mode, int64_t rows, int K, float* emb, float* e0,
               float* e1, float* lin, float* l0, float* l1, const int32_t* slot, const int32_t* uniq,
               const int32_t* counters, int64_t max_entries, const float* gemb, const float* glin, float l2,
-              float* sumsq_emb, float* sumsq_lin, hipStream_t st, hipStream_t st_lin = nullptr);
+              float* sumsq_emb, float* sumsq_lin, hipStream_t st, hipStream_t st_lin = nullptr, int pass = 0);
+enum { OPT_PASS_ALL = 0, OPT_PASS_UNTOUCHED = 1, OPT_PASS_TOUCHED = 2 };
 int step_state_advance(StepState* s, float* zero, int n_zero, hipStream_t st);
 int head_out_bwd(const float* x1, int ld1, const float* w1, int n1, int masked1, float* dx1, int lddx1,
                  const float* x2, int ld2, const float* w2, int n2, int masked2, float* dx2, int lddx2,
