@@ -46,7 +46,8 @@ enum { DCTR_MODEL_DEEPFM = 0,  /* DeepFM.py   */
         * (identity) columns share one stacked table, dense_size numeric columns enter as dense inputs */
        DCTR_MODEL_WIDE   = 7,  /* --model_type=wide         LinearClassifier            */
        DCTR_MODEL_DEEP   = 8,  /* --model_type=deep         DNNClassifier               */
-       DCTR_MODEL_WND    = 9   /* --model_type=wide_n_deep  DNNLinearCombinedClassifier */ };
+       DCTR_MODEL_WND    = 9,  /* --model_type=wide_n_deep  DNNLinearCombinedClassifier */
+       DCTR_MODEL_MVM    = 10  /* DeepMVM.py: prod_f (e_f + mvm_b_f) beside the MLP, fc([x_mvm || mlp_out]) */ };
 
 enum { DCTR_OPT_ADAM = 0, DCTR_OPT_ADAGRAD = 1, DCTR_OPT_MOMENTUM = 2, DCTR_OPT_FTRL = 3 }; /* DeepFM.py:204-211 */
 

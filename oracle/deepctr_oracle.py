@@ -26,7 +26,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-MODELS = ("deepfm", "fnn", "ipnn", "opnn", "nfm", "afm", "dcn")
+MODELS = ("deepfm", "fnn", "ipnn", "opnn", "nfm", "afm", "dcn", "mvm")
 
 
 @dataclass
@@ -51,12 +51,12 @@ class Config:
         return self.field_size * (self.field_size - 1) // 2   # PNN.py:113 (py2 int division)
 
     def has_linear(self) -> bool:
-        return self.model != "dcn"                  # DCN has no linear table (DCN.py:120-125)
+        return self.model not in ("dcn", "mvm")     # DCN / DeepMVM have no linear table (DCN.py:120-125, DeepMVM.py:114-118)
 
     def mlp_input_width(self) -> int:
         F, K, P = self.field_size, self.embedding_size, self.num_pairs
         return {"deepfm": F * K, "fnn": F * K, "ipnn": F * K + P, "opnn": F * K + P * K * K,
-                "nfm": K, "dcn": F * K, "afm": K}[self.model]
+                "nfm": K, "dcn": F * K, "afm": K, "mvm": F * K}[self.model]
 
 
 # --------------------------------------------------------------------------------------
@@ -66,7 +66,10 @@ class Config:
 def param_shapes(cfg: Config) -> Dict[str, Tuple[int, ...]]:
     F, K, V = cfg.field_size, cfg.embedding_size, cfg.feature_size
     shapes: Dict[str, Tuple[int, ...]] = {}
-    if cfg.model == "dcn":
+    if cfg.model == "mvm":
+        shapes["mvm_b"] = (F, K)                               # DeepMVM.py:118
+        shapes["emb"] = (V, K)                                 # DeepMVM.py:117 (mvm_w)
+    elif cfg.model == "dcn":
         shapes["cross_b"] = (cfg.cross_layers, F * K)          # DCN.py:120
         shapes["cross_w"] = (cfg.cross_layers, F * K)          # DCN.py:122
         shapes["emb"] = (V, K)                                 # DCN.py:124
@@ -95,7 +98,10 @@ def param_shapes(cfg: Config) -> Dict[str, Tuple[int, ...]]:
             shapes[f"bn_{i}/moving_mean"] = (h,)
             shapes[f"bn_{i}/moving_variance"] = (h,)
         d = h
-    if cfg.model == "dcn":
+    if cfg.model == "mvm":
+        shapes["deep_out/weights"] = (K + d, 1)                # DeepMVM.py:185-188
+        shapes["deep_out/biases"] = (1,)
+    elif cfg.model == "dcn":
         shapes["out_layer/weights"] = (F * K + d, 1)           # DCN.py:179-182
         shapes["out_layer/biases"] = (1,)
     else:
@@ -262,6 +268,15 @@ def forward(cfg: Config, p: Dict[str, torch.Tensor], ids, vals, train: bool = Fa
         h = mlp(x0)                                             # DCN.py:161-176
         stack = torch.cat([xl, h], 1)                           # DCN.py:179
         y = _fc(stack, p["out_layer/weights"], p["out_layer/biases"], relu=False).reshape(-1)
+    elif cfg.model == "mvm":
+        all_order = emb + p["mvm_b"]                            # DeepMVM.py:145
+        x_mvm = all_order[:, 0, :]                              # DeepMVM.py:146
+        for i in range(1, F):                                   # DeepMVM.py:147-148
+            x_mvm = x_mvm * all_order[:, i, :]
+        out["x_mvm"] = x_mvm
+        h = mlp(emb.reshape(B, F * K))                          # DeepMVM.py:167-181
+        stack = torch.cat([x_mvm, h], 1)                        # DeepMVM.py:185
+        y = _fc(stack, p["deep_out/weights"], p["deep_out/biases"], relu=False).reshape(-1)
     else:
         raise ValueError(cfg.model)
     out["y"] = y
@@ -279,6 +294,8 @@ def regularized_tables(cfg: Config) -> List[str]:
     """Variables that enter the loss through l2_loss: DeepFM.py:189-190, PNN.py:207,
     NFM.py:169, AFM.py:181 (linear + emb); DCN.py:199 (cross_b, cross_w, emb).  The MLP's
     weights_regularizer is dead code in the reference."""
+    if cfg.model == "mvm":
+        return ["emb", "mvm_b"]                                  # DeepMVM.py:197-199
     return ["cross_b", "cross_w", "emb"] if cfg.model == "dcn" else ["linear", "emb"]
 
 

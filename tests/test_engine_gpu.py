@@ -10,7 +10,7 @@ from tests.util import dev_batch, make_pair
 
 pytestmark = pytest.mark.gpu
 
-MODELS = ["deepfm", "fnn", "ipnn", "nfm", "dcn", "afm"]
+MODELS = ["deepfm", "fnn", "ipnn", "nfm", "dcn", "afm", "mvm"]
 
 
 @pytest.mark.parametrize("model", MODELS + ["opnn"])
@@ -153,4 +153,32 @@ def test_batch_norm_with_dropout_runs_and_freezes_moving_stats_under_ftrl(dev):
     mv = eng.get_param("bn_0/moving_variance")
     mm = eng.get_param("bn_0/moving_mean")
     assert np.all(mv > 0.4) and np.all(mv < 1.0) and np.abs(mm).max() > 0         # moved by the moving average only, not zeroed by Ftrl
+    eng.close()
+
+
+@pytest.mark.parametrize("opt", ["Adam", "Adagrad"])
+def test_deepmvm_product_layer_with_factors_near_one(opt, dev):
+    """DeepMVM.py:144-150: x_mvm = prod_f (e_f + mvm_b_f).  With N(0, 0.05) weights the 39-factor product underflows and the
+    layer is invisible; factors near 1 make its forward and backward matter."""
+    F, V, B, K = 39, 3000, 128, 8
+    ocfg, params, eng = make_pair("mvm", B=B, F=F, V=V, K=K, layers=(32, 16), opt=opt, lr=1e-2)
+    rng = np.random.default_rng(2)
+    params["mvm_b"] = torch.from_numpy((1.0 + rng.normal(0, 0.1, size=(F, K))).astype(np.float32))
+    eng.set_params(params)
+    ids, vals, labels = O.synth_batch(B, F, V, seed=31)
+    ref = O.forward(ocfg, params, ids, vals)
+    assert float(ref["x_mvm"].abs().mean()) > 1e-2                      # the product is alive
+    d = dev_batch(ids, vals, labels, dev)
+    logit = torch.empty(B, device=dev)
+    eng.predict(d[0], d[1], torch.empty(B, device=dev), logit)
+    assert np.abs(logit.cpu().numpy() - ref["y"].numpy()).max() <= 1e-4
+    oopt = O.Optimizer(ocfg, params)
+    for step in range(3):
+        ids, vals, labels = O.synth_batch(B, F, V, seed=300 + step)
+        ref_loss, _ = O.train_step(ocfg, params, oopt, ids, vals, labels)
+        loss = eng.train_step(*dev_batch(ids, vals, labels, dev))
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+    got = eng.get_params()
+    for name, refv in params.items():
+        assert np.abs(got[name] - refv.numpy()).max() <= 5e-6, name
     eng.close()

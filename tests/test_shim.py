@@ -32,6 +32,7 @@ def _trace(mod, params, mode="train"):
     ("PNN.py", {"model_type": "Outer"}, "opnn", {}),
     ("NFM.py", {}, "nfm", {}),
     ("DCN.py", {}, "dcn", {"cross_w": "cross_w", "cross_b": "cross_b", "out_layer/weights": "DCN-out/out_layer/weights"}),
+    ("DeepMVM.py", {}, "mvm", {"emb": "mvm_w", "mvm_b": "mvm_b", "deep_out/weights": "DeepMVM-out/deep_out/weights"}),
     ("AFM.py", {}, "afm", {"attention_out/weights": "Attention-part/attention_out/weights",
                             "deep_out/weights": "Attention-based-Pooling/deep_out/weights"}),
 ])

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libdeepctr_hip.so")
 
 DCTR_OK = 0
-MODELS = {"deepfm": 0, "fnn": 1, "ipnn": 2, "opnn": 3, "nfm": 4, "afm": 5, "dcn": 6, "wide": 7, "deep": 8, "wide_n_deep": 9}
+MODELS = {"deepfm": 0, "fnn": 1, "ipnn": 2, "opnn": 3, "nfm": 4, "afm": 5, "dcn": 6, "wide": 7, "deep": 8, "wide_n_deep": 9, "mvm": 10}
 OPTIMIZERS = {"Adam": 0, "Adagrad": 1, "Momentum": 2, "ftrl": 3}
 TABLE_MODES = {"dense_exact": 0, "touched_rows": 1}
 GATHER_RAW, GATHER_FM, GATHER_BI = 0, 1, 2

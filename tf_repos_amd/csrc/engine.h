@@ -104,6 +104,10 @@ struct dctr_engine {
     const float* dense = nullptr;    // [B, n_dense] inputs of the next call (dctr_set_dense_input), caller-owned
     int p_lin_dense = -1;
 
+    // DeepMVM (DeepMVM.py:144-150): x_mvm = prod_f (e_f + mvm_b_f)
+    int p_mvm_b = -1;
+    float *xmvm = nullptr, *dxmvm = nullptr;      // [MB, K]
+
     // AFM (afm.hip)
     int A = 0;                       // attention layer width
     int p_att_w = -1, p_att_b = -1, p_ao_w = -1, p_ao_b = -1;

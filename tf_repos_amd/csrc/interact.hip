@@ -278,6 +278,70 @@ int dcn_cross_bwd(const float* xs, const float* xlw, const float* w, const float
     return DCTR_OK;
 }
 
+// ---- DeepMVM "all-order" product (DeepMVM.py:144-150): x_mvm[b,k] = prod_f (e[b,f,k] + mvm_b[f,k]) -----------------------------
+// One lane per (example, k): the F factors of a lane are strided K apart in e, consecutive lanes read consecutive k.
+constexpr int MVM_MAXF = 64;
+
+__global__ __launch_bounds__(256) void mvm_fwd_kernel(const float* __restrict__ e, int e_ld, const float* __restrict__ mb, int B, int F,
+                                                     int K, float* __restrict__ xm) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * K) return;
+    const int b = (int)(i / K), k = (int)(i % K);
+    float p = 1.f;
+    for (int f = 0; f < F; ++f) p *= e[(size_t)b * e_ld + f * K + k] + mb[f * K + k];
+    xm[(size_t)b * K + k] = p;
+}
+
+// backward: with a_f = e_f + mvm_b_f,  d a_f = dxm * prod_{g != f} a_g  (prefix/suffix products: no division, zeros are fine);
+// dE[b,f,k] += d a_f,  d mvm_b[f,k] = sum_b d a_f  (block-level LDS accumulation, one partial slab per block).
+__global__ __launch_bounds__(256) void mvm_bwd_kernel(const float* __restrict__ e, int e_ld, const float* __restrict__ mb,
+                                                     const float* __restrict__ dxm, int B, int F, int K, int rows_per_block,
+                                                     float* __restrict__ dE, int de_ld, float* __restrict__ dmb_part, int64_t part_stride) {
+    extern __shared__ float acc[];          // [F*K]
+    for (int i = threadIdx.x; i < F * K; i += blockDim.x) acc[i] = 0.f;
+    __syncthreads();
+    const int epb = blockDim.x / K;         // examples per pass
+    const int k = threadIdx.x % K, bl = threadIdx.x / K;
+    const int bbeg = blockIdx.x * rows_per_block, bend = min(B, bbeg + rows_per_block);
+    if (bl < epb) {
+        for (int b = bbeg + bl; b < bend; b += epb) {
+            float a[MVM_MAXF];
+            float p = 1.f;
+            for (int f = 0; f < F; ++f) { a[f] = e[(size_t)b * e_ld + f * K + k] + mb[f * K + k]; }
+            // prefix products in place of a: pre[f] = prod_{g<f} a_g ; keep a suffix running product
+            float pre[MVM_MAXF];
+            for (int f = 0; f < F; ++f) { pre[f] = p; p *= a[f]; }
+            const float g = dxm[(size_t)b * K + k];
+            float suf = 1.f;
+            for (int f = F - 1; f >= 0; --f) {
+                const float d = g * pre[f] * suf;
+                suf *= a[f];
+                dE[(size_t)b * de_ld + f * K + k] += d;
+                atomicAdd(&acc[f * K + k], d);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < F * K; i += blockDim.x) dmb_part[(size_t)blockIdx.x * part_stride + i] = acc[i];
+}
+
+int mvm_fwd(const float* e, int e_ld, const float* mb, int B, int F, int K, float* xm, hipStream_t st) {
+    if (B <= 0) return DCTR_OK;
+    mvm_fwd_kernel<<<ceil_div((int64_t)B * K, 256), 256, 0, st>>>(e, e_ld, mb, B, F, K, xm);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+int mvm_bwd(const float* e, int e_ld, const float* mb, const float* dxm, int B, int F, int K, float* dE, int de_ld, float* dmb_part,
+            int64_t part_stride, int splits, hipStream_t st) {
+    DCTR_REQUIRE(F <= MVM_MAXF && K <= 256 && F * K * 4 <= 64 * 1024, "DeepMVM backward: field_size <= %d and F*K <= 16384 supported", MVM_MAXF);
+    if (B <= 0) return DCTR_OK;
+    mvm_bwd_kernel<<<splits, 256, (size_t)F * K * sizeof(float), st>>>(e, e_ld, mb, dxm, B, F, K, ceil_div(B, splits), dE, de_ld, dmb_part,
+                                                                     part_stride);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
 }  // namespace dctr
 
 using namespace dctr;

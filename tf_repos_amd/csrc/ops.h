@@ -139,4 +139,9 @@ int dcn_cross_bwd(const float* xs, const float* xlw, const float* w, const float
                   float* dx0, int dx0_ld, float* dw_part, float* db_part, int splits, int64_t part_stride,
                   float* scratch, hipStream_t st);
 
+// DeepMVM product layer (DeepMVM.py:144-150)
+int mvm_fwd(const float* e, int e_ld, const float* mb, int B, int F, int K, float* xm, hipStream_t st);
+int mvm_bwd(const float* e, int e_ld, const float* mb, const float* dxm, int B, int F, int K, float* dE, int de_ld, float* dmb_part,
+            int64_t part_stride, int splits, hipStream_t st);
+
 }  // namespace dctr

@@ -18,7 +18,7 @@ from . import capi, errors
 @dataclass
 class EngineConfig:
     """Field names follow the reference flags (DeepFM.py:34-60, DCN.py:52, AFM.py:52, PNN.py:61)."""
-    model: str = "deepfm"                      # deepfm | fnn | ipnn | opnn | nfm | dcn
+    model: str = "deepfm"                      # deepfm | fnn | ipnn | opnn | nfm | afm | dcn | mvm | wide | deep | wide_n_deep
     field_size: int = 39
     feature_size: int = 117581
     embedding_size: int = 32

@@ -84,6 +84,8 @@ def lower(loss: Optional[G.Tensor], train_op: Optional[G.Tensor], predictions: D
         model = "ipnn"
     elif by_op.get("matmul") and len(cross_vars) == 2:
         model = "dcn"
+    elif len(cross_vars) == 1 and tuple(cross_vars[0].shape) == (F, K) and lin_var is None:
+        model = "mvm"           # DeepMVM.py:117-118,144-150: mvm_w [V,K] gathered, mvm_b [F,K] added, product over the fields
     elif not hidden:
         raise _unsupported("no hidden fully_connected layers")
     else:
@@ -108,6 +110,10 @@ def lower(loss: Optional[G.Tensor], train_op: Optional[G.Tensor], predictions: D
             raise _unsupported("cross_w/cross_b must both be [cross_layers, F*K]")
         kw["cross_layers"] = int(cw.shape[0])
         name_map["cross_w"], name_map["cross_b"] = cw.var_name, cb.var_name
+    elif model == "mvm":
+        if bias_var is not None:
+            raise _unsupported("DeepMVM graph with a global bias")
+        name_map["mvm_b"] = cross_vars[0].var_name
     else:
         if lin_var is None or bias_var is None:
             raise _unsupported("%s graph without linear table / global bias" % model)
@@ -181,7 +187,7 @@ def lower(loss: Optional[G.Tensor], train_op: Optional[G.Tensor], predictions: D
             c, l = (a, b) if a.op == "const" else (b, a)
             if c.op == "const" and l.op == "l2_loss" and isinstance(l.inputs[0], G.Variable):
                 regs.append((l.inputs[0].var_name, float(c.attrs["value"])))
-        expect = {name_map[k] for k in (("cross_b", "cross_w", "emb") if model == "dcn" else ("linear", "emb"))}
+        expect = {name_map[k] for k in {"dcn": ("cross_b", "cross_w", "emb"), "mvm": ("mvm_b", "emb")}.get(model, ("linear", "emb"))}
         if regs:
             coefs = {round(c, 12) for _, c in regs}
             if {n for n, _ in regs} != expect or len(coefs) != 1:
