@@ -18,6 +18,10 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>      // types and prototypes only: every call goes through dlsym'd pointers
 
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "engine.h"
@@ -40,6 +44,7 @@ struct RcclApi {
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclAllToAllv) AllToAllv = nullptr;      // RCCL extension (optional): one call instead of 2*world send/recv calls
 };
 
 RcclApi g_rccl;
@@ -64,6 +69,8 @@ int load_rccl(const char* path) {
     DCTR_SYM(AllGather, ncclAllGather);
     DCTR_SYM(GetErrorString, ncclGetErrorString);
 #undef DCTR_SYM
+    g_rccl.AllToAllv = reinterpret_cast<decltype(g_rccl.AllToAllv)>(dlsym(lib, "ncclAllToAllv"));
+    if (getenv("DCTR_NO_ALLTOALLV") != nullptr) g_rccl.AllToAllv = nullptr;
     g_rccl.lib = lib;
     return DCTR_OK;
 }
@@ -93,6 +100,16 @@ int rccl_all_to_all(void* ctx, int ch, const void* send, const int64_t* scnt, vo
     RcclCtx* c = static_cast<RcclCtx*>(ctx);
     const char* s = static_cast<const char*>(send);
     char* r = static_cast<char*>(recv);
+    if (g_rccl.AllToAllv != nullptr) {
+        size_t sc[64], sd[64], rc[64], rd[64];
+        size_t so = 0, ro = 0;
+        for (int p = 0; p < c->world; ++p) {
+            sc[p] = (size_t)(scnt[p] * rec); sd[p] = so; so += sc[p];
+            rc[p] = (size_t)(rcnt[p] * rec); rd[p] = ro; ro += rc[p];
+        }
+        DCTR_NCCL_CHECK(g_rccl.AllToAllv(send, sc, sd, recv, rc, rd, ncclUint8, c->comm[ch], as_stream(st)));
+        return DCTR_OK;
+    }
     DCTR_NCCL_CHECK(g_rccl.GroupStart());
     int64_t so = 0, ro = 0;
     ncclResult_t bad = ncclSuccess;
@@ -126,7 +143,24 @@ struct RouteState {
     hipEvent_t counts_ready = nullptr;  // the split sizes are in h_all_counts
     hipEvent_t ready = nullptr;         // the whole route is complete (recorded on the stream that computed it)
     hipEvent_t done = nullptr;          // the step that used this state has finished (main stream)
+    hipEvent_t start = nullptr;         // recorded on the main stream when the routing of this batch is requested
     bool has_done = false;
+};
+
+// The routing of the next batch is ENQUEUED by a worker thread of its own (it owns the route stream and communicator 1): that is
+// ~20 launches, two collectives and the one host wait of the step taken off the thread that enqueues the step itself, which was
+// the bottleneck (0.47 ms of host time per 0.48 ms step).
+struct RouteWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool stop = false, has_job = false, done = true;
+    int which = 0;
+    const int32_t* ids = nullptr;
+    int B = 0;
+    int rc = DCTR_OK;
+    std::string err;
+    int device = 0;
 };
 
 }  // namespace
@@ -145,6 +179,7 @@ struct dctr_dist {
     int64_t cap = 0, cap_owner = 0;
     bool overlap = true;
     bool finish_early = true;
+    RouteWorker* worker = nullptr;
 };
 
 namespace {
@@ -182,6 +217,39 @@ int route_finish(dctr_dist* D, RouteState& r, int which, hipStream_t s) {
     return DCTR_OK;
 }
 
+void route_worker_main(dctr_dist* D) {
+    RouteWorker* w = D->worker;
+    hipSetDevice(w->device);
+    std::unique_lock<std::mutex> lk(w->mu);
+    while (true) {
+        w->cv.wait(lk, [&] { return w->has_job || w->stop; });
+        if (w->stop) return;
+        w->has_job = false;
+        const int which = w->which;
+        const int32_t* ids = w->ids;
+        const int B = w->B;
+        lk.unlock();
+        RouteState& r = D->rs[which];
+        int rc = DCTR_OK;
+        if (hipStreamWaitEvent(D->s_route, r.start, 0) != hipSuccess) { set_error("route worker: hipStreamWaitEvent failed"); rc = DCTR_ERR_HIP; }
+        if (rc == DCTR_OK) rc = route_begin(D, r, ids, B, D->s_route);
+        if (rc == DCTR_OK) rc = route_finish(D, r, which, D->s_route);
+        lk.lock();
+        w->rc = rc;
+        if (rc != DCTR_OK) w->err = get_error();
+        w->done = true;
+        w->cv.notify_all();
+    }
+}
+
+int wait_worker(dctr_dist* D) {
+    RouteWorker* w = D->worker;
+    std::unique_lock<std::mutex> lk(w->mu);
+    w->cv.wait(lk, [&] { return w->done; });
+    if (w->rc != DCTR_OK) { set_error("%s", w->err.c_str()); const int rc = w->rc; w->rc = DCTR_OK; return rc; }
+    return DCTR_OK;
+}
+
 // the route of (ids, B) on the main stream: the prefetched one if it matches, else computed inline
 int take_route(dctr_dist* D, const int32_t* ids, int B, hipStream_t M, int* which) {
     DCTR_HIP_CHECK(hipEventRecord(D->ev_start, M));
@@ -189,7 +257,8 @@ int take_route(dctr_dist* D, const int32_t* ids, int B, hipStream_t M, int* whic
         const int w = D->pending;
         RouteState& r = D->rs[w];
         D->pending = -1;
-        if (r.phase == 1) DCTR_TRY(route_finish(D, r, w, D->s_route));
+        if (D->worker != nullptr) DCTR_TRY(wait_worker(D));       // everything of this route has been enqueued (normally long ago)
+        else if (r.phase == 1) DCTR_TRY(route_finish(D, r, w, D->s_route));
         DCTR_HIP_CHECK(hipStreamWaitEvent(M, r.ready, 0));
         if (r.ids == ids && r.B == B) { *which = w; return DCTR_OK; }
         // a prefetch for some other batch: it has been waited for (its buffers are quiescent); route this one now
@@ -204,11 +273,23 @@ int take_route(dctr_dist* D, const int32_t* ids, int B, hipStream_t M, int* whic
     return DCTR_OK;
 }
 
-int prefetch_begin(dctr_dist* D, const int32_t* next_ids, int next_B) {
+int prefetch_begin(dctr_dist* D, const int32_t* next_ids, int next_B, hipStream_t M) {
     const int w = D->parity;
     D->parity ^= 1;
-    DCTR_HIP_CHECK(hipStreamWaitEvent(D->s_route, D->ev_start, 0));          // next_ids were produced before this step began
-    DCTR_TRY(route_begin(D, D->rs[w], next_ids, next_B, D->s_route));
+    RouteState& r = D->rs[w];
+    DCTR_HIP_CHECK(hipEventRecord(r.start, M));          // next_ids were produced before this point of the main stream
+    if (D->worker != nullptr) {
+        RouteWorker* wk = D->worker;
+        {
+            std::lock_guard<std::mutex> lk(wk->mu);
+            wk->which = w; wk->ids = next_ids; wk->B = next_B;
+            wk->has_job = true; wk->done = false;
+        }
+        wk->cv.notify_all();
+    } else {
+        DCTR_HIP_CHECK(hipStreamWaitEvent(D->s_route, r.start, 0));
+        DCTR_TRY(route_begin(D, r, next_ids, next_B, D->s_route));
+    }
     D->pending = w;
     return DCTR_OK;
 }
@@ -249,6 +330,7 @@ int dist_alloc(dctr_dist* D) {
         DCTR_HIP_CHECK(hipEventCreateWithFlags(&r.counts_ready, hipEventDisableTiming));
         DCTR_HIP_CHECK(hipEventCreateWithFlags(&r.ready, hipEventDisableTiming));
         DCTR_HIP_CHECK(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
+        DCTR_HIP_CHECK(hipEventCreateWithFlags(&r.start, hipEventDisableTiming));
     }
     DCTR_HIP_CHECK(hipMalloc(&D->rows_out, D->cap_owner * P * 4));
     DCTR_HIP_CHECK(hipMalloc(&D->rows_back, D->cap * P * 4));
@@ -267,9 +349,15 @@ int dist_alloc(dctr_dist* D) {
     D->overlap = !(ov != nullptr && ov[0] == '0');
     const char* fe = getenv("DCTR_SHARD_FINISH_EARLY");
     D->finish_early = !(fe != nullptr && fe[0] == '0');
+    const char* th = getenv("DCTR_SHARD_THREAD");
+    if (D->overlap && !(th != nullptr && th[0] == '0')) {
+        D->worker = new RouteWorker();
+        DCTR_HIP_CHECK(hipGetDevice(&D->worker->device));
+    }
     // both owner-side grouping states exist before the first step (creating one lazily would allocate in the middle of a step)
     DCTR_TRY(dctr_table_group_rows(E, 1, nullptr, 0, nullptr));
     DCTR_HIP_CHECK(hipDeviceSynchronize());
+    if (D->worker != nullptr) D->worker->th = std::thread(route_worker_main, D);
     return DCTR_OK;
 }
 
@@ -328,6 +416,17 @@ int dctr_dist_create_rccl(dctr_handle E, int rank, int world, const char* ids, c
 
 int dctr_dist_destroy(dctr_dist_t D) {
     if (D == nullptr) return DCTR_OK;
+    if (D->worker != nullptr) {
+        {
+            std::unique_lock<std::mutex> lk(D->worker->mu);
+            D->worker->cv.wait(lk, [&] { return D->worker->done; });
+            D->worker->stop = true;
+        }
+        D->worker->cv.notify_all();
+        if (D->worker->th.joinable()) D->worker->th.join();
+        delete D->worker;
+        D->worker = nullptr;
+    }
     hipDeviceSynchronize();
     for (RouteState& r : D->rs) {
         if (r.g) group_destroy(r.g);
@@ -336,6 +435,7 @@ int dctr_dist_destroy(dctr_dist_t D) {
         if (r.counts_ready) hipEventDestroy(r.counts_ready);
         if (r.ready) hipEventDestroy(r.ready);
         if (r.done) hipEventDestroy(r.done);
+        if (r.start) hipEventDestroy(r.start);
     }
     hipFree(D->rows_out); hipFree(D->rows_back); hipFree(D->send_grads); hipFree(D->recv_grads); hipFree(D->d_loss);
     if (D->ev_start) hipEventDestroy(D->ev_start);
@@ -361,7 +461,7 @@ int dctr_dist_train_step(dctr_dist_t D, const int32_t* d_ids, const float* d_val
     RouteState& r = D->rs[w];
     const bool prefetch = D->overlap && d_next_ids != nullptr && next_B > 0;
     // the first half of the next batch's routing is enqueued BEFORE this step's work so that it runs under the MLP GEMMs
-    if (prefetch) DCTR_TRY(prefetch_begin(D, d_next_ids, next_B));
+    if (prefetch) DCTR_TRY(prefetch_begin(D, d_next_ids, next_B, M));
     DCTR_TRY(fetch_and_forward(D, r, d_vals, d_labels, B, true, M));
     // dense side, beside the gradient exchange (the logit gradient already carries 1/global_batch: sum over ranks = mean)
     // (the side stream already holds the weight gradients; it still needs the output-layer / cross-network partials from M)
@@ -375,7 +475,7 @@ int dctr_dist_train_step(dctr_dist_t D, const int32_t* d_ids, const float* d_val
     }
     DCTR_TRY(dense_update(D, sd));
     if (sd != M) DCTR_HIP_CHECK(hipEventRecord(D->ev_dense, sd));
-    if (prefetch && D->finish_early) DCTR_TRY(route_finish(D, D->rs[D->pending], D->pending, D->s_route));
+    if (prefetch && D->finish_early && D->worker == nullptr) DCTR_TRY(route_finish(D, D->rs[D->pending], D->pending, D->s_route));
     // sparse side: per-distinct-id gradients in send order -> owners -> segment-sum + table optimizer
     const int64_t rec = (int64_t)(E->K + 4) * sizeof(float);
     DCTR_TRY(dctr_sharded_pack_row_grads(E, reinterpret_cast<dctr_group_t>(r.g), B, r.upos, D->send_grads, M));
@@ -384,7 +484,7 @@ int dctr_dist_train_step(dctr_dist_t D, const int32_t* d_ids, const float* d_val
     if (sd != M) DCTR_HIP_CHECK(hipStreamWaitEvent(M, D->ev_dense, 0));
     DCTR_HIP_CHECK(hipEventRecord(r.done, M));
     r.has_done = true;
-    if (prefetch && !D->finish_early) DCTR_TRY(route_finish(D, D->rs[D->pending], D->pending, D->s_route));
+    if (prefetch && !D->finish_early && D->worker == nullptr) DCTR_TRY(route_finish(D, D->rs[D->pending], D->pending, D->s_route));
     if (h_loss != nullptr) {
         // loss = mean xent over the GLOBAL batch + l2_reg * (l2_loss(tables, all shards) + l2_loss(regularised dense params))
         float sc[4];

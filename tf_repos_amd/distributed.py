@@ -375,6 +375,12 @@ class ShardedTrainer:
         capi.check(self._lib.dctr_last_outputs(self._h, C.byref(p), None))
         return _as_tensor(p.value, B, self.dev).clone()
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def close(self):
         if self._dist is not None and self._dist.value:
             self._lib.dctr_dist_destroy(self._dist)
@@ -394,6 +400,10 @@ class HostStagedTransport:
         self.comm = comm
         self._lib = capi.lib()
         self._exc = None
+        # channel 1 (routing) is driven by the native driver's worker thread, concurrently with the main thread's channels 0 / 2:
+        # it needs a process group of its own so that the two threads' collectives cannot interleave differently across ranks
+        ranks = dist.get_process_group_ranks(comm.group) if comm.group is not None else None
+        self._groups = {0: comm.group, 1: dist.new_group(ranks=ranks), 2: comm.group}
         self._cbs = (capi.ALL_GATHER_I32_FN(self._all_gather_i32), capi.ALL_TO_ALL_FN(self._all_to_all),
                      capi.ALL_REDUCE_F32_FN(self._all_reduce_f32))            # keep the thunks alive
         self.table = capi.Transport(None, *self._cbs)
@@ -427,7 +437,7 @@ class HostStagedTransport:
         def run():
             mine = torch.from_numpy(self._d2h(d_send, 4 * n, np.int32, stream))
             parts = [torch.empty(n, dtype=torch.int32) for _ in range(self.comm.world)]
-            dist.all_gather(parts, mine, group=self.comm.group)
+            dist.all_gather(parts, mine, group=self._groups[ch])
             self._h2d(d_recv, torch.cat(parts).numpy(), stream)
         return self._guard(run)
 
@@ -438,14 +448,14 @@ class HostStagedTransport:
             rc = [int(rcnt[p]) for p in range(W)]
             send = torch.from_numpy(self._d2h(d_send, sum(sc) * rec, np.uint8, stream)).reshape(sum(sc), rec)
             recv = torch.empty(sum(rc), rec, dtype=torch.uint8)
-            dist.all_to_all_single(recv, send, rc, sc, group=self.comm.group)
+            dist.all_to_all_single(recv, send, rc, sc, group=self._groups[ch])
             self._h2d(d_recv, recv.numpy(), stream)
         return self._guard(run)
 
     def _all_reduce_f32(self, ctx, ch, d_buf, n, stream):
         def run():
             h = torch.from_numpy(self._d2h(d_buf, 4 * n, np.float32, stream))
-            dist.all_reduce(h, group=self.comm.group)
+            dist.all_reduce(h, group=self._groups[ch])
             self._h2d(d_buf, h.numpy(), stream)
         return self._guard(run)
 
