@@ -138,12 +138,11 @@ def main():
         ids, vals, labels = synth_batch(B, w["field_size"], w["feature_size"], seed=20260924 + 1 + rank * 1000 + i,
                                         uniform_ids=args.uniform_ids)
         t = (torch.from_numpy(ids).to(dev), torch.from_numpy(vals).to(dev), torch.from_numpy(labels).to(dev))
-        if not sharded:
-            # resident inputs: the 8 synthetic batches live in the engine's 8 input slots (what the input pipeline's H2D copy
-            # targets), so a step reads them in place
-            si, sv, sl = eng.input_slot(i)
-            si[:B].copy_(t[0]); sv[:B].copy_(t[1]); sl[:B].copy_(t[2])
-            t = (si[:B], sv[:B], sl[:B])
+        # resident inputs: the 8 synthetic batches live in the engine's 8 input slots (what the input pipeline's H2D copy
+        # targets), so a step reads them in place
+        si, sv, sl = (trainer.eng if sharded else eng).input_slot(i)
+        si[:B].copy_(t[0]); sv[:B].copy_(t[1]); sl[:B].copy_(t[2])
+        t = (si[:B], sv[:B], sl[:B])
         batches.append(t)
 
     for s in range(args.warmup):

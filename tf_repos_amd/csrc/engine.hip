@@ -1016,6 +1016,11 @@ int sharded_forward_backward(dctr_engine* E, const float* d_rows, int n_rows, co
         DCTR_TRY(fork(E, st, sw));
         DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, sw));
     }
+    // inputs that already live in one of the engine's input slots are read in place (no staging copy at the head of the step)
+    for (int k = 0; k < DCTR_INPUT_SLOTS; ++k)
+        if (d_vals == E->slot_vals[k] && (d_labels == nullptr || d_labels == E->slot_labels[k])) {
+            E->cur_slot = k; E->ids = E->slot_ids[k]; E->vals = E->slot_vals[k]; E->labels = E->slot_labels[k];
+        }
     if (d_vals != E->vals) DCTR_HIP_CHECK(hipMemcpyAsync(E->vals, d_vals, n * 4, hipMemcpyDeviceToDevice, st));
     if (d_labels && d_labels != E->labels) DCTR_HIP_CHECK(hipMemcpyAsync(E->labels, d_labels, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
     const int mode = gather_mode(E);

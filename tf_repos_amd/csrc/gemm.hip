@@ -97,7 +97,7 @@ constexpr int H16 = BK / 2;    // MFMAs (k-pairs) per BK tile
 template <bool A_KC, bool B_NC, int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(
     const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
-    float* __restrict__ Cm, int ldc, int M, int N, int K, int kchunk, bool vecA, bool vecB, Epilogue ep, int abl, int nx, int over) {
+    float* __restrict__ Cm, int ldc, int M, int N, int K, int kchunk, bool vecA, bool vecB, Epilogue ep, int nx, int over) {
     constexpr int LDA = A_KC ? 66 : 68;      // 66: conflict-free transposing scalar writes; 68: 16B-aligned rows
     constexpr int LDB = B_NC ? 68 : 66;
     constexpr int ABUF = BK * LDA, BBUF = BK * LDB;
@@ -208,14 +208,10 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(
         // one k-step: tile kt's fragments are in (fa,fb); tile kt+1 goes registers -> (asn,bsn) -> (na,nb)
         auto step = [&](int kt, float* asn, float* bsn, float (&fa)[H16], float (&fb)[H16], float (&na)[H16], float (&nb)[H16]) {
             const bool more = kt + 1 < nk;
-            if (more && abl < 1) lstore(asn, bsn);
-            if (abl < 3) __syncthreads();
-            if (kt + 2 < nk && abl < 1) gload(kt + 2);
-            if (more && abl < 2) lread(asn, bsn, na, nb);
-            if (more && abl >= 2) {
-#pragma unroll
-                for (int j = 0; j < H16; ++j) { na[j] = fa[j]; nb[j] = fb[j]; }
-            }
+            if (more) lstore(asn, bsn);
+            __syncthreads();
+            if (kt + 2 < nk) gload(kt + 2);
+            if (more) lread(asn, bsn, na, nb);
             if (wave_live) {
 #pragma unroll
                 for (int j = 0; j < H16; ++j) accs[j % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb[j], accs[j % NACC], 0, 0, 0);
@@ -296,8 +292,7 @@ static int launch_gemm(const float* A, int lda, const float* B, int ldb, float* 
     const int nx = ceil_div(N, BN);
     dim3 grid((unsigned)((int64_t)nx * ceil_div(M, BM)), 1, splits), block(256);
     static const int dyn_lds = getenv("DCTR_GEMM_DYN_LDS") ? atoi(getenv("DCTR_GEMM_DYN_LDS")) : 0;   // occupancy experiments
-    static const int abl = getenv("DCTR_GEMM_ABLATE") ? atoi(getenv("DCTR_GEMM_ABLATE")) : 0;          // ablation experiments (wrong results!)
-    gemm_f32_mfma<A_KC, B_NC, EPI><<<grid, block, dyn_lds, st>>>(A, lda, B, ldb, C, ldc, M, N, K, kchunk, vecA, vecB, ep, abl, nx, over);
+    gemm_f32_mfma<A_KC, B_NC, EPI><<<grid, block, dyn_lds, st>>>(A, lda, B, ldb, C, ldc, M, N, K, kchunk, vecA, vecB, ep, nx, over);
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }
