@@ -33,6 +33,7 @@ __global__ void group_reset_kernel(int32_t* __restrict__ slot, const int32_t* __
     if (last && threadIdx.x == 0) {
         counters[0] = 0;
         counters[1] = 0;
+        counters[2] = 0;
         counters[3] = 0;
     }
 }
@@ -99,11 +100,17 @@ __global__ __launch_bounds__(256) void group_count_kernel(const int32_t* __restr
     }
 }
 
+// segments at least this long are not walked in runs (their per-run atomic flushes all land on ONE 64-byte compact row: 4096
+// entries in runs of 16 = 256 flushes x 17 floats serialised at ~90 atomics/us -- 48 us, the whole scatter); a block reduces
+// chunks of them in registers + LDS and flushes once per chunk
+constexpr int LONG_SEGMENT = 256;
+constexpr int LONG_CHUNK = 256;
+
 // one thread per distinct id: carve its segment of the grouped-entry array (one atomic per block on the running total)
 __global__ __launch_bounds__(256) void group_segments_kernel(int32_t* __restrict__ slot, const int32_t* __restrict__ uniq,
                                                             int32_t* __restrict__ cnt, int32_t* __restrict__ seg_start,
                                                             int32_t* __restrict__ cursor, int32_t* __restrict__ counters,
-                                                            float* __restrict__ glin) {
+                                                            float* __restrict__ glin, int32_t* __restrict__ long_list, int long_cap) {
     __shared__ int wsum[4];
     __shared__ int bbase;
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -133,6 +140,10 @@ __global__ __launch_bounds__(256) void group_segments_kernel(int32_t* __restrict
         cursor[u] = s;
         slot[id] = u + 1;
         glin[u] = 0.f;
+        if (c >= LONG_SEGMENT) {            // a hot id (Criteo's numeric fields: every example): reduced by a block of its own
+            const int k = atomicAdd(&counters[2], 1);
+            if (k < long_cap) long_list[k] = u;
+        }
     }
 }
 
@@ -169,7 +180,34 @@ __global__ __launch_bounds__(256) void group_fill_kernel(const int32_t* __restri
     }
 }
 
-constexpr int SCATTER_RUN = 16;   // grouped positions per walker
+// grouped positions per walker: 8 measured best on c2 once the long segments have their own blocks (6: 20.2 us, 8: 20.0, 12: 22.6,
+// 16: 27.0); A/B knob DCTR_SCATTER_RUN
+
+// gradient of one grouped entry i = f*B + b w.r.t. its table row piece kq, times the entry's value
+template <int KQ, int MODE>
+__device__ __forceinline__ float4 entry_grad(int i, int kq, const float4* __restrict__ dE, int de_ld4, const float4* __restrict__ e,
+                                             int e_ld4, const float4* __restrict__ S, const float* __restrict__ coef,
+                                             const float* __restrict__ vals, int B, int F, int& b_out, float& v_out) {
+    const int f = i / B, b = i - f * B;
+    const float v = vals[(size_t)b * F + f];
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (dE != nullptr) d = dE[(size_t)b * de_ld4 + (size_t)f * KQ + kq];
+    if (MODE == DCTR_GATHER_FM) {
+        // y_v = 0.5 sum_k[(sum_f e)^2 - sum_f e^2]  =>  d y_v / d e[b,f,k] = S[b,k] - e[b,f,k]   (DeepFM.py:133-135)
+        const float4 ee = e[(size_t)b * e_ld4 + (size_t)f * KQ + kq];
+        const float4 s = S[(size_t)b * KQ + kq];
+        const float c = coef[b];
+        d.x += c * (s.x - ee.x); d.y += c * (s.y - ee.y); d.z += c * (s.z - ee.z); d.w += c * (s.w - ee.w);
+    } else if (MODE == DCTR_GATHER_BI) {
+        // bi[b,k] = 0.5[(sum_f e)^2 - sum_f e^2]  =>  d e[b,f,k] = dbi[b,k] (S[b,k] - e[b,f,k])    (NFM.py:126-128)
+        const float4 ee = e[(size_t)b * e_ld4 + (size_t)f * KQ + kq];
+        const float4 s = S[(size_t)b * KQ + kq];
+        const float4 c = reinterpret_cast<const float4*>(coef)[(size_t)b * KQ + kq];
+        d.x += c.x * (s.x - ee.x); d.y += c.y * (s.y - ee.y); d.z += c.z * (s.z - ee.z); d.w += c.w * (s.w - ee.w);
+    }
+    b_out = b; v_out = v;
+    return make_float4(d.x * v, d.y * v, d.z * v, d.w * v);
+}
 
 template <int KQ, int MODE>
 __global__ __launch_bounds__(256) void scatter_bwd_kernel(
@@ -177,13 +215,62 @@ __global__ __launch_bounds__(256) void scatter_bwd_kernel(
     const int32_t* __restrict__ seg_start, const int32_t* __restrict__ cnt,
     const float4* __restrict__ dE, int de_ld4, const float4* __restrict__ e, int e_ld4,
     const float4* __restrict__ S, const float* __restrict__ coef, const float* __restrict__ dy,
-    const float* __restrict__ vals, int B, int F, float* __restrict__ gemb, float* __restrict__ glin, int dy_ld) {
+    const float* __restrict__ vals, int B, int F, float* __restrict__ gemb, float* __restrict__ glin, int dy_ld, int run,
+    int walker_blocks, const int32_t* __restrict__ long_list, int long_cap) {
+    if ((int)blockIdx.x >= walker_blocks) {
+        // ---- long segments, cut into chunks of LONG_CHUNK entries dealt round-robin to these blocks: KQ lanes per entry,
+        // 256/KQ entries in flight per pass, tree reduction in LDS, ONE atomic flush per (chunk, row piece)
+        constexpr int EL = 256 / KQ;
+        __shared__ float4 red[256];
+        __shared__ float redl[256];
+        const int kq = threadIdx.x % KQ, el = threadIdx.x / KQ;
+        const int n_long = min(counters[2], long_cap);
+        const int NB = (int)gridDim.x - walker_blocks, blk = (int)blockIdx.x - walker_blocks;
+        int base = 0;
+        for (int li = 0; li < n_long; ++li) {
+            const int u = long_list[li];
+            const int s0 = seg_start[u], len = cnt[u];
+            const int nch = (len + LONG_CHUNK - 1) / LONG_CHUNK;
+            for (int c = ((blk - base) % NB + NB) % NB; c < nch; c += NB) {
+                const int c0 = s0 + c * LONG_CHUNK, c1 = min(s0 + len, c0 + LONG_CHUNK);
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                float accl = 0.f;
+                for (int j = c0 + el; j < c1; j += EL) {
+                    int b; float v;
+                    const float4 d = entry_grad<KQ, MODE>(perm[j], kq, dE, de_ld4, e, e_ld4, S, coef, vals, B, F, b, v);
+                    acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+                    if (kq == 0 && dy != nullptr) accl += dy[(size_t)b * dy_ld] * v;
+                }
+                red[threadIdx.x] = acc; redl[threadIdx.x] = accl;
+                __syncthreads();
+                for (int half = EL / 2; half >= 1; half >>= 1) {        // tree over the entry lanes (EL is a power of two)
+                    if (el < half) {
+                        const float4 o = red[threadIdx.x + half * KQ];
+                        float4 m = red[threadIdx.x];
+                        m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+                        red[threadIdx.x] = m;
+                        redl[threadIdx.x] += redl[threadIdx.x + half * KQ];
+                    }
+                    __syncthreads();
+                }
+                if (el == 0) {
+                    float* g = gemb + ((size_t)u * KQ + kq) * 4;
+                    const float4 m = red[kq];
+                    atomicAdd(g + 0, m.x); atomicAdd(g + 1, m.y); atomicAdd(g + 2, m.z); atomicAdd(g + 3, m.w);
+                    if (kq == 0 && glin != nullptr) atomicAdd(glin + u, redl[0]);
+                }
+                __syncthreads();
+            }
+            base += nch;
+        }
+        return;
+    }
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int w = t / KQ, kq = t % KQ;
     const int total = counters[1];
-    const int j0 = w * SCATTER_RUN;
+    const int j0 = w * run;
     if (j0 >= total) return;
-    const int jend = min(total, j0 + SCATTER_RUN);
+    const int jend = min(total, j0 + run);
     int cur = -1;
     bool inside = false;          // the current segment started inside this run
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -202,32 +289,17 @@ __global__ __launch_bounds__(256) void scatter_bwd_kernel(
     };
     for (int j = j0; j < jend; ++j) {
         const int u = seg_of[j];
-        const int i = perm[j];
-        const int f = i / B, b = i - f * B;
         if (u != cur) {
             if (cur >= 0) flush(inside);                      // ended by a key change: it ended inside the run
+            if (cnt[u] >= LONG_SEGMENT) { cur = -1; continue; }   // (a long segment: left to its block)
             inside = (j > j0) || (seg_start[u] == j0);
             cur = u;
             acc = make_float4(0.f, 0.f, 0.f, 0.f);
             accl = 0.f;
         }
-        const float v = vals[(size_t)b * F + f];
-        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (dE != nullptr) d = dE[(size_t)b * de_ld4 + (size_t)f * KQ + kq];
-        if (MODE == DCTR_GATHER_FM) {
-            // y_v = 0.5 sum_k[(sum_f e)^2 - sum_f e^2]  =>  d y_v / d e[b,f,k] = S[b,k] - e[b,f,k]   (DeepFM.py:133-135)
-            const float4 ee = e[(size_t)b * e_ld4 + (size_t)f * KQ + kq];
-            const float4 s = S[(size_t)b * KQ + kq];
-            const float c = coef[b];
-            d.x += c * (s.x - ee.x); d.y += c * (s.y - ee.y); d.z += c * (s.z - ee.z); d.w += c * (s.w - ee.w);
-        } else if (MODE == DCTR_GATHER_BI) {
-            // bi[b,k] = 0.5[(sum_f e)^2 - sum_f e^2]  =>  d e[b,f,k] = dbi[b,k] (S[b,k] - e[b,f,k])    (NFM.py:126-128)
-            const float4 ee = e[(size_t)b * e_ld4 + (size_t)f * KQ + kq];
-            const float4 s = S[(size_t)b * KQ + kq];
-            const float4 c = reinterpret_cast<const float4*>(coef)[(size_t)b * KQ + kq];
-            d.x += c.x * (s.x - ee.x); d.y += c.y * (s.y - ee.y); d.z += c.z * (s.z - ee.z); d.w += c.w * (s.w - ee.w);
-        }
-        acc.x += d.x * v; acc.y += d.y * v; acc.z += d.z * v; acc.w += d.w * v;
+        int b; float v;
+        const float4 d = entry_grad<KQ, MODE>(perm[j], kq, dE, de_ld4, e, e_ld4, S, coef, vals, B, F, b, v);
+        acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
         if (kq == 0 && dy != nullptr) accl += dy[(size_t)b * dy_ld] * v;
     }
     if (cur >= 0) flush(inside && (seg_start[cur] + cnt[cur] <= jend));
@@ -238,13 +310,16 @@ static int launch_scatter(Group* g, const float* dE, int de_ld, const float* e, 
                           const float* coef, const float* dy, const float* vals, int B, int F, int mode,
                           float* gemb, float* glin, int dy_ld, hipStream_t st) {
     const int64_t n = (int64_t)B * F;
-    const int walkers = ceil_div(n, SCATTER_RUN);
-    dim3 grid(ceil_div((int64_t)walkers * KQ, 256)), block(256);
+    static const int run = getenv("DCTR_SCATTER_RUN") ? atoi(getenv("DCTR_SCATTER_RUN")) : 8;
+    const int walkers = ceil_div(n, run);
+    const int walker_blocks = ceil_div((int64_t)walkers * KQ, 256);
+    const int long_blocks = (int)std::min<int64_t>(ceil_div(n, LONG_CHUNK), 256);
+    dim3 grid(walker_blocks + long_blocks), block(256);
 #define DCTR_SC(MODE_)                                                                                         \
     scatter_bwd_kernel<KQ, MODE_><<<grid, block, 0, st>>>(                                                     \
         g->perm, g->seg_of, g->counters, g->seg_start, g->cnt, reinterpret_cast<const float4*>(dE), de_ld / 4,                       \
         reinterpret_cast<const float4*>(e), e_ld / 4, reinterpret_cast<const float4*>(S), coef, dy, vals, B, F, \
-        gemb, glin, dy_ld)
+        gemb, glin, dy_ld, run, walker_blocks, g->long_list, (int)g->long_cap)
     switch (mode) {
         case DCTR_GATHER_RAW: DCTR_SC(DCTR_GATHER_RAW); break;
         case DCTR_GATHER_FM:  DCTR_SC(DCTR_GATHER_FM); break;
@@ -274,6 +349,8 @@ int group_create(int64_t rows, int64_t max_entries, int K, Group** out) {
     DCTR_HIP_CHECK(hipMemset(g->counters, 0, 16));
     DCTR_HIP_CHECK(hipMalloc(&g->gemb, n * K * 4));
     DCTR_HIP_CHECK(hipMalloc(&g->glin, n * 4));
+    g->long_cap = (int64_t)(n / LONG_SEGMENT) + 1;        // at most n / LONG_SEGMENT segments can be that long
+    DCTR_HIP_CHECK(hipMalloc(&g->long_list, (size_t)g->long_cap * 4));
     // the memsets above run on the null stream and may still be pending: a first use on a non-blocking stream must not overtake them
     DCTR_HIP_CHECK(hipDeviceSynchronize());
     *out = g;
@@ -283,7 +360,7 @@ int group_create(int64_t rows, int64_t max_entries, int K, Group** out) {
 int group_destroy(Group* g) {
     if (!g) return DCTR_OK;
     hipFree(g->slot); hipFree(g->uniq); hipFree(g->cnt); hipFree(g->seg_start); hipFree(g->cursor);
-    hipFree(g->perm); hipFree(g->seg_of); hipFree(g->counters); hipFree(g->gemb); hipFree(g->glin);
+    hipFree(g->perm); hipFree(g->seg_of); hipFree(g->counters); hipFree(g->gemb); hipFree(g->glin); hipFree(g->long_list);
     delete g;
     return DCTR_OK;
 }
@@ -296,7 +373,8 @@ int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st) {
     if (n <= 0) { DCTR_LAUNCH_CHECK(); return DCTR_OK; }
     const int nb = ceil_div(n, 256);
     group_count_kernel<<<nb, 256, 0, st>>>(ids, B, F, g->rows, g->slot, g->uniq, g->counters);
-    group_segments_kernel<<<nb, 256, 0, st>>>(g->slot, g->uniq, g->cnt, g->seg_start, g->cursor, g->counters, g->glin);
+    group_segments_kernel<<<nb, 256, 0, st>>>(g->slot, g->uniq, g->cnt, g->seg_start, g->cursor, g->counters, g->glin, g->long_list,
+                                             (int)g->long_cap);
     const int KQ = g->K / 4;
     dim3 fgrid(ceil_div(n * KQ, 256));
     float4* gemb4 = reinterpret_cast<float4*>(g->gemb);

@@ -41,7 +41,9 @@ struct Group {
     int32_t* cursor = nullptr;    // [max_entries]
     int32_t* perm = nullptr;      // [max_entries]
     int32_t* seg_of = nullptr;    // [max_entries]
-    int32_t* counters = nullptr;  // [4]: 0 = U (distinct ids), 1 = total grouped entries
+    int32_t* counters = nullptr;  // [4]: 0 = U (distinct ids), 1 = total grouped entries, 2 = long segments, 3 = reset ticket
+    int32_t* long_list = nullptr; // [long_cap] distinct-id indices u of the segments with >= LONG_SEGMENT entries
+    int64_t long_cap = 0;
     float* gemb = nullptr;        // [max_entries, K] compact gradient rows
     float* glin = nullptr;        // [max_entries]
 };
