@@ -116,6 +116,7 @@ _SIGS = {
     "dctr_read_scalars": ([_P, C.POINTER(C.c_float * 4), _P], C.c_int),
     "dctr_last_outputs": ([_P, C.POINTER(_P), C.POINTER(_P)], C.c_int),
     "dctr_time_kernel": ([_P, C.c_char_p, C.c_int, C.POINTER(C.c_float), _P], C.c_int),
+    "dctr_step_timer": ([_P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)], C.c_int),
     "dctr_debug_tensor": ([_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int)], C.c_int),
     "dctr_set_dense_input": ([_P, _P], C.c_int),
     "dctr_measure_copy_bw": ([C.c_size_t, C.c_int, C.POINTER(C.c_float), _P], C.c_int),

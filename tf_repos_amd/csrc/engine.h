@@ -91,6 +91,10 @@ struct dctr_engine {
     // graphs
     std::map<int, hipGraphExec_t> train_graphs, predict_graphs;
     int last_B = 0;
+    // in-step timing of the first MLP GEMM (dctr_step_timer): event pairs recorded around its launch inside the step
+    bool timer_on = false;
+    std::vector<hipEvent_t> timer_ev;   // pairs
+    size_t timer_n = 0;
     hipStream_t s_group = nullptr, s_wgrad = nullptr;   // side streams of the step DAG
     int64_t* auc_counts = nullptr;   // [4*200] tp,fn,tn,fp per threshold (tf.metrics.auc)
     float* eval_scalars = nullptr;   // [0] sum xent over the eval set, [1..] scratch

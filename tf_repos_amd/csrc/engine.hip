@@ -13,6 +13,8 @@
 
 #include "common.h"
 #include "ops.h"
+#include <functional>
+
 #include "engine.h"
 
 using namespace dctr;
@@ -355,7 +357,8 @@ int gather_from(dctr_engine* E, const float* emb, const float* lin, int64_t rows
     return DCTR_OK;
 }
 
-int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st) {
+// after_layer0: called once the first MLP layer has been enqueued (the step uses it to start the id grouping there)
+int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::function<int()>* after_layer0 = nullptr) {
     const dctr_config& c = E->cfg;
     const int F = E->F, K = E->K, D = E->D;
     if (c.model == DCTR_MODEL_AFM) return afm_forward(E, B, train, st);
@@ -371,8 +374,12 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st) {
     for (size_t i = 0; i < E->mlp.size(); ++i) {
         const Fc& fc = E->mlp[i];
         // relu(x W + b) [-> batch_norm] -> dropout (DeepFM.py:156-162): without BN the dropout rides in the GEMM epilogue
+        const bool timed = E->timer_on && train && i == 0 && E->timer_n + 2 <= E->timer_ev.size();
+        if (timed) DCTR_HIP_CHECK(hipEventRecord(E->timer_ev[E->timer_n], st));
         DCTR_TRY(fc_fwd(x, ldx, E->pp(fc.w), E->pp(fc.b), E->h[i], fc.out, B, fc.in, fc.out, 1, (train && !E->bn) ? fc.keep : 1.f,
                         seedp, 0x1000ull + i, st, 1));
+        if (timed) { DCTR_HIP_CHECK(hipEventRecord(E->timer_ev[E->timer_n + 1], st)); E->timer_n += 2; }
+        if (i == 0 && after_layer0 != nullptr) DCTR_TRY((*after_layer0)());
         x = E->h[i]; ldx = fc.out;
         if (E->bn) {
             DCTR_TRY(bn_forward(E->h[i], fc.out, B, fc.out, train, 1e-3f, c.batch_norm_decay, E->pp(fc.bn_gamma), E->pp(fc.bn_beta),
@@ -609,13 +616,20 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, sw));
     DCTR_TRY(forward_gather(E, B, st));
     DCTR_TRY(fork(E, sw, st));              // (before the fork below: sg's table pass needs this step's lr_t and zeroed scalars)
-    DCTR_TRY(fork(E, st, sg));              // grouping starts after the gather (its atomics slow a concurrent gather 4x)
-    DCTR_TRY(group_ids(E->group, E->ids, B, E->F, sg));
     static const bool no_split = getenv("DCTR_NO_SPLIT_TABLE") != nullptr;      // A/B knob
     const bool split_table = E->cfg.table_mode == DCTR_TABLE_DENSE_EXACT && !no_split;
     static const bool bg_late = getenv("DCTR_BG_LATE") != nullptr;              // A/B knob: background table pass beside the backward
-    if (split_table && !bg_late) DCTR_TRY(step_untouched_rows(E, sg));
-    DCTR_TRY(forward_rest(E, B, true, st));
+    static const int group_after = getenv("DCTR_GROUP_AFTER") ? atoi(getenv("DCTR_GROUP_AFTER")) : 0;   // A/B knob: 0 = after the gather, 1 = after MLP layer 0
+    // the id grouping (and the background table pass behind it) on the grouping stream
+    const std::function<int()> start_grouping = [&]() -> int {
+        DCTR_TRY(fork(E, st, sg));          // not before the gather (its atomics slow a concurrent gather 4x)
+        DCTR_TRY(group_ids(E->group, E->ids, B, E->F, sg));
+        if (split_table && !bg_late) DCTR_TRY(step_untouched_rows(E, sg));
+        return DCTR_OK;
+    };
+    const bool have_mlp = !E->mlp.empty() && E->cfg.model != DCTR_MODEL_AFM;
+    if (!(group_after == 1 && have_mlp)) DCTR_TRY(start_grouping());
+    DCTR_TRY(forward_rest(E, B, true, st, (group_after == 1 && have_mlp) ? &start_grouping : nullptr));
     DCTR_TRY(head(E, B, B, true, st, nullptr, true));
     const bool fused_opt = E->cfg.model != DCTR_MODEL_AFM;
     if (fused_opt && E->head_did_out_bwd) {
@@ -753,6 +767,7 @@ int dctr_destroy(dctr_handle E) {
     if (E->group_alt) group_destroy(E->group_alt);
     if (E->xmvm) hipFree(E->xmvm);
     if (E->dxmvm) hipFree(E->dxmvm);
+    for (auto& ev : E->timer_ev) if (ev) hipEventDestroy(ev);
     for (float* p : E->hbn) hipFree(p);
     for (float* p : E->bn_stats) hipFree(p);
     if (E->bn_scratch) hipFree(E->bn_scratch);
@@ -910,6 +925,34 @@ int dctr_input_slot(dctr_handle E, int slot, int32_t** d_ids, float** d_vals, fl
     if (d_ids) *d_ids = E->slot_ids[slot];
     if (d_vals) *d_vals = E->slot_vals[slot];
     if (d_labels) *d_labels = E->slot_labels[slot];
+    return DCTR_OK;
+}
+
+// In-step duration of the first MLP layer's forward GEMM (the `roofline` kernel of bench.py): hipEvents recorded on the step's
+// own stream right around that launch, so the figure is the kernel as it runs INSIDE the step (beside the grouping / background
+// table pass), comparable with rocprofv3's per-kernel trace.  enable=1 arms up to 4096 steps; the read averages and disarms.
+int dctr_step_timer(dctr_handle E, int enable, float* h_avg_ms, int* h_count) {
+    DCTR_REQUIRE(E, "null handle");
+    if (enable) {
+        if (E->timer_ev.empty()) {
+            E->timer_ev.resize(8192);
+            for (auto& ev : E->timer_ev) DCTR_HIP_CHECK(hipEventCreate(&ev));
+        }
+        E->timer_n = 0;
+        E->timer_on = true;
+        return DCTR_OK;
+    }
+    E->timer_on = false;
+    double tot = 0.0;
+    int n = 0;
+    for (size_t i = 0; i + 1 < E->timer_n; i += 2) {
+        DCTR_HIP_CHECK(hipEventSynchronize(E->timer_ev[i + 1]));
+        float ms = 0.f;
+        DCTR_HIP_CHECK(hipEventElapsedTime(&ms, E->timer_ev[i], E->timer_ev[i + 1]));
+        tot += ms; ++n;
+    }
+    if (h_avg_ms) *h_avg_ms = n ? (float)(tot / n) : 0.f;
+    if (h_count) *h_count = n;
     return DCTR_OK;
 }
 

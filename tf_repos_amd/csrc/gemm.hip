@@ -107,6 +107,9 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(
     float* const Bs0 = smem + 2 * ABUF;
     float* const Bs1 = smem + 2 * ABUF + BBUF;
 
+    // the step runs background kernels (id grouping, the table pass over untouched rows) beside the MLP: GEMM waves go first at
+    // the SIMD's issue arbiter
+    __builtin_amdgcn_s_setprio(3);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;

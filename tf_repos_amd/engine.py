@@ -229,6 +229,12 @@ class Engine:
         capi.check(self._lib.dctr_time_kernel(self._h, stage.encode(), iters, C.byref(ms), st))
         return ms.value
 
+    def step_timer(self, enable: bool):
+        """Arms (True) / reads (False -> (avg_ms, count)) the in-step timer of the first MLP layer's forward GEMM."""
+        ms, n = C.c_float(), C.c_int()
+        capi.check(self._lib.dctr_step_timer(self._h, int(enable), C.byref(ms), C.byref(n)))
+        return None if enable else (ms.value, n.value)
+
     @staticmethod
     def measure_copy_bandwidth(nbytes: int = 1 << 30, iters: int = 20, stream=None) -> float:
         """GB/s (read + write) of a streaming float4 copy: the measured HBM roofline of this box."""
