@@ -353,7 +353,7 @@ int choose_wgrad_splits(int M, int K, int N) {
     int s = ceil_div(1024, tiles);                 // aim at ~4 blocks per CU
     const int max_by_m = ceil_div(M, 4 * BK);      // keep >= 4 k-steps per split
     if (s > max_by_m) s = max_by_m;
-    if (s > 32) s = 32;
+    if (s > 256) s = 256;          // (AFM's attention wgrad: a 16 x 256 output over 3 M pair rows -- 4 tiles, so the batch split is all there is)
     if (s < 1) s = 1;
     return s;
 }

@@ -1,0 +1,50 @@
+"""Step time of the other BASELINE configs (parity-test cases, not the headline bench): c1 DeepFM B=256 V=117581 K=8, c3 DCN,
+c4 PNN(inner) / NFM at B=8192 K=32, plus AFM and DeepMVM at c2's shape.  One JSON line per config.
+usage (GPU box): python tools/config_bench.py [steps]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from tf_repos_amd.engine import Engine, EngineConfig
+from tf_repos_amd.synth import synth_batch
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+CONFIGS = {
+    "c1 DeepFM B=256 V=117581 K=8 MLP 400x3": dict(model="deepfm", B=256, V=117581, K=8, layers=(400, 400, 400)),
+    "c2 DeepFM B=4096 V=1e6 K=16 MLP 400x3": dict(model="deepfm", B=4096, V=1_000_000, K=16, layers=(400, 400, 400)),
+    "c3 DCN B=4096 V=1e6 K=16 cross 3 MLP 400x2": dict(model="dcn", B=4096, V=1_000_000, K=16, layers=(400, 400), cross=3),
+    "c4 PNN-inner B=8192 V=1e6 K=32 MLP 256-128": dict(model="ipnn", B=8192, V=1_000_000, K=32, layers=(256, 128)),
+    "c4 NFM B=8192 V=1e6 K=32 MLP 256-128": dict(model="nfm", B=8192, V=1_000_000, K=32, layers=(256, 128)),
+    "AFM B=4096 V=1e6 K=16 att 256": dict(model="afm", B=4096, V=1_000_000, K=16, layers=(1,), att=(256,)),
+    "DeepMVM B=4096 V=1e6 K=16 MLP 400x3": dict(model="mvm", B=4096, V=1_000_000, K=16, layers=(400, 400, 400)),
+}
+dev = torch.device("cuda", 0)
+for name, c in CONFIGS.items():
+    keep = (0.5,) * max(len(c["layers"]), 2)
+    eng = Engine(EngineConfig(model=c["model"], field_size=39, feature_size=c["V"], embedding_size=c["K"], deep_layers=c["layers"],
+                              dropout=keep, cross_layers=c.get("cross", 3), attention_layers=c.get("att", (256,)), l2_reg=1e-4,
+                              learning_rate=5e-4, optimizer="Adam", max_batch=c["B"], seed=1))
+    rng = np.random.default_rng(1)
+    for pn, shp in eng.param_shapes.items():
+        eng.set_param(pn, rng.normal(0, 0.01, size=shp).astype(np.float32))
+    batches = []
+    for i in range(4):
+        ids, vals, labels = synth_batch(c["B"], 39, c["V"], seed=100 + i)
+        si, sv, sl = eng.input_slot(i)
+        si[:c["B"]].copy_(torch.from_numpy(ids)); sv[:c["B"]].copy_(torch.from_numpy(vals)); sl[:c["B"]].copy_(torch.from_numpy(labels))
+        batches.append((si[:c["B"]], sv[:c["B"]], sl[:c["B"]]))
+    for s in range(10):
+        eng.train_step(*batches[s % 4], want_loss=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        eng.train_step(*batches[s % 4], want_loss=False)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(json.dumps({"config": name, "ms_per_step": round(1e3 * el / steps, 4), "examples_per_sec": round(c["B"] * steps / el, 1)}), flush=True)
+    eng.close()
