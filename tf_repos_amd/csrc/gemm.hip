@@ -350,7 +350,8 @@ int sum_partials(const float* part, int64_t stride, int splits, int64_t n, float
 
 int choose_wgrad_splits(int M, int K, int N) {
     const int tiles = ceil_div(K, BM) * ceil_div(N, BN);
-    int s = ceil_div(1024, tiles);                 // aim at ~4 blocks per CU
+    static const int target = getenv("DCTR_WGRAD_BLOCKS") ? atoi(getenv("DCTR_WGRAD_BLOCKS")) : 1024;    // A/B knob
+    int s = ceil_div(target, tiles);               // aim at ~4 blocks per CU
     const int max_by_m = ceil_div(M, 4 * BK);      // keep >= 4 k-steps per split
     if (s > max_by_m) s = max_by_m;
     if (s > 256) s = 256;          // (AFM's attention wgrad: a 16 x 256 output over 3 M pair rows -- 4 tiles, so the batch split is all there is)
