@@ -124,7 +124,7 @@ int build(dctr_engine* E) {
         E->p_cross_b = add_param(E, "cross_b", {c.cross_layers, D}, false, 32, c.l2_reg);
         E->p_cross_w = add_param(E, "cross_w", {c.cross_layers, D}, false, 32, c.l2_reg);
     } else if (mvm) {
-        E->p_mvm_b = add_param(E, "mvm_b", {F, K}, false, 64, c.l2_reg);        // DeepMVM.py:118, in the loss (:197-199)
+        E->p_mvm_b = add_param(E, "mvm_b", {F, K}, false, 256, c.l2_reg);       // DeepMVM.py:118, in the loss (:197-199); 256 slabs = 256 blocks in mvm_bwd
     } else if (has_lin) {
         E->p_bias = add_param(E, "bias", {1}, false, E->out_splits, 0.f);
         add_param(E, "linear", {E->rows}, true, 1, c.l2_reg);
