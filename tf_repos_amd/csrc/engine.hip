@@ -271,8 +271,10 @@ int build(dctr_engine* E) {
             if (v == nullptr) return dflt;
             return v[0] == 'h' ? greatest : (v[0] == 'l' ? least : 0);
         };
-        DCTR_HIP_CHECK(hipStreamCreateWithPriority(&E->s_group, hipStreamNonBlocking, prio("DCTR_PRIO_GROUP", least)));
-        DCTR_HIP_CHECK(hipStreamCreateWithPriority(&E->s_wgrad, hipStreamNonBlocking, prio("DCTR_PRIO_WGRAD", greatest)));
+        // (use_graph: a graph captured across streams of different priorities replays 2.7x slower -- measured on c1 -- so the
+        //  graph mode keeps plain streams)
+        DCTR_HIP_CHECK(hipStreamCreateWithPriority(&E->s_group, hipStreamNonBlocking, c.use_graph ? 0 : prio("DCTR_PRIO_GROUP", least)));
+        DCTR_HIP_CHECK(hipStreamCreateWithPriority(&E->s_wgrad, hipStreamNonBlocking, c.use_graph ? 0 : prio("DCTR_PRIO_WGRAD", greatest)));
     }
     E->events.resize(64);
     for (auto& ev : E->events) DCTR_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
