@@ -175,6 +175,17 @@ int dctr_embed_scatter_bwd(dctr_group_t g, const float* d_dE, int de_ld,
                            int B, int F, int K, int mode,
                            float* d_gemb, float* d_glin, void* stream);
 
+/* ---- K2/K8 over CSR batches: tf.nn.embedding_lookup_sparse(params, sp_ids, sp_weights, combiner="sum") of the DIN / ESMM
+ * scripts (DIN.py:148,180-183; DeepCvrMTL.py:155-159).  d_offsets [B+1] row pointers into d_ids / d_weights [nnz]
+ * (d_weights NULL = all ones, DIN.py:148).
+ *   fwd: d_out[b, 0:K] = sum_j weights[j] * emb[ids[j], :]  (row stride out_ld floats; an empty row gives zeros)
+ *   bwd: groups the nnz ids in `g` (created with max_entries >= nnz) and leaves the per-distinct-id gradient rows in its
+ *        compact buffers (dctr_group_buffers: uniq / gemb), ready for dctr_opt_table; d_entry_row [nnz] is scratch */
+int dctr_embed_lookup_sparse_fwd(const float* d_emb, int64_t rows, int K, const int32_t* d_offsets, const int32_t* d_ids,
+                                 const float* d_weights, int B, float* d_out, int out_ld, int32_t* d_status, void* stream);
+int dctr_embed_lookup_sparse_bwd(dctr_group_t g, const float* d_dout, int dout_ld, const int32_t* d_offsets, const int32_t* d_ids,
+                                 const float* d_weights, int B, int nnz, int K, int32_t* d_entry_row, void* stream);
+
 /* ---- K9: optimizers (DeepFM.py:204-213), TF-1.4 update rules.
  * `hyper`: Adam {lr, beta1, beta2, eps, t}; Adagrad {lr}; Momentum {lr, momentum}; Ftrl {lr}.
  * slot0/slot1: Adam m/v, Adagrad accum/-, Momentum accum/-, Ftrl accum/linear.

@@ -187,9 +187,14 @@ __global__ __launch_bounds__(256) void group_fill_kernel(const int32_t* __restri
 template <int KQ, int MODE>
 __device__ __forceinline__ float4 entry_grad(int i, int kq, const float4* __restrict__ dE, int de_ld4, const float4* __restrict__ e,
                                              int e_ld4, const float4* __restrict__ S, const float* __restrict__ coef,
-                                             const float* __restrict__ vals, int B, int F, int& b_out, float& v_out) {
-    const int f = i / B, b = i - f * B;
-    const float v = vals[(size_t)b * F + f];
+                                             const float* __restrict__ vals, int B, int F, int& b_out, float& v_out,
+                                             const int32_t* __restrict__ entry_row) {
+    // fixed-F batches: entry i = f*B + b, value vals[b,f].  CSR batches (entry_row != nullptr, F == 1): entry i belongs to
+    // example entry_row[i] (whose gradient row it reads), value vals[i] (or 1)
+    int f = i / B, b = i - f * B;
+    float v;
+    if (entry_row != nullptr) { v = vals != nullptr ? vals[i] : 1.0f; b = entry_row[i]; f = 0; }
+    else v = vals[(size_t)b * F + f];
     float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
     if (dE != nullptr) d = dE[(size_t)b * de_ld4 + (size_t)f * KQ + kq];
     if (MODE == DCTR_GATHER_FM) {
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(256) void scatter_bwd_kernel(
     const float4* __restrict__ dE, int de_ld4, const float4* __restrict__ e, int e_ld4,
     const float4* __restrict__ S, const float* __restrict__ coef, const float* __restrict__ dy,
     const float* __restrict__ vals, int B, int F, float* __restrict__ gemb, float* __restrict__ glin, int dy_ld, int run,
-    int walker_blocks, const int32_t* __restrict__ long_list, int long_cap) {
+    int walker_blocks, const int32_t* __restrict__ long_list, int long_cap, const int32_t* __restrict__ entry_row) {
     if ((int)blockIdx.x >= walker_blocks) {
         // ---- long segments, cut into chunks of LONG_CHUNK entries dealt round-robin to these blocks: KQ lanes per entry,
         // 256/KQ entries in flight per pass, tree reduction in LDS, ONE atomic flush per (chunk, row piece)
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(256) void scatter_bwd_kernel(
                 float accl = 0.f;
                 for (int j = c0 + el; j < c1; j += EL) {
                     int b; float v;
-                    const float4 d = entry_grad<KQ, MODE>(perm[j], kq, dE, de_ld4, e, e_ld4, S, coef, vals, B, F, b, v);
+                    const float4 d = entry_grad<KQ, MODE>(perm[j], kq, dE, de_ld4, e, e_ld4, S, coef, vals, B, F, b, v, entry_row);
                     acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
                     if (kq == 0 && dy != nullptr) accl += dy[(size_t)b * dy_ld] * v;
                 }
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(256) void scatter_bwd_kernel(
             accl = 0.f;
         }
         int b; float v;
-        const float4 d = entry_grad<KQ, MODE>(perm[j], kq, dE, de_ld4, e, e_ld4, S, coef, vals, B, F, b, v);
+        const float4 d = entry_grad<KQ, MODE>(perm[j], kq, dE, de_ld4, e, e_ld4, S, coef, vals, B, F, b, v, entry_row);
         acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
         if (kq == 0 && dy != nullptr) accl += dy[(size_t)b * dy_ld] * v;
     }
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(256) void scatter_bwd_kernel(
 template <int KQ>
 static int launch_scatter(Group* g, const float* dE, int de_ld, const float* e, int e_ld, const float* S,
                           const float* coef, const float* dy, const float* vals, int B, int F, int mode,
-                          float* gemb, float* glin, int dy_ld, hipStream_t st) {
+                          float* gemb, float* glin, int dy_ld, hipStream_t st, const int32_t* entry_row) {
     const int64_t n = (int64_t)B * F;
     static const int run = getenv("DCTR_SCATTER_RUN") ? atoi(getenv("DCTR_SCATTER_RUN")) : 8;
     const int walkers = ceil_div(n, run);
@@ -319,7 +324,7 @@ static int launch_scatter(Group* g, const float* dE, int de_ld, const float* e, 
     scatter_bwd_kernel<KQ, MODE_><<<grid, block, 0, st>>>(                                                     \
         g->perm, g->seg_of, g->counters, g->seg_start, g->cnt, reinterpret_cast<const float4*>(dE), de_ld / 4,                       \
         reinterpret_cast<const float4*>(e), e_ld / 4, reinterpret_cast<const float4*>(S), coef, dy, vals, B, F, \
-        gemb, glin, dy_ld, run, walker_blocks, g->long_list, (int)g->long_cap)
+        gemb, glin, dy_ld, run, walker_blocks, g->long_list, (int)g->long_cap, entry_row)
     switch (mode) {
         case DCTR_GATHER_RAW: DCTR_SC(DCTR_GATHER_RAW); break;
         case DCTR_GATHER_FM:  DCTR_SC(DCTR_GATHER_FM); break;
@@ -391,7 +396,7 @@ int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st) {
 
 int embed_scatter_bwd(Group* g, const float* dE, int de_ld, const float* e, int e_ld, const float* S,
                       const float* coef, const float* dy, const float* vals, int B, int F, int K, int mode,
-                      float* gemb, float* glin, hipStream_t st, int dy_ld) {
+                      float* gemb, float* glin, hipStream_t st, int dy_ld, const int32_t* entry_row) {
     DCTR_REQUIRE(K == g->K, "scatter: K=%d but group was created with K=%d", K, g->K);
     DCTR_REQUIRE(dE == nullptr || de_ld % 4 == 0, "scatter: de_ld must be a multiple of 4");
     DCTR_REQUIRE(mode == DCTR_GATHER_RAW || (e != nullptr && S != nullptr && coef != nullptr && e_ld % 4 == 0),
@@ -399,7 +404,7 @@ int embed_scatter_bwd(Group* g, const float* dE, int de_ld, const float* e, int 
     if (gemb == nullptr) gemb = g->gemb;
     if (glin == nullptr && dy != nullptr) glin = g->glin;
     switch (K / 4) {
-#define DCTR_L(Q) case Q: return launch_scatter<Q>(g, dE, de_ld, e, e_ld, S, coef, dy, vals, B, F, mode, gemb, glin, dy_ld, st)
+#define DCTR_L(Q) case Q: return launch_scatter<Q>(g, dE, de_ld, e, e_ld, S, coef, dy, vals, B, F, mode, gemb, glin, dy_ld, st, entry_row)
         DCTR_L(1); DCTR_L(2); DCTR_L(4); DCTR_L(8); DCTR_L(16); DCTR_L(32); DCTR_L(64);
 #undef DCTR_L
         default: set_error("scatter: K=%d unsupported", K); return DCTR_ERR_UNSUPPORTED;

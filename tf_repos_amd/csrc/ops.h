@@ -54,7 +54,8 @@ int group_destroy(Group* g);
 int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st);
 int embed_scatter_bwd(Group* g, const float* dE, int de_ld, const float* e, int e_ld, const float* S,
                       const float* coef, const float* dy, const float* vals, int B, int F, int K, int mode,
-                      float* gemb, float* glin, hipStream_t st, int dy_ld = 1);   // dy_ld: stride (floats) between examples in dy
+                      float* gemb, float* glin, hipStream_t st, int dy_ld = 1,     // dy_ld: stride (floats) between examples in dy
+                      const int32_t* entry_row = nullptr);                       // CSR batches: example of every entry (F == 1, vals per entry)
 
 // ---- K2 (gather.hip)
 int embed_gather_fwd(const float* emb, const float* lin, int64_t rows, const int32_t* ids, const float* vals,

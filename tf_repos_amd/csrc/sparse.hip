@@ -1,0 +1,87 @@
+// Variable-length (multi-hot) lookups: tf.nn.embedding_lookup_sparse(params, sp_ids, sp_weights, combiner="sum") as the
+// DIN / ESMM scripts use it (DIN.py:148,180-183; DeepCvrMTL.py:155-159) = gather + weight + segment sum over a CSR batch
+// (K2/K8 generalised from fixed-F to CSR).  Op-level entry points; the DIN / ESMM models themselves are not
+// built yet.
+//   forward : out[b, :] = sum_{j in [offsets[b], offsets[b+1])} weights[j] * emb[ids[j], :]        (empty row -> zeros)
+//   backward: the IndexedSlices gradient, segment-summed per distinct id into a dctr_group's compact rows (group.hip),
+//             ready for dctr_opt_table -- the same machinery as the fixed-F path, with a per-entry example index
+#include "ops.h"
+
+namespace dctr {
+
+template <int KQ>
+__global__ __launch_bounds__(256) void lookup_sparse_fwd_kernel(const float4* __restrict__ emb, int64_t rows, const int32_t* __restrict__ offsets,
+                                                               const int32_t* __restrict__ ids, const float* __restrict__ weights, int B,
+                                                               float4* __restrict__ out, int out_ld4, int32_t* __restrict__ status) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = t / KQ, kq = t % KQ;
+    if (b >= B) return;
+    const int j0 = offsets[b], j1 = offsets[b + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = j0; j < j1; ++j) {
+        const int id = ids[j];
+        if (id < 0 || (int64_t)id >= rows) {            // TF CPU gather: InvalidArgumentError [TF-1.4]
+            if (kq == 0) { atomicExch(&status[1], id); atomicExch(&status[0], 1); }
+            continue;
+        }
+        const float w = weights != nullptr ? weights[j] : 1.0f;
+        const float4 r = emb[(size_t)id * KQ + kq];
+        acc.x += w * r.x; acc.y += w * r.y; acc.z += w * r.z; acc.w += w * r.w;
+    }
+    out[(size_t)b * out_ld4 + kq] = acc;
+}
+
+// entry_row[j] = b for offsets[b] <= j < offsets[b+1]   (binary search per entry)
+__global__ __launch_bounds__(256) void entry_row_kernel(const int32_t* __restrict__ offsets, int B, int nnz, int32_t* __restrict__ entry_row) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nnz) return;
+    int lo = 0, hi = B;                                  // invariant: offsets[lo] <= j < offsets[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offsets[mid] <= j) lo = mid; else hi = mid;
+    }
+    entry_row[j] = lo;
+}
+
+}  // namespace dctr
+
+using namespace dctr;
+
+extern "C" {
+
+int dctr_embed_lookup_sparse_fwd(const float* d_emb, int64_t rows, int K, const int32_t* d_offsets, const int32_t* d_ids,
+                                 const float* d_weights, int B, float* d_out, int out_ld, int32_t* d_status, void* stream) {
+    DCTR_REQUIRE(d_emb && d_offsets && d_ids && d_out && d_status, "null argument");
+    DCTR_REQUIRE(K % 4 == 0 && K >= 4 && K <= 256 && out_ld % 4 == 0 && out_ld >= K, "lookup_sparse: K=%d / out_ld=%d unsupported", K, out_ld);
+    if (B <= 0) return DCTR_OK;
+    const int KQ = K / 4;
+    const int grid = ceil_div((int64_t)B * KQ, 256);
+    hipStream_t st = as_stream(stream);
+    const float4* e4 = reinterpret_cast<const float4*>(d_emb);
+    float4* o4 = reinterpret_cast<float4*>(d_out);
+    switch (KQ) {
+#define DCTR_S(Q) case Q: lookup_sparse_fwd_kernel<Q><<<grid, 256, 0, st>>>(e4, rows, d_offsets, d_ids, d_weights, B, o4, out_ld / 4, d_status); break
+        DCTR_S(1); DCTR_S(2); DCTR_S(4); DCTR_S(8); DCTR_S(16); DCTR_S(32); DCTR_S(64);
+#undef DCTR_S
+        default: set_error("lookup_sparse: K=%d unsupported (K/4 must be a power of two)", K); return DCTR_ERR_UNSUPPORTED;
+    }
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+int dctr_embed_lookup_sparse_bwd(dctr_group_t g, const float* d_dout, int dout_ld, const int32_t* d_offsets, const int32_t* d_ids,
+                                 const float* d_weights, int B, int nnz, int K, int32_t* d_entry_row, void* stream) {
+    DCTR_REQUIRE(g && d_dout && d_offsets && d_ids && d_entry_row, "null argument");
+    Group* G = reinterpret_cast<Group*>(g);
+    hipStream_t st = as_stream(stream);
+    DCTR_REQUIRE(nnz >= 0 && (int64_t)nnz <= G->max_entries, "lookup_sparse_bwd: nnz=%d exceeds the group's capacity", nnz);
+    DCTR_TRY(group_ids(G, d_ids, nnz, 1, st));
+    if (nnz == 0 || B <= 0) return DCTR_OK;
+    entry_row_kernel<<<ceil_div(nnz, 256), 256, 0, st>>>(d_offsets, B, nnz, d_entry_row);
+    DCTR_LAUNCH_CHECK();
+    // nnz "examples" of one field: entry j reads the gradient row of example entry_row[j], scaled by weights[j]
+    return embed_scatter_bwd(G, d_dout, dout_ld, nullptr, 0, nullptr, nullptr, nullptr, d_weights, nnz, 1, K, DCTR_GATHER_RAW, G->gemb,
+                             nullptr, st, 1, d_entry_row);
+}
+
+}  // extern "C"
