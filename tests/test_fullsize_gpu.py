@@ -135,3 +135,25 @@ def test_edge_batches(case, dev):
     for k, v in params.items():
         assert np.abs(got[k] - v.numpy()).max() <= 5e-6, (case, k)
     eng.close()
+
+
+def test_c4_outer_pnn_at_k32(dev):
+    """c4's outer-product PNN at its real embedding size (K=32: 741 pairs x 1024 products = 758 784 extra MLP inputs per example,
+    PNN.py:154-167), batch reduced so that the oracle's [B, 758784] einsum fits the host; the full c4 batch (8192) runs
+    materialised in 2 x 24.9 GB on the GPU (tools/config_bench.py: 149 ms/step)."""
+    B, K, Vs = 128, 32, 100_000
+    ocfg, params, eng = make_pair("opnn", B=B, F=F, V=Vs, K=K, layers=(64, 32), opt="Adam", l2=1e-4, lr=5e-4, scale=0.02, use_graph=False)
+    ids, vals, labels = O.synth_batch(B, F, Vs, seed=77)
+    d = dev_batch(ids, vals, labels, dev)
+    ref = O.forward(ocfg, params, ids, vals)
+    logit = torch.empty(B, device=dev)
+    eng.predict(d[0], d[1], torch.empty(B, device=dev), logit)
+    assert np.abs(logit.cpu().numpy() - ref["y"].numpy()).max() <= 1e-4
+    oopt = O.Optimizer(ocfg, params)
+    ref_loss, _ = O.train_step(ocfg, params, oopt, ids, vals, labels)
+    loss = eng.train_step(*d)
+    assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+    got = eng.get_params()
+    for k in ("mlp0/weights", "mlp0/biases", "deep_out/weights", "bias"):
+        assert np.abs(got[k] - params[k].numpy()).max() <= 2e-6, k
+    eng.close()

@@ -14,17 +14,22 @@ from tf_repos_amd.engine import Engine, EngineConfig
 from tf_repos_amd.synth import synth_batch
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+only = sys.argv[2] if len(sys.argv) > 2 else None
 CONFIGS = {
     "c1 DeepFM B=256 V=117581 K=8 MLP 400x3": dict(model="deepfm", B=256, V=117581, K=8, layers=(400, 400, 400)),
     "c2 DeepFM B=4096 V=1e6 K=16 MLP 400x3": dict(model="deepfm", B=4096, V=1_000_000, K=16, layers=(400, 400, 400)),
     "c3 DCN B=4096 V=1e6 K=16 cross 3 MLP 400x2": dict(model="dcn", B=4096, V=1_000_000, K=16, layers=(400, 400), cross=3),
     "c4 PNN-inner B=8192 V=1e6 K=32 MLP 256-128": dict(model="ipnn", B=8192, V=1_000_000, K=32, layers=(256, 128)),
     "c4 NFM B=8192 V=1e6 K=32 MLP 256-128": dict(model="nfm", B=8192, V=1_000_000, K=32, layers=(256, 128)),
+    "c4 PNN-outer B=8192 V=1e6 K=32 MLP 256-128 (P*K^2 = 758784 outer-product inputs materialised: 2 x 24.9 GB)":
+        dict(model="opnn", B=8192, V=1_000_000, K=32, layers=(256, 128), steps=5),
     "AFM B=4096 V=1e6 K=16 att 256": dict(model="afm", B=4096, V=1_000_000, K=16, layers=(1,), att=(256,)),
     "DeepMVM B=4096 V=1e6 K=16 MLP 400x3": dict(model="mvm", B=4096, V=1_000_000, K=16, layers=(400, 400, 400)),
 }
 dev = torch.device("cuda", 0)
 for name, c in CONFIGS.items():
+    if only is not None and only not in name:
+        continue
     keep = (0.5,) * max(len(c["layers"]), 2)
     eng = Engine(EngineConfig(model=c["model"], field_size=39, feature_size=c["V"], embedding_size=c["K"], deep_layers=c["layers"],
                               dropout=keep, cross_layers=c.get("cross", 3), attention_layers=c.get("att", (256,)), l2_reg=1e-4,
@@ -38,13 +43,14 @@ for name, c in CONFIGS.items():
         si, sv, sl = eng.input_slot(i)
         si[:c["B"]].copy_(torch.from_numpy(ids)); sv[:c["B"]].copy_(torch.from_numpy(vals)); sl[:c["B"]].copy_(torch.from_numpy(labels))
         batches.append((si[:c["B"]], sv[:c["B"]], sl[:c["B"]]))
-    for s in range(10):
+    steps_c = c.get("steps", steps)
+    for s in range(min(10, steps_c)):
         eng.train_step(*batches[s % 4], want_loss=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for s in range(steps):
+    for s in range(steps_c):
         eng.train_step(*batches[s % 4], want_loss=False)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    print(json.dumps({"config": name, "ms_per_step": round(1e3 * el / steps, 4), "examples_per_sec": round(c["B"] * steps / el, 1)}), flush=True)
+    print(json.dumps({"config": name, "ms_per_step": round(1e3 * el / steps_c, 4), "examples_per_sec": round(c["B"] * steps_c / el, 1)}), flush=True)
     eng.close()
