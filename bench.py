@@ -117,7 +117,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        trainer = ShardedTrainer(w, rank, world, dev, table_mode=args.table_mode)
+        try:
+            trainer = ShardedTrainer(w, rank, world, dev, table_mode=args.table_mode)        # native C++ driver over RCCL
+        except Exception as e:                                                                # noqa: BLE001
+            # the same row-sharded protocol orchestrated from Python through torch.distributed (slower host side, same results)
+            print("rank %d: native sharded driver unavailable (%s); using the torch.distributed driver" % (rank, e), file=sys.stderr, flush=True)
+            trainer = ShardedTrainer(w, rank, world, dev, table_mode=args.table_mode, driver="python")
         step = lambda i, v, l, nxt: trainer.train_step(i, v, l, next_ids=nxt)      # routes the next batch's ids a step ahead
         barrier = dist.barrier
     else:
