@@ -182,3 +182,28 @@ def test_deepmvm_product_layer_with_factors_near_one(opt, dev):
     for name, refv in params.items():
         assert np.abs(got[name] - refv.numpy()).max() <= 5e-6, name
     eng.close()
+
+
+@pytest.mark.parametrize("K,A", [(4, 16), (8, 48), (16, 100), (16, 256), (32, 64), (8, 300)])
+def test_afm_attention_widths(K, A, dev):
+    """The attention network runs fused over the pair rows for K in {4,8,16,32}, A <= 256 (hidden width padded to 32/64/128/256
+    columns in LDS) and through the GEMM path otherwise ((8,300)); both must match AFM.py:141-166 with the same tolerances."""
+    F, V, B = 13, 2000, 70          # B*P = 5460 pair rows: a ragged last 32-row tile
+    ocfg, params, eng = make_pair("afm", B=B, F=F, V=V, K=K, layers=(1,), att=(A,), opt="Adagrad", lr=1e-2)
+    oopt = O.Optimizer(ocfg, params)
+    for step in range(2):
+        ids, vals, labels = O.synth_batch(B, F, V, seed=300 + step)
+        ref_loss, _ = O.train_step(ocfg, params, oopt, ids, vals, labels)
+        loss = eng.train_step(*dev_batch(ids, vals, labels, dev))
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (step, loss, ref_loss)
+    got = eng.get_params()
+    for name, ref in params.items():
+        diff = np.abs(got[name] - ref.numpy()).max()
+        assert diff <= 2e-6, (name, diff)
+    ids, vals, labels = O.synth_batch(B, F, V, seed=9)
+    d_ids, d_vals, _ = dev_batch(ids, vals, labels, dev)
+    logit = torch.empty(B, device=dev)
+    eng.predict(d_ids, d_vals, torch.empty(B, device=dev), logit)
+    torch.cuda.synchronize()
+    assert np.abs(logit.cpu().numpy() - O.forward(ocfg, params, ids, vals)["y"].numpy()).max() <= 1e-4
+    eng.close()

@@ -71,75 +71,93 @@ __global__ __launch_bounds__(256) void afm_pool_fwd_kernel(const float* __restri
         sm[p] = (train && keep_att < 1.f) ? a * dropout_scale(seed ^ 0xA0ull, (uint64_t)b * P + p, keep_att) : a;
     }
     __syncthreads();
-    const float* ppb = pp + (size_t)b * P * K;
-    for (int k = t; k < K; k += 256) {
-        float acc = 0.f;
-        for (int p = 0; p < P; ++p) acc += sm[p] * ppb[(size_t)p * K + k];
-        if (train && keep_emb < 1.f) acc *= dropout_scale(seed ^ 0xA1ull, (uint64_t)b * K + k, keep_emb);
-        yemb[(size_t)b * K + k] = acc;
+    // y_emb[k] = sum_p a'[p] pp[p,k]: thread = (pair slice, float4 piece), slices summed through LDS
+    __shared__ float4 acc4[256];
+    const int KQ = K >> 2, q = t % KQ, slice = t / KQ, n_slices = 256 / KQ;
+    const float4* pp4 = reinterpret_cast<const float4*>(pp) + (size_t)b * P * KQ;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = slice; p < P; p += n_slices) {
+        const float a = sm[p];
+        const float4 v = pp4[(size_t)p * KQ + q];
+        acc.x += a * v.x; acc.y += a * v.y; acc.z += a * v.z; acc.w += a * v.w;
+    }
+    acc4[t] = acc;
+    __syncthreads();
+    if (t < K) {
+        const float* accf = reinterpret_cast<const float*>(acc4);
+        float y = 0.f;
+        for (int sl = 0; sl < n_slices; ++sl) y += accf[(size_t)sl * K + t];
+        if (train && keep_emb < 1.f) y *= dropout_scale(seed ^ 0xA1ull, (uint64_t)b * K + t, keep_emb);
+        yemb[(size_t)b * K + t] = y;
     }
 }
 
-// backward of dropout[1] -> pooling -> dropout[0] -> softmax.  in: dyemb_post [B,K]; out: dsc [B,P], dpp [B,P,K]
-__global__ __launch_bounds__(256) void afm_pool_bwd_kernel(const float* __restrict__ dy_post, const float* __restrict__ pp,
+// backward of dropout[1] -> pooling -> dropout[0] -> softmax.  in: dy [B, dy_ld] = d y_emb (post-dropout); out: dsc [B,P], the
+// post-dropout attention a' [B,P] and, in place of dy, the pre-dropout d y_emb.  d pp = a' (x) d y_emb is NOT materialised: the
+// pair backward below forms it from these two.
+__global__ __launch_bounds__(256) void afm_pool_bwd_kernel(float* __restrict__ dy, int dy_ld, const float* __restrict__ pp,
                                                           const float* __restrict__ att, int P, int K, float keep_att, float keep_emb,
                                                           const uint64_t* __restrict__ seed_ptr, float* __restrict__ dsc,
-                                                          float* __restrict__ dpp) {
-    extern __shared__ float sm[];        // [K] dyemb (pre-dropout gradient) | [P] da | [P] a' (post-dropout attention)
+                                                          float* __restrict__ att_drop) {
+    extern __shared__ float sm[];        // [K] dyemb (pre-dropout gradient) | [P] da
     __shared__ float red[4];
     float* dye = sm;
     float* da = sm + K;
-    float* ad = sm + K + P;
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint64_t seed = (keep_att < 1.f || keep_emb < 1.f) ? *seed_ptr : 0ull;
     for (int k = t; k < K; k += 256) {
-        float g = dy_post[(size_t)b * K + k];
+        float g = dy[(size_t)b * dy_ld + k];
         if (keep_emb < 1.f) g *= dropout_scale(seed ^ 0xA1ull, (uint64_t)b * K + k, keep_emb);
         dye[k] = g;
+        dy[(size_t)b * dy_ld + k] = g;
     }
     __syncthreads();
-    const float* ppb = pp + (size_t)b * P * K;
+    // thread = (pair, float4 piece): d a'[p] = <d y_emb, pp[p,:]>, reduced over the KQ neighbouring lanes of the pair
+    const int KQ = K >> 2, q = t % KQ;
+    const float4* pp4 = reinterpret_cast<const float4*>(pp) + (size_t)b * P * KQ;
+    const float4 d4 = reinterpret_cast<const float4*>(dye)[q];
     const float* ab = att + (size_t)b * P;
     float part = 0.f;                                          // sum_q att[q] * da[q]
-    for (int p = wave; p < P; p += 4) {
-        float s = 0.f;
-        for (int k = lane; k < K; k += 64) s += dye[k] * ppb[(size_t)p * K + k];
-        s = wsum64(s);                                         // d a'[p]
-        const float msk = keep_att < 1.f ? dropout_scale(seed ^ 0xA0ull, (uint64_t)b * P + p, keep_att) : 1.f;
-        const float d = s * msk;                               // d att[p]
-        if (lane == 0) { da[p] = d; ad[p] = ab[p] * msk; part += ab[p] * d; }
+    for (int i = t; i < P * KQ; i += 256) {
+        const int p = i / KQ;
+        const float4 v = pp4[i];
+        float s = d4.x * v.x + d4.y * v.y + d4.z * v.z + d4.w * v.w;
+        for (int o = 1; o < KQ; o <<= 1) s += __shfl_xor(s, o);
+        if (q == 0) {
+            const float msk = keep_att < 1.f ? dropout_scale(seed ^ 0xA0ull, (uint64_t)b * P + p, keep_att) : 1.f;
+            const float d = s * msk, a = ab[p];                // d att[p]
+            da[p] = d;
+            att_drop[(size_t)b * P + p] = a * msk;
+            part += a * d;
+        }
     }
     part = wsum64(part);
     if (lane == 0) red[wave] = part;
     __syncthreads();
     const float tot = red[0] + red[1] + red[2] + red[3];
     for (int p = t; p < P; p += 256) dsc[(size_t)b * P + p] = ab[p] * (da[p] - tot);      // softmax backward
-    float* dppb = dpp + (size_t)b * P * K;
-    for (int p = wave; p < P; p += 4) {
-        const float a = ad[p];
-        for (int k = lane; k < K; k += 64) dppb[(size_t)p * K + k] = a * dye[k];
-    }
 }
 
-// dE[b,i,:] = sum_{j != i} (g1 + g2)[b,pair(i,j),:] * e[b,j,:]
-__global__ __launch_bounds__(256) void afm_pair_bwd_kernel(const float* __restrict__ e, int e_ld, const float* __restrict__ g1,
-                                                          const float* __restrict__ g2, int F, int K, int P, float* __restrict__ dE,
-                                                          int de_ld) {
+// dE[b,i,:] = sum_{j != i} (a'[b,pair(i,j)] * dyemb[b,:] + g2[b,pair(i,j),:]) * e[b,j,:]      (pooling path + attention path)
+__global__ __launch_bounds__(256) void afm_pair_bwd_kernel(const float* __restrict__ e, int e_ld, const float* __restrict__ att_drop,
+                                                          const float* __restrict__ dye, int dye_ld, const float* __restrict__ g2, int F,
+                                                          int K, int P, float* __restrict__ dE, int de_ld) {
     const int b = blockIdx.y;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= F * K) return;
     const int i = x / K, k = x - i * K;
     const float* eb = e + (size_t)b * e_ld;
-    const float* a = g1 + (size_t)b * P * K;
+    const float* ad = att_drop + (size_t)b * P;
     const float* c = g2 + (size_t)b * P * K;
+    const float dk = dye[(size_t)b * dye_ld + k];
     float s = 0.f;
     for (int j = 0; j < i; ++j) {
-        const size_t p = (size_t)(j * F - (j * (j + 1)) / 2 + (i - j - 1)) * K + k;
-        s += (a[p] + c[p]) * eb[j * K + k];
+        const int p = j * F - (j * (j + 1)) / 2 + (i - j - 1);
+        s += (ad[p] * dk + c[(size_t)p * K + k]) * eb[j * K + k];
     }
     for (int j = i + 1; j < F; ++j) {
-        const size_t p = (size_t)(i * F - (i * (i + 1)) / 2 + (j - i - 1)) * K + k;
-        s += (a[p] + c[p]) * eb[j * K + k];
+        const int p = i * F - (i * (i + 1)) / 2 + (j - i - 1);
+        s += (ad[p] * dk + c[(size_t)p * K + k]) * eb[j * K + k];
     }
     dE[(size_t)b * de_ld + x] = s;
 }
@@ -157,11 +175,15 @@ int afm_declare_params(dctr_engine* E) {
     E->keep_att = c.keep_prob[0] > 0.f ? c.keep_prob[0] : 1.f;
     E->keep_emb = c.keep_prob[1] > 0.f ? c.keep_prob[1] : 1.f;
     const int K = E->K, A = E->A;
-    E->att_splits = choose_wgrad_splits(E->MB * E->P, K, A);
+    // the attention network runs fused over the pair rows when its shape allows (afm_fused.hip): the hidden layer [B*P, A] is
+    // then never materialised, and the four attention parameters take their gradient from AFM_SLABS atomically filled slabs
+    E->afm_fused = getenv("DCTR_AFM_UNFUSED") == nullptr && afm_fused_supported(K, A);        // (the env knob is the A/B switch)
+    E->att_splits = E->afm_fused ? AFM_SLABS : choose_wgrad_splits(E->MB * E->P, K, A);
+    const int ao = E->afm_fused ? AFM_SLABS : E->ao_splits;
     E->p_att_w = add(E, "att_mlp0/weights", {K, A}, false, E->att_splits, 0.f);
     E->p_att_b = add(E, "att_mlp0/biases", {A}, false, E->att_splits, 0.f);
-    E->p_ao_w = add(E, "attention_out/weights", {A, 1}, false, E->ao_splits, 0.f);
-    E->p_ao_b = add(E, "attention_out/biases", {1}, false, E->ao_splits, 0.f);
+    E->p_ao_w = add(E, "attention_out/weights", {A, 1}, false, ao, 0.f);
+    E->p_ao_b = add(E, "attention_out/biases", {1}, false, ao, 0.f);
     E->p_out_w = add(E, "deep_out/weights", {K, 1}, false, E->out_splits, 0.f);
     E->p_out_b = add(E, "deep_out/biases", {1}, false, E->out_splits, 0.f);
     return DCTR_OK;
@@ -177,10 +199,11 @@ static int dm(T** p, size_t n) {
 int afm_alloc(dctr_engine* E) {
     const size_t MB = E->MB, P = E->P, K = E->K, A = E->A;
     DCTR_TRY(dm(&E->pairp, MB * P * K));
-    DCTR_TRY(dm(&E->dpairp, MB * P * K));
     DCTR_TRY(dm(&E->dpairp2, MB * P * K));
-    DCTR_TRY(dm(&E->ah, MB * P * A));
-    DCTR_TRY(dm(&E->dah, MB * P * A));
+    if (!E->afm_fused) {
+        DCTR_TRY(dm(&E->ah, MB * P * A));
+        DCTR_TRY(dm(&E->dah, MB * P * A));
+    }
     DCTR_TRY(dm(&E->sc, MB * P));
     DCTR_TRY(dm(&E->dsc, MB * P));
     DCTR_TRY(dm(&E->att, MB * P));
@@ -196,7 +219,7 @@ int afm_alloc(dctr_engine* E) {
 }
 
 void afm_free(dctr_engine* E) {
-    float* fl[] = {E->pairp, E->dpairp, E->dpairp2, E->ah, E->dah, E->sc, E->dsc, E->att, E->dE_buf};
+    float* fl[] = {E->pairp, E->dpairp2, E->ah, E->dah, E->sc, E->dsc, E->att, E->dE_buf};
     for (float* p : fl) if (p) hipFree(p);
     if (E->pair_i) hipFree(E->pair_i);
     if (E->pair_j) hipFree(E->pair_j);
@@ -210,8 +233,13 @@ int afm_forward(dctr_engine* E, int B, bool train, hipStream_t st) {
                                                             P, KQ, reinterpret_cast<float4*>(E->pairp));
     DCTR_LAUNCH_CHECK();
     (void)F;
-    DCTR_TRY(fc_fwd(E->pairp, K, E->pp(E->p_att_w), E->pp(E->p_att_b), E->ah, A, B * P, K, A, 1, 1.f, nullptr, 0, st));
-    DCTR_TRY(rowdot(E->ah, A, E->pp(E->p_ao_w), E->pp(E->p_ao_b), B * P, A, E->sc, 0, st));
+    if (E->afm_fused) {
+        // scores straight from the pair products (the hidden layer never leaves the registers; the backward recomputes it)
+        DCTR_TRY(afm_att_fwd(E->pairp, E->pp(E->p_att_w), E->pp(E->p_att_b), E->pp(E->p_ao_w), E->pp(E->p_ao_b), (int64_t)B * P, K, A, E->sc, st));
+    } else {
+        DCTR_TRY(fc_fwd(E->pairp, K, E->pp(E->p_att_w), E->pp(E->p_att_b), E->ah, A, B * P, K, A, 1, 1.f, nullptr, 0, st));
+        DCTR_TRY(rowdot(E->ah, A, E->pp(E->p_ao_w), E->pp(E->p_ao_b), B * P, A, E->sc, 0, st));
+    }
     afm_pool_fwd_kernel<<<B, 256, (size_t)P * sizeof(float), st>>>(E->sc, E->pairp, P, K, E->keep_att, E->keep_emb, &E->state->seed_t,
                                                                    train ? 1 : 0, E->att, E->x_in);
     DCTR_LAUNCH_CHECK();
@@ -226,12 +254,24 @@ int afm_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
     // deep_out (K -> 1): d y_emb(post-dropout) = dy (x) w_d into dx_in; dW/db partial slabs
     DCTR_TRY(out_layer_bwd(E->x_in, E->Din_ld, E->dy, E->pp(E->p_out_w), B, K, pw.n_part, 0, 1.f, E->dx_in, E->Din_ld,
                            E->part(E->p_out_w), pw.padded, E->part(E->p_out_b), pb.padded, st));
-    afm_pool_bwd_kernel<<<B, 256, (size_t)(K + 2 * P) * sizeof(float), st>>>(E->dx_in, E->pairp, E->att, P, K, E->keep_att, E->keep_emb,
-                                                                             &E->state->seed_t, E->dsc, E->dpairp);
+    // (E->sc, the forward's scores, is free by now: it takes the post-dropout attention)
+    afm_pool_bwd_kernel<<<B, 256, (size_t)(K + P) * sizeof(float), st>>>(E->dx_in, E->Din_ld, E->pairp, E->att, P, K, E->keep_att, E->keep_emb,
+                                                                         &E->state->seed_t, E->dsc, E->sc);
     DCTR_LAUNCH_CHECK();
-    // attention_out (A -> 1) over the B*P rows: d ah = dsc (x) w_o masked by relu, dW_o / db_o partial slabs
     const Param& aw = E->params[E->p_ao_w];
     const Param& ab = E->params[E->p_ao_b];
+    if (E->afm_fused) {
+        const Param& w = E->params[E->p_att_w];
+        const Param& b = E->params[E->p_att_b];
+        DCTR_TRY(afm_att_bwd(E->pairp, E->pp(E->p_att_w), E->pp(E->p_att_b), E->pp(E->p_ao_w), E->dsc, (int64_t)B * P, K, A, E->dpairp2,
+                             E->part(E->p_att_w), w.padded, E->part(E->p_att_b), b.padded, E->part(E->p_ao_w), aw.padded,
+                             E->part(E->p_ao_b), ab.padded, AFM_SLABS, st));
+        dim3 grid(ceil_div(F * K, 256), B);
+        afm_pair_bwd_kernel<<<grid, 256, 0, st>>>(E->e, E->e_ld, E->sc, E->dx_in, E->Din_ld, E->dpairp2, F, K, P, E->dE_buf, E->D);
+        DCTR_LAUNCH_CHECK();
+        return DCTR_OK;
+    }
+    // attention_out (A -> 1) over the B*P rows: d ah = dsc (x) w_o masked by relu, dW_o / db_o partial slabs
     DCTR_TRY(out_layer_bwd(E->ah, A, E->dsc, E->pp(E->p_ao_w), B * P, A, aw.n_part, 1, 1.f, E->dah, A, E->part(E->p_ao_w), aw.padded,
                            E->part(E->p_ao_b), ab.padded, st));
     // attention layer: wgrad on the side stream, dgrad on the critical path
@@ -242,7 +282,7 @@ int afm_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
                                      E->att_splits, sw));
     DCTR_TRY(fc_bwd_data(E->dah, A, E->pp(E->p_att_w), E->dpairp2, K, B * P, K, A, nullptr, 0, 1.f, st));
     dim3 grid(ceil_div(F * K, 256), B);
-    afm_pair_bwd_kernel<<<grid, 256, 0, st>>>(E->e, E->e_ld, E->dpairp, E->dpairp2, F, K, P, E->dE_buf, E->D);
+    afm_pair_bwd_kernel<<<grid, 256, 0, st>>>(E->e, E->e_ld, E->sc, E->dx_in, E->Din_ld, E->dpairp2, F, K, P, E->dE_buf, E->D);
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }

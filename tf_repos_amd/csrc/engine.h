@@ -116,8 +116,9 @@ struct dctr_engine {
     int A = 0;                       // attention layer width
     int p_att_w = -1, p_att_b = -1, p_ao_w = -1, p_ao_b = -1;
     int att_splits = 1, ao_splits = 1024;
+    bool afm_fused = false;          // attention network fused over the pair rows (afm_fused.hip)
     float keep_att = 1.f, keep_emb = 1.f;
-    float *pairp = nullptr, *dpairp = nullptr, *dpairp2 = nullptr, *ah = nullptr, *dah = nullptr, *sc = nullptr, *dsc = nullptr,
+    float *pairp = nullptr, *dpairp2 = nullptr, *ah = nullptr, *dah = nullptr, *sc = nullptr, *dsc = nullptr,
           *att = nullptr, *dE_buf = nullptr;
     int16_t *pair_i = nullptr, *pair_j = nullptr;
     // where dL/de lives for the table backward (dx_in for the MLP-family models, dE_buf for AFM)

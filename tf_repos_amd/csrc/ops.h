@@ -142,6 +142,15 @@ int dcn_cross_bwd(const float* xs, const float* xlw, const float* w, const float
                   float* dx0, int dx0_ld, float* dw_part, float* db_part, int splits, int64_t part_stride,
                   float* scratch, hipStream_t st);
 
+// afm_fused.hip: AFM attention network fused over the pair rows (no [B*P, A] hidden activations in HBM)
+bool afm_fused_supported(int K, int A);
+int afm_att_fwd(const float* pp, const float* W, const float* ba, const float* wo, const float* bo, int64_t rows, int K, int A, float* sc,
+                hipStream_t st);
+constexpr int AFM_SLABS = 64;        // gradient slabs of the fused attention backward
+int afm_att_bwd(const float* pp, const float* W, const float* ba, const float* wo, const float* dsc, int64_t rows, int K, int A, float* dpp2,
+                float* dW_part, int64_t dW_stride, float* dba_part, int64_t dba_stride, float* dwo_part, int64_t dwo_stride, float* dbo_part,
+                int64_t dbo_stride, int n_slabs, hipStream_t st);
+
 // DeepMVM product layer (DeepMVM.py:144-150)
 int mvm_fwd(const float* e, int e_ld, const float* mb, int B, int F, int K, float* xm, hipStream_t st);
 int mvm_bwd(const float* e, int e_ld, const float* mb, const float* dxm, int B, int F, int K, float* dE, int de_ld, float* dmb_part,
