@@ -47,7 +47,11 @@ enum { DCTR_MODEL_DEEPFM = 0,  /* DeepFM.py   */
        DCTR_MODEL_WIDE   = 7,  /* --model_type=wide         LinearClassifier            */
        DCTR_MODEL_DEEP   = 8,  /* --model_type=deep         DNNClassifier               */
        DCTR_MODEL_WND    = 9,  /* --model_type=wide_n_deep  DNNLinearCombinedClassifier */
-       DCTR_MODEL_MVM    = 10  /* DeepMVM.py: prod_f (e_f + mvm_b_f) beside the MLP, fc([x_mvm || mlp_out]) */ };
+       DCTR_MODEL_MVM    = 10, /* DeepMVM.py: prod_f (e_f + mvm_b_f) beside the MLP, fc([x_mvm || mlp_out]) */
+       /* variable-length (multi-hot) models over CSR batches (dctr_train_step_csr): field_size = number of K-wide SLOTS
+        * of the MLP input, each the weighted sum of its entries' rows (one-hot fields = one entry of weight 1) */
+       DCTR_MODEL_DIN    = 11, /* DIN.py, field-wise sum pooling (--attention_pooling=False, DIN.py:179-183,199-210) */
+       DCTR_MODEL_ESMM   = 12  /* DeepCvrMTL.py: shared embeddings, CTR + CVR towers, pCTCVR = pCTR*pCVR (:153-225) */ };
 
 enum { DCTR_OPT_ADAM = 0, DCTR_OPT_ADAGRAD = 1, DCTR_OPT_MOMENTUM = 2, DCTR_OPT_FTRL = 3 }; /* DeepFM.py:204-211 */
 
@@ -94,6 +98,9 @@ typedef struct dctr_config {
     int32_t lin_optimizer;               /* DCTR_OPT_* of the linear side (TF default Ftrl); `optimizer` drives the DNN side */
     float   lin_learning_rate;
     int32_t loss_sum;                    /* 1: loss (and its gradient) is the SUM over the batch [TF-1.4 canned heads], 0: mean */
+    /* CSR models only (DCTR_MODEL_DIN/ESMM); zero elsewhere */
+    int32_t max_entries;                 /* largest nnz any CSR call will pass (0: max_batch * field_size * 8)             */
+    float   ctr_task_wgt;                /* --ctr_task_wgt    DeepCvrMTL.py:47,225                                         */
 } dctr_config;
 
 typedef struct dctr_engine* dctr_handle;
@@ -272,9 +279,6 @@ int dctr_train_step(dctr_handle h, const int32_t* d_ids, const float* d_vals, co
  * buffers.  A caller that writes a batch straight into slot k (e.g. the H2D copy of the input pipeline) and passes those
  * same pointers to dctr_train_step / dctr_predict / dctr_eval_batch pays no staging copy; any other pointers are copied
  * device-to-device into slot 0 first. */
-/* canned-estimator models: the dense (numeric-column) inputs [B, dense_size] f32 of the NEXT train/predict/eval call; the
- * buffer is read in place and must stay valid until that call's work has finished */
-int dctr_set_dense_input(dctr_handle h, const float* d_dense);
 int dctr_input_slot(dctr_handle h, int slot, int32_t** d_ids, float** d_vals, float** d_labels);
 /* canned-estimator models: the dense (numeric-column) inputs [B, dense_size] f32 of the NEXT train/predict/eval call; the
  * buffer is read in place and must stay valid until that call's work has finished */
@@ -282,6 +286,19 @@ int dctr_set_dense_input(dctr_handle h, const float* d_dense);
 /* forward only (mode PREDICT/EVAL: dropout off, BN moving stats): d_prob [B] (may be NULL), d_logit [B] (may be NULL) */
 int dctr_predict(dctr_handle h, const int32_t* d_ids, const float* d_vals, int B,
                  float* d_prob, float* d_logit, void* stream);
+/* ---- CSR (multi-hot) models, DIN.py / DeepCvrMTL.py.  One batch = B examples x S = field_size slots; slot (b, s) owns the
+ * entries [d_offsets[b*S+s], d_offsets[b*S+s+1]) of d_ids / d_weights (d_weights NULL = all ones); the MLP input is
+ * x[b, s*K:(s+1)*K] = sum_j weights[j] * emb[ids[j], :] -- embedding_lookup (one entry) and embedding_lookup_sparse(sum)
+ * (DIN.py:144-148,180-183) in one kernel, slots in the order of the script's tf.concat (DIN.py:199).  nnz <= max_entries.
+ * Labels: d_y [B] (clicks); d_z [B] conversions (ESMM only, DeepCvrMTL.py:82-84; NULL for DIN).
+ * h_loss (may be NULL; syncs): DIN.py:222 / DeepCvrMTL.py:222-225 evaluated before the update.  Launched eagerly (nnz varies). */
+int dctr_train_step_csr(dctr_handle h, const int32_t* d_offsets, const int32_t* d_ids, const float* d_weights, int nnz,
+                        const float* d_y, const float* d_z, int B, float* h_loss, void* stream);
+/* forward only.  DIN: d_out0 = prob [B], d_out1 = logit [B].  ESMM: d_out0 = pctr, d_out1 = pcvr, d_out2 = pctcvr
+ * (predictions dict of DeepCvrMTL.py:212).  Any out pointer may be NULL. */
+int dctr_predict_csr(dctr_handle h, const int32_t* d_offsets, const int32_t* d_ids, const float* d_weights, int nnz, int B,
+                     float* d_out0, float* d_out1, float* d_out2, void* stream);
+
 /* mode EVAL (DeepFM.py:193-201): accumulate the loss and tf.metrics.auc's 200-threshold counters over an eval set */
 int dctr_eval_reset(dctr_handle h, void* stream);
 int dctr_eval_batch(dctr_handle h, const int32_t* d_ids, const float* d_vals, const float* d_labels, int B, void* stream);

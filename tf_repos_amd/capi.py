@@ -17,7 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libdeepctr_hip.so")
 
 DCTR_OK = 0
-MODELS = {"deepfm": 0, "fnn": 1, "ipnn": 2, "opnn": 3, "nfm": 4, "afm": 5, "dcn": 6, "wide": 7, "deep": 8, "wide_n_deep": 9, "mvm": 10}
+MODELS = {"deepfm": 0, "fnn": 1, "ipnn": 2, "opnn": 3, "nfm": 4, "afm": 5, "dcn": 6, "wide": 7, "deep": 8, "wide_n_deep": 9, "mvm": 10,
+          "din": 11, "esmm": 12}
 OPTIMIZERS = {"Adam": 0, "Adagrad": 1, "Momentum": 2, "ftrl": 3}
 TABLE_MODES = {"dense_exact": 0, "touched_rows": 1}
 GATHER_RAW, GATHER_FM, GATHER_BI = 0, 1, 2
@@ -36,7 +37,7 @@ class Config(C.Structure):
         ("batch_norm", C.c_int32), ("batch_norm_decay", C.c_float), ("max_batch", C.c_int32),
         ("seed", C.c_uint64), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
         ("use_graph", C.c_int32), ("dense_size", C.c_int32), ("lin_optimizer", C.c_int32),
-        ("lin_learning_rate", C.c_float), ("loss_sum", C.c_int32),
+        ("lin_learning_rate", C.c_float), ("loss_sum", C.c_int32), ("max_entries", C.c_int32), ("ctr_task_wgt", C.c_float),
     ]
 
 
@@ -101,6 +102,8 @@ _SIGS = {
     "dctr_get_global_step": ([_P, C.POINTER(C.c_int64)], C.c_int),
     "dctr_train_step": ([_P, _P, _P, _P, C.c_int, C.POINTER(C.c_float), _P], C.c_int),
     "dctr_predict": ([_P, _P, _P, C.c_int, _P, _P, _P], C.c_int),
+    "dctr_train_step_csr": ([_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_float), _P], C.c_int),
+    "dctr_predict_csr": ([_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
     "dctr_eval_reset": ([_P, _P], C.c_int),
     "dctr_eval_batch": ([_P, _P, _P, _P, C.c_int, _P], C.c_int),
     "dctr_eval_result": ([_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int64), _P], C.c_int),

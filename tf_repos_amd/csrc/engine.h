@@ -112,6 +112,16 @@ struct dctr_engine {
     int p_mvm_b = -1;
     float *xmvm = nullptr, *dxmvm = nullptr;      // [MB, K]
 
+    // CSR (multi-hot) models DIN / ESMM (dctr_train_step_csr); ESMM's second tower (CVR) lives in the *2 members and is
+    // swapped with the primary members (CTR) around the shared MLP forward / backward code
+    bool csr = false;
+    int64_t max_entries = 0;
+    int32_t* entry_off = nullptr;    // [max_entries] float4 offset of every entry's slot in x_in / dx_in
+    std::vector<Fc> mlp2;
+    std::vector<float*> h2, dh2;
+    int p_out2_w = -1, p_out2_b = -1;
+    float *dx_in2 = nullptr, *dy2 = nullptr, *y2 = nullptr, *prob2 = nullptr, *prob3 = nullptr;
+
     // AFM (afm.hip)
     int A = 0;                       // attention layer width
     int p_att_w = -1, p_att_b = -1, p_ao_w = -1, p_ao_b = -1;

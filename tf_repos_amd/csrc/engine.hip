@@ -80,7 +80,15 @@ int dropout_inplace(float* x, int64_t n, float keep, const uint64_t* seed_ptr, u
 
 int build(dctr_engine* E) {
     const dctr_config& c = E->cfg;
-    DCTR_REQUIRE(c.model >= DCTR_MODEL_DEEPFM && c.model <= DCTR_MODEL_MVM, "unknown model %d", c.model);
+    DCTR_REQUIRE(c.model >= DCTR_MODEL_DEEPFM && c.model <= DCTR_MODEL_ESMM, "unknown model %d", c.model);
+    E->csr = c.model == DCTR_MODEL_DIN || c.model == DCTR_MODEL_ESMM;
+    if (E->csr) {
+        DCTR_REQUIRE(c.batch_norm == 0, "batch_norm is not implemented for the CSR models");
+        DCTR_REQUIRE(c.shard_world == 1, "the CSR models are not row-sharded");
+        DCTR_REQUIRE(c.max_entries >= 0, "max_entries must be >= 0");
+        DCTR_REQUIRE(c.model != DCTR_MODEL_ESMM || (c.ctr_task_wgt >= 0.f && c.ctr_task_wgt <= 1.f), "ctr_task_wgt must be in [0,1]");
+        E->max_entries = c.max_entries > 0 ? c.max_entries : (int64_t)c.max_batch * c.field_size * 8;
+    }
     E->wnd = c.model >= DCTR_MODEL_WIDE && c.model <= DCTR_MODEL_WND;
     E->wnd_wide = c.model == DCTR_MODEL_WIDE || c.model == DCTR_MODEL_WND;
     E->wnd_deep = c.model == DCTR_MODEL_DEEP || c.model == DCTR_MODEL_WND;
@@ -117,7 +125,7 @@ int build(dctr_engine* E) {
     }
     E->Din_ld = (int)round_up(E->Din, 4);
     const bool mvm = c.model == DCTR_MODEL_MVM;
-    const bool has_lin = E->wnd ? E->wnd_wide : (c.model != DCTR_MODEL_DCN && !mvm);
+    const bool has_lin = E->wnd ? E->wnd_wide : (c.model != DCTR_MODEL_DCN && !mvm && !E->csr);
 
     // ---- parameters (engine names, tf_repos_amd.checkpoint maps them to TF names)
     if (c.model == DCTR_MODEL_DCN) {
@@ -133,30 +141,43 @@ int build(dctr_engine* E) {
     if (!E->wnd || E->wnd_deep) add_param(E, "emb", {E->rows, K}, true, 1, c.l2_reg);   // (wide-only: the table exists, unused)
     int d = E->Din;
     if (afm) DCTR_TRY(afm_declare_params(E));
-    for (int i = 0; i < (no_mlp ? 0 : c.n_deep_layers); ++i) {
-        Fc fc;
-        fc.in = d; fc.out = c.deep_layers[i]; fc.keep = c.keep_prob[i];
-        DCTR_REQUIRE(fc.out > 0, "deep layer widths must be positive (got %d)", fc.out);
-        fc.splits = choose_wgrad_splits(MB, fc.in, fc.out);
-        char nm[64];
-        snprintf(nm, sizeof(nm), "mlp%d/weights", i);
-        fc.w = add_param(E, nm, {fc.in, fc.out}, false, fc.splits, 0.f);
-        snprintf(nm, sizeof(nm), "mlp%d/biases", i);
-        fc.b = add_param(E, nm, {fc.out}, false, fc.splits, 0.f);
-        fc.last = fc.b;
-        if (E->bn) {        // variable names of contrib.layers.batch_norm under scope bn_%d (DeepFM.py:160,231-235)
-            snprintf(nm, sizeof(nm), "bn_%d/beta", i);            fc.bn_beta = add_param(E, nm, {fc.out}, false, 1, 0.f);
-            snprintf(nm, sizeof(nm), "bn_%d/gamma", i);           fc.bn_gamma = add_param(E, nm, {fc.out}, false, 1, 0.f);
-            snprintf(nm, sizeof(nm), "bn_%d/moving_mean", i);     fc.bn_mm = add_param(E, nm, {fc.out}, false, 1, 0.f);
-            snprintf(nm, sizeof(nm), "bn_%d/moving_variance", i); fc.bn_mv = add_param(E, nm, {fc.out}, false, 1, 0.f);
-            E->params[fc.bn_mm].frozen = E->params[fc.bn_mv].frozen = true;
-            fc.last = fc.bn_mv;
+    // ESMM declares two towers over the same input: "ctr_" (primary members) and "cvr_" (the *2 members)
+    const char* tower_prefix[2] = {c.model == DCTR_MODEL_ESMM ? "ctr_" : "", "cvr_"};
+    for (int t = 0; t < (c.model == DCTR_MODEL_ESMM ? 2 : 1); ++t) {
+        std::vector<Fc>& tower = t == 0 ? E->mlp : E->mlp2;
+        d = E->Din;
+        for (int i = 0; i < (no_mlp ? 0 : c.n_deep_layers); ++i) {
+            Fc fc;
+            fc.in = d; fc.out = c.deep_layers[i]; fc.keep = c.keep_prob[i];
+            DCTR_REQUIRE(fc.out > 0, "deep layer widths must be positive (got %d)", fc.out);
+            fc.splits = choose_wgrad_splits(MB, fc.in, fc.out);
+            char nm[64];
+            snprintf(nm, sizeof(nm), "%smlp%d/weights", tower_prefix[t], i);
+            fc.w = add_param(E, nm, {fc.in, fc.out}, false, fc.splits, 0.f);
+            snprintf(nm, sizeof(nm), "%smlp%d/biases", tower_prefix[t], i);
+            fc.b = add_param(E, nm, {fc.out}, false, fc.splits, 0.f);
+            fc.last = fc.b;
+            if (E->bn) {        // variable names of contrib.layers.batch_norm under scope bn_%d (DeepFM.py:160,231-235)
+                snprintf(nm, sizeof(nm), "bn_%d/beta", i);            fc.bn_beta = add_param(E, nm, {fc.out}, false, 1, 0.f);
+                snprintf(nm, sizeof(nm), "bn_%d/gamma", i);           fc.bn_gamma = add_param(E, nm, {fc.out}, false, 1, 0.f);
+                snprintf(nm, sizeof(nm), "bn_%d/moving_mean", i);     fc.bn_mm = add_param(E, nm, {fc.out}, false, 1, 0.f);
+                snprintf(nm, sizeof(nm), "bn_%d/moving_variance", i); fc.bn_mv = add_param(E, nm, {fc.out}, false, 1, 0.f);
+                E->params[fc.bn_mm].frozen = E->params[fc.bn_mv].frozen = true;
+                fc.last = fc.bn_mv;
+            }
+            tower.push_back(fc);
+            d = fc.out;
         }
-        E->mlp.push_back(fc);
-        d = fc.out;
+        if (c.model == DCTR_MODEL_ESMM) {       // ctr_out / cvr_out (DeepCvrMTL.py:182,203)
+            char nm[64];
+            snprintf(nm, sizeof(nm), "%sout/weights", tower_prefix[t]);
+            (t == 0 ? E->p_out_w : E->p_out2_w) = add_param(E, nm, {d, 1}, false, E->out_splits, 0.f);
+            snprintf(nm, sizeof(nm), "%sout/biases", tower_prefix[t]);
+            (t == 0 ? E->p_out_b : E->p_out2_b) = add_param(E, nm, {1}, false, E->out_splits, 0.f);
+        }
     }
-    if (afm || c.model == DCTR_MODEL_WIDE) {
-        // AFM: output layer declared by afm_declare_params; LinearClassifier: no DNN side at all
+    if (afm || c.model == DCTR_MODEL_WIDE || c.model == DCTR_MODEL_ESMM) {
+        // AFM: output layer declared by afm_declare_params; LinearClassifier: no DNN side at all; ESMM: declared per tower above
     } else if (c.model == DCTR_MODEL_DCN) {
         E->p_out_w = add_param(E, "out_layer/weights", {D + d, 1}, false, E->out_splits, 0.f);
         E->p_out_b = add_param(E, "out_layer/biases", {1}, false, E->out_splits, 0.f);
@@ -177,7 +198,8 @@ int build(dctr_engine* E) {
         DCTR_TRY(dmalloc(&E->lin_s0, (size_t)E->rows));
         DCTR_TRY(dmalloc(&E->lin_s1, (size_t)E->rows));
     }
-    DCTR_TRY(group_create(E->rows, (int64_t)MB * F * c.shard_world, K, &E->group));   // owner side may receive rows from every rank
+    // owner side may receive rows from every rank; CSR models group up to max_entries ids per step
+    DCTR_TRY(group_create(E->rows, E->csr ? E->max_entries : (int64_t)MB * F * c.shard_world, K, &E->group));
 
     // ---- dense arena + partial slabs + optimizer block metadata
     int64_t off = 0, poff = 0;
@@ -195,6 +217,7 @@ int build(dctr_engine* E) {
     // GEMM_SLACK_ROWS rows past a weight matrix -- normally the next parameters, past the last one this padding
     size_t wslack = 0;
     for (auto& fc : E->mlp) wslack = std::max(wslack, (size_t)GEMM_SLACK_ROWS * (size_t)std::max(fc.out, fc.in));
+    for (auto& fc : E->mlp2) wslack = std::max(wslack, (size_t)GEMM_SLACK_ROWS * (size_t)std::max(fc.out, fc.in));
     DCTR_TRY(dmalloc(&E->theta, (size_t)off + wslack));
     DCTR_TRY(dmalloc(&E->as0, (size_t)off));
     DCTR_TRY(dmalloc(&E->as1, (size_t)off));
@@ -321,6 +344,22 @@ int build(dctr_engine* E) {
             DCTR_TRY(dmalloc(&z, (size_t)(MB + GEMM_SLACK_ROWS) * fc.out));
             DCTR_TRY(dmalloc(&sx, (size_t)2 * fc.out));
             E->hbn.push_back(z); E->bn_stats.push_back(sx);
+        }
+    }
+    for (auto& fc : E->mlp2) {
+        float *a = nullptr, *g = nullptr;
+        DCTR_TRY(dmalloc(&a, (size_t)(MB + GEMM_SLACK_ROWS) * fc.out));
+        DCTR_TRY(dmalloc(&g, (size_t)(MB + GEMM_SLACK_ROWS) * fc.out));
+        E->h2.push_back(a); E->dh2.push_back(g);
+    }
+    if (E->csr) {
+        DCTR_TRY(dmalloc(&E->entry_off, (size_t)E->max_entries));
+        if (c.model == DCTR_MODEL_ESMM) {
+            DCTR_TRY(dmalloc(&E->dx_in2, (size_t)(MB + GEMM_SLACK_ROWS) * E->Din_ld));
+            DCTR_TRY(dmalloc(&E->dy2, (size_t)MB));
+            DCTR_TRY(dmalloc(&E->y2, (size_t)MB));
+            DCTR_TRY(dmalloc(&E->prob2, (size_t)MB));
+            DCTR_TRY(dmalloc(&E->prob3, (size_t)MB));
         }
     }
     if (E->bn) {
@@ -758,6 +797,10 @@ int dctr_destroy(dctr_handle E) {
     for (float* p : fl) if (p) hipFree(p);
     for (float* p : E->h) hipFree(p);
     for (float* p : E->dh) hipFree(p);
+    for (float* p : E->h2) hipFree(p);
+    for (float* p : E->dh2) hipFree(p);
+    { float* f2[] = {E->dx_in2, E->dy2, E->y2, E->prob2, E->prob3}; for (float* p : f2) if (p) hipFree(p); }
+    if (E->entry_off) hipFree(E->entry_off);
     for (int k = 0; k < DCTR_INPUT_SLOTS; ++k) { if (E->slot_ids[k]) hipFree(E->slot_ids[k]); if (E->slot_vals[k]) hipFree(E->slot_vals[k]); if (E->slot_labels[k]) hipFree(E->slot_labels[k]); }
     if (E->status) hipFree(E->status);
     if (E->state) hipFree(E->state);
@@ -848,6 +891,7 @@ int dctr_get_global_step(dctr_handle E, int64_t* step) {
 int dctr_train_step(dctr_handle E, const int32_t* d_ids, const float* d_vals, const float* d_labels, int B, float* h_loss,
                     void* stream) {
     DCTR_REQUIRE(E && d_ids && d_vals && d_labels, "null argument");
+    DCTR_REQUIRE(!E->csr, "this handle's model takes CSR batches (dctr_train_step_csr)");
     hipStream_t st = as_stream(stream);
     DCTR_TRY(stage_inputs(E, d_ids, d_vals, d_labels, B, st));
     DCTR_TRY(run_graph(E, E->train_graphs, B, true, st));
@@ -864,12 +908,119 @@ int dctr_train_step(dctr_handle E, const int32_t* d_ids, const float* d_vals, co
 
 int dctr_predict(dctr_handle E, const int32_t* d_ids, const float* d_vals, int B, float* d_prob, float* d_logit, void* stream) {
     DCTR_REQUIRE(E && d_ids && d_vals, "null argument");
+    DCTR_REQUIRE(!E->csr, "this handle's model takes CSR batches (dctr_predict_csr)");
     hipStream_t st = as_stream(stream);
     DCTR_TRY(stage_inputs(E, d_ids, d_vals, nullptr, B, st));
     DCTR_TRY(run_graph(E, E->predict_graphs, B, false, st));
     E->last_B = B;
     if (d_prob) DCTR_HIP_CHECK(hipMemcpyAsync(d_prob, E->prob, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
     if (d_logit) DCTR_HIP_CHECK(hipMemcpyAsync(d_logit, E->y, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    return DCTR_OK;
+}
+
+// ---- CSR (multi-hot) models: DIN (sum pooling) and ESMM ------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+// ESMM: exchange the primary (CTR) tower with the second (CVR) one, so that forward_rest / backward_dense run on either
+void swap_tower(dctr_engine* E) {
+    std::swap(E->mlp, E->mlp2);
+    std::swap(E->h, E->h2);
+    std::swap(E->dh, E->dh2);
+    std::swap(E->p_out_w, E->p_out2_w);
+    std::swap(E->p_out_b, E->p_out2_b);
+    std::swap(E->dy, E->dy2);
+    std::swap(E->dx_in, E->dx_in2);
+}
+
+int csr_check(dctr_engine* E, const int32_t* off, const int32_t* ids, int nnz, int B) {
+    DCTR_REQUIRE(E && off && ids, "null argument");
+    DCTR_REQUIRE(E->csr, "this handle's model takes fixed-field batches (dctr_train_step), not CSR batches");
+    DCTR_REQUIRE(B > 0 && B <= E->MB, "batch %d outside (0, max_batch=%d]", B, E->MB);
+    DCTR_REQUIRE(nnz >= 0 && (int64_t)nnz <= E->max_entries, "nnz=%d exceeds max_entries=%lld", nnz, (long long)E->max_entries);
+    return DCTR_OK;
+}
+
+// x_in[b, s*K:(s+1)*K] = sum of the slot's weighted rows, then the tower(s) and the head
+int csr_forward(dctr_engine* E, const int32_t* off, const int32_t* ids, const float* wts, int B, const float* y, const float* z,
+                bool train, hipStream_t st) {
+    const dctr_config& c = E->cfg;
+    DCTR_TRY(lookup_sparse_slots_fwd(E->emb, E->rows, E->K, off, ids, wts, B * E->F, E->F, E->x_in, E->Din_ld, E->status, st));
+    DCTR_TRY(forward_rest(E, B, train, st));
+    if (c.model == DCTR_MODEL_DIN) {
+        E->labels = const_cast<float*>(y);
+        return head(E, B, B, y != nullptr, st);
+    }
+    swap_tower(E);
+    int rc = forward_rest(E, B, train, st);
+    swap_tower(E);
+    DCTR_TRY(rc);
+    return esmm_head(E->h.back(), E->mlp.back().out, E->pp(E->p_out_w), E->pp(E->p_out_b), E->mlp.back().out, E->h2.back(),
+                     E->mlp2.back().out, E->pp(E->p_out2_w), E->pp(E->p_out2_b), E->mlp2.back().out, y, z, B, 1.0f / (float)B,
+                     c.ctr_task_wgt, E->y, E->y2, E->prob, E->prob2, E->prob3, E->dy, E->dy2, E->scalars, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dctr_train_step_csr(dctr_handle E, const int32_t* d_offsets, const int32_t* d_ids, const float* d_weights, int nnz,
+                        const float* d_y, const float* d_z, int B, float* h_loss, void* stream) {
+    DCTR_TRY(csr_check(E, d_offsets, d_ids, nnz, B));
+    const dctr_config& c = E->cfg;
+    const bool esmm = c.model == DCTR_MODEL_ESMM;
+    DCTR_REQUIRE(d_y != nullptr && (!esmm || d_z != nullptr), "labels missing (ESMM takes y and z)");
+    hipStream_t st = as_stream(stream), sg = E->s_group, sw = E->s_wgrad;
+    DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, st));
+    // grouping of the batch's ids + the entries' slot offsets: beside the forward pass
+    DCTR_TRY(fork(E, st, sg));
+    DCTR_TRY(group_ids(E->group, d_ids, nnz, 1, sg));
+    DCTR_TRY(csr_entry_offsets(d_offsets, B * E->F, nnz, E->F, E->Din_ld, E->K, E->entry_off, sg));
+    DCTR_TRY(csr_forward(E, d_offsets, d_ids, d_weights, B, d_y, d_z, true, st));
+    DCTR_TRY(backward_dense(E, B, st, sw, false));
+    if (esmm) {
+        swap_tower(E);
+        int rc = backward_dense(E, B, st, sw, false);
+        swap_tower(E);
+        DCTR_TRY(rc);
+        DCTR_TRY(add_inplace(E->dx_in, E->dx_in2, (int64_t)B * E->Din_ld, st));
+    }
+    // dense parameters on the weight-gradient stream (its last dW is done; the output layers' slabs were written on st)
+    DCTR_TRY(fork(E, st, sw));
+    DCTR_TRY(opt_dense_arena(c.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->parts, E->meta, E->n_blocks,
+                             nullptr, 1, E->scalars + 3 * SUMSQ_SHARDS, sw));
+    // table: per-entry gradient = weight * dL/dx[slot], segment-summed per distinct id, then the optimizer (DIN.py:222: the
+    // l2_loss(Feat_Emb) term makes the table gradient dense, as for the fixed-field models)
+    DCTR_TRY(fork(E, sg, st));
+    if (nnz > 0)
+        DCTR_TRY(embed_scatter_bwd(E->group, E->dx_in, 4, nullptr, 0, nullptr, nullptr, nullptr, d_weights, nnz, 1, E->K, DCTR_GATHER_RAW,
+                                   E->group->gemb, nullptr, st, 1, E->entry_off));
+    DCTR_TRY(opt_table(c.optimizer, &E->state->hyper, E->h_state.hyper, c.table_mode, E->rows, E->K, E->emb, E->emb_s0, E->emb_s1,
+                       nullptr, nullptr, nullptr, E->group->slot, E->group->uniq, E->group->counters, E->group->max_entries,
+                       E->group->gemb, nullptr, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, st, nullptr,
+                       OPT_PASS_ALL));
+    DCTR_TRY(fork(E, sw, st));
+    E->last_B = B;
+    if (h_loss) {
+        float sc[4];
+        DCTR_TRY(read_scalars(E, sc, st));
+        *h_loss = sc[0] / (float)B + c.l2_reg * 0.5f * sc[1];       // DIN.py:222 / DeepCvrMTL.py:225 (the head sums the task-weighted terms)
+    }
+    return DCTR_OK;
+}
+
+int dctr_predict_csr(dctr_handle E, const int32_t* d_offsets, const int32_t* d_ids, const float* d_weights, int nnz, int B,
+                     float* d_out0, float* d_out1, float* d_out2, void* stream) {
+    DCTR_TRY(csr_check(E, d_offsets, d_ids, nnz, B));
+    hipStream_t st = as_stream(stream);
+    DCTR_TRY(csr_forward(E, d_offsets, d_ids, d_weights, B, nullptr, nullptr, false, st));
+    E->last_B = B;
+    const bool esmm = E->cfg.model == DCTR_MODEL_ESMM;
+    const float* src[3] = {E->prob, esmm ? E->prob2 : E->y, esmm ? E->prob3 : nullptr};
+    float* dst[3] = {d_out0, d_out1, d_out2};
+    for (int k = 0; k < 3; ++k)
+        if (dst[k] && src[k]) DCTR_HIP_CHECK(hipMemcpyAsync(dst[k], src[k], (size_t)B * 4, hipMemcpyDeviceToDevice, st));
     return DCTR_OK;
 }
 

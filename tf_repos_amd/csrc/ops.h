@@ -142,6 +142,16 @@ int dcn_cross_bwd(const float* xs, const float* xlw, const float* w, const float
                   float* dx0, int dx0_ld, float* dw_part, float* db_part, int splits, int64_t part_stride,
                   float* scratch, hipStream_t st);
 
+// sparse.hip / mtl.hip: the CSR (multi-hot) models DIN / ESMM
+int lookup_sparse_slots_fwd(const float* emb, int64_t rows, int K, const int32_t* offsets, const int32_t* ids, const float* weights,
+                            int n_seg, int S, float* out, int out_ld, int32_t* status, hipStream_t st);
+int csr_entry_offsets(const int32_t* offsets, int n_seg, int nnz, int S, int ld, int K, int32_t* entry_off, hipStream_t st);
+int esmm_head(const float* h_ctr, int ld_ctr, const float* w_ctr, const float* b_ctr, int n_ctr, const float* h_cvr, int ld_cvr,
+              const float* w_cvr, const float* b_cvr, int n_cvr, const float* y, const float* z, int B, float inv_b, float wgt,
+              float* y_ctr, float* y_cvr, float* pctr, float* pcvr, float* pctcvr, float* dy_ctr, float* dy_cvr, float* loss_shards,
+              hipStream_t st);
+int add_inplace(float* a, const float* b, int64_t n, hipStream_t st);
+
 // afm_fused.hip: AFM attention network fused over the pair rows (no [B*P, A] hidden activations in HBM)
 bool afm_fused_supported(int K, int A);
 int afm_att_fwd(const float* pp, const float* W, const float* ba, const float* wo, const float* bo, int64_t rows, int K, int A, float* sc,

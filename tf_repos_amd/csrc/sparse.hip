@@ -1,7 +1,7 @@
 // Variable-length (multi-hot) lookups: tf.nn.embedding_lookup_sparse(params, sp_ids, sp_weights, combiner="sum") as the
 // DIN / ESMM scripts use it (DIN.py:148,180-183; DeepCvrMTL.py:155-159) = gather + weight + segment sum over a CSR batch
-// (K2/K8 generalised from fixed-F to CSR).  Op-level entry points; the DIN / ESMM models themselves are not
-// built yet.
+// (K2/K8 generalised from fixed-F to CSR).  Op-level entry points, plus the slot-addressed forms the DIN / ESMM
+// engine models use (engine.hip, dctr_train_step_csr).
 //   forward : out[b, :] = sum_{j in [offsets[b], offsets[b+1])} weights[j] * emb[ids[j], :]        (empty row -> zeros)
 //   backward: the IndexedSlices gradient, segment-summed per distinct id into a dctr_group's compact rows (group.hip),
 //             ready for dctr_opt_table -- the same machinery as the fixed-F path, with a per-entry example index
@@ -12,7 +12,8 @@ namespace dctr {
 template <int KQ>
 __global__ __launch_bounds__(256) void lookup_sparse_fwd_kernel(const float4* __restrict__ emb, int64_t rows, const int32_t* __restrict__ offsets,
                                                                const int32_t* __restrict__ ids, const float* __restrict__ weights, int B,
-                                                               float4* __restrict__ out, int out_ld4, int32_t* __restrict__ status) {
+                                                               int S, float4* __restrict__ out, int out_ld4, int32_t* __restrict__ status) {
+    // B segments; segment b is slot b % S of output row b / S (S == 1: one K-wide output per row)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = t / KQ, kq = t % KQ;
     if (b >= B) return;
@@ -28,11 +29,13 @@ __global__ __launch_bounds__(256) void lookup_sparse_fwd_kernel(const float4* __
         const float4 r = emb[(size_t)id * KQ + kq];
         acc.x += w * r.x; acc.y += w * r.y; acc.z += w * r.z; acc.w += w * r.w;
     }
-    out[(size_t)b * out_ld4 + kq] = acc;
+    out[(size_t)(b / S) * out_ld4 + (size_t)(b % S) * KQ + kq] = acc;
 }
 
-// entry_row[j] = b for offsets[b] <= j < offsets[b+1]   (binary search per entry)
-__global__ __launch_bounds__(256) void entry_row_kernel(const int32_t* __restrict__ offsets, int B, int nnz, int32_t* __restrict__ entry_row) {
+// entry_row[j] = b for offsets[b] <= j < offsets[b+1]   (binary search per entry); with S slots per output row the value is
+// the float4 offset of the segment's K-wide piece, (b / S) * ld4 + (b % S) * KQ  (S == 1, ld4 == 1, KQ == 0: the row b itself)
+__global__ __launch_bounds__(256) void entry_row_kernel(const int32_t* __restrict__ offsets, int B, int nnz, int S, int ld4, int KQ,
+                                                       int32_t* __restrict__ entry_row) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nnz) return;
     int lo = 0, hi = B;                                  // invariant: offsets[lo] <= j < offsets[hi]
@@ -40,7 +43,31 @@ __global__ __launch_bounds__(256) void entry_row_kernel(const int32_t* __restric
         const int mid = (lo + hi) >> 1;
         if (offsets[mid] <= j) lo = mid; else hi = mid;
     }
-    entry_row[j] = lo;
+    entry_row[j] = S == 1 && KQ == 0 ? lo : (lo / S) * ld4 + (lo % S) * KQ;
+}
+
+int lookup_sparse_slots_fwd(const float* emb, int64_t rows, int K, const int32_t* offsets, const int32_t* ids, const float* weights,
+                            int n_seg, int S, float* out, int out_ld, int32_t* status, hipStream_t st) {
+    if (n_seg <= 0) return DCTR_OK;
+    const int KQ = K / 4;
+    const int grid = ceil_div((int64_t)n_seg * KQ, 256);
+    const float4* e4 = reinterpret_cast<const float4*>(emb);
+    float4* o4 = reinterpret_cast<float4*>(out);
+    switch (KQ) {
+#define DCTR_S(Q) case Q: lookup_sparse_fwd_kernel<Q><<<grid, 256, 0, st>>>(e4, rows, offsets, ids, weights, n_seg, S, o4, out_ld / 4, status); break
+        DCTR_S(1); DCTR_S(2); DCTR_S(4); DCTR_S(8); DCTR_S(16); DCTR_S(32); DCTR_S(64);
+#undef DCTR_S
+        default: set_error("lookup_sparse: K=%d unsupported (K/4 must be a power of two)", K); return DCTR_ERR_UNSUPPORTED;
+    }
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+int csr_entry_offsets(const int32_t* offsets, int n_seg, int nnz, int S, int ld, int K, int32_t* entry_off, hipStream_t st) {
+    if (nnz <= 0) return DCTR_OK;
+    entry_row_kernel<<<ceil_div(nnz, 256), 256, 0, st>>>(offsets, n_seg, nnz, S, ld / 4, K / 4, entry_off);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
 }
 
 }  // namespace dctr
@@ -53,20 +80,7 @@ int dctr_embed_lookup_sparse_fwd(const float* d_emb, int64_t rows, int K, const 
                                  const float* d_weights, int B, float* d_out, int out_ld, int32_t* d_status, void* stream) {
     DCTR_REQUIRE(d_emb && d_offsets && d_ids && d_out && d_status, "null argument");
     DCTR_REQUIRE(K % 4 == 0 && K >= 4 && K <= 256 && out_ld % 4 == 0 && out_ld >= K, "lookup_sparse: K=%d / out_ld=%d unsupported", K, out_ld);
-    if (B <= 0) return DCTR_OK;
-    const int KQ = K / 4;
-    const int grid = ceil_div((int64_t)B * KQ, 256);
-    hipStream_t st = as_stream(stream);
-    const float4* e4 = reinterpret_cast<const float4*>(d_emb);
-    float4* o4 = reinterpret_cast<float4*>(d_out);
-    switch (KQ) {
-#define DCTR_S(Q) case Q: lookup_sparse_fwd_kernel<Q><<<grid, 256, 0, st>>>(e4, rows, d_offsets, d_ids, d_weights, B, o4, out_ld / 4, d_status); break
-        DCTR_S(1); DCTR_S(2); DCTR_S(4); DCTR_S(8); DCTR_S(16); DCTR_S(32); DCTR_S(64);
-#undef DCTR_S
-        default: set_error("lookup_sparse: K=%d unsupported (K/4 must be a power of two)", K); return DCTR_ERR_UNSUPPORTED;
-    }
-    DCTR_LAUNCH_CHECK();
-    return DCTR_OK;
+    return lookup_sparse_slots_fwd(d_emb, rows, K, d_offsets, d_ids, d_weights, B, 1, d_out, out_ld, d_status, as_stream(stream));
 }
 
 int dctr_embed_lookup_sparse_bwd(dctr_group_t g, const float* d_dout, int dout_ld, const int32_t* d_offsets, const int32_t* d_ids,
@@ -77,8 +91,7 @@ int dctr_embed_lookup_sparse_bwd(dctr_group_t g, const float* d_dout, int dout_l
     DCTR_REQUIRE(nnz >= 0 && (int64_t)nnz <= G->max_entries, "lookup_sparse_bwd: nnz=%d exceeds the group's capacity", nnz);
     DCTR_TRY(group_ids(G, d_ids, nnz, 1, st));
     if (nnz == 0 || B <= 0) return DCTR_OK;
-    entry_row_kernel<<<ceil_div(nnz, 256), 256, 0, st>>>(d_offsets, B, nnz, d_entry_row);
-    DCTR_LAUNCH_CHECK();
+    DCTR_TRY(csr_entry_offsets(d_offsets, B, nnz, 1, 4, 0, d_entry_row, st));
     // nnz "examples" of one field: entry j reads the gradient row of example entry_row[j], scaled by weights[j]
     return embed_scatter_bwd(G, d_dout, dout_ld, nullptr, 0, nullptr, nullptr, nullptr, d_weights, nnz, 1, K, DCTR_GATHER_RAW, G->gemb,
                              nullptr, st, 1, d_entry_row);

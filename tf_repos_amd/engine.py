@@ -42,6 +42,10 @@ class EngineConfig:
     lin_optimizer: str = "ftrl"
     lin_learning_rate: float = 0.005
     loss_sum: bool = False
+    # CSR (multi-hot) models din | esmm: field_size = number of K-wide slots of the MLP input (DIN.py:199), batches are
+    # (offsets [B*S+1], ids [nnz], weights [nnz]) with nnz <= max_entries (0: max_batch * field_size * 8)
+    max_entries: int = 0
+    ctr_task_wgt: float = 0.5                  # DeepCvrMTL.py:47
     use_graph: bool = False                    # False: eager launches on 3 HIP streams (measured faster: each stream keeps its own
                                                # hardware queue); True: one captured hipGraph per (batch size, input slot)
 
@@ -85,6 +89,8 @@ class EngineConfig:
         c.lin_optimizer = capi.OPTIMIZERS[self.lin_optimizer]
         c.lin_learning_rate = float(self.lin_learning_rate)
         c.loss_sum = int(self.loss_sum)
+        c.max_entries = int(self.max_entries)
+        c.ctr_task_wgt = float(self.ctr_task_wgt)
         return c
 
 
@@ -177,6 +183,23 @@ class Engine:
         capi.check(self._lib.dctr_train_step(self._h, capi.ptr(ids), capi.ptr(vals), capi.ptr(labels), B,
                                              C.byref(loss) if want_loss else None, st))
         return loss.value if want_loss else None
+
+    def train_step_csr(self, offsets, ids, weights, y, z=None, want_loss: bool = True, stream=None) -> Optional[float]:
+        """CSR models (din / esmm): offsets int32 [B*S+1], ids int32 [nnz], weights f32 [nnz] or None, labels y (and z for
+        esmm) f32 [B]; all device tensors."""
+        B = int(y.shape[0])
+        loss = C.c_float()
+        st = stream if stream is not None else capi.current_stream()
+        capi.check(self._lib.dctr_train_step_csr(self._h, capi.ptr(offsets), capi.ptr(ids), capi.ptr(weights), int(ids.shape[0]),
+                                                 capi.ptr(y), capi.ptr(z), B, C.byref(loss) if want_loss else None, st))
+        return loss.value if want_loss else None
+
+    def predict_csr(self, offsets, ids, weights, B: int, out0=None, out1=None, out2=None, stream=None):
+        """din: out0 = prob, out1 = logit; esmm: out0 = pctr, out1 = pcvr, out2 = pctcvr (DeepCvrMTL.py:212)."""
+        st = stream if stream is not None else capi.current_stream()
+        capi.check(self._lib.dctr_predict_csr(self._h, capi.ptr(offsets), capi.ptr(ids), capi.ptr(weights), int(ids.shape[0]), int(B),
+                                              capi.ptr(out0), capi.ptr(out1), capi.ptr(out2), st))
+        return out0
 
     def predict(self, ids, vals, out_prob=None, out_logit=None, stream=None, dense=None):
         self._set_dense(dense)
