@@ -154,6 +154,34 @@ int dctr_embed_gather_fwd(const float* d_emb, const float* d_lin, int64_t rows,
                           float* d_e, int e_ld, float* d_yw, float* d_sum, float* d_red,
                           int32_t* d_status, void* stream);
 
+/* ---- TFRecord input of the DIN / ESMM scripts (DIN.py:57-97, DeepCvrMTL.py:61-104): tf.data.TFRecordDataset +
+ * tf.parse_single_example over files written by Feature_pipeline/get_tfrecord.py:44-98.  Host code, re-entrant.
+ * dctr_tfrecord_scan: record framing.  rec_off[i] / rec_len[i] = payload of record i inside h_buf (either may be NULL to
+ * count only); stops at a truncated tail (*n_consumed = bytes of whole records); verify_crc checks both masked crc32c
+ * fields (DCTR_ERR_PARSE on mismatch = tf.errors.DataLossError).  dctr_tfrecord_frame writes one framed record
+ * (nbytes + 16 bytes) -- used to produce fixtures and caches. */
+int dctr_tfrecord_scan(const uint8_t* h_buf, size_t nbytes, int64_t max_records, int verify_crc, int64_t* rec_off,
+                       int64_t* rec_len, int64_t* n_records, size_t* n_consumed);
+int dctr_tfrecord_frame(const uint8_t* h_payload, size_t nbytes, uint8_t* h_out);
+/* one entry of the slot layout = one feature of the script's parse spec and where it lands in the MLP input:
+ *   fixed_len  > 0: FixedLenFeature([n], int64)  -> n slots of one entry each, weight 1   ("feat_ids", DIN.py:63)
+ *   fixed_len == 0: FixedLenFeature([], int64)   -> one slot, one entry                   ("a_catids",  DIN.py:73)
+ *   fixed_len  < 0: VarLenFeature(int64) [+ VarLenFeature(float32) weights]              ("u_catids"/"u_catvals", DIN.py:65-66) */
+typedef struct dctr_slot_spec {
+    const char* ids_feature;
+    const char* vals_feature;            /* NULL: all weights 1 (a_intids, DIN.py:76,148) */
+    int32_t     fixed_len;
+} dctr_slot_spec;
+/* tf.parse_single_example of n_records payloads straight into the slot-ordered CSR that dctr_train_step_csr consumes:
+ * h_offsets [n_records*S + 1] (S = total slots of the spec list, in list order), h_ids / h_weights [*n_entries],
+ * h_labels [n_labels, n_records] from FixedLenFeature([], float32) features (y, z).  Call once with h_ids == NULL to
+ * count *n_entries, then with buffers of cap_entries.  ids outside [0, feature_size) -> DCTR_ERR_INVALID_ARG (the
+ * gather's InvalidArgumentError, raised at parse time); a missing / wrong-length FixedLenFeature -> DCTR_ERR_PARSE. */
+int dctr_examples_to_slot_csr(const uint8_t* h_buf, const int64_t* rec_off, const int64_t* rec_len, int64_t n_records,
+                              const dctr_slot_spec* slots, int n_specs, const char* const* label_names, int n_labels,
+                              int64_t feature_size, int64_t cap_entries, int32_t* h_offsets, int32_t* h_ids,
+                              float* h_weights, float* h_labels, int64_t* n_entries);
+
 /* ---- K8a: group the batch's ids (the IndexedSlices -> unsorted_segment_sum bookkeeping,
  * SURVEY Appendix B item 2).  n = B*F entries, traversed field-major.  Workspace is owned by a
  * dctr_group object so that step calls never allocate. */

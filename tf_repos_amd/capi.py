@@ -41,6 +41,10 @@ class Config(C.Structure):
     ]
 
 
+class SlotSpec(C.Structure):
+    _fields_ = [("ids_feature", C.c_char_p), ("vals_feature", C.c_char_p), ("fixed_len", C.c_int32)]
+
+
 _lib: Optional[C.CDLL] = None
 
 _P = C.c_void_p
@@ -102,6 +106,10 @@ _SIGS = {
     "dctr_get_global_step": ([_P, C.POINTER(C.c_int64)], C.c_int),
     "dctr_train_step": ([_P, _P, _P, _P, C.c_int, C.POINTER(C.c_float), _P], C.c_int),
     "dctr_predict": ([_P, _P, _P, C.c_int, _P, _P, _P], C.c_int),
+    "dctr_tfrecord_scan": ([C.c_char_p, C.c_size_t, C.c_int64, C.c_int, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_size_t)], C.c_int),
+    "dctr_tfrecord_frame": ([C.c_char_p, C.c_size_t, _P], C.c_int),
+    "dctr_examples_to_slot_csr": ([C.c_char_p, _P, _P, C.c_int64, C.POINTER(SlotSpec), C.c_int, C.POINTER(C.c_char_p), C.c_int,
+                                   C.c_int64, C.c_int64, _P, _P, _P, _P, C.POINTER(C.c_int64)], C.c_int),
     "dctr_train_step_csr": ([_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_float), _P], C.c_int),
     "dctr_predict_csr": ([_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
     "dctr_eval_reset": ([_P, _P], C.c_int),
