@@ -327,6 +327,13 @@ int dctr_train_step_csr(dctr_handle h, const int32_t* d_offsets, const int32_t* 
 int dctr_predict_csr(dctr_handle h, const int32_t* d_offsets, const int32_t* d_ids, const float* d_weights, int nnz, int B,
                      float* d_out0, float* d_out1, float* d_out2, void* stream);
 
+/* mode EVAL of the CSR models: accumulates like dctr_eval_batch (same dctr_eval_reset / dctr_eval_result; the AUC there is
+ * auc(y, prob) for DIN and CTR_AUC = auc(y, pctr) for ESMM).  ESMM's CVR_AUC = auc(z, pcvr) and CTCVR_AUC = auc(z, pctcvr)
+ * (DeepCvrMTL.py:231-235) are read with dctr_eval_auc_extra(which = 1 / 2); syncs. */
+int dctr_eval_batch_csr(dctr_handle h, const int32_t* d_offsets, const int32_t* d_ids, const float* d_weights, int nnz,
+                        const float* d_y, const float* d_z, int B, void* stream);
+int dctr_eval_auc_extra(dctr_handle h, int which, float* h_auc, void* stream);
+
 /* mode EVAL (DeepFM.py:193-201): accumulate the loss and tf.metrics.auc's 200-threshold counters over an eval set */
 int dctr_eval_reset(dctr_handle h, void* stream);
 int dctr_eval_batch(dctr_handle h, const int32_t* d_ids, const float* d_vals, const float* d_labels, int B, void* stream);

@@ -112,6 +112,8 @@ _SIGS = {
                                    C.c_int64, C.c_int64, _P, _P, _P, _P, C.POINTER(C.c_int64)], C.c_int),
     "dctr_train_step_csr": ([_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_float), _P], C.c_int),
     "dctr_predict_csr": ([_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
+    "dctr_eval_batch_csr": ([_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, _P], C.c_int),
+    "dctr_eval_auc_extra": ([_P, C.c_int, C.POINTER(C.c_float), _P], C.c_int),
     "dctr_eval_reset": ([_P, _P], C.c_int),
     "dctr_eval_batch": ([_P, _P, _P, _P, C.c_int, _P], C.c_int),
     "dctr_eval_result": ([_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int64), _P], C.c_int),

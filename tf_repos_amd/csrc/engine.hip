@@ -302,7 +302,7 @@ int build(dctr_engine* E) {
     E->events.resize(64);
     for (auto& ev : E->events) DCTR_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 
-    DCTR_TRY(dmalloc(&E->auc_counts, 800));
+    DCTR_TRY(dmalloc(&E->auc_counts, 3 * 800));      // (ESMM: CTR_AUC, CVR_AUC, CTCVR_AUC -- DeepCvrMTL.py:231-235)
     DCTR_TRY(dmalloc(&E->eval_scalars, 2 * SUMSQ_SHARDS));   // [0..63] xent shards over the eval set, [64] sum of squares scratch
 
     // ---- activations
@@ -944,13 +944,14 @@ int csr_check(dctr_engine* E, const int32_t* off, const int32_t* ids, int nnz, i
 
 // x_in[b, s*K:(s+1)*K] = sum of the slot's weighted rows, then the tower(s) and the head
 int csr_forward(dctr_engine* E, const int32_t* off, const int32_t* ids, const float* wts, int B, const float* y, const float* z,
-                bool train, hipStream_t st) {
+                bool train, hipStream_t st, float* loss_shards = nullptr) {
+    if (loss_shards == nullptr) loss_shards = E->scalars;
     const dctr_config& c = E->cfg;
     DCTR_TRY(lookup_sparse_slots_fwd(E->emb, E->rows, E->K, off, ids, wts, B * E->F, E->F, E->x_in, E->Din_ld, E->status, st));
     DCTR_TRY(forward_rest(E, B, train, st));
     if (c.model == DCTR_MODEL_DIN) {
         E->labels = const_cast<float*>(y);
-        return head(E, B, B, y != nullptr, st);
+        return head(E, B, B, y != nullptr, st, loss_shards);
     }
     swap_tower(E);
     int rc = forward_rest(E, B, train, st);
@@ -958,7 +959,7 @@ int csr_forward(dctr_engine* E, const int32_t* off, const int32_t* ids, const fl
     DCTR_TRY(rc);
     return esmm_head(E->h.back(), E->mlp.back().out, E->pp(E->p_out_w), E->pp(E->p_out_b), E->mlp.back().out, E->h2.back(),
                      E->mlp2.back().out, E->pp(E->p_out2_w), E->pp(E->p_out2_b), E->mlp2.back().out, y, z, B, 1.0f / (float)B,
-                     c.ctr_task_wgt, E->y, E->y2, E->prob, E->prob2, E->prob3, E->dy, E->dy2, E->scalars, st);
+                     c.ctr_task_wgt, E->y, E->y2, E->prob, E->prob2, E->prob3, E->dy, E->dy2, loss_shards, st);
 }
 
 }  // namespace
@@ -1024,6 +1025,29 @@ int dctr_predict_csr(dctr_handle E, const int32_t* d_offsets, const int32_t* d_i
     return DCTR_OK;
 }
 
+// mode EVAL of the CSR models: loss + AUC counters accumulate exactly as dctr_eval_batch does (dctr_eval_reset / dctr_eval_result);
+// ESMM also counts CVR_AUC = auc(z, pcvr) and CTCVR_AUC = auc(z, pctcvr) (DeepCvrMTL.py:231-235), read with dctr_eval_auc_extra
+int dctr_eval_batch_csr(dctr_handle E, const int32_t* d_offsets, const int32_t* d_ids, const float* d_weights, int nnz,
+                        const float* d_y, const float* d_z, int B, void* stream) {
+    DCTR_TRY(csr_check(E, d_offsets, d_ids, nnz, B));
+    const bool esmm = E->cfg.model == DCTR_MODEL_ESMM;
+    DCTR_REQUIRE(d_y != nullptr && (!esmm || d_z != nullptr), "labels missing (ESMM takes y and z)");
+    DCTR_TRY(csr_forward(E, d_offsets, d_ids, d_weights, B, d_y, d_z, false, as_stream(stream), E->eval_scalars));
+    DCTR_TRY(dctr_auc_update(d_y, E->prob, B, E->auc_counts, stream));
+    if (esmm) {
+        DCTR_TRY(dctr_auc_update(d_z, E->prob2, B, E->auc_counts + 800, stream));
+        DCTR_TRY(dctr_auc_update(d_z, E->prob3, B, E->auc_counts + 1600, stream));
+    }
+    E->eval_examples += B;
+    E->last_B = B;
+    return DCTR_OK;
+}
+
+int dctr_eval_auc_extra(dctr_handle E, int which, float* h_auc, void* stream) {
+    DCTR_REQUIRE(E && h_auc && which >= 0 && which < 3, "which must be 0 (first output), 1 or 2");
+    return dctr_auc_result(E->auc_counts + 800 * which, h_auc, stream);
+}
+
 // ---- mode EVAL (DeepFM.py:193-201): streaming loss + tf.metrics.auc over an eval set --------------------------------------
 __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
     float s = 0.f;
@@ -1035,7 +1059,7 @@ __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __re
 
 int dctr_eval_reset(dctr_handle E, void* stream) {
     DCTR_REQUIRE(E, "null handle");
-    DCTR_HIP_CHECK(hipMemsetAsync(E->auc_counts, 0, 800 * sizeof(int64_t), as_stream(stream)));
+    DCTR_HIP_CHECK(hipMemsetAsync(E->auc_counts, 0, 3 * 800 * sizeof(int64_t), as_stream(stream)));
     DCTR_HIP_CHECK(hipMemsetAsync(E->eval_scalars, 0, 2 * SUMSQ_SHARDS * sizeof(float), as_stream(stream)));
     E->eval_examples = 0;
     return DCTR_OK;

@@ -194,6 +194,18 @@ class Engine:
                                                  capi.ptr(y), capi.ptr(z), B, C.byref(loss) if want_loss else None, st))
         return loss.value if want_loss else None
 
+    def eval_batch_csr(self, offsets, ids, weights, y, z=None, stream=None) -> None:
+        st = stream if stream is not None else capi.current_stream()
+        capi.check(self._lib.dctr_eval_batch_csr(self._h, capi.ptr(offsets), capi.ptr(ids), capi.ptr(weights), int(ids.shape[0]),
+                                                 capi.ptr(y), capi.ptr(z), int(y.shape[0]), st))
+
+    def eval_auc_extra(self, which: int, stream=None) -> float:
+        """esmm: which = 1 -> CVR_AUC (z, pcvr), 2 -> CTCVR_AUC (z, pctcvr); 0 -> the first output's AUC."""
+        a = C.c_float()
+        st = stream if stream is not None else capi.current_stream()
+        capi.check(self._lib.dctr_eval_auc_extra(self._h, int(which), C.byref(a), st))
+        return a.value
+
     def predict_csr(self, offsets, ids, weights, B: int, out0=None, out1=None, out2=None, stream=None):
         """din: out0 = prob, out1 = logit; esmm: out0 = pctr, out1 = pcvr, out2 = pctcvr (DeepCvrMTL.py:212)."""
         st = stream if stream is not None else capi.current_stream()

@@ -37,16 +37,21 @@ def build_module():
               "add", "subtract", "square", "reduce_sum", "reduce_mean", "matmul", "concat", "stack", "transpose", "gather", "einsum",
               "ones_like", "identity", "sigmoid", "cast", "cond", "split", "string_split", "string_to_number", "decode_csv"):
         setattr(tf, n, getattr(_g, n))
+    for n in ("FixedLenFeature", "VarLenFeature", "parse_single_example", "sparse_tensor_to_dense", "AUTO_REUSE"):
+        setattr(tf, n, getattr(_g, n))
+    tf.losses = _mod("tensorflow.losses", log_loss=_g.log_loss)
+    tf.summary = _mod("tensorflow.summary", scalar=_g.summary_scalar)
     tf.Graph = _g.Graph
     tf.nn = _mod("tensorflow.nn", embedding_lookup=_g.embedding_lookup, dropout=_g.dropout, softmax=_g.softmax, l2_loss=_g.l2_loss,
-                 sigmoid_cross_entropy_with_logits=_g.sigmoid_cross_entropy_with_logits, relu=_g.relu, sigmoid=_g.sigmoid)
+                 sigmoid_cross_entropy_with_logits=_g.sigmoid_cross_entropy_with_logits, relu=_g.relu, sigmoid=_g.sigmoid,
+                 embedding_lookup_sparse=_g.embedding_lookup_sparse)
     layers = _mod("tensorflow.contrib.layers", fully_connected=_g.fully_connected, l2_regularizer=_g.l2_regularizer, batch_norm=_g.batch_norm)
     tf.contrib = _mod("tensorflow.contrib", layers=layers)
     tf.train = _mod("tensorflow.train", AdamOptimizer=_g.AdamOptimizer, AdagradOptimizer=_g.AdagradOptimizer,
                     MomentumOptimizer=_g.MomentumOptimizer, FtrlOptimizer=_g.FtrlOptimizer, get_global_step=_g.get_global_step,
                     get_or_create_global_step=_g.get_or_create_global_step)
     tf.metrics = _mod("tensorflow.metrics", auc=_g.metrics_auc)
-    tf.data = _mod("tensorflow.data", TextLineDataset=_data.TextLineDataset)
+    tf.data = _mod("tensorflow.data", TextLineDataset=_data.TextLineDataset, TFRecordDataset=_data.TFRecordDataset)
     export = _mod("tensorflow.estimator.export", PredictOutput=_est.PredictOutput, ServingInputReceiver=_est.ServingInputReceiver,
                   build_raw_serving_input_receiver_fn=_est.build_raw_serving_input_receiver_fn,
                   build_parsing_serving_input_receiver_fn=_canned.build_parsing_serving_input_receiver_fn)
@@ -74,7 +79,7 @@ def install(force: bool = False):
         raise RuntimeError("a real tensorflow is already imported")
     tf = build_module()
     sys.modules["tensorflow"] = tf
-    for sub in ("nn", "contrib", "train", "metrics", "data", "estimator", "saved_model", "app", "feature_column"):
+    for sub in ("nn", "contrib", "train", "metrics", "data", "estimator", "saved_model", "app", "feature_column", "losses", "summary"):
         sys.modules["tensorflow." + sub] = getattr(tf, sub)
     sys.modules["tensorflow.contrib.layers"] = tf.contrib.layers
     sys.modules["tensorflow.estimator.export"] = tf.estimator.export

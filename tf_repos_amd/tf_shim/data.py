@@ -47,11 +47,19 @@ class Dataset:
         self.field_size: Optional[int] = None
         # CSV pipelines (wide_n_deep.py:66-89): column kinds/defaults of decode_csv, feature key -> column, label column
         self.csv: Optional[Dict] = None
+        # TFRecord pipelines (DIN.py:57-97, DeepCvrMTL.py:61-104): the traced parse spec; the slot layout comes from the model
+        self.tfrecord = False
+        self.example: Optional[Dict] = None      # {"features": {key: parsed node}, "labels": {key: parsed node} | node}
+        self.slot_specs = None                   # set by the Estimator after lowering (tfrecord.SlotSpec list)
+        self.label_keys: List[str] = []
+        self.feature_size = 0
 
     # -- pipeline construction (each call returns self: the pipeline is a linear chain in the reference) ---------------
     def map(self, fn, num_parallel_calls=None):
         if num_parallel_calls:
             self.num_parallel_calls = int(num_parallel_calls)
+        if self.tfrecord:
+            return self._map_example(fn)
         line = G.Tensor("text_line", [], {}, G.string, ())
         out = fn(line)
         if not (isinstance(out, tuple) and len(out) == 2 and isinstance(out[0], dict)):
@@ -66,6 +74,32 @@ class Dataset:
         if set(self.feature_keys) != {"ids", "vals"}:
             raise errors.UnimplementedError("features must be the libsvm ids and vals")
         return self
+
+    def _map_example(self, fn):
+        """map(_parse_fn): parsed = tf.parse_single_example(record, spec); labels popped from it (DIN.py:59-81)."""
+        out = fn(G.Tensor("tfrecord", [], {}, G.string, ()))
+        if not (isinstance(out, tuple) and len(out) == 2 and isinstance(out[0], dict)):
+            raise errors.UnimplementedError("map function must return (parsed_features_dict, labels)")
+        feats, labels = out
+        lab = labels if isinstance(labels, dict) else {"__label__": labels}
+        for k, v in list(feats.items()) + list(lab.items()):
+            if not (isinstance(v, G.Tensor) and v.op in ("parsed_fixed", "parsed_varlen")):
+                raise errors.UnimplementedError("feature %r is not an output of tf.parse_single_example" % k)
+        for k, v in lab.items():
+            if v.op != "parsed_fixed" or v.attrs["shape"] != () or v.dtype is not G.float32:
+                raise errors.UnimplementedError("label %r must be FixedLenFeature([], tf.float32)" % k)
+        self.example = {"features": dict(feats), "labels": labels}
+        return self
+
+    def slot_batches(self):
+        """numpy CSR batches (offsets, ids, weights, labels [n_labels, b]) in the slot layout the model was lowered to"""
+        from ..tfrecord import TFRecordSlotDataset
+        if self.slot_specs is None:
+            raise errors.InvalidArgumentError("slot layout unknown: the model_fn has not been lowered yet")
+        if not self.filenames:
+            return iter(())
+        return iter(TFRecordSlotDataset(self.filenames, self.slot_specs, self.label_keys, self.feature_size, self.batch_size,
+                                        self.num_epochs, self.perform_shuffle))
 
     def _map_csv(self, feats, label):
         """map(parse_csv): columns = tf.decode_csv(line, record_defaults); features = dict(zip(names, columns)); labels = pop."""
@@ -136,6 +170,19 @@ class _Iterator:
 
     def get_next(self):
         ds = self.ds
+        if ds.tfrecord:
+            if ds.example is None:
+                raise errors.UnimplementedError("TFRecordDataset without a parse map function")
+            def it(k, v):
+                if v.op == "parsed_fixed":
+                    return G.Tensor("iterator_fixed", [], {"dataset": ds, "key": v.attrs["key"], "shape": v.attrs["shape"]}, v.dtype,
+                                    (None,) + tuple(v.attrs["shape"]))
+                return G.Tensor("iterator_varlen", [], {"dataset": ds, "key": v.attrs["key"]}, v.dtype, (None, None))
+            feats = {k: it(k, v) for k, v in ds.example["features"].items()}
+            lab = ds.example["labels"]
+            labels = {k: it(k, v) for k, v in lab.items()} if isinstance(lab, dict) else it("__label__", lab)
+            G.current_graph().collections.setdefault("iterators", []).append(ds)
+            return feats, labels
         if ds.csv is not None:
             feats = {n: G.Tensor("iterator_csv", [], {"dataset": ds, "column": n}, G.float32 if k == 0 else G.int32, (None,))
                      for n, k in zip(ds.csv["names"], ds.csv["kinds"]) if n != "__label__"}
@@ -153,3 +200,9 @@ class _Iterator:
 
 def TextLineDataset(filenames, **_kw):
     return Dataset(filenames)
+
+
+def TFRecordDataset(filenames, **_kw):
+    ds = Dataset(filenames)
+    ds.tfrecord = True
+    return ds

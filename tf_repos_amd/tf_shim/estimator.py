@@ -163,20 +163,28 @@ class Estimator:
                 raise ValueError("model_fn should return an EstimatorSpec.")
             lowered = lower(spec.loss, spec.train_op, spec.predictions or {}, FLAGS_MODULE.FLAGS)
             pipeline = g.collections.get("iterators", [None])[-1]
-            if pipeline is not None:
+            if pipeline is not None and lowered.slots is not None:
+                from ..tfrecord import SlotSpec
+                pipeline.slot_specs = [SlotSpec(*s) for s in lowered.slots]   # the concat order of the model fixes the slot layout
+                pipeline.label_keys = list(lowered.label_keys)
+                pipeline.feature_size = int(lowered.config_kwargs["feature_size"])
+            elif pipeline is not None:
                 pipeline.field_size = lowered.config_kwargs["field_size"]     # reshape(feat_ids, [-1, field_size]) fixes F
             variables = dict(g.variables)
         return spec, lowered, pipeline, variables
 
-    def _ensure_engine(self, lowered: Lowered, variables, batch_size: int):
-        need_new = self._engine is None or self._engine.cfg.max_batch < batch_size
+    def _ensure_engine(self, lowered: Lowered, variables, batch_size: int, max_entries: int = 0):
+        need_new = self._engine is None or self._engine.cfg.max_batch < batch_size or self._engine.cfg.max_entries < max_entries
         if self._engine is not None and not need_new:
             return
         state = self._snapshot() if self._engine is not None else None
         if self._engine is not None:
+            batch_size = max(batch_size, self._engine.cfg.max_batch)
+            max_entries = max(max_entries, self._engine.cfg.max_entries)
             self._engine.close()
+        extra = {"max_entries": int(max_entries)} if lowered.slots is not None else {}
         cfg = lowered.engine_config(max_batch=batch_size, table_mode=self.table_mode,
-                                    seed=int(self._config.tf_random_seed or 0))
+                                    seed=int(self._config.tf_random_seed or 0), **extra)
         self._engine = Engine(cfg)
         self._lowered = lowered
         self._variables = variables
@@ -246,25 +254,59 @@ class Estimator:
                    torch.from_numpy(np.ascontiguousarray(vals)).pin_memory().to(dev, non_blocking=True),
                    torch.from_numpy(np.ascontiguousarray(labels)).pin_memory().to(dev, non_blocking=True))
 
+    # CSR (multi-hot) models: TFRecord pipelines in the slot layout the model was lowered to
+    def _csr_batches(self, pipeline: "D.Dataset"):
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory().to(dev, non_blocking=True)
+        for off, ids, wts, labels in pipeline.slot_batches():
+            yield up(off), up(ids), up(wts), up(labels[0]), (up(labels[1]) if labels.shape[0] > 1 else None)
+
+    @staticmethod
+    def _csr_capacity(pipeline: "D.Dataset") -> int:
+        """an upper bound of any batch's entry count: batch_size x the largest example"""
+        from ..tfrecord import TFRecordSlotDataset
+        if not pipeline.filenames:
+            return 0
+        ds = TFRecordSlotDataset(pipeline.filenames, pipeline.slot_specs, pipeline.label_keys, pipeline.feature_size)
+        off = ds._load()[0]
+        per_example = np.diff(off[::ds.n_slots])
+        return int(pipeline.batch_size * (per_example.max() if len(per_example) else 0))
+
+    def _metric_outputs(self, spec, lowered) -> Dict[str, int]:
+        """eval metric key -> engine output index (its tf.metrics.auc reads one of the predictions)"""
+        by_id = {id(t): lowered.outputs.get(k, 0) for k, t in (spec.predictions or {}).items()}
+        out = {}
+        for key, val in (spec.eval_metric_ops or {}).items():
+            node = val[0] if isinstance(val, tuple) else val
+            out[key] = by_id.get(id(node.inputs[1]), 0) if node is not None and node.op == "metrics_auc" else 0
+        return out
+
     def train(self, input_fn, hooks=None, steps=None, max_steps=None, saving_listeners=None):
         from . import logging as L
         spec, lowered, pipeline, variables = self._build(input_fn, ModeKeys.TRAIN)
         if pipeline is None:
             raise errors.InvalidArgumentError("input_fn must return tensors produced by a tf.data iterator")
-        self._ensure_engine(lowered, variables, pipeline.batch_size)
+        csr = lowered.slots is not None
+        self._ensure_engine(lowered, variables, pipeline.batch_size, self._csr_capacity(pipeline) if csr else 0)
         e = self._engine
         log_every = max(1, int(self._config.log_step_count_steps or 100))
         start_step = e.global_step
         t0, n0 = time.time(), 0
         done = 0
         loss = None
-        for ids, vals, labels in self._device_batches(pipeline):
+        for batch in (self._csr_batches(pipeline) if csr else self._device_batches(pipeline)):
             if steps is not None and done >= steps:
                 break
             if max_steps is not None and start_step + done >= max_steps:
                 break
             want = (done + 1) % log_every == 0
-            loss = e.train_step(ids, vals, labels, want_loss=want)
+            if csr:
+                off, ids, wts, labels, z = batch
+                loss = e.train_step_csr(off, ids, wts, labels, z, want_loss=want)
+            else:
+                ids, vals, labels = batch
+                loss = e.train_step(ids, vals, labels, want_loss=want)
             done += 1
             n0 += int(labels.shape[0])
             if want:
@@ -280,32 +322,51 @@ class Estimator:
     def evaluate(self, input_fn, steps=None, hooks=None, checkpoint_path=None, name=None):
         from . import logging as L
         spec, lowered, pipeline, variables = self._build(input_fn, ModeKeys.EVAL)
-        self._ensure_engine(lowered, variables, pipeline.batch_size)
+        csr = lowered.slots is not None
+        self._ensure_engine(lowered, variables, pipeline.batch_size, self._csr_capacity(pipeline) if csr else 0)
         e = self._engine
         e.eval_reset()
         n = 0
-        for ids, vals, labels in self._device_batches(pipeline):
+        for batch in (self._csr_batches(pipeline) if csr else self._device_batches(pipeline)):
             if steps is not None and n >= steps:
                 break
-            e.eval_batch(ids, vals, labels)
+            if csr:
+                e.eval_batch_csr(*batch)
+            else:
+                e.eval_batch(*batch)
             n += 1
         e.check_ids()
         auc, loss, _count = e.eval_result()
         out = {"loss": loss, "global_step": e.global_step}
+        which = self._metric_outputs(spec, lowered) if csr else {}
         for key in (spec.eval_metric_ops or {"auc": None}):
-            out[key] = auc
+            out[key] = e.eval_auc_extra(which[key]) if which.get(key, 0) else auc
         L.info("Saving dict for global step %d: %s" % (e.global_step, ", ".join("%s = %s" % kv for kv in sorted(out.items()))))
         return out
 
     def predict(self, input_fn, predict_keys=None, hooks=None, checkpoint_path=None, yield_single_examples=True) -> Iterator[Dict[str, Any]]:
         import torch
         spec, lowered, pipeline, variables = self._build(input_fn, ModeKeys.PREDICT)
-        self._ensure_engine(lowered, variables, pipeline.batch_size)
+        csr = lowered.slots is not None
+        self._ensure_engine(lowered, variables, pipeline.batch_size, self._csr_capacity(pipeline) if csr else 0)
         e = self._engine
         keys = list(spec.predictions.keys())
         if predict_keys is not None:
             want = [predict_keys] if isinstance(predict_keys, str) else list(predict_keys)
             keys = [k for k in keys if k in want]
+        if csr:
+            for off, ids, wts, y, _z in self._csr_batches(pipeline):
+                B = int(y.shape[0])
+                outs = [torch.empty(B, dtype=torch.float32, device=ids.device) for _ in range(3)]
+                e.predict_csr(off, ids, wts, B, *outs)
+                host = [o.cpu().numpy() for o in outs]
+                e.check_ids()
+                if yield_single_examples:
+                    for i in range(B):
+                        yield {k: host[lowered.outputs[k]][i] for k in keys}
+                else:
+                    yield {k: host[lowered.outputs[k]] for k in keys}
+            return
         for ids, vals, _labels in self._device_batches(pipeline):
             prob = torch.empty(int(ids.shape[0]), dtype=torch.float32, device=ids.device)
             e.predict(ids, vals, prob, None)
@@ -321,6 +382,9 @@ class Estimator:
         """Writes the variables (TF names) and the serving signature: inputs feat_ids int64 [None,F] / feat_vals float32
         [None,F], output key(s) of `predictions` (DeepFM.py:361-366).  Not a TF SavedModel protobuf (no TF here)."""
         recv = serving_input_receiver_fn()
+        if self._lowered is not None and self._lowered.slots is not None:
+            raise errors.UnimplementedError("export of the DIN / ESMM models: the scripts' own serving spec (feat_ids / feat_vals only, "
+                                            "DIN.py:387-391) does not feed their model_fn")
         with G.Graph() as g:
             feats = {k: G.placeholder(v.dtype, v.shape, name=k) for k, v in recv.features.items()}
             spec = self._call_model_fn(feats, None, ModeKeys.PREDICT)

@@ -11,6 +11,8 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+from .. import errors
+
 
 class DType:
     def __init__(self, name, np_dtype):
@@ -83,7 +85,21 @@ class variable_scope:
         return False
 
 
-name_scope = variable_scope
+class name_scope:
+    """tf.name_scope names ops only: variables created under it keep their variable_scope name [TF-1.x]
+    (DeepCvrMTL.py:166,185: 'cvr_mlp0/weights', not 'CVR_Task/cvr_mlp0/weights')."""
+
+    def __init__(self, name, *a, **_kw):
+        self.name = name
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+AUTO_REUSE = "AUTO_REUSE"
 
 
 def _bshape(a, b):
@@ -457,6 +473,56 @@ def batch_norm(inputs, decay=0.999, center=True, scale=False, epsilon=0.001, upd
     ins = [inputs] + [v for v in (beta, gamma, mm, mv) if v is not None]
     return Tensor("batch_norm", ins, {"decay": decay, "epsilon": epsilon, "is_training": bool(is_training), "center": center,
                                        "scale": scale}, inputs.dtype, inputs.shape)
+
+
+# ---- tf.Example parsing + variable-length lookups (DIN.py:57-97,143-183; DeepCvrMTL.py:61-104,153-165) ------------------------
+class FixedLenFeature:
+    def __init__(self, shape, dtype, default_value=None):
+        self.shape, self.dtype, self.default_value = list(shape), dtype, default_value
+
+
+class VarLenFeature:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+
+def parse_single_example(serialized, features, name=None, example_names=None):
+    """-> {key: Tensor}; FixedLenFeature -> dense tensor of its shape, VarLenFeature -> a SparseTensor node."""
+    out = {}
+    for key, spec in features.items():
+        if isinstance(spec, FixedLenFeature):
+            if spec.default_value is not None:
+                raise errors.UnimplementedError("FixedLenFeature(default_value=...) is not used by the reference scripts")
+            out[key] = Tensor("parsed_fixed", [serialized], {"key": key, "shape": tuple(spec.shape)}, spec.dtype, tuple(spec.shape))
+        elif isinstance(spec, VarLenFeature):
+            out[key] = Tensor("parsed_varlen", [serialized], {"key": key}, spec.dtype, (None,))
+        else:
+            raise errors.UnimplementedError("parse_single_example feature spec %r" % (spec,))
+    return out
+
+
+def embedding_lookup_sparse(params, sp_ids, sp_weights, partition_strategy="mod", name=None, combiner=None, max_norm=None):
+    """combiner="sum": out[b] = sum_j w_j params[id_j] over row b's entries (DIN.py:148,180-183)."""
+    if combiner != "sum":
+        raise errors.UnimplementedError("embedding_lookup_sparse(combiner=%r): the reference scripts use 'sum'" % (combiner,))
+    ins = [params, sp_ids] + ([sp_weights] if sp_weights is not None else [])
+    return Tensor("embedding_lookup_sparse", ins, {"weighted": sp_weights is not None}, params.dtype, (None, params.shape[1]))
+
+
+def sparse_tensor_to_dense(sp_input, default_value=0, validate_indices=True, name=None):
+    raise errors.UnimplementedError("DIN attention pooling (attention_unit, DIN.py:151-177) is not implemented in the engine: run with "
+                                    "--attention_pooling=False (field-wise sum pooling, DIN.py:179-183)")
+
+
+def log_loss(labels, predictions, weights=1.0, epsilon=1e-7, scope=None, **_kw):
+    """tf.losses.log_loss: mean over the batch of -z log(p+eps) - (1-z) log(1-p+eps) [TF-1.4] (DeepCvrMTL.py:224)."""
+    if weights != 1.0:
+        raise errors.UnimplementedError("log_loss(weights=...)")
+    return Tensor("log_loss", [_t(labels), _t(predictions)], {"epsilon": float(epsilon)}, float32, ())
+
+
+def summary_scalar(name, tensor, **_kw):
+    return None
 
 
 # ---- metrics / train ------------------------------------------------------------------------------------------------------

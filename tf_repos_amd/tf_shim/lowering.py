@@ -22,6 +22,11 @@ class Lowered:
     config_kwargs: Dict
     name_map: Dict[str, str]                 # engine parameter name -> TF variable name
     predict_keys: List[str] = field(default_factory=lambda: ["prob"])
+    # CSR (multi-hot) models: the slot layout of the MLP input [(ids_key, vals_key | None, fixed_len)], the label keys
+    # (["y"] / ["y", "z"]) and which engine output each predictions key / eval metric reads
+    slots: Optional[List[Tuple[str, Optional[str], int]]] = None
+    label_keys: List[str] = field(default_factory=list)
+    outputs: Dict[str, int] = field(default_factory=dict)
 
     def engine_config(self, max_batch: int, **overrides) -> EngineConfig:
         kw = dict(self.config_kwargs)
@@ -46,6 +51,8 @@ def lower(loss: Optional[G.Tensor], train_op: Optional[G.Tensor], predictions: D
     for n in nodes:
         by_op.setdefault(n.op, []).append(n)
     bn_ops = by_op.get("batch_norm", [])
+    if by_op.get("embedding_lookup_sparse") or by_op.get("iterator_varlen"):
+        return _lower_multihot(loss, train_op, predictions, nodes, by_op)
 
     # ---- tables --------------------------------------------------------------------------------------------------
     lookups = by_op.get("embedding_lookup", [])
@@ -211,6 +218,161 @@ def lower(loss: Optional[G.Tensor], train_op: Optional[G.Tensor], predictions: D
         kw["optimizer"] = a["optimizer"]
         kw["learning_rate"] = a["learning_rate"]
     return Lowered(model=model, config_kwargs=kw, name_map=name_map, predict_keys=list(predictions.keys()))
+
+
+def _optimizer_kwargs(train_op) -> Dict:
+    if train_op.op != "minimize":
+        raise _unsupported("train_op must come from optimizer.minimize(loss, global_step)")
+    a = train_op.attrs
+    h = a["hyper"]
+    ok = {"Adam": h.get("beta1") == 0.9 and h.get("beta2") == 0.999 and h.get("epsilon") == 1e-8,
+          "Adagrad": h.get("initial_accumulator_value") == 1e-8,
+          "Momentum": h.get("momentum") == 0.95 and not h.get("use_nesterov"),
+          "ftrl": h.get("learning_rate_power") == -0.5 and h.get("initial_accumulator_value") == 0.1 and not h.get("l1") and not h.get("l2")}
+    if not ok.get(a["optimizer"], False):
+        raise _unsupported("optimizer %s with hyper-parameters %s (engine implements the reference's settings only)" % (a["optimizer"], h))
+    return {"optimizer": a["optimizer"], "learning_rate": a["learning_rate"]}
+
+
+def _lower_multihot(loss, train_op, predictions, nodes, by_op) -> Lowered:
+    """DIN with field-wise sum pooling (DIN.py:143-148,179-222) and ESMM (DeepCvrMTL.py:153-225): one shared embedding table,
+    the MLP input = concat of [reshape(lookup(E, fixed ids [F'])) | lookup_sparse(E, ids, weights) ... | lookup(E, scalar id) ...],
+    one tower + sigmoid xent (DIN) or a CTR and a CVR tower with the pCTCVR log-loss (ESMM)."""
+    if by_op.get("batch_norm"):
+        raise _unsupported("batch_norm=True is not implemented for the DIN / ESMM graphs")
+    fcs = by_op.get("fully_connected", [])
+    hidden = [f for f in fcs if f.attrs["activation"] == "relu"]
+    outs = [f for f in fcs if f.attrs["activation"] == "identity"]
+    concats = [c for c in by_op.get("concat", []) if c.attrs["axis"] == 1]
+    if len(concats) != 1 or not hidden:
+        raise _unsupported("expected one tf.concat(axis=1) feeding the MLP(s)")
+    xcat = concats[0]
+
+    # ---- slot layout, in concat order ----------------------------------------------------------------------------------------------
+    emb_var = None
+    slots: List[Tuple[str, Optional[str], int]] = []
+    for part in xcat.inputs:
+        src = _through(part, ops=("reshape", "identity"))
+        if src.op == "embedding_lookup":
+            var, ids = src.inputs
+            if ids.op != "iterator_fixed":
+                raise _unsupported("embedding_lookup ids must be a FixedLenFeature of the parsed Example")
+            shp = ids.attrs["shape"]
+            if len(shp) > 1:
+                raise _unsupported("FixedLenFeature of rank %d" % len(shp))
+            slots.append((ids.attrs["key"], None, int(shp[0]) if shp else 0))
+        elif src.op == "embedding_lookup_sparse":
+            var, ids = src.inputs[0], src.inputs[1]
+            wts = src.inputs[2] if len(src.inputs) > 2 else None
+            if ids.op != "iterator_varlen" or (wts is not None and wts.op != "iterator_varlen"):
+                raise _unsupported("embedding_lookup_sparse ids / weights must be VarLenFeatures of the parsed Example")
+            slots.append((ids.attrs["key"], wts.attrs["key"] if wts is not None else None, -1))
+        else:
+            raise _unsupported("MLP input part produced by %s" % src.op)
+        if not isinstance(var, G.Variable) or (emb_var is not None and var is not emb_var):
+            raise _unsupported("all lookups must read one shared embedding variable")
+        emb_var = var
+    V, K = int(emb_var.shape[0]), int(emb_var.shape[1])
+    S = sum(n if n > 0 else 1 for _, _, n in slots)
+    name_map: Dict[str, str] = {"emb": emb_var.var_name}
+
+    # ---- towers ------------------------------------------------------------------------------------------------------------------------
+    def chain(out_fc):
+        """hidden layers from the concat to this output layer"""
+        layers = []
+        t = _through(out_fc.inputs[0], ops=("reshape", "identity", "dropout"))
+        while t is not xcat:
+            if t.op != "fully_connected" or t.attrs["activation"] != "relu":
+                raise _unsupported("tower contains %s" % t.op)
+            layers.append(t)
+            t = _through(t.inputs[0], ops=("reshape", "identity", "dropout"))
+        return layers[::-1]
+
+    if any(int(o.attrs["num_outputs"]) != 1 for o in outs):
+        raise _unsupported("output layers must have width 1")
+    xents = by_op.get("sigmoid_xent", [])
+    keep_of = {id(_through(d.inputs[0])): d.attrs["keep_prob"] for d in by_op.get("dropout", [])}
+    kw: Dict = dict(field_size=S, feature_size=V, embedding_size=K)
+    outputs: Dict[str, int] = {}
+    if len(outs) == 1:
+        model, label_keys = "din", ["y"]
+        tower = chain(outs[0])
+        towers = [("", "deep_out", tower, outs[0])]
+        outputs = {k: 0 for k in predictions}            # {"prob": sigmoid(y)} (DIN.py:210-212)
+    elif len(outs) == 2 and by_op.get("log_loss") or (len(outs) == 2 and loss is None):
+        model, label_keys = "esmm", ["y", "z"]
+        if loss is not None:
+            if len(xents) != 1:
+                raise _unsupported("ESMM loss must hold one sigmoid xent (CTR) and one log_loss (CTCVR)")
+            ctr_out = _through(xents[0].inputs[0])
+            if ctr_out not in outs:
+                raise _unsupported("CTR logits are not an output layer")
+        else:       # PREDICT graphs carry no loss: the towers are told apart by their variable scopes (DeepCvrMTL.py:195,203)
+            ctr_out = next((o for o in outs if "ctr" in o.inputs[1].var_name), outs[1])
+        cvr_out = next(o for o in outs if o is not ctr_out)
+        towers = [("ctr_", "ctr_out", chain(ctr_out), ctr_out), ("cvr_", "cvr_out", chain(cvr_out), cvr_out)]
+        if [int(f.attrs["num_outputs"]) for f in towers[0][2]] != [int(f.attrs["num_outputs"]) for f in towers[1][2]]:
+            raise _unsupported("the CTR and CVR towers must have the same layer widths")
+        # predictions (DeepCvrMTL.py:207-212): sigmoid of each tower's logit and their product
+        for key, t in predictions.items():
+            t0 = _through(t)
+            if t0.op == "sigmoid":
+                outputs[key] = 0 if _through(t0.inputs[0]) is ctr_out else 1
+            elif t0.op == "mul":
+                outputs[key] = 2
+            else:
+                raise _unsupported("prediction %r produced by %s" % (key, t0.op))
+    else:
+        raise _unsupported("%d output layers" % len(outs))
+    keep = None
+    for prefix, oname, layers, out in towers:
+        for i, f in enumerate(layers):
+            name_map["%smlp%d/weights" % (prefix, i)], name_map["%smlp%d/biases" % (prefix, i)] = f.inputs[1].var_name, f.inputs[2].var_name
+        name_map[oname + "/weights"], name_map[oname + "/biases"] = out.inputs[1].var_name, out.inputs[2].var_name
+        k2 = tuple(float(keep_of.get(id(f), 1.0)) for f in layers)
+        if keep is not None and k2 != keep:
+            raise _unsupported("the towers use different dropout keep_probs")
+        keep = k2
+    kw.update(model=model, deep_layers=tuple(int(f.attrs["num_outputs"]) for f in towers[0][2]), dropout=keep)
+
+    # ---- loss --------------------------------------------------------------------------------------------------------------------------
+    if loss is not None:
+        consts = {}
+        for m in by_op.get("mul", []):
+            a, b = m.inputs
+            c, l = (a, b) if a.op == "const" else (b, a)
+            if c.op != "const":
+                continue
+            l0 = _through(l, ops=("reshape", "identity", "reduce_mean"))
+            if l0.op == "l2_loss" and l0.inputs[0] is emb_var:
+                consts["l2"] = float(c.attrs["value"])
+            elif l0.op == "sigmoid_xent":
+                consts["ctr"] = float(c.attrs["value"])
+            elif l0.op == "log_loss":
+                consts["cvr"] = float(c.attrs["value"])
+        kw["l2_reg"] = consts.get("l2", 0.0)
+        if model == "esmm":
+            if "ctr" not in consts or "cvr" not in consts or abs(consts["ctr"] + consts["cvr"] - 1.0) > 1e-6:
+                raise _unsupported("ESMM loss must be w * ctr_loss + (1 - w) * cvr_loss (DeepCvrMTL.py:225)")
+            ll = by_op["log_loss"][0]
+            if abs(ll.attrs["epsilon"] - 1e-7) > 1e-15:
+                raise _unsupported("log_loss epsilon must be the default 1e-7")
+            kw["ctr_task_wgt"] = consts["ctr"]
+        elif len(xents) != 1:
+            raise _unsupported("DIN loss is not one sigmoid_cross_entropy_with_logits")
+        # which parsed label feeds which task: xent labels = clicks (y), log_loss labels = conversions (z)
+        def label_key(t):
+            t = _through(t)
+            if t.op != "iterator_fixed":
+                raise _unsupported("labels must be FixedLenFeature([], float32) outputs of the parsed Example")
+            return t.attrs["key"]
+        label_keys = [label_key(xents[0].inputs[1])]
+        if model == "esmm":
+            label_keys.append(label_key(by_op["log_loss"][0].inputs[0]))
+    if train_op is not None:
+        kw.update(_optimizer_kwargs(train_op))
+    return Lowered(model=model, config_kwargs=kw, name_map=name_map, predict_keys=list(predictions.keys()), slots=slots,
+                   label_keys=label_keys, outputs=outputs)
 
 
 def _uses(node, var, nodes) -> bool:
