@@ -111,3 +111,29 @@ def test_errors(dev):
     with pytest.raises(errors.InvalidArgumentError):       # ESMM needs both labels
         eng.train_step_csr(off, ids, wts, y, None)
     eng.close()
+
+
+def test_large_batch_with_hot_ids_uses_chunked_grouping(dev):
+    """nnz > 8192 with a Zipf head: the id grouping aggregates 2048-entry chunks in an LDS hash table (group.hip) -- results must
+    still match the oracle's dense segment sums."""
+    B = 600
+    ocfg, params, eng = make_pair("esmm", B, V=3000, opt="Adagrad", lr=1e-2)
+    ecap = B * (ocfg.n_slots + 5 * 41)
+    eng.close()
+    ecfg = EngineConfig(model="esmm", field_size=ocfg.n_slots, feature_size=3000, embedding_size=8, deep_layers=(32, 16), dropout=(1.0, 1.0),
+                        l2_reg=1e-3, learning_rate=1e-2, optimizer="Adagrad", max_batch=B, max_entries=ecap, ctr_task_wgt=0.5)
+    eng = Engine(ecfg)
+    eng.set_params(params)
+    oopt = M.Optimizer(ocfg, params)
+    for step in range(2):
+        batch = M.synth_batch(ocfg, B, seed=80 + step, max_len=40)
+        off, ids, wts, y, z = dev_csr(ocfg, batch, dev)
+        assert ids.shape[0] > 4 * 2048
+        ref_loss, _ = M.train_step(ocfg, params, oopt, batch)
+        loss = eng.train_step_csr(off, ids, wts, y, z)
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (step, loss, ref_loss)
+    got = eng.get_params()
+    for name, ref in params.items():
+        diff = np.abs(got[name] - ref.numpy()).max()
+        assert diff <= 5e-6, (name, diff)          # segment sums of up to ~10^4 entries in a different order than the oracle's
+    eng.close()

@@ -943,11 +943,11 @@ int csr_check(dctr_engine* E, const int32_t* off, const int32_t* ids, int nnz, i
 }
 
 // x_in[b, s*K:(s+1)*K] = sum of the slot's weighted rows, then the tower(s) and the head
-int csr_forward(dctr_engine* E, const int32_t* off, const int32_t* ids, const float* wts, int B, const float* y, const float* z,
+int csr_forward(dctr_engine* E, const int32_t* off, const int32_t* ids, const float* wts, int nnz, int B, const float* y, const float* z,
                 bool train, hipStream_t st, float* loss_shards = nullptr) {
     if (loss_shards == nullptr) loss_shards = E->scalars;
     const dctr_config& c = E->cfg;
-    DCTR_TRY(lookup_sparse_slots_fwd(E->emb, E->rows, E->K, off, ids, wts, B * E->F, E->F, E->x_in, E->Din_ld, E->status, st));
+    DCTR_TRY(lookup_sparse_slots_fwd(E->emb, E->rows, E->K, off, ids, wts, B * E->F, E->F, E->x_in, E->Din_ld, E->status, st, nnz));
     DCTR_TRY(forward_rest(E, B, train, st));
     if (c.model == DCTR_MODEL_DIN) {
         E->labels = const_cast<float*>(y);
@@ -978,7 +978,10 @@ int dctr_train_step_csr(dctr_handle E, const int32_t* d_offsets, const int32_t* 
     DCTR_TRY(fork(E, st, sg));
     DCTR_TRY(group_ids(E->group, d_ids, nnz, 1, sg));
     DCTR_TRY(csr_entry_offsets(d_offsets, B * E->F, nnz, E->F, E->Din_ld, E->K, E->entry_off, sg));
-    DCTR_TRY(csr_forward(E, d_offsets, d_ids, d_weights, B, d_y, d_z, true, st));
+    // dense-exact table: the rows this batch does not touch step now, under the MLP (as in record_train)
+    const bool split_table = c.table_mode == DCTR_TABLE_DENSE_EXACT && getenv("DCTR_NO_SPLIT_TABLE") == nullptr;
+    if (split_table) DCTR_TRY(step_untouched_rows(E, sg));
+    DCTR_TRY(csr_forward(E, d_offsets, d_ids, d_weights, nnz, B, d_y, d_z, true, st));
     DCTR_TRY(backward_dense(E, B, st, sw, false));
     if (esmm) {
         swap_tower(E);
@@ -1000,7 +1003,7 @@ int dctr_train_step_csr(dctr_handle E, const int32_t* d_offsets, const int32_t* 
     DCTR_TRY(opt_table(c.optimizer, &E->state->hyper, E->h_state.hyper, c.table_mode, E->rows, E->K, E->emb, E->emb_s0, E->emb_s1,
                        nullptr, nullptr, nullptr, E->group->slot, E->group->uniq, E->group->counters, E->group->max_entries,
                        E->group->gemb, nullptr, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, st, nullptr,
-                       OPT_PASS_ALL));
+                       split_table ? OPT_PASS_TOUCHED : OPT_PASS_ALL));
     DCTR_TRY(fork(E, sw, st));
     E->last_B = B;
     if (h_loss) {
@@ -1015,7 +1018,7 @@ int dctr_predict_csr(dctr_handle E, const int32_t* d_offsets, const int32_t* d_i
                      float* d_out0, float* d_out1, float* d_out2, void* stream) {
     DCTR_TRY(csr_check(E, d_offsets, d_ids, nnz, B));
     hipStream_t st = as_stream(stream);
-    DCTR_TRY(csr_forward(E, d_offsets, d_ids, d_weights, B, nullptr, nullptr, false, st));
+    DCTR_TRY(csr_forward(E, d_offsets, d_ids, d_weights, nnz, B, nullptr, nullptr, false, st));
     E->last_B = B;
     const bool esmm = E->cfg.model == DCTR_MODEL_ESMM;
     const float* src[3] = {E->prob, esmm ? E->prob2 : E->y, esmm ? E->prob3 : nullptr};
@@ -1032,7 +1035,7 @@ int dctr_eval_batch_csr(dctr_handle E, const int32_t* d_offsets, const int32_t* 
     DCTR_TRY(csr_check(E, d_offsets, d_ids, nnz, B));
     const bool esmm = E->cfg.model == DCTR_MODEL_ESMM;
     DCTR_REQUIRE(d_y != nullptr && (!esmm || d_z != nullptr), "labels missing (ESMM takes y and z)");
-    DCTR_TRY(csr_forward(E, d_offsets, d_ids, d_weights, B, d_y, d_z, false, as_stream(stream), E->eval_scalars));
+    DCTR_TRY(csr_forward(E, d_offsets, d_ids, d_weights, nnz, B, d_y, d_z, false, as_stream(stream), E->eval_scalars));
     DCTR_TRY(dctr_auc_update(d_y, E->prob, B, E->auc_counts, stream));
     if (esmm) {
         DCTR_TRY(dctr_auc_update(d_z, E->prob2, B, E->auc_counts + 800, stream));

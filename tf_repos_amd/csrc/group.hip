@@ -100,6 +100,100 @@ __global__ __launch_bounds__(256) void group_count_kernel(const int32_t* __restr
     }
 }
 
+// ---- CSR batches (F == 1, ids in example order): a wave of 64 neighbouring entries is one example's multi-hot list -- all
+// different -- so the wave-level aggregation above finds nothing to merge and a hot id (the same category in ~10 % of the
+// examples) takes one global atomic per occurrence, serialised at ~90/us on its word.  These variants aggregate a CHUNK of 2048
+// entries per block in an LDS hash table first: one global atomic per (block, distinct id).
+constexpr int HCHUNK = 2048;           // entries per block (8 per thread)
+constexpr int HSIZE = 4096;            // LDS hash slots (load factor <= 0.5)
+__device__ __forceinline__ int hash_find(int* hkey, int id) {
+    int h = (int)(((uint32_t)id * 2654435761u) >> 20);                       // top 12 bits
+    while (true) {
+        const int prev = atomicCAS(&hkey[h], -1, id);
+        if (prev == -1 || prev == id) return h;
+        h = (h + 1) & (HSIZE - 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void group_count_hash_kernel(const int32_t* __restrict__ ids, int n, int64_t rows,
+                                                              int32_t* __restrict__ slot, int32_t* __restrict__ uniq,
+                                                              int32_t* __restrict__ counters) {
+    __shared__ int hkey[HSIZE];
+    __shared__ int hcnt[HSIZE];
+    __shared__ int wsum[4];
+    __shared__ int bbase;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int h = tid; h < HSIZE; h += 256) { hkey[h] = -1; hcnt[h] = 0; }
+    __syncthreads();
+    const int base = blockIdx.x * HCHUNK;
+#pragma unroll
+    for (int k = 0; k < HCHUNK / 256; ++k) {
+        const int i = base + k * 256 + tid;
+        if (i < n) {
+            const int id = ids[i];
+            if (id >= 0 && (int64_t)id < rows) atomicAdd(&hcnt[hash_find(hkey, id)], 1);
+        }
+    }
+    __syncthreads();
+    int nf = 0;                                         // ids this block is the first to touch (hcnt -> -1 marks them)
+    for (int h = tid; h < HSIZE; h += 256)
+        if (hkey[h] >= 0 && atomicAdd(&slot[hkey[h]], hcnt[h]) == 0) { hcnt[h] = -1; ++nf; }
+    int incl = nf;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        bbase = tot ? atomicAdd(&counters[0], tot) : 0;
+    }
+    __syncthreads();
+    int o = bbase + incl - nf;
+    for (int w = 0; w < wave; ++w) o += wsum[w];
+    for (int h = tid; h < HSIZE; h += 256)
+        if (hkey[h] >= 0 && hcnt[h] == -1) uniq[o++] = hkey[h];
+}
+
+__global__ __launch_bounds__(256) void group_fill_hash_kernel(const int32_t* __restrict__ ids, int n, int64_t rows,
+                                                             const int32_t* __restrict__ slot, int32_t* __restrict__ cursor,
+                                                             int32_t* __restrict__ perm, int32_t* __restrict__ seg_of) {
+    __shared__ int hkey[HSIZE];                         // id, then (after the reservation) its distinct-id index u
+    __shared__ int hcnt[HSIZE];
+    __shared__ int hbase[HSIZE];
+    const int tid = threadIdx.x;
+    for (int h = tid; h < HSIZE; h += 256) { hkey[h] = -1; hcnt[h] = 0; }
+    __syncthreads();
+    const int base = blockIdx.x * HCHUNK;
+    int myh[HCHUNK / 256], myrank[HCHUNK / 256];
+#pragma unroll
+    for (int k = 0; k < HCHUNK / 256; ++k) {
+        const int i = base + k * 256 + tid;
+        myh[k] = -1; myrank[k] = 0;
+        if (i < n) {
+            const int id = ids[i];
+            if (id >= 0 && (int64_t)id < rows) { myh[k] = hash_find(hkey, id); myrank[k] = atomicAdd(&hcnt[myh[k]], 1); }
+        }
+    }
+    __syncthreads();
+    for (int h = tid; h < HSIZE; h += 256)
+        if (hkey[h] >= 0) {
+            const int u = slot[hkey[h]] - 1;
+            hbase[h] = atomicAdd(&cursor[u], hcnt[h]);  // this block's run inside the id's segment
+            hkey[h] = u;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < HCHUNK / 256; ++k)
+        if (myh[k] >= 0) {
+            const int pos = hbase[myh[k]] + myrank[k];
+            perm[pos] = base + k * 256 + tid;
+            seg_of[pos] = hkey[myh[k]];
+        }
+}
+
 // segments at least this long are not walked in runs (their per-run atomic flushes all land on ONE 64-byte compact row: 4096
 // entries in runs of 16 = 256 flushes x 17 floats serialised at ~90 atomics/us -- 48 us, the whole scatter); a block reduces
 // chunks of them in registers + LDS and flushes once per chunk
@@ -377,7 +471,10 @@ int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st) {
     group_reset_kernel<<<ceil_div(g->max_entries, 256), 256, 0, st>>>(g->slot, g->uniq, g->counters, (int)g->max_entries);
     if (n <= 0) { DCTR_LAUNCH_CHECK(); return DCTR_OK; }
     const int nb = ceil_div(n, 256);
-    group_count_kernel<<<nb, 256, 0, st>>>(ids, B, F, g->rows, g->slot, g->uniq, g->counters);
+    static const bool no_hash = getenv("DCTR_GROUP_NO_HASH") != nullptr;       // A/B knob
+    const bool hashed = F == 1 && n >= 4 * HCHUNK && !no_hash;                  // CSR-ordered ids: aggregate per 2048-entry chunk in LDS
+    if (hashed) group_count_hash_kernel<<<ceil_div(n, HCHUNK), 256, 0, st>>>(ids, (int)n, g->rows, g->slot, g->uniq, g->counters);
+    else group_count_kernel<<<nb, 256, 0, st>>>(ids, B, F, g->rows, g->slot, g->uniq, g->counters);
     group_segments_kernel<<<nb, 256, 0, st>>>(g->slot, g->uniq, g->cnt, g->seg_start, g->cursor, g->counters, g->glin, g->long_list,
                                              (int)g->long_cap);
     const int KQ = g->K / 4;
@@ -389,7 +486,8 @@ int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st) {
 #undef DCTR_FIN
         default: set_error("group: K=%d unsupported", g->K); return DCTR_ERR_UNSUPPORTED;
     }
-    group_fill_kernel<<<nb, 256, 0, st>>>(ids, B, F, g->rows, g->slot, g->cursor, g->perm, g->seg_of);
+    if (hashed) group_fill_hash_kernel<<<ceil_div(n, HCHUNK), 256, 0, st>>>(ids, (int)n, g->rows, g->slot, g->cursor, g->perm, g->seg_of);
+    else group_fill_kernel<<<nb, 256, 0, st>>>(ids, B, F, g->rows, g->slot, g->cursor, g->perm, g->seg_of);
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }

@@ -9,27 +9,35 @@
 
 namespace dctr {
 
-template <int KQ>
+// EL lanes walk a segment's entries side by side (KQ float4 pieces each), then fold their partial sums with shuffles: a
+// multi-hot slot of ~60 ids keeps 16 row loads in flight instead of one dependent chain.  EL = 1: one lane per (segment, piece).
+template <int KQ, int EL>
 __global__ __launch_bounds__(256) void lookup_sparse_fwd_kernel(const float4* __restrict__ emb, int64_t rows, const int32_t* __restrict__ offsets,
                                                                const int32_t* __restrict__ ids, const float* __restrict__ weights, int B,
                                                                int S, float4* __restrict__ out, int out_ld4, int32_t* __restrict__ status) {
     // B segments; segment b is slot b % S of output row b / S (S == 1: one K-wide output per row)
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = t / KQ, kq = t % KQ;
-    if (b >= B) return;
+    static_assert(KQ * EL <= 64, "a segment's lanes must sit in one wave");
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = (int)(t / (KQ * EL)), r = (int)(t % (KQ * EL));
+    const int el = r / KQ, kq = r % KQ;
+    if (b >= B) return;                                  // (whole groups leave together: KQ*EL divides the wave size)
     const int j0 = offsets[b], j1 = offsets[b + 1];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j = j0; j < j1; ++j) {
+    for (int j = j0 + el; j < j1; j += EL) {
         const int id = ids[j];
         if (id < 0 || (int64_t)id >= rows) {            // TF CPU gather: InvalidArgumentError [TF-1.4]
             if (kq == 0) { atomicExch(&status[1], id); atomicExch(&status[0], 1); }
             continue;
         }
         const float w = weights != nullptr ? weights[j] : 1.0f;
-        const float4 r = emb[(size_t)id * KQ + kq];
-        acc.x += w * r.x; acc.y += w * r.y; acc.z += w * r.z; acc.w += w * r.w;
+        const float4 v = emb[(size_t)id * KQ + kq];
+        acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
     }
-    out[(size_t)(b / S) * out_ld4 + (size_t)(b % S) * KQ + kq] = acc;
+#pragma unroll
+    for (int o = KQ; o < KQ * EL; o <<= 1) {
+        acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o); acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
+    }
+    if (el == 0) out[(size_t)(b / S) * out_ld4 + (size_t)(b % S) * KQ + kq] = acc;
 }
 
 // entry_row[j] = b for offsets[b] <= j < offsets[b+1]   (binary search per entry); with S slots per output row the value is
@@ -47,18 +55,30 @@ __global__ __launch_bounds__(256) void entry_row_kernel(const int32_t* __restric
 }
 
 int lookup_sparse_slots_fwd(const float* emb, int64_t rows, int K, const int32_t* offsets, const int32_t* ids, const float* weights,
-                            int n_seg, int S, float* out, int out_ld, int32_t* status, hipStream_t st) {
+                            int n_seg, int S, float* out, int out_ld, int32_t* status, hipStream_t st, int64_t nnz_hint) {
     if (n_seg <= 0) return DCTR_OK;
     const int KQ = K / 4;
-    const int grid = ceil_div((int64_t)n_seg * KQ, 256);
+    // entry lanes per segment from the average segment length (nnz_hint < 0: unknown -> one lane)
+    const int64_t avg = nnz_hint > 0 ? nnz_hint / n_seg : 0;
+    int EL = avg >= 8 ? 16 : (avg >= 2 ? 4 : 1);
+    while (EL > 1 && KQ * EL > 64) EL >>= 2;
     const float4* e4 = reinterpret_cast<const float4*>(emb);
     float4* o4 = reinterpret_cast<float4*>(out);
+#define DCTR_S2(Q, L)                                                                                                            \
+    lookup_sparse_fwd_kernel<Q, L><<<ceil_div((int64_t)n_seg * Q * L, 256), 256, 0, st>>>(e4, rows, offsets, ids, weights, n_seg, S, o4, \
+                                                                                           out_ld / 4, status)
+#define DCTR_S(Q)                                                                        \
+    case Q:                                                                              \
+        if (EL == 16 && Q * 16 <= 64) DCTR_S2(Q, (Q * 16 <= 64 ? 16 : 1));               \
+        else if (EL >= 4 && Q * 4 <= 64) DCTR_S2(Q, (Q * 4 <= 64 ? 4 : 1));              \
+        else DCTR_S2(Q, 1);                                                              \
+        break
     switch (KQ) {
-#define DCTR_S(Q) case Q: lookup_sparse_fwd_kernel<Q><<<grid, 256, 0, st>>>(e4, rows, offsets, ids, weights, n_seg, S, o4, out_ld / 4, status); break
         DCTR_S(1); DCTR_S(2); DCTR_S(4); DCTR_S(8); DCTR_S(16); DCTR_S(32); DCTR_S(64);
-#undef DCTR_S
         default: set_error("lookup_sparse: K=%d unsupported (K/4 must be a power of two)", K); return DCTR_ERR_UNSUPPORTED;
     }
+#undef DCTR_S
+#undef DCTR_S2
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }
@@ -80,7 +100,7 @@ int dctr_embed_lookup_sparse_fwd(const float* d_emb, int64_t rows, int K, const 
                                  const float* d_weights, int B, float* d_out, int out_ld, int32_t* d_status, void* stream) {
     DCTR_REQUIRE(d_emb && d_offsets && d_ids && d_out && d_status, "null argument");
     DCTR_REQUIRE(K % 4 == 0 && K >= 4 && K <= 256 && out_ld % 4 == 0 && out_ld >= K, "lookup_sparse: K=%d / out_ld=%d unsupported", K, out_ld);
-    return lookup_sparse_slots_fwd(d_emb, rows, K, d_offsets, d_ids, d_weights, B, 1, d_out, out_ld, d_status, as_stream(stream));
+    return lookup_sparse_slots_fwd(d_emb, rows, K, d_offsets, d_ids, d_weights, B, 1, d_out, out_ld, d_status, as_stream(stream), -1);
 }
 
 int dctr_embed_lookup_sparse_bwd(dctr_group_t g, const float* d_dout, int dout_ld, const int32_t* d_offsets, const int32_t* d_ids,

@@ -11,7 +11,7 @@ import sys
 def stats(path):
     cur = sqlite3.connect(path).cursor()
     rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
-    print("%-92s %8s %14s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "%"))
+    print("%-92s %8s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "%"))
     for name, calls, tot, avg, pct in rows:
         print("%-92s %8d %14.0f %12.1f %7.2f" % (name[:92], calls, tot, avg, pct))
 
