@@ -101,6 +101,13 @@ typedef struct dctr_config {
     /* CSR models only (DCTR_MODEL_DIN/ESMM); zero elsewhere */
     int32_t max_entries;                 /* largest nnz any CSR call will pass (0: max_batch * field_size * 8)             */
     float   ctr_task_wgt;                /* --ctr_task_wgt    DeepCvrMTL.py:47,225                                         */
+    /* DCTR_MODEL_DIN with attention pooling (--attention_pooling=True, DIN.py:45,151-177): n_att_pairs > 0 turns it on.  Pair p
+     * = (user multi-hot slot, ad slot whose embedding is the attention query), DIN.py:174-177.  The attention MLP has
+     * n_attention_layers layers of widths attention_layers[] (the script sizes them with the DEEP widths layers[i], DIN.py:164 --
+     * the caller passes what it wants built) and reuses keep_prob[i]; its variables are shared by all pairs (AUTO_REUSE). */
+    int32_t n_att_pairs;
+    int32_t att_user_slot[8];
+    int32_t att_ad_slot[8];
 } dctr_config;
 
 typedef struct dctr_engine* dctr_handle;

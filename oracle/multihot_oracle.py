@@ -2,7 +2,8 @@
 oracle/deepctr_oracle.py: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it).
 
 Restates, op for op in torch-CPU, the graphs built by
-  * deep_ctr/Model_pipeline/DIN.py:100-252   (model "din": field-wise SUM pooling, --attention_pooling=False, DIN.py:179-183)
+  * deep_ctr/Model_pipeline/DIN.py:100-252   (model "din": field-wise SUM pooling, --attention_pooling=False, DIN.py:179-183;
+                                              with Config.attention_layers non-empty: the attention units of DIN.py:151-177)
   * DeepMTL/Model_pipeline/DeepCvrMTL.py:107-238 (model "esmm": shared embeddings, CTR and CVR towers, pCTCVR = pCTR * pCVR)
 PARITY STATUS: parity unpinned (TensorFlow 1.4 is not available; the reference ships no golden vectors for these scripts).
 
@@ -45,6 +46,10 @@ class Config:
     learning_rate: float = 5e-4
     optimizer: str = "Adam"
     ctr_task_wgt: float = 0.5            # DeepCvrMTL.py:47
+    # DIN attention pooling (DIN.py:45,151-177): widths of the attention MLP; () = field-wise sum pooling.  NOTE the script sizes
+    # these layers with layers[i] (the DEEP layer widths, DIN.py:164) for i < len(attention_layers): callers restating the
+    # script pass deep_layers[:len(attention_layers)] here
+    attention_layers: Sequence[int] = ()
 
     @property
     def n_slots(self) -> int:
@@ -68,6 +73,14 @@ def param_shapes(cfg: Config) -> Dict[str, tuple]:
         out = f"{t}out" if t else "deep_out"
         shp[f"{out}/weights"] = (d, 1)
         shp[f"{out}/biases"] = (1,)
+    if cfg.attention_layers:                 # Field-wise-Pooling-layer/att_fc%d, att_out -- shared by the four units (AUTO_REUSE, DIN.py:150)
+        d = 3 * cfg.embedding_size
+        for i, h in enumerate(cfg.attention_layers):
+            shp[f"att_fc{i}/weights"] = (d, h)
+            shp[f"att_fc{i}/biases"] = (h,)
+            d = h
+        shp["att_out/weights"] = (d, 1)
+        shp["att_out/biases"] = (1,)
     return shp
 
 
@@ -87,19 +100,44 @@ def _lookup_sparse(E, offsets, ids, vals):
     return torch.zeros((B, E.shape[1]), dtype=E.dtype).index_add(0, seg, rows)
 
 
-def embed(cfg: Config, p, batch) -> torch.Tensor:
-    """x_concat [B, (F'+8)*K] (DIN.py:143-148,180-183,199; DeepCvrMTL.py:153-165)."""
+ATT_PAIRS = (("u_cat", "a_cat"), ("u_shop", "a_shop"), ("u_brand", "a_brand"), ("u_int", "a_int"))      # DIN.py:174-177
+
+
+def _attention_unit(cfg: Config, p, E, offsets, ids, vals, a_emb, train, masks, key):
+    """attention_unit (DIN.py:152-172) over the row's real entries: the padded positions of the dense [B, P] form have
+    dense_emb = E[0] * 0 = 0, so they add nothing to the output nor to any gradient.
+      ub = w * E[id];  x = [ub, ub - ax, ax];  att = sigmoid(fc(relu-MLP(x)));  out[b] = sum_j ub_j att_j [id_j > 0]"""
+    offsets = np.asarray(offsets)
+    B = len(offsets) - 1
+    idt = torch.as_tensor(np.asarray(ids), dtype=torch.long)
+    seg = torch.as_tensor(np.repeat(np.arange(B), np.diff(offsets)), dtype=torch.long)
+    ub = E[idt] * torch.as_tensor(np.asarray(vals), dtype=E.dtype)[:, None]
+    ax = a_emb[seg]
+    x = torch.cat([ub, ub - ax, ax], dim=1)
+    for i in range(len(cfg.attention_layers)):
+        x = _fc(x, p[f"att_fc{i}/weights"], p[f"att_fc{i}/biases"])
+        x = _dropout(x, cfg.dropout[i], train, masks, f"{key}/att_fc{i}")
+    att = torch.sigmoid(_fc(x, p["att_out/weights"], p["att_out/biases"], relu=False))          # [n, 1]
+    mask = (idt > 0).to(E.dtype)[:, None]                                                        # DIN.py:157: id 0 = padding
+    return torch.zeros((B, E.shape[1]), dtype=E.dtype).index_add(0, seg, ub * att * mask)
+
+
+def embed(cfg: Config, p, batch, train: bool = False, masks=None) -> torch.Tensor:
+    """x_concat [B, (F'+8)*K] (DIN.py:143-148,150-183,199; DeepCvrMTL.py:153-165)."""
     E = p["emb"]
     feat_ids = torch.as_tensor(np.asarray(batch["feat_ids"]), dtype=torch.long)
     B = feat_ids.shape[0]
-    parts = [E[feat_ids].reshape(B, -1)]
-    for n in MULTI_W:
-        parts.append(_lookup_sparse(E, *batch[n]))
-    for n in SINGLE:
-        parts.append(E[torch.as_tensor(np.asarray(batch[n]), dtype=torch.long)])
+    ad = {n: E[torch.as_tensor(np.asarray(batch[n]), dtype=torch.long)] for n in SINGLE}
     for n in MULTI_NW:
         off, ids, _ = batch[n]
-        parts.append(_lookup_sparse(E, off, ids, None))
+        ad[n] = _lookup_sparse(E, off, ids, None)
+    parts = [E[feat_ids].reshape(B, -1)]
+    for u, a in ATT_PAIRS:
+        if cfg.attention_layers:
+            parts.append(_attention_unit(cfg, p, E, *batch[u], ad[a], train, masks, u))
+        else:
+            parts.append(_lookup_sparse(E, *batch[u]))
+    parts += [ad[n] for n in SINGLE + MULTI_NW]
     return torch.cat(parts, dim=1)
 
 
@@ -112,7 +150,7 @@ def _tower(cfg: Config, p, x, prefix, train, masks):
 
 
 def forward(cfg: Config, p, batch, train: bool = False, masks=None):
-    x = embed(cfg, p, batch)
+    x = embed(cfg, p, batch, train, masks)
     if cfg.model == "din":
         y = _tower(cfg, p, x, "", train, masks)                      # DIN.py:200-210
         return {"x": x, "y": y, "prob": torch.sigmoid(y)}

@@ -137,3 +137,53 @@ def test_large_batch_with_hot_ids_uses_chunked_grouping(dev):
         diff = np.abs(got[name] - ref.numpy()).max()
         assert diff <= 5e-6, (name, diff)          # segment sums of up to ~10^4 entries in a different order than the oracle's
     eng.close()
+
+
+def make_att_pair(B, att=(16,), Fc=6, V=800, K=8, layers=(32, 16), opt="Adam", lr=1e-2, l2=1e-3):
+    ocfg = M.Config(model="din", field_size=Fc, feature_size=V, embedding_size=K, deep_layers=layers, dropout=(1.0,) * len(layers),
+                    l2_reg=l2, learning_rate=lr, optimizer=opt, attention_layers=att)
+    ecfg = EngineConfig(model="din", field_size=ocfg.n_slots, feature_size=V, embedding_size=K, deep_layers=layers,
+                        dropout=(1.0,) * len(layers), l2_reg=l2, learning_rate=lr, optimizer=opt, max_batch=B,
+                        max_entries=B * (ocfg.n_slots + 40), attention_layers=att, att_pairs=[(Fc + i, Fc + 4 + i) for i in range(4)])
+    params = M.init_params(ocfg, seed=4, scale=0.2)       # larger weights: the attention scores must matter
+    eng = Engine(ecfg)
+    eng.set_params(params)
+    return ocfg, params, eng
+
+
+@pytest.mark.parametrize("K,att", [(4, (8,)), (8, (16, 8)), (16, (32,))])
+def test_din_attention_pooling_forward(K, att, dev):
+    """attention_unit of DIN.py:152-172 for the four (user list, ad) pairs of DIN.py:174-177, variables shared"""
+    B = 40
+    ocfg, params, eng = make_att_pair(B, att=att, K=K)
+    batch = M.synth_batch(ocfg, B, seed=6)
+    batch["u_shop"][1][::5] = 0                             # id 0 = the padding id: masked out of the pooled sum (DIN.py:157)
+    ref = M.forward(ocfg, params, batch)
+    off, ids, wts, _, _ = dev_csr(ocfg, batch, dev)
+    prob, logit = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    eng.predict_csr(off, ids, wts, B, prob, logit)
+    torch.cuda.synchronize()
+    x = eng.debug_tensor("x_in")[:, :ocfg.n_slots * K].numpy()
+    np.testing.assert_allclose(x, ref["x"].numpy(), rtol=0, atol=2e-6)
+    assert np.abs(logit.cpu().numpy() - ref["y"].numpy()).max() <= 1e-4
+    eng.close()
+
+
+@pytest.mark.parametrize("opt", ["Adam", "Adagrad", "Momentum", "ftrl"])
+def test_din_attention_pooling_train_steps(opt, dev):
+    B = 48
+    lr = {"Adam": 1e-2, "Adagrad": 1e-2, "Momentum": 1e-2, "ftrl": 5e-2}[opt]
+    ocfg, params, eng = make_att_pair(B, att=(16, 8), opt=opt, lr=lr)
+    oopt = M.Optimizer(ocfg, params)
+    for step in range(3):
+        batch = M.synth_batch(ocfg, B, seed=90 + step)
+        batch["u_cat"][1][::7] = 0
+        ref_loss, _ = M.train_step(ocfg, params, oopt, batch)
+        off, ids, wts, y, _ = dev_csr(ocfg, batch, dev)
+        loss = eng.train_step_csr(off, ids, wts, y)
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (step, loss, ref_loss)
+    got = eng.get_params()
+    for name, ref in params.items():
+        diff = np.abs(got[name] - ref.numpy()).max()
+        assert diff <= 3e-6, (name, diff)
+    eng.close()

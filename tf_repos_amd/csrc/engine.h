@@ -121,6 +121,13 @@ struct dctr_engine {
     std::vector<float*> h2, dh2;
     int p_out2_w = -1, p_out2_b = -1;
     float *dx_in2 = nullptr, *dy2 = nullptr, *y2 = nullptr, *prob2 = nullptr, *prob3 = nullptr;
+    // DIN attention pooling (din_att.hip): the attention MLP is the *2 tower, run over the batch's nnz entry rows
+    bool att_on = false;
+    int32_t* pair_ad = nullptr;      // [F] ad slot paired with each user slot, -1 elsewhere
+    float *x_att = nullptr, *att_sc = nullptr, *att_w = nullptr;     // X [max_entries, 3K]; scores, sigmoid(scores) [max_entries]
+    float* dub = nullptr;            // [max_entries, K] per-entry gradient rows; lives behind dx_in in ONE allocation
+    int32_t* entry_goff = nullptr;   // [max_entries] where the table backward reads each entry's gradient row
+    int x_att_ld = 0;
 
     // AFM (afm.hip)
     int A = 0;                       // attention layer width

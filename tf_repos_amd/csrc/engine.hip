@@ -88,6 +88,20 @@ int build(dctr_engine* E) {
         DCTR_REQUIRE(c.max_entries >= 0, "max_entries must be >= 0");
         DCTR_REQUIRE(c.model != DCTR_MODEL_ESMM || (c.ctr_task_wgt >= 0.f && c.ctr_task_wgt <= 1.f), "ctr_task_wgt must be in [0,1]");
         E->max_entries = c.max_entries > 0 ? c.max_entries : (int64_t)c.max_batch * c.field_size * 8;
+        E->att_on = c.model == DCTR_MODEL_DIN && c.n_att_pairs > 0;
+        if (E->att_on) {
+            DCTR_REQUIRE(c.n_att_pairs <= 8, "at most 8 attention pairs");
+            DCTR_REQUIRE(c.n_attention_layers >= 1 && c.n_attention_layers <= DCTR_MAX_LAYERS, "attention pooling needs 1..%d attention layers", DCTR_MAX_LAYERS);
+            DCTR_REQUIRE(c.embedding_size <= 64, "attention pooling: embedding_size <= 64");
+            for (int p = 0; p < c.n_att_pairs; ++p) {
+                DCTR_REQUIRE(c.att_user_slot[p] >= 0 && c.att_user_slot[p] < c.field_size && c.att_ad_slot[p] >= 0 &&
+                             c.att_ad_slot[p] < c.field_size && c.att_ad_slot[p] != c.att_user_slot[p], "attention pair %d: bad slots", p);
+                for (int q = 0; q < c.n_att_pairs; ++q)
+                    DCTR_REQUIRE(q == p || (c.att_user_slot[q] != c.att_user_slot[p] && c.att_ad_slot[q] != c.att_ad_slot[p] &&
+                                            c.att_ad_slot[q] != c.att_user_slot[p]),
+                                 "attention pairs must use distinct user slots and distinct ad slots, and no slot in both roles");
+            }
+        }
     }
     E->wnd = c.model >= DCTR_MODEL_WIDE && c.model <= DCTR_MODEL_WND;
     E->wnd_wide = c.model == DCTR_MODEL_WIDE || c.model == DCTR_MODEL_WND;
@@ -175,6 +189,26 @@ int build(dctr_engine* E) {
             snprintf(nm, sizeof(nm), "%sout/biases", tower_prefix[t]);
             (t == 0 ? E->p_out_b : E->p_out2_b) = add_param(E, nm, {1}, false, E->out_splits, 0.f);
         }
+    }
+    if (E->att_on) {
+        // attention MLP over [ub | ub - ax | ax]: Field-wise-Pooling-layer/att_fc%d, att_out (DIN.py:163-168)
+        int da = 3 * K;
+        for (int i = 0; i < c.n_attention_layers; ++i) {
+            Fc fc;
+            fc.in = da; fc.out = c.attention_layers[i]; fc.keep = c.keep_prob[i];
+            DCTR_REQUIRE(fc.out > 0, "attention layer widths must be positive (got %d)", fc.out);
+            fc.splits = choose_wgrad_splits((int)std::min<int64_t>(E->max_entries, 1 << 30), fc.in, fc.out);
+            char nm[64];
+            snprintf(nm, sizeof(nm), "att_fc%d/weights", i);
+            fc.w = add_param(E, nm, {fc.in, fc.out}, false, fc.splits, 0.f);
+            snprintf(nm, sizeof(nm), "att_fc%d/biases", i);
+            fc.b = add_param(E, nm, {fc.out}, false, fc.splits, 0.f);
+            fc.last = fc.b;
+            E->mlp2.push_back(fc);
+            da = fc.out;
+        }
+        E->p_out2_w = add_param(E, "att_out/weights", {da, 1}, false, 1024, 0.f);
+        E->p_out2_b = add_param(E, "att_out/biases", {1}, false, 1024, 0.f);
     }
     if (afm || c.model == DCTR_MODEL_WIDE || c.model == DCTR_MODEL_ESMM) {
         // AFM: output layer declared by afm_declare_params; LinearClassifier: no DNN side at all; ESMM: declared per tower above
@@ -315,7 +349,11 @@ int build(dctr_engine* E) {
     }
     E->ids = E->slot_ids[0]; E->vals = E->slot_vals[0]; E->labels = E->slot_labels[0];
     DCTR_TRY(dmalloc(&E->x_in, (size_t)(MB + GEMM_SLACK_ROWS) * E->Din_ld));      // (+ slack rows: see gemm.hip `over`)
-    DCTR_TRY(dmalloc(&E->dx_in, (size_t)(MB + GEMM_SLACK_ROWS) * E->Din_ld));
+    {   // (attention pooling: the per-entry gradient rows `dub` sit behind dx_in so that one int32 float4 offset reaches both)
+        const size_t dxn = (size_t)(MB + GEMM_SLACK_ROWS) * E->Din_ld;
+        DCTR_TRY(dmalloc(&E->dx_in, dxn + (E->att_on ? (size_t)E->max_entries * K : 0)));
+        if (E->att_on) E->dub = E->dx_in + dxn;
+    }
     if (c.model == DCTR_MODEL_NFM || afm) {
         DCTR_TRY(dmalloc(&E->e_buf, (size_t)MB * D));
         E->e = E->e_buf; E->e_ld = D;
@@ -346,11 +384,25 @@ int build(dctr_engine* E) {
             E->hbn.push_back(z); E->bn_stats.push_back(sx);
         }
     }
+    const size_t rows2 = E->att_on ? (size_t)E->max_entries : (size_t)MB;        // the attention MLP runs over entry rows
     for (auto& fc : E->mlp2) {
         float *a = nullptr, *g = nullptr;
-        DCTR_TRY(dmalloc(&a, (size_t)(MB + GEMM_SLACK_ROWS) * fc.out));
-        DCTR_TRY(dmalloc(&g, (size_t)(MB + GEMM_SLACK_ROWS) * fc.out));
+        DCTR_TRY(dmalloc(&a, (rows2 + GEMM_SLACK_ROWS) * fc.out));
+        DCTR_TRY(dmalloc(&g, (rows2 + GEMM_SLACK_ROWS) * fc.out));
         E->h2.push_back(a); E->dh2.push_back(g);
+    }
+    if (E->att_on) {
+        E->x_att_ld = 3 * K;
+        DCTR_TRY(dmalloc(&E->x_att, (rows2 + GEMM_SLACK_ROWS) * E->x_att_ld));
+        DCTR_TRY(dmalloc(&E->dx_in2, (rows2 + GEMM_SLACK_ROWS) * E->x_att_ld));
+        DCTR_TRY(dmalloc(&E->att_sc, rows2));
+        DCTR_TRY(dmalloc(&E->att_w, rows2));
+        DCTR_TRY(dmalloc(&E->dy2, rows2));
+        DCTR_TRY(dmalloc(&E->entry_goff, rows2));
+        std::vector<int32_t> pa((size_t)F, -1);
+        for (int p = 0; p < c.n_att_pairs; ++p) pa[(size_t)c.att_user_slot[p]] = c.att_ad_slot[p];
+        DCTR_TRY(dmalloc(&E->pair_ad, pa.size(), false));
+        DCTR_HIP_CHECK(hipMemcpy(E->pair_ad, pa.data(), pa.size() * 4, hipMemcpyHostToDevice));
     }
     if (E->csr) {
         DCTR_TRY(dmalloc(&E->entry_off, (size_t)E->max_entries));
@@ -801,6 +853,9 @@ int dctr_destroy(dctr_handle E) {
     for (float* p : E->dh2) hipFree(p);
     { float* f2[] = {E->dx_in2, E->dy2, E->y2, E->prob2, E->prob3}; for (float* p : f2) if (p) hipFree(p); }
     if (E->entry_off) hipFree(E->entry_off);
+    if (E->entry_goff) hipFree(E->entry_goff);
+    if (E->pair_ad) hipFree(E->pair_ad);
+    { float* f3[] = {E->x_att, E->att_sc, E->att_w}; for (float* p : f3) if (p) hipFree(p); }
     for (int k = 0; k < DCTR_INPUT_SLOTS; ++k) { if (E->slot_ids[k]) hipFree(E->slot_ids[k]); if (E->slot_vals[k]) hipFree(E->slot_vals[k]); if (E->slot_labels[k]) hipFree(E->slot_labels[k]); }
     if (E->status) hipFree(E->status);
     if (E->state) hipFree(E->state);
@@ -934,6 +989,13 @@ void swap_tower(dctr_engine* E) {
     std::swap(E->dx_in, E->dx_in2);
 }
 
+// DIN attention pooling: exchange the main tower with the attention MLP, whose "batch" is the nnz entry rows X [nnz, 3K]
+void swap_att(dctr_engine* E) {
+    swap_tower(E);
+    std::swap(E->x_in, E->x_att);
+    std::swap(E->Din_ld, E->x_att_ld);
+}
+
 int csr_check(dctr_engine* E, const int32_t* off, const int32_t* ids, int nnz, int B) {
     DCTR_REQUIRE(E && off && ids, "null argument");
     DCTR_REQUIRE(E->csr, "this handle's model takes fixed-field batches (dctr_train_step), not CSR batches");
@@ -948,6 +1010,18 @@ int csr_forward(dctr_engine* E, const int32_t* off, const int32_t* ids, const fl
     if (loss_shards == nullptr) loss_shards = E->scalars;
     const dctr_config& c = E->cfg;
     DCTR_TRY(lookup_sparse_slots_fwd(E->emb, E->rows, E->K, off, ids, wts, B * E->F, E->F, E->x_in, E->Din_ld, E->status, st, nnz));
+    if (E->att_on && nnz > 0) {
+        // attention units (DIN.py:152-177): the user slots' plain sums just written are replaced by attention-weighted sums
+        DCTR_TRY(csr_entry_offsets(off, B * E->F, nnz, E->F, E->Din_ld, E->K, E->entry_off, st));
+        DCTR_TRY(att_build_x(E->emb, E->rows, E->K, ids, wts, E->entry_off, E->pair_ad, nnz, E->x_in, E->Din_ld, E->x_att, st));
+        swap_att(E);
+        int rc = forward_rest(E, nnz, train, st);
+        swap_att(E);
+        DCTR_TRY(rc);
+        const int wl = E->mlp2.back().out;
+        DCTR_TRY(rowdot(E->h2.back(), wl, E->pp(E->p_out2_w), E->pp(E->p_out2_b), nnz, wl, E->att_sc, 0, st));
+        DCTR_TRY(att_pool_fwd(off, ids, E->pair_ad, E->att_sc, B * E->F, E->F, E->K, E->x_att, E->att_w, E->x_in, E->Din_ld, st));
+    }
     DCTR_TRY(forward_rest(E, B, train, st));
     if (c.model == DCTR_MODEL_DIN) {
         E->labels = const_cast<float*>(y);
@@ -977,7 +1051,7 @@ int dctr_train_step_csr(dctr_handle E, const int32_t* d_offsets, const int32_t* 
     // grouping of the batch's ids + the entries' slot offsets: beside the forward pass
     DCTR_TRY(fork(E, st, sg));
     DCTR_TRY(group_ids(E->group, d_ids, nnz, 1, sg));
-    DCTR_TRY(csr_entry_offsets(d_offsets, B * E->F, nnz, E->F, E->Din_ld, E->K, E->entry_off, sg));
+    if (!E->att_on) DCTR_TRY(csr_entry_offsets(d_offsets, B * E->F, nnz, E->F, E->Din_ld, E->K, E->entry_off, sg));   // (attention: the forward computes them)
     // dense-exact table: the rows this batch does not touch step now, under the MLP (as in record_train)
     const bool split_table = c.table_mode == DCTR_TABLE_DENSE_EXACT && getenv("DCTR_NO_SPLIT_TABLE") == nullptr;
     if (split_table) DCTR_TRY(step_untouched_rows(E, sg));
@@ -990,6 +1064,18 @@ int dctr_train_step_csr(dctr_handle E, const int32_t* d_offsets, const int32_t* 
         DCTR_TRY(rc);
         DCTR_TRY(add_inplace(E->dx_in, E->dx_in2, (int64_t)B * E->Din_ld, st));
     }
+    const int32_t* goff = E->entry_off;
+    if (E->att_on && nnz > 0) {
+        // back through the attention units: scores -> attention MLP (the *2 tower over the entry rows) -> per-entry gradient rows
+        DCTR_TRY(att_bwd_scores(d_ids, E->entry_off, E->pair_ad, nnz, E->K, E->dx_in, E->Din_ld, E->x_att, E->att_w, E->dy2, st));
+        swap_att(E);
+        int rc = backward_dense(E, nnz, st, sw, false);
+        swap_att(E);
+        DCTR_TRY(rc);
+        DCTR_TRY(att_bwd_combine(d_offsets, d_ids, E->entry_off, E->pair_ad, nnz, B * E->F, E->F, E->K, E->dx_in, E->Din_ld, E->dx_in2,
+                                 E->att_w, E->dub, E->entry_goff, st));
+        goff = E->entry_goff;
+    }
     // dense parameters on the weight-gradient stream (its last dW is done; the output layers' slabs were written on st)
     DCTR_TRY(fork(E, st, sw));
     DCTR_TRY(opt_dense_arena(c.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->parts, E->meta, E->n_blocks,
@@ -999,7 +1085,7 @@ int dctr_train_step_csr(dctr_handle E, const int32_t* d_offsets, const int32_t* 
     DCTR_TRY(fork(E, sg, st));
     if (nnz > 0)
         DCTR_TRY(embed_scatter_bwd(E->group, E->dx_in, 4, nullptr, 0, nullptr, nullptr, nullptr, d_weights, nnz, 1, E->K, DCTR_GATHER_RAW,
-                                   E->group->gemb, nullptr, st, 1, E->entry_off));
+                                   E->group->gemb, nullptr, st, 1, goff));
     DCTR_TRY(opt_table(c.optimizer, &E->state->hyper, E->h_state.hyper, c.table_mode, E->rows, E->K, E->emb, E->emb_s0, E->emb_s1,
                        nullptr, nullptr, nullptr, E->group->slot, E->group->uniq, E->group->counters, E->group->max_entries,
                        E->group->gemb, nullptr, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, st, nullptr,

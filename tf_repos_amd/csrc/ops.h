@@ -152,6 +152,16 @@ int esmm_head(const float* h_ctr, int ld_ctr, const float* w_ctr, const float* b
               hipStream_t st);
 int add_inplace(float* a, const float* b, int64_t n, hipStream_t st);
 
+// din_att.hip: DIN attention pooling over CSR batches (DIN.py:152-172)
+int att_build_x(const float* emb, int64_t rows, int K, const int32_t* ids, const float* weights, const int32_t* entry_off,
+                const int32_t* pair_ad, int nnz, const float* x, int ld, float* X, hipStream_t st);
+int att_pool_fwd(const int32_t* offsets, const int32_t* ids, const int32_t* pair_ad, const float* sc, int n_seg, int S, int K,
+                 const float* X, float* att, float* x, int ld, hipStream_t st);
+int att_bwd_scores(const int32_t* ids, const int32_t* entry_off, const int32_t* pair_ad, int nnz, int K, const float* dx, int ld,
+                   const float* X, const float* att, float* dsc, hipStream_t st);
+int att_bwd_combine(const int32_t* offsets, const int32_t* ids, const int32_t* entry_off, const int32_t* pair_ad, int nnz, int n_seg,
+                    int S, int K, float* dx, int ld, const float* dX, const float* att, float* dub, int32_t* goff, hipStream_t st);
+
 // afm_fused.hip: AFM attention network fused over the pair rows (no [B*P, A] hidden activations in HBM)
 bool afm_fused_supported(int K, int A);
 int afm_att_fwd(const float* pp, const float* W, const float* ba, const float* wo, const float* bo, int64_t rows, int K, int A, float* sc,

@@ -46,6 +46,9 @@ class EngineConfig:
     # (offsets [B*S+1], ids [nnz], weights [nnz]) with nnz <= max_entries (0: max_batch * field_size * 8)
     max_entries: int = 0
     ctr_task_wgt: float = 0.5                  # DeepCvrMTL.py:47
+    # din with attention pooling (DIN.py:45,151-177): (user multi-hot slot, ad slot) pairs; the attention MLP takes its widths
+    # from attention_layers and its keep_probs from dropout[i]
+    att_pairs: Sequence[Tuple[int, int]] = ()
     use_graph: bool = False                    # False: eager launches on 3 HIP streams (measured faster: each stream keeps its own
                                                # hardware queue); True: one captured hipGraph per (batch size, input slot)
 
@@ -91,6 +94,9 @@ class EngineConfig:
         c.loss_sum = int(self.loss_sum)
         c.max_entries = int(self.max_entries)
         c.ctr_task_wgt = float(self.ctr_task_wgt)
+        c.n_att_pairs = len(self.att_pairs)
+        for i, (u, a) in enumerate(list(self.att_pairs)[:8]):
+            c.att_user_slot[i], c.att_ad_slot[i] = int(u), int(a)
         return c
 
 
