@@ -34,16 +34,41 @@ def input_fn(filenames, batch_size=32, num_epochs=1, perform_shuffle=False, fiel
     return ds.repeat(num_epochs).batch(batch_size).make_one_shot_iterator().get_next()
 
 
-def _embed(features, params):
+def _attend(table, sp_ids, sp_vals, query, params, mode):
+    """DIN-style attention pooling of one behaviour list against the candidate ad's embedding: every behaviour is scored by a
+    small MLP on [behaviour, behaviour - ad, ad], squashed by a sigmoid, and the list is summed with those scores."""
+    K = params["embedding_size"]
+    widths = [int(v) for v in params["attention_layers"].split(",")]
+    keep = [float(v) for v in params["dropout"].split(",")]
+    ids = tf.sparse_tensor_to_dense(sp_ids)
+    weights = tf.expand_dims(tf.sparse_tensor_to_dense(sp_vals), axis=-1)
+    behaviours = tf.multiply(tf.nn.embedding_lookup(table, ids), weights)                 # [B, P, K], zero at the padding
+    present = tf.expand_dims(tf.cast(ids > 0, tf.float32), axis=-1)
+    longest = tf.shape(ids)[1]
+    flat = tf.reshape(behaviours, [-1, K])
+    ad = tf.reshape(tf.tile(query, [1, longest]), [-1, K])
+    h = tf.concat([flat, flat - ad, ad], axis=1)
+    for i, width in enumerate(widths):
+        h = tf.contrib.layers.fully_connected(h, width, scope="score_fc%d" % i)
+        if mode == tf.estimator.ModeKeys.TRAIN:
+            h = tf.nn.dropout(h, keep_prob=keep[i])
+    score = tf.reshape(tf.contrib.layers.fully_connected(h, 1, activation_fn=tf.sigmoid, scope="score_out"), [-1, longest, 1])
+    return tf.reduce_sum(tf.multiply(tf.multiply(behaviours, score), present), 1)
+
+
+def _embed(features, params, mode=None, attention=False):
     table = tf.get_variable("embeddings", [params["feature_size"], params["embedding_size"]], initializer=tf.glorot_normal_initializer())
     K = params["embedding_size"]
+    ads = [tf.nn.embedding_lookup(table, features[a + "ids"]) for a in AD_SINGLE]
+    ads.append(tf.nn.embedding_lookup_sparse(table, sp_ids=features["a_intids"], sp_weights=None, combiner="sum"))
     parts = [tf.reshape(tf.nn.embedding_lookup(table, features["feat_ids"]), [-1, params["field_size"] * K])]
-    for u in USER_MULTI:
-        parts.append(tf.nn.embedding_lookup_sparse(table, sp_ids=features[u + "ids"], sp_weights=features[u + "vals"], combiner="sum"))
-    for a in AD_SINGLE:
-        parts.append(tf.nn.embedding_lookup(table, features[a + "ids"]))
-    parts.append(tf.nn.embedding_lookup_sparse(table, sp_ids=features["a_intids"], sp_weights=None, combiner="sum"))
-    return table, tf.concat(parts, axis=1)
+    with tf.variable_scope("pooling", reuse=tf.AUTO_REUSE):
+        for u, ad in zip(USER_MULTI, ads):
+            if attention:
+                parts.append(_attend(table, features[u + "ids"], features[u + "vals"], ad, params, mode))
+            else:
+                parts.append(tf.nn.embedding_lookup_sparse(table, sp_ids=features[u + "ids"], sp_weights=features[u + "vals"], combiner="sum"))
+    return table, tf.concat(parts + ads, axis=1)
 
 
 def _tower(x, params, mode, prefix):
@@ -69,7 +94,7 @@ def _optimizer(params):
 
 
 def din_model_fn(features, labels, mode, params):
-    table, x = _embed(features, params)
+    table, x = _embed(features, params, mode, attention=bool(params.get("attention_layers")))
     logit = _tower(x, params, mode, "din_")
     predictions = {"prob": tf.sigmoid(logit)}
     if mode == tf.estimator.ModeKeys.PREDICT:
@@ -110,7 +135,8 @@ def build_estimator(task, params, model_dir, log_steps=100):
 def main(_):
     F = tf.app.flags.FLAGS
     params = dict(field_size=F.field_size, feature_size=F.feature_size, embedding_size=F.embedding_size, deep_layers=F.deep_layers,
-                  dropout=F.dropout, l2_reg=F.l2_reg, learning_rate=F.learning_rate, optimizer=F.optimizer, ctr_task_wgt=F.ctr_task_wgt)
+                  dropout=F.dropout, l2_reg=F.l2_reg, learning_rate=F.learning_rate, optimizer=F.optimizer, ctr_task_wgt=F.ctr_task_wgt,
+                  attention_layers=F.attention_layers if F.task == "din" else "")
     est = build_estimator(F.task, params, F.model_dir)
     tr = glob.glob("%s/tr/*tfrecord" % F.data_dir)
     va = glob.glob("%s/te/*tfrecord" % F.data_dir)
@@ -135,4 +161,5 @@ if __name__ == "__main__":
     fl.DEFINE_float("learning_rate", 5e-4, "")
     fl.DEFINE_float("ctr_task_wgt", 0.5, "")
     fl.DEFINE_string("optimizer", "Adam", "")
+    fl.DEFINE_string("attention_layers", "64", "din: widths of the attention-pooling MLP ('' = plain sum pooling)")
     tf.app.run(main)

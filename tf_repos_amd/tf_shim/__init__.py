@@ -37,7 +37,8 @@ def build_module():
               "add", "subtract", "square", "reduce_sum", "reduce_mean", "matmul", "concat", "stack", "transpose", "gather", "einsum",
               "ones_like", "identity", "sigmoid", "cast", "cond", "split", "string_split", "string_to_number", "decode_csv"):
         setattr(tf, n, getattr(_g, n))
-    for n in ("FixedLenFeature", "VarLenFeature", "parse_single_example", "sparse_tensor_to_dense", "AUTO_REUSE"):
+    for n in ("FixedLenFeature", "VarLenFeature", "parse_single_example", "sparse_tensor_to_dense", "AUTO_REUSE", "expand_dims", "shape",
+              "tile"):
         setattr(tf, n, getattr(_g, n))
     tf.losses = _mod("tensorflow.losses", log_loss=_g.log_loss)
     tf.summary = _mod("tensorflow.summary", scalar=_g.summary_scalar)

@@ -145,6 +145,7 @@ class Tensor:
     def __mul__(self, o): return multiply(self, o)
     def __rmul__(self, o): return multiply(o, self)
     def __neg__(self): return multiply(-1.0, self)
+    def __gt__(self, o): return Tensor("greater", [self, _t(o, self.dtype)], {}, bool_, self.shape)
 
     def __getitem__(self, key):
         if not isinstance(key, tuple):
@@ -300,6 +301,10 @@ def reduce_mean(x, axis=None, keep_dims=False, name=None):
 def reshape(x, shape, name=None):
     if isinstance(shape, Tensor):       # reshape(values, dense_shape) in decode_libsvm
         return Tensor("reshape", [x, shape], {"shape": None}, x.dtype, None)
+    dyn = [s for s in shape if isinstance(s, Tensor)]            # e.g. [-1, tf.shape(ids)[1], 1] (DIN.py:169): dynamic dims
+    if dyn:
+        out = tuple(None if (isinstance(s, Tensor) or int(s) == -1) else int(s) for s in shape)
+        return Tensor("reshape", [x] + dyn, {"shape": tuple(None if isinstance(s, Tensor) else int(s) for s in shape)}, x.dtype, out)
     shape = [int(s) for s in shape]
     out = list(shape)
     if x.shape is not None and all(s is not None for s in x.shape) and -1 in out:
@@ -455,7 +460,7 @@ def fully_connected(inputs, num_outputs, activation_fn=relu, normalizer_fn=None,
         b = get_variable("biases", [num_outputs], initializer=biases_initializer or zeros_initializer())
         if weights_regularizer is not None:
             current_graph().collections.setdefault("regularization_losses", []).append((w.var_name, weights_regularizer.scale))
-    act = "relu" if activation_fn is relu else ("identity" if activation_fn in (identity, None) else None)
+    act = "relu" if activation_fn is relu else ("identity" if activation_fn in (identity, None) else ("sigmoid" if activation_fn is sigmoid else None))
     if act is None:
         raise NotImplementedError("fully_connected activation %r" % activation_fn)
     shp = tuple(inputs.shape[:-1]) + (num_outputs,)
@@ -510,8 +515,34 @@ def embedding_lookup_sparse(params, sp_ids, sp_weights, partition_strategy="mod"
 
 
 def sparse_tensor_to_dense(sp_input, default_value=0, validate_indices=True, name=None):
-    raise errors.UnimplementedError("DIN attention pooling (attention_unit, DIN.py:151-177) is not implemented in the engine: run with "
-                                    "--attention_pooling=False (field-wise sum pooling, DIN.py:179-183)")
+    """[B, P] dense form of a parsed VarLenFeature, rows padded with default_value up to the batch's longest (DIN.py:153-154)."""
+    if not (isinstance(sp_input, Tensor) and sp_input.op == "iterator_varlen"):
+        raise errors.UnimplementedError("sparse_tensor_to_dense of something that is not a parsed VarLenFeature")
+    if default_value != 0:
+        raise errors.UnimplementedError("sparse_tensor_to_dense(default_value != 0)")
+    return Tensor("sparse_to_dense", [sp_input], {}, sp_input.dtype, (None, None))
+
+
+def expand_dims(x, axis=None, name=None, dim=None):
+    axis = dim if axis is None else axis
+    shp = None
+    if x.shape is not None:
+        shp = list(x.shape)
+        shp.insert(axis % (len(shp) + 1) if axis < 0 else axis, 1)
+        shp = tuple(shp)
+    return Tensor("expand_dims", [x], {"axis": axis}, x.dtype, shp)
+
+
+def shape(x, name=None, out_type=None):
+    return Tensor("shape", [x], {}, int32, (len(x.shape),) if x.shape is not None else None)
+
+
+def tile(x, multiples, name=None):
+    dyn = [m for m in multiples if isinstance(m, Tensor)]
+    shp = None
+    if x.shape is not None:
+        shp = tuple(None if (isinstance(m, Tensor) or d is None) else d * int(m) for d, m in zip(x.shape, multiples))
+    return Tensor("tile", [x] + dyn, {"multiples": tuple(None if isinstance(m, Tensor) else int(m) for m in multiples)}, x.dtype, shp)
 
 
 def log_loss(labels, predictions, weights=1.0, epsilon=1e-7, scope=None, **_kw):

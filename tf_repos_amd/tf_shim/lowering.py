@@ -22,6 +22,7 @@ class Lowered:
     config_kwargs: Dict
     name_map: Dict[str, str]                 # engine parameter name -> TF variable name
     predict_keys: List[str] = field(default_factory=lambda: ["prob"])
+    # (DIN attention pooling: config_kwargs carries attention_layers + att_pairs)
     # CSR (multi-hot) models: the slot layout of the MLP input [(ids_key, vals_key | None, fixed_len)], the label keys
     # (["y"] / ["y", "z"]) and which engine output each predictions key / eval metric reads
     slots: Optional[List[Tuple[str, Optional[str], int]]] = None
@@ -51,7 +52,7 @@ def lower(loss: Optional[G.Tensor], train_op: Optional[G.Tensor], predictions: D
     for n in nodes:
         by_op.setdefault(n.op, []).append(n)
     bn_ops = by_op.get("batch_norm", [])
-    if by_op.get("embedding_lookup_sparse") or by_op.get("iterator_varlen"):
+    if by_op.get("embedding_lookup_sparse") or by_op.get("iterator_varlen") or by_op.get("sparse_to_dense"):
         return _lower_multihot(loss, train_op, predictions, nodes, by_op)
 
     # ---- tables --------------------------------------------------------------------------------------------------
@@ -241,12 +242,18 @@ def _lower_multihot(loss, train_op, predictions, nodes, by_op) -> Lowered:
     if by_op.get("batch_norm"):
         raise _unsupported("batch_norm=True is not implemented for the DIN / ESMM graphs")
     fcs = by_op.get("fully_connected", [])
+    att_outs = [f for f in fcs if f.attrs["activation"] == "sigmoid"]            # att_out of the attention units (DIN.py:168)
     hidden = [f for f in fcs if f.attrs["activation"] == "relu"]
     outs = [f for f in fcs if f.attrs["activation"] == "identity"]
-    concats = [c for c in by_op.get("concat", []) if c.attrs["axis"] == 1]
+    # the MLP input is the concat that is not the [ub | ub - ax | ax] input of an attention unit
+    unit_inputs = set()
+    for ao in att_outs:
+        unit_inputs.update(id(n) for n in G.ancestors([ao]) if n.op == "concat")
+    concats = [c for c in by_op.get("concat", []) if c.attrs["axis"] == 1 and id(c) not in unit_inputs]
     if len(concats) != 1 or not hidden:
         raise _unsupported("expected one tf.concat(axis=1) feeding the MLP(s)")
     xcat = concats[0]
+    units: List[Dict] = []           # attention units in concat order: {"part": index, "ad": tensor, "att_fcs": [...], "att_out": fc}
 
     # ---- slot layout, in concat order ----------------------------------------------------------------------------------------------
     emb_var = None
@@ -261,6 +268,12 @@ def _lower_multihot(loss, train_op, predictions, nodes, by_op) -> Lowered:
             if len(shp) > 1:
                 raise _unsupported("FixedLenFeature of rank %d" % len(shp))
             slots.append((ids.attrs["key"], None, int(shp[0]) if shp else 0))
+        elif src.op == "reduce_sum" and att_outs:
+            unit = _attention_unit(src, att_outs)
+            var = unit["var"]
+            unit["part"] = len(slots)
+            units.append(unit)
+            slots.append((unit["ids_key"], unit["vals_key"], -1))
         elif src.op == "embedding_lookup_sparse":
             var, ids = src.inputs[0], src.inputs[1]
             wts = src.inputs[2] if len(src.inputs) > 2 else None
@@ -275,6 +288,30 @@ def _lower_multihot(loss, train_op, predictions, nodes, by_op) -> Lowered:
     V, K = int(emb_var.shape[0]), int(emb_var.shape[1])
     S = sum(n if n > 0 else 1 for _, _, n in slots)
     name_map: Dict[str, str] = {"emb": emb_var.var_name}
+    att_kw: Dict = {}
+    if units:
+        # slot index of every concat part (a FixedLenFeature([n]) part spans n slots)
+        first_slot, acc = [], 0
+        for _, _, n in slots:
+            first_slot.append(acc)
+            acc += n if n > 0 else 1
+        parts = [_through(p, ops=("reshape", "identity")) for p in xcat.inputs]
+        pairs = []
+        for u in units:
+            ad_idx = [i for i, p in enumerate(parts) if p is _through(u["ad"], ops=("reshape", "identity"))]
+            if len(ad_idx) != 1:
+                raise _unsupported("an attention unit's ad embedding must also be one part of the MLP input (DIN.py:174-177,199)")
+            pairs.append((first_slot[u["part"]], first_slot[ad_idx[0]]))
+            if [id(v) for f in u["att_fcs"] + [u["att_out"]] for v in f.inputs[1:]] != \
+               [id(v) for f in units[0]["att_fcs"] + [units[0]["att_out"]] for v in f.inputs[1:]]:
+                raise _unsupported("the attention units must share their variables (variable_scope(reuse=tf.AUTO_REUSE), DIN.py:150)")
+        u0 = units[0]
+        for i, f in enumerate(u0["att_fcs"]):
+            name_map["att_fc%d/weights" % i], name_map["att_fc%d/biases" % i] = f.inputs[1].var_name, f.inputs[2].var_name
+        name_map["att_out/weights"], name_map["att_out/biases"] = u0["att_out"].inputs[1].var_name, u0["att_out"].inputs[2].var_name
+        att_kw = dict(attention_layers=tuple(int(f.attrs["num_outputs"]) for f in u0["att_fcs"]), att_pairs=tuple(pairs))
+        att_fc_ids = {id(f) for u in units for f in u["att_fcs"]}
+        hidden = [f for f in hidden if id(f) not in att_fc_ids]
 
     # ---- towers ------------------------------------------------------------------------------------------------------------------------
     def chain(out_fc):
@@ -334,6 +371,14 @@ def _lower_multihot(loss, train_op, predictions, nodes, by_op) -> Lowered:
             raise _unsupported("the towers use different dropout keep_probs")
         keep = k2
     kw.update(model=model, deep_layers=tuple(int(f.attrs["num_outputs"]) for f in towers[0][2]), dropout=keep)
+    if units:
+        if model != "din":
+            raise _unsupported("attention pooling outside the DIN graph")
+        for u in units:         # the units' dropout reuses dropout[i] of the deep layers (DIN.py:166-167)
+            for i, f in enumerate(u["att_fcs"]):
+                if abs(float(keep_of.get(id(f), 1.0)) - keep[i]) > 1e-12:
+                    raise _unsupported("attention layer %d keep_prob differs from dropout[%d]" % (i, i))
+        kw.update(att_kw)
 
     # ---- loss --------------------------------------------------------------------------------------------------------------------------
     if loss is not None:
@@ -373,6 +418,47 @@ def _lower_multihot(loss, train_op, predictions, nodes, by_op) -> Lowered:
         kw.update(_optimizer_kwargs(train_op))
     return Lowered(model=model, config_kwargs=kw, name_map=name_map, predict_keys=list(predictions.keys()), slots=slots,
                    label_keys=label_keys, outputs=outputs)
+
+
+def _attention_unit(pooled: G.Tensor, att_outs) -> Dict:
+    """One attention_unit (DIN.py:152-172) from its output reduce_sum(dense_emb * att_wgt * dense_mask, 1):
+    which parsed features it reads, the ad embedding it is queried with, its layers."""
+    if pooled.attrs.get("axis") != 1:
+        raise _unsupported("attention unit must pool over axis 1")
+    anc = G.ancestors([pooled])
+    ops: Dict[str, List[G.Tensor]] = {}
+    for n in anc:
+        ops.setdefault(n.op, []).append(n)
+    dense = ops.get("sparse_to_dense", [])
+    ids = [d for d in dense if d.dtype in (G.int64, G.int32)]
+    vals = [d for d in dense if d.dtype is G.float32]
+    lookups = [l for l in ops.get("embedding_lookup", []) if l.inputs[1] in ids]
+    if len(ids) != 1 or len(vals) != 1 or len(lookups) != 1:
+        raise _unsupported("attention unit must read one id list and one weight list through sparse_tensor_to_dense")
+    outs = [a for a in att_outs if a in anc]
+    tiles = ops.get("tile", [])
+    if len(outs) != 1 or len(tiles) != 1:
+        raise _unsupported("attention unit must hold one sigmoid output layer and one tiled ad embedding")
+    cat = [c for c in ops.get("concat", []) if len(c.inputs) == 3]
+    if len(cat) != 1:
+        raise _unsupported("attention unit input must be concat([ub, ub - ax, ax])")
+    a, d, b = cat[0].inputs
+    if not (d.op == "sub" and d.inputs[0] is a and d.inputs[1] is b and _through(b) is tiles[0] and _through(a).op == "mul"):
+        raise _unsupported("attention unit input is not [ub | ub - ax | ax] (DIN.py:162)")
+    gr = ops.get("greater", [])
+    if len(gr) != 1 or gr[0].inputs[0] is not ids[0] or gr[0].inputs[1].op != "const" or float(gr[0].inputs[1].attrs["value"]) != 0.0:
+        raise _unsupported("attention unit mask must be dense_ids > 0 (DIN.py:157)")
+    layers = []
+    t = _through(outs[0].inputs[0], ops=("reshape", "identity", "dropout"))
+    while t is not cat[0]:
+        if t.op != "fully_connected" or t.attrs["activation"] != "relu":
+            raise _unsupported("attention MLP contains %s" % t.op)
+        layers.append(t)
+        t = _through(t.inputs[0], ops=("reshape", "identity", "dropout"))
+    if int(outs[0].attrs["num_outputs"]) != 1:
+        raise _unsupported("att_out must have width 1")
+    return {"var": lookups[0].inputs[0], "ids_key": ids[0].inputs[0].attrs["key"], "vals_key": vals[0].inputs[0].attrs["key"],
+            "ad": tiles[0].inputs[0], "att_fcs": layers[::-1], "att_out": outs[0]}
 
 
 def _uses(node, var, nodes) -> bool:

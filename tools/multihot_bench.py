@@ -1,5 +1,5 @@
 """Step time of the CSR (multi-hot) models at the Ali-CCP shape of DeepMTL/README.md:19-25,38 (V ~ 4.5 M ids, ~250 ids per
-example): DIN (sum pooling) and ESMM, MLP 256-128-64 (DIN.py:40 / DeepCvrMTL.py:51), K=16.  One JSON line per configuration.
+example): DIN (sum pooling), ESMM and DIN with attention pooling (att_fc0 = 256 wide, DIN.py:164), MLP 256-128-64 (DIN.py:40 / DeepCvrMTL.py:51), K=16.  One JSON line per configuration.
 usage (GPU box): python tools/multihot_bench.py [steps] [B]"""
 import json
 import os
@@ -40,11 +40,13 @@ def synth(B, seed):
 
 batches = [[torch.from_numpy(a).to(dev) for a in synth(B, 100 + i)] for i in range(4)]
 max_nnz = max(int(b[1].shape[0]) for b in batches)
-for model in ("din", "esmm"):
+for model in ("din", "esmm", "din_att"):
     for table_mode in ("dense_exact", "touched_rows"):
+        att = dict(attention_layers=(256,), att_pairs=[(FC + i, FC + 4 + i) for i in range(4)]) if model == "din_att" else {}
+        name, model = model, model.split("_")[0]
         eng = Engine(EngineConfig(model=model, field_size=S, feature_size=V, embedding_size=K, deep_layers=(256, 128, 64), dropout=(0.5, 0.5, 0.5),
                                   l2_reg=1e-4, learning_rate=5e-4, optimizer="Adam", table_mode=table_mode, max_batch=B,
-                                  max_entries=max_nnz + 1024, seed=1))
+                                  max_entries=max_nnz + 1024, seed=1, **att))
         for pn, shp in eng.param_shapes.items():
             if pn != "emb":
                 eng.set_param(pn, rng.normal(0, 0.01, size=shp).astype(np.float32))
@@ -59,6 +61,7 @@ for model in ("din", "esmm"):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         eng.check_ids()
+        model = name
         print(json.dumps({"config": "%s B=%d V=4.5e6 K=16 slots=%d MLP 256-128-64 avg nnz/example=%.0f table=%s" % (model, B, S, max_nnz / B, table_mode),
                           "ms_per_step": round(dt * 1e3, 4), "examples_per_sec": round(B / dt, 1), "ids_per_sec": round(max_nnz / dt, 1)}), flush=True)
         eng.close()
