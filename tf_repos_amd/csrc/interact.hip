@@ -89,9 +89,71 @@ __global__ __launch_bounds__(256) void pnn_inner_bwd_kernel(const float* __restr
     }
 }
 
+// The same product as G_b E_b with G_b the dense symmetric [F, F] matrix of the example's pair gradients (zero diagonal):
+// a wave per example expands dip[b, :] into G in LDS, a lane owns one embedding column k and keeps e[b, :, k] in F registers,
+// and every output row is F FMAs against a row of G read as broadcast float4s -- one LDS read per 4 MACs instead of two per MAC
+// plus the pair-index arithmetic (B=8192, F=39, K=32: 192 -> 121 us; what is left is the latency of the dependent loads of one example at a time).  F is a template parameter (register array).
+template <int F, int NG>          // NG = 64 / min(K, 64) row groups per wave
+__global__ __launch_bounds__(256) void pnn_inner_bwd_reg_kernel(const float* __restrict__ e, int e_ld, const float* __restrict__ dip,
+                                                               int dip_ld, int B, int K, float* __restrict__ dE, int de_ld) {
+    constexpr int P = F * (F - 1) / 2;
+    constexpr int FS = (F + 3) & ~3;                     // row stride of G: float4 reads, zero padding behind column F-1
+    constexpr int KL = 64 / NG;                          // lanes over k
+    __shared__ __attribute__((aligned(16))) float Gs[4][F * FS];
+    __shared__ int16_t pi[P], pj[P];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        int i = 0, base = 0;
+        while (p >= base + (F - 1 - i)) { base += F - 1 - i; ++i; }
+        pi[p] = (int16_t)i; pj[p] = (int16_t)(i + 1 + (p - base));
+    }
+    float* G = Gs[wave];
+    for (int x = lane; x < F * FS; x += 64) G[x] = 0.f;   // diagonal and padding stay zero
+    __syncthreads();
+    const int kg = lane % KL, rg = lane / KL;
+    for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
+        const float* dr = dip + (size_t)b * dip_ld;
+        for (int p = lane; p < P; p += 64) {
+            const float v = dr[p];
+            G[pi[p] * FS + pj[p]] = v;
+            G[pj[p] * FS + pi[p]] = v;
+        }
+        __builtin_amdgcn_wave_barrier();                  // (wave-private tile: the LDS queue of a wave is in order)
+        for (int kb = 0; kb < K; kb += KL) {
+            const int k = kb + kg;
+            float tr[FS];
+#pragma unroll
+            for (int j = 0; j < FS; ++j) tr[j] = j < F ? e[(size_t)b * e_ld + j * K + k] : 0.f;
+            for (int i = rg; i < F; i += NG) {
+                const float4* grow = reinterpret_cast<const float4*>(G + i * FS);
+                float s = 0.f;
+#pragma unroll
+                for (int j4 = 0; j4 < FS / 4; ++j4) {
+                    const float4 g = grow[j4];
+                    s += g.x * tr[4 * j4] + g.y * tr[4 * j4 + 1] + g.z * tr[4 * j4 + 2] + g.w * tr[4 * j4 + 3];
+                }
+                dE[(size_t)b * de_ld + i * K + k] += s;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                  // G is rewritten for the next example
+    }
+}
+
 int pnn_inner_bwd(const float* e, int e_ld, const float* dip, int dip_ld, int B, int F, int K, float* dE, int de_ld,
                   hipStream_t st) {
     if (B <= 0) return DCTR_OK;
+    static const bool generic = getenv("DCTR_PNN_GENERIC") != nullptr;          // A/B knob
+    if (F == 39 && (K % 64 == 0 || 64 % K == 0) && K >= 4 && !generic) {       // the Criteo field count: register-tiled form
+        const int grid = std::min(ceil_div(B, 4), 256 * 8);
+        switch (K >= 64 ? 1 : 64 / K) {
+#define DCTR_PB(N) case N: pnn_inner_bwd_reg_kernel<39, N><<<grid, 256, 0, st>>>(e, e_ld, dip, dip_ld, B, K, dE, de_ld); break
+            DCTR_PB(1); DCTR_PB(2); DCTR_PB(4); DCTR_PB(8); DCTR_PB(16);
+#undef DCTR_PB
+            default: set_error("pnn_inner_bwd: K=%d", K); return DCTR_ERR_UNSUPPORTED;
+        }
+        DCTR_LAUNCH_CHECK();
+        return DCTR_OK;
+    }
     const int P = F * (F - 1) / 2;
     const size_t lds = (size_t)4 * (F * K + P) * sizeof(float);
     DCTR_REQUIRE(lds <= 160 * 1024, "pnn_inner_bwd: tile too large for LDS (F=%d K=%d)", F, K);
