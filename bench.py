@@ -137,6 +137,19 @@ def main():
         step = lambda i, v, l, nxt: eng.train_step(i, v, l, want_loss=False)
         barrier = lambda: None
 
+    # watchdog: a wedged collective (multi-GPU runs are launched by the driver, not from here) must end the job with a message,
+    # not sit until an outer timeout
+    import threading
+    done = threading.Event()
+
+    def watchdog(limit=float(os.environ.get("DCTR_BENCH_TIMEOUT", "900"))):
+        if not done.wait(limit):
+            import faulthandler
+            print("rank %d: bench did not finish within %.0f s -- aborting (stacks follow)" % (rank, limit), file=sys.stderr, flush=True)
+            faulthandler.dump_traceback(file=sys.stderr)
+            os._exit(3)
+    threading.Thread(target=watchdog, daemon=True).start()
+
     nb = 8
     batches = []
     for i in range(nb):
@@ -242,6 +255,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    done.set()
     if sharded:
         import torch.distributed as dist
         trainer.close()

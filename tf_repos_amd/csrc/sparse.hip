@@ -83,8 +83,23 @@ int lookup_sparse_slots_fwd(const float* emb, int64_t rows, int K, const int32_t
     return DCTR_OK;
 }
 
+// the same table written segment by segment (4 lanes per segment): no search, entries of a segment are contiguous
+__global__ __launch_bounds__(256) void entry_fill_kernel(const int32_t* __restrict__ offsets, int n_seg, int S, int ld4, int KQ,
+                                                        int32_t* __restrict__ entry_row) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int seg = (int)(t >> 2), l = (int)(t & 3);
+    if (seg >= n_seg) return;
+    const int v = S == 1 && KQ == 0 ? seg : (seg / S) * ld4 + (seg % S) * KQ;
+    for (int j = offsets[seg] + l; j < offsets[seg + 1]; j += 4) entry_row[j] = v;
+}
+
 int csr_entry_offsets(const int32_t* offsets, int n_seg, int nnz, int S, int ld, int K, int32_t* entry_off, hipStream_t st) {
     if (nnz <= 0) return DCTR_OK;
+    if (nnz >= n_seg / 4) {           // (very sparse segment lists: the per-entry search touches less)
+        entry_fill_kernel<<<ceil_div((int64_t)n_seg * 4, 256), 256, 0, st>>>(offsets, n_seg, S, ld / 4, K / 4, entry_off);
+        DCTR_LAUNCH_CHECK();
+        return DCTR_OK;
+    }
     entry_row_kernel<<<ceil_div(nnz, 256), 256, 0, st>>>(offsets, n_seg, nnz, S, ld / 4, K / 4, entry_off);
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;

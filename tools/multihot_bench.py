@@ -42,6 +42,8 @@ batches = [[torch.from_numpy(a).to(dev) for a in synth(B, 100 + i)] for i in ran
 max_nnz = max(int(b[1].shape[0]) for b in batches)
 for model in ("din", "esmm", "din_att"):
     for table_mode in ("dense_exact", "touched_rows"):
+        if os.environ.get("DCTR_MH_ONLY") and os.environ["DCTR_MH_ONLY"] != "%s:%s" % (model, table_mode):
+            continue
         att = dict(attention_layers=(256,), att_pairs=[(FC + i, FC + 4 + i) for i in range(4)]) if model == "din_att" else {}
         name, model = model, model.split("_")[0]
         eng = Engine(EngineConfig(model=model, field_size=S, feature_size=V, embedding_size=K, deep_layers=(256, 128, 64), dropout=(0.5, 0.5, 0.5),
