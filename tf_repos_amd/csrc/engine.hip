@@ -43,6 +43,13 @@ int fork(dctr_engine* E, hipStream_t from, hipStream_t to) {
     return DCTR_OK;
 }
 
+// one record, several waiters (an event record is a barrier packet on the recording stream: ~5 us of the critical path each)
+int record_on(dctr_engine* E, hipStream_t from, hipEvent_t* ev) {
+    *ev = E->events[E->ev_next++ % E->events.size()];
+    DCTR_HIP_CHECK(hipEventRecord(*ev, from));
+    return DCTR_OK;
+}
+
 namespace {
 
 static int add_param(dctr_engine* E, const std::string& name, std::initializer_list<int64_t> dims, bool table, int n_part, float l2) {
@@ -561,7 +568,9 @@ int opt_dense_range(dctr_engine* E, int p_first, int p_last, hipStream_t st, boo
 
 // fused_opt: step each MLP layer's weights on the side stream as soon as BOTH its wgrad (same stream) and its dgrad (which
 // still reads the old weights, other stream) are done -- the dense optimizer then costs nothing at the end of the step
-int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool fused_opt = false) {
+// head_ev: an event recorded on st right after the head (nothing enqueued on st since): the first layer's wgrad waits on it
+// instead of a record of its own
+int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool fused_opt = false, const hipEvent_t* head_ev = nullptr) {
     const dctr_config& c = E->cfg;
     if (c.model == DCTR_MODEL_AFM) return afm_backward(E, B, st, sw);
     const int F = E->F, K = E->K, D = E->D;
@@ -597,7 +606,11 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
         if (E->bn)      // dh[i] holds dL/d(layer output): dropout mask, BN backward, ReLU mask -> dL/d(pre-activation), in place
             DCTR_TRY(bn_backward(E->dh[i], fc.out, E->h[i], fc.out, B, fc.out, E->bn_stats[i], E->pp(fc.bn_gamma), fc.keep, bn_seedp,
                                  0x1000ull + i, E->bn_scratch, E->part(fc.bn_beta), E->part(fc.bn_gamma), E->dh[i], fc.out, st));
-        DCTR_TRY(fork(E, st, sw));      // dh[i] is complete on st
+        // dh[i] is complete on st -- and so is dgrad_{i+1}, the last reader of W_{i+1}: ONE record serves the weight gradient of
+        // this layer and (fused_opt) the optimizer step of the layer above, whose wgrad is already queued on sw
+        if (i == nl - 1 && head_ev != nullptr && !E->bn && E->head_did_out_bwd) DCTR_HIP_CHECK(hipStreamWaitEvent(sw, *head_ev, 0));
+        else DCTR_TRY(fork(E, st, sw));
+        if (fused_opt && i < nl - 1) DCTR_TRY(opt_dense_range(E, E->mlp[i + 1].w, E->mlp[i + 1].last, sw));
         DCTR_TRY(fc_bwd_weights_partials(x, ldx, E->dh[i], fc.out, E->part(fc.w), w.padded, E->part(fc.b), b.padded, B, fc.in,
                                          fc.out, fc.splits, sw, 1));
         if (i > 0)
@@ -605,10 +618,6 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
                                  E->bn ? nullptr : E->h[i - 1], E->mlp[i - 1].out, E->bn ? 1.f : E->mlp[i - 1].keep, st, 1));
         else
             DCTR_TRY(fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w), E->dx_in, E->Din_ld, B, fc.in, fc.out, nullptr, 0, 1.f, st, 1));
-        if (fused_opt) {
-            DCTR_TRY(fork(E, st, sw));          // dgrad_i (reader of the old W_i) is complete
-            DCTR_TRY(opt_dense_range(E, fc.w, fc.last, sw));
-        }
     }
     const uint64_t* seedp = &E->state->seed_t;
     if (c.model == DCTR_MODEL_IPNN) DCTR_TRY(pnn_inner_bwd(E->e, E->e_ld, E->dx_in + D, E->Din_ld, B, F, K, E->dx_in, E->Din_ld, st));
@@ -622,6 +631,12 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
         const Param& cw = E->params[E->p_cross_w];
         DCTR_TRY(dcn_cross_bwd(E->xs, E->xlw, E->pp(E->p_cross_w), E->dxL, D, B, D, c.cross_layers, E->dx_in, E->Din_ld,
                                E->part(E->p_cross_w), E->part(E->p_cross_b), cw.n_part, cw.padded, E->cross_scratch, st));
+    }
+    if (fused_opt) {
+        // everything the dense side reads or writes on st is enqueued: the first layer's step (its dgrad is done) and, for the
+        // caller, the cross-network / output-layer partial slabs
+        DCTR_TRY(fork(E, st, sw));
+        DCTR_TRY(opt_dense_range(E, E->mlp[0].w, E->mlp[0].last, sw));
     }
     return DCTR_OK;
 }
@@ -725,19 +740,23 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     DCTR_TRY(forward_rest(E, B, true, st, (group_after == 1 && have_mlp) ? &start_grouping : nullptr));
     DCTR_TRY(head(E, B, B, true, st, nullptr, true));
     const bool fused_opt = E->cfg.model != DCTR_MODEL_AFM;
+    hipEvent_t head_ev = nullptr;
+    bool have_head_ev = false;
     if (fused_opt && E->head_did_out_bwd) {
         // the output layer (and the global bias, whose gradient aliases the output bias' slabs) is final right after the fused
         // head kernel: step it now, beside the MLP backward, instead of at the end of the step beside the scatter
         // (on the grouping stream, idle since the MLP forward: on the wgrad stream these two latency-bound launches -- 128 slabs
         //  summed by one block each, ~35 us -- would delay the whole weight-gradient chain behind them)
-        DCTR_TRY(fork(E, st, sg));
+        DCTR_TRY(record_on(E, st, &head_ev));
+        have_head_ev = true;
+        DCTR_HIP_CHECK(hipStreamWaitEvent(sg, head_ev, 0));
         if (split_table && bg_late) DCTR_TRY(step_untouched_rows(E, sg));
         DCTR_TRY(opt_dense_range(E, E->p_out_w, E->p_out_b, sg));
         if (E->p_bias >= 0) DCTR_TRY(opt_dense_range(E, E->p_bias, E->p_bias, sg));
     }
     const bool out_done = fused_opt && E->head_did_out_bwd;
-    DCTR_TRY(backward_dense(E, B, st, sw, fused_opt));
-    DCTR_TRY(fork(E, st, sw));          // cross-network / output-layer partials are written on st
+    DCTR_TRY(backward_dense(E, B, st, sw, fused_opt, have_head_ev ? &head_ev : nullptr));
+    if (!fused_opt) DCTR_TRY(fork(E, st, sw));          // (fused_opt: backward_dense ends with that fork)
     if (fused_opt) {
         // what is left of the dense arena: cross_w / cross_b (DCN), and the output layer + bias if they were not stepped above
         for (int i = 0; i < (int)E->params.size(); ++i) {
