@@ -167,6 +167,14 @@ def lib() -> C.CDLL:
             raise errors.NotFoundError(
                 "libdeepctr_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        # PyTorch-ROCm bundles its own libamdhip64 under the same SONAME this library links against: whichever copy is loaded
+        # first serves the whole process.  If ours (/opt/rocm) came first, torch would come up on a runtime it was not built
+        # for and report "No HIP GPUs are available" -- so when torch is installed it is imported before the library.
+        if os.environ.get("DCTR_NO_TORCH_PRELOAD") is None:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         l = C.CDLL(LIB_PATH)
         for name, (args, res) in _SIGS.items():
             fn = getattr(l, name)          # AttributeError if the ABI and the header drift apart

@@ -1,0 +1,100 @@
+"""Host -> device input feeder for the fixed-field models: a background thread stages numpy batches through pinned buffers into
+the engine's own input slots (dctr_input_slot) on a copy stream, up to DCTR_INPUT_SLOTS - 1 batches ahead of the step that
+consumes them; the training loop then passes the slot tensors to train_step, which reads them in place (no staging copy, no
+allocation per step).  This is the prefetch(500000) of the reference pipeline (DeepFM.py:84) at device granularity: at
+~11 M examples/s a step lasts 0.37 ms, the feeder needs ~0.15 ms of one host thread per batch (one memcpy into pinned memory +
+three async H2D copies, 1.3 MB at B=4096) and ~3.5 GB/s of the link."""
+from __future__ import annotations
+
+import queue
+import threading
+from typing import Iterable, Iterator, Tuple
+
+import numpy as np
+
+from . import capi
+
+
+class DeviceFeeder:
+    def __init__(self, engine, batches: Iterable[Tuple[np.ndarray, np.ndarray, np.ndarray]], slots: int = capi.INPUT_SLOTS):
+        import torch
+        self._torch = torch
+        self.eng = engine
+        self.n_slots = int(slots)
+        MB, F = engine.cfg.max_batch, engine.cfg.field_size
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        self.slot = [engine.input_slot(k) for k in range(self.n_slots)]                 # (ids, vals, labels) device views
+        self.pin = [(torch.empty((MB, F), dtype=torch.int32).pin_memory(), torch.empty((MB, F), dtype=torch.float32).pin_memory(),
+                     torch.empty((MB,), dtype=torch.float32).pin_memory()) for _ in range(self.n_slots)]
+        self.copy_stream = torch.cuda.Stream(device=self.dev)
+        self.copied = [torch.cuda.Event() for _ in range(self.n_slots)]                 # H2D of the slot's batch is complete
+        self.consumed = [None] * self.n_slots                                           # the step that read the slot has finished
+        # host-side handshake per slot: the feeder may refill slot k only after the consumer has ENQUEUED the step that reads
+        # it (release) -- taking the item off the queue is not enough -- and then waits for that step's event on the device
+        self.free = [threading.Semaphore(1) for _ in range(self.n_slots)]
+        self._q: "queue.Queue" = queue.Queue(maxsize=self.n_slots - 1)
+        self._err = None
+        self._stop = False
+        self._thread = threading.Thread(target=self._run, args=(iter(batches),), daemon=True)
+        self._thread.start()
+
+    def _run(self, it):
+        torch = self._torch
+        try:
+            torch.cuda.set_device(self.dev)
+            k = 0
+            for ids, vals, labels in it:
+                if self._stop:
+                    break
+                B = int(labels.shape[0])
+                while not self.free[k].acquire(timeout=0.2):
+                    if self._stop:
+                        return
+                ev = self.consumed[k]
+                if ev is not None:
+                    ev.synchronize()                      # the slot (and its pinned buffer) is free again
+                p_i, p_v, p_l = self.pin[k]
+                np.copyto(p_i.numpy()[:B], ids, casting="same_kind")
+                np.copyto(p_v.numpy()[:B], vals, casting="same_kind")
+                np.copyto(p_l.numpy()[:B], labels, casting="same_kind")
+                s_i, s_v, s_l = self.slot[k]
+                with torch.cuda.stream(self.copy_stream):
+                    s_i[:B].copy_(p_i[:B], non_blocking=True)
+                    s_v[:B].copy_(p_v[:B], non_blocking=True)
+                    s_l[:B].copy_(p_l[:B], non_blocking=True)
+                    self.copied[k].record(self.copy_stream)
+                self._q.put((k, B))
+                k = (k + 1) % self.n_slots
+        except BaseException as e:                        # noqa: BLE001  (surfaced in the consumer)
+            self._err = e
+        finally:
+            self._q.put(None)
+
+    def __iter__(self) -> Iterator[Tuple["object", "object", "object", int]]:
+        torch = self._torch
+        while True:
+            item = self._q.get()
+            if item is None:
+                if self._err is not None:
+                    raise self._err
+                return
+            k, B = item
+            torch.cuda.current_stream().wait_event(self.copied[k])
+            s_i, s_v, s_l = self.slot[k]
+            yield s_i[:B], s_v[:B], s_l[:B], k
+
+    def release(self, k: int) -> None:
+        """call after enqueueing the step that reads slot k (on the current stream)"""
+        ev = self._torch.cuda.Event()
+        ev.record(self._torch.cuda.current_stream())
+        self.consumed[k] = ev
+        self.free[k].release()
+
+    def close(self) -> None:
+        self._stop = True
+        try:
+            while self._q.get_nowait() is not None:
+                pass
+        except queue.Empty:
+            pass
+        self._thread.join(timeout=5)

@@ -106,12 +106,22 @@ class LibsvmDataset:
                     for s in range(0, n, 256):
                         rng.shuffle(perm[s:s + 256])
                     ids, vals, labels = ids[perm], vals[perm], labels[perm]
-                if carry is not None:
-                    ids = np.concatenate([carry[0], ids]); vals = np.concatenate([carry[1], vals]); labels = np.concatenate([carry[2], labels])
-                    carry = None
                 n = len(labels)
-                full = n // B * B
-                for s in range(0, full, B):
+                s0 = 0
+                if carry is not None:
+                    # repeat().batch(): the batch that spans the file / epoch edge = the carried tail + the head of this file
+                    # (only that one batch is assembled by copy; the rest are views)
+                    take = min(B - len(carry[2]), n)
+                    carry = (np.concatenate([carry[0], ids[:take]]), np.concatenate([carry[1], vals[:take]]),
+                             np.concatenate([carry[2], labels[:take]]))
+                    s0 = take
+                    if len(carry[2]) == B:
+                        yield carry
+                        carry = None
+                    else:
+                        continue                # this file was shorter than the gap: keep filling from the next one
+                full = s0 + (n - s0) // B * B
+                for s in range(s0, full, B):
                     yield ids[s:s + B], vals[s:s + B], labels[s:s + B]
                 if full < n:
                     carry = (ids[full:], vals[full:], labels[full:])

@@ -295,7 +295,12 @@ class Estimator:
         t0, n0 = time.time(), 0
         done = 0
         loss = None
-        for batch in (self._csr_batches(pipeline) if csr else self._device_batches(pipeline)):
+        # fixed-field libsvm pipelines: batches are staged into the engine's input slots by a background feeder
+        feeder = None
+        if not csr and pipeline.csv is None and not getattr(e.cfg, "dense_size", 0):
+            from ..feeder import DeviceFeeder
+            feeder = DeviceFeeder(e, pipeline.numpy_batches())
+        for batch in (self._csr_batches(pipeline) if csr else (feeder if feeder is not None else self._device_batches(pipeline))):
             if steps is not None and done >= steps:
                 break
             if max_steps is not None and start_step + done >= max_steps:
@@ -304,6 +309,10 @@ class Estimator:
             if csr:
                 off, ids, wts, labels, z = batch
                 loss = e.train_step_csr(off, ids, wts, labels, z, want_loss=want)
+            elif feeder is not None:
+                ids, vals, labels, slot = batch
+                loss = e.train_step(ids, vals, labels, want_loss=want)
+                feeder.release(slot)
             else:
                 ids, vals, labels = batch
                 loss = e.train_step(ids, vals, labels, want_loss=want)
@@ -314,6 +323,8 @@ class Estimator:
                 dt = time.time() - t0
                 L.info("global_step/sec: %.4g  examples/sec: %.4g  loss = %.7g, step = %d" % (log_every / dt, n0 / dt, loss, start_step + done))
                 t0, n0 = time.time(), 0
+        if feeder is not None:
+            feeder.close()
         e.check_ids()
         path = self._save()
         L.info("Saving checkpoints for %d into %s." % (e.global_step, path))
