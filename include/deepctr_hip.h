@@ -135,6 +135,12 @@ int dctr_parse_libsvm(const char* h_text, size_t nbytes, int field_size, int64_t
                       int32_t* h_ids, float* h_vals, float* h_labels,
                       int64_t* n_rows, size_t* n_consumed);
 
+/* the same decode of a whole buffer with `threads` workers inside the library (map(decode_libsvm, num_parallel_calls=10),
+ * DeepFM.py:84).  h_ids == NULL: count only (*n_rows = rows the buffer holds).  Otherwise the arrays must hold capacity_rows
+ * >= that count.  Errors are the serial parser's (same message and line number). */
+int dctr_parse_libsvm_mt(const char* h_text, size_t nbytes, int field_size, int threads, int32_t* h_ids, float* h_vals,
+                         float* h_labels, int64_t capacity_rows, int64_t* n_rows);
+
 /* CSV text -> column tensors.  Replaces tf.decode_csv(line, record_defaults) (wide_n_deep.py:67-73; defaults :59-64):
  * kinds[c] = 0 float / 1 int32 column; an empty field takes its column's default; float (int) columns land in order of
  * appearance in h_f [rows, n_float] (h_i [rows, n_int]).  Same whole-lines / n_consumed contract as dctr_parse_libsvm. */

@@ -8,8 +8,12 @@
 // with mantissa n < 2^29 and k <= 22 fractional digits converts as (float)((double)n / 10^k), which is
 // correctly rounded (the double quotient's 2^-53 relative error cannot cross a binary32 rounding boundary
 // for n < 2^29 -- see DESIGN.md "parser"); everything else goes through glibc strtof.
+#include <algorithm>
 #include <cerrno>
 #include <cstdlib>
+#include <functional>
+#include <thread>
+#include <vector>
 
 #include "common.h"
 
@@ -152,6 +156,75 @@ extern "C" int dctr_parse_libsvm(const char* h_text, size_t nbytes, int field_si
     // swallow trailing blank lines so callers see end-of-input
     *n_rows = row;
     if (n_consumed) *n_consumed = consumed;
+    return DCTR_OK;
+}
+
+// The same decode over a whole file with a thread team inside the library (tf.data's map(decode_libsvm, num_parallel_calls),
+// DeepFM.py:84): the buffer is cut at line boundaries into `threads` chunks; pass 1 counts the row-producing lines of every chunk
+// (a line is skipped iff it holds nothing but spaces / a '\r', exactly as above), pass 2 parses every chunk straight into its rows
+// of the caller's arrays.  h_ids == NULL: count only.  On a malformed line the buffer is re-parsed serially so that the error
+// (message, line number) is the single-threaded one.
+extern "C" int dctr_parse_libsvm_mt(const char* h_text, size_t nbytes, int field_size, int threads, int32_t* h_ids, float* h_vals,
+                                    float* h_labels, int64_t capacity_rows, int64_t* n_rows) {
+    using namespace dctr;
+    DCTR_REQUIRE(h_text != nullptr || nbytes == 0, "null buffer");
+    DCTR_REQUIRE(n_rows != nullptr && field_size > 0, "bad argument");
+    threads = std::max(1, std::min(threads, 1024));
+    if (nbytes < ((size_t)1 << 20)) threads = 1;
+    std::vector<size_t> cut((size_t)threads + 1, nbytes);
+    cut[0] = 0;
+    for (int t = 1; t < threads; ++t) {
+        size_t pos = std::max(cut[(size_t)t - 1], nbytes / (size_t)threads * (size_t)t);
+        const char* nl = pos < nbytes ? static_cast<const char*>(memchr(h_text + pos, '\n', nbytes - pos)) : nullptr;
+        cut[(size_t)t] = nl ? (size_t)(nl - h_text) + 1 : nbytes;
+    }
+    std::vector<int64_t> rows((size_t)threads, 0);
+    auto count = [&](int t) {
+        const char* p = h_text + cut[(size_t)t];
+        const char* end = h_text + cut[(size_t)t + 1];
+        int64_t n = 0;
+        while (p < end) {
+            const char* eol = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+            const char* le = eol ? eol : end;
+            if (le > p && le[-1] == '\r') --le;
+            const char* q = p;
+            while (q < le && *q == ' ') ++q;
+            if (q < le) ++n;
+            p = eol ? eol + 1 : end;
+        }
+        rows[(size_t)t] = n;
+    };
+    auto run = [&](const std::function<void(int)>& fn) {
+        std::vector<std::thread> team;
+        for (int t = 1; t < threads; ++t) team.emplace_back(fn, t);
+        fn(0);
+        for (auto& th : team) th.join();
+    };
+    run(count);
+    std::vector<int64_t> first((size_t)threads + 1, 0);
+    for (int t = 0; t < threads; ++t) first[(size_t)t + 1] = first[(size_t)t] + rows[(size_t)t];
+    *n_rows = first[(size_t)threads];
+    if (h_ids == nullptr) return DCTR_OK;
+    DCTR_REQUIRE(h_vals != nullptr && h_labels != nullptr, "null output");
+    DCTR_REQUIRE(capacity_rows >= *n_rows, "capacity_rows=%lld < %lld lines", (long long)capacity_rows, (long long)*n_rows);
+    std::vector<int> rc((size_t)threads, DCTR_OK);
+    auto parse = [&](int t) {
+        int64_t n = 0;
+        const size_t r0 = (size_t)first[(size_t)t];
+        rc[(size_t)t] = dctr_parse_libsvm(h_text + cut[(size_t)t], cut[(size_t)t + 1] - cut[(size_t)t], field_size, rows[(size_t)t] + 1,
+                                          h_ids + r0 * (size_t)field_size, h_vals + r0 * (size_t)field_size, h_labels + r0, &n, nullptr);
+        if (rc[(size_t)t] == DCTR_OK && n != rows[(size_t)t]) rc[(size_t)t] = DCTR_ERR_PARSE;
+    };
+    run(parse);
+    for (int t = 0; t < threads; ++t)
+        if (rc[(size_t)t] != DCTR_OK) {
+            // the canonical error: parse serially up to the failure (outputs into scratch-free positions are harmless: same rows)
+            int64_t n = 0;
+            const int r = dctr_parse_libsvm(h_text, nbytes, field_size, capacity_rows, h_ids, h_vals, h_labels, &n, nullptr);
+            if (r != DCTR_OK) return r;
+            set_error("multi-threaded libsvm parse failed in chunk %d although the serial parse succeeded", t);
+            return DCTR_ERR_PARSE;
+        }
     return DCTR_OK;
 }
 

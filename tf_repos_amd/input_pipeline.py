@@ -1,7 +1,7 @@
 """input_fn side of the hot path (DeepFM.py:63-98): libsvm text -> batched (feat_ids, feat_vals, labels).
 
 The text decode (K1) is the C ABI's dctr_parse_libsvm -- host C++ inside libdeepctr_hip.so, re-entrant, so a file is
-split on line boundaries and parsed by a thread pool (ctypes releases the GIL) like tf.data's
+parsed by a thread team inside the library (dctr_parse_libsvm_mt) like tf.data's
 map(decode_libsvm, num_parallel_calls=10) (DeepFM.py:84).  Batches are staged in pinned host memory and copied to
 the GPU on a side stream so the training step never waits for the parser.
 """
@@ -50,14 +50,20 @@ def _split_on_lines(buf: bytes, parts: int) -> List[bytes]:
 
 
 def parse_file(path: str, field_size: int, threads: int = 10):
+    """A whole libsvm file through dctr_parse_libsvm_mt: the thread team lives inside the library (count pass, then every chunk
+    parsed straight into its rows of the result -- no Python per chunk, no concatenation)."""
     with open(path, "rb") as f:
         buf = f.read()
-    chunks = _split_on_lines(buf, threads)
-    if len(chunks) == 1:
-        return parse_libsvm(chunks[0], field_size)
-    with ThreadPoolExecutor(max_workers=threads) as ex:
-        parts = list(ex.map(lambda c: parse_libsvm(c, field_size), chunks))
-    return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts]))
+    lib = capi.lib()
+    n = C.c_int64()
+    capi.check(lib.dctr_parse_libsvm_mt(buf, len(buf), field_size, int(threads), None, None, None, 0, C.byref(n)))
+    rows = n.value
+    ids = np.empty((max(rows, 1), field_size), dtype=np.int32)
+    vals = np.empty((max(rows, 1), field_size), dtype=np.float32)
+    labels = np.empty(max(rows, 1), dtype=np.float32)
+    capi.check(lib.dctr_parse_libsvm_mt(buf, len(buf), field_size, int(threads), capi.ptr(ids), capi.ptr(vals), capi.ptr(labels), rows,
+                                        C.byref(n)))
+    return ids[:rows], vals[:rows], labels[:rows]
 
 
 class LibsvmDataset:
