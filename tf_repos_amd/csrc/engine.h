@@ -95,6 +95,7 @@ struct dctr_engine {
     bool timer_on = false;
     std::vector<hipEvent_t> timer_ev;   // pairs
     size_t timer_n = 0;
+    uint64_t timer_tick = 0;
     hipStream_t s_group = nullptr, s_wgrad = nullptr;   // side streams of the step DAG
     int64_t* auc_counts = nullptr;   // [4*200] tp,fn,tn,fp per threshold (tf.metrics.auc)
     float* eval_scalars = nullptr;   // [0] sum xent over the eval set, [1..] scratch
