@@ -85,6 +85,11 @@ def pmc_traffic_bytes(kernel_substr):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON: everything else that native libraries print there (RCCL writes a version banner
+    # to stdout at exit) is sent to stderr by pointing fd 1 at fd 2 and keeping the real stdout aside for the final line
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -254,7 +259,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(w)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     done.set()
     if sharded:
         import torch.distributed as dist
