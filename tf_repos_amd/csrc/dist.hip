@@ -187,7 +187,8 @@ namespace {
 int route_begin(dctr_dist* D, RouteState& r, const int32_t* ids, int B, hipStream_t s) {
     dctr_engine* E = D->E;
     const int W = D->world;
-    if (r.has_done) DCTR_HIP_CHECK(hipStreamWaitEvent(s, r.done, 0));        // this state's buffers are free again
+    // (this state's buffers are free: a side-stream route starts behind r.start, recorded on the main stream after the step that
+    //  last used the state was enqueued there; an inline route runs on the main stream itself -- no per-step `done` record)
     DCTR_TRY(group_ids(r.g, ids, B, E->F, s));
     DCTR_TRY(dctr_route_unique(reinterpret_cast<dctr_group_t>(r.g), W, r.send_rows, r.upos, r.counts, s));
     DCTR_TRY(D->t.all_gather_i32(D->t.ctx, 1, r.counts, W, r.all_counts, s));
@@ -252,7 +253,6 @@ int wait_worker(dctr_dist* D) {
 
 // the route of (ids, B) on the main stream: the prefetched one if it matches, else computed inline
 int take_route(dctr_dist* D, const int32_t* ids, int B, hipStream_t M, int* which) {
-    DCTR_HIP_CHECK(hipEventRecord(D->ev_start, M));
     if (D->pending >= 0) {
         const int w = D->pending;
         RouteState& r = D->rs[w];
@@ -262,8 +262,6 @@ int take_route(dctr_dist* D, const int32_t* ids, int B, hipStream_t M, int* whic
         DCTR_HIP_CHECK(hipStreamWaitEvent(M, r.ready, 0));
         if (r.ids == ids && r.B == B) { *which = w; return DCTR_OK; }
         // a prefetch for some other batch: it has been waited for (its buffers are quiescent); route this one now
-        DCTR_HIP_CHECK(hipEventRecord(r.done, M));
-        r.has_done = true;
     }
     const int w = D->parity;
     D->parity ^= 1;
@@ -482,8 +480,6 @@ int dctr_dist_train_step(dctr_dist_t D, const int32_t* d_ids, const float* d_val
     DCTR_TRY(D->t.all_to_all(D->t.ctx, 0, D->send_grads, r.scnt.data(), D->recv_grads, r.rcnt.data(), rec, M));
     DCTR_TRY(dctr_table_apply_packed(E, w, (int)r.n_recv, D->recv_grads, M));
     if (sd != M) DCTR_HIP_CHECK(hipStreamWaitEvent(M, D->ev_dense, 0));
-    DCTR_HIP_CHECK(hipEventRecord(r.done, M));
-    r.has_done = true;
     if (prefetch && !D->finish_early && D->worker == nullptr) DCTR_TRY(route_finish(D, D->rs[D->pending], D->pending, D->s_route));
     if (h_loss != nullptr) {
         // loss = mean xent over the GLOBAL batch + l2_reg * (l2_loss(tables, all shards) + l2_loss(regularised dense params))
@@ -508,8 +504,6 @@ int dctr_dist_predict(dctr_dist_t D, const int32_t* d_ids, const float* d_vals, 
     DCTR_TRY(take_route(D, d_ids, B, M, &w));
     RouteState& r = D->rs[w];
     DCTR_TRY(fetch_and_forward(D, r, d_vals, nullptr, B, false, M));
-    DCTR_HIP_CHECK(hipEventRecord(r.done, M));
-    r.has_done = true;
     if (d_prob != nullptr) {
         float* p = nullptr;
         DCTR_TRY(dctr_last_outputs(E, &p, nullptr));

@@ -1356,10 +1356,7 @@ int sharded_forward_backward(dctr_engine* E, const float* d_rows, int n_rows, co
     hipStream_t sw = E->s_wgrad;
     const size_t n = (size_t)B * E->F;
     const int P = E->K + 4;
-    if (train) {
-        DCTR_TRY(fork(E, st, sw));
-        DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, sw));
-    }
+    if (train) DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, st));    // (on st: see record_train)
     // inputs that already live in one of the engine's input slots are read in place (no staging copy at the head of the step)
     for (int k = 0; k < DCTR_INPUT_SLOTS; ++k)
         if (d_vals == E->slot_vals[k] && (d_labels == nullptr || d_labels == E->slot_labels[k])) {
@@ -1371,7 +1368,6 @@ int sharded_forward_backward(dctr_engine* E, const float* d_rows, int n_rows, co
     float* red = mode == DCTR_GATHER_FM ? E->yv : (mode == DCTR_GATHER_BI ? E->x_in : nullptr);
     DCTR_TRY(embed_gather_strided(d_rows, P, E->lin ? d_rows + E->K : nullptr, P, n_rows, d_idx, E->vals, B, E->F, E->K, mode, E->e,
                                   E->e_ld, E->lin ? E->yw : nullptr, E->S, red, E->status, st));
-    if (train) DCTR_TRY(fork(E, sw, st));
     DCTR_TRY(forward_rest(E, B, train, st));
     DCTR_TRY(head(E, B, global_batch, d_labels != nullptr, st, nullptr, train));
     if (train) {
