@@ -142,7 +142,14 @@ int embed_gather_strided(const float* emb, int emb_ld, const float* lin, int lin
         case 1:  DCTR_G(1, 16, 3);
         case 2:  DCTR_G(2, 8, 5);
         case 4:  DCTR_G(4, 8, 5);
-        case 8:  DCTR_G(8, 4, 5);
+        case 8: {
+            // HBM-resident table (V=1e8, uniform ids, B=8192; tools/gather_variants.py): <8,8,5> 20.0 us (4.28 TB/s), <8,4,5> 20.5,
+            // <8,4,10> 20.4
+            static const int v = getenv("DCTR_GATHER_K32") ? atoi(getenv("DCTR_GATHER_K32")) : 1;       // A/B knob
+            if (v == 0) DCTR_G(8, 4, 5);
+            if (v == 2) DCTR_G(8, 4, 10);
+            DCTR_G(8, 8, 5);
+        }
         case 16: DCTR_G(16, 4, 5);
         case 32: DCTR_G(32, 2, 4);
         case 64: DCTR_G(64, 1, 4);
