@@ -54,8 +54,82 @@ __global__ __launch_bounds__(256) void pnn_inner_fwd_kernel(const float* __restr
     }
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// C/D layout of v_mfma_f32_32x32x2_f32: register r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31
+__device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// ---- inner products on the matrix cores: per example G = E E^T ([F,K] x [K,F], F <= 64 padded to 64) as three 32x32 blocks
+// (the lower-left one is never needed), K/2 MFMA steps each; a wave per example, E staged once in LDS (row stride K+1: both
+// operands read conflict-free).  For a fixed i the pairs (i, j > i) are consecutive p: the accumulator rows store coalesced.
+// The scalar form moved 2 LDS words per MAC (LDS-bound: 55 us at B=8192, F=39, K=32); MFMA operands are 1/32 of that.
+template <int F, int K>
+__global__ __launch_bounds__(256) void pnn_inner_fwd_mfma_kernel(const float* __restrict__ e, int e_ld, int B,
+                                                                float* __restrict__ ip, int ip_ld) {
+    constexpr int KS = K + 1, KQ = K / 4;
+    constexpr int NLD = (F * KQ + 63) / 64;               // float4 loads per lane to stage one example
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, col = lane & 31;
+    float* t = smem + (size_t)wave * 64 * KS;
+    for (int x = lane; x < (64 - F) * KS; x += 64) t[F * KS + x] = 0.f;          // rows F..63 stay zero
+    for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
+        // the example's [F, K] tile: every lane's loads are issued together (a load -> LDS store loop would expose the memory
+        // latency NLD times per example: that, not LDS or FLOPs, was what the scalar kernel spent its 55 us on)
+        const float4* er = reinterpret_cast<const float4*>(e + (size_t)b * e_ld);
+        float4 v[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int x = u * 64 + lane;
+            v[u] = x < F * KQ ? er[x] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int x = u * 64 + lane;
+            if (x < F * KQ) {
+                float* d = t + (x / KQ) * KS + 4 * (x % KQ);
+                d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x16 acc[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; k += 2) {
+            const float lo = t[col * KS + k + half], hi = t[(32 + col) * KS + k + half];      // rows 0..31 / 32..63 at column k+half
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(lo, lo, acc[0], 0, 0, 0);           // i in [0,32),  j in [0,32)
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(lo, hi, acc[1], 0, 0, 0);           // i in [0,32),  j in [32,64)
+            if (F > 33) acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(hi, hi, acc[2], 0, 0, 0);   // i in [32,64), j in [32,64)
+        }
+        float* out = ip + (size_t)b * ip_ld;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int i0 = q == 2 ? 32 : 0, j0 = q == 0 ? 0 : 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + mfma_row(r, half), j = j0 + col;
+                if (i < j && j < F) out[pair_index(i, j, F)] = acc[q][r];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 int pnn_inner_fwd(const float* e, int e_ld, int B, int F, int K, float* ip, int ip_ld, hipStream_t st) {
     if (B <= 0) return DCTR_OK;
+    static const bool generic = getenv("DCTR_PNN_GENERIC") != nullptr;          // A/B knob
+    if (F == 39 && e_ld % 4 == 0 && !generic) {         // the Criteo field count (compile-time sizes for the register arrays)
+        const size_t ldsm = (size_t)4 * 64 * (K + 1) * sizeof(float);
+        const int grid = std::min(ceil_div(B, 4), 256 * 4);
+        switch (K) {
+#define DCTR_PF(KK) case KK: pnn_inner_fwd_mfma_kernel<39, KK><<<grid, 256, ldsm, st>>>(e, e_ld, B, ip, ip_ld); DCTR_LAUNCH_CHECK(); return DCTR_OK
+            DCTR_PF(4); DCTR_PF(8); DCTR_PF(16); DCTR_PF(32); DCTR_PF(64);
+#undef DCTR_PF
+            default: break;
+        }
+    }
     const size_t lds = (size_t)4 * F * (K + 1) * sizeof(float);
     DCTR_REQUIRE(lds <= 160 * 1024, "pnn_inner: F*K tile too large for LDS (F=%d K=%d)", F, K);
     pnn_inner_fwd_kernel<<<ceil_div(B, 4), 256, lds, st>>>(e, e_ld, B, F, K, ip, ip_ld);
@@ -89,50 +163,74 @@ __global__ __launch_bounds__(256) void pnn_inner_bwd_kernel(const float* __restr
     }
 }
 
-// The same product as G_b E_b with G_b the dense symmetric [F, F] matrix of the example's pair gradients (zero diagonal):
-// a wave per example expands dip[b, :] into G in LDS, a lane owns one embedding column k and keeps e[b, :, k] in F registers,
-// and every output row is F FMAs against a row of G read as broadcast float4s -- one LDS read per 4 MACs instead of two per MAC
-// plus the pair-index arithmetic (B=8192, F=39, K=32: 192 -> 121 us; what is left is the latency of the dependent loads of one example at a time).  F is a template parameter (register array).
-template <int F, int NG>          // NG = 64 / min(K, 64) row groups per wave
-__global__ __launch_bounds__(256) void pnn_inner_bwd_reg_kernel(const float* __restrict__ e, int e_ld, const float* __restrict__ dip,
-                                                               int dip_ld, int B, int K, float* __restrict__ dE, int de_ld) {
+// On the matrix cores: dE_b += G_b E_b with G_b the dense symmetric [F, F] matrix of the example's pair gradients (zero
+// diagonal), F <= 64 padded to 64 rows x FP columns.  A wave per example expands dip[b, :] into G in LDS (row stride odd: the A
+// operand reads are conflict-free), the B operand e[b, k, n] comes straight from global memory (coalesced, each element once), two
+// 32-row blocks x FP/2 MFMA steps per 32 embedding columns, and the accumulator rows are added into dE coalesced.
+// (scalar form: 192 us at B=8192, F=39, K=32 -- two LDS words and the pair-index arithmetic per MAC.)
+template <int F>
+__global__ __launch_bounds__(256) void pnn_inner_bwd_mfma_kernel(const float* __restrict__ e, int e_ld, const float* __restrict__ dip,
+                                                                int dip_ld, int B, int K, float* __restrict__ dE, int de_ld) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int P = F * (F - 1) / 2;
-    constexpr int FS = (F + 3) & ~3;                     // row stride of G: float4 reads, zero padding behind column F-1
-    constexpr int KL = 64 / NG;                          // lanes over k
-    __shared__ __attribute__((aligned(16))) float Gs[4][F * FS];
-    __shared__ int16_t pi[P], pj[P];
+    constexpr int FP = (F + 1) & ~1;                      // contraction length (even)
+    constexpr int GS = FP | 1;                            // row stride of G (odd)
+    constexpr int NP = (P + 63) / 64;                     // pair gradients per lane
+    int16_t* pi = reinterpret_cast<int16_t*>(smem);
+    int16_t* pj = pi + P;
+    float* Gall = smem + (((size_t)2 * P * sizeof(int16_t) + 15) / 16) * 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, col = lane & 31;
     for (int p = threadIdx.x; p < P; p += 256) {
         int i = 0, base = 0;
         while (p >= base + (F - 1 - i)) { base += F - 1 - i; ++i; }
         pi[p] = (int16_t)i; pj[p] = (int16_t)(i + 1 + (p - base));
     }
-    float* G = Gs[wave];
-    for (int x = lane; x < F * FS; x += 64) G[x] = 0.f;   // diagonal and padding stay zero
+    float* G = Gall + (size_t)wave * 64 * GS;
+    for (int x = lane; x < 64 * GS; x += 64) G[x] = 0.f;  // diagonal, rows >= F and the padding column stay zero
     __syncthreads();
-    const int kg = lane % KL, rg = lane / KL;
     for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
+        // (every batch of global loads below is issued together and consumed afterwards: one dependent load per loop trip
+        //  exposes the memory latency dozens of times per example -- that was the 120-190 us of the earlier forms)
         const float* dr = dip + (size_t)b * dip_ld;
-        for (int p = lane; p < P; p += 64) {
-            const float v = dr[p];
-            G[pi[p] * FS + pj[p]] = v;
-            G[pj[p] * FS + pi[p]] = v;
+        float gv[NP];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) { const int p = u * 64 + lane; gv[u] = p < P ? dr[p] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int p = u * 64 + lane;
+            if (p < P) { G[pi[p] * GS + pj[p]] = gv[u]; G[pj[p] * GS + pi[p]] = gv[u]; }
         }
         __builtin_amdgcn_wave_barrier();                  // (wave-private tile: the LDS queue of a wave is in order)
-        for (int kb = 0; kb < K; kb += KL) {
-            const int k = kb + kg;
-            float tr[FS];
+        const float* er = e + (size_t)b * e_ld;
+        float* dr_out = dE + (size_t)b * de_ld;
+        for (int n0 = 0; n0 < K; n0 += 32) {
+            const int n = n0 + col;
+            float bop[FP / 2], o0[16], o1[16];
 #pragma unroll
-            for (int j = 0; j < FS; ++j) tr[j] = j < F ? e[(size_t)b * e_ld + j * K + k] : 0.f;
-            for (int i = rg; i < F; i += NG) {
-                const float4* grow = reinterpret_cast<const float4*>(G + i * FS);
-                float s = 0.f;
+            for (int s2 = 0; s2 < FP / 2; ++s2) { const int kk = 2 * s2 + half; bop[s2] = (kk < F && n < K) ? er[kk * K + n] : 0.f; }
 #pragma unroll
-                for (int j4 = 0; j4 < FS / 4; ++j4) {
-                    const float4 g = grow[j4];
-                    s += g.x * tr[4 * j4] + g.y * tr[4 * j4 + 1] + g.z * tr[4 * j4 + 2] + g.w * tr[4 * j4 + 3];
+            for (int r = 0; r < 16; ++r) {
+                const int i = mfma_row(r, half);
+                o0[r] = (i < F && n < K) ? dr_out[i * K + n] : 0.f;
+                o1[r] = (32 + i < F && n < K) ? dr_out[(32 + i) * K + n] : 0.f;
+            }
+            f32x16 a0, a1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+#pragma unroll
+            for (int s2 = 0; s2 < FP / 2; ++s2) {
+                const int kk = 2 * s2 + half;
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(G[col * GS + kk], bop[s2], a0, 0, 0, 0);
+                if (F > 32) a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(G[(32 + col) * GS + kk], bop[s2], a1, 0, 0, 0);
+            }
+            if (n < K) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = mfma_row(r, half);
+                    if (i < F) dr_out[i * K + n] = o0[r] + a0[r];
+                    if (32 + i < F) dr_out[(32 + i) * K + n] = o1[r] + a1[r];
                 }
-                dE[(size_t)b * de_ld + i * K + k] += s;
             }
         }
         __builtin_amdgcn_wave_barrier();                  // G is rewritten for the next example
@@ -143,14 +241,10 @@ int pnn_inner_bwd(const float* e, int e_ld, const float* dip, int dip_ld, int B,
                   hipStream_t st) {
     if (B <= 0) return DCTR_OK;
     static const bool generic = getenv("DCTR_PNN_GENERIC") != nullptr;          // A/B knob
-    if (F == 39 && (K % 64 == 0 || 64 % K == 0) && K >= 4 && !generic) {       // the Criteo field count: register-tiled form
-        const int grid = std::min(ceil_div(B, 4), 256 * 8);
-        switch (K >= 64 ? 1 : 64 / K) {
-#define DCTR_PB(N) case N: pnn_inner_bwd_reg_kernel<39, N><<<grid, 256, 0, st>>>(e, e_ld, dip, dip_ld, B, K, dE, de_ld); break
-            DCTR_PB(1); DCTR_PB(2); DCTR_PB(4); DCTR_PB(8); DCTR_PB(16);
-#undef DCTR_PB
-            default: set_error("pnn_inner_bwd: K=%d", K); return DCTR_ERR_UNSUPPORTED;
-        }
+    if (F == 39 && !generic) {                          // the Criteo field count (compile-time sizes for the register arrays)
+        constexpr int P2 = 39 * 38 / 2, GS = 41;
+        const size_t ldsm = (((size_t)2 * P2 * sizeof(int16_t) + 15) / 16) * 16 + (size_t)4 * 64 * GS * sizeof(float);
+        pnn_inner_bwd_mfma_kernel<39><<<std::min(ceil_div(B, 4), 256 * 3), 256, ldsm, st>>>(e, e_ld, dip, dip_ld, B, K, dE, de_ld);
         DCTR_LAUNCH_CHECK();
         return DCTR_OK;
     }
