@@ -142,9 +142,7 @@ struct RouteState {
     int phase = 0;                      // 0 = empty, 1 = begun (split sizes in flight), 2 = complete
     hipEvent_t counts_ready = nullptr;  // the split sizes are in h_all_counts
     hipEvent_t ready = nullptr;         // the whole route is complete (recorded on the stream that computed it)
-    hipEvent_t done = nullptr;          // the step that used this state has finished (main stream)
     hipEvent_t start = nullptr;         // recorded on the main stream when the routing of this batch is requested
-    bool has_done = false;
 };
 
 // The routing of the next batch is ENQUEUED by a worker thread of its own (it owns the route stream and communicator 1): that is
@@ -174,7 +172,7 @@ struct dctr_dist {
     int parity = 0;
     int pending = -1;                   // index of the prefetched route, -1 = none
     hipStream_t s_route = nullptr, s_dense = nullptr;
-    hipEvent_t ev_start = nullptr, ev_fb = nullptr, ev_dense = nullptr;
+    hipEvent_t ev_fb = nullptr, ev_dense = nullptr;
     float *rows_out = nullptr, *rows_back = nullptr, *send_grads = nullptr, *recv_grads = nullptr, *d_loss = nullptr;
     int64_t cap = 0, cap_owner = 0;
     bool overlap = true;
@@ -327,7 +325,6 @@ int dist_alloc(dctr_dist* D) {
         r.scnt.assign(W, 0); r.rcnt.assign(W, 0);
         DCTR_HIP_CHECK(hipEventCreateWithFlags(&r.counts_ready, hipEventDisableTiming));
         DCTR_HIP_CHECK(hipEventCreateWithFlags(&r.ready, hipEventDisableTiming));
-        DCTR_HIP_CHECK(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
         DCTR_HIP_CHECK(hipEventCreateWithFlags(&r.start, hipEventDisableTiming));
     }
     DCTR_HIP_CHECK(hipMalloc(&D->rows_out, D->cap_owner * P * 4));
@@ -340,7 +337,6 @@ int dist_alloc(dctr_dist* D) {
     // runs on the engine's grouping stream (idle in the sharded step), the dense update continues on its wgrad stream.
     D->s_route = E->s_group;
     D->s_dense = E->s_wgrad;
-    DCTR_HIP_CHECK(hipEventCreateWithFlags(&D->ev_start, hipEventDisableTiming));
     DCTR_HIP_CHECK(hipEventCreateWithFlags(&D->ev_fb, hipEventDisableTiming));
     DCTR_HIP_CHECK(hipEventCreateWithFlags(&D->ev_dense, hipEventDisableTiming));
     const char* ov = getenv("DCTR_SHARD_OVERLAP");
@@ -432,11 +428,9 @@ int dctr_dist_destroy(dctr_dist_t D) {
         if (r.h_all_counts) hipHostFree(r.h_all_counts);
         if (r.counts_ready) hipEventDestroy(r.counts_ready);
         if (r.ready) hipEventDestroy(r.ready);
-        if (r.done) hipEventDestroy(r.done);
         if (r.start) hipEventDestroy(r.start);
     }
     hipFree(D->rows_out); hipFree(D->rows_back); hipFree(D->send_grads); hipFree(D->recv_grads); hipFree(D->d_loss);
-    if (D->ev_start) hipEventDestroy(D->ev_start);
     if (D->ev_fb) hipEventDestroy(D->ev_fb);
     if (D->ev_dense) hipEventDestroy(D->ev_dense);
     if (D->rccl) {
