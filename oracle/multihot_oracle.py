@@ -50,6 +50,8 @@ class Config:
     # these layers with layers[i] (the DEEP layer widths, DIN.py:164) for i < len(attention_layers): callers restating the
     # script pass deep_layers[:len(attention_layers)] here
     attention_layers: Sequence[int] = ()
+    batch_norm: bool = False             # --batch_norm: batch_norm_layer after every hidden ReLU (DIN.py:203-204, DeepCvrMTL.py:177-178)
+    batch_norm_decay: float = 0.9
 
     @property
     def n_slots(self) -> int:
@@ -69,6 +71,9 @@ def param_shapes(cfg: Config) -> Dict[str, tuple]:
         for i, h in enumerate(cfg.deep_layers):
             shp[f"{t}mlp{i}/weights"] = (d, h)
             shp[f"{t}mlp{i}/biases"] = (h,)
+            if cfg.batch_norm:           # scopes bn_%d (DIN.py:204) / cvr_bn_%d, ctr_bn_%d (DeepCvrMTL.py:178,199)
+                for nm in ("beta", "gamma", "moving_mean", "moving_variance"):
+                    shp[f"{t}bn_{i}/{nm}"] = (h,)
             d = h
         out = f"{t}out" if t else "deep_out"
         shp[f"{out}/weights"] = (d, 1)
@@ -86,7 +91,11 @@ def param_shapes(cfg: Config) -> Dict[str, tuple]:
 
 def init_params(cfg: Config, seed: int = 0, scale: float = 0.05) -> Dict[str, torch.Tensor]:
     g = torch.Generator().manual_seed(seed)
-    return {n: (torch.randn(s, generator=g) * scale).to(torch.float32) for n, s in param_shapes(cfg).items()}
+    p = {n: (torch.randn(s, generator=g) * scale).to(torch.float32) for n, s in param_shapes(cfg).items()}
+    for n in p:                          # gamma / moving_variance around one, as a trained model would hold them
+        if n.endswith(("gamma", "moving_variance")):
+            p[n] = 1.0 + p[n].abs()
+    return p
 
 
 def _lookup_sparse(E, offsets, ids, vals):
@@ -141,9 +150,26 @@ def embed(cfg: Config, p, batch, train: bool = False, masks=None) -> torch.Tenso
     return torch.cat(parts, dim=1)
 
 
-def _tower(cfg: Config, p, x, prefix, train, masks):
+def _bn(cfg: Config, p, x, scope, train, new_stats):
+    """contrib.layers.batch_norm(decay, center, scale, eps=1e-3), moving averages updated in place in TRAIN [TF-1.4]
+    (batch_norm_layer, DIN.py:254-258)."""
+    g, bt, mm, mv = (p[f"{scope}/{n}"] for n in ("gamma", "beta", "moving_mean", "moving_variance"))
+    if train:
+        mean, var = x.mean(0), x.var(0, unbiased=False)
+        d = cfg.batch_norm_decay
+        new_stats[f"{scope}/moving_mean"] = d * mm + (1 - d) * mean.detach()
+        new_stats[f"{scope}/moving_variance"] = d * mv + (1 - d) * var.detach()
+    else:
+        mean, var = mm, mv
+    return (x - mean) / torch.sqrt(var + 1e-3) * g + bt
+
+
+def _tower(cfg: Config, p, x, prefix, train, masks, new_stats=None):
+    new_stats = {} if new_stats is None else new_stats
     for i in range(len(cfg.deep_layers)):
         x = _fc(x, p[f"{prefix}mlp{i}/weights"], p[f"{prefix}mlp{i}/biases"])
+        if cfg.batch_norm:
+            x = _bn(cfg, p, x, f"{prefix}bn_{i}", train, new_stats)
         x = _dropout(x, cfg.dropout[i], train, masks, f"{prefix}mlp{i}")
     out = f"{prefix}out" if prefix else "deep_out"
     return _fc(x, p[f"{out}/weights"], p[f"{out}/biases"], relu=False).reshape(-1)
@@ -151,13 +177,14 @@ def _tower(cfg: Config, p, x, prefix, train, masks):
 
 def forward(cfg: Config, p, batch, train: bool = False, masks=None):
     x = embed(cfg, p, batch, train, masks)
+    ns: Dict[str, torch.Tensor] = {}
     if cfg.model == "din":
-        y = _tower(cfg, p, x, "", train, masks)                      # DIN.py:200-210
-        return {"x": x, "y": y, "prob": torch.sigmoid(y)}
-    y_cvr = _tower(cfg, p, x, "cvr_", train, masks)                  # DeepCvrMTL.py:167-184
-    y_ctr = _tower(cfg, p, x, "ctr_", train, masks)                  # DeepCvrMTL.py:186-205
+        y = _tower(cfg, p, x, "", train, masks, ns)                  # DIN.py:200-210
+        return {"x": x, "y": y, "prob": torch.sigmoid(y), "_new_stats": ns}
+    y_cvr = _tower(cfg, p, x, "cvr_", train, masks, ns)              # DeepCvrMTL.py:167-184
+    y_ctr = _tower(cfg, p, x, "ctr_", train, masks, ns)              # DeepCvrMTL.py:186-205
     pctr, pcvr = torch.sigmoid(y_ctr), torch.sigmoid(y_cvr)          # DeepCvrMTL.py:207-210
-    return {"x": x, "y_ctr": y_ctr, "y_cvr": y_cvr, "pctr": pctr, "pcvr": pcvr, "pctcvr": pctr * pcvr}
+    return {"x": x, "y_ctr": y_ctr, "y_cvr": y_cvr, "pctr": pctr, "pcvr": pcvr, "pctcvr": pctr * pcvr, "_new_stats": ns}
 
 
 def _xent(y, z):
@@ -178,16 +205,20 @@ def loss_fn(cfg: Config, p, out, batch):
 
 
 def grads(cfg: Config, p, batch, train=True, masks=None):
-    names = list(p)
+    names = [n for n in p if not n.endswith(("moving_mean", "moving_variance"))]
     leaves = {n: p[n].detach().clone().requires_grad_(True) for n in names}
-    out = forward(cfg, leaves, batch, train=train, masks=masks)
-    loss = loss_fn(cfg, leaves, out, batch)
+    q = dict(p)
+    q.update(leaves)
+    out = forward(cfg, q, batch, train=train, masks=masks)
+    loss = loss_fn(cfg, q, out, batch)
     gs = torch.autograd.grad(loss, [leaves[n] for n in names])
     return loss.detach(), dict(zip(names, gs)), out
 
 
 def train_step(cfg: Config, p, opt: Optimizer, batch, masks=None):
     loss, g, out = grads(cfg, p, batch, train=True, masks=masks)
+    for k, v in out["_new_stats"].items():
+        p[k] = v
     opt.step(p, g)
     return float(loss), out
 

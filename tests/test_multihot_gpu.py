@@ -187,3 +187,41 @@ def test_din_attention_pooling_train_steps(opt, dev):
         diff = np.abs(got[name] - ref.numpy()).max()
         assert diff <= 3e-6, (name, diff)
     eng.close()
+
+
+@pytest.mark.parametrize("model", ["din", "esmm"])
+@pytest.mark.parametrize("opt", ["Momentum", "Adagrad"])
+def test_batch_norm_towers_match_oracle(model, opt, dev):
+    """--batch_norm=True: batch_norm_layer after every hidden ReLU of the tower(s) (DIN.py:203-204, DeepCvrMTL.py:177-178,198-199):
+    batch statistics + in-place moving averages in TRAIN, moving statistics in PREDICT.  (Adam is left out as for the other BN
+    tests: the bias gradients are exactly zero in exact arithmetic and Adam amplifies their rounding noise.)"""
+    B = 64
+    layers = (32, 16)
+    ocfg = M.Config(model=model, field_size=6, feature_size=800, embedding_size=8, deep_layers=layers, dropout=(1.0, 1.0), l2_reg=1e-3,
+                    learning_rate=1e-2, optimizer=opt, ctr_task_wgt=0.4, batch_norm=True, batch_norm_decay=0.9)
+    ecfg = EngineConfig(model=model, field_size=ocfg.n_slots, feature_size=800, embedding_size=8, deep_layers=layers, dropout=(1.0, 1.0),
+                        l2_reg=1e-3, learning_rate=1e-2, optimizer=opt, max_batch=B, max_entries=B * (ocfg.n_slots + 40), ctr_task_wgt=0.4,
+                        batch_norm=True, batch_norm_decay=0.9)
+    params = M.init_params(ocfg, seed=5)
+    eng = Engine(ecfg)
+    eng.set_params(params)
+    oopt = M.Optimizer(ocfg, params)
+    for step in range(3):
+        batch = M.synth_batch(ocfg, B, seed=120 + step)
+        ref_loss, _ = M.train_step(ocfg, params, oopt, batch)
+        off, ids, wts, y, z = dev_csr(ocfg, batch, dev)
+        loss = eng.train_step_csr(off, ids, wts, y, z if model == "esmm" else None)
+        assert abs(loss - ref_loss) <= 2e-5 * max(1.0, abs(ref_loss)), (step, loss, ref_loss)
+    got = eng.get_params()
+    for name, ref in params.items():
+        diff = np.abs(got[name] - ref.numpy()).max()
+        assert diff <= 2e-5, (name, diff)                 # tolerance of the other batch_norm tests
+    batch = M.synth_batch(ocfg, B, seed=7)
+    ref = M.forward(ocfg, params, batch)                   # PREDICT: moving statistics
+    off, ids, wts, _, _ = dev_csr(ocfg, batch, dev)
+    o = [torch.empty(B, device=dev) for _ in range(3)]
+    eng.predict_csr(off, ids, wts, B, *o)
+    torch.cuda.synchronize()
+    key = "prob" if model == "din" else "pctr"
+    assert np.abs(o[0].cpu().numpy() - ref[key].numpy()).max() <= 2e-5
+    eng.close()

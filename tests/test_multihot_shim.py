@@ -52,6 +52,11 @@ def test_reference_din_and_esmm_scripts_lower_onto_the_engine():
     assert low.name_map["mlp1/biases"] == "MLP-layer/mlp1/biases"
     assert pipe.tfrecord and [(s.ids_feature, s.vals_feature, s.fixed_len) for s in pipe.slot_specs] == SLOTS
 
+    shim.FLAGS_MODULE.FLAGS.batch_norm = True              # --batch_norm=True: bn_%d after every hidden ReLU (DIN.py:203-204)
+    est, (spec, low, pipe, variables) = _trace(mod.model_fn, fn, PARAMS)
+    assert low.config_kwargs["batch_norm"] is True and low.config_kwargs["batch_norm_decay"] == 0.9
+    assert low.name_map["bn_1/moving_variance"] == "MLP-layer/bn_1/moving_variance" and low.config_kwargs["dropout"] == (0.5, 0.5)
+
     mod = load_reference_module(REF_ESMM)
     shim.FLAGS_MODULE.FLAGS.field_size = 11
     fn = lambda: mod.input_fn(["/tmp/none.tfrecord"], num_epochs=1, batch_size=256)
@@ -62,6 +67,11 @@ def test_reference_din_and_esmm_scripts_lower_onto_the_engine():
     assert low.name_map["cvr_mlp0/weights"] == "cvr_mlp0/weights" and low.name_map["ctr_out/biases"] == "ctr_out/biases"
     est, (spec, low, pipe, variables) = _trace(mod.model_fn, fn, PARAMS, "eval")
     assert est._metric_outputs(spec, low) == {"CTR_AUC": 0, "CVR_AUC": 1, "CTCVR_AUC": 2}
+    shim.FLAGS_MODULE.FLAGS.batch_norm = True              # scopes cvr_bn_%d / ctr_bn_%d (DeepCvrMTL.py:178,199)
+    est, (spec, low, pipe, variables) = _trace(mod.model_fn, fn, PARAMS)
+    assert low.config_kwargs["batch_norm"] is True and low.name_map["cvr_bn_0/gamma"] == "cvr_bn_0/gamma"
+    assert low.name_map["ctr_bn_1/moving_mean"] == "ctr_bn_1/moving_mean"
+    shim.FLAGS_MODULE.FLAGS.batch_norm = False
     with pytest.raises(TypeError):           # PREDICT passes labels=None and the script indexes labels['y'] (DeepCvrMTL.py:146): as in TF
         _trace(mod.model_fn, fn, PARAMS, "infer")
 

@@ -119,7 +119,7 @@ struct dctr_engine {
     int64_t max_entries = 0;
     int32_t* entry_off = nullptr;    // [max_entries] float4 offset of every entry's slot in x_in / dx_in
     std::vector<Fc> mlp2;
-    std::vector<float*> h2, dh2;
+    std::vector<float*> h2, dh2, hbn2, bn_stats2;
     int p_out2_w = -1, p_out2_b = -1;
     float *dx_in2 = nullptr, *dy2 = nullptr, *y2 = nullptr, *prob2 = nullptr, *prob3 = nullptr;
     // DIN attention pooling (din_att.hip): the attention MLP is the *2 tower, run over the batch's nnz entry rows

@@ -90,12 +90,13 @@ int build(dctr_engine* E) {
     DCTR_REQUIRE(c.model >= DCTR_MODEL_DEEPFM && c.model <= DCTR_MODEL_ESMM, "unknown model %d", c.model);
     E->csr = c.model == DCTR_MODEL_DIN || c.model == DCTR_MODEL_ESMM;
     if (E->csr) {
-        DCTR_REQUIRE(c.batch_norm == 0, "batch_norm is not implemented for the CSR models");
         DCTR_REQUIRE(c.shard_world == 1, "the CSR models are not row-sharded");
         DCTR_REQUIRE(c.max_entries >= 0, "max_entries must be >= 0");
         DCTR_REQUIRE(c.model != DCTR_MODEL_ESMM || (c.ctr_task_wgt >= 0.f && c.ctr_task_wgt <= 1.f), "ctr_task_wgt must be in [0,1]");
         E->max_entries = c.max_entries > 0 ? c.max_entries : (int64_t)c.max_batch * c.field_size * 8;
         E->att_on = c.model == DCTR_MODEL_DIN && c.n_att_pairs > 0;
+        // (DIN.py:165 applies batch_norm_layer inside attention_unit with an undefined `train_phase`: a NameError in the script)
+        DCTR_REQUIRE(!(E->att_on && c.batch_norm), "batch_norm together with DIN attention pooling is not implemented");
         if (E->att_on) {
             DCTR_REQUIRE(c.n_att_pairs <= 8, "at most 8 attention pairs");
             DCTR_REQUIRE(c.n_attention_layers >= 1 && c.n_attention_layers <= DCTR_MAX_LAYERS, "attention pooling needs 1..%d attention layers", DCTR_MAX_LAYERS);
@@ -128,7 +129,8 @@ int build(dctr_engine* E) {
     DCTR_REQUIRE(c.shard_world >= 1 && c.shard_rank >= 0 && c.shard_rank < c.shard_world, "bad shard rank/world");
     E->bn = c.batch_norm != 0;
     if (E->bn) {
-        DCTR_REQUIRE(c.model != DCTR_MODEL_AFM && c.model < DCTR_MODEL_WIDE, "batch_norm is implemented for the MLP-family models");
+        DCTR_REQUIRE(c.model != DCTR_MODEL_AFM && (c.model < DCTR_MODEL_WIDE || E->csr),
+                     "batch_norm is implemented for the MLP-family models");
         DCTR_REQUIRE(c.shard_world == 1, "batch_norm with row-sharded tables would need synchronised statistics: not implemented");
         DCTR_REQUIRE(c.batch_norm_decay >= 0.f && c.batch_norm_decay <= 1.f, "batch_norm_decay must be in [0,1]");
     }
@@ -179,10 +181,11 @@ int build(dctr_engine* E) {
             fc.b = add_param(E, nm, {fc.out}, false, fc.splits, 0.f);
             fc.last = fc.b;
             if (E->bn) {        // variable names of contrib.layers.batch_norm under scope bn_%d (DeepFM.py:160,231-235)
-                snprintf(nm, sizeof(nm), "bn_%d/beta", i);            fc.bn_beta = add_param(E, nm, {fc.out}, false, 1, 0.f);
-                snprintf(nm, sizeof(nm), "bn_%d/gamma", i);           fc.bn_gamma = add_param(E, nm, {fc.out}, false, 1, 0.f);
-                snprintf(nm, sizeof(nm), "bn_%d/moving_mean", i);     fc.bn_mm = add_param(E, nm, {fc.out}, false, 1, 0.f);
-                snprintf(nm, sizeof(nm), "bn_%d/moving_variance", i); fc.bn_mv = add_param(E, nm, {fc.out}, false, 1, 0.f);
+                // (ESMM: scopes cvr_bn_%d / ctr_bn_%d, DeepCvrMTL.py:178,199)
+                snprintf(nm, sizeof(nm), "%sbn_%d/beta", tower_prefix[t], i);            fc.bn_beta = add_param(E, nm, {fc.out}, false, 1, 0.f);
+                snprintf(nm, sizeof(nm), "%sbn_%d/gamma", tower_prefix[t], i);           fc.bn_gamma = add_param(E, nm, {fc.out}, false, 1, 0.f);
+                snprintf(nm, sizeof(nm), "%sbn_%d/moving_mean", tower_prefix[t], i);     fc.bn_mm = add_param(E, nm, {fc.out}, false, 1, 0.f);
+                snprintf(nm, sizeof(nm), "%sbn_%d/moving_variance", tower_prefix[t], i); fc.bn_mv = add_param(E, nm, {fc.out}, false, 1, 0.f);
                 E->params[fc.bn_mm].frozen = E->params[fc.bn_mv].frozen = true;
                 fc.last = fc.bn_mv;
             }
@@ -404,6 +407,12 @@ int build(dctr_engine* E) {
         DCTR_TRY(dmalloc(&a, (rows2 + GEMM_SLACK_ROWS) * fc.out));
         DCTR_TRY(dmalloc(&g, (rows2 + GEMM_SLACK_ROWS) * fc.out));
         E->h2.push_back(a); E->dh2.push_back(g);
+        if (E->bn && !E->att_on) {
+            float *z = nullptr, *sx = nullptr;
+            DCTR_TRY(dmalloc(&z, (rows2 + GEMM_SLACK_ROWS) * fc.out));
+            DCTR_TRY(dmalloc(&sx, (size_t)2 * fc.out));
+            E->hbn2.push_back(z); E->bn_stats2.push_back(sx);
+        }
     }
     if (E->att_on) {
         E->x_att_ld = 3 * K;
@@ -431,6 +440,7 @@ int build(dctr_engine* E) {
     if (E->bn) {
         int hmax = 0;
         for (auto& fc : E->mlp) hmax = std::max(hmax, fc.out);
+        for (auto& fc : E->mlp2) hmax = std::max(hmax, fc.out);
         DCTR_TRY(dmalloc(&E->bn_scratch, (size_t)bn_scratch_floats(hmax)));
     }
     if (mvm) {
@@ -905,6 +915,8 @@ int dctr_destroy(dctr_handle E) {
     for (auto& ev : E->timer_ev) if (ev) hipEventDestroy(ev);
     for (float* p : E->hbn) hipFree(p);
     for (float* p : E->bn_stats) hipFree(p);
+    for (float* p : E->hbn2) hipFree(p);
+    for (float* p : E->bn_stats2) hipFree(p);
     if (E->bn_scratch) hipFree(E->bn_scratch);
     group_destroy(E->group);
     afm_free(E);
@@ -1018,6 +1030,8 @@ void swap_tower(dctr_engine* E) {
     std::swap(E->mlp, E->mlp2);
     std::swap(E->h, E->h2);
     std::swap(E->dh, E->dh2);
+    std::swap(E->hbn, E->hbn2);
+    std::swap(E->bn_stats, E->bn_stats2);
     std::swap(E->p_out_w, E->p_out2_w);
     std::swap(E->p_out_b, E->p_out2_b);
     std::swap(E->dy, E->dy2);
@@ -1066,8 +1080,8 @@ int csr_forward(dctr_engine* E, const int32_t* off, const int32_t* ids, const fl
     int rc = forward_rest(E, B, train, st);
     swap_tower(E);
     DCTR_TRY(rc);
-    return esmm_head(E->h.back(), E->mlp.back().out, E->pp(E->p_out_w), E->pp(E->p_out_b), E->mlp.back().out, E->h2.back(),
-                     E->mlp2.back().out, E->pp(E->p_out2_w), E->pp(E->p_out2_b), E->mlp2.back().out, y, z, B, 1.0f / (float)B,
+    return esmm_head(E->bn ? E->hbn.back() : E->h.back(), E->mlp.back().out, E->pp(E->p_out_w), E->pp(E->p_out_b), E->mlp.back().out,
+                     E->bn ? E->hbn2.back() : E->h2.back(), E->mlp2.back().out, E->pp(E->p_out2_w), E->pp(E->p_out2_b), E->mlp2.back().out, y, z, B, 1.0f / (float)B,
                      c.ctr_task_wgt, E->y, E->y2, E->prob, E->prob2, E->prob3, E->dy, E->dy2, loss_shards, st);
 }
 

@@ -239,8 +239,7 @@ def _lower_multihot(loss, train_op, predictions, nodes, by_op) -> Lowered:
     """DIN with field-wise sum pooling (DIN.py:143-148,179-222) and ESMM (DeepCvrMTL.py:153-225): one shared embedding table,
     the MLP input = concat of [reshape(lookup(E, fixed ids [F'])) | lookup_sparse(E, ids, weights) ... | lookup(E, scalar id) ...],
     one tower + sigmoid xent (DIN) or a CTR and a CVR tower with the pCTCVR log-loss (ESMM)."""
-    if by_op.get("batch_norm"):
-        raise _unsupported("batch_norm=True is not implemented for the DIN / ESMM graphs")
+    bn_ops = by_op.get("batch_norm", [])
     fcs = by_op.get("fully_connected", [])
     att_outs = [f for f in fcs if f.attrs["activation"] == "sigmoid"]            # att_out of the attention units (DIN.py:168)
     hidden = [f for f in fcs if f.attrs["activation"] == "relu"]
@@ -317,18 +316,18 @@ def _lower_multihot(loss, train_op, predictions, nodes, by_op) -> Lowered:
     def chain(out_fc):
         """hidden layers from the concat to this output layer"""
         layers = []
-        t = _through(out_fc.inputs[0], ops=("reshape", "identity", "dropout"))
+        t = _through(out_fc.inputs[0], ops=("reshape", "identity", "dropout", "batch_norm"))
         while t is not xcat:
             if t.op != "fully_connected" or t.attrs["activation"] != "relu":
                 raise _unsupported("tower contains %s" % t.op)
             layers.append(t)
-            t = _through(t.inputs[0], ops=("reshape", "identity", "dropout"))
+            t = _through(t.inputs[0], ops=("reshape", "identity", "dropout", "batch_norm"))
         return layers[::-1]
 
     if any(int(o.attrs["num_outputs"]) != 1 for o in outs):
         raise _unsupported("output layers must have width 1")
     xents = by_op.get("sigmoid_xent", [])
-    keep_of = {id(_through(d.inputs[0])): d.attrs["keep_prob"] for d in by_op.get("dropout", [])}
+    keep_of = {id(_through(d.inputs[0], ops=("reshape", "identity", "cast", "batch_norm"))): d.attrs["keep_prob"] for d in by_op.get("dropout", [])}
     kw: Dict = dict(field_size=S, feature_size=V, embedding_size=K)
     outputs: Dict[str, int] = {}
     if len(outs) == 1:
@@ -362,6 +361,7 @@ def _lower_multihot(loss, train_op, predictions, nodes, by_op) -> Lowered:
     else:
         raise _unsupported("%d output layers" % len(outs))
     keep = None
+    bn_decays = set()
     for prefix, oname, layers, out in towers:
         for i, f in enumerate(layers):
             name_map["%smlp%d/weights" % (prefix, i)], name_map["%smlp%d/biases" % (prefix, i)] = f.inputs[1].var_name, f.inputs[2].var_name
@@ -370,6 +370,24 @@ def _lower_multihot(loss, train_op, predictions, nodes, by_op) -> Lowered:
         if keep is not None and k2 != keep:
             raise _unsupported("the towers use different dropout keep_probs")
         keep = k2
+        if bn_ops:
+            # batch_norm_layer(x, train_phase, scope_bn) after every hidden ReLU of the tower (DIN.py:203-204, DeepCvrMTL.py:177-178)
+            if units:
+                raise _unsupported("batch_norm together with attention pooling (DIN.py:165 uses an undefined train_phase there)")
+            for i, f in enumerate(layers):
+                mine = [b for b in bn_ops if _through(b.inputs[0]) is f]
+                if len(mine) != 1:
+                    raise _unsupported("expected one batch_norm on the output of %smlp%d" % (prefix, i))
+                b = mine[0]
+                if not (b.attrs["center"] and b.attrs["scale"]) or abs(b.attrs["epsilon"] - 1e-3) > 1e-12:
+                    raise _unsupported("batch_norm must use center=True, scale=True, epsilon=0.001")
+                bn_decays.add(float(b.attrs["decay"]))
+                for nm, v in zip(("beta", "gamma", "moving_mean", "moving_variance"), b.inputs[1:]):
+                    name_map["%sbn_%d/%s" % (prefix, i, nm)] = v.var_name
+    if bn_ops:
+        if len(bn_decays) != 1:
+            raise _unsupported("batch_norm layers with different decays")
+        kw["batch_norm"], kw["batch_norm_decay"] = True, bn_decays.pop()
     kw.update(model=model, deep_layers=tuple(int(f.attrs["num_outputs"]) for f in towers[0][2]), dropout=keep)
     if units:
         if model != "din":
