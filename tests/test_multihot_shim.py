@@ -157,3 +157,42 @@ def test_estimator_over_tfrecords_matches_oracle(task, tmp_path, dev):
         got = np.array([d[key[2]] for d in preds])
         want = np.concatenate([o[key[2]].numpy() for o in outs])
         assert np.abs(got - want).max() <= 1e-5, key
+
+
+REF_TFR = "/root/reference/DeepMTL/Feature_pipeline/get_tfrecord.py"
+
+
+@pytest.mark.skipif(not os.path.isfile(REF_TFR), reason="reference tree not present (GPU box)")
+def test_reference_tfrecord_writer_feeds_the_c_parser(tmp_path):
+    """Feature_pipeline/get_tfrecord.py (tf.python_io.TFRecordWriter + tf.train.Example, run unchanged under the shim) writes the
+    joined Ali-CCP sample lines as TFRecords; the C parser reads them back in the slot layout of DIN.py."""
+    from tf_repos_amd.run_reference import load_reference_module
+    from tf_repos_amd import tfrecord as T
+    import tf_repos_amd.tf_shim as shim
+    mod = load_reference_module(REF_TFR)
+    # two sample lines in the format of get_tfrecord.py:43: sample_id,y,z,"field:id:value ..."
+    lines = ["40362692,0,0,216:9342395:1.0 301:9351665:1.0 205:7702673:1.0 206:8317829:1.0 207:8967741:1.0 508:9356012:2.30259 "
+             "210:9059239:1.0 210:9042796:1.0 210:9076972:1.0 127_14:3529789:2.3979 127_14:3806412:2.70805",
+             "40362693,1,1,101:11:1.0 121:12:1.0 109_14:500:0.5 109_14:501:1.5 110_14:600:2.0 150_14:700:1.0 206:801:1.0 216:901:1.0"]
+    src = tmp_path / "part-00000"
+    src.write_text("\n".join(lines) + "\nmalformed,line\n")
+    shim.FLAGS_MODULE.FLAGS.output_dir = str(tmp_path)
+    mod.gen_tfrecords(str(src))
+    buf = (tmp_path / "part-00000.tfrecord").read_bytes()
+    specs = [T.SlotSpec("feat_ids", None, 11), T.SlotSpec("u_catids", "u_catvals"), T.SlotSpec("u_shopids", "u_shopvals"),
+             T.SlotSpec("u_brandids", "u_brandvals"), T.SlotSpec("u_intids", "u_intvals"), T.SlotSpec("a_catids", None, 0),
+             T.SlotSpec("a_shopids", None, 0), T.SlotSpec("a_brandids", None, 0), T.SlotSpec("a_intids", None, -1)]
+    off, ids, wts, labels = T.parse_slot_csr(buf, specs, ["y", "z"], 10_000_000)
+    assert labels.tolist() == [[0.0, 1.0], [0.0, 1.0]] and len(off) == 2 * 19 + 1
+    S = 19
+    slot = lambda b, s: (ids[off[b * S + s]:off[b * S + s + 1]].tolist(), wts[off[b * S + s]:off[b * S + s + 1]].tolist())
+    # example 0: common fields 205 / 301 present, the others take their default ids 1..11 (get_tfrecord.py:34,64-70)
+    common0 = [slot(0, s)[0][0] for s in range(11)]
+    assert sorted(common0) == sorted([1, 2, 3, 4, 5, 6, 7, 8, 9, 7702673, 9351665])
+    assert slot(0, 13) == ([3529789, 3806412], [np.float32(2.3979), np.float32(2.70805)])        # u_brand = field 127_14 with its values
+    assert slot(0, 11) == ([12], [1.0])                                                            # u_cat absent: default id 12, weight 1
+    assert slot(0, 15)[0] == [8317829] and slot(0, 16)[0] == [8967741] and slot(0, 17)[0] == [9342395]   # a_cat 206, a_shop 207, a_brand 216
+    assert slot(0, 18)[0] == [9059239, 9042796, 9076972]                                           # a_int = field 210, multi-hot
+    # example 1
+    assert slot(1, 11) == ([500, 501], [0.5, 1.5]) and slot(1, 12) == ([600], [2.0]) and slot(1, 14) == ([700], [1.0])
+    assert slot(1, 15)[0] == [801] and slot(1, 16)[0] == [17] and slot(1, 17)[0] == [901] and slot(1, 18)[0] == [18]

@@ -48,9 +48,14 @@ def build_module():
                  embedding_lookup_sparse=_g.embedding_lookup_sparse)
     layers = _mod("tensorflow.contrib.layers", fully_connected=_g.fully_connected, l2_regularizer=_g.l2_regularizer, batch_norm=_g.batch_norm)
     tf.contrib = _mod("tensorflow.contrib", layers=layers)
+    from .. import tfrecord as _tfr
     tf.train = _mod("tensorflow.train", AdamOptimizer=_g.AdamOptimizer, AdagradOptimizer=_g.AdagradOptimizer,
                     MomentumOptimizer=_g.MomentumOptimizer, FtrlOptimizer=_g.FtrlOptimizer, get_global_step=_g.get_global_step,
-                    get_or_create_global_step=_g.get_or_create_global_step)
+                    get_or_create_global_step=_g.get_or_create_global_step,
+                    # the message classes of Feature_pipeline/get_tfrecord.py:52-95
+                    Example=_tfr.Example, Features=_tfr.Features, Feature=_tfr.Feature, Int64List=_tfr.Int64List,
+                    FloatList=_tfr.FloatList, BytesList=_tfr.BytesList)
+    tf.python_io = _mod("tensorflow.python_io", TFRecordWriter=_tfr.TFRecordWriter)
     tf.metrics = _mod("tensorflow.metrics", auc=_g.metrics_auc)
     tf.data = _mod("tensorflow.data", TextLineDataset=_data.TextLineDataset, TFRecordDataset=_data.TFRecordDataset)
     export = _mod("tensorflow.estimator.export", PredictOutput=_est.PredictOutput, ServingInputReceiver=_est.ServingInputReceiver,
@@ -80,7 +85,7 @@ def install(force: bool = False):
         raise RuntimeError("a real tensorflow is already imported")
     tf = build_module()
     sys.modules["tensorflow"] = tf
-    for sub in ("nn", "contrib", "train", "metrics", "data", "estimator", "saved_model", "app", "feature_column", "losses", "summary"):
+    for sub in ("nn", "contrib", "train", "metrics", "data", "estimator", "saved_model", "app", "feature_column", "losses", "summary", "python_io"):
         sys.modules["tensorflow." + sub] = getattr(tf, sub)
     sys.modules["tensorflow.contrib.layers"] = tf.contrib.layers
     sys.modules["tensorflow.estimator.export"] = tf.estimator.export

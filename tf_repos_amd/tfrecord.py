@@ -50,6 +50,49 @@ def encode_example(features: Dict[str, Tuple[str, Sequence]]) -> bytes:
     return _ld(1, entries)
 
 
+# tf.train.{Example, Features, Feature, Int64List, FloatList, BytesList}: the message classes get_tfrecord.py:52-95 builds
+class Int64List:
+    kind = "int64"
+
+    def __init__(self, value=()):
+        self.value = [int(v) for v in value]
+
+
+class FloatList:
+    kind = "float"
+
+    def __init__(self, value=()):
+        self.value = [float(v) for v in value]
+
+
+class BytesList:
+    kind = "bytes"
+
+    def __init__(self, value=()):
+        self.value = [bytes(v) for v in value]
+
+
+class Feature:
+    def __init__(self, bytes_list=None, float_list=None, int64_list=None):
+        given = [l for l in (bytes_list, float_list, int64_list) if l is not None]
+        if len(given) > 1:
+            raise errors.InvalidArgumentError("tf.train.Feature holds exactly one of bytes_list / float_list / int64_list")
+        self.list = given[0] if given else None
+
+
+class Features:
+    def __init__(self, feature=None):
+        self.feature = dict(feature or {})
+
+
+class Example:
+    def __init__(self, features=None):
+        self.features = features or Features()
+
+    def SerializeToString(self) -> bytes:
+        return encode_example({k: (f.list.kind, f.list.value) if f.list is not None else ("bytes", []) for k, f in self.features.feature.items()})
+
+
 class TFRecordWriter:
     """tf.python_io.TFRecordWriter(path): write(serialized_example) / close()  (get_tfrecord.py:47,96,101)."""
 
