@@ -186,12 +186,19 @@ class CsvDataset:
         for _epoch in range(self.num_epochs):
             for path in self.filenames:
                 f, i = self._load(path)
-                if carry is not None:
-                    f = np.concatenate([carry[0], f]); i = np.concatenate([carry[1], i])
-                    carry = None
                 n = len(f)
-                full = n // B * B
-                for s in range(0, full, B):
+                s0 = 0
+                if carry is not None:       # only the batch that spans the file / epoch edge is assembled by copy
+                    take = min(B - len(carry[0]), n)
+                    carry = (np.concatenate([carry[0], f[:take]]), np.concatenate([carry[1], i[:take]]))
+                    s0 = take
+                    if len(carry[0]) == B:
+                        yield carry
+                        carry = None
+                    else:
+                        continue
+                full = s0 + (n - s0) // B * B
+                for s in range(s0, full, B):
                     yield f[s:s + B], i[s:s + B]
                 if full < n:
                     carry = (f[full:], i[full:])
