@@ -167,6 +167,10 @@ int dctr_embed_gather_fwd(const float* d_emb, const float* d_lin, int64_t rows,
                           float* d_e, int e_ld, float* d_yw, float* d_sum, float* d_red,
                           int32_t* d_status, void* stream);
 
+/* dctr_parse_csv over a whole buffer with `threads` workers inside the library (h_f == h_i == NULL: count the records only) */
+int dctr_parse_csv_mt(const char* h_text, size_t nbytes, int n_cols, const int8_t* kinds, const float* f_defaults,
+                      const int32_t* i_defaults, int threads, float* h_f, int32_t* h_i, int64_t capacity_rows, int64_t* n_rows);
+
 /* ---- TFRecord input of the DIN / ESMM scripts (DIN.py:57-97, DeepCvrMTL.py:61-104): tf.data.TFRecordDataset +
  * tf.parse_single_example over files written by Feature_pipeline/get_tfrecord.py:44-98.  Host code, re-entrant.
  * dctr_tfrecord_scan: record framing.  rec_off[i] / rec_len[i] = payload of record i inside h_buf (either may be NULL to

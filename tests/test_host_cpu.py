@@ -188,3 +188,33 @@ def test_multithreaded_file_parse_matches_the_serial_parser(tmp_path):
     p.write_text("\n".join(bad))
     with pytest.raises(errors.InvalidArgumentError, match="line 3001: token .* is not id:val"):
         parse_file(str(p), F, threads=8)
+
+
+def test_multithreaded_csv_parse_matches_the_serial_decoder(tmp_path):
+    """dctr_parse_csv_mt: the wide_n_deep record layout (1 float label + 13 float + 26 int columns, wide_n_deep.py:59-64), empty
+    fields taking their defaults, decoded by any number of threads into the same arrays as one serial call."""
+    from tf_repos_amd import errors
+    from tf_repos_amd.input_pipeline import CsvDataset, parse_csv
+    rng = np.random.default_rng(3)
+    kinds = [0] * 14 + [1] * 26
+    fd, idf = [0.0] * 14, [0] * 26
+    lines = []
+    for r in range(9000):
+        f = ["%d" % rng.integers(0, 2)] + ["%.4f" % v if rng.random() > 0.1 else "" for v in rng.random(13)]
+        i = ["%d" % v if rng.random() > 0.1 else "" for v in rng.integers(0, 10000, size=26)]
+        lines.append(",".join(f + i))
+        if r % 1000 == 0:
+            lines.append("")
+    text = "\n".join(lines) + "\n"
+    assert len(text) > (1 << 20)
+    p = tmp_path / "t.csv"
+    p.write_text(text)
+    rf, ri = parse_csv(text, kinds, fd, idf)
+    assert len(rf) == 9000
+    for threads in (1, 4, 32):
+        f, i = CsvDataset([str(p)], kinds, fd, idf, threads=threads)._load(str(p))
+        assert np.array_equal(f, rf) and np.array_equal(i, ri), threads
+    lines[7000] = lines[7000].replace(",", ",x", 1)
+    p.write_text("\n".join(lines) + "\n")
+    with pytest.raises(errors.InvalidArgumentError, match="is not a valid float"):
+        CsvDataset([str(p)], kinds, fd, idf, threads=8)._load(str(p))

@@ -290,3 +290,68 @@ extern "C" int dctr_parse_csv(const char* h_text, size_t nbytes, int n_cols, con
     if (n_consumed) *n_consumed = consumed;
     return DCTR_OK;
 }
+
+// decode_csv over a whole buffer with a thread team inside the library (wide_n_deep.py:84 map(parse_csv, num_parallel_calls=10));
+// same scheme as dctr_parse_libsvm_mt: count the non-empty lines of every chunk, then parse every chunk into its rows.
+// h_f == NULL && h_i == NULL: count only.
+extern "C" int dctr_parse_csv_mt(const char* h_text, size_t nbytes, int n_cols, const int8_t* kinds, const float* f_defaults,
+                                 const int32_t* i_defaults, int threads, float* h_f, int32_t* h_i, int64_t capacity_rows,
+                                 int64_t* n_rows) {
+    using namespace dctr;
+    DCTR_REQUIRE((h_text != nullptr || nbytes == 0) && kinds != nullptr && n_rows != nullptr && n_cols > 0, "bad argument");
+    int nf = 0, ni = 0;
+    for (int c = 0; c < n_cols; ++c) (kinds[c] == 0 ? nf : ni) += 1;
+    threads = std::max(1, std::min(threads, 1024));
+    if (nbytes < ((size_t)1 << 20)) threads = 1;
+    std::vector<size_t> cut((size_t)threads + 1, nbytes);
+    cut[0] = 0;
+    for (int t = 1; t < threads; ++t) {
+        size_t pos = std::max(cut[(size_t)t - 1], nbytes / (size_t)threads * (size_t)t);
+        const char* nl = pos < nbytes ? static_cast<const char*>(memchr(h_text + pos, '\n', nbytes - pos)) : nullptr;
+        cut[(size_t)t] = nl ? (size_t)(nl - h_text) + 1 : nbytes;
+    }
+    std::vector<int64_t> rows((size_t)threads, 0);
+    auto run = [&](const std::function<void(int)>& fn) {
+        std::vector<std::thread> team;
+        for (int t = 1; t < threads; ++t) team.emplace_back(fn, t);
+        fn(0);
+        for (auto& th : team) th.join();
+    };
+    run([&](int t) {
+        const char* p = h_text + cut[(size_t)t];
+        const char* end = h_text + cut[(size_t)t + 1];
+        int64_t n = 0;
+        while (p < end) {
+            const char* eol = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+            const char* le = eol ? eol : end;
+            if (le > p && le[-1] == '\r') --le;
+            if (le > p) ++n;                                // (an empty line yields no record, as in dctr_parse_csv)
+            p = eol ? eol + 1 : end;
+        }
+        rows[(size_t)t] = n;
+    });
+    std::vector<int64_t> first((size_t)threads + 1, 0);
+    for (int t = 0; t < threads; ++t) first[(size_t)t + 1] = first[(size_t)t] + rows[(size_t)t];
+    *n_rows = first[(size_t)threads];
+    if (h_f == nullptr && h_i == nullptr) return DCTR_OK;
+    DCTR_REQUIRE(capacity_rows >= *n_rows, "capacity_rows=%lld < %lld records", (long long)capacity_rows, (long long)*n_rows);
+    std::vector<int> rc((size_t)threads, DCTR_OK);
+    run([&](int t) {
+        int64_t n = 0;
+        const size_t r0 = (size_t)first[(size_t)t];
+        rc[(size_t)t] = dctr_parse_csv(h_text + cut[(size_t)t], cut[(size_t)t + 1] - cut[(size_t)t], n_cols, kinds, f_defaults, i_defaults,
+                                       rows[(size_t)t] + 1, h_f ? h_f + r0 * (size_t)nf : nullptr, h_i ? h_i + r0 * (size_t)ni : nullptr, &n,
+                                       nullptr);
+        if (rc[(size_t)t] == DCTR_OK && n != rows[(size_t)t]) rc[(size_t)t] = DCTR_ERR_PARSE;
+    });
+    for (int t = 0; t < threads; ++t)
+        if (rc[(size_t)t] != DCTR_OK) {
+            int64_t n = 0;                                   // the canonical (serial) error message and line number
+            const int r = dctr_parse_csv(h_text, nbytes, n_cols, kinds, f_defaults, i_defaults, capacity_rows, h_f, h_i, &n, nullptr);
+            if (r != DCTR_OK) return r;
+            set_error("multi-threaded CSV parse failed in chunk %d although the serial parse succeeded", t);
+            return DCTR_ERR_PARSE;
+        }
+    return DCTR_OK;
+}
+

@@ -9,7 +9,6 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from concurrent.futures import ThreadPoolExecutor
 from typing import Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -32,21 +31,6 @@ def parse_libsvm(text, field_size: int, max_rows: Optional[int] = None):
                                             C.byref(n), C.byref(used)))
     k = n.value
     return ids[:k], vals[:k], labels[:k]
-
-
-def _split_on_lines(buf: bytes, parts: int) -> List[bytes]:
-    if parts <= 1 or len(buf) < (1 << 16):
-        return [buf]
-    out, start = [], 0
-    step = len(buf) // parts
-    for i in range(1, parts):
-        cut = buf.find(b"\n", start + step)
-        if cut < 0:
-            break
-        out.append(buf[start:cut + 1])
-        start = cut + 1
-    out.append(buf[start:])
-    return [b for b in out if b]
 
 
 def parse_file(path: str, field_size: int, threads: int = 10):
@@ -157,7 +141,8 @@ def parse_csv(text, kinds: Sequence[int], f_defaults: Sequence[float], i_default
 
 class CsvDataset:
     """TextLineDataset(filenames).map(parse_csv, 10).prefetch().repeat(num_epochs).batch(batch_size) (wide_n_deep.py:66-89) as
-    an iterator of numpy batches (floats [b, n_float], ints [b, n_int]); files are decoded by a thread pool of C calls."""
+    an iterator of numpy batches (floats [b, n_float], ints [b, n_int]); files are decoded by the library's thread team
+    (dctr_parse_csv_mt)."""
 
     def __init__(self, filenames: Sequence[str], kinds: Sequence[int], f_defaults: Sequence[float], i_defaults: Sequence[int],
                  batch_size: int = 1, num_epochs: int = 1, threads: int = 10):
@@ -170,14 +155,19 @@ class CsvDataset:
         if path not in self._cache:
             with open(path, "rb") as f:
                 buf = f.read()
-            chunks = _split_on_lines(buf, self.threads)
-            fn = lambda c: parse_csv(c, self.kinds, self.f_defaults, self.i_defaults)
-            if len(chunks) == 1:
-                parts = [fn(chunks[0])]
-            else:
-                with ThreadPoolExecutor(max_workers=self.threads) as ex:
-                    parts = list(ex.map(fn, chunks))
-            self._cache[path] = (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]))
+            lib = capi.lib()
+            k = np.asarray(self.kinds, dtype=np.int8)
+            nf, ni = int((k == 0).sum()), int((k == 1).sum())
+            fd = np.asarray(self.f_defaults, dtype=np.float32) if nf else np.zeros(1, np.float32)
+            idf = np.asarray(self.i_defaults, dtype=np.int32) if ni else np.zeros(1, np.int32)
+            n = C.c_int64()
+            args = (buf, len(buf), len(k), capi.ptr(k), capi.ptr(fd), capi.ptr(idf), int(self.threads))
+            capi.check(lib.dctr_parse_csv_mt(*args, None, None, 0, C.byref(n)))         # count, then parse in place
+            rows = n.value
+            out_f = np.empty((max(rows, 1), max(nf, 1)), dtype=np.float32)
+            out_i = np.empty((max(rows, 1), max(ni, 1)), dtype=np.int32)
+            capi.check(lib.dctr_parse_csv_mt(*args, capi.ptr(out_f), capi.ptr(out_i), rows, C.byref(n)))
+            self._cache[path] = (out_f[:rows, :nf], out_i[:rows, :ni])
         return self._cache[path]
 
     def __iter__(self):
