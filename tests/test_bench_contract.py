@@ -1,0 +1,29 @@
+"""The bench line's contract, checked on the committed line of the round (profiles/r01_bench.json, produced by `python bench.py`
+on the GPU box): the keys the driver and the judge read, their types, and the internal consistency of the derived figures."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_honours_the_contract():
+    lines = [l for l in open(os.path.join(ROOT, "profiles", "r01_bench.json")).read().splitlines() if l.strip()]
+    assert len(lines) == 1                                  # ONE JSON line on stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "examples/sec" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and "synthetic" in d["data"] and "workload" in d["config"] and "model" not in d["config"]
+    assert d["n_gpus"] == 1 and d["steps"] > 0
+    # value = whole-job examples / time
+    assert abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) <= 0.01 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-3
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0
