@@ -303,6 +303,9 @@ static int launch_gemm(const float* A, int lda, const float* B, int ldb, float* 
 // ---- public (namespace-level) entry points used by the engine -------------------------------------
 int fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N,
            int relu, float keep, const uint64_t* seed_ptr, uint64_t seed, hipStream_t st, int over) {
+    bool done = false;          // small products: the direct-to-register kernel family (gemm_dr.h) when one of its tiles fits the shape
+    DCTR_TRY(dr_fc_fwd(x, ldx, w, b, y, ldy, M, K, N, relu, keep, seed_ptr, seed, st, &done));
+    if (done) return DCTR_OK;
     Epilogue ep{};
     ep.bias = b; ep.relu = relu; ep.keep = keep; ep.seed = seed; ep.seed_ptr = seed_ptr;
     return launch_gemm<true, true, EPI_BIAS_ACT>(x, ldx, w, N, y, ldy, M, N, K, 1, ep, st, over);
@@ -311,6 +314,9 @@ int fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y, in
 int fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int K, int N,
                 const float* act, int ldact, float keep_prev, hipStream_t st, int over) {
     // dX[M,K] = dY[M,N] * W[K,N]^T : reduction over N; "B" = W^T[N,K] stored as W[K,N] => k(N)-contiguous
+    bool done = false;
+    DCTR_TRY(dr_fc_bwd_data(dy, lddy, w, dx, lddx, M, K, N, act, ldact, keep_prev, st, &done));
+    if (done) return DCTR_OK;
     Epilogue ep{};
     if (act != nullptr) {
         ep.act = act; ep.ldact = ldact; ep.inv_keep = 1.0f / keep_prev;
@@ -322,6 +328,9 @@ int fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, 
 // dW partials: out[s][K*N] for s < splits (split over the batch dimension M), db partials: outb[s][N]
 int fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int lddy, float* dw_part, int64_t dw_stride,
                             float* db_part, int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, int over) {
+    bool done = false;
+    DCTR_TRY(dr_fc_bwd_weights_partials(x, ldx, dy, lddy, dw_part, dw_stride, db_part, db_stride, M, K, N, splits, st, &done));
+    if (done) return DCTR_OK;
     Epilogue ep{};
     ep.split_stride = dw_stride;
     ep.colsum = db_part;            // db = column sums of dY, fused into the first row of tiles
@@ -349,6 +358,8 @@ int sum_partials(const float* part, int64_t stride, int splits, int64_t n, float
 }
 
 int choose_wgrad_splits(int M, int K, int N) {
+    const int dr = dr_wgrad_splits(M, K, N);      // the direct kernel's one-round split when one of its tiles fits [K, N]
+    if (dr > 0) return dr;
     const int tiles = ceil_div(K, BM) * ceil_div(N, BN);
     static const int target = getenv("DCTR_WGRAD_BLOCKS") ? atoi(getenv("DCTR_WGRAD_BLOCKS")) : 1024;    // A/B knob
     int s = ceil_div(target, tiles);               // aim at ~4 blocks per CU

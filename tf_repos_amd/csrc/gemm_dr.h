@@ -1,0 +1,442 @@
+// K6, second kernel family: "direct-to-register, wave-split-K" exact-f32 MFMA GEMM for the SMALL dense products of the CTR
+// step (4096 x 400 x 624 and friends: ~2 GFLOP, i.e. 13 us of matrix-core time -- one 80x80 output patch per CU).
+// Replaces contrib.layers.fully_connected forward (DeepFM.py:156-158,165-166) and its MatMul gradients (DeepFM.py:213) like
+// gemm.hip's LDS-tiled kernel does; the host-side chooser (gemm.hip) picks per shape.
+//
+// Why a second design.  A 64x64-tile kernel cuts 4096x400 into 448 tiles for 256 CUs (1.75 waves of tiles, N padded to 448);
+// here ONE block per CU owns a (16 TM) x (16 TN) tile chosen so that the grid is <= 256 blocks and as close to 256 as the
+// shape allows (32 x 208: 128 x 2 = 256 blocks, 26 of the 25x256/256 = 25 ideal 16x16 tiles per CU = 96 %).  The four
+// waves of a block (one per SIMD) split the REDUCTION range in four contiguous quarters; each wave owns the whole tile
+// (TM x TN accumulators of v_mfma_f32_16x16x4_f32, bitwise an fmaf chain) and streams ITS k-slices of both operands
+// straight from L2 into MFMA fragments -- no LDS staging, no barrier in the main loop, every operand element enters the
+// CU exactly once.  The four partial tiles meet in LDS at the end; the epilogue re-stages the tile row-major so that the
+// global stores are whole rows (float4 per lane).
+//
+// Fragment / k assignment.  16x16x4: lane l = (c = l & 15, q = l >> 4) supplies A[row c][k_q] and B[k_q][col c].  The order in
+// which k is consumed is free, so within a group of 16 consecutive k lane-quarter q takes k = 4 q + s at step s: an operand
+// whose reduction dimension is contiguous in memory ("RC": X[M,K] for fwd/dgrad, W[Kin,N] read as B^T for dgrad) gets its four
+// steps with ONE 16-byte load per lane; the other layout ("NC": W[K,N] for fwd, X and dY for wgrad) takes one dword per step,
+// 16 lanes = 64 contiguous bytes.  All loads are buffer loads: the 15-20 lane offsets are computed once, the per-group part
+// is a scalar offset, so the main loop has no address arithmetic at all; num_records is the true end of the operand, so whatever
+// a clamped tail read or an empty wave addresses beyond it comes back as 0.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <type_traits>
+
+#ifdef DR_STAMPS            // tools/gemm_dr_probe.hip only: cycle stamps per wave at the phase boundaries
+#define DR_STAMP(i) do { if (lane == 0) dr_stamps[((blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+extern __device__ long long dr_stamps[];
+#else
+#define DR_STAMP(i) do { } while (0)
+#endif
+
+namespace dctr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+enum { DR_STORE = 0, DR_BIAS_ACT = 1, DR_MASK = 2 };
+
+struct DrEpilogue {
+    const float* bias;          // DR_BIAS_ACT: [N] or null
+    int relu;
+    float keep;                 // dropout keep_prob of this layer (1 = off)
+    uint64_t seed;
+    const uint64_t* seed_ptr;   // per-step seed in device memory (graph replay), may be null
+    const float* act;           // DR_MASK: stored output of the producing layer (ReLU mask), row stride ldact
+    int ldact;
+    float inv_keep;
+    int64_t split_stride;       // DR_STORE with gridDim.y > 1: C + y * split_stride
+    float* colsum;              // wgrad: column sums of B (= dY) over this block's reduction range -> colsum[y * colsum_stride + n]
+    int64_t colsum_stride;
+};
+
+__device__ __forceinline__ float dr_dropout_scale(uint64_t seed, uint64_t idx, float keep);   // = dropout_scale of common.h (defined by the includer)
+
+// Row / column of the tile that MFMA output row rho (= A-fragment lane) of A tile i / output column c (= B-fragment lane) of B
+// tile j stands for.  An operand whose NON-reduction dimension is contiguous ("NC") is loaded with one dwordx4 (dwordx2) per
+// lane along that dimension: lane c then holds one element of 4 (2) different 16-wide tiles, i.e. tile j = 4 jj + e covers the
+// columns 64 jj + 4 c + e.  Which columns a tile covers is free -- only the epilogue needs to know.
+template <int TN, bool B_RC>
+__device__ __forceinline__ constexpr int dr_col(int j, int c) {
+    constexpr int TQ = B_RC ? 0 : TN / 4;
+    return j < 4 * TQ ? 64 * (j / 4) + 4 * c + (j % 4) : 64 * TQ + 16 * (j - 4 * TQ) + c;
+}
+template <int TM, bool A_RC>
+__device__ __forceinline__ constexpr int dr_row(int i, int rho) {
+    constexpr int VA = A_RC ? 1 : (TM % 4 == 0 ? 4 : (TM % 2 == 0 ? 2 : 1));
+    return VA == 1 ? 16 * i + rho : 16 * VA * (i / VA) + VA * rho + (i % VA);
+}
+// reduction unit of tile (i,j): the four tiles of a quad stay together (their stage write is one b128)
+template <int TN, bool B_RC>
+__device__ __forceinline__ constexpr int dr_owner(int i, int j) {
+    constexpr int TQ = B_RC ? 0 : TN / 4;
+    constexpr int UPR = TQ + (TN - 4 * TQ);
+    return (i * UPR + (j < 4 * TQ ? j / 4 : TQ + (j - 4 * TQ))) & 3;
+}
+
+// Cross-wave reduction of the four partial tiles + row-major staging, for wave W (compile-time, so that every register index is
+// static and the LDS reads of all owned tiles are issued together).  The non-owners dump their registers as
+// [tile][src][lane] float4 (conflict-free b128); the owner adds them to its own and writes the result into the
+// [16 TM][16 TN + 4] row-major stage that aliases the slots (hence the barrier in between).
+template <int TM, int TN, bool A_RC, bool B_RC, int W>
+__device__ __forceinline__ void dr_reduce_tiles(f32x4 (&acc)[TM][TN], float* lds, int lane) {
+    constexpr int LDS_ = 16 * TN + 4;
+    constexpr int TQ = B_RC ? 0 : TN / 4;
+    f32x4* slots = reinterpret_cast<f32x4*>(lds);
+    const int c = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int tid = i * TN + j, owner = dr_owner<TN, B_RC>(i, j);
+            if (owner != W) slots[tid * 192 + ((W - owner - 1) & 3) * 64 + lane] = acc[i][j];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int tid = i * TN + j, owner = dr_owner<TN, B_RC>(i, j);
+            if (owner == W) {
+                const f32x4* sp = slots + tid * 192 + lane;
+                acc[i][j] = acc[i][j] + sp[0] + sp[64] + sp[128];
+            }
+        }
+    __syncthreads();          // everybody has read its slots: the space becomes the output stage
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int jj = 0; jj < TQ; ++jj) {
+            if (dr_owner<TN, B_RC>(i, 4 * jj) == W) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    *reinterpret_cast<f32x4*>(&lds[dr_row<TM, A_RC>(i, 4 * q + r) * LDS_ + 64 * jj + 4 * c]) =
+                        f32x4{acc[i][4 * jj][r], acc[i][4 * jj + 1][r], acc[i][4 * jj + 2][r], acc[i][4 * jj + 3][r]};
+            }
+        }
+#pragma unroll
+        for (int j = 4 * TQ; j < TN; ++j) {
+            if (dr_owner<TN, B_RC>(i, j) == W) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lds[dr_row<TM, A_RC>(i, 4 * q + r) * LDS_ + dr_col<TN, B_RC>(j, c)] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+template <int TM, int TN, bool A_RC, bool B_RC, bool CS, int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_dr_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                         float* __restrict__ C, int ldc, int M, int N, int K, int kchunk, int nbn,
+                                                         DrEpilogue ep) {
+    constexpr int TQ = B_RC ? 0 : TN / 4;                    // quads of B tiles sharing one dwordx4 per lane (NC only)
+    constexpr int VA = A_RC ? 1 : (TM % 4 == 0 ? 4 : (TM % 2 == 0 ? 2 : 1));
+    constexpr int AG = TM / VA;                              // A load groups per step (NC only)
+    extern __shared__ __attribute__((aligned(16))) float dr_lds[];
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    int bm, bn;
+    {   // XCD-aware order: hardware puts linear block b on XCD b % 8; every XCD gets a contiguous run of tiles (n fastest) so the
+        // blocks sharing an A row-panel sit behind the same L2.  Speed only: any placement computes the same result.
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int qq = nwg / 8, r = nwg % 8, xcd = b % 8, idx = b / 8;
+        const int lb = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+        bn = lb % nbn;
+        bm = lb / nbn;
+    }
+    DR_STAMP(0);
+    const int m0 = bm * 16 * TM, n0 = bn * 16 * TN;
+    const int kb0 = blockIdx.y * kchunk, kb1 = min(K, kb0 + kchunk);
+    // (wave-uniform by construction; the readfirstlane's make the compiler believe it -- a scalar offset or descriptor it cannot
+    // PROVE uniform gets every buffer load wrapped in a waterfall loop: ~10 instructions per load, no overlap between loads)
+    const int kw = ((max(kb1 - kb0, 0) + 15) / 16) * 4;                 // k per wave, a multiple of 4
+    const int kbeg = __builtin_amdgcn_readfirstlane(min(kb0 + w * kw, kb1));
+    const int kend = __builtin_amdgcn_readfirstlane(min(kb1, kbeg + kw));
+    const int Gf = __builtin_amdgcn_readfirstlane((kend - kbeg) / 16);  // full groups of 16 k
+    const int kt = kbeg + 16 * Gf;                                      // tail: < 16 k
+    const int ns = __builtin_amdgcn_readfirstlane((kend - kt + 3) / 4); // tail steps (0..4), step-major k = kt + 4 s + q
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // wave-uniform bases + 32-bit lane offsets.  num_records is the true end of the operand behind the base, so rows / columns
+    // beyond the matrix need no clamping and no predication: a load past the end returns 0 without touching memory, and
+    // whatever a load finds beyond M or N INSIDE the buffer only feeds outputs nobody stores.
+    const float* Ab = A + (A_RC ? (size_t)m0 * lda + kbeg : (size_t)kbeg * lda + m0);
+    const float* Bb = B + (B_RC ? (size_t)n0 * ldb + kbeg : (size_t)kbeg * ldb + n0);
+    const int bytesA = 4 * (A_RC ? (M - m0 - 1) * lda + (K - kbeg) : (K - kbeg - 1) * lda + (M - m0));
+    const int bytesB = 4 * (B_RC ? (N - n0 - 1) * ldb + (K - kbeg) : (K - kbeg - 1) * ldb + (N - n0));
+    auto uni_ptr = [](const float* p) {
+        const uint64_t v = reinterpret_cast<uint64_t>(p);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+    };
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(Ab), 0, __builtin_amdgcn_readfirstlane(max(bytesA, 0)), 0x00020000);
+    const auto rb = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(Bb), 0, __builtin_amdgcn_readfirstlane(max(bytesB, 0)), 0x00020000);
+    constexpr int NA = A_RC ? TM : AG, NB = B_RC ? TN : TQ + (TN - 4 * TQ);         // lane offsets per operand
+    int aoff[NA], boff[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) aoff[i] = 4 * (A_RC ? (16 * i + c) * lda + 4 * q : 4 * q * lda + 16 * VA * i + VA * c);
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+        boff[j] = 4 * (B_RC ? (16 * j + c) * ldb + 4 * q : 4 * q * ldb + (j < TQ ? 64 * j + 4 * c : 64 * TQ + 16 * (j - TQ) + c));
+    const unsigned strideA = 4u * (unsigned)lda, strideB = 4u * (unsigned)ldb;    // bytes per k step of an NC operand
+
+    struct Frag { float a[TM][4]; float b[TN][4]; };
+    auto ldv = [](auto rs, int voff, unsigned soff_, auto nt, float* d, int stride) {      // nt dwords -> d[0], d[stride], ...
+        constexpr int NV = decltype(nt)::value;
+        const unsigned soff = __builtin_amdgcn_readfirstlane(soff_);
+        if constexpr (NV == 4) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e * stride] = __uint_as_float(v[e]);
+        } else if constexpr (NV == 2) {
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+            d[0] = __uint_as_float(v[0]);
+            d[stride] = __uint_as_float(v[1]);
+        } else {
+            d[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+        }
+    };
+    using I1 = std::integral_constant<int, 1>;
+    using I4 = std::integral_constant<int, 4>;
+    using IVA = std::integral_constant<int, VA>;
+    // the A loads of one group (RC: one dwordx4 per tile = its 4 steps; NC: per step, one VA-wide load per VA tiles)
+    auto loadA = [&](Frag& f, unsigned sA, unsigned dA) {        // sA: scalar offset of step 0, dA: per step (NC)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (A_RC) ldv(ra, aoff[i], sA, I4{}, &f.a[i][0], 1);
+            else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) ldv(ra, aoff[i], sA + s * dA, IVA{}, &f.a[VA * i][s], 4);
+            }
+        }
+    };
+    // the B loads of step s (NC) / all of them with s == 0 (RC)
+    auto loadB_unit = [&](Frag& f, int u, int s, unsigned sB) {
+        if (B_RC) ldv(rb, boff[u], sB, I4{}, &f.b[u][0], 1);
+        else if (u < TQ) ldv(rb, boff[u], sB, I4{}, &f.b[4 * u][s], 4);
+        else ldv(rb, boff[u], sB, I1{}, &f.b[4 * TQ + (u - TQ)][s], 4);
+    };
+    float cs[TN];                                   // wgrad: column sums of B (= dY), from the fragments as they pass by
+#pragma unroll
+    for (int j = 0; j < TN; ++j) cs[j] = 0.f;
+    auto mma_tile = [&](const Frag& f, int j, int s) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[i][s], f.b[j][s], acc[i][j], 0, 0, 0);
+        if (CS) cs[j] += f.b[j][s];
+    };
+    auto gA = [&](int g) -> unsigned { return A_RC ? 64u * g : 16u * g * strideA; };
+    auto gB = [&](int g) -> unsigned { return B_RC ? 64u * g : 16u * g * strideB; };
+    // one pipeline half: prefetch group gn into nxt while the MFMAs of cur run.  The sched_group_barrier pipeline asks for the
+    // issue order  A loads, then {1 B load, the MFMAs of the tiles it feeds} repeated, so the VMEM issue slots hide inside the
+    // matrix pipe's 32-cycle passes instead of forming a burst during which the pipe drains.
+    auto half = [&](Frag& nxt, int gn, const Frag& cur) {
+        __builtin_amdgcn_sched_barrier(0);
+        loadA(nxt, gA(gn), strideA);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                // NC: unit u's load of step s.  RC: one dwordx4 carries a tile's 4 steps -> one load every 4th slot, spread over the half
+                if (!B_RC) loadB_unit(nxt, u, s, gB(gn) + s * strideB);
+                else if (((s * NB + u) & 3) == 0) loadB_unit(nxt, (s * NB + u) >> 2, 0, gB(gn));
+                if (!B_RC && u < TQ) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mma_tile(cur, 4 * u + e, s);
+                } else {
+                    mma_tile(cur, B_RC ? u : 4 * TQ + (u - TQ), s);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x20, A_RC ? TM : 4 * AG, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int u = 0; u < TQ; ++u) {                    // (NC quads)
+                __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 4 * TM, 0);
+            }
+#pragma unroll
+            for (int u = TQ; u < NB; ++u) {
+                if (!B_RC || ((s * NB + u) & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, TM, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto load_all = [&](Frag& f, int g) {        // same issue order as half(): the compiler's vmcnt counts then agree on both loop entries
+        loadA(f, gA(g), strideA);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int u = 0; u < NB; ++u)
+                if (!B_RC || s == 0) loadB_unit(f, u, s, gB(g) + (B_RC ? 0u : s * strideB));
+    };
+    auto mma_all = [&](const Frag& f, int nsteps) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s < nsteps) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) mma_tile(f, j, s);
+            }
+        }
+    };
+
+    Frag ft, f0, f1;
+    // first groups: an odd count computes group 0 alone so that the pair loop below has no remainder
+    int g = Gf & 1;
+    if (Gf > 0) {
+        if (Gf & 1) load_all(f1, 0);
+        load_all(f0, min(g, Gf - 1));
+    }
+    // ---- tail (< 16 k): loaded now, behind the first groups, consumed AFTER the main loop (the order of k is free) so that
+    // nobody ever waits for it.  Step-major k assignment (k = kt + 4 s + q); a lane whose k lies beyond the wave's range reads
+    // at an offset past num_records: the hardware returns 0 (no select after the load, no branch, no wait).
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {           // all four steps, unconditionally: a step beyond the tail is all-OOB (zeros, no traffic)
+        const int k = kt + 4 * s + q;
+        const bool ok = k < kend;
+        const int kr = k - kbeg;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int off = 4 * (A_RC ? (16 * i + c) * lda + kr : kr * lda + 16 * VA * i + VA * c);
+            if (A_RC) ldv(ra, ok ? off : 0x7ffffff0, 0u, I1{}, &ft.a[i][s], 4);
+            else ldv(ra, ok ? off : 0x7ffffff0, 0u, IVA{}, &ft.a[VA * i][s], 4);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int off = 4 * (B_RC ? (16 * u + c) * ldb + kr : kr * ldb + (u < TQ ? 64 * u + 4 * c : 64 * TQ + 16 * (u - TQ) + c));
+            if (B_RC) ldv(rb, ok ? off : 0x7ffffff0, 0u, I1{}, &ft.b[u][s], 4);
+            else if (u < TQ) ldv(rb, ok ? off : 0x7ffffff0, 0u, I4{}, &ft.b[4 * u][s], 4);
+            else ldv(rb, ok ? off : 0x7ffffff0, 0u, I1{}, &ft.b[4 * TQ + (u - TQ)][s], 4);
+        }
+    }
+    DR_STAMP(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (Gf > 0) {
+        if (Gf & 1) mma_all(f1, 4);
+        for (; g < Gf; g += 2) {          // both halves unconditional: a load whose only use sits in a branch gets sunk into it
+            half(f1, g + 1, f0);          // (g + 1 < Gf always: an even number of groups is left)
+            half(f0, min(g + 2, Gf - 1), f1);      // the last prefetch re-reads a loaded group; nobody consumes it
+        }
+    }
+    mma_all(ft, ns);
+    DR_STAMP(2);
+
+    // ---- wgrad: bias gradient = column sums of B (= dY) over this block's reduction range, first row of tiles only
+    if (CS && ep.colsum != nullptr && bm == 0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float v = cs[j];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (q == 0) dr_lds[w * 16 * TN + dr_col<TN, B_RC>(j, c)] = v;
+        }
+        __syncthreads();
+        if (t < 16 * TN && n0 + t < N)
+            ep.colsum[(size_t)blockIdx.y * ep.colsum_stride + n0 + t] = dr_lds[t] + dr_lds[16 * TN + t] + dr_lds[32 * TN + t] + dr_lds[48 * TN + t];
+        __syncthreads();
+    }
+
+    // this thread's output column (store phase below) and its bias, loaded here so that the latency hides behind the reduction
+    constexpr int C4 = 4 * TN;                  // float4s per tile row
+    constexpr int RPI = 256 / C4;               // tile rows stored per pass of the block
+    const int tr = t / C4, tc = t - tr * C4;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == DR_BIAS_ACT && ep.bias != nullptr && t < RPI * C4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n0 + 4 * tc + e < N) bias4[e] = ep.bias[n0 + 4 * tc + e];
+    }
+    // ---- cross-wave reduction + row-major staging (dr_reduce_tiles), one instantiation per wave id
+    constexpr int LDS_ = 16 * TN + 4;           // staged row stride
+    switch (w) {
+        case 0: dr_reduce_tiles<TM, TN, A_RC, B_RC, 0>(acc, dr_lds, lane); break;
+        case 1: dr_reduce_tiles<TM, TN, A_RC, B_RC, 1>(acc, dr_lds, lane); break;
+        case 2: dr_reduce_tiles<TM, TN, A_RC, B_RC, 2>(acc, dr_lds, lane); break;
+        default: dr_reduce_tiles<TM, TN, A_RC, B_RC, 3>(acc, dr_lds, lane); break;
+    }
+    DR_STAMP(3);
+    __syncthreads();
+    DR_STAMP(4);
+
+    // ---- coalesced row-major stores: a thread keeps ONE float4 column of the tile and walks down the rows (its bias was loaded
+    // before the reduction; the ReLU-mask reads of all its rows are issued together ahead of the stores).  Bias / ReLU /
+    // dropout or the ReLU mask are applied here.
+    constexpr int NIT = (16 * TM + RPI - 1) / RPI;
+    const int gn = n0 + 4 * tc;
+    float* Cz = C + (EPI == DR_STORE ? (size_t)blockIdx.y * ep.split_stride : 0);
+    uint64_t seed = 0;
+    if (EPI == DR_BIAS_ACT) seed = ep.seed ^ (ep.seed_ptr ? *ep.seed_ptr : 0ull);
+    // fast path: every float4 of the tile is either whole or absent, and 16-byte aligned on both sides
+    const bool fast = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cz) & 15) == 0) && ((N & 3) == 0) &&
+                      (EPI != DR_MASK || (((ep.ldact & 3) == 0) && ((reinterpret_cast<uintptr_t>(ep.act) & 15) == 0)));
+    if (fast) {
+        const bool col_on = t < RPI * C4 && gn < N;
+        float4 am[NIT];
+        if (EPI == DR_MASK) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int row = tr + RPI * it, gm = m0 + row;
+                am[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (col_on && row < 16 * TM && gm < M) am[it] = *reinterpret_cast<const float4*>(ep.act + (size_t)gm * ep.ldact + gn);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = tr + RPI * it, gm = m0 + row;
+            if (col_on && row < 16 * TM && gm < M) {
+                const float4 v4 = *reinterpret_cast<const float4*>(&dr_lds[row * LDS_ + 4 * tc]);
+                float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                const float a[4] = {am[it].x, am[it].y, am[it].z, am[it].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (EPI == DR_BIAS_ACT) {
+                        v[e] += bias4[e];
+                        if (ep.relu) v[e] = fmaxf(v[e], 0.f);
+                        if (ep.keep < 1.0f) v[e] *= dr_dropout_scale(seed, (uint64_t)gm * (uint64_t)N + gn + e, ep.keep);
+                    } else if (EPI == DR_MASK) {
+                        v[e] = (a[e] > 0.f) ? v[e] * ep.inv_keep : 0.f;
+                    }
+                }
+                *reinterpret_cast<float4*>(Cz + (size_t)gm * ldc + gn) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    } else {                     // odd strides / widths: element by element (not a tuned path)
+        for (int idx = t; idx < 16 * TM * 16 * TN; idx += 256) {
+            const int row = idx / (16 * TN), col = idx - row * (16 * TN);
+            const int gm = m0 + row, gc = n0 + col;
+            if (gm < M && gc < N) {
+                float v = dr_lds[row * LDS_ + col];
+                if (EPI == DR_BIAS_ACT) {
+                    if (ep.bias != nullptr) v += ep.bias[gc];
+                    if (ep.relu) v = fmaxf(v, 0.f);
+                    if (ep.keep < 1.0f) v *= dr_dropout_scale(seed, (uint64_t)gm * (uint64_t)N + gc, ep.keep);
+                } else if (EPI == DR_MASK) {
+                    v = (ep.act[(size_t)gm * ep.ldact + gc] > 0.f) ? v * ep.inv_keep : 0.f;
+                }
+                Cz[(size_t)gm * ldc + gc] = v;
+            }
+        }
+    }
+    DR_STAMP(5);
+}
+
+// LDS bytes of one block: the register dump of the reduction (3 KB per 16x16 tile) or the row-major stage, whichever is larger
+template <int TM, int TN>
+constexpr size_t gemm_dr_lds_bytes() {
+    const size_t slots = (size_t)TM * TN * 3 * 64 * 16;
+    const size_t stage = (size_t)16 * TM * (16 * TN + 4) * 4;
+    const size_t cs = (size_t)4 * 16 * TN * 4;
+    size_t m = slots > stage ? slots : stage;
+    return m > cs ? m : cs;
+}
+
+}  // namespace dctr

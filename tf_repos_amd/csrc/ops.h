@@ -82,6 +82,14 @@ int fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int lddy, 
 constexpr int GEMM_SLACK_ROWS = 64;
 int sum_partials(const float* part, int64_t stride, int splits, int64_t n, float* out, hipStream_t st);
 int choose_wgrad_splits(int M, int K, int N);
+// gemm_dr.hip: the direct-to-register wave-split-K kernel family; *done = false -> not taken, the caller runs the LDS-tiled kernel
+int dr_fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N, int relu, float keep,
+              const uint64_t* seed_ptr, uint64_t seed, hipStream_t st, bool* done);
+int dr_fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int K, int N, const float* act, int ldact,
+                   float keep_prev, hipStream_t st, bool* done);
+int dr_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int lddy, float* dw_part, int64_t dw_stride, float* db_part,
+                               int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, bool* done);
+int dr_wgrad_splits(int M, int K, int N);
 
 // ---- dense_ops.hip
 int rowdot(const float* x, int ldx, const float* w, const float* bias, int M, int n, float* y, int accumulate,
