@@ -445,6 +445,109 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(HeadSeg s1, HeadSeg s
     }
 }
 
+// Same contract in ONE pass over x (the kernel above reads every row twice and gives a block of 256 threads 32 rows: 23 us for
+// 13 MB).  A block of 1024 threads takes 32 rows at a time, 32 lanes per row; a lane keeps its NI float4 pieces of the row and of
+// w in registers, so the logit's dot product, dX = dy (x) w [masked] and the lane's share of dW = x^T dy all come from the same
+// loads.  A block (4 waves: light enough to be placed beside whatever else the step has on the chip) walks its rows 8 at a time,
+// dW accumulating in registers; it meets across the block in two steps: the two rows of a wave by a lane swap, the 4 waves
+// through LDS.
+template <int NI>
+__global__ __launch_bounds__(256) void head_out_bwd_rows_kernel(HeadSeg s1, HeadSeg s2, const float* __restrict__ b_out,
+                                                                const float* __restrict__ bias, const float* __restrict__ yw,
+                                                                const float* __restrict__ yv, const float* __restrict__ labels, int B,
+                                                                float inv_batch, float inv_keep, int rows_per_block,
+                                                                float* __restrict__ yd_out, float* __restrict__ y_out,
+                                                                float* __restrict__ prob, float* __restrict__ dy_out,
+                                                                float* __restrict__ loss_shards, float* __restrict__ dw_part,
+                                                                int64_t dw_stride, float* __restrict__ db_part, int64_t db_stride) {
+    constexpr int NW = 4;                   // waves per block: 2 rows each
+    __shared__ float4 wred[NW][NI * 32];
+    __shared__ float lred[NW], dred[NW];
+    const int t = threadIdx.x, l = t & 31, rr = t >> 5, wave = t >> 6;
+    const int rbeg = blockIdx.x * rows_per_block, rend = min(B, rbeg + rows_per_block);
+    const int n41 = s1.n >> 2, n4 = n41 + (s2.x != nullptr ? (s2.n >> 2) : 0);
+    float4 wv[NI], dw[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int f = l + 32 * i;
+        wv[i] = dw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < n4) wv[i] = f < n41 ? *reinterpret_cast<const float4*>(s1.w + 4 * f) : *reinterpret_cast<const float4*>(s2.w + 4 * (f - n41));
+    }
+    const float b0 = (b_out ? b_out[0] : 0.f), g0 = (bias ? bias[0] : 0.f);
+    float lsum = 0.f, dsum = 0.f;
+    for (int rb = rbeg; rb < rend; rb += 2 * NW) {
+        const int r = rb + rr;
+        const bool valid = r < rend;
+        float4 xv[NI];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int f = l + 32 * i;
+            xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid && f < n4)
+                xv[i] = f < n41 ? *reinterpret_cast<const float4*>(s1.x + (size_t)r * s1.ld + 4 * f)
+                                : *reinterpret_cast<const float4*>(s2.x + (size_t)r * s2.ld + 4 * (f - n41));
+            s += xv[i].x * wv[i].x + xv[i].y * wv[i].y + xv[i].z * wv[i].z + xv[i].w * wv[i].w;
+        }
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
+        float d = 0.f;
+        if (valid) {
+            const float ydv = s + b0;
+            float y = ydv + g0;
+            if (yw) y += yw[r];
+            if (yv) y += yv[r];
+            const float en = __expf(-fabsf(y));
+            const float p = (y >= 0.f) ? 1.0f / (1.0f + en) : en / (1.0f + en);
+            const float z = labels[r];
+            d = (p - z) * inv_batch;
+            if (l == 0) {
+                lsum += fmaxf(y, 0.f) - y * z + log1pf(expf(-fabsf(y)));
+                dsum += d;
+                yd_out[r] = ydv; y_out[r] = y; prob[r] = p; dy_out[r] = d;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int f = l + 32 * i;
+            if (valid && f < n4) {
+                const bool first = f < n41;
+                const HeadSeg& g = first ? s1 : s2;
+                float4 o = make_float4(d * wv[i].x, d * wv[i].y, d * wv[i].z, d * wv[i].w);
+                if (g.masked) {
+                    o.x = xv[i].x > 0.f ? o.x * inv_keep : 0.f; o.y = xv[i].y > 0.f ? o.y * inv_keep : 0.f;
+                    o.z = xv[i].z > 0.f ? o.z * inv_keep : 0.f; o.w = xv[i].w > 0.f ? o.w * inv_keep : 0.f;
+                }
+                *reinterpret_cast<float4*>(g.dx + (size_t)r * g.lddx + 4 * (first ? f : f - n41)) = o;
+                dw[i].x += d * xv[i].x; dw[i].y += d * xv[i].y; dw[i].z += d * xv[i].z; dw[i].w += d * xv[i].w;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {          // the wave's two rows: lanes l and l + 32
+        dw[i].x += __shfl_xor(dw[i].x, 32); dw[i].y += __shfl_xor(dw[i].y, 32);
+        dw[i].z += __shfl_xor(dw[i].z, 32); dw[i].w += __shfl_xor(dw[i].w, 32);
+        if ((t & 63) < 32) wred[wave][l + 32 * i] = dw[i];
+    }
+    lsum += __shfl_xor(lsum, 32);
+    dsum += __shfl_xor(dsum, 32);
+    if ((t & 63) == 0) { lred[wave] = lsum; dred[wave] = dsum; }
+    __syncthreads();
+    for (int f = t; f < n4; f += 64 * NW) {
+        const int t = f;
+        float4 a = wred[0][t];
+#pragma unroll
+        for (int wv_ = 1; wv_ < NW; ++wv_) { const float4 o = wred[wv_][t]; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+        *reinterpret_cast<float4*>(dw_part + (size_t)blockIdx.x * dw_stride + 4 * t) = a;
+    }
+    if (t == 0) {
+        float ls = 0.f, ds = 0.f;
+#pragma unroll
+        for (int wv_ = 0; wv_ < NW; ++wv_) { ls += lred[wv_]; ds += dred[wv_]; }
+        atomicAdd(loss_shards + (blockIdx.x & (SUMSQ_SHARDS - 1)), ls);
+        db_part[(size_t)blockIdx.x * db_stride] = ds;
+    }
+}
+
 // returns DCTR_ERR_UNSUPPORTED (without setting an error) when the shapes do not meet the float4 alignment rules
 int head_out_bwd(const float* x1, int ld1, const float* w1, int n1, int masked1, float* dx1, int lddx1,
                  const float* x2, int ld2, const float* w2, int n2, int masked2, float* dx2, int lddx2,
@@ -457,6 +560,18 @@ int head_out_bwd(const float* x1, int ld1, const float* w1, int n1, int masked1,
         !ok(w2, 4, n2) || dw_stride % 4 != 0 || (reinterpret_cast<uintptr_t>(dw_part) & 15) != 0)
         return DCTR_ERR_UNSUPPORTED;
     HeadSeg s1{x1, ld1, w1, n1, masked1, dx1, lddx1}, s2{x2, ld2, w2, n2, masked2, dx2, lddx2};
+    static const bool two_pass = getenv("DCTR_HEAD_TWO_PASS") != nullptr;       // A/B knob: the 256-thread two-pass kernel
+    const int n4 = (n1 + (x2 ? n2 : 0)) / 4;
+    if (!two_pass && n4 <= 256) {
+        if (n4 <= 128)
+            head_out_bwd_rows_kernel<4><<<splits, 256, 0, st>>>(s1, s2, b_out, bias, yw, yv, labels, B, inv_batch, 1.0f / keep, rpb, yd, y, prob,
+                                                                 dy, loss_shards, dw_part, dw_stride, db_part, db_stride);
+        else
+            head_out_bwd_rows_kernel<8><<<splits, 256, 0, st>>>(s1, s2, b_out, bias, yw, yv, labels, B, inv_batch, 1.0f / keep, rpb, yd, y, prob,
+                                                                 dy, loss_shards, dw_part, dw_stride, db_part, db_stride);
+        DCTR_LAUNCH_CHECK();
+        return DCTR_OK;
+    }
     head_out_bwd_kernel<<<splits, 256, 0, st>>>(s1, s2, b_out, bias, yw, yv, labels, B, inv_batch, 1.0f / keep, rpb, yd, y, prob, dy,
                                                 loss_shards, dw_part, dw_stride, db_part, db_stride);
     DCTR_LAUNCH_CHECK();
@@ -661,7 +776,9 @@ __global__ __launch_bounds__(256) void opt_table_kernel(const Hyper* __restrict_
 // (a wave or two per SIMD, so the GEMM blocks still find their wave slots) with UNR independent row pieces in flight per lane
 // to keep the HBM pipe full from few waves.
 template <int KIND, int KQ, int UNR>
-__global__ __launch_bounds__(256) void opt_table_untouched_kernel(const Hyper* __restrict__ hdev, Hyper hval, int64_t rows,
+// (5 waves per SIMD asked for = at most 96 VGPRs: two of its waves and one block of the direct GEMM kernels, up to 320 VGPRs, then
+// share a SIMD -- a GEMM block that finds no room beside this background pass has to wait for its blocks to END)
+__global__ __launch_bounds__(256, 5) void opt_table_untouched_kernel(const Hyper* __restrict__ hdev, Hyper hval, int64_t rows,
                                                                  float4* __restrict__ emb, float4* __restrict__ s0,
                                                                  float4* __restrict__ s1, const int32_t* __restrict__ slot, float l2,
                                                                  float* __restrict__ sumsq_emb) {

@@ -342,6 +342,7 @@ int build(dctr_engine* E) {
         //  graph mode keeps plain streams)
         DCTR_HIP_CHECK(hipStreamCreateWithPriority(&E->s_group, hipStreamNonBlocking, c.use_graph ? 0 : prio("DCTR_PRIO_GROUP", least)));
         DCTR_HIP_CHECK(hipStreamCreateWithPriority(&E->s_wgrad, hipStreamNonBlocking, c.use_graph ? 0 : prio("DCTR_PRIO_WGRAD", greatest)));
+        DCTR_HIP_CHECK(hipStreamCreateWithPriority(&E->s_opt, hipStreamNonBlocking, c.use_graph ? 0 : prio("DCTR_PRIO_OPT", least)));
     }
     E->events.resize(64);
     {
@@ -615,6 +616,10 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
                                pw.padded, E->part(E->p_out_b), pb.padded, st));
     }
     const uint64_t* bn_seedp = &E->state->seed_t;
+    // A/B knob DCTR_WGRAD_LATE=1: all weight gradients after the dgrad chain (measured SLOWER, 0.375 vs 0.344 ms/step at c2: beside
+    // the scatter a one-block-per-CU GEMM and the scatter's many small blocks get in each other's way, 23 -> 42 us and 32 -> 47 us)
+    static const bool wgrad_late_env = getenv("DCTR_WGRAD_LATE") != nullptr;
+    const bool wgrad_late = wgrad_late_env && E->s_opt != nullptr && sw != st;
     for (int i = nl - 1; i >= 0; --i) {
         const Fc& fc = E->mlp[i];
         const float* x = i > 0 ? (E->bn ? E->hbn[i - 1] : E->h[i - 1]) : E->x_in;
@@ -624,18 +629,40 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
         if (E->bn)      // dh[i] holds dL/d(layer output): dropout mask, BN backward, ReLU mask -> dL/d(pre-activation), in place
             DCTR_TRY(bn_backward(E->dh[i], fc.out, E->h[i], fc.out, B, fc.out, E->bn_stats[i], E->pp(fc.bn_gamma), fc.keep, bn_seedp,
                                  0x1000ull + i, E->bn_scratch, E->part(fc.bn_beta), E->part(fc.bn_gamma), E->dh[i], fc.out, st));
-        // dh[i] is complete on st -- and so is dgrad_{i+1}, the last reader of W_{i+1}: ONE record serves the weight gradient of
-        // this layer and (fused_opt) the optimizer step of the layer above, whose wgrad is already queued on sw
-        if (i == nl - 1 && head_ev != nullptr && !E->bn && E->head_did_out_bwd) DCTR_HIP_CHECK(hipStreamWaitEvent(sw, *head_ev, 0));
-        else DCTR_TRY(fork(E, st, sw));
-        if (fused_opt && i < nl - 1) DCTR_TRY(opt_dense_range(E, E->mlp[i + 1].w, E->mlp[i + 1].last, sw));
-        DCTR_TRY(fc_bwd_weights_partials(x, ldx, E->dh[i], fc.out, E->part(fc.w), w.padded, E->part(fc.b), b.padded, B, fc.in,
-                                         fc.out, fc.splits, sw, 1));
+        if (!wgrad_late) {
+            // dh[i] is complete on st -- and so is dgrad_{i+1}, the last reader of W_{i+1}: ONE record serves the weight gradient of
+            // this layer and (fused_opt) the optimizer step of the layer above, whose wgrad is already queued on sw
+            if (i == nl - 1 && head_ev != nullptr && !E->bn && E->head_did_out_bwd) DCTR_HIP_CHECK(hipStreamWaitEvent(sw, *head_ev, 0));
+            else DCTR_TRY(fork(E, st, sw));
+            if (fused_opt && i < nl - 1) DCTR_TRY(opt_dense_range(E, E->mlp[i + 1].w, E->mlp[i + 1].last, sw));
+            DCTR_TRY(fc_bwd_weights_partials(x, ldx, E->dh[i], fc.out, E->part(fc.w), w.padded, E->part(fc.b), b.padded, B, fc.in,
+                                             fc.out, fc.splits, sw, 1));
+        }
         if (i > 0)
             DCTR_TRY(fc_bwd_data(E->dh[i], fc.out, E->pp(fc.w), E->dh[i - 1], E->mlp[i - 1].out, B, fc.in, fc.out,
                                  E->bn ? nullptr : E->h[i - 1], E->mlp[i - 1].out, E->bn ? 1.f : E->mlp[i - 1].keep, st, 1));
         else
             DCTR_TRY(fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w), E->dx_in, E->Din_ld, B, fc.in, fc.out, nullptr, 0, 1.f, st, 1));
+    }
+    if (wgrad_late) {
+        // (experiment) the weight gradients AFTER the whole dgrad chain, beside the interaction backward, the scatter and the
+        // table step, with ONE cross-stream record on st instead of one per layer; each layer's optimizer step follows its
+        // gradient on a stream of its own.
+        DCTR_TRY(fork(E, st, sw));
+        for (int i = nl - 1; i >= 0; --i) {
+            const Fc& fc = E->mlp[i];
+            const float* x = i > 0 ? (E->bn ? E->hbn[i - 1] : E->h[i - 1]) : E->x_in;
+            const int ldx = i > 0 ? E->mlp[i - 1].out : E->Din_ld;
+            const Param& w = E->params[fc.w];
+            const Param& b = E->params[fc.b];
+            DCTR_TRY(fc_bwd_weights_partials(x, ldx, E->dh[i], fc.out, E->part(fc.w), w.padded, E->part(fc.b), b.padded, B, fc.in,
+                                             fc.out, fc.splits, sw, 1));
+            if (fused_opt) {
+                DCTR_TRY(fork(E, sw, E->s_opt));
+                DCTR_TRY(opt_dense_range(E, fc.w, fc.last, E->s_opt));
+                E->opt_pending = true;
+            }
+        }
     }
     const uint64_t* seedp = &E->state->seed_t;
     if (c.model == DCTR_MODEL_IPNN) DCTR_TRY(pnn_inner_bwd(E->e, E->e_ld, E->dx_in + D, E->Din_ld, B, F, K, E->dx_in, E->Din_ld, st));
@@ -654,7 +681,7 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
         // everything the dense side reads or writes on st is enqueued: the first layer's step (its dgrad is done) and, for the
         // caller, the cross-network / output-layer partial slabs
         DCTR_TRY(fork(E, st, sw));
-        DCTR_TRY(opt_dense_range(E, E->mlp[0].w, E->mlp[0].last, sw));
+        if (!wgrad_late) DCTR_TRY(opt_dense_range(E, E->mlp[0].w, E->mlp[0].last, sw));
     }
     return DCTR_OK;
 }
@@ -802,6 +829,7 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     if (split_table) DCTR_TRY(scatter_and_step_tables(E, B, st, nullptr, OPT_PASS_TOUCHED));
     else DCTR_TRY(scatter_and_step_tables(E, B, st, sg));  // the grouping stream is idle by now: linear table beside the embedding table
     DCTR_TRY(fork(E, sw, st));
+    if (E->opt_pending) { DCTR_TRY(fork(E, E->s_opt, st)); E->opt_pending = false; }
     return DCTR_OK;
 }
 
@@ -923,6 +951,7 @@ int dctr_destroy(dctr_handle E) {
     for (auto& ev : E->events) if (ev) hipEventDestroy(ev);
     if (E->s_group) hipStreamDestroy(E->s_group);
     if (E->s_wgrad) hipStreamDestroy(E->s_wgrad);
+    if (E->s_opt) hipStreamDestroy(E->s_opt);
     delete E;
     return DCTR_OK;
 }

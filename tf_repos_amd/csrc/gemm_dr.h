@@ -147,6 +147,7 @@ __global__ __launch_bounds__(256, 1) void gemm_dr_kernel(const float* __restrict
         bm = lb / nbn;
     }
     DR_STAMP(0);
+    __builtin_amdgcn_s_setprio(3);          // the step runs background kernels beside the MLP: GEMM waves go first at the issue arbiter
     const int m0 = bm * 16 * TM, n0 = bn * 16 * TN;
     const int kb0 = blockIdx.y * kchunk, kb1 = min(K, kb0 + kchunk);
     // (wave-uniform by construction; the readfirstlane's make the compiler believe it -- a scalar offset or descriptor it cannot
@@ -289,34 +290,12 @@ __global__ __launch_bounds__(256, 1) void gemm_dr_kernel(const float* __restrict
         }
     };
 
-    Frag ft, f0, f1;
+    Frag f0, f1;
     // first groups: an odd count computes group 0 alone so that the pair loop below has no remainder
     int g = Gf & 1;
     if (Gf > 0) {
         if (Gf & 1) load_all(f1, 0);
         load_all(f0, min(g, Gf - 1));
-    }
-    // ---- tail (< 16 k): loaded now, behind the first groups, consumed AFTER the main loop (the order of k is free) so that
-    // nobody ever waits for it.  Step-major k assignment (k = kt + 4 s + q); a lane whose k lies beyond the wave's range reads
-    // at an offset past num_records: the hardware returns 0 (no select after the load, no branch, no wait).
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {           // all four steps, unconditionally: a step beyond the tail is all-OOB (zeros, no traffic)
-        const int k = kt + 4 * s + q;
-        const bool ok = k < kend;
-        const int kr = k - kbeg;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int off = 4 * (A_RC ? (16 * i + c) * lda + kr : kr * lda + 16 * VA * i + VA * c);
-            if (A_RC) ldv(ra, ok ? off : 0x7ffffff0, 0u, I1{}, &ft.a[i][s], 4);
-            else ldv(ra, ok ? off : 0x7ffffff0, 0u, IVA{}, &ft.a[VA * i][s], 4);
-        }
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const int off = 4 * (B_RC ? (16 * u + c) * ldb + kr : kr * ldb + (u < TQ ? 64 * u + 4 * c : 64 * TQ + 16 * (u - TQ) + c));
-            if (B_RC) ldv(rb, ok ? off : 0x7ffffff0, 0u, I1{}, &ft.b[u][s], 4);
-            else if (u < TQ) ldv(rb, ok ? off : 0x7ffffff0, 0u, I4{}, &ft.b[4 * u][s], 4);
-            else ldv(rb, ok ? off : 0x7ffffff0, 0u, I1{}, &ft.b[4 * TQ + (u - TQ)][s], 4);
-        }
     }
     DR_STAMP(1);
     __builtin_amdgcn_sched_barrier(0);
@@ -327,7 +306,33 @@ __global__ __launch_bounds__(256, 1) void gemm_dr_kernel(const float* __restrict
             half(f0, min(g + 2, Gf - 1), f1);      // the last prefetch re-reads a loaded group; nobody consumes it
         }
     }
-    mma_all(ft, ns);
+    if (ns > 0) {
+        // ---- tail (< 16 k), after the main loop and into f0's registers: a third fragment set alive across the loop would push the
+        // kernel past 304 VGPRs, the most that still shares a SIMD with two waves of the background table pass (104 each) -- and a
+        // GEMM block that cannot be placed beside them waits for them to END.  Its load latency (~0.7 us) is exposed instead.
+        // Step-major k assignment (k = kt + 4 s + q); a lane whose k lies beyond the wave's range reads at an offset past
+        // num_records: the hardware returns 0 (no select after the load, no branch).
+    #pragma unroll
+        for (int s = 0; s < 4; ++s) {           // all four steps, unconditionally: a step beyond the tail is all-OOB (zeros, no traffic)
+            const int k = kt + 4 * s + q;
+            const bool ok = k < kend;
+            const int kr = k - kbeg;
+    #pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int off = 4 * (A_RC ? (16 * i + c) * lda + kr : kr * lda + 16 * VA * i + VA * c);
+                if (A_RC) ldv(ra, ok ? off : 0x7ffffff0, 0u, I1{}, &f0.a[i][s], 4);
+                else ldv(ra, ok ? off : 0x7ffffff0, 0u, IVA{}, &f0.a[VA * i][s], 4);
+            }
+    #pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int off = 4 * (B_RC ? (16 * u + c) * ldb + kr : kr * ldb + (u < TQ ? 64 * u + 4 * c : 64 * TQ + 16 * (u - TQ) + c));
+                if (B_RC) ldv(rb, ok ? off : 0x7ffffff0, 0u, I1{}, &f0.b[u][s], 4);
+                else if (u < TQ) ldv(rb, ok ? off : 0x7ffffff0, 0u, I4{}, &f0.b[4 * u][s], 4);
+                else ldv(rb, ok ? off : 0x7ffffff0, 0u, I1{}, &f0.b[4 * TQ + (u - TQ)][s], 4);
+            }
+        }
+        mma_all(f0, ns);
+    }
     DR_STAMP(2);
 
     // ---- wgrad: bias gradient = column sums of B (= dY) over this block's reduction range, first row of tiles only

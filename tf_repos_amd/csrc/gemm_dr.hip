@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "common.h"
 #include "gemm_dr.h"
@@ -36,9 +37,18 @@ double dr_efficiency(int Mo, int No, int64_t R, int S, Tile t, int* blocks_out) 
     return ideal / ((double)rounds * block_cycles);
 }
 
-bool dr_enabled() {
-    static const int on = [] { const char* e = getenv("DCTR_GEMM"); return (e && (!strcmp(e, "lds") || !strcmp(e, "LDS"))) ? 0 : 1; }();
-    return on != 0;
+// DCTR_GEMM = "lds": never; otherwise a subset of "fdw" (forward / dgrad / wgrad products that may take the direct kernel).
+// Default "fw".  Alone the direct kernel wins all three (c2 layer 0: fwd 25 vs 32 us, dgrad 26 vs 29, wgrad 28 vs 30), but a
+// training step runs each dgrad beside the weight gradient of the layer above, and there a one-block-per-CU dgrad loses:
+// measured ms/step at c2 (400 steps): lds 0.338, f 0.333, fw 0.329, fd 0.353, fdw 0.347.
+bool dr_enabled(char op) {
+    static const std::string ops = [] {
+        const char* e = getenv("DCTR_GEMM");
+        if (e == nullptr) return std::string("fw");
+        if (!strcmp(e, "lds") || !strcmp(e, "LDS")) return std::string();
+        return std::string(e);
+    }();
+    return ops.find(op) != std::string::npos;
 }
 double dr_threshold() {
     static const double th = [] { const char* e = getenv("DCTR_GEMM_DR_MIN_EFF"); return e ? atof(e) : 0.50; }();
@@ -76,7 +86,8 @@ int pick(const Tile (&list)[NT], int Mo, int No, int64_t R, int S, double* eff) 
 
 constexpr Tile FWD_TILES[] = {{2, 13}, {4, 7}, {2, 8}};
 constexpr Tile DGRAD_TILES[] = {{2, 13}, {4, 10}, {2, 8}};
-constexpr Tile WGRAD_TILES[] = {{2, 13}, {3, 13}, {2, 8}};
+// (no 3x13 here: 392 VGPRs -- a wgrad runs beside the background table pass, whose two waves per SIMD leave room for 320)
+constexpr Tile WGRAD_TILES[] = {{2, 13}, {2, 8}};
 
 }  // namespace
 
@@ -84,7 +95,7 @@ constexpr Tile WGRAD_TILES[] = {{2, 13}, {3, 13}, {2, 8}};
 int dr_fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N, int relu, float keep,
               const uint64_t* seed_ptr, uint64_t seed, hipStream_t st, bool* done) {
     *done = false;
-    if (!dr_enabled() || M <= 0 || N <= 0 || K < 64) return DCTR_OK;
+    if (!dr_enabled('f') || M <= 0 || N <= 0 || K < 64) return DCTR_OK;
     if (!al16(x) || !al16(w) || (ldx & 3) || (N & 3) || !fits31(M, ldx) || !fits31(K, N)) return DCTR_OK;
     double eff;
     const int t = pick(FWD_TILES, M, N, K, 1, &eff);
@@ -104,7 +115,7 @@ int dr_fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y,
 int dr_fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int K, int N, const float* act, int ldact,
                    float keep_prev, hipStream_t st, bool* done) {
     *done = false;
-    if (!dr_enabled() || M <= 0 || K <= 0 || N < 64) return DCTR_OK;
+    if (!dr_enabled('d') || M <= 0 || K <= 0 || N < 64) return DCTR_OK;
     if (!al16(dy) || !al16(w) || (lddy & 3) || (N & 3) || !fits31(M, lddy) || !fits31(K, N)) return DCTR_OK;
     double eff;
     const int t = pick(DGRAD_TILES, M, K, N, 1, &eff);
@@ -129,7 +140,7 @@ int dr_fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int ldd
 // the batch split the direct kernel wants for dW[K,N] = X^T dY over M rows: as many splits as keep the grid within one round of
 // the chip (0: no tile of the list fits this shape well -> the LDS-tiled kernel and its own split rule)
 int dr_wgrad_splits(int M, int K, int N) {
-    if (!dr_enabled() || M < 256) return 0;
+    if (!dr_enabled('w') || M < 256) return 0;
     int best_s = 0;
     double best = 0.0;
     for (const Tile& t : WGRAD_TILES) {
@@ -147,7 +158,7 @@ int dr_wgrad_splits(int M, int K, int N) {
 int dr_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int lddy, float* dw_part, int64_t dw_stride, float* db_part,
                                int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, bool* done) {
     *done = false;
-    if (!dr_enabled() || M <= 0 || splits < 1 || (int64_t)ceil_div(M, splits) < 64) return DCTR_OK;
+    if (!dr_enabled('w') || M <= 0 || splits < 1 || (int64_t)ceil_div(M, splits) < 64) return DCTR_OK;
     if (!al16(x) || !al16(dy) || (ldx & 3) || (lddy & 3) || (N & 3) || !fits31(M, ldx) || !fits31(M, lddy) || !al16(dw_part) || (dw_stride & 3))
         return DCTR_OK;
     double eff;
@@ -163,7 +174,6 @@ int dr_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int ldd
     *done = true;
     switch (t) {
         case 0: return dr_launch<2, 13, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
-        case 1: return dr_launch<3, 13, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
         default: return dr_launch<2, 8, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
     }
 }
