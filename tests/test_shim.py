@@ -165,3 +165,44 @@ def test_estimator_train_eval_predict_matches_oracle(model, tmp_path, dev):
         {"feat_ids": sys.modules["tensorflow"].placeholder(sys.modules["tensorflow"].int64, [None, F_], name="feat_ids"),
          "feat_vals": sys.modules["tensorflow"].placeholder(sys.modules["tensorflow"].float32, [None, F_], name="feat_vals")}))
     assert os.path.exists(os.path.join(exp, "variables.npz")) and os.path.exists(os.path.join(exp, "signature.json"))
+
+
+@pytest.mark.gpu
+def test_engine_hyperparameters_come_from_the_train_graph_whatever_the_call_order(tmp_path, dev):
+    """evaluate() before train(), and an evaluate() with a LARGER batch between two train() calls: training must still run with
+    the script's optimizer / learning rate (an EVAL graph carries neither; the engine once silently fell back to Adam@5e-4)."""
+    import torch
+    mod = _load_example()
+    F_, V, K, B = 39, 2000, 8, 64
+    ids, vals, labels = O.synth_batch(4 * B, F_, V, seed=5)
+    (tmp_path / "tr.libsvm").write_text(O.to_libsvm(ids, vals, labels))
+    vi, vv, vl = O.synth_batch(3 * B, F_, V, seed=6)
+    (tmp_path / "va.libsvm").write_text(O.to_libsvm(vi, vv, vl))
+    p = dict(model="deepfm", field_size=F_, feature_size=V, embedding_size=K, learning_rate=0.02, l2_reg=1e-3, deep_layers="16,8",
+             dropout="1.0,1.0", cross_layers=2, optimizer="Momentum")
+    est = mod.build_estimator(p, str(tmp_path / "ckpt"))
+    tr_fn = lambda: mod.input_fn([str(tmp_path / "tr.libsvm")], num_epochs=1, batch_size=B)
+    va_small = lambda: mod.input_fn([str(tmp_path / "va.libsvm")], num_epochs=1, batch_size=B // 2)
+    va_big = lambda: mod.input_fn([str(tmp_path / "va.libsvm")], num_epochs=1, batch_size=3 * B)
+    est.evaluate(input_fn=va_small)                                  # engine built from an EVAL graph first
+    assert est._engine.cfg.optimizer == "Adam"                       # (the EVAL lowering knows no optimizer)
+    inv = None
+    params0 = None
+    # the oracle starts from what the estimator initialised
+    spec, lowered, pipe, variables = est._build(tr_fn, "train")
+    inv = lowered.name_map
+    ocfg = O.Config(model="deepfm", field_size=F_, feature_size=V, embedding_size=K, deep_layers=(16, 8), dropout=(1.0, 1.0),
+                    l2_reg=1e-3, learning_rate=0.02, optimizer="Momentum")
+    params0 = {k: torch.from_numpy(est._engine.get_param(k).copy()) for k in O.param_shapes(ocfg)}
+    est.train(input_fn=tr_fn)
+    assert est._engine.cfg.optimizer == "Momentum" and abs(est._engine.cfg.learning_rate - 0.02) < 1e-9
+    est.evaluate(input_fn=va_big)                                    # larger batch: the engine is rebuilt for capacity ...
+    assert est._engine.cfg.max_batch >= 3 * B and est._engine.cfg.optimizer == "Momentum"      # ... from the TRAIN configuration
+    est.train(input_fn=tr_fn)
+    opt = O.Optimizer(ocfg, params0)
+    for _epoch in range(2):
+        for s in range(0, len(labels), B):
+            O.train_step(ocfg, params0, opt, ids[s:s + B], vals[s:s + B], labels[s:s + B])
+    for ename, tfname in inv.items():
+        assert np.abs(est.get_variable_value(tfname) - params0[ename].numpy()).max() <= 5e-6, tfname
+    assert est._engine.global_step == 8

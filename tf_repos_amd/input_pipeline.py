@@ -70,16 +70,29 @@ class LibsvmDataset:
         if path in self._cache:
             return self._cache[path]
         npz = path + ".f%d.dctr.npz" % self.field_size
-        if self.binary_cache and os.path.exists(npz) and os.path.getmtime(npz) >= os.path.getmtime(path):
-            z = np.load(npz)
-            data = (z["ids"], z["vals"], z["labels"])
-        else:
+        st = os.stat(path)
+        data = None
+        if self.binary_cache and os.path.exists(npz):
+            # the cache names the exact source it was made from (size + mtime_ns): a dataset replaced by an OLDER file (cp -p,
+            # rsync) must not serve stale rows, and a cache another process is still writing (or died writing) is just re-parsed
+            try:
+                z = np.load(npz)
+                if int(z["src_size"]) == st.st_size and int(z["src_mtime_ns"]) == st.st_mtime_ns:
+                    data = (z["ids"], z["vals"], z["labels"])
+            except Exception:           # noqa: BLE001  (BadZipFile, KeyError of an old-format cache, truncated file ...)
+                data = None
+        if data is None:
             data = parse_file(path, self.field_size, self.threads)
             if self.binary_cache:
-                try:
-                    np.savez(npz, ids=data[0], vals=data[1], labels=data[2])     # pre-tokenised cache
+                tmp = npz + ".tmp.%d.npz" % os.getpid()
+                try:                    # pre-tokenised cache, written atomically: several ranks load the same file
+                    np.savez(tmp, ids=data[0], vals=data[1], labels=data[2], src_size=np.int64(st.st_size), src_mtime_ns=np.int64(st.st_mtime_ns))
+                    os.replace(tmp, npz)
                 except OSError:
-                    pass
+                    try:
+                        os.remove(tmp)
+                    except OSError:
+                        pass
         self._cache[path] = data
         return data
 

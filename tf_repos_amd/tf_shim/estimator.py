@@ -120,6 +120,10 @@ def _init_value(v: G.Variable, rng: np.random.Generator) -> np.ndarray:
     raise errors.UnimplementedError("initializer %s" % init.kind)
 
 
+def _norm(v):
+    return tuple(v) if isinstance(v, (list, tuple)) else v
+
+
 class Estimator:
     def __init__(self, model_fn=None, model_dir=None, config=None, params=None, warm_start_from=None):
         self._model_fn = model_fn
@@ -173,27 +177,49 @@ class Estimator:
             variables = dict(g.variables)
         return spec, lowered, pipeline, variables
 
-    def _ensure_engine(self, lowered: Lowered, variables, batch_size: int, max_entries: int = 0):
-        need_new = self._engine is None or self._engine.cfg.max_batch < batch_size or self._engine.cfg.max_entries < max_entries
-        if self._engine is not None and not need_new:
+    # hyper-parameters only a TRAIN graph carries (an EVAL / PREDICT graph has no train_op and no dropout, so its lowering falls
+    # back to EngineConfig's defaults for them)
+    _TRAIN_ONLY = ("optimizer", "learning_rate", "dropout", "lin_optimizer", "lin_learning_rate")
+
+    def _ensure_engine(self, lowered: Lowered, variables, batch_size: int, max_entries: int = 0, mode: str = ModeKeys.TRAIN):
+        """Capacity (max_batch / max_entries) and hyper-parameters are separate concerns.  The engine is always configured from the
+        TRAIN lowering once one has been seen: evaluate() / predict() before train(), or an evaluate() with a larger batch in
+        between two train() calls, must not leave training running with Adam@5e-4 and no dropout.  A TRAIN lowering that
+        disagrees with the live engine rebuilds it (variables kept; optimizer slots kept when the optimizer is the same)."""
+        if mode == ModeKeys.TRAIN:
+            self._train_lowered = lowered
+        cfg_src = getattr(self, "_train_lowered", None) or lowered
+        live = self._engine
+        stale = False
+        if live is not None and mode == ModeKeys.TRAIN:
+            kw = cfg_src.config_kwargs
+            stale = any(k in kw and _norm(kw[k]) != _norm(getattr(live.cfg, k)) for k in self._TRAIN_ONLY)
+        need_new = live is None or stale or live.cfg.max_batch < batch_size or live.cfg.max_entries < max_entries
+        if not need_new:
             return
-        state = self._snapshot() if self._engine is not None else None
-        if self._engine is not None:
-            batch_size = max(batch_size, self._engine.cfg.max_batch)
-            max_entries = max(max_entries, self._engine.cfg.max_entries)
-            self._engine.close()
-        extra = {"max_entries": int(max_entries)} if lowered.slots is not None else {}
-        cfg = lowered.engine_config(max_batch=batch_size, table_mode=self.table_mode,
+        state = self._snapshot() if live is not None else None
+        if live is not None:
+            if stale and _norm(cfg_src.config_kwargs.get("optimizer")) != _norm(live.cfg.optimizer) and state is not None:
+                # slots of another optimizer mean nothing.  An engine built by evaluate() / predict() has not trained: what it holds
+                # came from the latest checkpoint (whose slots belong to the optimizer that wrote it) or from the initializers
+                disk = None if getattr(self, "_trained_since_build", False) else self._load_latest()
+                state = disk if disk is not None else {k: v for k, v in state.items() if not k.endswith(("/slot0", "/slot1"))}
+            batch_size = max(batch_size, live.cfg.max_batch)
+            max_entries = max(max_entries, live.cfg.max_entries)
+            live.close()
+        extra = {"max_entries": int(max_entries)} if cfg_src.slots is not None else {}
+        cfg = cfg_src.engine_config(max_batch=batch_size, table_mode=self.table_mode,
                                     seed=int(self._config.tf_random_seed or 0), **extra)
         self._engine = Engine(cfg)
-        self._lowered = lowered
+        self._lowered = cfg_src
         self._variables = variables
+        self._trained_since_build = False
         ck = state or self._load_latest()
         if ck is not None:
             self._restore(ck)
         else:
             rng = np.random.default_rng(int(self._config.tf_random_seed or 0))
-            for ename, tfname in lowered.name_map.items():
+            for ename, tfname in cfg_src.name_map.items():
                 self._engine.set_param(ename, _init_value(variables[tfname], rng).reshape(self._engine.param_shapes[ename]))
 
     # -- checkpoints (TF variable names) ----------------------------------------------------------------------------------
@@ -218,7 +244,7 @@ class Estimator:
         e.global_step = int(ck["global_step"]) if "global_step" in ck else 0
 
     def latest_checkpoint(self) -> Optional[str]:
-        files = glob.glob(os.path.join(self.model_dir, "model.ckpt-*.npz"))
+        files = [f for f in glob.glob(os.path.join(self.model_dir, "model.ckpt-*.npz")) if ".tmp." not in f]
         if not files:
             return None
         return max(files, key=lambda f: int(f.rsplit("-", 1)[1].split(".")[0]))
@@ -231,9 +257,12 @@ class Estimator:
         os.makedirs(self.model_dir, exist_ok=True)
         snap = self._snapshot()
         path = os.path.join(self.model_dir, "model.ckpt-%d.npz" % int(snap["global_step"]))
-        np.savez(path, **snap)
+        tmp = path + ".tmp.%d.npz" % os.getpid()       # a crash mid-save must not leave a corrupt file that wins latest_checkpoint()
+        np.savez(tmp, **snap)
+        os.replace(tmp, path)
         keep = self._config.keep_checkpoint_max or 5
-        files = sorted(glob.glob(os.path.join(self.model_dir, "model.ckpt-*.npz")), key=lambda f: int(f.rsplit("-", 1)[1].split(".")[0]))
+        files = sorted((f for f in glob.glob(os.path.join(self.model_dir, "model.ckpt-*.npz")) if ".tmp." not in f),
+                       key=lambda f: int(f.rsplit("-", 1)[1].split(".")[0]))
         for f in files[:-keep]:
             os.remove(f)
         return path
@@ -288,7 +317,8 @@ class Estimator:
         if pipeline is None:
             raise errors.InvalidArgumentError("input_fn must return tensors produced by a tf.data iterator")
         csr = lowered.slots is not None
-        self._ensure_engine(lowered, variables, pipeline.batch_size, self._csr_capacity(pipeline) if csr else 0)
+        self._ensure_engine(lowered, variables, pipeline.batch_size, self._csr_capacity(pipeline) if csr else 0, ModeKeys.TRAIN)
+        self._trained_since_build = True
         e = self._engine
         log_every = max(1, int(self._config.log_step_count_steps or 100))
         start_step = e.global_step
@@ -334,7 +364,7 @@ class Estimator:
         from . import logging as L
         spec, lowered, pipeline, variables = self._build(input_fn, ModeKeys.EVAL)
         csr = lowered.slots is not None
-        self._ensure_engine(lowered, variables, pipeline.batch_size, self._csr_capacity(pipeline) if csr else 0)
+        self._ensure_engine(lowered, variables, pipeline.batch_size, self._csr_capacity(pipeline) if csr else 0, ModeKeys.EVAL)
         e = self._engine
         e.eval_reset()
         n = 0
@@ -359,7 +389,7 @@ class Estimator:
         import torch
         spec, lowered, pipeline, variables = self._build(input_fn, ModeKeys.PREDICT)
         csr = lowered.slots is not None
-        self._ensure_engine(lowered, variables, pipeline.batch_size, self._csr_capacity(pipeline) if csr else 0)
+        self._ensure_engine(lowered, variables, pipeline.batch_size, self._csr_capacity(pipeline) if csr else 0, ModeKeys.PREDICT)
         e = self._engine
         keys = list(spec.predictions.keys())
         if predict_keys is not None:
@@ -402,7 +432,7 @@ class Estimator:
             from . import FLAGS_MODULE
             lowered = lower(None, None, spec.predictions, FLAGS_MODULE.FLAGS)
             variables = dict(g.variables)
-        self._ensure_engine(lowered, variables, 1024)
+        self._ensure_engine(lowered, variables, 1024, 0, ModeKeys.PREDICT)
         out = os.path.join(export_dir_base, str(int(time.time())))
         os.makedirs(out, exist_ok=True)
         snap = {k: v for k, v in self._snapshot().items() if "/slot" not in k}
