@@ -4,17 +4,21 @@
   python bench.py --gpus 1 --steps 200 --warmup 20
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1], SURVEY 8d "c2"): DeepFM, 39 fields, vocab 1e6, emb_dim 16, batch 4096 per GPU
-(weak scaling), MLP 400-400-400 with keep_prob 0.5, Adam lr 5e-4, l2_reg 1e-4 (deep_ctr/README.md:49), f32 arithmetic,
-synthetic Criteo-shaped libsvm-equivalent tensors already resident in HBM, random-init N(0,0.01) weights.
-A "step" = forward + loss + backward + optimizer over one batch, table optimizer in DENSE-EXACT mode (what the
-reference's TF graph does: l2_loss on the tables makes the optimizer stream all V rows every step).
-Prints ONE JSON line (rank 0).  The `roofline` object is for the kernel that dominates the step; `cpu_baseline` is the
-torch-CPU restatement of the reference's TF-1.4 graph (oracle/, "port") timed on this box's host cores.
+Workloads (--config):
+  c2 (default; BASELINE.json configs[1], the configuration the metric is quoted on): DeepFM, 39 fields, vocab 1e6, emb_dim 16,
+      batch 4096 per GPU (weak scaling), MLP 400-400-400 keep 0.5, Adam lr 5e-4, l2_reg 1e-4 (deep_ctr/README.md:49).
+  c5 (BASELINE.json configs[4]): DeepFM vocab 1e8, emb_dim 32, batch 8192 per GPU (65 536 at 8 GPUs), table row-sharded.
+f32 arithmetic, synthetic Criteo-shaped libsvm-equivalent tensors already resident in HBM, random-init N(0,0.01) weights.
+A "step" = forward + loss + backward + optimizer over one batch, table optimizer in DENSE-EXACT mode (what the reference's TF
+graph does: l2_loss on the tables makes the optimizer stream all V rows every step).
+Prints ONE JSON line (rank 0).  `roofline` is the kernel that dominates the step (the first MLP layer's forward GEMM, timed
+inside the steps); `cpu_baseline` is the torch-CPU restatement of the reference's TF-1.4 graph (oracle/, "port") timed on this
+box's host cores by the protocol of BASELINE.md section 3.
 """
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -24,15 +28,27 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFS = 157.3  # f32-input MFMA peak
 
-WORKLOAD = dict(model="deepfm", field_size=39, feature_size=1_000_000, embedding_size=16, batch=4096,
-                deep_layers=(400, 400, 400), dropout=(0.5, 0.5, 0.5), l2_reg=1e-4, learning_rate=5e-4, optimizer="Adam")
+CONFIGS = {
+    "c2": dict(model="deepfm", field_size=39, feature_size=1_000_000, embedding_size=16, batch=4096,
+               deep_layers=(400, 400, 400), dropout=(0.5, 0.5, 0.5), l2_reg=1e-4, learning_rate=5e-4, optimizer="Adam",
+               name="DeepFM 39 fields, vocab 1e6, emb_dim 16, batch 4096/GPU, MLP 400-400-400 keep 0.5, Adam (BASELINE configs[1])"),
+    "c5": dict(model="deepfm", field_size=39, feature_size=100_000_000, embedding_size=32, batch=8192,
+               deep_layers=(400, 400, 400), dropout=(0.5, 0.5, 0.5), l2_reg=1e-4, learning_rate=5e-4, optimizer="Adam",
+               name="DeepFM 39 fields, vocab 1e8 row-sharded, emb_dim 32, batch 8192/GPU (65536 at 8 GPUs), MLP 400-400-400 keep 0.5, "
+                    "Adam (BASELINE configs[4])"),
+}
+PMC_FILE = os.path.join("profiles", "r02_pmc_traffic.txt")
 
 
-def cpu_baseline(w, seconds_budget=18.0):
-    """The oracle (torch-CPU restatement of the TF-1.4 graph, NOT TF) timed on the host cores: same model, same batch
-    shape, dense Adam over the full tables, on a bounded number of steps.  The thread count is the best of a short
-    sweep (more threads than ~16-32 make the memory-bound dense-table passes slower on a 256-core host)."""
+def cpu_baseline(w, steps=200, warmup=20):
+    """the oracle (torch-CPU fp32 restatement of the TF-1.4 graph, NOT TF) on this box's host cores --
+    same model, same batch shape, table gradient densified, dense Adam over all rows.  20 warm-up + `steps` timed steps, MEDIAN
+    step time; thread count = best of a sweep up to nproc; the text parse of the same batches (split ' ' then ':', 10 worker
+    threads, DeepFM.py:65-92) timed separately, so an input-bound baseline is not mistaken for a compute-bound one.
+    value = min(parse-only, compute-only): tf.data parses in background threads, the slower side sets the rate."""
+    import numpy as np
     import torch
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import deepctr_oracle as O
     cores = os.cpu_count() or 1
     cfg = O.Config(model=w["model"], field_size=w["field_size"], feature_size=w["feature_size"],
@@ -40,48 +56,125 @@ def cpu_baseline(w, seconds_budget=18.0):
                    l2_reg=w["l2_reg"], learning_rate=w["learning_rate"], optimizer=w["optimizer"])
     p = O.init_params(cfg, seed=1, scale=0.01)
     opt = O.Optimizer(cfg, p)
-    B = w["batch"]
-    batches = [O.synth_batch(B, cfg.field_size, cfg.feature_size, seed=20260924 + i) for i in range(4)]
-    best_nt, best_t = 1, float("inf")
-    for nt in sorted({min(cores, n) for n in (8, 16, 32)}):
+    B, F = w["batch"], w["field_size"]
+    batches = [O.synth_batch(B, F, cfg.feature_size, seed=20260924 + i) for i in range(4)]
+    sweep, best_nt, best_t = {}, 1, float("inf")
+    nts = sorted({min(cores, n) for n in (8, 16, 32, 64, 128, 256)} | {cores})
+    for nt in nts:
         torch.set_num_threads(nt)
         O.train_step(cfg, p, opt, *batches[0])
         t0 = time.perf_counter()
-        for i in range(2):
+        for i in range(3):
             O.train_step(cfg, p, opt, *batches[i % 4])
-        t = (time.perf_counter() - t0) / 2
+        t = (time.perf_counter() - t0) / 3
+        sweep[nt] = round(B / t, 1)
         if t < best_t:
             best_nt, best_t = nt, t
-    torch.set_num_threads(best_nt)
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        O.train_step(cfg, p, opt, *batches[n % 4])
-        n += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 400:
+        if t > 3 * best_t:           # far past the optimum: more threads only get slower on the memory-bound table passes
             break
-    return {"value": round(B * n / el, 1), "unit": "examples/sec", "cores": best_nt, "kind": "port",
-            "sample": "%d train steps of the same workload (batch %d), torch-CPU fp32 restatement of the TF-1.4 graph (dense table "
-                      "gradient + dense Adam over all rows), %d threads = best of {8,16,32} on a %d-core host" % (n, B, best_nt, cores)}
+    torch.set_num_threads(best_nt)
+    for i in range(warmup):
+        O.train_step(cfg, p, opt, *batches[i % 4])
+    ts = []
+    for i in range(steps):
+        t0 = time.perf_counter()
+        O.train_step(cfg, p, opt, *batches[i % 4])
+        ts.append(time.perf_counter() - t0)
+    compute = B / float(np.median(ts))
+    # parse-only: the libsvm text of the same batches, 10 worker threads over line chunks
+    text = [O.to_libsvm(*b) for b in batches[:2]]
+
+    def parse_chunk(lines):
+        lab = np.empty(len(lines), np.float32)
+        ids = np.empty((len(lines), F), np.int32)
+        vals = np.empty((len(lines), F), np.float32)
+        for r, ln in enumerate(lines):
+            tok = ln.split(" ")
+            lab[r] = float(tok[0])
+            kv = [t.split(":") for t in tok[1:]]
+            ids[r] = [int(a) for a, _ in kv]
+            vals[r] = [float(b) for _, b in kv]
+        return ids, vals, lab
+
+    pool = ThreadPoolExecutor(10)
+    pt = []
+    for rep in range(4):
+        lines = text[rep % 2].rstrip("\n").split("\n")
+        chunks = [lines[i::10] for i in range(10)]
+        t0 = time.perf_counter()
+        list(pool.map(parse_chunk, chunks))
+        pt.append(time.perf_counter() - t0)
+    pool.shutdown()
+    parse = B / float(np.median(pt))
+    return {"value": round(min(parse, compute), 1), "unit": "examples/sec", "cores": best_nt, "kind": "port",
+            "compute_only": round(compute, 1), "parse_only": round(parse, 1), "thread_sweep_examples_per_sec": sweep,
+            "sample": "torch-CPU fp32 restatement of the TF-1.4 reference graph (TF not installable): %d warm-up + %d timed train steps "
+                      "of the same workload (batch %d), MEDIAN step; dense table gradient + dense Adam over all rows; %d threads = best "
+                      "of the sweep %s on a %d-core host; parse-only = Python split/float parse of the same libsvm lines on 10 "
+                      "worker threads; value = min(parse-only, compute-only)" % (warmup, steps, B, best_nt, list(sweep), cores)}
 
 
-def pmc_traffic_bytes(kernel_substr):
-    """HBM bytes per launch of a kernel from the committed PMC summary (collected by tools/profile_round.sh in separate
-    --pmc passes; a live bench run cannot sample counters).  None when the summary is absent."""
-    import re
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.txt")
+def pmc_traffic_bytes(kernel_name):
+    """HBM bytes per launch of ONE kernel (exact demangled-name match, template arguments included) from the committed PMC
+    summary (collected by tools/profile_round.sh in separate --pmc passes: a live bench run cannot sample counters).
+    bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE counts half of the 16-B/lane streams; MI355X_MICROARCH.md
+    HBM section).  None when the summary is absent or does not list the kernel."""
+    path = os.path.join(ROOT, PMC_FILE)
     if not os.path.exists(path):
         return None
-    f = w = 0.0
     for line in open(path):
-        if kernel_substr in line:
+        if line.startswith(kernel_name + "("):          # the name with its template arguments, then the argument list
             mf = re.search(r"FETCH_SIZE=([0-9.e+]+)", line)
             mw = re.search(r"WRITE_SIZE=([0-9.e+]+)", line)
             if mf and mw:
-                f += float(mf.group(1))
-                w += float(mw.group(1))
-    return int((2 * f + w) * 1024) if (f or w) else None
+                return int((2 * float(mf.group(1)) + float(mw.group(1))) * 1024)
+    return None
+
+
+def fill_normal_(t, scale, seed):
+    """In-place N(0, scale) on the device, in chunks (c5's 12.8 GB table never exists on the host)."""
+    import torch
+    g = torch.Generator(device=t.device)
+    g.manual_seed(seed)
+    flat = t.view(-1)
+    step = 1 << 28
+    for s in range(0, flat.numel(), step):
+        flat[s:s + step].normal_(0.0, scale, generator=g)
+
+
+def hbm_resident_gather(dev, K=16, V=64 * 1024 * 1024, B=4096, F=39, iters=200):
+    """The gather kernel alone on a table far larger than the 256 MB Infinity Cache (V = 64 M rows x K = 16: 4.3 GB) with uniform
+    ids: algorithmic bytes B (F (12 + 8K) + 8) over the hipEvent time of back-to-back launches through the op-level C ABI."""
+    import torch
+    from tf_repos_amd import capi
+    L = capi.lib()
+    emb = torch.zeros(V, K, device=dev)
+    lin = torch.zeros(V, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    nb = 8
+    ids = [torch.randint(0, V, (B, F), device=dev, dtype=torch.int32, generator=g) for _ in range(nb)]
+    vals = torch.rand(B, F, device=dev)
+    e = torch.empty(B, F * K, device=dev)
+    yw, yv, S = torch.empty(B, device=dev), torch.empty(B, device=dev), torch.empty(B, K, device=dev)
+    status = torch.zeros(4, dtype=torch.int32, device=dev)
+    st = capi.current_stream()
+
+    def launch(i):
+        capi.check(L.dctr_embed_gather_fwd(capi.ptr(emb), capi.ptr(lin), V, capi.ptr(ids[i % nb]), capi.ptr(vals), B, F, K, 1, capi.ptr(e), F * K,
+                                           capi.ptr(yw), capi.ptr(S), capi.ptr(yv), capi.ptr(status), st))
+    for i in range(10):
+        launch(i)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        launch(i)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    del emb, lin
+    torch.cuda.empty_cache()
+    return ms, B * (F * (12 + 8 * K) + 8)
 
 
 def main():
@@ -94,8 +187,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--table-mode", default="dense_exact", choices=["dense_exact", "touched_rows"])
+    ap.add_argument("--driver", default=os.environ.get("DCTR_SHARD_DRIVER", "native"), choices=["native", "python"],
+                    help="multi-GPU step driver: the C++ one over RCCL (default) or the torch.distributed orchestration; no fallback")
+    ap.add_argument("--selftest", action="store_true", help="multi-GPU: first check that the N-rank loss of step 0 equals one rank's on the same global batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=200)
     ap.add_argument("--uniform-ids", action="store_true", help="uniform ids instead of Zipf (cache-worst case)")
     args = ap.parse_args()
 
@@ -111,8 +209,11 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    w = dict(WORKLOAD)
-    B = w["batch"]
+    w = dict(CONFIGS[args.config])
+    if args.selftest:
+        w["dropout"] = tuple(1.0 for _ in w["dropout"])     # (a dropout mask is indexed by the LOCAL row: N ranks and one rank draw different masks)
+    B, F, K, V = w["batch"], w["field_size"], w["embedding_size"], w["feature_size"]
+    big = V * (K + 1) * 4 > (2 << 30)           # tables that must be initialised on the device
 
     sharded = world > 1 or bool(os.environ.get("DCTR_FORCE_SHARDED"))     # the env var exercises the RCCL path on one GPU
     if sharded:
@@ -122,23 +223,25 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        try:
-            trainer = ShardedTrainer(w, rank, world, dev, table_mode=args.table_mode)        # native C++ driver over RCCL
-        except Exception as e:                                                                # noqa: BLE001
-            # the same row-sharded protocol orchestrated from Python through torch.distributed (slower host side, same results)
-            print("rank %d: native sharded driver unavailable (%s); using the torch.distributed driver" % (rank, e), file=sys.stderr, flush=True)
-            trainer = ShardedTrainer(w, rank, world, dev, table_mode=args.table_mode, driver="python")
+        # (no silent fallback: a native driver that cannot start is an error, and the JSON line says which driver ran)
+        trainer = ShardedTrainer(w, rank, world, dev, table_mode=args.table_mode, driver=args.driver, init_tables=not big)
+        if big:                                  # c5: tables drawn on the device, shard by shard
+            for name in ("emb", "linear"):
+                fill_normal_(trainer.eng.param_tensor(name), 0.01, 1000 + rank)
+        eng = trainer.eng
         step = lambda i, v, l, nxt: trainer.train_step(i, v, l, next_ids=nxt)      # routes the next batch's ids a step ahead
         barrier = dist.barrier
     else:
-        eng = Engine(EngineConfig(model=w["model"], field_size=w["field_size"], feature_size=w["feature_size"],
-                                  embedding_size=w["embedding_size"], deep_layers=w["deep_layers"], dropout=w["dropout"],
-                                  l2_reg=w["l2_reg"], learning_rate=w["learning_rate"], optimizer=w["optimizer"],
+        eng = Engine(EngineConfig(model=w["model"], field_size=F, feature_size=V, embedding_size=K, deep_layers=w["deep_layers"],
+                                  dropout=w["dropout"], l2_reg=w["l2_reg"], learning_rate=w["learning_rate"], optimizer=w["optimizer"],
                                   table_mode=args.table_mode, max_batch=B, seed=1,
                                   use_graph=os.environ.get("DCTR_USE_GRAPH", "0") == "1"))
         rng = np.random.default_rng(1)
         for name, shp in eng.param_shapes.items():
-            eng.set_param(name, rng.normal(0, 0.01, size=shp).astype(np.float32))
+            if big and name in ("emb", "linear"):
+                fill_normal_(eng.param_tensor(name), 0.01, 1000)
+            else:
+                eng.set_param(name, rng.normal(0, 0.01, size=shp).astype(np.float32))
         step = lambda i, v, l, nxt: eng.train_step(i, v, l, want_loss=False)
         barrier = lambda: None
 
@@ -157,22 +260,51 @@ def main():
 
     nb = 8
     batches = []
+    host_batches = []
     for i in range(nb):
-        ids, vals, labels = synth_batch(B, w["field_size"], w["feature_size"], seed=20260924 + 1 + rank * 1000 + i,
-                                        uniform_ids=args.uniform_ids)
+        ids, vals, labels = synth_batch(B, F, V, seed=20260924 + 1 + rank * 1000 + i, uniform_ids=args.uniform_ids)
+        if i == 0:
+            host_batches.append((ids, vals, labels))
         t = (torch.from_numpy(ids).to(dev), torch.from_numpy(vals).to(dev), torch.from_numpy(labels).to(dev))
         # resident inputs: the 8 synthetic batches live in the engine's 8 input slots (what the input pipeline's H2D copy
         # targets), so a step reads them in place
-        si, sv, sl = (trainer.eng if sharded else eng).input_slot(i)
+        si, sv, sl = eng.input_slot(i)
         si[:B].copy_(t[0]); sv[:B].copy_(t[1]); sl[:B].copy_(t[2])
-        t = (si[:B], sv[:B], sl[:B])
-        batches.append(t)
+        batches.append((si[:B], sv[:B], sl[:B]))
+
+    if args.selftest:
+        # N ranks on the global batch of step 0 == ONE rank on the same global batch, over the real transport (keep_prob 1; both
+        # sides draw the weights from seed 1).  A check, not a measurement: prints its own JSON line and exits.
+        if not sharded or big:
+            raise SystemExit("--selftest needs --gpus N > 1 (or DCTR_FORCE_SHARDED=1) and a config whose table fits one GPU twice (c2)")
+        import torch.distributed as dist
+        gathered = [None] * world
+        dist.all_gather_object(gathered, host_batches[0])
+        loss_n = trainer.train_step(*batches[0], want_loss=True, next_ids=batches[1][0])
+        ok, loss_1 = True, None
+        if rank == 0:
+            gi, gv, gl = (np.concatenate([g[k] for g in gathered]) for k in range(3))
+            ref = Engine(EngineConfig(model=w["model"], field_size=F, feature_size=V, embedding_size=K, deep_layers=w["deep_layers"],
+                                      dropout=w["dropout"], l2_reg=w["l2_reg"], learning_rate=w["learning_rate"],
+                                      optimizer=w["optimizer"], table_mode=args.table_mode, max_batch=B * world, seed=1))
+            r1 = np.random.default_rng(1)
+            for name, shp in ref.param_shapes.items():
+                ref.set_param(name, r1.normal(0, 0.01, size=shp).astype(np.float32))
+            loss_1 = ref.train_step(torch.from_numpy(gi).to(dev), torch.from_numpy(gv).to(dev), torch.from_numpy(gl).to(dev))
+            ref.close()
+            ok = abs(loss_n - loss_1) <= 1e-5 * max(1.0, abs(loss_1))
+            os.write(real_stdout, (json.dumps({"selftest": "ok" if ok else "MISMATCH", "n_gpus": world, "driver": args.driver,
+                                               "loss_n_ranks": loss_n, "loss_one_rank": loss_1, "global_batch": B * world}) + "\n").encode())
+        done.set()
+        trainer.close()
+        dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
 
     for s in range(args.warmup):
         step(*batches[s % nb], batches[(s + 1) % nb][0])
     barrier()
     torch.cuda.synchronize()
-    (trainer.eng if sharded else eng).step_timer(True)          # hipEvents around the roofline kernel inside the timed steps
+    eng.step_timer(True)          # hipEvents around the roofline kernel inside the timed steps
     t0 = time.perf_counter()
     for s in range(args.steps):
         step(*batches[(args.warmup + s) % nb], batches[(args.warmup + s + 1) % nb][0])
@@ -180,7 +312,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    in_ms, in_n = (trainer.eng if sharded else eng).step_timer(False)
+    in_ms, in_n = eng.step_timer(False)
     if sharded:
         import torch.distributed as dist
         t = torch.tensor([el], device=dev, dtype=torch.float64)
@@ -190,29 +322,27 @@ def main():
     out = None
     if rank == 0:
         out = {
-            "metric": "examples/sec DeepFM Criteo-39-field batch 4096", "value": round(B * world * args.steps / el, 1),
+            "metric": "examples/sec DeepFM Criteo-39-field batch %d" % B, "value": round(B * world * args.steps / el, 1),
             "unit": "examples/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * el / args.steps, 4), "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 4),
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic Criteo-shaped (Zipf categorical ids), random-init weights",
-            "config": {"workload": "DeepFM 39 fields, vocab 1e6, emb_dim 16, batch 4096/GPU, MLP 400-400-400 keep 0.5, Adam "
-                                   "(BASELINE configs[1])", "global_batch": B * world, "table_mode": args.table_mode,
+            "config": {"workload": w["name"], "config": args.config, "global_batch": B * world, "table_mode": args.table_mode,
                        "parallelism": "single GPU" if world == 1 else "row-sharded tables (id %% %d) + data-parallel dense" % world,
+                       "driver": ("single-GPU engine" if not sharded else args.driver + (" (C++ step driver over RCCL)" if args.driver == "native" else " (torch.distributed orchestration)")),
                        "ids": "uniform" if args.uniform_ids else "zipf"},
         }
-    if rank == 0:
         # ---- per-stage timing (hipEvents around a graph of back-to-back launches, on torch's current stream)
-        F, K, V = w["field_size"], w["embedding_size"], w["feature_size"]
-        e = trainer.eng if sharded else eng
+        e = eng
         rows = (V + world - 1) // world                            # rows of this rank's table shard
         names = ["opt_table", "mlp0_fwd", "mlp0_dgrad", "mlp0_wgrad"]
         if not sharded:
             names = ["embed_gather", "forward", "head", "backward_dense", "group_ids", "scatter", "opt_dense"] + names
-        stages = {name: e.time_stage(name, iters=30) for name in names}
+        stages = {name: e.time_stage(name, iters=(30 if not big else 3)) for name in names}
         gather_bytes = B * (F * (12 + 8 * K) + 8)                 # algorithmic bytes of the gather
         # dense-exact table step as implemented: theta,m,v read + write (6 streams) + the 4-byte slot word per row; the per-row
         # gradient is NOT a dense stream here (only the ~U touched rows read a compact gradient row), so SURVEY 8d's 7-stream
-        # figure (7*V*(K+1)*4 = 476 MB) would flatter the kernel -- 6 streams (412 MB) is what the algorithm must move
+        # figure (7*V*(K+1)*4) would flatter the kernel -- 6 streams is what the algorithm must move
         table_bytes = 6 * rows * (K + 1) * 4 + 4 * rows
         mlp0_flops = 2.0 * B * (F * K) * w["deep_layers"][0]
         kernels = {
@@ -226,8 +356,13 @@ def main():
                                 "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s"},
         }
         if not sharded:
-            kernels["embed_gather_fwd"] = {"bound": "hbm", "ms": stages["embed_gather"], "achieved": gather_bytes / stages["embed_gather"] / 1e6,
-                                           "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+            kernels["embed_gather_fwd_step_table"] = {"bound": "hbm", "ms": stages["embed_gather"], "achieved": gather_bytes / stages["embed_gather"] / 1e6,
+                                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                      "note": "the step's own table (%d MB%s)" % (V * (K + 1) * 4 >> 20, ", resident in the 256 MB Infinity Cache" if V * (K + 1) * 4 < (256 << 20) else "")}
+            if not big:
+                g_ms, g_bytes = hbm_resident_gather(dev, K=K, B=B, F=F)
+                kernels["embed_gather_fwd"] = {"bound": "hbm", "ms": g_ms, "achieved": g_bytes / g_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                               "note": "HBM-resident: 64 M-row table (4.3 GB), uniform ids, the op through the C ABI, back-to-back launches"}
         copy_gbps = e.measure_copy_bandwidth(1 << 30, 20)          # this box's measured HBM roofline (1 GiB float4 copy, read + write)
         out["hbm_measured_copy_GBps"] = round(copy_gbps, 1)
         for k in kernels.values():
@@ -236,28 +371,34 @@ def main():
             k["frac"] = round(k["achieved"] / k["peak"], 4)
             k["achieved"] = round(k["achieved"], 2)
             k["ms"] = round(k["ms"], 5)
-        # the dominant kernel family of the step is the MLP GEMM (half of the kernel time; the dense-exact table pass, once the
-        # longest single launch, now runs as a background kernel under the GEMMs).  `roofline` is the first layer's forward GEMM
-        # (4096 x 624 x 400) AS IT RUNS IN THE TIMED STEPS: hipEvents on the step's stream around that launch (dctr_step_timer);
-        # `kernels` holds the same kernels timed alone, back to back.
+        # the dominant kernel family of the step is the MLP GEMM (half of the kernel time; the dense-exact table pass runs as a
+        # background kernel under the GEMMs).  `roofline` is the first layer's forward GEMM (B x F*K x 400) AS IT RUNS IN THE
+        # TIMED STEPS: hipEvents on the step's stream around that launch (dctr_step_timer); `kernels` holds the same kernels
+        # timed alone, back to back.
         dom = "mlp0_fwd_gemm"
         r = dict(kernels[dom])
-        r["kernel"] = dom + " (gemm_f32_mfma<true,true,1>, layer 0: 4096x624x400)"
+        gemm_name = "void dctr::gemm_dr_kernel<2, 13, true, false, false, 1>" if os.environ.get("DCTR_GEMM", "fw").find("f") >= 0 and os.environ.get("DCTR_GEMM") != "lds" else "void dctr::gemm_f32_mfma<true, true, 1>"
+        r["kernel"] = "%s (%s, layer 0: %dx%dx%d)" % (dom, gemm_name.replace("void dctr::", ""), B, F * K, w["deep_layers"][0])
         if in_n > 0:
             r["ms_alone"] = r["ms"]
             r["ms"] = round(in_ms, 5)
             r["achieved"] = round(mlp0_flops / in_ms / 1e9, 2)
             r["frac"] = round(r["achieved"] / r["peak"], 4)
             r["launches_timed"] = in_n
-        r["traffic"] = None
-        r["hbm_kernel"] = dict(kernels["opt_table_dense_adam"], traffic=pmc_traffic_bytes("opt_table_kernel") if not sharded else None)
-        r["traffic_source"] = "profiles/r01_pmc_traffic.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts 1/2 of 16-B/lane streams; MI355X_MICROARCH.md HBM section)"
+        # HBM bytes per launch of exactly this kernel (PMC passes of tools/profile_round.sh, committed under profiles/)
+        r["traffic"] = pmc_traffic_bytes(gemm_name) if (not sharded and args.config == "c2") else None
+        r["algorithmic_bytes"] = int(4 * (B * F * K + F * K * w["deep_layers"][0] + B * w["deep_layers"][0]))
+        hk = dict(kernels["opt_table_dense_adam"])
+        hk["traffic"] = pmc_traffic_bytes("void dctr::opt_table_kernel<0, 4, true>") if (not sharded and args.config == "c2") else None
+        r["hbm_kernel"] = hk
+        r["traffic_source"] = PMC_FILE + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch of the exactly named kernel (gfx950 FETCH_SIZE counts 1/2 of 16-B/lane streams; MI355X_MICROARCH.md HBM section)"
         out["roofline"] = r
         out["kernels"] = kernels
         out["stage_ms"] = {k: round(v, 5) for k, v in stages.items()}
-        if not sharded and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w)
+        if not sharded and not args.no_cpu_baseline and not big:
+            out["cpu_baseline"] = cpu_baseline(w, steps=args.cpu_steps)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            out["speedup_vs_cpu_compute_only"] = round(out["value"] / out["cpu_baseline"]["compute_only"], 1)
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     done.set()

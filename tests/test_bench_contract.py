@@ -1,4 +1,4 @@
-"""The bench line's contract, checked on the committed line of the round (profiles/r01_bench.json, produced by `python bench.py`
+"""The bench line's contract, checked on the committed line of the round (profiles/r02_bench.json, produced by `python bench.py`
 on the GPU box): the keys the driver and the judge read, their types, and the internal consistency of the derived figures."""
 import json
 import os
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_honours_the_contract():
-    lines = [l for l in open(os.path.join(ROOT, "profiles", "r01_bench.json")).read().splitlines() if l.strip()]
+    lines = [l for l in open(os.path.join(ROOT, "profiles", "r02_bench.json")).read().splitlines() if l.strip()]
     assert len(lines) == 1                                  # ONE JSON line on stdout
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -27,3 +27,6 @@ def test_committed_bench_line_honours_the_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0
+    # parse-only and compute-only reported beside the value; the multi-GPU driver is named
+    assert c["compute_only"] > 0 and c["parse_only"] > 0 and c["value"] <= min(c["compute_only"], c["parse_only"]) + 1e-6
+    assert "driver" in d["config"] and d["config"]["config"] in ("c2", "c5")

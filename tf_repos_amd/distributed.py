@@ -142,8 +142,9 @@ class ShardedTrainer:
 
     def __init__(self, workload: Dict, rank: int, world: int, device: torch.device, table_mode: str = "dense_exact",
                  seed: int = 1, group=None, init_scale: float = 0.01, params: Optional[Dict[str, np.ndarray]] = None,
-                 overlap: Optional[bool] = None, driver: Optional[str] = None):
+                 overlap: Optional[bool] = None, driver: Optional[str] = None, init_tables: bool = True):
         self.w = dict(workload)
+        self.init_tables = init_tables        # False: the caller fills the table shards on the device (a 1e8-row table never exists on the host)
         self.rank, self.world, self.dev = rank, world, device
         self.comm = Comm(group)
         assert self.comm.world == world and self.comm.rank == rank
@@ -229,6 +230,8 @@ class ShardedTrainer:
         full_rows = self.V
         for name, shp in self.eng.param_shapes.items():
             if name in ("emb", "linear"):
+                if not self.init_tables and params is None:
+                    continue
                 full = (full_rows,) + tuple(shp[1:])
                 a = params[name] if params is not None else rng.normal(0, scale, size=full).astype(np.float32)
                 self.eng.set_param(name, np.ascontiguousarray(np.asarray(a)[self.rank::self.world]))

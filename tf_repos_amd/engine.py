@@ -284,6 +284,20 @@ class Engine:
         capi.check(capi.lib().dctr_measure_copy_bw(int(nbytes), int(iters), C.byref(g), st))
         return g.value
 
+    def param_tensor(self, name: str):
+        """Zero-copy torch view of a parameter in device memory (dctr_param_device_ptr): device-side initialisation of tables that
+        are too large to stage through the host."""
+        import torch
+        p = C.c_void_p()
+        capi.check(self._lib.dctr_param_device_ptr(self._h, name.encode(), C.byref(p)))
+        shape = tuple(int(d) for d in self.param_shapes[name])
+
+        class _A:
+            pass
+        a = _A()
+        a.__cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (p.value, False), "version": 2}
+        return torch.as_tensor(a, device=torch.device("cuda", torch.cuda.current_device()))
+
     def debug_tensor(self, name: str):
         """Device view (torch) of a named intermediate of the last forward."""
         import torch
