@@ -157,3 +157,99 @@ def test_c4_outer_pnn_at_k32(dev):
     for k in ("mlp0/weights", "mlp0/biases", "deep_out/weights", "bias"):
         assert np.abs(got[k] - params[k].numpy()).max() <= 2e-6, k
     eng.close()
+
+
+def test_c1_reference_operating_point_full_size(dev):
+    """BASELINE configs[0] / deep_ctr/README.md:49 as documented: DeepFM, feature_size 117581, B=256, K=8, 400-400-400, Adam 5e-4."""
+    ocfg, params, eng = make_pair("deepfm", B=256, F=F, V=117581, K=8, layers=(400, 400, 400), opt="Adam", l2=1e-4, lr=5e-4, scale=0.01,
+                                  use_graph=False)
+    oopt = O.Optimizer(ocfg, params)
+    for s in range(3):
+        ids, vals, labels = O.synth_batch(256, F, 117581, seed=100 + s)
+        d = dev_batch(ids, vals, labels, dev)
+        if s == 0:
+            ref = O.forward(ocfg, params, ids, vals)
+            logit, prob = torch.empty(256, device=dev), torch.empty(256, device=dev)
+            eng.predict(d[0], d[1], prob, logit)
+            assert np.abs(logit.cpu().numpy() - ref["y"].numpy()).max() <= 1e-4
+        ref_loss, _ = O.train_step(ocfg, params, oopt, ids, vals, labels)
+        loss = eng.train_step(*d)
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+    got = eng.get_params()
+    for k, v in params.items():
+        assert np.abs(got[k] - v.numpy()).max() <= 2e-6, k
+    eng.close()
+
+
+def test_afm_at_the_reference_operating_point(dev):
+    """AFM.py:44,52 / run.sh:18: embedding_size 256, attention_layers '256' (the fused attention kernels stop at K = 32: this is
+    the unfused path), batch 128 as the script's default."""
+    B, K, A = 128, 256, 256
+    ocfg, params, eng = make_pair("afm", B=B, F=F, V=20000, K=K, layers=(1,), att=(A,), opt="Adagrad", l2=1e-3, lr=1e-2, scale=0.02,
+                                  use_graph=False, keep=(1.0, 1.0))
+    ids, vals, labels = O.synth_batch(B, F, 20000, seed=9)
+    d = dev_batch(ids, vals, labels, dev)
+    ref = O.forward(ocfg, params, ids, vals)
+    logit, prob = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    eng.predict(d[0], d[1], prob, logit)
+    assert np.abs(logit.cpu().numpy() - ref["y"].numpy()).max() <= 1e-4
+    oopt = O.Optimizer(ocfg, params)
+    ref_loss, _ = O.train_step(ocfg, params, oopt, ids, vals, labels)
+    loss = eng.train_step(*d)
+    assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+    got = eng.get_params()
+    for k, v in params.items():       # (Adagrad, as test_afm_attention_widths: Adam would turn fp32 noise on the near-zero attention gradients into lr-sized steps)
+        assert np.abs(got[k] - v.numpy()).max() <= 2e-6, k
+    eng.close()
+
+
+def test_c5_shape_one_step_properties(dev):
+    """BASELINE configs[4] on one GPU: vocab 1e8, K = 32 (13.2 GB of parameters + 26.4 GB of Adam state).  The oracle cannot hold
+    this table, so the step is checked through a size-independent property: the rows the batch touches must end up exactly where
+    a COMPACT engine (vocabulary = the batch's distinct ids, same initial rows, same dense weights) puts them, and untouched rows
+    must follow the closed form of one dense Adam step on the pure l2 gradient."""
+    from tf_repos_amd.engine import Engine, EngineConfig
+    V5, K, B = 100_000_000, 32, 8192
+    kw = dict(model="deepfm", field_size=F, embedding_size=K, deep_layers=(400, 400, 400), dropout=(1.0, 1.0, 1.0), l2_reg=1e-4,
+              learning_rate=5e-4, optimizer="Adam", max_batch=B, seed=1)
+    big = Engine(EngineConfig(feature_size=V5, **kw))
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    for name in ("emb", "linear"):
+        t = big.param_tensor(name).view(-1)
+        for s in range(0, t.numel(), 1 << 28):
+            t[s:s + (1 << 28)].normal_(0.0, 0.01, generator=g)
+    rng = np.random.default_rng(2)
+    dense = {n: rng.normal(0, 0.01, size=shp).astype(np.float32) for n, shp in big.param_shapes.items() if n not in ("emb", "linear")}
+    for n, a in dense.items():
+        big.set_param(n, a)
+    ids = np.random.default_rng(3).integers(0, V5, size=(B, F)).astype(np.int32)
+    ids[:, :13] = np.arange(1, 14)                                  # Criteo's numeric fields: every example hits ids 1..13
+    vals = np.random.default_rng(4).random((B, F)).astype(np.float32)
+    labels = (np.random.default_rng(5).random(B) < 0.3).astype(np.float32)
+    uniq, inv = np.unique(ids, return_inverse=True)
+    emb0 = big.param_tensor("emb")[torch.from_numpy(uniq).to(dev).long()].cpu().numpy()
+    lin0 = big.param_tensor("linear")[torch.from_numpy(uniq).to(dev).long()].cpu().numpy()
+    probe = np.setdiff1d(np.random.default_rng(6).integers(0, V5, size=64), uniq)          # untouched rows
+    pe0 = big.param_tensor("emb")[torch.from_numpy(probe).to(dev).long()].cpu().numpy().astype(np.float64)
+    small = Engine(EngineConfig(feature_size=len(uniq), **kw))
+    small.set_param("emb", emb0); small.set_param("linear", lin0)
+    for n, a in dense.items():
+        small.set_param(n, a)
+    d_big = dev_batch(ids, vals, labels, dev)
+    d_small = dev_batch(inv.reshape(B, F).astype(np.int32), vals, labels, dev)
+    loss_big, loss_small = big.train_step(*d_big), small.train_step(*d_small)
+    # the reported loss carries l2/2 * |table|^2 over ALL rows: compare the cross-entropy parts through the touched-row share only
+    emb1 = big.param_tensor("emb")[torch.from_numpy(uniq).to(dev).long()].cpu().numpy()
+    lin1 = big.param_tensor("linear")[torch.from_numpy(uniq).to(dev).long()].cpu().numpy()
+    assert np.abs(emb1 - small.get_param("emb")).max() <= 1e-6 and np.abs(lin1 - small.get_param("linear")).max() <= 1e-6
+    for n in dense:
+        assert np.abs(big.get_param(n) - small.get_param(n)).max() <= 1e-6, n
+    # untouched rows: g = l2 * theta; Adam step 1: m = .1 g, v = .001 g^2, lr_t = lr sqrt(1-.999)/(1-.9)
+    gpe = 1e-4 * pe0
+    lr_t = 5e-4 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    expect = pe0 - lr_t * (0.1 * gpe) / (np.sqrt(0.001 * gpe * gpe) + 1e-8)
+    pe1 = big.param_tensor("emb")[torch.from_numpy(probe).to(dev).long()].cpu().numpy()
+    assert np.abs(pe1 - expect).max() <= 1e-6
+    assert np.isfinite(loss_big) and np.isfinite(loss_small)
+    big.close(); small.close()
