@@ -180,6 +180,9 @@ int dctr_parse_csv_mt(const char* h_text, size_t nbytes, int n_cols, const int8_
 int dctr_tfrecord_scan(const uint8_t* h_buf, size_t nbytes, int64_t max_records, int verify_crc, int64_t* rec_off,
                        int64_t* rec_len, int64_t* n_records, size_t* n_consumed);
 int dctr_tfrecord_frame(const uint8_t* h_payload, size_t nbytes, uint8_t* h_out);
+/* crc32c (Castagnoli) of a host buffer; masked = TF's ((crc >> 15 | crc << 17) + 0xa282ead8), the checksum of TFRecord framing
+ * and of the tensors / table blocks of a TF checkpoint bundle (the Saver behind Estimator's model_dir, DeepFM.py:288,341). */
+int dctr_crc32c(const uint8_t* h_buf, size_t nbytes, int masked, uint32_t* h_crc);
 /* one entry of the slot layout = one feature of the script's parse spec and where it lands in the MLP input:
  *   fixed_len  > 0: FixedLenFeature([n], int64)  -> n slots of one entry each, weight 1   ("feat_ids", DIN.py:63)
  *   fixed_len == 0: FixedLenFeature([], int64)   -> one slot, one entry                   ("a_catids",  DIN.py:73)

@@ -206,3 +206,26 @@ def test_engine_hyperparameters_come_from_the_train_graph_whatever_the_call_orde
     for ename, tfname in inv.items():
         assert np.abs(est.get_variable_value(tfname) - params0[ename].numpy()).max() <= 5e-6, tfname
     assert est._engine.global_step == 8
+
+
+@pytest.mark.gpu
+def test_estimator_resumes_from_a_tensorflow_checkpoint_bundle(tmp_path, dev):
+    """model_dir holding only model.ckpt-N.index/.data-* + `checkpoint` (what a TF run of the reference leaves): variables and
+    Adam slots come back by TF names, training continues exactly as from this package's own checkpoint."""
+    mod = _load_example()
+    F_, V, K, B = 39, 1500, 8, 64
+    ids, vals, labels = O.synth_batch(3 * B, F_, V, seed=21)
+    (tmp_path / "tr.libsvm").write_text(O.to_libsvm(ids, vals, labels))
+    p = dict(model="deepfm", field_size=F_, feature_size=V, embedding_size=K, learning_rate=0.01, l2_reg=1e-3, deep_layers="16,8",
+             dropout="1.0,1.0", cross_layers=2, optimizer="Adam")
+    tr_fn = lambda: mod.input_fn([str(tmp_path / "tr.libsvm")], num_epochs=1, batch_size=B)
+    est = mod.build_estimator(p, str(tmp_path / "a"))
+    est.train(input_fn=tr_fn)
+    prefix = est.export_tf_checkpoint(str(tmp_path / "tfdir" / "model.ckpt-3"))
+    assert os.path.exists(prefix + ".index") and os.path.exists(prefix + ".data-00000-of-00001") and os.path.exists(str(tmp_path / "tfdir" / "checkpoint"))
+    est2 = mod.build_estimator(p, str(tmp_path / "tfdir"))
+    est2.train(input_fn=tr_fn)            # restores from the bundle, then 3 more steps
+    est.train(input_fn=tr_fn)             # the original continues from its live state
+    assert est2._engine.global_step == est._engine.global_step == 6
+    for name in est.get_variable_names():
+        assert np.array_equal(est2.get_variable_value(name), est.get_variable_value(name)), name

@@ -170,6 +170,13 @@ using namespace dctr;
 
 extern "C" {
 
+int dctr_crc32c(const uint8_t* h_buf, size_t nbytes, int masked, uint32_t* h_crc) {
+    DCTR_REQUIRE(h_crc != nullptr && (h_buf != nullptr || nbytes == 0), "null argument");
+    crc_init();
+    *h_crc = masked ? masked_crc(h_buf, nbytes) : crc32c(h_buf, nbytes);
+    return DCTR_OK;
+}
+
 int dctr_tfrecord_scan(const uint8_t* h_buf, size_t nbytes, int64_t max_records, int verify_crc, int64_t* rec_off, int64_t* rec_len,
                        int64_t* n_records, size_t* n_consumed) {
     DCTR_REQUIRE(h_buf != nullptr || nbytes == 0, "null buffer");

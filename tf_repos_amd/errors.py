@@ -29,3 +29,8 @@ class InternalError(OpError):
 
 class UnimplementedError(OpError):
     pass
+
+
+class DataLossError(OpError):
+    """Unrecoverable data loss or corruption (tf.errors.DataLossError): a TFRecord or checkpoint checksum that does not match,
+    a truncated record."""

@@ -238,9 +238,9 @@ class Estimator:
             if tfname not in ck:
                 raise errors.NotFoundError("Key %s not found in checkpoint" % tfname)
             e.set_param(ename, np.asarray(ck[tfname]).reshape(e.param_shapes[ename]))
-            if tfname + "/slot0" in ck:
-                e.set_slot(ename, 0, np.asarray(ck[tfname + "/slot0"]).reshape(e.param_shapes[ename]))
-                e.set_slot(ename, 1, np.asarray(ck[tfname + "/slot1"]).reshape(e.param_shapes[ename]))
+            for which in (0, 1):
+                if tfname + "/slot%d" % which in ck:
+                    e.set_slot(ename, which, np.asarray(ck[tfname + "/slot%d" % which]).reshape(e.param_shapes[ename]))
         e.global_step = int(ck["global_step"]) if "global_step" in ck else 0
 
     def latest_checkpoint(self) -> Optional[str]:
@@ -250,8 +250,28 @@ class Estimator:
         return max(files, key=lambda f: int(f.rsplit("-", 1)[1].split(".")[0]))
 
     def _load_latest(self):
+        """The newest checkpoint of model_dir: this package's .npz, else a TensorFlow checkpoint bundle (model.ckpt-N.index +
+        .data-*), e.g. one a TF run of the reference left there -- read by variable name (tf_bundle.py)."""
         f = self.latest_checkpoint()
-        return dict(np.load(f)) if f else None
+        if f:
+            return dict(np.load(f))
+        from .. import tf_bundle
+        prefix = tf_bundle.latest_tf_checkpoint(self.model_dir)
+        if prefix is None:
+            return None
+        opt = (getattr(self, "_train_lowered", None) or self._lowered).config_kwargs.get("optimizer", "Adam") if (getattr(self, "_train_lowered", None) or self._lowered) else "Adam"
+        return tf_bundle.bundle_to_state(tf_bundle.read_bundle(prefix), opt)
+
+    def export_tf_checkpoint(self, prefix: Optional[str] = None) -> str:
+        """Writes the live variables (and optimizer slots, under TF's slot names) as a TensorFlow checkpoint bundle that
+        tf.train.Saver / tf.estimator can restore; returns the prefix."""
+        from .. import tf_bundle
+        snap = self._snapshot()
+        prefix = prefix or os.path.join(self.model_dir, "model.ckpt-%d" % int(snap["global_step"]))
+        tf_bundle.write_bundle(prefix, tf_bundle.state_to_bundle(snap, self._lowered.config_kwargs.get("optimizer", "Adam")))
+        with open(os.path.join(os.path.dirname(prefix), "checkpoint"), "w") as f:
+            f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (os.path.basename(prefix), os.path.basename(prefix)))
+        return prefix
 
     def _save(self) -> str:
         os.makedirs(self.model_dir, exist_ok=True)
