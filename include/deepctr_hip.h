@@ -367,7 +367,9 @@ int dctr_debug_tensor(dctr_handle h, const char* name, float** d_ptr, int64_t* n
 /* ---- row-sharded multi-GPU path: owner(id) = id % world, local row = id / world.  There is no reference
  * call site -- this replaces the async parameter-server push/pull of set_dist_env (DeepFM.py:237-282) with a
  * synchronous step whose only exchanges are three all-to-alls (distinct rows out, rows back, row gradients back) and
- * one all-reduce of the dense gradients, all issued by the host through torch.distributed (RCCL).
+ * one all-reduce of the dense gradients.  The step is enqueued natively (csrc/dist.hip, dctr_dist_train_step: RCCL resolved from the
+ * librccl already in the process, grouped send/recv on three communicators); the split API below is what that driver -- and the
+ * torch.distributed orchestration kept as a readable reference -- is built from.
  * Rows and row gradients cross the fabric as PACKED records of K+4 floats: K embedding floats | linear weight | 3 pad
  * (16-byte aligned; one all-to-all per direction covers both tables).
  * Requester side, on a dctr_group_t created over the GLOBAL id space (rows = feature_size):

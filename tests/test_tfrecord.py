@@ -109,7 +109,8 @@ def test_unpacked_lists_missing_features_and_errors(tmp_path):
     raw[20] ^= 0x01                                                             # flip a payload bit
     with pytest.raises(errors.InvalidArgumentError, match="checksum"):
         T.parse_slot_csr(bytes(raw), specs, ["y"], V)
-    # a truncated tail record is ignored (whole records only)
+    # a cut-off file is a DataLossError, as under tf.data.TFRecordDataset -- not a shorter dataset
     good = path.read_bytes()
-    off2, _ = T.scan(good + good[:10])
-    assert len(off2) == 1
+    with pytest.raises(errors.DataLossError, match="truncated"):
+        T.scan(good + good[:10])
+    assert len(T.scan(good + good)[0]) == 2

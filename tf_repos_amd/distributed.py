@@ -94,6 +94,7 @@ class Route:
     recv_rows: torch.Tensor                     # [n_recv] local rows requested from this rank, grouped by requester
     parity: int = 0
     ids_key: int = 0
+    ids_ref: object = None      # the prefetched ids tensor itself: a freed tensor's address can be handed to a new one
     event: Optional[object] = None              # recorded on the stream that computed the route
 
     @property
@@ -272,7 +273,7 @@ class ShardedTrainer:
         r = self.x_route.route(self.send_rows[par], self.counts[par], out=self.recv_rows[par])      # the one host sync
         capi.check(L.dctr_entry_index(g, capi.ptr(ids), B * self.F, capi.ptr(self.upos[par]), capi.ptr(self.idx[par]), st))
         capi.check(L.dctr_table_group_rows(self._h, par, capi.ptr(self.recv_rows[par]), r.n_recv, st))
-        r.parity, r.ids_key = par, ids.data_ptr()
+        r.parity, r.ids_key, r.ids_ref = par, ids.data_ptr(), ids
         return r
 
     def prefetch(self, next_ids: torch.Tensor) -> None:
@@ -291,7 +292,11 @@ class ShardedTrainer:
         self._ev_start = torch.cuda.Event()
         self._ev_start.record(torch.cuda.current_stream())
         r, self._pref = self._pref, None
-        if r is not None and r.ids_key == ids.data_ptr():
+        # a prefetched route belongs to THIS tensor (same storage, same view), not merely to its address: torch's caching allocator
+        # reuses freed addresses, and a new ids tensor at the old address with other contents must be routed afresh
+        if r is not None and (r.ids_ref is ids or (r.ids_ref is not None and r.ids_key == ids.data_ptr() and r.ids_ref.shape == ids.shape
+                                                   and r.ids_ref.untyped_storage().data_ptr() == ids.untyped_storage().data_ptr()
+                                                   and r.ids_ref._version == ids._version)):
             torch.cuda.current_stream().wait_event(r.event)
             return r
         if r is not None:                       # a prefetch for some other batch: wait for it, then drop it

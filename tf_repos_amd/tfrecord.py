@@ -134,7 +134,10 @@ def scan(buf: bytes, verify_crc: bool = True) -> Tuple[np.ndarray, np.ndarray]:
     """(payload offsets, payload lengths) of the whole records in buf."""
     lib = capi.lib()
     n = C.c_int64()
-    capi.check(lib.dctr_tfrecord_scan(buf, len(buf), -1, int(verify_crc), None, None, C.byref(n), None))
+    used = C.c_size_t()
+    capi.check(lib.dctr_tfrecord_scan(buf, len(buf), -1, int(verify_crc), None, None, C.byref(n), C.byref(used)))
+    if used.value != len(buf):          # TFRecordDataset raises DataLossError on a cut-off file; fewer examples is not an answer
+        raise errors.DataLossError("truncated record at %d: the file holds %d bytes behind its last whole record" % (used.value, len(buf) - used.value))
     off = np.empty(n.value, np.int64)
     ln = np.empty(n.value, np.int64)
     capi.check(lib.dctr_tfrecord_scan(buf, len(buf), n.value, 0, capi.ptr(off), capi.ptr(ln), C.byref(n), None))
@@ -188,7 +191,8 @@ class TFRecordSlotDataset:
                 with open(path, "rb") as f:
                     parts.append(parse_slot_csr(f.read(), self.specs, self.label_names, self.feature_size, self.verify_crc))
             base = np.cumsum([0] + [len(p[1]) for p in parts])
-            offsets = np.concatenate([parts[0][0][:1]] + [p[0][1:] + int(b) for p, b in zip(parts, base[:-1])]).astype(np.int32)
+            # global entry offsets in int64 (several files together can pass 2^31 entries; take() rebases every batch to int32)
+            offsets = np.concatenate([parts[0][0][:1].astype(np.int64)] + [p[0][1:].astype(np.int64) + int(b) for p, b in zip(parts, base[:-1])])
             self._data = (offsets, np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts]),
                           np.concatenate([p[3] for p in parts], axis=1))
         return self._data
