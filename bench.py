@@ -254,7 +254,12 @@ def main():
                 fill_normal_(eng.param_tensor(name), 0.01, 1000)
             else:
                 eng.set_param(name, rng.normal(0, 0.01, size=shp).astype(np.float32))
-        step = lambda i, v, l, nxt: eng.train_step(i, v, l, want_loss=False)
+        if os.environ.get("DCTR_BENCH_PREFETCH", "1") == "1":      # the input pipeline's hint: next batch's ids grouped a step ahead
+            def step(i, v, l, nxt):
+                eng.train_step(i, v, l, want_loss=False)
+                eng.prefetch_ids(nxt)
+        else:
+            step = lambda i, v, l, nxt: eng.train_step(i, v, l, want_loss=False)
         barrier = lambda: None
 
     # watchdog: a wedged collective (multi-GPU runs are launched by the driver, not from here) must end the job with a message,
@@ -342,7 +347,8 @@ def main():
             "config": {"workload": w["name"], "config": args.config, "global_batch": B * world, "table_mode": args.table_mode,
                        "parallelism": "single GPU" if world == 1 else "row-sharded tables (id %% %d) + data-parallel dense" % world,
                        "driver": ("single-GPU engine" if not sharded else (driver_note or (args.driver + (" (C++ step driver over RCCL)" if args.driver == "native" else " (torch.distributed orchestration)")))),
-                       "ids": "uniform" if args.uniform_ids else "zipf"},
+                       "ids": "uniform" if args.uniform_ids else "zipf",
+                       "next_batch_hint": bool(not sharded and os.environ.get("DCTR_BENCH_PREFETCH", "1") == "1")},
         }
         # ---- per-stage timing (hipEvents around a graph of back-to-back launches, on torch's current stream)
         e = eng

@@ -328,6 +328,12 @@ int dctr_train_step(dctr_handle h, const int32_t* d_ids, const float* d_vals, co
  * same pointers to dctr_train_step / dctr_predict / dctr_eval_batch pays no staging copy; any other pointers are copied
  * device-to-device into slot 0 first. */
 int dctr_input_slot(dctr_handle h, int slot, int32_t** d_ids, float** d_vals, float** d_labels);
+/* The input pipeline announces the NEXT training batch: its ids -- already written into one of the input slots, and left
+ * untouched until that dctr_train_step call -- are grouped (the de-duplication of the IndexedSlices gradient of
+ * embedding_lookup, DeepFM.py:126,130 / 213) during the tail of the step in flight instead of beside the next step's first MLP
+ * layer.  Purely a scheduling hint: results are identical with or without it; ids outside the input slots, CSR / canned /
+ * row-sharded handles are ignored. */
+int dctr_prefetch_ids(dctr_handle h, const int32_t* d_ids_next, int B);
 /* canned-estimator models: the dense (numeric-column) inputs [B, dense_size] f32 of the NEXT train/predict/eval call; the
  * buffer is read in place and must stay valid until that call's work has finished */
 int dctr_set_dense_input(dctr_handle h, const float* d_dense);

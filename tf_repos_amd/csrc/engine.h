@@ -58,7 +58,13 @@ struct dctr_engine {
     // tables
     float *emb = nullptr, *emb_s0 = nullptr, *emb_s1 = nullptr, *lin = nullptr, *lin_s0 = nullptr, *lin_s1 = nullptr;
     Group* group = nullptr;
-    Group* group_alt = nullptr;     // second owner-side grouping state of the row-sharded path (created on first use)
+    Group* group_alt = nullptr;     // second grouping state: owner side of the row-sharded path / the NEXT batch's ids grouped ahead
+    // dctr_prefetch_ids: group_alt holds the grouping of `pre_ids` (an input slot), enqueued on s_group behind ev_tail
+    const int32_t* pre_ids = nullptr;
+    int pre_B = 0;
+    bool pre_valid = false;
+    hipEvent_t ev_tail = nullptr;   // recorded on the main stream when the dense backward of the last step was enqueued
+    bool have_tail = false;
     // arena
     float *theta = nullptr, *as0 = nullptr, *as1 = nullptr, *gflat = nullptr, *parts = nullptr;
     int64_t arena_n = 0, parts_n = 0;

@@ -782,9 +782,13 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     static const bool bg_late = getenv("DCTR_BG_LATE") != nullptr;              // A/B knob: background table pass beside the backward
     static const int group_after = getenv("DCTR_GROUP_AFTER") ? atoi(getenv("DCTR_GROUP_AFTER")) : 0;   // A/B knob: 0 = after the gather, 1 = after MLP layer 0
     // the id grouping (and the background table pass behind it) on the grouping stream
+    // ids grouped ahead (dctr_prefetch_ids, during the tail of the previous step): the two grouping states change roles
+    const bool pregrouped = E->pre_valid && E->pre_ids == E->ids && E->pre_B == B && E->group_alt != nullptr && !E->cfg.use_graph;
+    E->pre_valid = false;
+    if (pregrouped) std::swap(E->group, E->group_alt);
     const std::function<int()> start_grouping = [&]() -> int {
         DCTR_TRY(fork(E, st, sg));          // not before the gather (its atomics slow a concurrent gather 4x)
-        DCTR_TRY(group_ids(E->group, E->ids, B, E->F, sg));
+        if (!pregrouped) DCTR_TRY(group_ids(E->group, E->ids, B, E->F, sg));
         if (split_table && !bg_late) DCTR_TRY(step_untouched_rows(E, sg));
         return DCTR_OK;
     };
@@ -809,6 +813,11 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     }
     const bool out_done = fused_opt && E->head_did_out_bwd;
     DCTR_TRY(backward_dense(E, B, st, sw, fused_opt, have_head_ev ? &head_ev : nullptr));
+    if (!E->cfg.use_graph) {                 // where a prefetched grouping of the next batch may start: beside scatter + table step
+        if (E->ev_tail == nullptr) DCTR_HIP_CHECK(hipEventCreateWithFlags(&E->ev_tail, hipEventDisableTiming));
+        DCTR_HIP_CHECK(hipEventRecord(E->ev_tail, st));
+        E->have_tail = true;
+    }
     if (!fused_opt) DCTR_TRY(fork(E, st, sw));          // (fused_opt: backward_dense ends with that fork)
     if (fused_opt) {
         // what is left of the dense arena: cross_w / cross_b (DCN), and the output layer + bias if they were not stepped above
@@ -952,6 +961,7 @@ int dctr_destroy(dctr_handle E) {
     if (E->s_group) hipStreamDestroy(E->s_group);
     if (E->s_wgrad) hipStreamDestroy(E->s_wgrad);
     if (E->s_opt) hipStreamDestroy(E->s_opt);
+    if (E->ev_tail) hipEventDestroy(E->ev_tail);
     delete E;
     return DCTR_OK;
 }
@@ -1034,6 +1044,20 @@ int dctr_train_step(dctr_handle E, const int32_t* d_ids, const float* d_vals, co
         *h_loss = sc[0] / (float)B + E->cfg.l2_reg * 0.5f * (sc[1] + sc[2] + sc[3]);
         if (E->cfg.loss_sum) *h_loss = sc[0];       // canned heads report the batch SUM, no regulariser
     }
+    return DCTR_OK;
+}
+
+int dctr_prefetch_ids(dctr_handle E, const int32_t* d_ids_next, int B) {
+    DCTR_REQUIRE(E && d_ids_next, "null argument");
+    if (E->csr || E->wnd || E->cfg.use_graph || E->cfg.shard_world > 1) return DCTR_OK;       // not a path that groups per step: no-op
+    DCTR_REQUIRE(B > 0 && B <= E->MB, "batch %d outside (0, max_batch=%d]", B, E->MB);
+    bool is_slot = false;
+    for (int k = 0; k < DCTR_INPUT_SLOTS; ++k) is_slot = is_slot || d_ids_next == E->slot_ids[k];
+    if (!is_slot) return DCTR_OK;           // foreign buffers are staged by copy: their address says nothing about their contents
+    if (E->group_alt == nullptr) DCTR_TRY(group_create(E->rows, E->group->max_entries, E->K, &E->group_alt));
+    if (E->have_tail) DCTR_HIP_CHECK(hipStreamWaitEvent(E->s_group, E->ev_tail, 0));
+    DCTR_TRY(group_ids(E->group_alt, d_ids_next, B, E->F, E->s_group));
+    E->pre_ids = d_ids_next; E->pre_B = B; E->pre_valid = true;
     return DCTR_OK;
 }
 

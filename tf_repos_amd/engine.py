@@ -219,6 +219,11 @@ class Engine:
                                               capi.ptr(out0), capi.ptr(out1), capi.ptr(out2), st))
         return out0
 
+    def prefetch_ids(self, ids_next) -> None:
+        """Announces the next training batch's ids (a view of an input slot, unchanged until that train_step): grouped during the
+        tail of the step in flight.  A scheduling hint only."""
+        capi.check(self._lib.dctr_prefetch_ids(self._h, capi.ptr(ids_next), int(ids_next.shape[0])))
+
     def predict(self, ids, vals, out_prob=None, out_logit=None, stream=None, dense=None):
         self._set_dense(dense)
         B = int(ids.shape[0])
