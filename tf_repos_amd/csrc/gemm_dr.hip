@@ -38,13 +38,14 @@ double dr_efficiency(int Mo, int No, int64_t R, int S, Tile t, int* blocks_out) 
 }
 
 // DCTR_GEMM = "lds": never; otherwise a subset of "fdw" (forward / dgrad / wgrad products that may take the direct kernel).
-// Default "fw".  Alone the direct kernel wins all three (c2 layer 0: fwd 25 vs 32 us, dgrad 26 vs 29, wgrad 28 vs 30), but a
-// training step runs each dgrad beside the weight gradient of the layer above, and there a one-block-per-CU dgrad loses:
-// measured ms/step at c2 (400 steps): lds 0.338, f 0.333, fw 0.329, fd 0.353, fdw 0.347.
+// Default "fdw".  Alone the direct kernel wins all three (c2 layer 0: fwd 25 vs 32 us, dgrad 26 vs 29, wgrad 27 vs 30).  In the
+// training step each dgrad runs beside the weight gradient of the layer above; measured ms/step at c2 (3 x 600 steps, next-batch
+// hint on): lds 0.338, f 0.324, fw 0.3186, fdw 0.3166.  (Before the background table pass was capped at 96 VGPRs and the kernels
+// here at <= 312, a direct dgrad could not share a SIMD with anything and "fdw" LOST: 0.347 vs 0.329 for "fw".)
 bool dr_enabled(char op) {
     static const std::string ops = [] {
         const char* e = getenv("DCTR_GEMM");
-        if (e == nullptr) return std::string("fw");
+        if (e == nullptr) return std::string("fdw");
         if (!strcmp(e, "lds") || !strcmp(e, "LDS")) return std::string();
         return std::string(e);
     }();
