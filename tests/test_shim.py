@@ -228,4 +228,5 @@ def test_estimator_resumes_from_a_tensorflow_checkpoint_bundle(tmp_path, dev):
     est.train(input_fn=tr_fn)             # the original continues from its live state
     assert est2._engine.global_step == est._engine.global_step == 6
     for name in est.get_variable_names():
-        assert np.array_equal(est2.get_variable_value(name), est.get_variable_value(name)), name
+        # (not bit-equal: the scatter's float atomics make two identical runs differ by ~1e-7)
+        assert np.abs(est2.get_variable_value(name) - est.get_variable_value(name)).max() <= 1e-6, name

@@ -974,6 +974,28 @@ __global__ void step_state_kernel(StepState* s, float* zero, int n_zero) {
     s->seed_t = s->seed ^ ((uint64_t)s->t * 0xD1B54A32D192ED03ULL);
 }
 
+// the NEXT step's state from the current one, into a second StepState (and a second set of loss scalars, zeroed): launched under
+// the tail of the step in flight, so that the next step starts with its state ready instead of with this 5 us kernel
+__global__ void step_state_next_kernel(const StepState* __restrict__ cur, StepState* __restrict__ nxt, float* __restrict__ zero, int n_zero) {
+    for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero[i] = 0.f;
+    if (threadIdx.x != 0) return;
+    StepState s = *cur;
+    s.t += 1;
+    const double t = (double)s.t;
+    for (Hyper* hp : {&s.hyper, &s.hyper_lin}) {
+        Hyper& h = *hp;
+        h.lr_t = (float)((double)h.lr * sqrt(1.0 - pow((double)h.beta2, t)) / (1.0 - pow((double)h.beta1, t)));
+    }
+    s.seed_t = s.seed ^ ((uint64_t)s.t * 0xD1B54A32D192ED03ULL);
+    *nxt = s;
+}
+
+int step_state_next(const StepState* cur, StepState* nxt, float* zero, int n_zero, hipStream_t st) {
+    step_state_next_kernel<<<1, 256, 0, st>>>(cur, nxt, zero, n_zero);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
 int step_state_advance(StepState* s, float* zero, int n_zero, hipStream_t st) {
     step_state_kernel<<<1, 256, 0, st>>>(s, zero, n_zero);
     DCTR_LAUNCH_CHECK();

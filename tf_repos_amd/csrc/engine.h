@@ -74,6 +74,9 @@ struct dctr_engine {
     int n_blocks = 0;
     // state
     StepState* state = nullptr;
+    StepState* state_alt = nullptr;   // the NEXT step's state, prepared under the tail of the step in flight (record_train)
+    float* scalars_alt = nullptr;
+    bool state_ready = false;
     StepState h_state{};
     float* scalars = nullptr;     // [0] xent sum, [1] sumsq emb, [2] sumsq linear, [3] sumsq dense-l2 params
     int32_t* status = nullptr;    // [2]

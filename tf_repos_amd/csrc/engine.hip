@@ -307,6 +307,8 @@ int build(dctr_engine* E) {
     E->h_state = s;
     DCTR_TRY(dmalloc(&E->state, 1, false));
     DCTR_HIP_CHECK(hipMemcpy(E->state, &s, sizeof(s), hipMemcpyHostToDevice));
+    DCTR_TRY(dmalloc(&E->state_alt, 1, false));
+    DCTR_TRY(dmalloc(&E->scalars_alt, 4 * SUMSQ_SHARDS));
     DCTR_TRY(dmalloc(&E->scalars, 4 * SUMSQ_SHARDS));   // [0..63] xent shards; [64..127] emb^2 shards; [128..191] linear^2; [192..255] dense l2 params
     DCTR_TRY(dmalloc(&E->status, 2));
 
@@ -768,7 +770,13 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     // the per-step state kernel (5 us) runs on st: handing it to a side stream costs st a record AND a wait on a fresh
     // dependency -- two cross-queue hops of ~10 us each, measured 0.374 -> 0.351 ms/step.  DCTR_STATE_ON_SIDE=1 is the old placement
     static const bool state_on_main = getenv("DCTR_STATE_ON_SIDE") == nullptr;
-    if (state_on_main) {
+    if (E->state_ready) {
+        // prepared under the tail of the previous step (below): the two states / scalar sets change roles
+        std::swap(E->state, E->state_alt);
+        std::swap(E->scalars, E->scalars_alt);
+        E->state_ready = false;
+        DCTR_TRY(forward_gather(E, B, st));
+    } else if (state_on_main) {
         DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, st));
         DCTR_TRY(forward_gather(E, B, st));
     } else {
@@ -837,6 +845,13 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     DCTR_TRY(fork(E, sg, st));
     if (split_table) DCTR_TRY(scatter_and_step_tables(E, B, st, nullptr, OPT_PASS_TOUCHED));
     else DCTR_TRY(scatter_and_step_tables(E, B, st, sg));  // the grouping stream is idle by now: linear table beside the embedding table
+    static const bool no_state_ahead = getenv("DCTR_NO_STATE_AHEAD") != nullptr;       // A/B knob
+    if (!E->cfg.use_graph && !no_state_ahead && sw != st) {
+        // the next step's state (global_step + 1, Adam's lr_t, dropout seed, zeroed loss scalars) into the second StepState, on
+        // the weight-gradient stream beside scatter / table step: it only READS the live state, and the join below orders it
+        DCTR_TRY(step_state_next(E->state, E->state_alt, E->scalars_alt, 4 * SUMSQ_SHARDS, sw));
+        E->state_ready = true;
+    }
     DCTR_TRY(fork(E, sw, st));
     if (E->opt_pending) { DCTR_TRY(fork(E, E->s_opt, st)); E->opt_pending = false; }
     return DCTR_OK;
@@ -941,6 +956,8 @@ int dctr_destroy(dctr_handle E) {
     for (int k = 0; k < DCTR_INPUT_SLOTS; ++k) { if (E->slot_ids[k]) hipFree(E->slot_ids[k]); if (E->slot_vals[k]) hipFree(E->slot_vals[k]); if (E->slot_labels[k]) hipFree(E->slot_labels[k]); }
     if (E->status) hipFree(E->status);
     if (E->state) hipFree(E->state);
+    if (E->state_alt) hipFree(E->state_alt);
+    if (E->scalars_alt) hipFree(E->scalars_alt);
     if (E->meta) hipFree(E->meta);
     if (E->meta_flat) hipFree(E->meta_flat);
     if (E->auc_counts) hipFree(E->auc_counts);
@@ -1019,6 +1036,7 @@ int dctr_set_global_step(dctr_handle E, int64_t step) {
     DCTR_REQUIRE(E && step >= 0, "bad argument");
     DCTR_HIP_CHECK(hipDeviceSynchronize());
     E->h_state.t = step;
+    E->state_ready = false;                 // a state prepared ahead was derived from the old global_step
     DCTR_HIP_CHECK(hipMemcpy(&E->state->t, &step, sizeof(step), hipMemcpyHostToDevice));
     return DCTR_OK;
 }
@@ -1423,6 +1441,7 @@ int sharded_forward_backward(dctr_engine* E, const float* d_rows, int n_rows, co
     hipStream_t sw = E->s_wgrad;
     const size_t n = (size_t)B * E->F;
     const int P = E->K + 4;
+    E->state_ready = false;
     if (train) DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, st));    // (on st: see record_train)
     // inputs that already live in one of the engine's input slots are read in place (no staging copy at the head of the step)
     for (int k = 0; k < DCTR_INPUT_SLOTS; ++k)

@@ -114,6 +114,7 @@ int opt_table(int kind, const Hyper* hdev, const Hyper& hval, int table_mode, in
               float* sumsq_emb, float* sumsq_lin, hipStream_t st, hipStream_t st_lin = nullptr, int pass = 0);
 enum { OPT_PASS_ALL = 0, OPT_PASS_UNTOUCHED = 1, OPT_PASS_TOUCHED = 2 };
 int step_state_advance(StepState* s, float* zero, int n_zero, hipStream_t st);
+int step_state_next(const StepState* cur, StepState* nxt, float* zero, int n_zero, hipStream_t st);
 int head_out_bwd(const float* x1, int ld1, const float* w1, int n1, int masked1, float* dx1, int lddx1,
                  const float* x2, int ld2, const float* w2, int n2, int masked2, float* dx2, int lddx2,
                  const float* b_out, const float* bias, const float* yw, const float* yv, const float* labels, int B, float inv_batch,
