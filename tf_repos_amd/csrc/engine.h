@@ -63,7 +63,8 @@ struct dctr_engine {
     const int32_t* pre_ids = nullptr;
     int pre_B = 0;
     bool pre_valid = false;
-    hipEvent_t ev_tail = nullptr;   // recorded on the main stream when the dense backward of the last step was enqueued
+    hipEvent_t ev_tail = nullptr;   // = the event of the main stream's last fork when the dense backward was enqueued (ring of 64: one step uses ~12)
+    hipEvent_t last_fork_ev = nullptr;
     bool have_tail = false;
     // arena
     float *theta = nullptr, *as0 = nullptr, *as1 = nullptr, *gflat = nullptr, *parts = nullptr;

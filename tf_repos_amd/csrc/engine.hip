@@ -38,6 +38,7 @@ int engine_add_param(dctr_engine* E, const std::string& name, std::initializer_l
 int fork(dctr_engine* E, hipStream_t from, hipStream_t to) {
     if (from == to) return DCTR_OK;
     hipEvent_t ev = E->events[E->ev_next++ % E->events.size()];
+    E->last_fork_ev = ev;
     DCTR_HIP_CHECK(hipEventRecord(ev, from));
     DCTR_HIP_CHECK(hipStreamWaitEvent(to, ev, 0));
     return DCTR_OK;
@@ -821,12 +822,10 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     }
     const bool out_done = fused_opt && E->head_did_out_bwd;
     DCTR_TRY(backward_dense(E, B, st, sw, fused_opt, have_head_ev ? &head_ev : nullptr));
-    if (!E->cfg.use_graph) {                 // where a prefetched grouping of the next batch may start: beside scatter + table step
-        if (E->ev_tail == nullptr) DCTR_HIP_CHECK(hipEventCreateWithFlags(&E->ev_tail, hipEventDisableTiming));
-        DCTR_HIP_CHECK(hipEventRecord(E->ev_tail, st));
-        E->have_tail = true;
-    }
     if (!fused_opt) DCTR_TRY(fork(E, st, sw));          // (fused_opt: backward_dense ends with that fork)
+    // where a prefetched grouping of the next batch may start (beside scatter + table step): the record of that last st -> sw
+    // fork serves -- one more record here is one more barrier packet (~5 us) in front of the scatter
+    if (!E->cfg.use_graph && E->last_fork_ev != nullptr) { E->ev_tail = E->last_fork_ev; E->have_tail = true; }
     if (fused_opt) {
         // what is left of the dense arena: cross_w / cross_b (DCN), and the output layer + bias if they were not stepped above
         for (int i = 0; i < (int)E->params.size(); ++i) {
@@ -978,7 +977,6 @@ int dctr_destroy(dctr_handle E) {
     if (E->s_group) hipStreamDestroy(E->s_group);
     if (E->s_wgrad) hipStreamDestroy(E->s_wgrad);
     if (E->s_opt) hipStreamDestroy(E->s_opt);
-    if (E->ev_tail) hipEventDestroy(E->ev_tail);
     delete E;
     return DCTR_OK;
 }

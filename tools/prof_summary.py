@@ -33,7 +33,7 @@ def pmc(paths):
         print("%-80s %s" % (k[:80], "  ".join("%s=%.4g (n=%d)" % (c, sum(v) / len(v), len(v)) for c, v in sorted(d.items()))))
 
 
-def timeline(path, anchor="step_state_kernel", which=40):
+def timeline(path, anchor="gather_fwd_kernel", which=40):
     """Start offset / duration of every kernel between two consecutive launches of `anchor` (one training step)."""
     cur = sqlite3.connect(path).cursor()
     cols = [d[0] for d in cur.execute("select * from kernels limit 1").description]
