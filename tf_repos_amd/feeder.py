@@ -83,6 +83,18 @@ class DeviceFeeder:
             s_i, s_v, s_l = self.slot[k]
             yield s_i[:B], s_v[:B], s_l[:B], k
 
+    def peek_next_ids(self):
+        """ids view of the NEXT staged batch if its H2D copy has already completed, else None -- what Engine.prefetch_ids wants
+        right after the step that consumes the current batch has been enqueued (a hint: skipped when the copy is still in flight)."""
+        with self._q.mutex:
+            item = self._q.queue[0] if self._q.queue else None
+        if item is None:
+            return None
+        k, B = item
+        if not self.copied[k].query():
+            return None
+        return self.slot[k][0][:B]
+
     def release(self, k: int) -> None:
         """call after enqueueing the step that reads slot k (on the current stream)"""
         ev = self._torch.cuda.Event()

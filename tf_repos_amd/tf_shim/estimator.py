@@ -363,6 +363,9 @@ class Estimator:
                 ids, vals, labels, slot = batch
                 loss = e.train_step(ids, vals, labels, want_loss=want)
                 feeder.release(slot)
+                nxt = feeder.peek_next_ids()          # the next batch is already in its input slot: group its ids a step ahead
+                if nxt is not None:
+                    e.prefetch_ids(nxt)
             else:
                 ids, vals, labels = batch
                 loss = e.train_step(ids, vals, labels, want_loss=want)
