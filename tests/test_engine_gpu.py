@@ -16,8 +16,7 @@ MODELS = ["deepfm", "fnn", "ipnn", "nfm", "dcn", "afm", "mvm"]
 @pytest.mark.parametrize("model", MODELS + ["opnn"])
 @pytest.mark.parametrize("K", [4, 8, 16, 32])
 def test_forward_logits(model, K, dev):
-    if model == "opnn" and K > 8:
-        pytest.skip("materialised outer product kept small")
+    # (opnn: K < 16 takes the materialising kernels, K >= 16 forms the pair products inside the first layer's GEMM)
     F, V, B = (39, 5000, 96) if model != "opnn" else (10, 500, 32)
     ocfg, params, eng = make_pair(model, B=B, F=F, V=V, K=K, layers=(64, 32))
     ids, vals, labels = O.synth_batch(B, F, V, seed=7)
@@ -53,6 +52,30 @@ def test_train_steps_match_oracle(model, opt, dev):
         diff = np.abs(got[name] - ref.numpy()).max()
         assert diff <= 2e-6, (name, diff)       # tolerance: per-parameter 1e-6-class abs after 3 steps
     assert eng.global_step == 3
+    eng.close()
+
+
+@pytest.mark.parametrize("K,H,B", [(16, 256, 96), (16, 200, 77), (32, 64, 130), (16, 320, 64)])
+def test_outer_pnn_fused_first_layer(K, H, B, dev):
+    """Outer-PNN with K >= 16: the [B, P K K] product tensor is never formed (gemm_dr.h DR_AGEN_*); forward, weight gradient and
+    dL/de against the oracle's materialised einsum (PNN.py:139-167), ragged batches, every tile width of the kernel."""
+    F, V = 10, 700
+    ocfg, params, eng = make_pair("opnn", B=B, F=F, V=V, K=K, layers=(H, 32), opt="Adam", lr=1e-3, l2=1e-4, scale=0.05)
+    oopt = O.Optimizer(ocfg, params)
+    for step in range(2):
+        ids, vals, labels = O.synth_batch(B, F, V, seed=300 + step)
+        d = dev_batch(ids, vals, labels, dev)
+        if step == 0:
+            ref = O.forward(ocfg, params, ids, vals)
+            logit = torch.empty(B, device=dev)
+            eng.predict(d[0], d[1], torch.empty(B, device=dev), logit)
+            assert np.abs(logit.cpu().numpy() - ref["y"].numpy()).max() <= 1e-4
+        ref_loss, _ = O.train_step(ocfg, params, oopt, ids, vals, labels)
+        loss = eng.train_step(*d)
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (step, loss, ref_loss)
+    got = eng.get_params()
+    for name, ref in params.items():
+        assert np.abs(got[name] - ref.numpy()).max() <= 2e-6, name
     eng.close()
 
 

@@ -90,6 +90,11 @@ struct dctr_engine {
     bool head_did_out_bwd = false;   // the fused head kernel already produced the output layer's backward
     float *vals = nullptr, *labels = nullptr;
     float *x_in = nullptr, *dx_in = nullptr, *e_buf = nullptr, *S = nullptr, *yw = nullptr, *yv = nullptr;
+    // Outer-PNN with the pair products formed inside the first layer's GEMMs (gemm_dr.h DR_AGEN_*)
+    bool opnn_fused = false;
+    int* opnn_pairs = nullptr;       // [P] i << 16 | j
+    float* opnn_ws = nullptr;        // forward split-K slabs
+    float* opnn_dop = nullptr;       // [MB, P K K] d(pair products)
     float *yd = nullptr, *y = nullptr, *prob = nullptr, *dy = nullptr;
     std::vector<float*> h, dh;
     bool bn = false;

@@ -142,7 +142,11 @@ int build(dctr_engine* E) {
     const int F = E->F, K = E->K, D = E->D, P = E->P, MB = E->MB;
     switch (c.model) {
         case DCTR_MODEL_IPNN: E->Din = D + P; break;
-        case DCTR_MODEL_OPNN: E->Din = D + P * K * K; break;
+        case DCTR_MODEL_OPNN:
+            // fused first layer (gemm_dr.h DR_AGEN_*): the [B, P K K] product tensor is never written -- x_in is the flat part only
+            E->opnn_fused = !no_mlp && opnn_fused_ok(F, K, c.deep_layers[0]);
+            E->Din = E->opnn_fused ? D : D + P * K * K;
+            break;
         case DCTR_MODEL_NFM: E->Din = K; break;
         case DCTR_MODEL_AFM: E->Din = K; break;
         default: E->Din = D + E->n_dense; break;     // canned DNN: [embeddings | numeric columns]
@@ -175,6 +179,7 @@ int build(dctr_engine* E) {
             fc.in = d; fc.out = c.deep_layers[i]; fc.keep = c.keep_prob[i];
             DCTR_REQUIRE(fc.out > 0, "deep layer widths must be positive (got %d)", fc.out);
             fc.splits = choose_wgrad_splits(MB, fc.in, fc.out);
+            if (i == 0 && E->opnn_fused) { fc.in = D + P * K * K; fc.splits = 1; }    // (the weight keeps the reference's [F K + P K K, H] shape)
             char nm[64];
             snprintf(nm, sizeof(nm), "%smlp%d/weights", tower_prefix[t], i);
             fc.w = add_param(E, nm, {fc.in, fc.out}, false, fc.splits, 0.f);
@@ -370,6 +375,15 @@ int build(dctr_engine* E) {
     }
     E->ids = E->slot_ids[0]; E->vals = E->slot_vals[0]; E->labels = E->slot_labels[0];
     DCTR_TRY(dmalloc(&E->x_in, (size_t)(MB + GEMM_SLACK_ROWS) * E->Din_ld));      // (+ slack rows: see gemm.hip `over`)
+    if (E->opnn_fused) {
+        std::vector<int> pairs;
+        for (int i = 0; i < F; ++i)
+            for (int j = i + 1; j < F; ++j) pairs.push_back(i << 16 | j);           // PNN.py:142-146 loop order
+        DCTR_TRY(dmalloc(&E->opnn_pairs, pairs.size()));
+        DCTR_HIP_CHECK(hipMemcpy(E->opnn_pairs, pairs.data(), pairs.size() * sizeof(int), hipMemcpyHostToDevice));
+        DCTR_TRY(dmalloc(&E->opnn_ws, (size_t)opnn_fwd_ws_floats_max(MB, c.deep_layers[0])));
+        DCTR_TRY(dmalloc(&E->opnn_dop, (size_t)(MB + GEMM_SLACK_ROWS) * P * K * K, false));
+    }
     {   // (attention pooling: the per-entry gradient rows `dub` sit behind dx_in so that one int32 float4 offset reaches both)
         const size_t dxn = (size_t)(MB + GEMM_SLACK_ROWS) * E->Din_ld;
         DCTR_TRY(dmalloc(&E->dx_in, dxn + (E->att_on ? (size_t)E->max_entries * K : 0)));
@@ -485,7 +499,7 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::f
     if (c.model == DCTR_MODEL_AFM) return afm_forward(E, B, train, st);
     const uint64_t* seedp = &E->state->seed_t;
     if (c.model == DCTR_MODEL_IPNN) DCTR_TRY(pnn_inner_fwd(E->e, E->e_ld, B, F, K, E->x_in + D, E->Din_ld, st));
-    if (c.model == DCTR_MODEL_OPNN) DCTR_TRY(pnn_outer_fwd(E->e, E->e_ld, B, F, K, E->x_in + D, E->Din_ld, st));
+    if (c.model == DCTR_MODEL_OPNN && !E->opnn_fused) DCTR_TRY(pnn_outer_fwd(E->e, E->e_ld, B, F, K, E->x_in + D, E->Din_ld, st));
     if (c.model == DCTR_MODEL_NFM && train) DCTR_TRY(dropout_inplace(E->x_in, (int64_t)B * K, c.keep_prob[0], seedp, 0xB1ull, st));   // NFM.py:136-137
     if (c.model == DCTR_MODEL_DCN)
         DCTR_TRY(dcn_cross_fwd(E->x_in, E->Din_ld, E->pp(E->p_cross_w), E->pp(E->p_cross_b), B, D, c.cross_layers, E->xs, E->xlw, st));
@@ -498,6 +512,12 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::f
         // (every 8th step only: the two extra event records cost the step ~15 us, which the bench's `value` should not carry)
         const bool timed = E->timer_on && train && i == 0 && E->timer_n + 2 <= E->timer_ev.size() && (E->timer_tick++ % 8) == 0;
         if (timed) DCTR_HIP_CHECK(hipEventRecord(E->timer_ev[E->timer_n], st));
+        if (i == 0 && E->opnn_fused) {
+            // flat rows of W0 as an ordinary product (raw sums), then the pair-product rows with A formed in registers + bias/ReLU/dropout
+            DCTR_TRY(fc_fwd(x, ldx, E->pp(fc.w), nullptr, E->h[0], fc.out, B, D, fc.out, 0, 1.f, nullptr, 0, st, 1));
+            DCTR_TRY(opnn_outer_fwd(E->e, E->e_ld, B, F, K, E->opnn_pairs, E->pp(fc.w) + (size_t)D * fc.out, E->pp(fc.b), E->h[0], fc.out, fc.out, 1,
+                                    (train && !E->bn) ? fc.keep : 1.f, seedp, 0x1000ull, E->opnn_ws, st));
+        } else
         DCTR_TRY(fc_fwd(x, ldx, E->pp(fc.w), E->pp(fc.b), E->h[i], fc.out, B, fc.in, fc.out, 1, (train && !E->bn) ? fc.keep : 1.f,
                         seedp, 0x1000ull + i, st, 1));
         if (timed) { DCTR_HIP_CHECK(hipEventRecord(E->timer_ev[E->timer_n + 1], st)); E->timer_n += 2; }
@@ -592,6 +612,16 @@ int opt_dense_range(dctr_engine* E, int p_first, int p_last, hipStream_t st, boo
 // still reads the old weights, other stream) are done -- the dense optimizer then costs nothing at the end of the step
 // head_ev: an event recorded on st right after the head (nothing enqueued on st since): the first layer's wgrad waits on it
 // instead of a record of its own
+// d(pair products) -> dL/de for the fused Outer-PNN first layer: dOP[b][(p,a,c)] = sum_h dh0[b][h] W0[F K + (p,a,c)][h], then
+// de_i[a] += sum_c dOP e_j[c], de_j[c] += sum_a dOP e_i[a].  dx_in already holds the flat rows' share.
+int opnn_outer_dgrad(dctr_engine* E, int B, hipStream_t st) {
+    const Fc& fc = E->mlp[0];
+    const int F = E->F, K = E->K, D = E->D;
+    const int64_t L = (int64_t)E->P * K * K;
+    DCTR_TRY(fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w) + (size_t)D * fc.out, E->opnn_dop, (int)L, B, (int)L, fc.out, nullptr, 0, 1.f, st, 1));
+    return pnn_outer_bwd(E->e, E->e_ld, E->opnn_dop, L, B, F, K, E->dx_in, E->Din_ld, st);
+}
+
 int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool fused_opt = false, const hipEvent_t* head_ev = nullptr) {
     const dctr_config& c = E->cfg;
     if (c.model == DCTR_MODEL_AFM) return afm_backward(E, B, st, sw);
@@ -638,13 +668,18 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
             if (i == nl - 1 && head_ev != nullptr && !E->bn && E->head_did_out_bwd) DCTR_HIP_CHECK(hipStreamWaitEvent(sw, *head_ev, 0));
             else DCTR_TRY(fork(E, st, sw));
             if (fused_opt && i < nl - 1) DCTR_TRY(opt_dense_range(E, E->mlp[i + 1].w, E->mlp[i + 1].last, sw));
-            DCTR_TRY(fc_bwd_weights_partials(x, ldx, E->dh[i], fc.out, E->part(fc.w), w.padded, E->part(fc.b), b.padded, B, fc.in,
-                                             fc.out, fc.splits, sw, 1));
+            DCTR_TRY(fc_bwd_weights_partials(x, ldx, E->dh[i], fc.out, E->part(fc.w), w.padded, E->part(fc.b), b.padded, B,
+                                             (i == 0 && E->opnn_fused) ? D : fc.in, fc.out, fc.splits, sw, 1));
+            if (i == 0 && E->opnn_fused)
+                DCTR_TRY(opnn_outer_wgrad(E->e, E->e_ld, B, F, K, E->opnn_pairs, E->dh[0], fc.out, fc.out, E->part(fc.w) + (size_t)D * fc.out, sw));
         }
         if (i > 0)
             DCTR_TRY(fc_bwd_data(E->dh[i], fc.out, E->pp(fc.w), E->dh[i - 1], E->mlp[i - 1].out, B, fc.in, fc.out,
                                  E->bn ? nullptr : E->h[i - 1], E->mlp[i - 1].out, E->bn ? 1.f : E->mlp[i - 1].keep, st, 1));
-        else
+        else if (E->opnn_fused) {
+            DCTR_TRY(fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w), E->dx_in, E->Din_ld, B, D, fc.out, nullptr, 0, 1.f, st, 1));
+            DCTR_TRY(opnn_outer_dgrad(E, B, st));
+        } else
             DCTR_TRY(fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w), E->dx_in, E->Din_ld, B, fc.in, fc.out, nullptr, 0, 1.f, st, 1));
     }
     if (wgrad_late) {
@@ -669,7 +704,7 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
     }
     const uint64_t* seedp = &E->state->seed_t;
     if (c.model == DCTR_MODEL_IPNN) DCTR_TRY(pnn_inner_bwd(E->e, E->e_ld, E->dx_in + D, E->Din_ld, B, F, K, E->dx_in, E->Din_ld, st));
-    if (c.model == DCTR_MODEL_OPNN) DCTR_TRY(pnn_outer_bwd(E->e, E->e_ld, E->dx_in + D, E->Din_ld, B, F, K, E->dx_in, E->Din_ld, st));
+    if (c.model == DCTR_MODEL_OPNN && !E->opnn_fused) DCTR_TRY(pnn_outer_bwd(E->e, E->e_ld, E->dx_in + D, E->Din_ld, B, F, K, E->dx_in, E->Din_ld, st));
     if (c.model == DCTR_MODEL_NFM) DCTR_TRY(dropout_inplace(E->dx_in, (int64_t)B * K, c.keep_prob[0], seedp, 0xB1ull, st));
     if (c.model == DCTR_MODEL_MVM) {         // after the MLP's dgrad wrote dx_in: the product layer adds its share of dL/de
         const Param& pm = E->params[E->p_mvm_b];
@@ -948,6 +983,9 @@ int dctr_destroy(dctr_handle E) {
     for (float* p : E->h2) hipFree(p);
     for (float* p : E->dh2) hipFree(p);
     { float* f2[] = {E->dx_in2, E->dy2, E->y2, E->prob2, E->prob3}; for (float* p : f2) if (p) hipFree(p); }
+    if (E->opnn_pairs) hipFree(E->opnn_pairs);
+    if (E->opnn_ws) hipFree(E->opnn_ws);
+    if (E->opnn_dop) hipFree(E->opnn_dop);
     if (E->entry_off) hipFree(E->entry_off);
     if (E->entry_goff) hipFree(E->entry_goff);
     if (E->pair_ad) hipFree(E->pair_ad);

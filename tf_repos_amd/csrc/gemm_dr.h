@@ -38,6 +38,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 enum { DR_STORE = 0, DR_BIAS_ACT = 1, DR_MASK = 2 };
+// A operand generated on the fly (Outer-PNN, PNN.py:139-153 'Outer': the [B, P K K] product tensor is never written):
+//   DR_AGEN_OUTER_FWD    A[b][(p,a,c)] = e[b][i_p][a] e[b][j_p][c], reduction over (p,a,c)   (first MLP layer forward)
+//   DR_AGEN_OUTER_WGRAD  A^T[(p,a,c)][b], reduction over b                                   (its weight gradient)
+enum { DR_AGEN_NONE = 0, DR_AGEN_OUTER_FWD = 1, DR_AGEN_OUTER_WGRAD = 2 };
+
+struct DrOuter {
+    const float* e;             // gathered embeddings [rows][F K], row stride e_ld
+    int e_ld;
+    int rows;                   // true batch rows (the reduction length handed to the kernel may be rounded up: rows beyond read as 0)
+    const int* pairs;           // [P] field pairs, i << 16 | j (i < j), the reference's double loop order
+    int logk;                   // K = 1 << logk, K >= 16: a group of 16 reduction steps never straddles two (p, a)
+};
 
 struct DrEpilogue {
     const float* bias;          // DR_BIAS_ACT: [N] or null
@@ -127,12 +139,14 @@ __device__ __forceinline__ void dr_reduce_tiles(f32x4 (&acc)[TM][TN], float* lds
     }
 }
 
-template <int TM, int TN, bool A_RC, bool B_RC, bool CS, int EPI>
+template <int TM, int TN, bool A_RC, bool B_RC, bool CS, int EPI, int AGEN = DR_AGEN_NONE>
 __global__ __launch_bounds__(256, 1) void gemm_dr_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                          float* __restrict__ C, int ldc, int M, int N, int K, int kchunk, int nbn,
-                                                         DrEpilogue ep) {
+                                                         DrEpilogue ep, DrOuter og) {
+    static_assert(AGEN == DR_AGEN_NONE || (AGEN == DR_AGEN_OUTER_FWD && A_RC) || (AGEN == DR_AGEN_OUTER_WGRAD && !A_RC), "generated A: fwd is RC, wgrad is NC");
+    constexpr bool A_PLAIN = A_RC || AGEN != DR_AGEN_NONE;   // tile i = rows 16 i .. 16 i + 15 (no interleave)
     constexpr int TQ = B_RC ? 0 : TN / 4;                    // quads of B tiles sharing one dwordx4 per lane (NC only)
-    constexpr int VA = A_RC ? 1 : (TM % 4 == 0 ? 4 : (TM % 2 == 0 ? 2 : 1));
+    constexpr int VA = A_PLAIN ? 1 : (TM % 4 == 0 ? 4 : (TM % 2 == 0 ? 2 : 1));
     constexpr int AG = TM / VA;                              // A load groups per step (NC only)
     extern __shared__ __attribute__((aligned(16))) float dr_lds[];
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -168,10 +182,14 @@ __global__ __launch_bounds__(256, 1) void gemm_dr_kernel(const float* __restrict
     // wave-uniform bases + 32-bit lane offsets.  num_records is the true end of the operand behind the base, so rows / columns
     // beyond the matrix need no clamping and no predication: a load past the end returns 0 without touching memory, and
     // whatever a load finds beyond M or N INSIDE the buffer only feeds outputs nobody stores.
-    const float* Ab = A + (A_RC ? (size_t)m0 * lda + kbeg : (size_t)kbeg * lda + m0);
+    // generated A: the buffer is the embedding matrix, whole rows from the block's first batch row (fwd: m0, wgrad: kbeg) on
+    const float* Ab = AGEN == DR_AGEN_OUTER_FWD ? og.e + (size_t)m0 * og.e_ld : AGEN == DR_AGEN_OUTER_WGRAD ? og.e + (size_t)kbeg * og.e_ld
+                      : A + (A_RC ? (size_t)m0 * lda + kbeg : (size_t)kbeg * lda + m0);
     const float* Bb = B + (B_RC ? (size_t)n0 * ldb + kbeg : (size_t)kbeg * ldb + n0);
-    const int bytesA = 4 * (A_RC ? (M - m0 - 1) * lda + (K - kbeg) : (K - kbeg - 1) * lda + (M - m0));
-    const int bytesB = 4 * (B_RC ? (N - n0 - 1) * ldb + (K - kbeg) : (K - kbeg - 1) * ldb + (N - n0));
+    const int Kb = AGEN == DR_AGEN_OUTER_WGRAD ? min(K, og.rows) : K;          // true rows of B behind a rounded-up reduction length
+    const int bytesA = AGEN == DR_AGEN_OUTER_FWD ? 4 * (og.rows - m0) * og.e_ld : AGEN == DR_AGEN_OUTER_WGRAD ? 4 * (og.rows - kbeg) * og.e_ld
+                       : 4 * (A_RC ? (M - m0 - 1) * lda + (K - kbeg) : (K - kbeg - 1) * lda + (M - m0));
+    const int bytesB = 4 * (B_RC ? (N - n0 - 1) * ldb + (Kb - kbeg) : (Kb - kbeg - 1) * ldb + (N - n0));
     auto uni_ptr = [](const float* p) {
         const uint64_t v = reinterpret_cast<uint64_t>(p);
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
@@ -182,13 +200,35 @@ __global__ __launch_bounds__(256, 1) void gemm_dr_kernel(const float* __restrict
     constexpr int NA = A_RC ? TM : AG, NB = B_RC ? TN : TQ + (TN - 4 * TQ);         // lane offsets per operand
     int aoff[NA], boff[NB];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) aoff[i] = 4 * (A_RC ? (16 * i + c) * lda + 4 * q : 4 * q * lda + 16 * VA * i + VA * c);
+    for (int i = 0; i < NA; ++i)
+        aoff[i] = AGEN == DR_AGEN_OUTER_FWD ? 4 * ((16 * i + c) * og.e_ld + 4 * q) : AGEN == DR_AGEN_OUTER_WGRAD ? 4 * (4 * q * og.e_ld + c)
+                  : 4 * (A_RC ? (16 * i + c) * lda + 4 * q : 4 * q * lda + 16 * VA * i + VA * c);
+    // generated A: lane offset of the e_i factor (fwd: this lane's row, one scalar for its 4 steps; wgrad: row 4 q + s, per step) and,
+    // wgrad, the block's fixed (pair, a, c0) per tile as scalar offsets
+    int aoffI[AGEN != DR_AGEN_NONE ? NA : 1];
+    unsigned sJt[AGEN == DR_AGEN_OUTER_WGRAD ? TM : 1], sIt[AGEN == DR_AGEN_OUTER_WGRAD ? TM : 1];
+    if constexpr (AGEN == DR_AGEN_OUTER_FWD) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) aoffI[i] = 4 * (16 * i + c) * og.e_ld;
+    }
+    if constexpr (AGEN == DR_AGEN_OUTER_WGRAD) {
+        const int km = (1 << og.logk) - 1;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            aoffI[i] = 4 * (4 * q * og.e_ld);
+            const int mm = m0 + 16 * i;
+            const int pr = og.pairs[__builtin_amdgcn_readfirstlane(mm >> (2 * og.logk))];
+            sJt[i] = __builtin_amdgcn_readfirstlane(4u * (unsigned)(((pr & 0xffff) << og.logk) + (mm & km)));
+            sIt[i] = __builtin_amdgcn_readfirstlane(4u * (unsigned)(((pr >> 16) << og.logk) + ((mm >> og.logk) & km)));
+        }
+    }
+    const unsigned strideE = 4u * (unsigned)og.e_ld;
 #pragma unroll
     for (int j = 0; j < NB; ++j)
         boff[j] = 4 * (B_RC ? (16 * j + c) * ldb + 4 * q : 4 * q * ldb + (j < TQ ? 64 * j + 4 * c : 64 * TQ + 16 * (j - TQ) + c));
     const unsigned strideA = 4u * (unsigned)lda, strideB = 4u * (unsigned)ldb;    // bytes per k step of an NC operand
 
-    struct Frag { float a[TM][4]; float b[TN][4]; };
+    struct Frag { float a[TM][4]; float b[TN][4]; float ai[AGEN != DR_AGEN_NONE ? TM : 1][AGEN == DR_AGEN_OUTER_WGRAD ? 4 : 1]; };
     auto ldv = [](auto rs, int voff, unsigned soff_, auto nt, float* d, int stride) {      // nt dwords -> d[0], d[stride], ...
         constexpr int NV = decltype(nt)::value;
         const unsigned soff = __builtin_amdgcn_readfirstlane(soff_);
@@ -209,7 +249,31 @@ __global__ __launch_bounds__(256, 1) void gemm_dr_kernel(const float* __restrict
     using I4 = std::integral_constant<int, 4>;
     using IVA = std::integral_constant<int, VA>;
     // the A loads of one group (RC: one dwordx4 per tile = its 4 steps; NC: per step, one VA-wide load per VA tiles)
-    auto loadA = [&](Frag& f, unsigned sA, unsigned dA) {        // sA: scalar offset of step 0, dA: per step (NC)
+    auto loadA = [&](Frag& f, int g, unsigned sA, unsigned dA) { // g: group; sA: scalar offset of its step 0, dA: per step (NC)
+        if constexpr (AGEN == DR_AGEN_OUTER_FWD) {
+            // the 16 k of group g share (pair, a); lane-quarter q takes c = c0 + 4 q .. + 3 of e_j (one dwordx4) and the scalar e_i[a]
+            const int kk = kbeg + 16 * g, km = (1 << og.logk) - 1;
+            const int pr = og.pairs[__builtin_amdgcn_readfirstlane(kk >> (2 * og.logk))];
+            const unsigned sJ = 4u * (unsigned)(((pr & 0xffff) << og.logk) + (kk & km));
+            const unsigned sI = 4u * (unsigned)(((pr >> 16) << og.logk) + ((kk >> og.logk) & km));
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                ldv(ra, aoff[i], sJ, I4{}, &f.a[i][0], 1);
+                ldv(ra, aoffI[i], sI, I1{}, &f.ai[i][0], 1);
+            }
+            return;
+        }
+        if constexpr (AGEN == DR_AGEN_OUTER_WGRAD) {
+            // step s, lane (c, q): batch row kbeg + 16 g + 4 q + s; e_j[c0 + c] (16 lanes = 64 contiguous bytes) and e_i[a] (broadcast)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    ldv(ra, aoff[i], sJt[i] + (16u * g + s) * strideE, I1{}, &f.a[i][s], 4);
+                    ldv(ra, aoffI[i], sIt[i] + (16u * g + s) * strideE, I1{}, &f.ai[i][s], 4);
+                }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if (A_RC) ldv(ra, aoff[i], sA, I4{}, &f.a[i][0], 1);
@@ -225,6 +289,14 @@ __global__ __launch_bounds__(256, 1) void gemm_dr_kernel(const float* __restrict
         else if (u < TQ) ldv(rb, boff[u], sB, I4{}, &f.b[4 * u][s], 4);
         else ldv(rb, boff[u], sB, I1{}, &f.b[4 * TQ + (u - TQ)][s], 4);
     };
+    auto fin = [&](Frag& f) {                       // generated A: the products, once per fragment set, right before its MFMAs
+        if constexpr (AGEN != DR_AGEN_NONE) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) f.a[i][s] *= f.ai[i][AGEN == DR_AGEN_OUTER_WGRAD ? s : 0];
+        }
+    };
     float cs[TN];                                   // wgrad: column sums of B (= dY), from the fragments as they pass by
 #pragma unroll
     for (int j = 0; j < TN; ++j) cs[j] = 0.f;
@@ -238,9 +310,11 @@ __global__ __launch_bounds__(256, 1) void gemm_dr_kernel(const float* __restrict
     // one pipeline half: prefetch group gn into nxt while the MFMAs of cur run.  The sched_group_barrier pipeline asks for the
     // issue order  A loads, then {1 B load, the MFMAs of the tiles it feeds} repeated, so the VMEM issue slots hide inside the
     // matrix pipe's 32-cycle passes instead of forming a burst during which the pipe drains.
-    auto half = [&](Frag& nxt, int gn, const Frag& cur) {
+    constexpr int A_LOADS = AGEN == DR_AGEN_OUTER_FWD ? 2 * TM : AGEN == DR_AGEN_OUTER_WGRAD ? 8 * TM : (A_RC ? TM : 4 * AG);
+    auto half = [&](Frag& nxt, int gn, Frag& cur) {
         __builtin_amdgcn_sched_barrier(0);
-        loadA(nxt, gA(gn), strideA);
+        fin(cur);
+        loadA(nxt, gn, gA(gn), strideA);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -256,7 +330,7 @@ __global__ __launch_bounds__(256, 1) void gemm_dr_kernel(const float* __restrict
                 }
             }
         }
-        __builtin_amdgcn_sched_group_barrier(0x20, A_RC ? TM : 4 * AG, 0);
+        __builtin_amdgcn_sched_group_barrier(0x20, A_LOADS, 0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -273,14 +347,15 @@ __global__ __launch_bounds__(256, 1) void gemm_dr_kernel(const float* __restrict
         __builtin_amdgcn_sched_barrier(0);
     };
     auto load_all = [&](Frag& f, int g) {        // same issue order as half(): the compiler's vmcnt counts then agree on both loop entries
-        loadA(f, gA(g), strideA);
+        loadA(f, g, gA(g), strideA);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int u = 0; u < NB; ++u)
                 if (!B_RC || s == 0) loadB_unit(f, u, s, gB(g) + (B_RC ? 0u : s * strideB));
     };
-    auto mma_all = [&](const Frag& f, int nsteps) {
+    auto mma_all = [&](Frag& f, int nsteps) {
+        fin(f);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if (s < nsteps) {
@@ -306,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void gemm_dr_kernel(const float* __restrict
             half(f0, min(g + 2, Gf - 1), f1);      // the last prefetch re-reads a loaded group; nobody consumes it
         }
     }
-    if (ns > 0) {
+    if (AGEN == DR_AGEN_NONE && ns > 0) {       // (generated A: the host rounds the reduction length so that no wave has a tail)
         // ---- tail (< 16 k), after the main loop and into f0's registers: a third fragment set alive across the loop would push the
         // kernel past 304 VGPRs, the most that still shares a SIMD with two waves of the background table pass (104 each) -- and a
         // GEMM block that cannot be placed beside them waits for them to END.  Its load latency (~0.7 us) is exposed instead.
@@ -363,10 +438,10 @@ __global__ __launch_bounds__(256, 1) void gemm_dr_kernel(const float* __restrict
     // ---- cross-wave reduction + row-major staging (dr_reduce_tiles), one instantiation per wave id
     constexpr int LDS_ = 16 * TN + 4;           // staged row stride
     switch (w) {
-        case 0: dr_reduce_tiles<TM, TN, A_RC, B_RC, 0>(acc, dr_lds, lane); break;
-        case 1: dr_reduce_tiles<TM, TN, A_RC, B_RC, 1>(acc, dr_lds, lane); break;
-        case 2: dr_reduce_tiles<TM, TN, A_RC, B_RC, 2>(acc, dr_lds, lane); break;
-        default: dr_reduce_tiles<TM, TN, A_RC, B_RC, 3>(acc, dr_lds, lane); break;
+        case 0: dr_reduce_tiles<TM, TN, A_PLAIN, B_RC, 0>(acc, dr_lds, lane); break;
+        case 1: dr_reduce_tiles<TM, TN, A_PLAIN, B_RC, 1>(acc, dr_lds, lane); break;
+        case 2: dr_reduce_tiles<TM, TN, A_PLAIN, B_RC, 2>(acc, dr_lds, lane); break;
+        default: dr_reduce_tiles<TM, TN, A_PLAIN, B_RC, 3>(acc, dr_lds, lane); break;
     }
     DR_STAMP(3);
     __syncthreads();

@@ -65,7 +65,25 @@ int dr_launch(const float* A, int lda, const float* B, int ldb, float* C, int ld
     DCTR_HIP_CHECK(attr);
     const int nbm = ceil_div(M, 16 * TM), nbn = ceil_div(N, 16 * TN);
     const int kchunk = (int)round_up(ceil_div(K, splits), 16);
-    kern<<<dim3((unsigned)(nbm * nbn), (unsigned)splits), 256, lds, st>>>(A, lda, B, ldb, C, ldc, M, N, K, kchunk, nbn, ep);
+    kern<<<dim3((unsigned)(nbm * nbn), (unsigned)splits), 256, lds, st>>>(A, lda, B, ldb, C, ldc, M, N, K, kchunk, nbn, ep, DrOuter{});
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+// generated-A products of the Outer-PNN first layer (gemm_dr.h DR_AGEN_*): R = reduction length (a multiple of 64), kchunk a multiple of 64
+template <int TN, int AGEN>
+int dr_launch_outer(const DrOuter& og, const float* Bm, int ldb, float* C, int ldc, int M, int N, int R, int splits, int64_t split_stride,
+                    hipStream_t st) {
+    constexpr bool FWD = AGEN == DR_AGEN_OUTER_FWD;
+    auto kern = gemm_dr_kernel<2, TN, FWD, false, false, DR_STORE, AGEN>;
+    constexpr size_t lds = gemm_dr_lds_bytes<2, TN>();
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    DCTR_HIP_CHECK(attr);
+    const int nbm = ceil_div(M, 32), nbn = ceil_div(N, 16 * TN);
+    const int kchunk = (int)round_up(ceil_div(R, splits), 64);
+    DrEpilogue ep{};
+    ep.split_stride = split_stride;
+    kern<<<dim3((unsigned)(nbm * nbn), (unsigned)ceil_div(R, kchunk)), 256, lds, st>>>(nullptr, 0, Bm, ldb, C, ldc, M, N, R, kchunk, nbn, ep, og);
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }
@@ -177,6 +195,80 @@ int dr_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int ldd
         case 0: return dr_launch<2, 13, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
         default: return dr_launch<2, 8, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
     }
+}
+
+// ---- Outer-PNN without the [B, P K K] product tensor (PNN.py:139-153 'Outer' + the first fully_connected, PNN.py:159-166) ---------------
+// The first MLP layer's weight is [F K + P K K, H]: rows [0, F K) meet the flat embeddings (an ordinary layer product, done by the
+// caller), rows F K + (p K + a) K + c meet e_i[a] e_j[c] of pair p = (i, j).  Here those products are formed in the MFMA A fragments
+// from the gathered embeddings (41 MB at B = 8192, L2 / Infinity-Cache resident) instead of being written and re-read (24.9 GB each
+// way at the run.sh operating point K = 32).
+bool opnn_fused_ok(int F, int K, int H) {
+    static const bool off = getenv("DCTR_OPNN_MATERIALISE") != nullptr;         // A/B knob: the materialising path
+    if (off || K < 16 || (K & (K - 1)) != 0 || F < 2 || F > 0x7fff || (H & 3) != 0 || H < 4) return false;
+    const int64_t L = (int64_t)F * (F - 1) / 2 * K * K;
+    return fits31(L, H);
+}
+
+int opnn_fwd_splits(int B, int H) {
+    const int blocks = ceil_div(B, 32) * ceil_div(H, 256);
+    return std::max(1, CUS / blocks);
+}
+
+__global__ __launch_bounds__(256) void opnn_finish_kernel(float* __restrict__ y, int ldy, const float* __restrict__ ws, int64_t ws_stride, int splits,
+                                                          const float* __restrict__ bias, int B, int H, int relu, float keep, uint64_t seed,
+                                                          const uint64_t* __restrict__ seed_ptr) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;        // one float4 of the [B, H] output
+    const int h4 = H / 4;
+    if (idx >= (int64_t)B * h4) return;
+    const int b = (int)(idx / h4), col = 4 * (int)(idx - (int64_t)b * h4);
+    float4 v = *reinterpret_cast<const float4*>(y + (size_t)b * ldy + col);
+    for (int s = 0; s < splits; ++s) {
+        const float4 p = *reinterpret_cast<const float4*>(ws + (size_t)s * ws_stride + (size_t)b * H + col);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    float o[4] = {v.x, v.y, v.z, v.w};
+    const uint64_t sd = seed ^ (seed_ptr ? *seed_ptr : 0ull);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (bias != nullptr) o[e] += bias[col + e];
+        if (relu) o[e] = fmaxf(o[e], 0.f);
+        if (keep < 1.0f) o[e] *= dropout_scale(sd, (uint64_t)b * (uint64_t)H + col + e, keep);
+    }
+    *reinterpret_cast<float4*>(y + (size_t)b * ldy + col) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// y[B, H] holds the flat part's product on entry; on return act(y + outer part + bias).  ws: opnn_fwd_ws_floats_max() floats.
+// (splits * ceil(B / 32) <= 256 whenever splits > 1, so no batch needs more than max(8192 + 32 splits, B) slab rows)
+int64_t opnn_fwd_ws_floats_max(int max_batch, int H) { return ((int64_t)std::max(max_batch, 8192) + 32 * CUS) * H; }
+
+int opnn_outer_fwd(const float* e, int e_ld, int B, int F, int K, const int* pairs, const float* w_outer, const float* bias, float* y, int ldy,
+                   int H, int relu, float keep, const uint64_t* seed_ptr, uint64_t seed, float* ws, hipStream_t st) {
+    if (B <= 0) return DCTR_OK;
+    DCTR_REQUIRE(opnn_fused_ok(F, K, H) && al16(e) && al16(w_outer) && al16(y) && al16(ws) && (e_ld & 3) == 0 && (ldy & 3) == 0 && fits31(B, e_ld),
+                 "opnn_outer_fwd: unsupported shape / alignment");
+    DrOuter og{e, e_ld, B, pairs, 31 - __builtin_clz((unsigned)K)};
+    const int L = F * (F - 1) / 2 * K * K, S = opnn_fwd_splits(B, H);
+    const int64_t stride = (int64_t)B * H;
+    if (H > 208) DCTR_TRY((dr_launch_outer<16, DR_AGEN_OUTER_FWD>(og, w_outer, H, ws, H, B, H, L, S, stride, st)));
+    else if (H > 128) DCTR_TRY((dr_launch_outer<13, DR_AGEN_OUTER_FWD>(og, w_outer, H, ws, H, B, H, L, S, stride, st)));
+    else DCTR_TRY((dr_launch_outer<8, DR_AGEN_OUTER_FWD>(og, w_outer, H, ws, H, B, H, L, S, stride, st)));
+    const int splits = ceil_div(L, (int)round_up(ceil_div(L, S), 64));
+    opnn_finish_kernel<<<(unsigned)ceil_div((int64_t)B * (H / 4), 256), 256, 0, st>>>(y, ldy, ws, stride, splits, bias, B, H, relu, keep, seed, seed_ptr);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+// dW_outer[(p,a,c)][h] = sum_b e_i[b][a] e_j[b][c] dY[b][h]   (one slab: P K K / 32 row blocks are far more than the chip has CUs)
+int opnn_outer_wgrad(const float* e, int e_ld, int B, int F, int K, const int* pairs, const float* dy, int lddy, int H, float* dw_outer, hipStream_t st) {
+    DCTR_REQUIRE(opnn_fused_ok(F, K, H) && al16(e) && al16(dy) && al16(dw_outer) && (e_ld & 3) == 0 && (lddy & 3) == 0 && fits31(B, e_ld) && fits31(B, lddy),
+                 "opnn_outer_wgrad: unsupported shape / alignment");
+    const int L = F * (F - 1) / 2 * K * K;
+    if (B <= 0) { DCTR_HIP_CHECK(hipMemsetAsync(dw_outer, 0, (size_t)L * H * sizeof(float), st)); return DCTR_OK; }
+    DrOuter og{e, e_ld, B, pairs, 31 - __builtin_clz((unsigned)K)};
+    const int R = (int)round_up(B, 64);
+    if (H > 208) return dr_launch_outer<16, DR_AGEN_OUTER_WGRAD>(og, dy, lddy, dw_outer, H, L, H, R, 1, 0, st);
+    if (H > 128) return dr_launch_outer<13, DR_AGEN_OUTER_WGRAD>(og, dy, lddy, dw_outer, H, L, H, R, 1, 0, st);
+    return dr_launch_outer<8, DR_AGEN_OUTER_WGRAD>(og, dy, lddy, dw_outer, H, L, H, R, 1, 0, st);
 }
 
 }  // namespace dctr

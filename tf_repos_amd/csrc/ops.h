@@ -90,6 +90,12 @@ int dr_fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int ldd
 int dr_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int lddy, float* dw_part, int64_t dw_stride, float* db_part,
                                int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, bool* done);
 int dr_wgrad_splits(int M, int K, int N);
+// Outer-PNN first layer with the pair products formed in the MFMA fragments (gemm_dr.hip)
+bool opnn_fused_ok(int F, int K, int H);
+int64_t opnn_fwd_ws_floats_max(int max_batch, int H);
+int opnn_outer_fwd(const float* e, int e_ld, int B, int F, int K, const int* pairs, const float* w_outer, const float* bias, float* y, int ldy,
+                   int H, int relu, float keep, const uint64_t* seed_ptr, uint64_t seed, float* ws, hipStream_t st);
+int opnn_outer_wgrad(const float* e, int e_ld, int B, int F, int K, const int* pairs, const float* dy, int lddy, int H, float* dw_outer, hipStream_t st);
 
 // ---- dense_ops.hip
 int rowdot(const float* x, int ldx, const float* w, const float* bias, int M, int n, float* y, int accumulate,

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Kernel-trace stats of an arbitrary command on the GPU box: bash tools/prof_cmd.sh <tag> <limit_s> <command...>
+# (every stage under `timeout`: a profiler that produced nothing must not leave a reader waiting on stdin)
+set -u
+TAG=$1; LIM=$2; shift 2
+R=$PWD
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+timeout $LIM rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG -- "$@" > $OUT/cmd.out 2> $OUT/trace.err
+cd $R
+if [ -f $OUT/trace/${TAG}_results.db ]; then
+    timeout 120 python tools/prof_summary.py stats $OUT/trace/${TAG}_results.db > $OUT/${TAG}_kernel_stats.txt 2>&1
+    head -25 $OUT/${TAG}_kernel_stats.txt
+else
+    echo "no results db"; tail -5 $OUT/trace.err
+fi
+rm -rf $OUT/trace
