@@ -55,7 +55,7 @@ def test_train_steps_match_oracle(model, opt, dev):
     eng.close()
 
 
-@pytest.mark.parametrize("K,H,B", [(16, 256, 96), (16, 200, 77), (32, 64, 130), (16, 320, 64)])
+@pytest.mark.parametrize("K,H,B", [(16, 256, 96), (16, 200, 77), (32, 64, 130), (16, 320, 64), (64, 128, 40), (32, 256, 33)])
 def test_outer_pnn_fused_first_layer(K, H, B, dev):
     """Outer-PNN with K >= 16: the [B, P K K] product tensor is never formed (gemm_dr.h DR_AGEN_*); forward, weight gradient and
     dL/de against the oracle's materialised einsum (PNN.py:139-167), ragged batches, every tile width of the kernel."""

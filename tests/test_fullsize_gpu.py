@@ -1,8 +1,8 @@
 """Parity at BASELINE.json's FULL sizes (configs c2, c3, c4) plus size-independent properties and edge cases.
 
 c2 DeepFM  B=4096 V=1e6 K=16 MLP 400-400-400;  c3 DCN B=4096 V=1e6 K=16, 3 cross layers + 400-400;
-c4 PNN(inner) / NFM  B=8192 V=1e6 K=32 MLP 256-128  (outer-PNN at K=32 materialises [B, 741*1024] per PNN.py:161-167:
-25 GB at this batch -- exercised at small K in test_engine_gpu.py only).
+c4 PNN(inner) / NFM  B=8192 V=1e6 K=32 MLP 256-128  (outer-PNN at K=32: 741*1024 pair products per example, PNN.py:161-167, formed
+inside the first layer's GEMMs -- checked here at a batch the oracle's materialised einsum fits the host).
 The oracle is timed in seconds at these sizes (one step), so the comparison is direct: logits 1e-4 (north_star), loss 1e-5
 rel, every parameter 2e-6 abs after one dense-exact Adam step.  Properties: the per-row gradient sums reproduce the
 per-entry sums (checksum of checksums), grouping finds exactly numpy's distinct ids, predict is idempotent, a step
@@ -140,7 +140,7 @@ def test_edge_batches(case, dev):
 def test_c4_outer_pnn_at_k32(dev):
     """c4's outer-product PNN at its real embedding size (K=32: 741 pairs x 1024 products = 758 784 extra MLP inputs per example,
     PNN.py:154-167), batch reduced so that the oracle's [B, 758784] einsum fits the host; the full c4 batch (8192) runs
-    materialised in 2 x 24.9 GB on the GPU (tools/config_bench.py: 149 ms/step)."""
+    without that tensor on the GPU (tools/config_bench.py: 76 ms/step)."""
     B, K, Vs = 128, 32, 100_000
     ocfg, params, eng = make_pair("opnn", B=B, F=F, V=Vs, K=K, layers=(64, 32), opt="Adam", l2=1e-4, lr=5e-4, scale=0.02, use_graph=False)
     ids, vals, labels = O.synth_batch(B, F, Vs, seed=77)

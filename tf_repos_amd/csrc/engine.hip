@@ -382,7 +382,8 @@ int build(dctr_engine* E) {
         DCTR_TRY(dmalloc(&E->opnn_pairs, pairs.size()));
         DCTR_HIP_CHECK(hipMemcpy(E->opnn_pairs, pairs.data(), pairs.size() * sizeof(int), hipMemcpyHostToDevice));
         DCTR_TRY(dmalloc(&E->opnn_ws, (size_t)opnn_fwd_ws_floats_max(MB, c.deep_layers[0])));
-        DCTR_TRY(dmalloc(&E->opnn_dop, (size_t)(MB + GEMM_SLACK_ROWS) * P * K * K, false));
+        static const bool dop_env = getenv("DCTR_OPNN_DGRAD_MATERIALISE") != nullptr;       // A/B knob
+        if (dop_env || !opnn_dgrad_fused_ok(K, c.deep_layers[0])) DCTR_TRY(dmalloc(&E->opnn_dop, (size_t)(MB + GEMM_SLACK_ROWS) * P * K * K, false));
     }
     {   // (attention pooling: the per-entry gradient rows `dub` sit behind dx_in so that one int32 float4 offset reaches both)
         const size_t dxn = (size_t)(MB + GEMM_SLACK_ROWS) * E->Din_ld;
@@ -618,6 +619,9 @@ int opnn_outer_dgrad(dctr_engine* E, int B, hipStream_t st) {
     const Fc& fc = E->mlp[0];
     const int F = E->F, K = E->K, D = E->D;
     const int64_t L = (int64_t)E->P * K * K;
+    if (E->opnn_dop == nullptr)
+        return opnn_outer_dgrad_fused(E->dh[0], fc.out, fc.out, E->pp(fc.w) + (size_t)D * fc.out, E->e, E->e_ld, E->opnn_pairs, B, F, K, E->dx_in, E->Din_ld, st);
+    // (first layer wider than 256 or K > 64: d(pair products) materialised, then contracted)
     DCTR_TRY(fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w) + (size_t)D * fc.out, E->opnn_dop, (int)L, B, (int)L, fc.out, nullptr, 0, 1.f, st, 1));
     return pnn_outer_bwd(E->e, E->e_ld, E->opnn_dop, L, B, F, K, E->dx_in, E->Din_ld, st);
 }

@@ -96,6 +96,10 @@ int64_t opnn_fwd_ws_floats_max(int max_batch, int H);
 int opnn_outer_fwd(const float* e, int e_ld, int B, int F, int K, const int* pairs, const float* w_outer, const float* bias, float* y, int ldy,
                    int H, int relu, float keep, const uint64_t* seed_ptr, uint64_t seed, float* ws, hipStream_t st);
 int opnn_outer_wgrad(const float* e, int e_ld, int B, int F, int K, const int* pairs, const float* dy, int lddy, int H, float* dw_outer, hipStream_t st);
+// ... and its backward to the embeddings without the [B, P K K] gradient tensor (opnn_dgrad.hip)
+bool opnn_dgrad_fused_ok(int K, int H);
+int opnn_outer_dgrad_fused(const float* dh, int lddh, int H, const float* w_outer, const float* e, int e_ld, const int* pairs, int B, int F, int K,
+                           float* dE, int de_ld, hipStream_t st);
 
 // ---- dense_ops.hip
 int rowdot(const float* x, int ldx, const float* w, const float* bias, int M, int n, float* y, int accumulate,

@@ -21,7 +21,7 @@ CONFIGS = {
     "c3 DCN B=4096 V=1e6 K=16 cross 3 MLP 400x2": dict(model="dcn", B=4096, V=1_000_000, K=16, layers=(400, 400), cross=3),
     "c4 PNN-inner B=8192 V=1e6 K=32 MLP 256-128": dict(model="ipnn", B=8192, V=1_000_000, K=32, layers=(256, 128)),
     "c4 NFM B=8192 V=1e6 K=32 MLP 256-128": dict(model="nfm", B=8192, V=1_000_000, K=32, layers=(256, 128)),
-    "c4 PNN-outer B=8192 V=1e6 K=32 MLP 256-128 (P*K^2 = 758784 outer-product inputs materialised: 2 x 24.9 GB)":
+    "c4 PNN-outer B=8192 V=1e6 K=32 MLP 256-128 (P*K^2 = 758784 pair products per example, formed inside the first-layer GEMMs)":
         dict(model="opnn", B=8192, V=1_000_000, K=32, layers=(256, 128), steps=5),
     "AFM B=4096 V=1e6 K=16 att 256": dict(model="afm", B=4096, V=1_000_000, K=16, layers=(1,), att=(256,)),
     "DeepMVM B=4096 V=1e6 K=16 MLP 400x3": dict(model="mvm", B=4096, V=1_000_000, K=16, layers=(400, 400, 400)),
