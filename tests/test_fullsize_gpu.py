@@ -159,6 +159,51 @@ def test_c4_outer_pnn_at_k32(dev):
     eng.close()
 
 
+def _opnn_full_batch_step(out_path):
+    """One c4 Outer-PNN step at the FULL batch (B=8192, K=32, 256-128); writes loss, logits and samples of every variable."""
+    dev = torch.device("cuda", 0)
+    B, K, Vs = 8192, 32, 200_000
+    ocfg, params, eng = make_pair("opnn", B=B, F=F, V=Vs, K=K, layers=(256, 128), opt="Adam", l2=1e-4, lr=5e-4, scale=0.02, use_graph=False)
+    ids, vals, labels = O.synth_batch(B, F, Vs, seed=4242)
+    d = dev_batch(ids, vals, labels, dev)
+    logit = torch.empty(B, device=dev)
+    eng.predict(d[0], d[1], torch.empty(B, device=dev), logit)
+    loss = eng.train_step(*d)
+    rows = np.random.default_rng(5).choice(params["mlp0/weights"].shape[0], 8192, replace=False)
+    out = {"loss": np.float64(loss), "logit": logit.cpu().numpy(), "w0_rows": eng.param_tensor("mlp0/weights")[torch.from_numpy(rows).to(dev)].cpu().numpy(),
+           "emb_rows": eng.param_tensor("emb")[torch.from_numpy(np.unique(ids)[:20000]).to(dev)].cpu().numpy()}
+    for k in ("mlp0/biases", "mlp1/weights", "mlp1/biases", "deep_out/weights", "deep_out/biases", "bias"):
+        out[k.replace("/", "__")] = eng.get_param(k)
+    eng.close()
+    np.savez(out_path, **out)
+    return ocfg, params, ids, vals
+
+
+def test_c4_outer_pnn_full_batch_fused_equals_materialised(dev, tmp_path):
+    """c4's Outer-PNN at its full batch: (1) logits of 64 sampled examples against the oracle (the forward is per example);
+    (2) the whole training step with the pair products formed inside the GEMMs against the SAME step with the [B, 758784]
+    tensors materialised as PNN.py:161-167 writes them (child process, DCTR_OPNN_MATERIALISE=1 -- the path test_c4_outer_pnn_at_k32
+    pins to the oracle at a batch the host can hold)."""
+    import os, subprocess, sys
+    ocfg, params, ids, vals = _opnn_full_batch_step(str(tmp_path / "fused.npz"))
+    fused = dict(np.load(str(tmp_path / "fused.npz")))
+    pick = np.random.default_rng(1).choice(8192, 64, replace=False)
+    ref = O.forward(ocfg, params, ids[pick], vals[pick])
+    assert np.abs(fused["logit"][pick] - ref["y"].numpy()).max() <= 1e-4
+    env = dict(os.environ, DCTR_OPNN_MATERIALISE="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", "import sys; from tests.test_fullsize_gpu import _opnn_full_batch_step as f; f(sys.argv[1])",
+                        str(tmp_path / "mat.npz")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    mat = dict(np.load(str(tmp_path / "mat.npz")))
+    assert abs(float(fused["loss"]) - float(mat["loss"])) <= 1e-5 * max(1.0, abs(float(mat["loss"])))
+    assert np.abs(fused["logit"] - mat["logit"]).max() <= 1e-4
+    for k in mat:
+        if k not in ("loss", "logit"):
+            # (embedding rows: a first Adam step moves an element by lr g / (|g| + 1e-8); the two paths sum dL/de in different orders --
+            # float atomics here, a tree there -- and for an id seen once with |g| ~ 1e-7 that rounding shows as a few % of lr = 5e-4)
+            assert np.abs(fused[k] - mat[k]).max() <= (3e-5 if k == "emb_rows" else 2e-6), k
+
+
 def test_c1_reference_operating_point_full_size(dev):
     """BASELINE configs[0] / deep_ctr/README.md:49 as documented: DeepFM, feature_size 117581, B=256, K=8, 400-400-400, Adam 5e-4."""
     ocfg, params, eng = make_pair("deepfm", B=256, F=F, V=117581, K=8, layers=(400, 400, 400), opt="Adam", l2=1e-4, lr=5e-4, scale=0.01,
