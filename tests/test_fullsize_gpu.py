@@ -199,9 +199,9 @@ def test_c4_outer_pnn_full_batch_fused_equals_materialised(dev, tmp_path):
     assert np.abs(fused["logit"] - mat["logit"]).max() <= 1e-4
     for k in mat:
         if k not in ("loss", "logit"):
-            # (embedding rows: a first Adam step moves an element by lr g / (|g| + 1e-8); the two paths sum dL/de in different orders --
+            # (embedding and first-layer rows: a first Adam step moves an element by lr g / (|g| + 1e-8); the two paths sum dL/de in different orders --
             # float atomics here, a tree there -- and for an id seen once with |g| ~ 1e-7 that rounding shows as a few % of lr = 5e-4)
-            assert np.abs(fused[k] - mat[k]).max() <= (3e-5 if k == "emb_rows" else 2e-6), k
+            assert np.abs(fused[k] - mat[k]).max() <= (3e-5 if k in ("emb_rows", "w0_rows") else 2e-6), k
 
 
 def test_c1_reference_operating_point_full_size(dev):

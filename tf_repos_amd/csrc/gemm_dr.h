@@ -186,17 +186,27 @@ __global__ __launch_bounds__(256, 1) void gemm_dr_kernel(const float* __restrict
     const float* Ab = AGEN == DR_AGEN_OUTER_FWD ? og.e + (size_t)m0 * og.e_ld : AGEN == DR_AGEN_OUTER_WGRAD ? og.e + (size_t)kbeg * og.e_ld
                       : A + (A_RC ? (size_t)m0 * lda + kbeg : (size_t)kbeg * lda + m0);
     const float* Bb = B + (B_RC ? (size_t)n0 * ldb + kbeg : (size_t)kbeg * ldb + n0);
-    const int Kb = AGEN == DR_AGEN_OUTER_WGRAD ? min(K, og.rows) : K;          // true rows of B behind a rounded-up reduction length
-    const int bytesA = AGEN == DR_AGEN_OUTER_FWD ? 4 * (og.rows - m0) * og.e_ld : AGEN == DR_AGEN_OUTER_WGRAD ? 4 * (og.rows - kbeg) * og.e_ld
-                       : 4 * (A_RC ? (M - m0 - 1) * lda + (K - kbeg) : (K - kbeg - 1) * lda + (M - m0));
-    const int bytesB = 4 * (B_RC ? (N - n0 - 1) * ldb + (Kb - kbeg) : (Kb - kbeg - 1) * ldb + (N - n0));
+    // num_records: the true end of the operand where this wave could reach it, i.e. clipped to the wave's own rows -- an
+    // operand of several GB (AFM's 3 M pair rows) stays addressable with 32-bit offsets behind the per-wave base
+    const int Kb = AGEN == DR_AGEN_OUTER_WGRAD ? min(kend, og.rows) : kend;      // last reduction index this wave reads, exclusive
+    // (32-bit compares only: HIP's min / max on int64 resolve to the double overloads -- f64 VALU code, and a descriptor word that
+    // leaves the scalar unit costs every buffer load a waterfall loop)
+    auto clip31 = [](int64_t floats) -> int {
+        const int hi = (int)(floats >> 32);
+        const unsigned top = (unsigned)((uint64_t)floats >> 29);        // != 0: negative, or 2^31 bytes and more
+        return hi < 0 ? 0 : (top != 0u ? 0x7ffffff0 : (int)((unsigned)floats * 4u));
+    };
+    const int bytesA = AGEN == DR_AGEN_OUTER_FWD ? clip31((int64_t)min(og.rows - m0, 16 * TM) * og.e_ld)
+                       : AGEN == DR_AGEN_OUTER_WGRAD ? clip31((int64_t)(min(kend, og.rows) - kbeg) * og.e_ld)
+                       : clip31(A_RC ? (int64_t)(min(M - m0, 16 * TM) - 1) * lda + (K - kbeg) : (int64_t)(kend - kbeg - 1) * lda + (M - m0));
+    const int bytesB = clip31(B_RC ? (int64_t)(min(N - n0, 16 * TN) - 1) * ldb + (K - kbeg) : (int64_t)(Kb - kbeg - 1) * ldb + (N - n0));
     auto uni_ptr = [](const float* p) {
         const uint64_t v = reinterpret_cast<uint64_t>(p);
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
         return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
     };
-    const auto ra = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(Ab), 0, __builtin_amdgcn_readfirstlane(max(bytesA, 0)), 0x00020000);
-    const auto rb = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(Bb), 0, __builtin_amdgcn_readfirstlane(max(bytesB, 0)), 0x00020000);
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(Ab), 0, __builtin_amdgcn_readfirstlane(bytesA), 0x00020000);
+    const auto rb = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(Bb), 0, __builtin_amdgcn_readfirstlane(bytesB), 0x00020000);
     constexpr int NA = A_RC ? TM : AG, NB = B_RC ? TN : TQ + (TN - 4 * TQ);         // lane offsets per operand
     int aoff[NA], boff[NB];
 #pragma unroll

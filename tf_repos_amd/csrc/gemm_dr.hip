@@ -89,8 +89,10 @@ int dr_launch_outer(const DrOuter& og, const float* Bm, int ldb, float* C, int l
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-// an operand the kernel addresses with 32-bit byte offsets behind a per-block base
+// the kernel addresses an operand with 32-bit byte offsets behind a per-WAVE base: what must fit is the wave's own extent -- its
+// tile's rows of a reduction-contiguous operand, its quarter of the (split) reduction range of the other kind
 inline bool fits31(int64_t rows, int64_t ld) { return rows * ld * 4 < (int64_t)0x7fff0000; }
+inline int64_t wave_rows(int64_t R, int S) { return (round_up(ceil_div(R, S), 16) + 15) / 16 * 4 + 16; }
 
 template <size_t NT>
 int pick(const Tile (&list)[NT], int Mo, int No, int64_t R, int S, double* eff) {
@@ -106,7 +108,8 @@ int pick(const Tile (&list)[NT], int Mo, int No, int64_t R, int S, double* eff) 
 constexpr Tile FWD_TILES[] = {{2, 13}, {4, 7}, {2, 8}};
 constexpr Tile DGRAD_TILES[] = {{2, 13}, {4, 10}, {2, 8}};
 // (no 3x13 here: 392 VGPRs -- a wgrad runs beside the background table pass, whose two waves per SIMD leave room for 320)
-constexpr Tile WGRAD_TILES[] = {{2, 13}, {2, 8}};
+// (2x16: a 256-wide output in one column block -- AFM's attention weight over 3 M pair rows, 8 row tiles x 32 batch splits)
+constexpr Tile WGRAD_TILES[] = {{2, 13}, {2, 8}, {2, 16}};
 
 }  // namespace
 
@@ -115,7 +118,7 @@ int dr_fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y,
               const uint64_t* seed_ptr, uint64_t seed, hipStream_t st, bool* done) {
     *done = false;
     if (!dr_enabled('f') || M <= 0 || N <= 0 || K < 64) return DCTR_OK;
-    if (!al16(x) || !al16(w) || (ldx & 3) || (N & 3) || !fits31(M, ldx) || !fits31(K, N)) return DCTR_OK;
+    if (!al16(x) || !al16(w) || (ldx & 3) || (N & 3) || !fits31(64, ldx) || !fits31(wave_rows(K, 1), N)) return DCTR_OK;
     double eff;
     const int t = pick(FWD_TILES, M, N, K, 1, &eff);
     if (t < 0 || eff < dr_threshold()) return DCTR_OK;
@@ -135,7 +138,7 @@ int dr_fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int ldd
                    float keep_prev, hipStream_t st, bool* done) {
     *done = false;
     if (!dr_enabled('d') || M <= 0 || K <= 0 || N < 64) return DCTR_OK;
-    if (!al16(dy) || !al16(w) || (lddy & 3) || (N & 3) || !fits31(M, lddy) || !fits31(K, N)) return DCTR_OK;
+    if (!al16(dy) || !al16(w) || (lddy & 3) || (N & 3) || !fits31(64, lddy) || !fits31(256, N)) return DCTR_OK;
     double eff;
     const int t = pick(DGRAD_TILES, M, K, N, 1, &eff);
     if (t < 0 || eff < dr_threshold()) return DCTR_OK;
@@ -178,7 +181,8 @@ int dr_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int ldd
                                int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, bool* done) {
     *done = false;
     if (!dr_enabled('w') || M <= 0 || splits < 1 || (int64_t)ceil_div(M, splits) < 64) return DCTR_OK;
-    if (!al16(x) || !al16(dy) || (ldx & 3) || (lddy & 3) || (N & 3) || !fits31(M, ldx) || !fits31(M, lddy) || !al16(dw_part) || (dw_stride & 3))
+    if (!al16(x) || !al16(dy) || (ldx & 3) || (lddy & 3) || (N & 3) || !fits31(wave_rows(M, splits), ldx) || !fits31(wave_rows(M, splits), lddy) ||
+        !al16(dw_part) || (dw_stride & 3))
         return DCTR_OK;
     double eff;
     const int t = pick(WGRAD_TILES, K, N, M, splits, &eff);
@@ -193,7 +197,8 @@ int dr_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int ldd
     *done = true;
     switch (t) {
         case 0: return dr_launch<2, 13, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
-        default: return dr_launch<2, 8, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
+        case 1: return dr_launch<2, 8, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
+        default: return dr_launch<2, 16, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
     }
 }
 
