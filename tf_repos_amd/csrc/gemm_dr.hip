@@ -34,6 +34,9 @@ double dr_efficiency(int Mo, int No, int64_t R, int S, Tile t, int* blocks_out) 
     const double steps = (double)((kw + 3) / 4);                  // MFMA steps per wave
     const double ideal = (double)Mo * No * (double)R / 32768.0;
     const double block_cycles = steps * t.tm * t.tn * 32.0 + 9000.0;
+    // one block per CU at a time (launch bounds, LDS): nothing hides a block's prologue and reduction behind its neighbour's MFMAs,
+    // so a grid of many rounds is the LDS-tiled kernel's territory (AFM's 3 M-row attention dgrad: 9.6 ms here, 5.8 ms there)
+    if (rounds > 4) return 0.0;
     return ideal / ((double)rounds * block_cycles);
 }
 
@@ -109,7 +112,7 @@ constexpr Tile FWD_TILES[] = {{2, 13}, {4, 7}, {2, 8}};
 constexpr Tile DGRAD_TILES[] = {{2, 13}, {4, 10}, {2, 8}};
 // (no 3x13 here: 392 VGPRs -- a wgrad runs beside the background table pass, whose two waves per SIMD leave room for 320)
 // (2x16: a 256-wide output in one column block -- AFM's attention weight over 3 M pair rows, 8 row tiles x 32 batch splits)
-constexpr Tile WGRAD_TILES[] = {{2, 13}, {2, 8}, {2, 16}};
+constexpr Tile WGRAD_TILES[] = {{2, 13}, {2, 16}, {2, 8}};
 
 }  // namespace
 
@@ -197,8 +200,8 @@ int dr_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int ldd
     *done = true;
     switch (t) {
         case 0: return dr_launch<2, 13, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
-        case 1: return dr_launch<2, 8, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
-        default: return dr_launch<2, 16, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
+        case 1: return dr_launch<2, 16, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
+        default: return dr_launch<2, 8, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
     }
 }
 
