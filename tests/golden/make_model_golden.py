@@ -161,6 +161,10 @@ CASES = [
     ("mvm", "DeepMVM.py", {}, BASE),
     # the operating point of deep_ctr/README.md:49 (K = 8 as BASELINE c1), vocabulary shrunk so the fixture stays small
     ("deepfm_c1_shape", "DeepFM.py", {}, dict(BASE, feature_size=2000, embedding_size=8, learning_rate=0.0005, l2_reg=1e-4, deep_layers="400,400,400")),
+    # (appended, so that the seeds of the cases above stay what they were)
+    # AFM.py:143-145 with two attention widths; Outer-PNN at K = 16, where the engine forms the pair products inside the GEMMs
+    ("afm_2att", "AFM.py", {}, dict(BASE, dropout="1.0,1.0", attention_layers="12,6")),
+    ("opnn_k16", "PNN.py", {"model_type": "Outer"}, dict(BASE, field_size=8, feature_size=300, embedding_size=16)),
 ]
 
 if __name__ == "__main__":

@@ -79,6 +79,30 @@ def test_outer_pnn_fused_first_layer(K, H, B, dev):
     eng.close()
 
 
+@pytest.mark.parametrize("att", [(16, 8), (24, 12, 8)])
+def test_afm_multi_layer_attention(att, dev):
+    """AFM.py:143-145 loops over --attention_layers: more than one width runs layer by layer over the B*P pair rows."""
+    F, V, B, K = 12, 800, 48, 8
+    ocfg, params, eng = make_pair("afm", B=B, F=F, V=V, K=K, att=att, opt="Adam", lr=1e-2, l2=1e-3)
+    assert all("att_mlp%d/weights" % i in eng.param_shapes for i in range(len(att)))
+    oopt = O.Optimizer(ocfg, params)
+    for step in range(2):
+        ids, vals, labels = O.synth_batch(B, F, V, seed=500 + step)
+        d = dev_batch(ids, vals, labels, dev)
+        if step == 0:
+            ref = O.forward(ocfg, params, ids, vals)
+            logit = torch.empty(B, device=dev)
+            eng.predict(d[0], d[1], torch.empty(B, device=dev), logit)
+            assert np.abs(logit.cpu().numpy() - ref["y"].numpy()).max() <= 1e-4
+        ref_loss, _ = O.train_step(ocfg, params, oopt, ids, vals, labels)
+        loss = eng.train_step(*d)
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (step, loss, ref_loss)
+    got = eng.get_params()
+    for name, ref in params.items():
+        assert np.abs(got[name] - ref.numpy()).max() <= 2e-6, name
+    eng.close()
+
+
 def test_touched_rows_mode_only_updates_batch_rows(dev):
     F, V, B, K = 39, 3000, 64, 8
     ocfg, params, eng = make_pair("deepfm", B=B, F=F, V=V, K=K, table_mode="touched_rows")

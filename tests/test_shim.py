@@ -60,6 +60,17 @@ def test_reference_scripts_lower_onto_the_engine(script, flags, model, names):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_afm_with_several_attention_layers_lowers():
+    """AFM.py:143-145: --attention_layers is a list; every width becomes an att_mlp%d layer of the engine."""
+    from tf_repos_amd.run_reference import load_reference_module
+    mod = load_reference_module(os.path.join(REF, "AFM.py"))
+    _spec, low, _pipe, _vars = _trace(mod, dict(PARAMS, attention_layers="64,16"))
+    assert low.model == "afm" and low.config_kwargs["attention_layers"] == (64, 16)
+    assert low.name_map["att_mlp1/weights"] == "Attention-part/mlp1/weights"
+    assert low.name_map["attention_out/weights"] == "Attention-part/attention_out/weights"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
 def test_reference_quirks_surface_unchanged():
     from tf_repos_amd.run_reference import load_reference_module
     import tf_repos_amd.tf_shim as shim

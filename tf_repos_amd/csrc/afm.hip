@@ -169,19 +169,35 @@ using namespace dctr;
 int afm_declare_params(dctr_engine* E) {
     auto add = engine_add_param;
     const dctr_config& c = E->cfg;
-    DCTR_REQUIRE(c.n_attention_layers == 1, "AFM: exactly one attention layer is supported (got %d)", c.n_attention_layers);
-    E->A = c.attention_layers[0];
-    DCTR_REQUIRE(E->A > 0, "AFM: attention layer width must be > 0");
+    const int nl = c.n_attention_layers;
+    DCTR_REQUIRE(nl >= 1 && nl <= DCTR_MAX_LAYERS, "AFM: 1..%d attention layers (got %d)", DCTR_MAX_LAYERS, nl);
+    for (int l = 0; l < nl; ++l) DCTR_REQUIRE(c.attention_layers[l] > 0, "AFM: attention layer widths must be > 0");
+    E->A = c.attention_layers[nl - 1];          // what attention_out projects (AFM.py:147)
     E->keep_att = c.keep_prob[0] > 0.f ? c.keep_prob[0] : 1.f;
     E->keep_emb = c.keep_prob[1] > 0.f ? c.keep_prob[1] : 1.f;
     const int K = E->K, A = E->A;
     // the attention network runs fused over the pair rows when its shape allows (afm_fused.hip): the hidden layer [B*P, A] is
     // then never materialised, and the four attention parameters take their gradient from AFM_SLABS atomically filled slabs
-    E->afm_fused = getenv("DCTR_AFM_UNFUSED") == nullptr && afm_fused_supported(K, A);        // (the env knob is the A/B switch)
-    E->att_splits = E->afm_fused ? AFM_SLABS : choose_wgrad_splits(E->MB * E->P, K, A);
+    // (one hidden layer, the reference's default; the AFM.py:143-145 loop with more widths runs layer by layer)
+    E->afm_fused = nl == 1 && getenv("DCTR_AFM_UNFUSED") == nullptr && afm_fused_supported(K, A);        // (the env knob is the A/B switch)
     const int ao = E->afm_fused ? AFM_SLABS : E->ao_splits;
-    E->p_att_w = add(E, "att_mlp0/weights", {K, A}, false, E->att_splits, 0.f);
-    E->p_att_b = add(E, "att_mlp0/biases", {A}, false, E->att_splits, 0.f);
+    int d = K;
+    for (int l = 0; l < nl; ++l) {
+        Fc fc;
+        fc.in = d; fc.out = c.attention_layers[l];
+        fc.splits = E->afm_fused ? AFM_SLABS : choose_wgrad_splits(E->MB * E->P, fc.in, fc.out);
+        char nm[64];
+        snprintf(nm, sizeof(nm), "att_mlp%d/weights", l);
+        fc.w = add(E, nm, {fc.in, fc.out}, false, fc.splits, 0.f);
+        snprintf(nm, sizeof(nm), "att_mlp%d/biases", l);
+        fc.b = add(E, nm, {fc.out}, false, fc.splits, 0.f);
+        fc.last = fc.b;
+        E->att_fc.push_back(fc);
+        d = fc.out;
+    }
+    E->att_splits = E->att_fc[0].splits;
+    E->p_att_w = E->att_fc[0].w;
+    E->p_att_b = E->att_fc[0].b;
     E->p_ao_w = add(E, "attention_out/weights", {A, 1}, false, ao, 0.f);
     E->p_ao_b = add(E, "attention_out/biases", {1}, false, ao, 0.f);
     E->p_out_w = add(E, "deep_out/weights", {K, 1}, false, E->out_splits, 0.f);
@@ -201,9 +217,17 @@ int afm_alloc(dctr_engine* E) {
     DCTR_TRY(dm(&E->pairp, MB * P * K));
     DCTR_TRY(dm(&E->dpairp2, MB * P * K));
     if (!E->afm_fused) {
-        DCTR_TRY(dm(&E->ah, MB * P * A));
-        DCTR_TRY(dm(&E->dah, MB * P * A));
+        for (const Fc& fc : E->att_fc) {
+            float *a = nullptr, *da = nullptr;
+            DCTR_TRY(dm(&a, MB * P * (size_t)fc.out));
+            DCTR_TRY(dm(&da, MB * P * (size_t)fc.out));
+            E->ahs.push_back(a);
+            E->dahs.push_back(da);
+        }
+        E->ah = E->ahs.back();
+        E->dah = E->dahs.back();
     }
+    (void)A;
     DCTR_TRY(dm(&E->sc, MB * P));
     DCTR_TRY(dm(&E->dsc, MB * P));
     DCTR_TRY(dm(&E->att, MB * P));
@@ -219,8 +243,10 @@ int afm_alloc(dctr_engine* E) {
 }
 
 void afm_free(dctr_engine* E) {
-    float* fl[] = {E->pairp, E->dpairp2, E->ah, E->dah, E->sc, E->dsc, E->att, E->dE_buf};
+    float* fl[] = {E->pairp, E->dpairp2, E->sc, E->dsc, E->att, E->dE_buf};
     for (float* p : fl) if (p) hipFree(p);
+    for (float* p : E->ahs) hipFree(p);
+    for (float* p : E->dahs) hipFree(p);
     if (E->pair_i) hipFree(E->pair_i);
     if (E->pair_j) hipFree(E->pair_j);
 }
@@ -237,7 +263,12 @@ int afm_forward(dctr_engine* E, int B, bool train, hipStream_t st) {
         // scores straight from the pair products (the hidden layer never leaves the registers; the backward recomputes it)
         DCTR_TRY(afm_att_fwd(E->pairp, E->pp(E->p_att_w), E->pp(E->p_att_b), E->pp(E->p_ao_w), E->pp(E->p_ao_b), (int64_t)B * P, K, A, E->sc, st));
     } else {
-        DCTR_TRY(fc_fwd(E->pairp, K, E->pp(E->p_att_w), E->pp(E->p_att_b), E->ah, A, B * P, K, A, 1, 1.f, nullptr, 0, st));
+        const float* x = E->pairp;
+        for (size_t l = 0; l < E->att_fc.size(); ++l) {     // relu(x W_l + b_l) over the B*P pair rows
+            const Fc& fc = E->att_fc[l];
+            DCTR_TRY(fc_fwd(x, fc.in, E->pp(fc.w), E->pp(fc.b), E->ahs[l], fc.out, B * P, fc.in, fc.out, 1, 1.f, nullptr, 0, st));
+            x = E->ahs[l];
+        }
         DCTR_TRY(rowdot(E->ah, A, E->pp(E->p_ao_w), E->pp(E->p_ao_b), B * P, A, E->sc, 0, st));
     }
     afm_pool_fwd_kernel<<<B, 256, (size_t)P * sizeof(float), st>>>(E->sc, E->pairp, P, K, E->keep_att, E->keep_emb, &E->state->seed_t,
@@ -274,13 +305,18 @@ int afm_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
     // attention_out (A -> 1) over the B*P rows: d ah = dsc (x) w_o masked by relu, dW_o / db_o partial slabs
     DCTR_TRY(out_layer_bwd(E->ah, A, E->dsc, E->pp(E->p_ao_w), B * P, A, aw.n_part, 1, 1.f, E->dah, A, E->part(E->p_ao_w), aw.padded,
                            E->part(E->p_ao_b), ab.padded, st));
-    // attention layer: wgrad on the side stream, dgrad on the critical path
-    DCTR_TRY(fork(E, st, sw));
-    const Param& w = E->params[E->p_att_w];
-    const Param& b = E->params[E->p_att_b];
-    DCTR_TRY(fc_bwd_weights_partials(E->pairp, K, E->dah, A, E->part(E->p_att_w), w.padded, E->part(E->p_att_b), b.padded, B * P, K, A,
-                                     E->att_splits, sw));
-    DCTR_TRY(fc_bwd_data(E->dah, A, E->pp(E->p_att_w), E->dpairp2, K, B * P, K, A, nullptr, 0, 1.f, st));
+    // attention layers, last to first: wgrad on the side stream, dgrad (x the ReLU mask of the layer below) on the critical path
+    for (int l = (int)E->att_fc.size() - 1; l >= 0; --l) {
+        const Fc& fc = E->att_fc[l];
+        const Param& w = E->params[fc.w];
+        const Param& b = E->params[fc.b];
+        const float* xin = l > 0 ? E->ahs[l - 1] : E->pairp;
+        DCTR_TRY(fork(E, st, sw));              // dahs[l] is complete on st
+        DCTR_TRY(fc_bwd_weights_partials(xin, fc.in, E->dahs[l], fc.out, E->part(fc.w), w.padded, E->part(fc.b), b.padded, B * P, fc.in, fc.out,
+                                         fc.splits, sw));
+        if (l > 0) DCTR_TRY(fc_bwd_data(E->dahs[l], fc.out, E->pp(fc.w), E->dahs[l - 1], fc.in, B * P, fc.in, fc.out, E->ahs[l - 1], fc.in, 1.f, st));
+        else DCTR_TRY(fc_bwd_data(E->dahs[0], fc.out, E->pp(fc.w), E->dpairp2, K, B * P, K, fc.out, nullptr, 0, 1.f, st));
+    }
     dim3 grid(ceil_div(F * K, 256), B);
     afm_pair_bwd_kernel<<<grid, 256, 0, st>>>(E->e, E->e_ld, E->sc, E->dx_in, E->Din_ld, E->dpairp2, F, K, P, E->dE_buf, E->D);
     DCTR_LAUNCH_CHECK();

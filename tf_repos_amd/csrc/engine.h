@@ -151,6 +151,8 @@ struct dctr_engine {
     int A = 0;                       // attention layer width
     int p_att_w = -1, p_att_b = -1, p_ao_w = -1, p_ao_b = -1;
     int att_splits = 1, ao_splits = 1024;
+    std::vector<Fc> att_fc;          // the attention network's hidden layers (AFM.py:143-145); [0] = p_att_w / p_att_b
+    std::vector<float*> ahs, dahs;   // their activations / gradients over the B*P pair rows (unfused path); ah / dah = the last ones
     bool afm_fused = false;          // attention network fused over the pair rows (afm_fused.hip)
     float keep_att = 1.f, keep_emb = 1.f;
     float *pairp = nullptr, *dpairp2 = nullptr, *ah = nullptr, *dah = nullptr, *sc = nullptr, *dsc = nullptr,
