@@ -8,9 +8,20 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-timeout $LIM rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG -- "$@" > $OUT/cmd.out 2> $OUT/trace.err
+# PMC="FETCH_SIZE" (one counter set per run, never together with other trace domains): mean counter value per dispatch instead
+if [ -n "${PMC:-}" ]; then
+    timeout $LIM rocprofv3 --kernel-trace --pmc $PMC -d $OUT/trace -o $TAG -- "$@" > $OUT/cmd.out 2> $OUT/trace.err
+else
+    timeout $LIM rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG -- "$@" > $OUT/cmd.out 2> $OUT/trace.err
+fi
 cd $R
 if [ -f $OUT/trace/${TAG}_results.db ]; then
+    if [ -n "${PMC:-}" ]; then
+        timeout 120 python tools/prof_summary.py pmc $OUT/trace/${TAG}_results.db > $OUT/${TAG}_pmc.txt 2>&1
+        head -25 $OUT/${TAG}_pmc.txt
+        rm -rf $OUT/trace
+        exit 0
+    fi
     timeout 120 python tools/prof_summary.py stats $OUT/trace/${TAG}_results.db > $OUT/${TAG}_kernel_stats.txt 2>&1
     head -25 $OUT/${TAG}_kernel_stats.txt
 else
