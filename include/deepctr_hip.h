@@ -280,6 +280,20 @@ int dctr_pnn_inner_bwd(const float* d_e, int e_ld, const float* d_dip, int dip_l
 int dctr_pnn_outer_fwd(const float* d_e, int e_ld, int B, int F, int K, float* d_op, int64_t op_ld, void* stream);
 int dctr_pnn_outer_bwd(const float* d_e, int e_ld, const float* d_dop, int64_t dop_ld, int B, int F, int K,
                        float* d_dE, int de_ld, void* stream);
+/* Outer-PNN WITHOUT the product tensor: the first fully_connected over [flat embeddings | outer products] (PNN.py:154-167 feeding
+ * PNN.py:159-166) with the products e[b,i_p,a] e[b,j_p,c] formed inside the GEMM fragments.  d_w is the layer's weight exactly as
+ * the reference declares it, [F K + P K K, H] row-major (rows F K + (p K + a) K + c meet pair p's products).  K a power of two
+ * >= 16, H a multiple of 4; bwd_data additionally K <= 64 and H <= 256.
+ *   fwd:          y[B,H] = act([e | outer(e)] W + b)   (relu / dropout as dctr_fc_fwd; workspace: dctr_pnn_outer_fc_workspace_bytes)
+ *   bwd_weights:  dW[F K + P K K, H], db[H] (overwritten)
+ *   bwd_data:     dE[B, F K] = dL/de through both row groups of W (overwritten) */
+size_t dctr_pnn_outer_fc_workspace_bytes(int max_batch, int H);
+int dctr_pnn_outer_fc_fwd(const float* d_e, int e_ld, int B, int F, int K, const float* d_w, const float* d_b, float* d_y, int ldy,
+                          int H, int relu, float keep, uint64_t seed, float* d_workspace, size_t workspace_bytes, void* stream);
+int dctr_pnn_outer_fc_bwd_weights(const float* d_e, int e_ld, int B, int F, int K, const float* d_dy, int lddy, int H, float* d_dw,
+                                  float* d_db, void* stream);
+int dctr_pnn_outer_fc_bwd_data(const float* d_e, int e_ld, int B, int F, int K, const float* d_dy, int lddy, int H, const float* d_w,
+                               float* d_dE, int de_ld, void* stream);
 /* DCN cross network (DCN.py:140-145): x_{l+1} = x0*(x_l . w_l) + x_l + b_l, w,b [L,D].
  * d_xs [L+1, B, D] keeps every x_l (x_0 copied in) and d_xlw [L,B] every x_l.w_l for the backward. */
 int dctr_dcn_cross_fwd(const float* d_x0, int x0_ld, const float* d_w, const float* d_b, int B, int D, int L,

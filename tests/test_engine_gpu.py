@@ -79,6 +79,50 @@ def test_outer_pnn_fused_first_layer(K, H, B, dev):
     eng.close()
 
 
+@pytest.mark.parametrize("K,H,B,F", [(16, 64, 50, 6), (32, 256, 70, 5)])
+def test_outer_pnn_first_layer_ops_through_the_c_abi(K, H, B, F, dev):
+    """dctr_pnn_outer_fc_{fwd,bwd_weights,bwd_data} against the materialised form of PNN.py:154-167 + fully_connected in fp64."""
+    from tf_repos_amd import capi
+    L = capi.lib()
+    g = torch.Generator().manual_seed(3)
+    P = F * (F - 1) // 2
+    e = torch.randn(B, F * K, generator=g) * 0.3
+    w = torch.randn(F * K + P * K * K, H, generator=g) * 0.05
+    b = torch.randn(H, generator=g) * 0.1
+    dy = torch.randn(B, H, generator=g) * 0.1
+    e3 = e.double().view(B, F, K)
+    ops = [torch.einsum("ba,bc->bac", e3[:, i], e3[:, j]).reshape(B, K * K) for i in range(F) for j in range(i + 1, F)]     # PNN.py:142-146,161-166
+    x = torch.cat([e.double()] + ops, dim=1).requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    y_ref = torch.relu(x @ wd + b.double())
+    y_ref.backward(dy.double() * (y_ref > 0))       # (the C ABI takes the gradient at the pre-activation, like dctr_fc_bwd_*)
+    pre = dy.double() * (y_ref > 0).double()
+    # dE through both row groups of W: chain rule of the products by hand
+    dx = x.grad
+    dE = dx[:, :F * K].clone().view(B, F, K)
+    col = F * K
+    for i in range(F):
+        for j in range(i + 1, F):
+            d = dx[:, col:col + K * K].view(B, K, K)
+            dE[:, i] += torch.einsum("bac,bc->ba", d, e3[:, j])
+            dE[:, j] += torch.einsum("bac,ba->bc", d, e3[:, i])
+            col += K * K
+    d_e, d_w, d_b, d_pre = e.to(dev), w.to(dev), b.to(dev), pre.float().to(dev)
+    y = torch.empty(B, H, device=dev)
+    nws = L.dctr_pnn_outer_fc_workspace_bytes(B, H)
+    ws = torch.empty(nws // 4, device=dev)
+    st = capi.current_stream()
+    capi.check(L.dctr_pnn_outer_fc_fwd(capi.ptr(d_e), F * K, B, F, K, capi.ptr(d_w), capi.ptr(d_b), capi.ptr(y), H, H, 1, 1.0, 0, capi.ptr(ws), nws, st))
+    assert (y.cpu().double() - y_ref.detach()).abs().max() <= 1e-5
+    dw, db = torch.empty_like(d_w), torch.empty(H, device=dev)
+    capi.check(L.dctr_pnn_outer_fc_bwd_weights(capi.ptr(d_e), F * K, B, F, K, capi.ptr(d_pre), H, H, capi.ptr(dw), capi.ptr(db), st))
+    assert (dw.cpu().double() - wd.grad).abs().max() <= 1e-5
+    assert (db.cpu().double() - pre.sum(0)).abs().max() <= 1e-5
+    dEg = torch.full((B, F * K), 7.0, device=dev)           # overwritten
+    capi.check(L.dctr_pnn_outer_fc_bwd_data(capi.ptr(d_e), F * K, B, F, K, capi.ptr(d_pre), H, H, capi.ptr(d_w), capi.ptr(dEg), F * K, st))
+    assert (dEg.cpu().double() - dE.reshape(B, F * K)).abs().max() <= 1e-5
+
+
 @pytest.mark.parametrize("att", [(16, 8), (24, 12, 8)])
 def test_afm_multi_layer_attention(att, dev):
     """AFM.py:143-145 loops over --attention_layers: more than one width runs layer by layer over the B*P pair rows."""

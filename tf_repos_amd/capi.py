@@ -89,6 +89,10 @@ _SIGS = {
     "dctr_pnn_inner_bwd": ([_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P], C.c_int),
     "dctr_pnn_outer_fwd": ([_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P], C.c_int),
     "dctr_pnn_outer_bwd": ([_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P], C.c_int),
+    "dctr_pnn_outer_fc_workspace_bytes": ([C.c_int, C.c_int], C.c_size_t),
+    "dctr_pnn_outer_fc_fwd": ([_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, _P, C.c_size_t, _P], C.c_int),
+    "dctr_pnn_outer_fc_bwd_weights": ([_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P], C.c_int),
+    "dctr_pnn_outer_fc_bwd_data": ([_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P], C.c_int),
     "dctr_dcn_cross_fwd": ([_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P], C.c_int),
     "dctr_dcn_cross_bwd": ([_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P,
                             _P, C.c_size_t, _P], C.c_int),

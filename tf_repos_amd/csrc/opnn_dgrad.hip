@@ -230,3 +230,75 @@ int opnn_outer_dgrad_fused(const float* dh, int lddh, int H, const float* w_oute
 }
 
 }  // namespace dctr
+
+// ---- op-level C ABI of the fused Outer-PNN first layer (include/deepctr_hip.h) ---------------------------------------------------
+#include <map>
+#include <mutex>
+#include <vector>
+
+using namespace dctr;
+
+namespace {
+
+// device copy of the pair table (i << 16 | j, the reference's double loop order, PNN.py:142-146), one per field count
+int pair_table(int F, const int** out) {
+    static std::mutex mu;
+    static std::map<int, int*> tables;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = tables.find(F);
+    if (it == tables.end()) {
+        std::vector<int> pairs;
+        for (int i = 0; i < F; ++i)
+            for (int j = i + 1; j < F; ++j) pairs.push_back(i << 16 | j);
+        int* d = nullptr;
+        DCTR_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d), std::max<size_t>(pairs.size(), 1) * sizeof(int)));
+        DCTR_HIP_CHECK(hipMemcpy(d, pairs.data(), pairs.size() * sizeof(int), hipMemcpyHostToDevice));
+        it = tables.emplace(F, d).first;
+    }
+    *out = it->second;
+    return DCTR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dctr_pnn_outer_fc_workspace_bytes(int max_batch, int H) { return (size_t)opnn_fwd_ws_floats_max(max_batch, H) * sizeof(float); }
+
+int dctr_pnn_outer_fc_fwd(const float* d_e, int e_ld, int B, int F, int K, const float* d_w, const float* d_b, float* d_y, int ldy, int H, int relu,
+                          float keep, uint64_t seed, float* d_workspace, size_t workspace_bytes, void* stream) {
+    DCTR_REQUIRE(keep > 0.f && keep <= 1.f, "keep_prob must be in (0,1], got %f", keep);
+    DCTR_REQUIRE(opnn_fused_ok(F, K, H), "dctr_pnn_outer_fc_fwd: needs K a power of two >= 16 and H a multiple of 4 (got K=%d H=%d)", K, H);
+    DCTR_REQUIRE(d_workspace != nullptr && workspace_bytes >= dctr_pnn_outer_fc_workspace_bytes(B, H), "dctr_pnn_outer_fc_fwd: workspace too small");
+    const int* pairs = nullptr;
+    DCTR_TRY(pair_table(F, &pairs));
+    hipStream_t st = as_stream(stream);
+    const int D = F * K;
+    DCTR_TRY(fc_fwd(d_e, e_ld, d_w, nullptr, d_y, ldy, B, D, H, 0, 1.f, nullptr, 0, st));            // rows [0, F K): the flat embeddings
+    return opnn_outer_fwd(d_e, e_ld, B, F, K, pairs, d_w + (size_t)D * H, d_b, d_y, ldy, H, relu, keep, nullptr, seed, d_workspace, st);
+}
+
+int dctr_pnn_outer_fc_bwd_weights(const float* d_e, int e_ld, int B, int F, int K, const float* d_dy, int lddy, int H, float* d_dw, float* d_db,
+                                  void* stream) {
+    DCTR_REQUIRE(opnn_fused_ok(F, K, H), "dctr_pnn_outer_fc_bwd_weights: needs K a power of two >= 16 and H a multiple of 4 (got K=%d H=%d)", K, H);
+    const int* pairs = nullptr;
+    DCTR_TRY(pair_table(F, &pairs));
+    hipStream_t st = as_stream(stream);
+    const int D = F * K;
+    DCTR_TRY(fc_bwd_weights_partials(d_e, e_ld, d_dy, lddy, d_dw, 0, d_db, 0, B, D, H, 1, st));
+    return opnn_outer_wgrad(d_e, e_ld, B, F, K, pairs, d_dy, lddy, H, d_dw + (size_t)D * H, st);
+}
+
+int dctr_pnn_outer_fc_bwd_data(const float* d_e, int e_ld, int B, int F, int K, const float* d_dy, int lddy, int H, const float* d_w, float* d_dE,
+                               int de_ld, void* stream) {
+    DCTR_REQUIRE(opnn_fused_ok(F, K, H) && opnn_dgrad_fused_ok(K, H),
+                 "dctr_pnn_outer_fc_bwd_data: needs K in {16, 32, 64} and H <= 256, a multiple of 4 (got K=%d H=%d)", K, H);
+    const int* pairs = nullptr;
+    DCTR_TRY(pair_table(F, &pairs));
+    hipStream_t st = as_stream(stream);
+    const int D = F * K;
+    DCTR_TRY(fc_bwd_data(d_dy, lddy, d_w, d_dE, de_ld, B, D, H, nullptr, 0, 1.f, st));             // overwrites dE[:, :F K] with the flat rows' share
+    return opnn_outer_dgrad_fused(d_dy, lddy, H, d_w + (size_t)D * H, d_e, e_ld, pairs, B, F, K, d_dE, de_ld, st);
+}
+
+}  // extern "C"
