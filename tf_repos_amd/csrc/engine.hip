@@ -609,10 +609,6 @@ int opt_dense_range(dctr_engine* E, int p_first, int p_last, hipStream_t st, boo
                            E->scalars + 3 * SUMSQ_SHARDS, st);
 }
 
-// fused_opt: step each MLP layer's weights on the side stream as soon as BOTH its wgrad (same stream) and its dgrad (which
-// still reads the old weights, other stream) are done -- the dense optimizer then costs nothing at the end of the step
-// head_ev: an event recorded on st right after the head (nothing enqueued on st since): the first layer's wgrad waits on it
-// instead of a record of its own
 // d(pair products) -> dL/de for the fused Outer-PNN first layer: dOP[b][(p,a,c)] = sum_h dh0[b][h] W0[F K + (p,a,c)][h], then
 // de_i[a] += sum_c dOP e_j[c], de_j[c] += sum_a dOP e_i[a].  dx_in already holds the flat rows' share.
 int opnn_outer_dgrad(dctr_engine* E, int B, hipStream_t st) {
@@ -626,6 +622,10 @@ int opnn_outer_dgrad(dctr_engine* E, int B, hipStream_t st) {
     return pnn_outer_bwd(E->e, E->e_ld, E->opnn_dop, L, B, F, K, E->dx_in, E->Din_ld, st);
 }
 
+// fused_opt: step each MLP layer's weights on the side stream as soon as BOTH its wgrad (same stream) and its dgrad (which
+// still reads the old weights, other stream) are done -- the dense optimizer then costs nothing at the end of the step
+// head_ev: an event recorded on st right after the head (nothing enqueued on st since): the first layer's wgrad waits on it
+// instead of a record of its own
 int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool fused_opt = false, const hipEvent_t* head_ev = nullptr) {
     const dctr_config& c = E->cfg;
     if (c.model == DCTR_MODEL_AFM) return afm_backward(E, B, st, sw);
@@ -671,7 +671,19 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
             // this layer and (fused_opt) the optimizer step of the layer above, whose wgrad is already queued on sw
             if (i == nl - 1 && head_ev != nullptr && !E->bn && E->head_did_out_bwd) DCTR_HIP_CHECK(hipStreamWaitEvent(sw, *head_ev, 0));
             else DCTR_TRY(fork(E, st, sw));
-            if (fused_opt && i < nl - 1) DCTR_TRY(opt_dense_range(E, E->mlp[i + 1].w, E->mlp[i + 1].last, sw));
+            // A/B knob DCTR_OPT_SIDE=1: the optimizer step of the layer above on a stream of its own instead of in front of this
+            // layer's weight gradient (measured at c2: 0.3052 vs 0.3062 ms/step -- nothing; every kernel here fills the chip, the
+            // step is the sum of their solo times whatever the order)
+            static const bool opt_side = getenv("DCTR_OPT_SIDE") != nullptr;
+            if (fused_opt && i < nl - 1) {
+                if (opt_side && E->s_opt != nullptr && sw != st) {
+                    DCTR_TRY(fork(E, sw, E->s_opt));
+                    DCTR_TRY(opt_dense_range(E, E->mlp[i + 1].w, E->mlp[i + 1].last, E->s_opt));
+                    E->opt_pending = true;
+                } else {
+                    DCTR_TRY(opt_dense_range(E, E->mlp[i + 1].w, E->mlp[i + 1].last, sw));
+                }
+            }
             DCTR_TRY(fc_bwd_weights_partials(x, ldx, E->dh[i], fc.out, E->part(fc.w), w.padded, E->part(fc.b), b.padded, B,
                                              (i == 0 && E->opnn_fused) ? D : fc.in, fc.out, fc.splits, sw, 1));
             if (i == 0 && E->opnn_fused)
