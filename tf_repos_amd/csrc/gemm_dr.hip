@@ -107,9 +107,16 @@ int pick(const Tile (&list)[NT], int Mo, int No, int64_t R, int S, double* eff) 
     }
     return best;
 }
+// An output of fewer than 128 of the LDS-tiled kernel's 64 x 64 tiles leaves more than half of the chip idle there, each block
+// walking the whole reduction behind a barrier per 16 k (c1, B = 256: 28 blocks, 16-19 us for 64 MFLOP).  No tile of the direct
+// kernel reaches the efficiency threshold on such a shape either -- its fixed cost dominates -- but the fastest of them wins by
+// 3x: the best efficiency is the least rounds x cycles.
+bool small_problem(int Mo, int No) { return (int64_t)ceil_div(Mo, 64) * ceil_div(No, 64) < 128; }
 
-constexpr Tile FWD_TILES[] = {{2, 13}, {4, 7}, {2, 8}};
-constexpr Tile DGRAD_TILES[] = {{2, 13}, {4, 10}, {2, 8}};
+// (1x4: small batches -- c1's B = 256, serving -- where the output has too few big tiles for the chip: 16 x 64 patches, 112 blocks
+//  for 256 x 400, each wave a quarter of the reduction; see small_problem())
+constexpr Tile FWD_TILES[] = {{2, 13}, {4, 7}, {2, 8}, {1, 4}};
+constexpr Tile DGRAD_TILES[] = {{2, 13}, {4, 10}, {2, 8}, {1, 4}};
 // (no 3x13 here: 392 VGPRs -- a wgrad runs beside the background table pass, whose two waves per SIMD leave room for 320)
 // (2x16: a 256-wide output in one column block -- AFM's attention weight over 3 M pair rows, 8 row tiles x 32 batch splits)
 constexpr Tile WGRAD_TILES[] = {{2, 13}, {2, 16}, {2, 8}};
@@ -124,14 +131,15 @@ int dr_fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y,
     if (!al16(x) || !al16(w) || (ldx & 3) || (N & 3) || !fits31(64, ldx) || !fits31(wave_rows(K, 1), N)) return DCTR_OK;
     double eff;
     const int t = pick(FWD_TILES, M, N, K, 1, &eff);
-    if (t < 0 || eff < dr_threshold()) return DCTR_OK;
+    if (t < 0 || (eff < dr_threshold() && !small_problem(M, N))) return DCTR_OK;
     DrEpilogue ep{};
     ep.bias = b; ep.relu = relu; ep.keep = keep; ep.seed = seed; ep.seed_ptr = seed_ptr;
     *done = true;
     switch (t) {
         case 0: return dr_launch<2, 13, true, false, false, DR_BIAS_ACT>(x, ldx, w, N, y, ldy, M, N, K, 1, ep, st);
         case 1: return dr_launch<4, 7, true, false, false, DR_BIAS_ACT>(x, ldx, w, N, y, ldy, M, N, K, 1, ep, st);
-        default: return dr_launch<2, 8, true, false, false, DR_BIAS_ACT>(x, ldx, w, N, y, ldy, M, N, K, 1, ep, st);
+        case 2: return dr_launch<2, 8, true, false, false, DR_BIAS_ACT>(x, ldx, w, N, y, ldy, M, N, K, 1, ep, st);
+        default: return dr_launch<1, 4, true, false, false, DR_BIAS_ACT>(x, ldx, w, N, y, ldy, M, N, K, 1, ep, st);
     }
 }
 
@@ -144,7 +152,7 @@ int dr_fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int ldd
     if (!al16(dy) || !al16(w) || (lddy & 3) || (N & 3) || !fits31(64, lddy) || !fits31(256, N)) return DCTR_OK;
     double eff;
     const int t = pick(DGRAD_TILES, M, K, N, 1, &eff);
-    if (t < 0 || eff < dr_threshold()) return DCTR_OK;
+    if (t < 0 || (eff < dr_threshold() && !small_problem(M, K))) return DCTR_OK;
     DrEpilogue ep{};
     ep.act = act; ep.ldact = ldact; ep.inv_keep = act ? 1.0f / keep_prev : 1.f;
     *done = true;
@@ -152,13 +160,15 @@ int dr_fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int ldd
         switch (t) {
             case 0: return dr_launch<2, 13, true, true, false, DR_MASK>(dy, lddy, w, N, dx, lddx, M, K, N, 1, ep, st);
             case 1: return dr_launch<4, 10, true, true, false, DR_MASK>(dy, lddy, w, N, dx, lddx, M, K, N, 1, ep, st);
-            default: return dr_launch<2, 8, true, true, false, DR_MASK>(dy, lddy, w, N, dx, lddx, M, K, N, 1, ep, st);
+            case 2: return dr_launch<2, 8, true, true, false, DR_MASK>(dy, lddy, w, N, dx, lddx, M, K, N, 1, ep, st);
+            default: return dr_launch<1, 4, true, true, false, DR_MASK>(dy, lddy, w, N, dx, lddx, M, K, N, 1, ep, st);
         }
     }
     switch (t) {
         case 0: return dr_launch<2, 13, true, true, false, DR_STORE>(dy, lddy, w, N, dx, lddx, M, K, N, 1, ep, st);
         case 1: return dr_launch<4, 10, true, true, false, DR_STORE>(dy, lddy, w, N, dx, lddx, M, K, N, 1, ep, st);
-        default: return dr_launch<2, 8, true, true, false, DR_STORE>(dy, lddy, w, N, dx, lddx, M, K, N, 1, ep, st);
+        case 2: return dr_launch<2, 8, true, true, false, DR_STORE>(dy, lddy, w, N, dx, lddx, M, K, N, 1, ep, st);
+        default: return dr_launch<1, 4, true, true, false, DR_STORE>(dy, lddy, w, N, dx, lddx, M, K, N, 1, ep, st);
     }
 }
 

@@ -23,7 +23,8 @@ if [ -f $OUT/trace/${TAG}_results.db ]; then
         exit 0
     fi
     timeout 120 python tools/prof_summary.py stats $OUT/trace/${TAG}_results.db > $OUT/${TAG}_kernel_stats.txt 2>&1
-    head -25 $OUT/${TAG}_kernel_stats.txt
+    timeout 120 python tools/prof_summary.py timeline $OUT/trace/${TAG}_results.db > $OUT/${TAG}_timeline.txt 2>&1
+    if [ -n "${TIMELINE:-}" ]; then head -60 $OUT/${TAG}_timeline.txt; else head -25 $OUT/${TAG}_kernel_stats.txt; fi
 else
     echo "no results db"; tail -5 $OUT/trace.err
 fi
