@@ -443,6 +443,11 @@ typedef struct {
                       const int64_t* recv_counts, int64_t record_bytes, void* stream);
     int (*all_reduce_f32)(void* ctx, int channel, float* d_buf, int64_t n, void* stream);   /* sum, in place */
 } dctr_transport;
+/* batch_norm (DeepFM.py:159-160,231-235) under data-parallel ranks: every BN layer's column sums (forward: sum y, sum y^2;
+ * backward: the two gradient sums) pass through this in-place cross-rank SUM on the step's stream, so that N ranks of B examples
+ * normalise like one rank of N*B.  dctr_dist_create installs the transport's all_reduce_f32 (channel 0); a host that drives
+ * dctr_sharded_forward_backward itself installs its own.  world = 1 removes it. */
+int dctr_set_stat_sync(dctr_handle h, int (*all_reduce_f32)(void* ctx, int channel, float* d_buf, int64_t n, void* stream), void* ctx, int world);
 #define DCTR_RCCL_ID_BYTES 128
 /* rank 0: one ncclUniqueId (128 bytes) per channel -- call 3 times, hand the 384 bytes to every rank (any host-side
  * rendezvous: torch.distributed store, MPI, a file).  rccl_path: librccl to load when the process has none yet (may be NULL). */

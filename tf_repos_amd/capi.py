@@ -164,6 +164,9 @@ class Transport(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("all_gather_i32", ALL_GATHER_I32_FN), ("all_to_all", ALL_TO_ALL_FN),
                 ("all_reduce_f32", ALL_REDUCE_F32_FN)]
 
+
+_SIGS["dctr_set_stat_sync"] = ([_P, ALL_REDUCE_F32_FN, _P, C.c_int], C.c_int)
+
 DECLARED_SYMBOLS = tuple(_SIGS)
 
 

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
 }
 
 // mean / invstd of the batch (stats[0][c], stats[1][c]) and the moving-average update
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int S, int B, int H, float eps, float decay,
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int S, int64_t B, int H, float eps, float decay,
                                          float* __restrict__ stats, float* __restrict__ mm, float* __restrict__ mv) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= H) return;
@@ -93,21 +93,31 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     }
 }
 
-// dbeta / dgamma (written to their gradient slabs and to sums[0..H), sums[H..2H) for the apply kernel)
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int S, int H, float* __restrict__ sums,
+// dbeta / dgamma (written to their gradient slabs and to sums[0..H), sums[H..2H) for the apply kernel).  gscale: 1, or 1 / world
+// when the sums are already global (synchronised statistics): the dense all-reduce that follows sums the slabs of all ranks.
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int S, int H, float gscale, float* __restrict__ sums,
                                        float* __restrict__ dbeta, float* __restrict__ dgamma) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= H) return;
     double s = 0.0, q = 0.0;
     for (int k = 0; k < S; ++k) { s += part[((size_t)k * 2 + 0) * H + c]; q += part[((size_t)k * 2 + 1) * H + c]; }
     sums[c] = (float)s; sums[H + c] = (float)q;
-    dbeta[c] = (float)s; dgamma[c] = (float)q;
+    dbeta[c] = (float)s * gscale; dgamma[c] = (float)q * gscale;
+}
+
+// out[0][c], out[1][c] = the S partial sums folded (what goes through the cross-rank sum)
+__global__ void bn_fold_kernel(const float* __restrict__ part, int S, int H, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= H) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < S; ++k) { s += part[((size_t)k * 2 + 0) * H + c]; q += part[((size_t)k * 2 + 1) * H + c]; }
+    out[c] = (float)s; out[H + c] = (float)q;
 }
 
 // dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)), then the ReLU that produced y: dpre = dy * (y > 0)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, int ldd, const float* __restrict__ y, int ldy,
                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                          const float* __restrict__ sums, int B, int H, float keep,
+                                                          const float* __restrict__ sums, int B, int64_t Bstat, int H, float keep,
                                                           const uint64_t* __restrict__ seed_ptr, uint64_t salt,
                                                           float* __restrict__ dpre, int ldp) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -118,18 +128,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     if (keep < 1.0f) dz *= dropout_scale(*seed_ptr ^ salt, (uint64_t)i, keep);
     const float inv = stats[H + c];
     const float xhat = (yv - stats[c]) * inv;
-    const float invB = 1.0f / (float)B;
+    const float invB = 1.0f / (float)Bstat;
     const float dy = gamma[c] * inv * (dz - sums[c] * invB - xhat * sums[H + c] * invB);
     dpre[(size_t)r * ldp + c] = yv > 0.f ? dy : 0.f;
 }
 
+// sync (optional): data-parallel ranks, each with B rows of ONE global batch of B * world -- the column sums go through a
+// cross-rank sum so that mean / variance (and, backward, the two gradient sums) are the global batch's: N ranks == 1 rank.
 int bn_forward(const float* y, int ldy, int B, int H, bool train, float eps, float decay, const float* gamma, const float* beta,
                float* mm, float* mv, float keep, const uint64_t* seed_ptr, uint64_t salt, float* stats, float* scratch, float* out,
-               int ldo, hipStream_t st) {
+               int ldo, hipStream_t st, const BnSync* sync) {
     if (train) {
         const int S = BN_SPLITS;
         bn_stats_partial_kernel<<<dim3(ceil_div(H, 64), S), 256, 0, st>>>(y, ldy, B, H, ceil_div(B, S), scratch);
-        bn_stats_finalize_kernel<<<ceil_div(H, 256), 256, 0, st>>>(scratch, S, B, H, eps, decay, stats, mm, mv);
+        if (sync != nullptr && sync->world > 1) {
+            float* folded = scratch + (size_t)S * 2 * H;
+            bn_fold_kernel<<<ceil_div(H, 256), 256, 0, st>>>(scratch, S, H, folded);
+            DCTR_LAUNCH_CHECK();
+            DCTR_TRY(sync->all_reduce(sync->ctx, 0, folded, 2 * (int64_t)H, st));
+            bn_stats_finalize_kernel<<<ceil_div(H, 256), 256, 0, st>>>(folded, 1, (int64_t)B * sync->world, H, eps, decay, stats, mm, mv);
+        } else {
+            bn_stats_finalize_kernel<<<ceil_div(H, 256), 256, 0, st>>>(scratch, S, B, H, eps, decay, stats, mm, mv);
+        }
     } else {
         bn_stats_moving_kernel<<<ceil_div(H, 256), 256, 0, st>>>(mm, mv, H, eps, stats);
     }
@@ -141,13 +161,22 @@ int bn_forward(const float* y, int ldy, int B, int H, bool train, float eps, flo
 
 int bn_backward(const float* dout, int ldd, const float* y, int ldy, int B, int H, const float* stats, const float* gamma, float keep,
                 const uint64_t* seed_ptr, uint64_t salt, float* scratch, float* dbeta, float* dgamma, float* dpre, int ldp,
-                hipStream_t st) {
+                hipStream_t st, const BnSync* sync) {
     const int S = BN_SPLITS;
     float* sums = scratch + (size_t)S * 2 * H;
     bn_bwd_partial_kernel<<<dim3(ceil_div(H, 64), S), 256, 0, st>>>(dout, ldd, y, ldy, stats, B, H, ceil_div(B, S), keep, seed_ptr, salt,
                                                                     scratch);
-    bn_bwd_finalize_kernel<<<ceil_div(H, 256), 256, 0, st>>>(scratch, S, H, sums, dbeta, dgamma);
-    bn_bwd_apply_kernel<<<ceil_div((int64_t)B * H, 256), 256, 0, st>>>(dout, ldd, y, ldy, stats, gamma, sums, B, H, keep, seed_ptr, salt,
+    int64_t Bstat = B;
+    if (sync != nullptr && sync->world > 1) {
+        bn_fold_kernel<<<ceil_div(H, 256), 256, 0, st>>>(scratch, S, H, sums);
+        DCTR_LAUNCH_CHECK();
+        DCTR_TRY(sync->all_reduce(sync->ctx, 0, sums, 2 * (int64_t)H, st));
+        bn_bwd_finalize_kernel<<<ceil_div(H, 256), 256, 0, st>>>(sums, 1, H, 1.0f / (float)sync->world, sums, dbeta, dgamma);
+        Bstat = (int64_t)B * sync->world;
+    } else {
+        bn_bwd_finalize_kernel<<<ceil_div(H, 256), 256, 0, st>>>(scratch, S, H, 1.0f, sums, dbeta, dgamma);
+    }
+    bn_bwd_apply_kernel<<<ceil_div((int64_t)B * H, 256), 256, 0, st>>>(dout, ldd, y, ldy, stats, gamma, sums, B, Bstat, H, keep, seed_ptr, salt,
                                                                        dpre, ldp);
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;

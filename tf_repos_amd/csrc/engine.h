@@ -90,6 +90,7 @@ struct dctr_engine {
     bool head_did_out_bwd = false;   // the fused head kernel already produced the output layer's backward
     float *vals = nullptr, *labels = nullptr;
     float *x_in = nullptr, *dx_in = nullptr, *e_buf = nullptr, *S = nullptr, *yw = nullptr, *yv = nullptr;
+    dctr::BnSync bn_sync;            // batch_norm under data-parallel ranks: cross-rank sum of the column sums (dctr_set_stat_sync)
     // Outer-PNN with the pair products formed inside the first layer's GEMMs (gemm_dr.h DR_AGEN_*)
     bool opnn_fused = false;
     int* opnn_pairs = nullptr;       // [P] i << 16 | j

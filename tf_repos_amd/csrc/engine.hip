@@ -132,7 +132,8 @@ int build(dctr_engine* E) {
     if (E->bn) {
         DCTR_REQUIRE(c.model != DCTR_MODEL_AFM && (c.model < DCTR_MODEL_WIDE || E->csr),
                      "batch_norm is implemented for the MLP-family models");
-        DCTR_REQUIRE(c.shard_world == 1, "batch_norm with row-sharded tables would need synchronised statistics: not implemented");
+        // (row-sharded tables = data-parallel ranks: the batch statistics are synchronised through dctr_set_stat_sync, which the
+        //  sharded drivers install; sharded_forward_backward refuses to run without it)
         DCTR_REQUIRE(c.batch_norm_decay >= 0.f && c.batch_norm_decay <= 1.f, "batch_norm_decay must be in [0,1]");
     }
     for (int i = 0; i < (afm ? 2 : (no_mlp ? 0 : c.n_deep_layers)); ++i)
@@ -527,7 +528,7 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::f
         if (E->bn) {
             DCTR_TRY(bn_forward(E->h[i], fc.out, B, fc.out, train, 1e-3f, c.batch_norm_decay, E->pp(fc.bn_gamma), E->pp(fc.bn_beta),
                                 E->pp(fc.bn_mm), E->pp(fc.bn_mv), fc.keep, seedp, 0x1000ull + i, E->bn_stats[i], E->bn_scratch,
-                                E->hbn[i], fc.out, st));
+                                E->hbn[i], fc.out, st, E->bn_sync.world > 1 ? &E->bn_sync : nullptr));
             x = E->hbn[i];
         }
     }
@@ -665,7 +666,8 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
         const Param& b = E->params[fc.b];
         if (E->bn)      // dh[i] holds dL/d(layer output): dropout mask, BN backward, ReLU mask -> dL/d(pre-activation), in place
             DCTR_TRY(bn_backward(E->dh[i], fc.out, E->h[i], fc.out, B, fc.out, E->bn_stats[i], E->pp(fc.bn_gamma), fc.keep, bn_seedp,
-                                 0x1000ull + i, E->bn_scratch, E->part(fc.bn_beta), E->part(fc.bn_gamma), E->dh[i], fc.out, st));
+                                 0x1000ull + i, E->bn_scratch, E->part(fc.bn_beta), E->part(fc.bn_gamma), E->dh[i], fc.out, st,
+                                 E->bn_sync.world > 1 ? &E->bn_sync : nullptr));
         if (!wgrad_late) {
             // dh[i] is complete on st -- and so is dgrad_{i+1}, the last reader of W_{i+1}: ONE record serves the weight gradient of
             // this layer and (fused_opt) the optimizer step of the layer above, whose wgrad is already queued on sw
@@ -1487,7 +1489,9 @@ int dctr_table_apply_packed(dctr_handle E, int which, int n, const float* d_grad
 int sharded_forward_backward(dctr_engine* E, const float* d_rows, int n_rows, const int32_t* d_idx, const float* d_vals,
                              const float* d_labels, int B, int global_batch, bool train, bool join_wgrad, hipStream_t st) {
     DCTR_REQUIRE(E && d_rows && d_idx && d_vals, "null argument");
-    DCTR_REQUIRE(!E->wnd && !E->bn, "canned-estimator models / batch_norm are not row-sharded");
+    DCTR_REQUIRE(!E->wnd, "canned-estimator models are not row-sharded");
+    DCTR_REQUIRE(!E->bn || global_batch == B || (E->bn_sync.all_reduce != nullptr && (int64_t)B * E->bn_sync.world == global_batch),
+                 "batch_norm over data-parallel ranks needs the cross-rank sum (dctr_set_stat_sync) and equal per-rank batches");
     DCTR_REQUIRE(B > 0 && B <= E->MB && global_batch >= B, "bad batch sizes B=%d global=%d", B, global_batch);
     DCTR_REQUIRE(!train || d_labels, "labels required for training");
     hipStream_t sw = E->s_wgrad;
@@ -1517,6 +1521,14 @@ int sharded_forward_backward(dctr_engine* E, const float* d_rows, int n_rows, co
 }
 
 extern "C" {
+
+int dctr_set_stat_sync(dctr_handle E, int (*all_reduce_f32)(void* ctx, int channel, float* d_buf, int64_t n, void* stream), void* ctx, int world) {
+    DCTR_REQUIRE(E != nullptr && world >= 1 && (world == 1 || all_reduce_f32 != nullptr), "bad argument");
+    E->bn_sync.all_reduce = all_reduce_f32;
+    E->bn_sync.ctx = ctx;
+    E->bn_sync.world = world;
+    return DCTR_OK;
+}
 
 int dctr_sharded_forward_backward(dctr_handle E, const float* d_rows, int n_rows, const int32_t* d_idx, const float* d_vals,
                                   const float* d_labels, int B, int global_batch, int train, void* stream) {

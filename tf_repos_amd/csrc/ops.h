@@ -140,12 +140,18 @@ int opt_lin_touched(int kind, const Hyper* hdev, const Hyper& hval, float* lin, 
                     const int32_t* counters, int64_t max_entries, const float* glin, hipStream_t st);
 
 // ---- bn.hip: contrib.layers.batch_norm after each hidden layer's ReLU, then dropout (DeepFM.py:159-162, 231-235)
+// cross-rank sum of small device vectors (batch_norm's column sums under data-parallel ranks); the transport's all-reduce
+struct BnSync {
+    int (*all_reduce)(void* ctx, int channel, float* d_buf, int64_t n, void* stream) = nullptr;
+    void* ctx = nullptr;
+    int world = 1;
+};
 int bn_forward(const float* y, int ldy, int B, int H, bool train, float eps, float decay, const float* gamma, const float* beta,
                float* mm, float* mv, float keep, const uint64_t* seed_ptr, uint64_t salt, float* stats, float* scratch, float* out,
-               int ldo, hipStream_t st);
+               int ldo, hipStream_t st, const BnSync* sync = nullptr);
 int bn_backward(const float* dout, int ldd, const float* y, int ldy, int B, int H, const float* stats, const float* gamma, float keep,
                 const uint64_t* seed_ptr, uint64_t salt, float* scratch, float* dbeta, float* dgamma, float* dpre, int ldp,
-                hipStream_t st);
+                hipStream_t st, const BnSync* sync = nullptr);
 int bn_scratch_floats(int H);
 
 // ---- interact.hip

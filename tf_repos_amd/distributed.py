@@ -177,13 +177,15 @@ class ShardedTrainer:
                                        deep_layers=w["deep_layers"], dropout=w["dropout"], cross_layers=w.get("cross_layers", 3),
                                        l2_reg=w["l2_reg"], learning_rate=w["learning_rate"], optimizer=w["optimizer"],
                                        table_mode=table_mode, max_batch=self.B, seed=seed, shard_rank=rank, shard_world=world,
-                                       use_graph=False))
+                                       use_graph=False, batch_norm=bool(w.get("batch_norm", False)),
+                                       batch_norm_decay=float(w.get("batch_norm_decay", 0.9))))
         self._lib = capi.lib()
         self._h = self.eng._h
         self.init_params(params, init_scale, seed)
         if self.driver == "native":
             self._create_native()
             return
+        self._install_stat_sync()
         cap = self.B * self.F                    # distinct ids this rank can request
         cap_owner = cap * world                  # rows this rank can be asked for
         i32 = dict(dtype=torch.int32, device=device)
@@ -204,6 +206,20 @@ class ShardedTrainer:
         self.rows_back = torch.empty(cap, self.P, **f32)
         self.send_grads = torch.empty(cap, self.P, **f32)
         self.recv_grads = torch.empty(cap_owner, self.P, **f32)
+
+    def _install_stat_sync(self) -> None:
+        """Python driver: batch_norm's column sums through this process group (the native driver installs its transport's)."""
+        self._stat_exc = None
+
+        def cb(ctx, ch, d_buf, n, stream):
+            try:
+                self.comm.all_reduce_sum(_as_tensor(d_buf, int(n), self.dev))
+                return 0
+            except BaseException as e:      # never let an exception unwind through the C frames
+                self._stat_exc = e
+                return 5
+        self._stat_cb = capi.ALL_REDUCE_F32_FN(cb)
+        capi.check(self._lib.dctr_set_stat_sync(self._h, self._stat_cb, None, self.world))
 
     def _create_native(self) -> None:
         L = self._lib
