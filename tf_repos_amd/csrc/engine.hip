@@ -657,7 +657,7 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
     // A/B knob DCTR_WGRAD_LATE=1: all weight gradients after the dgrad chain (measured SLOWER, 0.375 vs 0.344 ms/step at c2: beside
     // the scatter a one-block-per-CU GEMM and the scatter's many small blocks get in each other's way, 23 -> 42 us and 32 -> 47 us)
     static const bool wgrad_late_env = getenv("DCTR_WGRAD_LATE") != nullptr;
-    const bool wgrad_late = wgrad_late_env && E->s_opt != nullptr && sw != st;
+    const bool wgrad_late = wgrad_late_env && E->s_opt != nullptr && sw != st && !E->opnn_fused;
     for (int i = nl - 1; i >= 0; --i) {
         const Fc& fc = E->mlp[i];
         const float* x = i > 0 ? (E->bn ? E->hbn[i - 1] : E->h[i - 1]) : E->x_in;
@@ -1612,6 +1612,7 @@ int dctr_time_kernel(dctr_handle E, const char* kernel, int iters, float* h_ms_p
             return opt_dense_arena(c.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->parts, E->meta,
                                    E->n_blocks, nullptr, 1, E->scalars + 3 * SUMSQ_SHARDS, cs);
         if (s == "mlp0_fwd" || s == "mlp0_dgrad" || s == "mlp0_wgrad") {
+            if (E->opnn_fused) { set_error("dctr_time_kernel: the fused Outer-PNN first layer is not one product (time it with rocprofv3)"); return DCTR_ERR_UNSUPPORTED; }
             const Fc& fc = E->mlp[0];
             if (s == "mlp0_fwd")
                 return fc_fwd(E->x_in, E->Din_ld, E->pp(fc.w), E->pp(fc.b), E->h[0], fc.out, B, fc.in, fc.out, 1, fc.keep,
