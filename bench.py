@@ -395,7 +395,7 @@ def main():
         # timed alone, back to back.
         dom = "mlp0_fwd_gemm"
         r = dict(kernels[dom])
-        gemm_name = "void dctr::gemm_dr_kernel<2, 13, true, false, false, 1>" if os.environ.get("DCTR_GEMM", "fdw").find("f") >= 0 and os.environ.get("DCTR_GEMM") != "lds" else "void dctr::gemm_f32_mfma<true, true, 1>"
+        gemm_name = "void dctr::gemm_dr_kernel<2, 13, true, false, false, 1, 0>" if os.environ.get("DCTR_GEMM", "fdw").find("f") >= 0 and os.environ.get("DCTR_GEMM") != "lds" else "void dctr::gemm_f32_mfma<true, true, 1>"
         r["kernel"] = "%s (%s, layer 0: %dx%dx%d)" % (dom, gemm_name.replace("void dctr::", ""), B, F * K, w["deep_layers"][0])
         if in_n > 0:
             r["ms_alone"] = r["ms"]

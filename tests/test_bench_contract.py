@@ -30,3 +30,21 @@ def test_committed_bench_line_honours_the_contract():
     # parse-only and compute-only reported beside the value; the multi-GPU driver is named
     assert c["compute_only"] > 0 and c["parse_only"] > 0 and c["value"] <= min(c["compute_only"], c["parse_only"]) + 1e-6
     assert "driver" in d["config"] and d["config"]["config"] in ("c2", "c5")
+    # the HBM traffic of the headline kernel comes from the round's PMC summary, matched by the EXACT kernel name the line prints
+    assert isinstance(r["traffic"], int) and r["traffic"] > 0 and r["hbm_kernel"]["traffic"] > 0
+
+
+def test_bench_kernel_names_exist_in_the_committed_pmc_summary():
+    """bench.py reads `roofline.traffic` from profiles/r02_pmc_traffic.txt by kernel name: a renamed template parameter list must
+    not turn the field into null on the next run."""
+    import re
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    names = set(re.findall(r'"(void dctr::(?:gemm_dr_kernel|gemm_f32_mfma|opt_table_kernel)<[^"]*>)"', src))
+    assert any("gemm_dr_kernel" in n for n in names) and any("opt_table_kernel" in n for n in names)
+    for n in names:
+        if "gemm_f32_mfma" in n:            # (the A/B alternative DCTR_GEMM=lds: not in the default step, so not in its PMC summary)
+            continue
+        assert bench.pmc_traffic_bytes(n) is not None, n

@@ -81,10 +81,13 @@ def _shard_worker(rank, world, port, model, overlap, driver, ret):
         F, V, K, Bg = 39, 2003, 8, 128
         bn = model.endswith("+bn")          # batch_norm: the statistics are the GLOBAL batch's (cross-rank sums, dctr_set_stat_sync)
         model = model.split("+")[0]
+        # (batch_norm cases step with Momentum: Adam's g / (|g| + 1e-8) turns the rounding of a nearly dead unit's 1e-9 gradient into
+        #  a step of either sign -- the golden-fixture test masks such elements; a linear rule keeps the comparison at 1e-6)
+        opt = "Momentum" if bn else "Adam"
         w = dict(model=model, field_size=F, feature_size=V, embedding_size=K, batch=Bg // world, deep_layers=(32, 16),
-                 dropout=(1.0, 1.0), cross_layers=2, l2_reg=1e-3, learning_rate=1e-2, optimizer="Adam", batch_norm=bn)
+                 dropout=(1.0, 1.0), cross_layers=2, l2_reg=1e-3, learning_rate=1e-2, optimizer=opt, batch_norm=bn)
         ocfg = O.Config(model=model, field_size=F, feature_size=V, embedding_size=K, deep_layers=(32, 16), dropout=(1.0, 1.0),
-                        cross_layers=2, l2_reg=1e-3, learning_rate=1e-2, optimizer="Adam", batch_norm=bn)
+                        cross_layers=2, l2_reg=1e-3, learning_rate=1e-2, optimizer=opt, batch_norm=bn)
         params = {k: v.numpy() for k, v in O.init_params(ocfg, seed=5, scale=0.05).items()}
         tr = ShardedTrainer(w, rank, world, dev, params=params, overlap=overlap, driver=driver)
         losses = []
@@ -122,21 +125,20 @@ def test_two_ranks_equal_one_rank(model, overlap, driver, dev):
         got, losses = dict(ret["params"]), list(ret["losses"])
         probs = np.concatenate([ret["prob0"], ret["prob1"]])
     F, V, K, Bg = 39, 2003, 8, 128
-    ocfg, params, eng = make_pair(model.split("+")[0], B=Bg, F=F, V=V, K=K, layers=(32, 16), cross=2, opt="Adam", l2=1e-3, lr=1e-2, seed=4,
-                                  batch_norm=model.endswith("+bn"))
+    ocfg, params, eng = make_pair(model.split("+")[0], B=Bg, F=F, V=V, K=K, layers=(32, 16), cross=2,
+                                  opt="Momentum" if model.endswith("+bn") else "Adam", l2=1e-3, lr=1e-2, seed=4, batch_norm=model.endswith("+bn"))
     ref_losses = []
     for step in range(3):
         ids, vals, labels = O.synth_batch(Bg, F, V, seed=300 + step)
         ref_losses.append(eng.train_step(*dev_batch(ids, vals, labels, dev)))
     one = eng.get_params()
     for k in one:
-        # tolerance: N ranks == 1 rank within 1e-6; with batch_norm 1e-4 (the statistics are summed in a different order, and Adam
-        # turns that rounding into ~0.1 % of lr = 1e-2 on nearly dead units -- un-synchronised statistics would be off by 1e-3 and more)
-        assert np.abs(one[k] - got[k]).max() <= (1e-4 if model.endswith("+bn") else 1e-6), k
+        # tolerance: N ranks == 1 rank within 1e-6 (batch_norm: 5e-6, the statistics are summed in a different order)
+        assert np.abs(one[k] - got[k]).max() <= (5e-6 if model.endswith("+bn") else 1e-6), k
     assert np.allclose(losses, ref_losses, rtol=1e-5, atol=1e-6)
     ids, vals, labels = O.synth_batch(Bg, F, V, seed=999)
     d = dev_batch(ids, vals, labels, dev)
     p1 = torch.empty(Bg, device=dev)
     eng.predict(d[0], d[1], p1, None)
-    assert np.abs(p1.cpu().numpy() - probs).max() <= (1e-4 if model.endswith("+bn") else 1e-6)
+    assert np.abs(p1.cpu().numpy() - probs).max() <= (5e-6 if model.endswith("+bn") else 1e-6)
     eng.close()
