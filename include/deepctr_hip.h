@@ -263,6 +263,9 @@ int dctr_opt_table(int kind, const float* hyper, int table_mode, int64_t rows, i
  * bwd_data:  dX[M,K] = dY[M,N] W^T, then if d_act != NULL: dX *= (act>0)/keep_prev  (ReLU+dropout of the
  *            producing layer; act is that layer's stored output)
  * bwd_weights: dW[K,N] = X^T dY, db[N] = colsum(dY) */
+/* host logic only (no GPU needed): which kernel a layer product of this shape takes -- op 'f' forward Y[M,N] = X[M,K] W[K,N],
+ * 'd' dX[M,K] = dY[M,N] W^T, 'w' dW[K,N] = X^T dY over M rows.  Writes "dr TMxTN", "dr TMxTN xS" (S batch splits) or "lds[ xS]". */
+int dctr_gemm_plan(char op, int M, int K, int N, char* out, int out_len);
 int dctr_fc_fwd(const float* d_x, int ldx, const float* d_w, const float* d_b, float* d_y, int ldy,
                 int M, int K, int N, int relu, float keep, uint64_t seed, void* stream);
 int dctr_fc_bwd_data(const float* d_dy, int lddy, const float* d_w, float* d_dx, int lddx,

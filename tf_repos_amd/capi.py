@@ -165,6 +165,7 @@ class Transport(C.Structure):
                 ("all_reduce_f32", ALL_REDUCE_F32_FN)]
 
 
+_SIGS["dctr_gemm_plan"] = ([C.c_char, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int], C.c_int)
 _SIGS["dctr_set_stat_sync"] = ([_P, ALL_REDUCE_F32_FN, _P, C.c_int], C.c_int)
 
 DECLARED_SYMBOLS = tuple(_SIGS)

@@ -123,6 +123,39 @@ constexpr Tile WGRAD_TILES[] = {{2, 13}, {2, 16}, {2, 8}};
 
 }  // namespace
 
+// Which kernel a layer product of this shape takes (host logic only, no launch): "dr TMxTN[ xS]" or "lds[ xS]".  Alignment is
+// assumed (16-byte bases, leading dimensions multiples of 4), as the engine's buffers have it.
+int gemm_plan(char op, int M, int K, int N, char* out, int out_len) {
+    double eff = 0.0;
+    int t = -1, s = 1;
+    const Tile* tile = nullptr;
+    if (op == 'f') {
+        if (dr_enabled('f') && M > 0 && N > 0 && K >= 64 && (N & 3) == 0) {
+            t = pick(FWD_TILES, M, N, K, 1, &eff);
+            if (t >= 0 && (eff >= dr_threshold() || small_problem(M, N))) tile = &FWD_TILES[t];
+        }
+    } else if (op == 'd') {
+        if (dr_enabled('d') && M > 0 && K > 0 && N >= 64 && (N & 3) == 0) {
+            t = pick(DGRAD_TILES, M, K, N, 1, &eff);
+            if (t >= 0 && (eff >= dr_threshold() || small_problem(M, K))) tile = &DGRAD_TILES[t];
+        }
+    } else if (op == 'w') {
+        s = choose_wgrad_splits(M, K, N);
+        if (dr_wgrad_splits(M, K, N) == s && s > 0 && (int64_t)ceil_div(M, s) >= 64 && (N & 3) == 0) {
+            t = pick(WGRAD_TILES, K, N, M, s, &eff);
+            int blocks = 0;
+            if (t >= 0) dr_efficiency(K, N, M, s, WGRAD_TILES[t], &blocks);
+            if (t >= 0 && eff >= dr_threshold() && blocks <= CUS) tile = &WGRAD_TILES[t];
+        }
+    } else {
+        set_error("gemm_plan: op must be 'f', 'd' or 'w'");
+        return DCTR_ERR_INVALID_ARG;
+    }
+    if (tile != nullptr) snprintf(out, (size_t)out_len, op == 'w' ? "dr %dx%d x%d" : "dr %dx%d", tile->tm, tile->tn, s);
+    else snprintf(out, (size_t)out_len, op == 'w' ? "lds x%d" : "lds", s);
+    return DCTR_OK;
+}
+
 // ---- Y = act(X W + b)  (A = X [M,K] reduction-contiguous, B = W [K,N])
 int dr_fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N, int relu, float keep,
               const uint64_t* seed_ptr, uint64_t seed, hipStream_t st, bool* done) {
@@ -290,3 +323,8 @@ int opnn_outer_wgrad(const float* e, int e_ld, int B, int F, int K, const int* p
 }
 
 }  // namespace dctr
+
+extern "C" int dctr_gemm_plan(char op, int M, int K, int N, char* out, int out_len) {
+    DCTR_REQUIRE(out != nullptr && out_len >= 24, "dctr_gemm_plan: output buffer of >= 24 bytes");
+    return dctr::gemm_plan(op, M, K, N, out, out_len);
+}

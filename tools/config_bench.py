@@ -36,7 +36,8 @@ for name, c in CONFIGS.items():
     keep = (0.5,) * max(len(c["layers"]), 2)
     eng = Engine(EngineConfig(model=c["model"], field_size=39, feature_size=c["V"], embedding_size=c["K"], deep_layers=c["layers"],
                               dropout=keep, cross_layers=c.get("cross", 3), attention_layers=c.get("att", (256,)), l2_reg=1e-4,
-                              learning_rate=5e-4, optimizer="Adam", max_batch=c["B"], seed=1))
+                              learning_rate=5e-4, optimizer="Adam", max_batch=c["B"], seed=1,
+                              use_graph=os.environ.get("DCTR_USE_GRAPH", "0") == "1"))
     rng = np.random.default_rng(1)
     for pn, shp in eng.param_shapes.items():
         eng.set_param(pn, rng.normal(0, 0.01, size=shp).astype(np.float32))
