@@ -7,6 +7,7 @@ libdeepctr_hip.so.  torch tensors are only device buffers whose raw pointers cro
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -87,7 +88,7 @@ class EngineConfig:
         c.seed = self.seed
         c.shard_rank = self.shard_rank
         c.shard_world = self.shard_world
-        c.use_graph = int(self.use_graph)
+        c.use_graph = int(self.use_graph if os.environ.get("DCTR_FORCE_GRAPH") is None else os.environ["DCTR_FORCE_GRAPH"] == "1")   # (A/B knob)
         c.dense_size = int(self.dense_size)
         c.lin_optimizer = capi.OPTIMIZERS[self.lin_optimizer]
         c.lin_learning_rate = float(self.lin_learning_rate)

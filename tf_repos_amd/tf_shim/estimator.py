@@ -208,6 +208,12 @@ class Estimator:
             max_entries = max(max_entries, live.cfg.max_entries)
             live.close()
         extra = {"max_entries": int(max_entries)} if cfg_src.slots is not None else {}
+        if cfg_src.slots is None:
+            # small batches (the reference's default 256): the step is ~25 launches of a few microseconds each, and enqueueing them
+            # one by one costs the host 0.2-0.3 ms per step -- more than the GPU needs.  One captured hipGraph per (batch size, input
+            # slot) is 13 % slower on the GPU and immune to the host (measured through DeepFM.py, B = 256, same box: 0.79 M
+            # examples/s eager, 1.18 M replayed).  Large batches keep the eager path and its next-batch id grouping.
+            extra["use_graph"] = int(batch_size) * int(cfg_src.config_kwargs.get("field_size", 0)) < 65536
         cfg = cfg_src.engine_config(max_batch=batch_size, table_mode=self.table_mode,
                                     seed=int(self._config.tf_random_seed or 0), **extra)
         self._engine = Engine(cfg)
@@ -363,9 +369,10 @@ class Estimator:
                 ids, vals, labels, slot = batch
                 loss = e.train_step(ids, vals, labels, want_loss=want)
                 feeder.release(slot)
-                nxt = feeder.peek_next_ids()          # the next batch is already in its input slot: group its ids a step ahead
-                if nxt is not None:
-                    e.prefetch_ids(nxt)
+                if not e.cfg.use_graph:                # (a replayed graph groups the ids inside the step)
+                    nxt = feeder.peek_next_ids()      # the next batch is already in its input slot: group its ids a step ahead
+                    if nxt is not None:
+                        e.prefetch_ids(nxt)
             else:
                 ids, vals, labels = batch
                 loss = e.train_step(ids, vals, labels, want_loss=want)
