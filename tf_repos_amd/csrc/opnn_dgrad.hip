@@ -6,7 +6,7 @@
 //     dE[b][j_p][c]  += sum_a dOP[b][(p,a,c)] e[b][i_p][a]
 //
 // One block owns 32 batch rows (two 16-row MFMA tiles) and a contiguous range of field pairs; its dh0 rows sit in LDS (32 KB) as the
-// A operand of every product.  Each of its 8 waves (two per SIMD: one contracts while the other multiplies) takes a contiguous
+// A operand of every product.  Each of its 12 waves (three per SIMD; two for K = 64: one contracts while the others multiply) takes a contiguous
 // slice of the block's pairs and streams ITS rows of W0 straight from L2 into B fragments, double-buffered one chunk (64 MFMAs) ahead
 // (the weight rows of consecutive (p, a) are one linear stream).  A (p, a) step is a 32 x K patch of dOP held in 4 K/16
 // accumulators; it never leaves the registers: de_j accumulates over a in registers (one float atomic per element and pair), de_i
@@ -39,12 +39,17 @@ __device__ __forceinline__ float row16_sum(float v) {
     return dpp_add<0x140>(v);   // row_mirror
 }
 
+// waves per block: three per SIMD where the registers allow it (K <= 32: 162 VGPRs), else two.  With three, c4's backward went
+// 76.4 -> 74.0 ms/step: one more wave's MFMAs to run under a neighbour's contraction.
+constexpr int opnn_dgrad_waves(int KT) { return KT <= 2 ? 12 : 8; }
+
 // KT = K / 16 column tiles per (p, a); NG = groups of 16 h (H <= 16 NG; columns beyond H are zero in the LDS copy of dh0)
 template <int KT, int NG>
-__global__ __launch_bounds__(512) void opnn_dgrad_kernel(const float* __restrict__ dh, int lddh, int H, const float* __restrict__ w_outer,
+__global__ __launch_bounds__(64 * opnn_dgrad_waves(KT)) void opnn_dgrad_kernel(const float* __restrict__ dh, int lddh, int H, const float* __restrict__ w_outer,
                                                          const float* __restrict__ e, int e_ld, const int* __restrict__ pairs, int P,
                                                          int pairs_per_block, int B, float* __restrict__ dE, int de_ld) {
     // CG: groups of 16 h per B chunk (two chunk buffers of KT CG 4 registers each: <= 64 VGPRs); HS: LDS row stride
+    constexpr int NWV = opnn_dgrad_waves(KT);
     constexpr int K = 16 * KT, CG = (NG / 2 < 8 / KT) ? NG / 2 : 8 / KT, NCH = NG / CG, HS = 16 * NG + 4;
     static_assert(NCH % 2 == 0 && CG >= 1, "an even number of chunks per (p, a): the buffer of a chunk is a compile-time choice");
     extern __shared__ __attribute__((aligned(16))) float dh_lds[];      // [32][HS]
@@ -52,7 +57,7 @@ __global__ __launch_bounds__(512) void opnn_dgrad_kernel(const float* __restrict
     const int c = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.x * 32;
     // ---- dh0 rows of this block -> LDS (zero beyond B rows / H columns)
-    for (int idx = t; idx < 32 * 4 * NG; idx += 512) {
+    for (int idx = t; idx < 32 * 4 * NG; idx += 64 * NWV) {
         const int r = idx / (4 * NG), h4 = idx - r * (4 * NG);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (m0 + r < B && 4 * h4 < H) v = *reinterpret_cast<const f32x4*>(dh + (size_t)(m0 + r) * lddh + 4 * h4);
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(512) void opnn_dgrad_kernel(const float* __restrict
     // ---- this wave's pairs
     const int pb = blockIdx.y * pairs_per_block, pe = min(P, pb + pairs_per_block);
     const int np = max(pe - pb, 0);
-    const int p0 = __builtin_amdgcn_readfirstlane(pb + (int)((int64_t)np * w / 8)), p1 = __builtin_amdgcn_readfirstlane(pb + (int)((int64_t)np * (w + 1) / 8));
+    const int p0 = __builtin_amdgcn_readfirstlane(pb + (int)((int64_t)np * w / NWV)), p1 = __builtin_amdgcn_readfirstlane(pb + (int)((int64_t)np * (w + 1) / NWV));
     if (p0 >= p1) return;
 
     auto uni_ptr = [](const float* p) {
@@ -193,12 +198,13 @@ template <int KT, int NG>
 int launch(const float* dh, int lddh, int H, const float* w_outer, const float* e, int e_ld, const int* pairs, int P, int B, float* dE, int de_ld,
            hipStream_t st) {
     auto kern = opnn_dgrad_kernel<KT, NG>;
+    constexpr int NWV = opnn_dgrad_waves(KT);
     constexpr size_t lds = (size_t)32 * (16 * NG + 4) * sizeof(float);
     const int nbm = ceil_div(B, 32);
     int splits = std::max(1, 256 / nbm);                    // small batches: the pairs are split over blocks as well
-    splits = std::min(splits, std::max(1, P / 8));          // (>= 8 pairs per block: one per wave)
+    splits = std::min(splits, std::max(1, P / NWV));        // (>= one pair per wave)
     const int ppb = ceil_div(P, splits);
-    kern<<<dim3((unsigned)nbm, (unsigned)ceil_div(P, ppb)), 512, lds, st>>>(dh, lddh, H, w_outer, e, e_ld, pairs, P, ppb, B, dE, de_ld);
+    kern<<<dim3((unsigned)nbm, (unsigned)ceil_div(P, ppb)), 64 * NWV, lds, st>>>(dh, lddh, H, w_outer, e, e_ld, pairs, P, ppb, B, dE, de_ld);
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }
