@@ -18,7 +18,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>      // types and prototypes only: every call goes through dlsym'd pointers
 
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -178,9 +180,25 @@ struct dctr_dist {
     bool overlap = true;
     bool finish_early = true;
     RouteWorker* worker = nullptr;
+    // DCTR_DIST_TIMING=1: host microseconds the enqueueing thread spends in each phase of dctr_dist_train_step (printed at destroy)
+    bool timing = false;
+    double t_phase[6] = {0, 0, 0, 0, 0, 0};
+    int64_t t_steps = 0;
 };
 
 namespace {
+
+struct PhaseClock {
+    dctr_dist* D;
+    std::chrono::steady_clock::time_point t0;
+    explicit PhaseClock(dctr_dist* d) : D(d) { if (D->timing) t0 = std::chrono::steady_clock::now(); }
+    void lap(int i) {
+        if (!D->timing) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        D->t_phase[i] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+        t0 = t1;
+    }
+};
 
 int route_begin(dctr_dist* D, RouteState& r, const int32_t* ids, int B, hipStream_t s) {
     dctr_engine* E = D->E;
@@ -343,6 +361,7 @@ int dist_alloc(dctr_dist* D) {
     D->overlap = !(ov != nullptr && ov[0] == '0');
     const char* fe = getenv("DCTR_SHARD_FINISH_EARLY");
     D->finish_early = !(fe != nullptr && fe[0] == '0');
+    D->timing = getenv("DCTR_DIST_TIMING") != nullptr;
     const char* th = getenv("DCTR_SHARD_THREAD");
     if (D->overlap && !(th != nullptr && th[0] == '0')) {
         D->worker = new RouteWorker();
@@ -424,6 +443,10 @@ int dctr_dist_destroy(dctr_dist_t D) {
         D->worker = nullptr;
     }
     hipDeviceSynchronize();
+    if (D->timing && D->t_steps > 0)
+        fprintf(stderr, "[dctr_dist rank %d] host us/step over %lld steps: route %.1f | fetch+fwd+bwd %.1f | dense update %.1f | pack+grad exchange %.1f | table apply %.1f\n",
+                D->rank, (long long)D->t_steps, D->t_phase[0] / D->t_steps, D->t_phase[1] / D->t_steps, D->t_phase[2] / D->t_steps,
+                D->t_phase[3] / D->t_steps, D->t_phase[4] / D->t_steps);
     for (RouteState& r : D->rs) {
         if (r.g) group_destroy(r.g);
         hipFree(r.send_rows); hipFree(r.upos); hipFree(r.idx); hipFree(r.counts); hipFree(r.recv_rows); hipFree(r.all_counts);
@@ -451,12 +474,15 @@ int dctr_dist_train_step(dctr_dist_t D, const int32_t* d_ids, const float* d_val
     DCTR_REQUIRE(B > 0 && B <= E->MB && next_B >= 0 && next_B <= E->MB, "batch %d (next %d) outside (0, max_batch=%d]", B, next_B, E->MB);
     hipStream_t M = as_stream(stream);
     int w = 0;
+    PhaseClock clk(D);
     DCTR_TRY(take_route(D, d_ids, B, M, &w));
     RouteState& r = D->rs[w];
     const bool prefetch = D->overlap && d_next_ids != nullptr && next_B > 0;
     // the first half of the next batch's routing is enqueued BEFORE this step's work so that it runs under the MLP GEMMs
     if (prefetch) DCTR_TRY(prefetch_begin(D, d_next_ids, next_B, M));
+    clk.lap(0);
     DCTR_TRY(fetch_and_forward(D, r, d_vals, d_labels, B, true, M));
+    clk.lap(1);
     // dense side, beside the gradient exchange (the logit gradient already carries 1/global_batch: sum over ranks = mean)
     // (the side stream already holds the weight gradients; it still needs the output-layer / cross-network partials from M)
     hipStream_t sd = D->s_dense;
@@ -469,12 +495,16 @@ int dctr_dist_train_step(dctr_dist_t D, const int32_t* d_ids, const float* d_val
     }
     DCTR_TRY(dense_update(D, sd));
     if (sd != M) DCTR_HIP_CHECK(hipEventRecord(D->ev_dense, sd));
+    clk.lap(2);
     if (prefetch && D->finish_early && D->worker == nullptr) DCTR_TRY(route_finish(D, D->rs[D->pending], D->pending, D->s_route));
     // sparse side: per-distinct-id gradients in send order -> owners -> segment-sum + table optimizer
     const int64_t rec = (int64_t)(E->K + 4) * sizeof(float);
     DCTR_TRY(dctr_sharded_pack_row_grads(E, reinterpret_cast<dctr_group_t>(r.g), B, r.upos, D->send_grads, M));
     DCTR_TRY(D->t.all_to_all(D->t.ctx, 0, D->send_grads, r.scnt.data(), D->recv_grads, r.rcnt.data(), rec, M));
+    clk.lap(3);
     DCTR_TRY(dctr_table_apply_packed(E, w, (int)r.n_recv, D->recv_grads, M));
+    clk.lap(4);
+    if (D->timing) ++D->t_steps;
     if (sd != M) DCTR_HIP_CHECK(hipStreamWaitEvent(M, D->ev_dense, 0));
     if (prefetch && !D->finish_early && D->worker == nullptr) DCTR_TRY(route_finish(D, D->rs[D->pending], D->pending, D->s_route));
     if (h_loss != nullptr) {
