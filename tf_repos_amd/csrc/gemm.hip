@@ -303,7 +303,10 @@ static int launch_gemm(const float* A, int lda, const float* B, int ldb, float* 
 // ---- public (namespace-level) entry points used by the engine -------------------------------------
 int fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N,
            int relu, float keep, const uint64_t* seed_ptr, uint64_t seed, hipStream_t st, int over) {
-    bool done = false;          // small products: the direct-to-register kernel family (gemm_dr.h) when one of its tiles fits the shape
+    bool done = false;
+    DCTR_TRY(ws_fc_fwd(x, ldx, w, b, y, ldy, M, K, N, relu, keep, seed_ptr, seed, st, &done));      // tall operands: the weights stay in LDS (gemm_ws.hip)
+    if (done) return DCTR_OK;
+    // small products: the direct-to-register kernel family (gemm_dr.h) when one of its tiles fits the shape
     DCTR_TRY(dr_fc_fwd(x, ldx, w, b, y, ldy, M, K, N, relu, keep, seed_ptr, seed, st, &done));
     if (done) return DCTR_OK;
     Epilogue ep{};
@@ -315,6 +318,8 @@ int fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, 
                 const float* act, int ldact, float keep_prev, hipStream_t st, int over) {
     // dX[M,K] = dY[M,N] * W[K,N]^T : reduction over N; "B" = W^T[N,K] stored as W[K,N] => k(N)-contiguous
     bool done = false;
+    DCTR_TRY(ws_fc_bwd_data(dy, lddy, w, dx, lddx, M, K, N, act, ldact, keep_prev, st, &done));
+    if (done) return DCTR_OK;
     DCTR_TRY(dr_fc_bwd_data(dy, lddy, w, dx, lddx, M, K, N, act, ldact, keep_prev, st, &done));
     if (done) return DCTR_OK;
     Epilogue ep{};
