@@ -264,7 +264,7 @@ int dctr_opt_table(int kind, const float* hyper, int table_mode, int64_t rows, i
  *            producing layer; act is that layer's stored output)
  * bwd_weights: dW[K,N] = X^T dY, db[N] = colsum(dY) */
 /* host logic only (no GPU needed): which kernel a layer product of this shape takes -- op 'f' forward Y[M,N] = X[M,K] W[K,N],
- * 'd' dX[M,K] = dY[M,N] W^T, 'w' dW[K,N] = X^T dY over M rows.  Writes "dr TMxTN", "dr TMxTN xS" (S batch splits) or "lds[ xS]". */
+ * 'd' dX[M,K] = dY[M,N] W^T, 'w' dW[K,N] = X^T dY over M rows.  Writes "ws" (weights-stationary, tall operands), "dr TMxTN", "dr TMxTN xS" (S batch splits) or "lds[ xS]". */
 int dctr_gemm_plan(char op, int M, int K, int N, char* out, int out_len);
 int dctr_fc_fwd(const float* d_x, int ldx, const float* d_w, const float* d_b, float* d_y, int ldy,
                 int M, int K, int N, int relu, float keep, uint64_t seed, void* stream);

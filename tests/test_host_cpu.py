@@ -223,7 +223,7 @@ def test_multithreaded_csv_parse_matches_the_serial_decoder(tmp_path):
 def test_gemm_kernel_choice_per_shape():
     """Host logic of the layer products (csrc/gemm_dr.hip, no GPU): which kernel family and tile each shape of the BASELINE configs
     takes.  The direct-to-register kernel owns the one-round grids (c2 / c5 MLP), its 1x4 tile the small batches (c1, serving); grids
-    of hundreds of rounds (AFM's 3 M pair rows) stay on the LDS-tiled kernel except the long-reduction weight gradient."""
+    of hundreds of rounds (AFM's 3 M pair rows) take the weights-stationary kernel, their long-reduction weight gradient the direct one."""
     import ctypes as C
     from tf_repos_amd import capi
     L = capi.lib()
@@ -236,7 +236,7 @@ def test_gemm_kernel_choice_per_shape():
     assert [plan(o, 4096, 400, 400) for o in "fdw"] == ["dr 2x13", "dr 2x13", "dr 2x13 x9"]            # c2 layers 1, 2
     assert [plan(o, 256, 312, 400) for o in "fd"] == ["dr 1x4", "dr 1x4"]                              # c1 (README.md:49), B = 256
     assert plan("f", 1, 312, 400) == "dr 1x4"                                                          # one serving example
-    assert [plan(o, 4096 * 741, 256, 256) for o in "fdw"] == ["lds", "lds", "dr 2x16 x32"]             # AFM.py:44,52 attention layer
+    assert [plan(o, 4096 * 741, 256, 256) for o in "fdw"] == ["ws", "ws", "dr 2x16 x32"]               # AFM.py:44,52 attention layer
     assert plan("w", 4096 * 741, 16, 256).startswith("lds")                                            # (K = 16: the fused AFM path anyway)
     with pytest.raises(Exception):
         plan("x", 1, 1, 1)

@@ -123,7 +123,7 @@ constexpr Tile WGRAD_TILES[] = {{2, 13}, {2, 16}, {2, 8}};
 
 }  // namespace
 
-// Which kernel a layer product of this shape takes (host logic only, no launch): "dr TMxTN[ xS]" or "lds[ xS]".  Alignment is
+// Which kernel a layer product of this shape takes (host logic only, no launch): "ws" (gemm_ws.hip), "dr TMxTN[ xS]" or "lds[ xS]".  Alignment is
 // assumed (16-byte bases, leading dimensions multiples of 4), as the engine's buffers have it.
 int gemm_plan(char op, int M, int K, int N, char* out, int out_len) {
     double eff = 0.0;
@@ -151,6 +151,7 @@ int gemm_plan(char op, int M, int K, int N, char* out, int out_len) {
         set_error("gemm_plan: op must be 'f', 'd' or 'w'");
         return DCTR_ERR_INVALID_ARG;
     }
+    if ((op == 'f' && ws_takes(M, K, N)) || (op == 'd' && ws_takes(M, N, K))) { snprintf(out, (size_t)out_len, "ws"); return DCTR_OK; }
     if (tile != nullptr) snprintf(out, (size_t)out_len, op == 'w' ? "dr %dx%d x%d" : "dr %dx%d", tile->tm, tile->tn, s);
     else snprintf(out, (size_t)out_len, op == 'w' ? "lds x%d" : "lds", s);
     return DCTR_OK;

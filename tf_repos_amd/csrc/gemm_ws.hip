@@ -197,6 +197,9 @@ int dispatch_ws(const float* A, int lda, const float* Bm, int ldb, int b_trans, 
 
 }  // namespace
 
+// host logic: would a product C[M, N] over a reduction of R take this kernel (alignment permitting, no dropout epilogue)?
+bool ws_takes(int64_t M, int R, int N) { return ws_enabled() && ws_shape_ok(M, R, N); }
+
 // Y[M,N] = act(X[M,K] W[K,N] + b)
 int ws_fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N, int relu, float keep,
               const uint64_t* seed_ptr, uint64_t seed, hipStream_t st, bool* done) {

@@ -90,6 +90,7 @@ int dr_fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int ldd
 int dr_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int lddy, float* dw_part, int64_t dw_stride, float* db_part,
                                int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, bool* done);
 // tall operands, the small one resident in LDS (gemm_ws.hip; DCTR_GEMM_WS=0 turns it off)
+bool ws_takes(int64_t M, int R, int N);
 int ws_fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N, int relu, float keep,
               const uint64_t* seed_ptr, uint64_t seed, hipStream_t st, bool* done);
 int ws_fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int K, int N, const float* act, int ldact,
