@@ -99,7 +99,7 @@ def test_oracle_on_the_reference_serving_sample():
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/deep_ctr"), reason="reference tree not present (GPU box)")
-@pytest.mark.parametrize("case", ["deepfm_adam", "afm", "dcn"])
+@pytest.mark.parametrize("case", ["deepfm_adam", "afm", "dcn", "afm_2att", "opnn_k16"])
 def test_committed_fixtures_are_what_the_reference_source_produces_today(case, tmp_path):
     """Re-runs the generator on the reference tree (build container only) and requires the committed fixture, bit for bit."""
     import make_model_golden as gen
