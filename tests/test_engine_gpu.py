@@ -75,7 +75,8 @@ def test_outer_pnn_fused_first_layer(K, H, B, dev):
         assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (step, loss, ref_loss)
     got = eng.get_params()
     for name, ref in params.items():
-        assert np.abs(got[name] - ref.numpy()).max() <= 2e-6, name
+        # (5e-6: dL/de is summed by float atomics -- 12 waves of a block and the pair-split blocks meet in the same rows in no fixed order)
+        assert np.abs(got[name] - ref.numpy()).max() <= 5e-6, name
     eng.close()
 
 
