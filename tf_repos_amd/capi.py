@@ -62,7 +62,8 @@ _SIGS = {
     "dctr_stream_sync": ([_P], C.c_int),
     "dctr_parse_libsvm": ([C.c_char_p, C.c_size_t, C.c_int, C.c_int64, _P, _P, _P,
                            C.POINTER(C.c_int64), C.POINTER(C.c_size_t)], C.c_int),
-    "dctr_parse_libsvm_mt": ([C.c_char_p, C.c_size_t, C.c_int, C.c_int, _P, _P, _P, C.c_int64, C.POINTER(C.c_int64)], C.c_int),
+    # (text as void*: bytes objects and mapped files both pass)
+    "dctr_parse_libsvm_mt": ([_P, C.c_size_t, C.c_int, C.c_int, _P, _P, _P, C.c_int64, C.POINTER(C.c_int64)], C.c_int),
     "dctr_parse_csv": ([C.c_char_p, C.c_size_t, C.c_int, _P, _P, _P, C.c_int64, _P, _P, C.POINTER(C.c_int64),
                         C.POINTER(C.c_size_t)], C.c_int),
     "dctr_embed_gather_fwd": ([_P, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,

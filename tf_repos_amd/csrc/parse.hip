@@ -111,6 +111,31 @@ extern "C" int dctr_parse_libsvm(const char* h_text, size_t nbytes, int field_si
             while (q < le && *q == ' ') ++q;
             if (q == le) break;
             t = q;
+            // ---- one-pass fast path for the token shape every Criteo line is made of: digits ':' digits [ '.' digits ] then a
+            // space or the end of the line.  Anything else (signs, exponents, empty pieces, >9-digit ids, mantissas >= 2^29, more
+            // tokens than fields) rewinds to `t` and takes the general path below, which owns all the error messages.
+            if (f < field_size) {
+                uint32_t id = 0;
+                int nd = 0;
+                while (q < le && (unsigned)(*q - '0') <= 9u) { id = id * 10u + (unsigned)(*q - '0'); ++q; ++nd; }
+                if (nd >= 1 && nd <= 9 && q < le && *q == ':') {
+                    ++q;
+                    uint64_t n = 0;
+                    int digits = 0, frac = 0;
+                    while (q < le && (unsigned)(*q - '0') <= 9u && digits < 19) { n = n * 10 + (uint64_t)(*q - '0'); ++q; ++digits; }
+                    if (q < le && *q == '.') {
+                        ++q;
+                        while (q < le && (unsigned)(*q - '0') <= 9u && digits < 19) { n = n * 10 + (uint64_t)(*q - '0'); ++q; ++digits; ++frac; }
+                    }
+                    if (digits >= 1 && digits <= 18 && (q == le || *q == ' ') && n < (1ull << 29) && frac <= 22) {
+                        ir[f] = (int32_t)id;
+                        vr[f] = frac == 0 ? (float)n : (float)((double)n / kPow10[frac]);       // (same conversion as parse_f32's fast path)
+                        ++f;
+                        continue;
+                    }
+                }
+                q = t;
+            }
             while (q < le && *q != ' ') ++q;
             // id:val with empty pieces dropped -> exactly two pieces
             const char* a0 = t;

@@ -37,6 +37,8 @@ for threads in sorted({1, 8, 32, os.cpu_count() or 8}):
     assert len(pl) == lines and np.array_equal(pi, ids)
     print(json.dumps({"parse_threads": threads, "lines_per_sec": round(lines / dt), "MB_per_sec": round(size / dt / 1e6, 1)}), flush=True)
 
+if os.environ.get("DCTR_INPUT_BENCH_PARSE_ONLY"):
+    sys.exit(0)
 import tf_repos_amd.tf_shim as shim
 shim.install()
 spec = importlib.util.spec_from_file_location("ctr_estimator_example", os.path.join(ROOT, "examples", "ctr_estimator.py"))
