@@ -169,15 +169,15 @@ class CsvDataset:
 
     def _load(self, path):
         if path not in self._cache:
-            with open(path, "rb") as f:
-                buf = f.read()
+            size = os.path.getsize(path)           # (mapped, not read: see parse_file)
+            buf = np.memmap(path, dtype=np.uint8, mode="r") if size > 0 else np.zeros(0, dtype=np.uint8)
             lib = capi.lib()
             k = np.asarray(self.kinds, dtype=np.int8)
             nf, ni = int((k == 0).sum()), int((k == 1).sum())
             fd = np.asarray(self.f_defaults, dtype=np.float32) if nf else np.zeros(1, np.float32)
             idf = np.asarray(self.i_defaults, dtype=np.int32) if ni else np.zeros(1, np.int32)
             n = C.c_int64()
-            args = (buf, len(buf), len(k), capi.ptr(k), capi.ptr(fd), capi.ptr(idf), int(self.threads))
+            args = (capi.ptr(buf), size, len(k), capi.ptr(k), capi.ptr(fd), capi.ptr(idf), int(self.threads))
             capi.check(lib.dctr_parse_csv_mt(*args, None, None, 0, C.byref(n)))         # count, then parse in place
             rows = n.value
             out_f = np.empty((max(rows, 1), max(nf, 1)), dtype=np.float32)
