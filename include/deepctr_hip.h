@@ -67,6 +67,18 @@ enum { DCTR_GATHER_RAW = 0,   /* e only                    (PNN.py:133-136, DCN.
        DCTR_GATHER_BI  = 2    /* + bi[B,K] bi-interaction  (NFM.py:126-128)                                  */ };
 
 #define DCTR_MAX_LAYERS 8
+
+/* ---- dropout sites (nn.dropout, DeepFM.py:161-162; NFM.py:136-137; AFM.py:152-153,157-158) --------------------------------
+ * The engine draws no random stream: the keep/drop decision of element `idx` (row-major index in the logical shape of the
+ * dropped tensor) of site `site` in train step `t` (global_step during that step: 1 for the first) is a pure function
+ *     u = hash32((seed ^ t * 0xD1B54A32D192ED03) ^ site ^ idx * 0x9E3779B97F4A7C15) >> 8) / 2^24,   kept iff u >= 1 - keep
+ * (nn.dropout's floor(keep + u) [TF-1.4]), kept elements scaled by 1/keep.  dctr_dropout_mask evaluates it on the host, so a
+ * parity test can hand the engine's own masks to the oracle. */
+#define DCTR_DROPOUT_SITE_MLP(i)   (0x1000ull + (uint64_t)(i))   /* output of deep layer i [B, H_i] (after batch_norm when on)      */
+#define DCTR_DROPOUT_SITE_MLP2(i)  (0x2000ull + (uint64_t)(i))   /* second tower: ESMM's cvr_ tower [B, H_i]; DIN's att_fc%d [nnz, A_i] */
+#define DCTR_DROPOUT_SITE_NFM_BI   0xB1ull                       /* NFM bi-interaction [B, K]            (NFM.py:136-137)           */
+#define DCTR_DROPOUT_SITE_AFM_ATT  0xA0ull                       /* AFM attention weights [B, P]         (AFM.py:152-153)           */
+#define DCTR_DROPOUT_SITE_AFM_YEMB 0xA1ull                       /* AFM pooled embedding [B, K]          (AFM.py:157-158)           */
 #define DCTR_INPUT_SLOTS 8     /* engine-owned input staging sets, see dctr_input_slot */
 
 typedef struct dctr_config {
@@ -477,6 +489,10 @@ int dctr_step_timer(dctr_handle h, int enable, float* h_avg_ms, int* h_count);
 /* measured HBM roofline: GB/s (read + write) of a streaming float4 copy of `nbytes` (use >> 256 MB so the Infinity Cache does
  * not serve it), averaged over `iters` launches between two hipEvents on `stream` */
 int dctr_measure_copy_bw(size_t nbytes, int iters, float* h_gbps, void* stream);
+/* host-side evaluation of the engine's dropout decision (see "dropout sites" above): h_mask[idx] = 1 (kept) or 0 for idx in
+ * [0, n).  `seed` = dctr_config.seed, `global_step` = the step the mask belongs to (dctr_get_global_step() + 1 before the
+ * train call).  No device work; usable without a GPU. */
+int dctr_dropout_mask(uint64_t seed, int64_t global_step, uint64_t site, int64_t n, float keep, uint8_t* h_mask);
 
 #ifdef __cplusplus
 }

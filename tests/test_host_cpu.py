@@ -240,3 +240,41 @@ def test_gemm_kernel_choice_per_shape():
     assert plan("w", 4096 * 741, 16, 256).startswith("lds")                                            # (K = 16: the fused AFM path anyway)
     with pytest.raises(Exception):
         plan("x", 1, 1, 1)
+
+
+def test_dropout_mask_is_the_documented_function():
+    """dctr_dropout_mask (host side of the engine's counter-based dropout, include/deepctr_hip.h "dropout sites") against a
+    Python restatement of the documented formula; nn.dropout keeps with probability keep_prob (DeepFM.py:161-162)."""
+    import ctypes as C
+    from tf_repos_amd import capi
+    L = capi.lib()
+    M64 = (1 << 64) - 1
+
+    def hash32(x):
+        x ^= x >> 33; x = (x * 0xff51afd7ed558ccd) & M64; x ^= x >> 33; x = (x * 0xc4ceb9fe1a85ec53) & M64; x ^= x >> 33
+        return x & 0xffffffff
+
+    def ref(seed, t, site, n, keep):
+        s = (seed ^ ((t * 0xD1B54A32D192ED03) & M64)) ^ site
+        out = np.empty(n, np.uint8)
+        for i in range(n):
+            u = np.float32(hash32(s ^ ((i * 0x9E3779B97F4A7C15) & M64)) >> 8) * np.float32(1.0 / 16777216.0)
+            out[i] = u >= np.float32(1.0) - np.float32(keep)
+        return out
+
+    def mask(seed, t, site, n, keep):
+        m = np.empty(n, np.uint8)
+        capi.check(L.dctr_dropout_mask(seed, t, site, n, keep, capi.ptr(m)))
+        return m
+    for seed, t, site, keep in [(0, 1, capi.SITE_MLP(0), 0.5), (1234, 7, capi.SITE_MLP2(2), 0.8), (2**63 + 5, 10**6, capi.SITE_AFM_ATT, 0.3)]:
+        np.testing.assert_array_equal(mask(seed, t, site, 4000, keep), ref(seed, t, site, 4000, keep))
+    big = mask(3, 2, capi.SITE_NFM_BI, 1 << 20, 0.8)
+    assert abs(big.mean() - 0.8) < 2e-3                                        # kept with probability keep_prob
+    assert mask(3, 2, capi.SITE_NFM_BI, 1000, 1.0).all()
+    a = mask(3, 2, capi.SITE_MLP(0), 4096, 0.5)
+    assert not np.array_equal(a, mask(3, 3, capi.SITE_MLP(0), 4096, 0.5))      # a new draw per step,
+    assert not np.array_equal(a, mask(3, 2, capi.SITE_MLP(1), 4096, 0.5))      # per site
+    assert not np.array_equal(a, mask(4, 2, capi.SITE_MLP(0), 4096, 0.5))      # and per seed
+    assert abs(np.corrcoef(a[:-1], a[1:])[0, 1]) < 0.05                        # neighbours independent
+    with pytest.raises(Exception):
+        mask(0, 1, 0, 4, 0.0)

@@ -23,6 +23,10 @@ OPTIMIZERS = {"Adam": 0, "Adagrad": 1, "Momentum": 2, "ftrl": 3}
 TABLE_MODES = {"dense_exact": 0, "touched_rows": 1}
 GATHER_RAW, GATHER_FM, GATHER_BI = 0, 1, 2
 MAX_LAYERS = 8
+# dropout sites (include/deepctr_hip.h DCTR_DROPOUT_SITE_*)
+SITE_MLP = lambda i: 0x1000 + i          # noqa: E731
+SITE_MLP2 = lambda i: 0x2000 + i         # noqa: E731
+SITE_NFM_BI, SITE_AFM_ATT, SITE_AFM_YEMB = 0xB1, 0xA0, 0xA1
 INPUT_SLOTS = 8
 
 
@@ -166,6 +170,7 @@ class Transport(C.Structure):
                 ("all_reduce_f32", ALL_REDUCE_F32_FN)]
 
 
+_SIGS["dctr_dropout_mask"] = ([C.c_uint64, C.c_int64, C.c_uint64, C.c_int64, C.c_float, _P], C.c_int)
 _SIGS["dctr_gemm_plan"] = ([C.c_char, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int], C.c_int)
 _SIGS["dctr_set_stat_sync"] = ([_P, ALL_REDUCE_F32_FN, _P, C.c_int], C.c_int)
 

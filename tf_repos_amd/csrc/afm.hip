@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void afm_pool_fwd_kernel(const float* __restri
     for (int p = t; p < P; p += 256) {
         const float a = sm[p] * inv;
         att[(size_t)b * P + p] = a;                                            // softmax output (before dropout): kept for the backward
-        sm[p] = (train && keep_att < 1.f) ? a * dropout_scale(seed ^ 0xA0ull, (uint64_t)b * P + p, keep_att) : a;
+        sm[p] = (train && keep_att < 1.f) ? a * dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_ATT, (uint64_t)b * P + p, keep_att) : a;
     }
     __syncthreads();
     // y_emb[k] = sum_p a'[p] pp[p,k]: thread = (pair slice, float4 piece), slices summed through LDS
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void afm_pool_fwd_kernel(const float* __restri
         const float* accf = reinterpret_cast<const float*>(acc4);
         float y = 0.f;
         for (int sl = 0; sl < n_slices; ++sl) y += accf[(size_t)sl * K + t];
-        if (train && keep_emb < 1.f) y *= dropout_scale(seed ^ 0xA1ull, (uint64_t)b * K + t, keep_emb);
+        if (train && keep_emb < 1.f) y *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + t, keep_emb);
         yemb[(size_t)b * K + t] = y;
     }
 }
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void afm_pool_bwd_kernel(float* __restrict__ d
     const uint64_t seed = (keep_att < 1.f || keep_emb < 1.f) ? *seed_ptr : 0ull;
     for (int k = t; k < K; k += 256) {
         float g = dy[(size_t)b * dy_ld + k];
-        if (keep_emb < 1.f) g *= dropout_scale(seed ^ 0xA1ull, (uint64_t)b * K + k, keep_emb);
+        if (keep_emb < 1.f) g *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + k, keep_emb);
         dye[k] = g;
         dy[(size_t)b * dy_ld + k] = g;
     }
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void afm_pool_bwd_kernel(float* __restrict__ d
         float s = d4.x * v.x + d4.y * v.y + d4.z * v.z + d4.w * v.w;
         for (int o = 1; o < KQ; o <<= 1) s += __shfl_xor(s, o);
         if (q == 0) {
-            const float msk = keep_att < 1.f ? dropout_scale(seed ^ 0xA0ull, (uint64_t)b * P + p, keep_att) : 1.f;
+            const float msk = keep_att < 1.f ? dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_ATT, (uint64_t)b * P + p, keep_att) : 1.f;
             const float d = s * msk, a = ab[p];                // d att[p]
             da[p] = d;
             att_drop[(size_t)b * P + p] = a * msk;

@@ -53,13 +53,15 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
-// counter-based RNG for dropout: one 32-bit hash per element, keyed by (seed, index).
+// counter-based RNG for dropout: one 32-bit hash per element, keyed by (seed, index); seed = StepState::seed_t ^ site
+// (include/deepctr_hip.h "dropout sites"; dctr_dropout_mask in core.hip is the host-side evaluation of the same function).
 // u in [0,1): mask = floor(keep + u) = (u >= 1-keep)   [nn.dropout, TF-1.4]
-__device__ __forceinline__ uint32_t hash32(uint64_t x) {
+constexpr uint64_t STEP_SEED_MULT = 0xD1B54A32D192ED03ULL;      // seed_t = seed ^ global_step * STEP_SEED_MULT (step_state_kernel)
+__host__ __device__ __forceinline__ uint32_t hash32(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
     return (uint32_t)x;
 }
-__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float keep) {
+__host__ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float keep) {
     const float u = (float)(hash32(seed ^ (idx * 0x9E3779B97F4A7C15ULL)) >> 8) * (1.0f / 16777216.0f);
     return (u >= 1.0f - keep) ? 1.0f / keep : 0.0f;
 }

@@ -48,6 +48,14 @@ int dctr_measure_copy_bw(size_t nbytes, int iters, float* h_gbps, void* stream) 
     return DCTR_OK;
 }
 
+int dctr_dropout_mask(uint64_t seed, int64_t global_step, uint64_t site, int64_t n, float keep, uint8_t* h_mask) {
+    DCTR_REQUIRE(h_mask != nullptr && n >= 0, "bad argument");
+    DCTR_REQUIRE(keep > 0.f && keep <= 1.f, "keep_prob must be in (0,1], got %f", keep);
+    const uint64_t s = (seed ^ ((uint64_t)global_step * STEP_SEED_MULT)) ^ site;      // StepState::seed_t ^ site
+    for (int64_t i = 0; i < n; ++i) h_mask[i] = (keep >= 1.f || dropout_scale(s, (uint64_t)i, keep) != 0.f) ? 1 : 0;
+    return DCTR_OK;
+}
+
 int dctr_version(void) { return 100; }
 const char* dctr_last_error(void) { return get_error(); }
 

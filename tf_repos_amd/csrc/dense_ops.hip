@@ -971,7 +971,7 @@ __global__ void step_state_kernel(StepState* s, float* zero, int n_zero) {
         Hyper& h = *hp;
         h.lr_t = (float)((double)h.lr * sqrt(1.0 - pow((double)h.beta2, t)) / (1.0 - pow((double)h.beta1, t)));
     }
-    s->seed_t = s->seed ^ ((uint64_t)s->t * 0xD1B54A32D192ED03ULL);
+    s->seed_t = s->seed ^ ((uint64_t)s->t * STEP_SEED_MULT);
 }
 
 // the NEXT step's state from the current one, into a second StepState (and a second set of loss scalars, zeroed): launched under
@@ -986,7 +986,7 @@ __global__ void step_state_next_kernel(const StepState* __restrict__ cur, StepSt
         Hyper& h = *hp;
         h.lr_t = (float)((double)h.lr * sqrt(1.0 - pow((double)h.beta2, t)) / (1.0 - pow((double)h.beta1, t)));
     }
-    s.seed_t = s.seed ^ ((uint64_t)s.t * 0xD1B54A32D192ED03ULL);
+    s.seed_t = s.seed ^ ((uint64_t)s.t * STEP_SEED_MULT);
     *nxt = s;
 }
 

@@ -30,6 +30,7 @@ struct Fc {
     int in = 0, out = 0;
     int w = -1, b = -1;          // indices into params
     float keep = 1.f;
+    uint64_t salt = 0;           // dropout site of this layer's output (DCTR_DROPOUT_SITE_MLP / _MLP2 of include/deepctr_hip.h)
     int splits = 1;
     int bn_beta = -1, bn_gamma = -1, bn_mm = -1, bn_mv = -1;   // batch_norm after this layer's ReLU (DeepFM.py:159-160)
     int last = -1;               // last parameter index of this layer (biases, or the BN moving variance)

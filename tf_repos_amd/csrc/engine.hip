@@ -178,6 +178,7 @@ int build(dctr_engine* E) {
         for (int i = 0; i < (no_mlp ? 0 : c.n_deep_layers); ++i) {
             Fc fc;
             fc.in = d; fc.out = c.deep_layers[i]; fc.keep = c.keep_prob[i];
+            fc.salt = t == 0 ? DCTR_DROPOUT_SITE_MLP(i) : DCTR_DROPOUT_SITE_MLP2(i);   // (independent draws per tower, as two nn.dropout ops are)
             DCTR_REQUIRE(fc.out > 0, "deep layer widths must be positive (got %d)", fc.out);
             fc.splits = choose_wgrad_splits(MB, fc.in, fc.out);
             if (i == 0 && E->opnn_fused) { fc.in = D + P * K * K; fc.splits = 1; }    // (the weight keeps the reference's [F K + P K K, H] shape)
@@ -213,6 +214,7 @@ int build(dctr_engine* E) {
         for (int i = 0; i < c.n_attention_layers; ++i) {
             Fc fc;
             fc.in = da; fc.out = c.attention_layers[i]; fc.keep = c.keep_prob[i];
+            fc.salt = DCTR_DROPOUT_SITE_MLP2(i);
             DCTR_REQUIRE(fc.out > 0, "attention layer widths must be positive (got %d)", fc.out);
             fc.splits = choose_wgrad_splits((int)std::min<int64_t>(E->max_entries, 1 << 30), fc.in, fc.out);
             char nm[64];
@@ -502,7 +504,7 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::f
     const uint64_t* seedp = &E->state->seed_t;
     if (c.model == DCTR_MODEL_IPNN) DCTR_TRY(pnn_inner_fwd(E->e, E->e_ld, B, F, K, E->x_in + D, E->Din_ld, st));
     if (c.model == DCTR_MODEL_OPNN && !E->opnn_fused) DCTR_TRY(pnn_outer_fwd(E->e, E->e_ld, B, F, K, E->x_in + D, E->Din_ld, st));
-    if (c.model == DCTR_MODEL_NFM && train) DCTR_TRY(dropout_inplace(E->x_in, (int64_t)B * K, c.keep_prob[0], seedp, 0xB1ull, st));   // NFM.py:136-137
+    if (c.model == DCTR_MODEL_NFM && train) DCTR_TRY(dropout_inplace(E->x_in, (int64_t)B * K, c.keep_prob[0], seedp, DCTR_DROPOUT_SITE_NFM_BI, st));   // NFM.py:136-137
     if (c.model == DCTR_MODEL_DCN)
         DCTR_TRY(dcn_cross_fwd(E->x_in, E->Din_ld, E->pp(E->p_cross_w), E->pp(E->p_cross_b), B, D, c.cross_layers, E->xs, E->xlw, st));
     if (c.model == DCTR_MODEL_MVM) DCTR_TRY(mvm_fwd(E->e, E->e_ld, E->pp(E->p_mvm_b), B, F, K, E->xmvm, st));
@@ -518,16 +520,16 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::f
             // flat rows of W0 as an ordinary product (raw sums), then the pair-product rows with A formed in registers + bias/ReLU/dropout
             DCTR_TRY(fc_fwd(x, ldx, E->pp(fc.w), nullptr, E->h[0], fc.out, B, D, fc.out, 0, 1.f, nullptr, 0, st, 1));
             DCTR_TRY(opnn_outer_fwd(E->e, E->e_ld, B, F, K, E->opnn_pairs, E->pp(fc.w) + (size_t)D * fc.out, E->pp(fc.b), E->h[0], fc.out, fc.out, 1,
-                                    (train && !E->bn) ? fc.keep : 1.f, seedp, 0x1000ull, E->opnn_ws, st));
+                                    (train && !E->bn) ? fc.keep : 1.f, seedp, fc.salt, E->opnn_ws, st));
         } else
         DCTR_TRY(fc_fwd(x, ldx, E->pp(fc.w), E->pp(fc.b), E->h[i], fc.out, B, fc.in, fc.out, 1, (train && !E->bn) ? fc.keep : 1.f,
-                        seedp, 0x1000ull + i, st, 1));
+                        seedp, fc.salt, st, 1));
         if (timed) { DCTR_HIP_CHECK(hipEventRecord(E->timer_ev[E->timer_n + 1], st)); E->timer_n += 2; }
         if (i == 0 && after_layer0 != nullptr) DCTR_TRY((*after_layer0)());
         x = E->h[i]; ldx = fc.out;
         if (E->bn) {
             DCTR_TRY(bn_forward(E->h[i], fc.out, B, fc.out, train, 1e-3f, c.batch_norm_decay, E->pp(fc.bn_gamma), E->pp(fc.bn_beta),
-                                E->pp(fc.bn_mm), E->pp(fc.bn_mv), fc.keep, seedp, 0x1000ull + i, E->bn_stats[i], E->bn_scratch,
+                                E->pp(fc.bn_mm), E->pp(fc.bn_mv), fc.keep, seedp, fc.salt, E->bn_stats[i], E->bn_scratch,
                                 E->hbn[i], fc.out, st, E->bn_sync.world > 1 ? &E->bn_sync : nullptr));
             x = E->hbn[i];
         }
@@ -666,7 +668,7 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
         const Param& b = E->params[fc.b];
         if (E->bn)      // dh[i] holds dL/d(layer output): dropout mask, BN backward, ReLU mask -> dL/d(pre-activation), in place
             DCTR_TRY(bn_backward(E->dh[i], fc.out, E->h[i], fc.out, B, fc.out, E->bn_stats[i], E->pp(fc.bn_gamma), fc.keep, bn_seedp,
-                                 0x1000ull + i, E->bn_scratch, E->part(fc.bn_beta), E->part(fc.bn_gamma), E->dh[i], fc.out, st,
+                                 fc.salt, E->bn_scratch, E->part(fc.bn_beta), E->part(fc.bn_gamma), E->dh[i], fc.out, st,
                                  E->bn_sync.world > 1 ? &E->bn_sync : nullptr));
         if (!wgrad_late) {
             // dh[i] is complete on st -- and so is dgrad_{i+1}, the last reader of W_{i+1}: ONE record serves the weight gradient of
@@ -723,7 +725,7 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
     const uint64_t* seedp = &E->state->seed_t;
     if (c.model == DCTR_MODEL_IPNN) DCTR_TRY(pnn_inner_bwd(E->e, E->e_ld, E->dx_in + D, E->Din_ld, B, F, K, E->dx_in, E->Din_ld, st));
     if (c.model == DCTR_MODEL_OPNN && !E->opnn_fused) DCTR_TRY(pnn_outer_bwd(E->e, E->e_ld, E->dx_in + D, E->Din_ld, B, F, K, E->dx_in, E->Din_ld, st));
-    if (c.model == DCTR_MODEL_NFM) DCTR_TRY(dropout_inplace(E->dx_in, (int64_t)B * K, c.keep_prob[0], seedp, 0xB1ull, st));
+    if (c.model == DCTR_MODEL_NFM) DCTR_TRY(dropout_inplace(E->dx_in, (int64_t)B * K, c.keep_prob[0], seedp, DCTR_DROPOUT_SITE_NFM_BI, st));
     if (c.model == DCTR_MODEL_MVM) {         // after the MLP's dgrad wrote dx_in: the product layer adds its share of dL/de
         const Param& pm = E->params[E->p_mvm_b];
         DCTR_TRY(mvm_bwd(E->e, E->e_ld, E->pp(E->p_mvm_b), E->dxmvm, B, F, K, E->dx_in, E->Din_ld, E->part(E->p_mvm_b), pm.padded, pm.n_part, st));
@@ -1616,7 +1618,7 @@ int dctr_time_kernel(dctr_handle E, const char* kernel, int iters, float* h_ms_p
             const Fc& fc = E->mlp[0];
             if (s == "mlp0_fwd")
                 return fc_fwd(E->x_in, E->Din_ld, E->pp(fc.w), E->pp(fc.b), E->h[0], fc.out, B, fc.in, fc.out, 1, fc.keep,
-                              &E->state->seed_t, 0x1000ull, cs, 1);
+                              &E->state->seed_t, fc.salt, cs, 1);
             if (s == "mlp0_dgrad")
                 return fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w), E->dx_in, E->Din_ld, B, fc.in, fc.out, nullptr, 0, 1.f, cs, 1);
             return fc_bwd_weights_partials(E->x_in, E->Din_ld, E->dh[0], fc.out, E->part(fc.w), E->params[fc.w].padded,

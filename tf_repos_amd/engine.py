@@ -176,6 +176,15 @@ class Engine:
     def global_step(self, v: int) -> None:
         capi.check(self._lib.dctr_set_global_step(self._h, int(v)))
 
+    def dropout_mask(self, site: int, shape, keep: float, step: Optional[int] = None) -> np.ndarray:
+        """The 0/1 keep mask (uint8, `shape`) the engine applies at dropout site `site` (capi.SITE_*) in train step `step`
+        (default: the next train_step).  Evaluated on the host by dctr_dropout_mask -- the engine's dropout is a pure function of
+        (seed, step, site, element index), see include/deepctr_hip.h "dropout sites"."""
+        m = np.empty(tuple(int(d) for d in shape), dtype=np.uint8)
+        t = self.global_step + 1 if step is None else int(step)
+        capi.check(self._lib.dctr_dropout_mask(int(self.cfg.seed), t, int(site), int(m.size), float(keep), capi.ptr(m)))
+        return m
+
     # -- ops ---------------------------------------------------------------------------------
     def _set_dense(self, dense) -> None:
         if dense is not None:
