@@ -361,8 +361,14 @@ int dctr_input_slot(dctr_handle h, int slot, int32_t** d_ids, float** d_vals, fl
  * untouched until that dctr_train_step call -- are grouped (the de-duplication of the IndexedSlices gradient of
  * embedding_lookup, DeepFM.py:126,130 / 213) during the tail of the step in flight instead of beside the next step's first MLP
  * layer.  Purely a scheduling hint: results are identical with or without it; ids outside the input slots, CSR / canned /
- * row-sharded handles are ignored. */
+ * row-sharded handles are ignored.
+ * The hint is tied to the slot's GENERATION: dctr_input_slot_rewrite(slot) -- which an input pipeline calls before it refills a
+ * slot -- and the engine's own staging copies advance it, and a step whose slot has moved on since the hint groups the ids
+ * itself instead of using a stale grouping.  dctr_prefetch_cancel drops a pending hint (end of a training loop: the announced
+ * batch will not be trained).  dctr_input_slot_rewrite is safe to call from the input pipeline's thread. */
 int dctr_prefetch_ids(dctr_handle h, const int32_t* d_ids_next, int B);
+int dctr_prefetch_cancel(dctr_handle h);
+int dctr_input_slot_rewrite(dctr_handle h, int slot);
 /* canned-estimator models: the dense (numeric-column) inputs [B, dense_size] f32 of the NEXT train/predict/eval call; the
  * buffer is read in place and must stay valid until that call's work has finished */
 int dctr_set_dense_input(dctr_handle h, const float* d_dense);

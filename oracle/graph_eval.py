@@ -45,7 +45,7 @@ class GraphEval:
     """eval(feed) computes every node reachable from the roots; grad(loss) back-propagates to the variables.
 
     ``variables``: {variable name -> ndarray}; ``feed``: {node -> ndarray} for the iterator / placeholder nodes;
-    ``dropout_masks``: optional {dropout node id -> 0/1 mask}: with keep_prob < 1 a mask MUST be supplied (TF's RNG stream
+    ``dropout_masks``: optional {dropout node id -> 0/1 mask} (or a callable (node, input shape) -> mask): with keep_prob < 1 a mask MUST be supplied (TF's RNG stream
     cannot be reproduced); keep_prob == 1 is the identity.
     """
 
@@ -66,6 +66,10 @@ class GraphEval:
     def eval(self, feed: Dict) -> None:
         for n in self.nodes:
             if n in feed:
+                if isinstance(feed[n], tuple):      # a batched VarLenFeature (tf.SparseTensor): (row offsets [B+1], values [nnz])
+                    off, v = np.asarray(feed[n][0]), np.asarray(feed[n][1])
+                    self.val[n.id] = (off, v.astype(F64) if v.dtype.kind == "f" else v)
+                    continue
                 v = np.asarray(feed[n])
                 self.val[n.id] = v.astype(F64) if v.dtype.kind == "f" else v
                 continue
@@ -83,7 +87,11 @@ class GraphEval:
 
     # reshape(tensor, shape) [TF]: row-major, one -1 allowed
     def f_reshape(self, n):
-        return np.reshape(self._in(n, 0), n.attrs["shape"])
+        shape = n.attrs["shape"]
+        if any(d is None for d in shape):          # dims given as scalar tensors, e.g. [-1, tf.shape(ids)[1], 1] (DIN.py:169)
+            dyn = iter(n.inputs[1:])
+            shape = [int(d) if d is not None else int(self.val[next(dyn).id]) for d in shape]
+        return np.reshape(self._in(n, 0), shape)
 
     # tf.nn.embedding_lookup(params, ids) with one unpartitioned variable == gather along axis 0 (Appendix B 1); ids are
     # range-checked like TF's CPU kernel
@@ -162,9 +170,13 @@ class GraphEval:
         x, keep = self._in(n, 0), n.attrs["keep_prob"]
         if keep >= 1.0:
             return x
-        if n.id not in self.masks:
+        if callable(self.masks):                   # mask provider: (dropout node, shape of its input) -> 0/1 array
+            m01 = self.masks(n, x.shape)
+        elif n.id in self.masks:
+            m01 = self.masks[n.id]
+        else:
             raise ValueError("dropout with keep_prob %g needs an explicit mask (node %s)" % (keep, n.name))
-        m = np.asarray(self.masks[n.id], dtype=F64) / keep
+        m = np.asarray(m01, dtype=F64).reshape(x.shape) / keep
         self.aux[n.id] = m
         return x * m
 
@@ -190,6 +202,59 @@ class GraphEval:
         self.aux[n.id] = (xh, inv, gamma, a["is_training"])
         return xh * gamma + beta
 
+
+    # ---- the CSR (multi-hot) scripts: DIN.py:143-183, DeepCvrMTL.py:153-165 ------------------------------------------------
+    # A parsed + batched tf.VarLenFeature is a SparseTensor whose indices are (row, position) in row-major order; it is fed here
+    # as (row offsets, values).
+    @staticmethod
+    def _segments(off):
+        return np.repeat(np.arange(len(off) - 1), np.diff(off))
+
+    # tf.nn.embedding_lookup_sparse(params, sp_ids, sp_weights, combiner="sum") [TF-1.4 embedding_ops.py]: rows of params gathered
+    # by sp_ids.values, scaled by sp_weights.values (all ones when sp_weights is None), segment-summed by sp_ids.indices[:, 0].
+    # The result has max(row index) + 1 rows: a batch whose LAST example has an empty list comes out one row short in TF and
+    # fails the script's concat -- raised here as well; empty lists elsewhere are rows of zeros.
+    def f_embedding_lookup_sparse(self, n):
+        p = self._in(n, 0)
+        off, ids = self.val[n.inputs[1].id]
+        w = self.val[n.inputs[2].id][1] if n.attrs["weighted"] else np.ones(len(ids), F64)
+        if len(ids) and (ids.min() < 0 or ids.max() >= p.shape[0]):
+            raise IndexError("indices out of range [0, %d)" % p.shape[0])
+        if len(off) > 1 and off[-1] == off[-2]:
+            raise ValueError("embedding_lookup_sparse: the last row of the batch is empty -- TF returns %d rows, not %d" % (
+                int(np.max(np.nonzero(np.diff(off))[0], initial=-1)) + 1, len(off) - 1))
+        seg = self._segments(off)
+        out = np.zeros((len(off) - 1, p.shape[1]), F64)
+        np.add.at(out, seg, p[ids] * w[:, None])
+        self.aux[n.id] = (seg, ids, w)
+        return out
+
+    # tf.sparse_tensor_to_dense(sp, default_value=0): [B, longest row of the batch], rows left-aligned (DIN.py:153-154)
+    def f_sparse_to_dense(self, n):
+        off, v = self.val[n.inputs[0].id]
+        B, P = len(off) - 1, int(np.diff(off).max()) if len(off) > 1 else 0
+        out = np.zeros((B, P), v.dtype)
+        seg = self._segments(off)
+        out[seg, np.arange(len(v)) - off[seg]] = v
+        return out
+
+    def f_expand_dims(self, n): return np.expand_dims(self._in(n, 0), n.attrs["axis"])
+    def f_greater(self, n): return self._in(n, 0) > self._in(n, 1)
+    def f_shape(self, n): return np.asarray(np.shape(self._in(n, 0)), np.int64)
+
+    # tf.tile(x, multiples): multiples given as Python ints or scalar tensors (DIN.py:160: [1, padded_dim])
+    def f_tile(self, n):
+        dyn = iter(n.inputs[1:])
+        reps = [int(m) if m is not None else int(self.val[next(dyn).id]) for m in n.attrs["multiples"]]
+        self.aux[n.id] = reps
+        return np.tile(self._in(n, 0), reps)
+
+    # tf.losses.log_loss(labels, predictions, epsilon=1e-7) [TF-1.4 losses_impl.py]: -z log(p + eps) - (1 - z) log(1 - p + eps),
+    # reduced SUM_BY_NONZERO_WEIGHTS = the mean over the batch with weights 1 (DeepCvrMTL.py:224)
+    def f_log_loss(self, n):
+        z, p, eps = self._in(n, 0), self._in(n, 1), n.attrs["epsilon"]
+        return np.mean(-z * np.log(p + eps) - (1.0 - z) * np.log(1.0 - p + eps))
+
     def f_minimize(self, n): return self._in(n, 0)
     def f_metrics_auc(self, n): return np.float64(0.0)
 
@@ -208,7 +273,8 @@ class GraphEval:
                 continue
             fn = getattr(self, "b_" + n.op, None)
             if fn is None:
-                if n.op in ("const", "ones_like", "iterator_ids", "iterator_vals", "iterator_labels", "placeholder", "cast"):
+                if n.op in ("const", "ones_like", "iterator_ids", "iterator_vals", "iterator_labels", "placeholder", "cast",
+                            "iterator_fixed", "iterator_varlen", "sparse_to_dense", "greater", "shape"):
                     continue
                 raise NotImplementedError("graph_eval backward: op %r" % n.op)
             for inp, gi in fn(n, gn):
@@ -343,6 +409,27 @@ class GraphEval:
             gx = gx * inv
         outs.append((n.inputs[0], gx))
         return outs
+
+
+    def b_embedding_lookup_sparse(self, n, g):
+        seg, ids, w = self.aux[n.id]
+        gp = np.zeros_like(self._in(n, 0))
+        np.add.at(gp, ids, g[seg] * w[:, None])
+        return [(n.inputs[0], gp)]
+
+    def b_expand_dims(self, n, g): return [(n.inputs[0], g.reshape(self._shape(n, 0)))]
+
+    def b_tile(self, n, g):
+        x = self._in(n, 0)
+        reps = self.aux[n.id]
+        shp = []
+        for r, d in zip(reps, x.shape):
+            shp += [r, d]
+        return [(n.inputs[0], g.reshape(shp).sum(axis=tuple(range(0, 2 * x.ndim, 2))))]
+
+    def b_log_loss(self, n, g):
+        z, p, eps = self._in(n, 0), self._in(n, 1), n.attrs["epsilon"]
+        return [(n.inputs[1], g * (-z / (p + eps) + (1.0 - z) / (1.0 - p + eps)) / p.size)]
 
     def b_minimize(self, n, g): return [(n.inputs[0], g)]
 

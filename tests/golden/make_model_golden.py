@@ -74,8 +74,51 @@ def trace(script, flags, params, mode="train", batch=8):
     return spec, nodes, feats, labels, variables, lowered
 
 
+def _fc_scope(node):
+    """the fully_connected scope ('mlp0', 'cvr_mlp1', 'att_fc0', ...) whose output (optionally through batch_norm) `node` is, or None"""
+    while node is not None and getattr(node, "op", None) in ("batch_norm",):
+        node = node.inputs[0]
+    if getattr(node, "op", None) != "fully_connected":
+        return None
+    return node.inputs[1].var_name.split("/")[-2]
+
+
+def engine_mask(seed, step, site, shape, keep):
+    """the 0/1 mask the HIP engine applies at `site` in train step `step` (host function of the C ABI; no GPU involved)"""
+    from tf_repos_amd import capi
+    m = np.empty(shape, np.uint8)
+    capi.check(capi.lib().dctr_dropout_mask(int(seed), int(step), int(site), int(m.size), float(keep), capi.ptr(m)))
+    return m
+
+
+class FixedFieldMasks:
+    """nn.dropout sites of the fixed-field scripts in the engine's numbering (include/deepctr_hip.h "dropout sites"): the layer
+    outputs (DeepFM.py:161-162) by the scope of the fully_connected they follow, NFM's bi-interaction (NFM.py:136-137), AFM's
+    attention weights and pooled embedding in call order (AFM.py:152-153,157-158).  Called by GraphEval for every dropout node."""
+
+    def __init__(self, model, seed, step):
+        self.model, self.seed, self.step, self.used, self.n_other = model, seed, step, {}, 0
+
+    def __call__(self, node, shape):
+        from tf_repos_amd import capi
+        scope = _fc_scope(node.inputs[0])
+        if scope is not None and re.fullmatch(r"mlp\d+", scope):
+            key, site = scope, capi.SITE_MLP(int(scope[3:]))
+        elif self.model == "nfm":
+            key, site = "bi", capi.SITE_NFM_BI
+        elif self.model == "afm":
+            key, site = [("att", capi.SITE_AFM_ATT), ("y_emb", capi.SITE_AFM_YEMB)][self.n_other]
+            self.n_other += 1
+        else:
+            raise ValueError("unexpected dropout node %s in model %s" % (node.name, self.model))
+        assert key not in self.used, key
+        self.used[key] = engine_mask(self.seed, self.step, site, shape, node.attrs["keep_prob"])
+        return self.used[key]
+
+
 def run_case(name, script, flags, params, B=24, steps=2, seed=0, var_scale=0.05, out_dir=None, quiet=False):
     spec, nodes, feats, labels, variables, lowered = trace(script, flags, params)
+    with_dropout = any(n.op == "dropout" and n.attrs["keep_prob"] < 1.0 for n in nodes)
     F, V = int(params["field_size"]), int(params["feature_size"])
     var0 = draw_variables(variables, 1000 + seed, var_scale)
     mini = [n for n in nodes if n.op == "minimize"][0]
@@ -92,9 +135,14 @@ def run_case(name, script, flags, params, B=24, steps=2, seed=0, var_scale=0.05,
     slots = {}
     for s in range(steps):
         ids, vals, lab = synth(B, F, V, seed=7000 + 10 * seed + s)
-        ev = GraphEval(nodes, var, training=True)
+        masks = FixedFieldMasks(lowered.model, 1000 + seed, s + 1) if with_dropout else None
+        ev = GraphEval(nodes, var, training=True, dropout_masks=masks)
         ev.eval({feats["feat_ids"]: ids.reshape(B, F, 1), feats["feat_vals"]: vals.reshape(B, F, 1), labels: lab})
         g = ev.grad(spec.loss)
+        if with_dropout:        # the engine draws these itself from (meta_engine_seed, step, site); the oracle is handed them
+            out["meta_engine_seed"] = 1000 + seed
+            for k, m in masks.used.items():
+                out["step%d/mask/%s" % (s, k)] = m
         out["step%d/ids" % s], out["step%d/vals" % s], out["step%d/labels" % s] = ids, vals, lab
         out["step%d/logits" % s] = ev.val[logit.id].reshape(-1)
         out["step%d/prob" % s] = ev.val[prob.id].reshape(-1)
@@ -165,6 +213,13 @@ CASES = [
     # AFM.py:143-145 with two attention widths; Outer-PNN at K = 16, where the engine forms the pair products inside the GEMMs
     ("afm_2att", "AFM.py", {}, dict(BASE, dropout="1.0,1.0", attention_layers="12,6")),
     ("opnn_k16", "PNN.py", {"model_type": "Outer"}, dict(BASE, field_size=8, feature_size=300, embedding_size=16)),
+    # TRAIN graphs WITH dropout (keep_prob < 1: every operating point of run.sh / README.md:49): the masks are the ones the HIP
+    # engine draws (a pure function of seed, step, site and element index, evaluated on the host), stored in the fixture
+    ("deepfm_dropout", "DeepFM.py", {}, dict(BASE, dropout="0.5,0.5,0.5")),
+    ("nfm_dropout", "NFM.py", {}, dict(BASE, dropout="0.5,0.8,0.8")),
+    ("afm_dropout", "AFM.py", {}, dict(BASE, dropout="0.7,0.6")),
+    ("deepfm_bn_dropout", "DeepFM.py", {"batch_norm": True, "optimizer": "Momentum"}, dict(BASE, dropout="0.8,0.5,0.5")),
+    ("dcn_dropout", "DCN.py", {}, dict(BASE, dropout="0.8,0.8")),
 ]
 
 if __name__ == "__main__":

@@ -349,3 +349,45 @@ def test_prefetched_id_grouping_changes_nothing(dev):
     assert np.allclose(runs[0][0], runs[1][0], rtol=0, atol=1e-6)
     for k in runs[0][1]:
         assert np.abs(runs[0][1][k] - runs[1][1][k]).max() <= 1e-6, k      # (the scatter's float atomics: two identical runs differ by ~1e-7 too)
+
+
+@pytest.mark.parametrize("how", ["rewrite", "cancel", "staging_copy"])
+def test_stale_prefetch_is_dropped(how, dev):
+    """A hint whose batch is never trained (a training loop that stops on max_steps) must not leak into the next loop: the slot's
+    generation (dctr_input_slot_rewrite, called by the feeder before a refill; the engine's own staging copy), or an explicit
+    dctr_prefetch_cancel, invalidates it.  Without that the next step would scatter into the OLD batch's rows with no error."""
+    F, V, B = 39, 3000, 128
+    runs = []
+    for hint in (False, True):
+        ocfg, params, eng = make_pair("deepfm", B=B, F=F, V=V, K=8, layers=(32, 16), opt="Adam", seed=3, use_graph=False)
+        b = [O.synth_batch(B, F, V, seed=800 + i) for i in range(3)]
+        slot = 0 if how == "staging_copy" else 1                # (foreign buffers are staged into slot 0)
+        s0, s1 = eng.input_slot(0), eng.input_slot(slot)
+
+        def fill(s, batch):
+            for dst, src in zip(s, batch):
+                dst[:B].copy_(torch.from_numpy(src))
+            torch.cuda.synchronize()
+        if slot == 0:
+            loss0 = eng.train_step(*dev_batch(*b[0], dev))
+        else:
+            fill(s0, b[0])
+            loss0 = eng.train_step(s0[0][:B], s0[1][:B], s0[2][:B])
+        fill(s1, b[1])
+        if hint:
+            eng.prefetch_ids(s1[0][:B])                         # announced ... and never trained
+        if how == "rewrite":
+            eng.input_slot_rewrite(slot)
+            fill(s1, b[2])                                      # a new loop's feeder refills the slot: same address, same B
+            loss1 = eng.train_step(s1[0][:B], s1[1][:B], s1[2][:B])
+        elif how == "cancel":
+            eng.prefetch_cancel()
+            fill(s1, b[2])
+            loss1 = eng.train_step(s1[0][:B], s1[1][:B], s1[2][:B])
+        else:
+            loss1 = eng.train_step(*dev_batch(*b[2], dev))      # staged by copy into slot 0, the slot that was announced
+        runs.append((loss0, loss1, eng.get_params()))
+        eng.close()
+    assert abs(runs[0][0] - runs[1][0]) <= 1e-6 and abs(runs[0][1] - runs[1][1]) <= 1e-6
+    for k in runs[0][2]:
+        assert np.abs(runs[0][2][k] - runs[1][2][k]).max() <= 1e-6, k

@@ -47,6 +47,15 @@ def var_err(fx, s, t, got, gmin=0.0):
     return float(d[keep].max()) if keep.any() else 0.0
 
 
+def masks_of(fx, s, as_torch=None):
+    """{oracle dropout key: 0/1 mask} stored for step s (fixtures traced with keep_prob < 1), else None"""
+    pre = "step%d/mask/" % s
+    m = {k[len(pre):]: v for k, v in fx.items() if k.startswith(pre)}
+    if not m:
+        return None
+    return {k: torch.from_numpy(v.astype(np.float64)).to(as_torch) for k, v in m.items()} if as_torch is not None else m
+
+
 def oracle_config(cfg):
     keys = ("model", "field_size", "feature_size", "embedding_size", "deep_layers", "dropout", "attention_layers", "cross_layers",
             "l2_reg", "learning_rate", "optimizer", "batch_norm", "batch_norm_decay")
@@ -71,17 +80,37 @@ def test_oracle_reproduces_the_reference_graph(case, dtype, tol):
     opt = O.Optimizer(ocfg, p)
     for s in range(int(fx["meta_steps"])):
         ids, vals, labels = fx["step%d/ids" % s], fx["step%d/vals" % s], fx["step%d/labels" % s]
-        out = O.forward(ocfg, p, ids, vals, train=True)
+        masks = masks_of(fx, s, dtype)
+        out = O.forward(ocfg, p, ids, vals, train=True, masks=masks)
         assert np.abs(out["y"].double().numpy() - fx["step%d/logits" % s]).max() <= tol
         loss = float(O.loss_fn(ocfg, p, out["y"], torch.from_numpy(labels).to(dtype)))
         assert abs(loss - float(fx["step%d/loss" % s])) <= tol * max(1.0, abs(loss))
-        g = O.grads(ocfg, p, ids, vals, labels, train=True)[1]
+        g = O.grads(ocfg, p, ids, vals, labels, train=True, masks=masks)[1]
         for e, t in name_map.items():
             if "step%d/grad/%s" % (s, t) in fx or "step%d/grad/%s@idx" % (s, t) in fx:
                 assert max_err(fx, "step%d/grad/%s" % (s, t), g[e].double().numpy()) <= tol, (s, t)
-        O.train_step(ocfg, p, opt, ids, vals, labels)
+        O.train_step(ocfg, p, opt, ids, vals, labels, masks=masks)
         for e, t in name_map.items():
             assert var_err(fx, s, t, p[e].double().numpy(), gmin=(1e-4 if dtype == torch.float32 else 0.0)) <= tol * 5, (s, t)
+
+
+def test_stored_dropout_masks_are_the_engine_function():
+    """the masks in the keep_prob < 1 fixtures are dctr_dropout_mask(meta_engine_seed, step, site): what the HIP engine will draw"""
+    from tf_repos_amd import capi
+    sites = {"bi": capi.SITE_NFM_BI, "att": capi.SITE_AFM_ATT, "y_emb": capi.SITE_AFM_YEMB}
+    sites.update({"mlp%d" % i: capi.SITE_MLP(i) for i in range(8)})
+    seen = 0
+    for case in CASES:
+        fx, cfg, _, _ = load(case)
+        for s in range(int(fx["meta_steps"])):
+            for key, m in (masks_of(fx, s) or {}).items():
+                keep = {"bi": cfg["dropout"][0], "att": cfg["dropout"][0], "y_emb": cfg["dropout"][1]}.get(key) or cfg["dropout"][int(key[3:])]
+                again = np.empty(m.shape, np.uint8)
+                capi.check(capi.lib().dctr_dropout_mask(int(fx["meta_engine_seed"]), s + 1, sites[key], m.size, float(keep), capi.ptr(again)))
+                assert np.array_equal(again, m), (case, s, key)
+                assert 0 < m.mean() < 1
+                seen += 1
+    assert seen >= 10
 
 
 def test_oracle_on_the_reference_serving_sample():
@@ -99,7 +128,7 @@ def test_oracle_on_the_reference_serving_sample():
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/deep_ctr"), reason="reference tree not present (GPU box)")
-@pytest.mark.parametrize("case", ["deepfm_adam", "afm", "dcn", "afm_2att", "opnn_k16"])
+@pytest.mark.parametrize("case", ["deepfm_adam", "afm", "dcn", "afm_2att", "opnn_k16", "deepfm_dropout", "afm_dropout"])
 def test_committed_fixtures_are_what_the_reference_source_produces_today(case, tmp_path):
     """Re-runs the generator on the reference tree (build container only) and requires the committed fixture, bit for bit."""
     import make_model_golden as gen
@@ -121,13 +150,15 @@ def test_engine_reproduces_the_reference_graph(case, dev):
     from tf_repos_amd.engine import Engine, EngineConfig
     fx, cfg, name_map, var0 = load(case)
     B = int(fx["step0/ids"].shape[0])
-    eng = Engine(EngineConfig(max_batch=B, **cfg))
+    dropout = "meta_engine_seed" in fx      # traced with keep_prob < 1: the engine draws the stored masks itself from this seed
+    eng = Engine(EngineConfig(max_batch=B, seed=int(fx["meta_engine_seed"]) if dropout else 0, **cfg))
     for e, t in name_map.items():
         eng.set_param(e, var0[t].reshape(eng.param_shapes[e]))
     t_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     for s in range(int(fx["meta_steps"])):
         ids, vals, labels = fx["step%d/ids" % s], fx["step%d/vals" % s], fx["step%d/labels" % s]
-        if not cfg.get("batch_norm"):          # (a PREDICT pass of a batch-norm model uses the moving statistics, the TRAIN graph the batch's)
+        # (a PREDICT pass of a batch-norm model uses the moving statistics, the TRAIN graph the batch's; and it has no dropout)
+        if not cfg.get("batch_norm") and not dropout:
             prob, logit = torch.empty(B, device=dev), torch.empty(B, device=dev)
             eng.predict(t_(ids), t_(vals), prob, logit)
             assert np.abs(logit.cpu().numpy().astype(np.float64) - fx["step%d/logits" % s]).max() <= 1e-4

@@ -1,5 +1,6 @@
 // Engine state shared by engine.hip (MLP-family models) and afm.hip (attention model).
 #pragma once
+#include <atomic>
 #include <map>
 #include <string>
 #include <vector>
@@ -64,6 +65,9 @@ struct dctr_engine {
     const int32_t* pre_ids = nullptr;
     int pre_B = 0;
     bool pre_valid = false;
+    int pre_slot = 0;               // ... of input slot `pre_slot` at generation `pre_gen`: a slot rewritten since (dctr_input_slot_rewrite,
+    uint32_t pre_gen = 0;           // or a staging copy into it) no longer matches and the hint is dropped
+    std::atomic<uint32_t> slot_gen[DCTR_INPUT_SLOTS] = {};
     hipEvent_t ev_tail = nullptr;   // = the event of the main stream's last fork when the dense backward was enqueued (ring of 64: one step uses ~12)
     hipEvent_t last_fork_ev = nullptr;
     bool have_tail = false;

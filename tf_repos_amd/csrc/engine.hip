@@ -847,7 +847,8 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     static const int group_after = getenv("DCTR_GROUP_AFTER") ? atoi(getenv("DCTR_GROUP_AFTER")) : 0;   // A/B knob: 0 = after the gather, 1 = after MLP layer 0
     // the id grouping (and the background table pass behind it) on the grouping stream
     // ids grouped ahead (dctr_prefetch_ids, during the tail of the previous step): the two grouping states change roles
-    const bool pregrouped = E->pre_valid && E->pre_ids == E->ids && E->pre_B == B && E->group_alt != nullptr && !E->cfg.use_graph;
+    const bool pregrouped = E->pre_valid && E->pre_ids == E->ids && E->pre_B == B && E->group_alt != nullptr && !E->cfg.use_graph &&
+                            E->pre_gen == E->slot_gen[E->pre_slot].load();     // (the slot still holds what was grouped)
     E->pre_valid = false;
     if (pregrouped) std::swap(E->group, E->group_alt);
     const std::function<int()> start_grouping = [&]() -> int {
@@ -949,7 +950,10 @@ int stage_inputs(dctr_engine* E, const int32_t* ids, const float* vals, const fl
         if (ids == E->slot_ids[k] && vals == E->slot_vals[k] && (labels == nullptr || labels == E->slot_labels[k])) slot = k;
     E->cur_slot = slot;
     E->ids = E->slot_ids[slot]; E->vals = E->slot_vals[slot]; E->labels = E->slot_labels[slot];
-    if (ids != E->ids) DCTR_HIP_CHECK(hipMemcpyAsync(E->ids, ids, n * 4, hipMemcpyDeviceToDevice, st));
+    if (ids != E->ids) {
+        E->slot_gen[slot]++;                // the staging copy rewrites the slot: a grouping prefetched from it is stale
+        DCTR_HIP_CHECK(hipMemcpyAsync(E->ids, ids, n * 4, hipMemcpyDeviceToDevice, st));
+    }
     if (vals != E->vals) DCTR_HIP_CHECK(hipMemcpyAsync(E->vals, vals, n * 4, hipMemcpyDeviceToDevice, st));
     if (labels != nullptr && labels != E->labels)
         DCTR_HIP_CHECK(hipMemcpyAsync(E->labels, labels, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
@@ -1125,13 +1129,26 @@ int dctr_prefetch_ids(dctr_handle E, const int32_t* d_ids_next, int B) {
     DCTR_REQUIRE(E && d_ids_next, "null argument");
     if (E->csr || E->wnd || E->cfg.use_graph || E->cfg.shard_world > 1) return DCTR_OK;       // not a path that groups per step: no-op
     DCTR_REQUIRE(B > 0 && B <= E->MB, "batch %d outside (0, max_batch=%d]", B, E->MB);
-    bool is_slot = false;
-    for (int k = 0; k < DCTR_INPUT_SLOTS; ++k) is_slot = is_slot || d_ids_next == E->slot_ids[k];
-    if (!is_slot) return DCTR_OK;           // foreign buffers are staged by copy: their address says nothing about their contents
+    int slot = -1;
+    for (int k = 0; k < DCTR_INPUT_SLOTS; ++k) if (d_ids_next == E->slot_ids[k]) slot = k;
+    if (slot < 0) return DCTR_OK;           // foreign buffers are staged by copy: their address says nothing about their contents
     if (E->group_alt == nullptr) DCTR_TRY(group_create(E->rows, E->group->max_entries, E->K, &E->group_alt));
     if (E->have_tail) DCTR_HIP_CHECK(hipStreamWaitEvent(E->s_group, E->ev_tail, 0));
     DCTR_TRY(group_ids(E->group_alt, d_ids_next, B, E->F, E->s_group));
     E->pre_ids = d_ids_next; E->pre_B = B; E->pre_valid = true;
+    E->pre_slot = slot; E->pre_gen = E->slot_gen[slot].load();
+    return DCTR_OK;
+}
+
+int dctr_prefetch_cancel(dctr_handle E) {
+    DCTR_REQUIRE(E, "null argument");
+    E->pre_valid = false;
+    return DCTR_OK;
+}
+
+int dctr_input_slot_rewrite(dctr_handle E, int slot) {
+    DCTR_REQUIRE(E && slot >= 0 && slot < DCTR_INPUT_SLOTS, "input slot %d outside [0, %d)", slot, DCTR_INPUT_SLOTS);
+    E->slot_gen[slot]++;                    // (atomic: the input pipeline's thread calls this while the training thread enqueues steps)
     return DCTR_OK;
 }
 

@@ -234,6 +234,14 @@ class Engine:
         tail of the step in flight.  A scheduling hint only."""
         capi.check(self._lib.dctr_prefetch_ids(self._h, capi.ptr(ids_next), int(ids_next.shape[0])))
 
+    def prefetch_cancel(self) -> None:
+        """Drops a pending prefetch_ids hint (the announced batch will not be trained)."""
+        capi.check(self._lib.dctr_prefetch_cancel(self._h))
+
+    def input_slot_rewrite(self, slot: int) -> None:
+        """Call before refilling input slot `slot`: a grouping prefetched from its old contents is dropped (thread-safe)."""
+        capi.check(self._lib.dctr_input_slot_rewrite(self._h, int(slot)))
+
     def predict(self, ids, vals, out_prob=None, out_logit=None, stream=None, dense=None):
         self._set_dense(dense)
         B = int(ids.shape[0])

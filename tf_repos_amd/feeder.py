@@ -58,6 +58,7 @@ class DeviceFeeder:
                 np.copyto(p_v.numpy()[:B], vals, casting="same_kind")
                 np.copyto(p_l.numpy()[:B], labels, casting="same_kind")
                 s_i, s_v, s_l = self.slot[k]
+                self.eng.input_slot_rewrite(k)            # a grouping prefetched from the slot's old contents is stale from here on
                 with torch.cuda.stream(self.copy_stream):
                     s_i[:B].copy_(p_i[:B], non_blocking=True)
                     s_v[:B].copy_(p_v[:B], non_blocking=True)
@@ -104,6 +105,7 @@ class DeviceFeeder:
 
     def close(self) -> None:
         self._stop = True
+        self.eng.prefetch_cancel()                        # the batch announced last (peek_next_ids) will not be trained
         try:
             while self._q.get_nowait() is not None:
                 pass
