@@ -355,7 +355,7 @@ def main():
         rows = (V + world - 1) // world                            # rows of this rank's table shard
         names = ["opt_table", "mlp0_fwd", "mlp0_dgrad", "mlp0_wgrad"]
         if not sharded:
-            names = ["embed_gather", "forward", "head", "backward_dense", "group_ids", "scatter", "opt_dense"] + names
+            names = ["embed_gather", "forward", "head", "backward_dense", "group_ids", "scatter", "tail", "opt_dense"] + names
         stages = {name: e.time_stage(name, iters=(30 if not big else 3)) for name in names}
         gather_bytes = B * (F * (12 + 8 * K) + 8)                 # algorithmic bytes of the gather
         # dense-exact table step as implemented: theta,m,v read + write (6 streams) + the 4-byte slot word per row; the per-row

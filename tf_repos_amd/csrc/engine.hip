@@ -744,12 +744,28 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
     return DCTR_OK;
 }
 
+// the step's tail as ONE launch (embed_scatter_apply): whenever the table step after the scatter visits only the batch's distinct
+// rows -- dense-exact with the untouched rows stepped in the background, or the lazy touched_rows mode.  DCTR_FUSED_TAIL=0 keeps
+// the two-launch tail (A/B knob)
+bool split_table_on(const dctr_engine* E) {
+    static const bool no_split = getenv("DCTR_NO_SPLIT_TABLE") != nullptr;      // A/B knob
+    return E->cfg.table_mode == DCTR_TABLE_DENSE_EXACT && !no_split;
+}
+bool tail_fused(const dctr_engine* E) {
+    static const bool off = [] { const char* v = getenv("DCTR_FUSED_TAIL"); return v != nullptr && v[0] == '0'; }();
+    return !off && !E->wnd && E->cfg.shard_world == 1 && (split_table_on(E) || E->cfg.table_mode != DCTR_TABLE_DENSE_EXACT);
+}
+
 // ---- table side of the backward: segment-sum the row gradients (ids already grouped), step the tables ------------
 int scatter_and_step_tables(dctr_engine* E, int B, hipStream_t st, hipStream_t st_lin = nullptr, int pass = OPT_PASS_ALL) {
     const dctr_config& c = E->cfg;
     const int mode = gather_mode(E);
     const float* dE = mode == DCTR_GATHER_BI ? nullptr : E->dE;
     const float* coef = mode == DCTR_GATHER_FM ? E->dy : (mode == DCTR_GATHER_BI ? E->dx_in : nullptr);
+    if (tail_fused(E) && (pass == OPT_PASS_TOUCHED || c.table_mode != DCTR_TABLE_DENSE_EXACT))
+        return embed_scatter_apply(E->group, c.optimizer, &E->state->hyper, E->h_state.hyper, E->emb, E->emb_s0, E->emb_s1, E->lin, E->lin_s0,
+                                   E->lin_s1, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, dE, E->dE_ld, E->e, E->e_ld,
+                                   E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F, E->K, mode, st);
     DCTR_TRY(embed_scatter_bwd(E->group, dE, E->dE_ld, E->e, E->e_ld, E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F,
                                E->K, mode, E->group->gemb, E->lin ? E->group->glin : nullptr, st));
     if (pass == OPT_PASS_TOUCHED) st_lin = nullptr;     // the touched-rows kernel steps the linear weights in the same launch
@@ -841,8 +857,7 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
         DCTR_TRY(forward_gather(E, B, st));
         DCTR_TRY(fork(E, sw, st));          // (before the fork below: sg's table pass needs this step's lr_t and zeroed scalars)
     }
-    static const bool no_split = getenv("DCTR_NO_SPLIT_TABLE") != nullptr;      // A/B knob
-    const bool split_table = E->cfg.table_mode == DCTR_TABLE_DENSE_EXACT && !no_split;
+    const bool split_table = split_table_on(E);
     static const bool bg_late = getenv("DCTR_BG_LATE") != nullptr;              // A/B knob: background table pass beside the backward
     static const int group_after = getenv("DCTR_GROUP_AFTER") ? atoi(getenv("DCTR_GROUP_AFTER")) : 0;   // A/B knob: 0 = after the gather, 1 = after MLP layer 0
     // the id grouping (and the background table pass behind it) on the grouping stream
@@ -851,10 +866,17 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
                             E->pre_gen == E->slot_gen[E->pre_slot].load();     // (the slot still holds what was grouped)
     E->pre_valid = false;
     if (pregrouped) std::swap(E->group, E->group_alt);
+    hipEvent_t tables_ev = nullptr;
+    bool have_tables_ev = false;
     const std::function<int()> start_grouping = [&]() -> int {
         DCTR_TRY(fork(E, st, sg));          // not before the gather (its atomics slow a concurrent gather 4x)
-        if (!pregrouped) DCTR_TRY(group_ids(E->group, E->ids, B, E->F, sg));
+        // (a captured step is replayed from states this enqueue cannot see: it always carries the slot-reset kernel)
+        if (E->cfg.use_graph) E->group->slots_clean = false;
+        if (!pregrouped) DCTR_TRY(group_ids(E->group, E->ids, B, E->F, sg, !tail_fused(E)));
         if (split_table && !bg_late) DCTR_TRY(step_untouched_rows(E, sg));
+        // what the scatter needs from this stream ends here: it waits for THIS record, not for the output layer's optimizer
+        // launches that follow on sg (two latency-bound kernels, ~80 us in the step: they used to hold the scatter back ~10 us)
+        if (!bg_late) { DCTR_TRY(record_on(E, sg, &tables_ev)); have_tables_ev = true; }
         return DCTR_OK;
     };
     const bool have_mlp = !E->mlp.empty() && E->cfg.model != DCTR_MODEL_AFM;
@@ -897,7 +919,8 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
         DCTR_TRY(opt_dense_arena(E->cfg.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->parts, E->meta,
                                  E->n_blocks, nullptr, 1, E->scalars + 3 * SUMSQ_SHARDS, sw));
     }
-    DCTR_TRY(fork(E, sg, st));
+    if (have_tables_ev) DCTR_HIP_CHECK(hipStreamWaitEvent(st, tables_ev, 0));
+    else DCTR_TRY(fork(E, sg, st));
     if (split_table) DCTR_TRY(scatter_and_step_tables(E, B, st, nullptr, OPT_PASS_TOUCHED));
     else DCTR_TRY(scatter_and_step_tables(E, B, st, sg));  // the grouping stream is idle by now: linear table beside the embedding table
     static const bool no_state_ahead = getenv("DCTR_NO_STATE_AHEAD") != nullptr;       // A/B knob
@@ -908,6 +931,7 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
         E->state_ready = true;
     }
     DCTR_TRY(fork(E, sw, st));
+    if (have_tables_ev) DCTR_TRY(fork(E, sg, st));      // (the output layer's step on sg: long finished, joined for the next forward)
     if (E->opt_pending) { DCTR_TRY(fork(E, E->s_opt, st)); E->opt_pending = false; }
     return DCTR_OK;
 }
@@ -1133,8 +1157,11 @@ int dctr_prefetch_ids(dctr_handle E, const int32_t* d_ids_next, int B) {
     for (int k = 0; k < DCTR_INPUT_SLOTS; ++k) if (d_ids_next == E->slot_ids[k]) slot = k;
     if (slot < 0) return DCTR_OK;           // foreign buffers are staged by copy: their address says nothing about their contents
     if (E->group_alt == nullptr) DCTR_TRY(group_create(E->rows, E->group->max_entries, E->K, &E->group_alt));
-    if (E->have_tail) DCTR_HIP_CHECK(hipStreamWaitEvent(E->s_group, E->ev_tail, 0));
-    DCTR_TRY(group_ids(E->group_alt, d_ids_next, B, E->F, E->s_group));
+    // where the grouping of the next batch may start: behind the step's last st -> sw fork (beside scatter + table step, default),
+    // or as soon as the grouping stream has drained its own work of the step (DCTR_PREGROUP_WAIT=none: beside the dense backward)
+    static const bool wait_tail = [] { const char* v = getenv("DCTR_PREGROUP_WAIT"); return v == nullptr || strcmp(v, "none") != 0; }();
+    if (E->have_tail && wait_tail) DCTR_HIP_CHECK(hipStreamWaitEvent(E->s_group, E->ev_tail, 0));
+    DCTR_TRY(group_ids(E->group_alt, d_ids_next, B, E->F, E->s_group, !tail_fused(E)));
     E->pre_ids = d_ids_next; E->pre_B = B; E->pre_valid = true;
     E->pre_slot = slot; E->pre_gen = E->slot_gen[slot].load();
     return DCTR_OK;
@@ -1243,10 +1270,12 @@ int dctr_train_step_csr(dctr_handle E, const int32_t* d_offsets, const int32_t* 
     DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, st));
     // grouping of the batch's ids + the entries' slot offsets: beside the forward pass
     DCTR_TRY(fork(E, st, sg));
-    DCTR_TRY(group_ids(E->group, d_ids, nnz, 1, sg));
+    const bool split_table = split_table_on(E);
+    const bool fused = tail_fused(E);
+    if (E->cfg.use_graph) E->group->slots_clean = false;
+    DCTR_TRY(group_ids(E->group, d_ids, nnz, 1, sg, !fused));
     if (!E->att_on) DCTR_TRY(csr_entry_offsets(d_offsets, B * E->F, nnz, E->F, E->Din_ld, E->K, E->entry_off, sg));   // (attention: the forward computes them)
     // dense-exact table: the rows this batch does not touch step now, under the MLP (as in record_train)
-    const bool split_table = c.table_mode == DCTR_TABLE_DENSE_EXACT && getenv("DCTR_NO_SPLIT_TABLE") == nullptr;
     if (split_table) DCTR_TRY(step_untouched_rows(E, sg));
     DCTR_TRY(csr_forward(E, d_offsets, d_ids, d_weights, nnz, B, d_y, d_z, true, st));
     DCTR_TRY(backward_dense(E, B, st, sw, false));
@@ -1276,6 +1305,12 @@ int dctr_train_step_csr(dctr_handle E, const int32_t* d_offsets, const int32_t* 
     // table: per-entry gradient = weight * dL/dx[slot], segment-summed per distinct id, then the optimizer (DIN.py:222: the
     // l2_loss(Feat_Emb) term makes the table gradient dense, as for the fixed-field models)
     DCTR_TRY(fork(E, sg, st));
+    if (fused) {
+        if (nnz > 0)
+            DCTR_TRY(embed_scatter_apply(E->group, c.optimizer, &E->state->hyper, E->h_state.hyper, E->emb, E->emb_s0, E->emb_s1, nullptr, nullptr,
+                                         nullptr, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, E->dx_in, 4, nullptr, 0,
+                                         nullptr, nullptr, nullptr, d_weights, nnz, 1, E->K, DCTR_GATHER_RAW, st, 1, goff));
+    } else {
     if (nnz > 0)
         DCTR_TRY(embed_scatter_bwd(E->group, E->dx_in, 4, nullptr, 0, nullptr, nullptr, nullptr, d_weights, nnz, 1, E->K, DCTR_GATHER_RAW,
                                    E->group->gemb, nullptr, st, 1, goff));
@@ -1283,6 +1318,7 @@ int dctr_train_step_csr(dctr_handle E, const int32_t* d_offsets, const int32_t* 
                        nullptr, nullptr, nullptr, E->group->slot, E->group->uniq, E->group->counters, E->group->max_entries,
                        E->group->gemb, nullptr, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, st, nullptr,
                        split_table ? OPT_PASS_TOUCHED : OPT_PASS_ALL));
+    }
     DCTR_TRY(fork(E, sw, st));
     E->last_B = B;
     if (h_loss) {
@@ -1605,6 +1641,8 @@ int dctr_time_kernel(dctr_handle E, const char* kernel, int iters, float* h_ms_p
     const int B = E->last_B;
     const std::string s(kernel);
     const dctr_config& c = E->cfg;
+    // the stages are captured once and REPLAYED: a grouping in them must not rely on what this enqueue knows about the slot words
+    E->group->slots_clean = false;
     auto stage = [&](hipStream_t cs) -> int {
         if (s == "embed_gather") {
             const int mode = gather_mode(E);
@@ -1615,7 +1653,11 @@ int dctr_time_kernel(dctr_handle E, const char* kernel, int iters, float* h_ms_p
         if (s == "forward") return forward(E, B, true, cs);
         if (s == "head") return head(E, B, B, true, cs, nullptr, true);
         if (s == "backward_dense") return backward_dense(E, B, cs, cs);
-        if (s == "group_ids") return group_ids(E->group, E->ids, B, E->F, cs);
+        if (s == "group_ids") return group_ids(E->group, E->ids, B, E->F, cs, !tail_fused(E));
+        if (s == "tail") {          // grouping + the step's tail (fused: ONE launch; else scatter + touched-rows table step): repeatable as a pair
+            DCTR_TRY(group_ids(E->group, E->ids, B, E->F, cs, !tail_fused(E)));
+            return scatter_and_step_tables(E, B, cs, nullptr, split_table_on(E) ? OPT_PASS_TOUCHED : OPT_PASS_ALL);
+        }
         if (s == "scatter") {
             const int mode = gather_mode(E);
             const float* dE = mode == DCTR_GATHER_BI ? nullptr : E->dx_in;
@@ -1672,6 +1714,11 @@ int dctr_time_kernel(dctr_handle E, const char* kernel, int iters, float* h_ms_p
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipGraphExecDestroy(exec);
     *h_ms_per_launch = ms / (float)iters;
+    if (s == "scatter" && !E->group->gemb_clean) {      // the plain scatter wrote compact rows: back to the fused tail's all-zero invariant
+        DCTR_HIP_CHECK(hipMemsetAsync(E->group->gemb, 0, (size_t)E->group->max_entries * E->group->K * 4, st));
+        DCTR_HIP_CHECK(hipStreamSynchronize(st));
+        E->group->gemb_clean = true;
+    }
     return DCTR_OK;
 }
 

@@ -15,9 +15,15 @@
 //              round-trips through HBM for those terms.
 #include "common.h"
 #include "ops.h"
+#include "opt_rules.h"
 
 namespace dctr {
 
+__device__ __forceinline__ float wave_sum_g(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
 
 // forget the previous batch: slot words of its distinct ids back to 0; the last block to finish also zeroes the counters
 // (ticket in counters[3]) so that no separate one-thread launch is needed
@@ -35,6 +41,7 @@ __global__ void group_reset_kernel(int32_t* __restrict__ slot, const int32_t* __
         counters[1] = 0;
         counters[2] = 0;
         counters[3] = 0;
+        counters[4] = 0;
     }
 }
 
@@ -197,6 +204,7 @@ __global__ __launch_bounds__(256) void group_fill_hash_kernel(const int32_t* __r
 // segments at least this long are not walked in runs (their per-run atomic flushes all land on ONE 64-byte compact row: 4096
 // entries in runs of 16 = 256 flushes x 17 floats serialised at ~90 atomics/us -- 48 us, the whole scatter); a block reduces
 // chunks of them in registers + LDS and flushes once per chunk
+constexpr int SHORT_SEGMENT = 8;        // embed_scatter_apply: segments up to this long take one walker (KQ lanes), entries loaded together
 constexpr int LONG_SEGMENT = 256;
 constexpr int LONG_CHUNK = 256;
 
@@ -204,7 +212,8 @@ constexpr int LONG_CHUNK = 256;
 __global__ __launch_bounds__(256) void group_segments_kernel(int32_t* __restrict__ slot, const int32_t* __restrict__ uniq,
                                                             int32_t* __restrict__ cnt, int32_t* __restrict__ seg_start,
                                                             int32_t* __restrict__ cursor, int32_t* __restrict__ counters,
-                                                            float* __restrict__ glin, int32_t* __restrict__ long_list, int long_cap) {
+                                                            float* __restrict__ glin, int32_t* __restrict__ long_list, int long_cap,
+                                                            int32_t* __restrict__ done, int32_t* __restrict__ medium_list, int medium_cap) {
     __shared__ int wsum[4];
     __shared__ int bbase;
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -234,10 +243,28 @@ __global__ __launch_bounds__(256) void group_segments_kernel(int32_t* __restrict
         cursor[u] = s;
         slot[id] = u + 1;
         glin[u] = 0.f;
+        done[u] = 0;                        // entries of the segment folded so far (scatter_apply_kernel's completion ticket)
         if (c >= LONG_SEGMENT) {            // a hot id (Criteo's numeric fields: every example): reduced by a block of its own
             const int k = atomicAdd(&counters[2], 1);
             if (k < long_cap) long_list[k] = u;
         }
+    }
+    // medium segments (SHORT_SEGMENT < c < LONG_SEGMENT, ~10^3 per Criteo batch): the list embed_scatter_apply deals to waves;
+    // one atomic per block on the shared counter
+    const bool med = u < U && c > SHORT_SEGMENT && c < LONG_SEGMENT;
+    const unsigned long long mm = __ballot(med);
+    __syncthreads();
+    if (lane == 0) wsum[wave] = __popcll(mm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        bbase = tot ? atomicAdd(&counters[4], tot) : 0;
+    }
+    __syncthreads();
+    if (med) {
+        int k = bbase + __popcll(mm & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) k += wsum[w];
+        if (k < medium_cap) medium_list[k] = u;
     }
 }
 
@@ -430,6 +457,298 @@ static int launch_scatter(Group* g, const float* dE, int de_ld, const float* e, 
     return DCTR_OK;
 }
 
+// ---- scatter + table optimizer in ONE launch (the training step's tail) -------------------------------------------------------
+// Same walk as scatter_bwd_kernel, but a segment's gradient sum goes straight into the optimizer step of its table row instead
+// of into the compact [U, K] buffer that a second launch (opt_table_kernel<.., false>) used to re-read:
+//   * segments of up to SHORT_SEGMENT entries (most ids occur once per batch): one walker of K/4 lanes per distinct id, the
+//     entries' gradients loaded together, summed in registers, applied at once;
+//   * up to LONG_SEGMENT: one wave per segment (a compacted list built by group_segments_kernel), folded with shuffles;
+//   * longer ones, reduced chunk-wise by blocks of their own: partial sums meet in the compact row by float atomics, every
+//     chunk then adds its entry count to done[u]; the block that completes cnt[u] takes the total back out with
+//     atomicExch(.., 0) -- which also leaves the row zeroed for the next batch, so the fused path needs no group_finalize
+//     pass -- and applies it.  No fences: everything that crosses blocks is an atomic, and an add is waited for (its returned
+//     value consumed) before its ticket is drawn.
+// Row arithmetic = opt_table_kernel<KIND, KQ, false>, operation for operation (l2*theta + segment sum, opt_update, sum theta^2).
+struct TableStep {
+    float4* emb; float4* s0; float4* s1;        // [rows, K] parameters and optimizer slots
+    float* lin; float* l0; float* l1;           // [rows] linear weights and slots (nullptr: the model has none)
+    const Hyper* hdev; Hyper hval;
+    float l2;
+    float* sumsq_emb; float* sumsq_lin;         // SUMSQ_SHARDS-way sharded sum theta^2 of the visited rows (pre-update)
+    const int32_t* uniq;                        // distinct id u -> table row
+    int32_t* slot;                              // the grouping's slot word of every visited row goes back to 0 (no group_reset pass)
+    int32_t* done;                              // [U] completion tickets
+};
+
+// the row's pieces are LOADED as soon as the distinct id is known (before the gradient loads: one latency instead of two) and
+// stepped once the gradient sum is there
+struct RowRegs { float4 th, a, b; float lt, la, lb; int64_t r; };
+
+template <int KIND, int KQ>
+__device__ __forceinline__ RowRegs table_row_load(const TableStep& T, int u, int kq) {
+    constexpr bool TWO = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL);
+    RowRegs R;
+    R.r = T.uniq[u];
+    const size_t i4 = (size_t)R.r * KQ + kq;
+    R.th = T.emb[i4]; R.a = T.s0[i4]; R.b = TWO ? T.s1[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    R.lt = R.la = R.lb = 0.f;
+    if (kq == 0 && T.lin != nullptr) { R.lt = T.lin[R.r]; R.la = T.l0[R.r]; R.lb = TWO ? T.l1[R.r] : 0.f; }
+    return R;
+}
+
+template <int KIND, int KQ>
+__device__ __forceinline__ void table_row_step(const TableStep& T, const Hyper& h, RowRegs& R, int kq, float4 gs, float gl, float& sq, float& sql) {
+    constexpr bool TWO = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL);
+    const size_t i4 = (size_t)R.r * KQ + kq;
+    float4 th = R.th, a = R.a, b = R.b;
+    sq += th.x * th.x + th.y * th.y + th.z * th.z + th.w * th.w;
+    float4 g = make_float4(T.l2 * th.x, T.l2 * th.y, T.l2 * th.z, T.l2 * th.w);
+    g.x += gs.x; g.y += gs.y; g.z += gs.z; g.w += gs.w;
+    opt_update(KIND, h, th.x, a.x, b.x, g.x);
+    opt_update(KIND, h, th.y, a.y, b.y, g.y);
+    opt_update(KIND, h, th.z, a.z, b.z, g.z);
+    opt_update(KIND, h, th.w, a.w, b.w, g.w);
+    T.emb[i4] = th; T.s0[i4] = a;
+    if (TWO) T.s1[i4] = b;
+    if (kq == 0) T.slot[R.r] = 0;
+    if (kq == 0 && T.lin != nullptr) {
+        float lt = R.lt, la = R.la, lb = R.lb;
+        sql += lt * lt;
+        float lg = T.l2 * lt;
+        lg += gl;
+        opt_update(KIND, h, lt, la, lb, lg);
+        T.lin[R.r] = lt; T.l0[R.r] = la;
+        if (TWO) T.l1[R.r] = lb;
+    }
+}
+
+template <int KIND, int KQ>
+__device__ __forceinline__ void table_step_row(const TableStep& T, const Hyper& h, int u, int kq, float4 gs, float gl, float& sq, float& sql) {
+    RowRegs R = table_row_load<KIND, KQ>(T, u, kq);
+    table_row_step<KIND, KQ>(T, h, R, kq, gs, gl, sq, sql);
+}
+
+// returned-atomic float add: the result is consumed (asm), so the wave waits until the add has been PERFORMED at the device-scope
+// point of coherence -- what orders it before the completion ticket that follows, without a release fence (a __threadfence()
+// writes back the XCD's whole L2: ~3.5 us each, MI355X_MICROARCH.md "inter-workgroup visibility")
+__device__ __forceinline__ void atomic_add4_performed(float* p, float4 v, float* pl, float vl) {
+    const float o0 = atomicAdd(p + 0, v.x), o1 = atomicAdd(p + 1, v.y), o2 = atomicAdd(p + 2, v.z), o3 = atomicAdd(p + 3, v.w);
+    const float o4 = pl != nullptr ? atomicAdd(pl, vl) : 0.f;             // (all five in flight, one wait)
+    asm volatile("" ::"v"(o0), "v"(o1), "v"(o2), "v"(o3), "v"(o4));
+}
+
+
+template <int KIND, int KQ, int MODE>
+__global__ __launch_bounds__(256) void scatter_apply_kernel(
+    const int32_t* __restrict__ perm, const int32_t* __restrict__ counters,
+    const int32_t* __restrict__ seg_start, const int32_t* __restrict__ cnt,
+    const float4* __restrict__ dE, int de_ld4, const float4* __restrict__ e, int e_ld4,
+    const float4* __restrict__ S, const float* __restrict__ coef, const float* __restrict__ dy,
+    const float* __restrict__ vals, int B, int F, float* __restrict__ gemb, float* __restrict__ glin, int dy_ld,
+    int short_blocks, int medium_blocks, const int32_t* __restrict__ medium_list, int medium_cap,
+    const int32_t* __restrict__ long_list, int long_cap, const int32_t* __restrict__ entry_row, TableStep T) {
+    const Hyper h = load_hyper(T.hdev, T.hval);
+    float sq = 0.f, sql = 0.f;
+    __shared__ float4 red[256];
+    __shared__ float redl[256];
+    __shared__ int last_flag;
+    auto grad = [&](int i, int kq, float& gl) {
+        int b; float v;
+        const float4 d = entry_grad<KQ, MODE>(i, kq, dE, de_ld4, e, e_ld4, S, coef, vals, B, F, b, v, entry_row);
+        gl = (kq == 0 && dy != nullptr) ? dy[(size_t)b * dy_ld] * v : 0.f;
+        return d;
+    };
+    // (block order = dispatch order: the long segments' blocks -- the longest dependent chains -- start first, the many short
+    //  walkers fill in behind them)
+    const int long_blocks = (int)gridDim.x - short_blocks - medium_blocks;
+    if ((int)blockIdx.x >= long_blocks + medium_blocks) {
+        // ---- short segments (most ids occur once or twice per batch): walker u owns distinct id u, its entries' gradients are
+        // loaded together (up to 4 independent loads in flight per lane) and the sum goes straight into the row's optimizer step
+        const int t = ((int)blockIdx.x - long_blocks - medium_blocks) * blockDim.x + threadIdx.x;
+        const int u = t / KQ, kq = t % KQ;
+        const int len = u < counters[0] ? cnt[u] : 0;
+        if (len >= 1 && len <= SHORT_SEGMENT) {
+            const int s0 = seg_start[u];
+            RowRegs R = table_row_load<KIND, KQ>(T, u, kq);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            float accl = 0.f;
+            if (len == 1) {
+                acc = grad(perm[s0], kq, accl);
+            } else {
+#pragma unroll
+                for (int base = 0; base < SHORT_SEGMENT; base += 4) {
+                    if (base >= len) break;
+                    int pj[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pj[k] = perm[s0 + min(base + k, len - 1)];       // (clamped: the loads carry no branch)
+                    float4 d[4]; float gl[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d[k] = grad(pj[k], kq, gl[k]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (base + k < len) { acc.x += d[k].x; acc.y += d[k].y; acc.z += d[k].z; acc.w += d[k].w; accl += gl[k]; }
+                }
+            }
+            table_row_step<KIND, KQ>(T, h, R, kq, acc, accl, sq, sql);
+        }
+    } else if ((int)blockIdx.x >= long_blocks) {
+        // ---- medium segments (the hot categories of each field): one WAVE per segment, 64/KQ entries in flight per pass, folded
+        // with shuffles -- still no atomics
+        constexpr int EL = 64 / KQ;
+        const int lane = threadIdx.x & 63, kq = lane % KQ, el = lane / KQ;
+        const int n_med = min(counters[4], medium_cap);
+        const int wave = ((int)blockIdx.x - long_blocks) * 4 + (threadIdx.x >> 6), n_waves = medium_blocks * 4;
+        for (int mi = wave; mi < n_med; mi += n_waves) {
+            const int u = medium_list[mi];
+            const int s0 = seg_start[u], len = cnt[u];
+            RowRegs R;
+            if (el == 0) R = table_row_load<KIND, KQ>(T, u, kq);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            float accl = 0.f;
+            for (int j0 = el; j0 < len; j0 += 4 * EL) {              // 4 passes of the wave in flight (clamped: the loads carry no branch)
+                int pj[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pj[k] = perm[s0 + min(j0 + k * EL, len - 1)];
+                float4 d[4]; float gl[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = grad(pj[k], kq, gl[k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (j0 + k * EL < len) { acc.x += d[k].x; acc.y += d[k].y; acc.z += d[k].z; acc.w += d[k].w; accl += gl[k]; }
+            }
+#pragma unroll
+            for (int o = KQ; o < 64; o <<= 1) {
+                acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o); acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
+                accl += __shfl_xor(accl, o);
+            }
+            if (el == 0) table_row_step<KIND, KQ>(T, h, R, kq, acc, accl, sq, sql);
+        }
+    } else {
+        // ---- long segments (Criteo's numeric ids: every example of the batch): chunks of LONG_CHUNK entries dealt round-robin to
+        // these blocks, partial sums meet in the compact row by (performed) float atomics, the block that completes cnt[u] takes
+        // the total back out -- leaving zeros for the next batch -- and steps the row
+        constexpr int EL = 256 / KQ;
+        const int kq = threadIdx.x % KQ, el = threadIdx.x / KQ;
+        const int n_long = min(counters[2], long_cap);
+        const int NB = long_blocks, blk = (int)blockIdx.x;
+        int base = 0;
+        for (int li = 0; li < n_long; ++li) {
+            const int u = long_list[li];
+            const int s0 = seg_start[u], len = cnt[u];
+            const int nch = (len + LONG_CHUNK - 1) / LONG_CHUNK;
+            for (int c = ((blk - base) % NB + NB) % NB; c < nch; c += NB) {
+                const int c0 = s0 + c * LONG_CHUNK, c1 = min(s0 + len, c0 + LONG_CHUNK);
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                float accl = 0.f;
+                for (int j0 = c0 + el; j0 < c1; j0 += 4 * EL) {
+                    int pj[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pj[k] = perm[min(j0 + k * EL, c1 - 1)];
+                    float4 d[4]; float gl[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d[k] = grad(pj[k], kq, gl[k]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (j0 + k * EL < c1) { acc.x += d[k].x; acc.y += d[k].y; acc.z += d[k].z; acc.w += d[k].w; accl += gl[k]; }
+                }
+                red[threadIdx.x] = acc; redl[threadIdx.x] = accl;
+                __syncthreads();
+                for (int half = EL / 2; half >= 1; half >>= 1) {
+                    if (el < half) {
+                        const float4 o = red[threadIdx.x + half * KQ];
+                        float4 m = red[threadIdx.x];
+                        m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+                        red[threadIdx.x] = m;
+                        redl[threadIdx.x] += redl[threadIdx.x + half * KQ];
+                    }
+                    __syncthreads();
+                }
+                float* g = gemb + ((size_t)u * KQ + kq) * 4;
+                if (el == 0) {
+                    const float4 m = red[kq];
+                    atomic_add4_performed(g, m, (kq == 0 && dy != nullptr) ? glin + u : nullptr, redl[0]);
+                }
+                __syncthreads();                                    // every piece of the chunk's sum has been performed
+                if (threadIdx.x == 0) last_flag = (atomicAdd(&T.done[u], c1 - c0) + (c1 - c0) == len);
+                __syncthreads();
+                if (last_flag && el == 0) {
+                    float4 tot;
+                    tot.x = atomicExch(g + 0, 0.f); tot.y = atomicExch(g + 1, 0.f); tot.z = atomicExch(g + 2, 0.f); tot.w = atomicExch(g + 3, 0.f);
+                    const float tl = (kq == 0 && dy != nullptr) ? atomicExch(glin + u, 0.f) : 0.f;
+                    table_step_row<KIND, KQ>(T, h, u, kq, tot, tl, sq, sql);
+                }
+                __syncthreads();
+            }
+            base += nch;
+        }
+    }
+    if (T.sumsq_emb != nullptr) {
+        __shared__ float rs[2][4];
+        sq = wave_sum_g(sq);
+        sql = wave_sum_g(sql);
+        if ((threadIdx.x & 63) == 0) { rs[0][threadIdx.x >> 6] = sq; rs[1][threadIdx.x >> 6] = sql; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float a = rs[0][0] + rs[0][1] + rs[0][2] + rs[0][3], bq = rs[1][0] + rs[1][1] + rs[1][2] + rs[1][3];
+            if (a != 0.f) atomicAdd(T.sumsq_emb + (blockIdx.x & (SUMSQ_SHARDS - 1)), a);
+            if (T.sumsq_lin != nullptr && bq != 0.f) atomicAdd(T.sumsq_lin + (blockIdx.x & (SUMSQ_SHARDS - 1)), bq);
+        }
+    }
+}
+
+template <int KIND, int KQ>
+static int launch_scatter_apply(Group* g, const float* dE, int de_ld, const float* e, int e_ld, const float* S, const float* coef,
+                                const float* dy, const float* vals, int B, int F, int mode, int dy_ld, hipStream_t st,
+                                const int32_t* entry_row, const TableStep& T) {
+    const int64_t n = (int64_t)B * F;
+    const int short_blocks = ceil_div(n * KQ, 256);                                 // one walker per possible distinct id
+    const int medium_blocks = (int)std::min<int64_t>(ceil_div(g->medium_cap, 4), 512);
+    const int long_blocks = (int)std::min<int64_t>(ceil_div(n, LONG_CHUNK), 256);
+    dim3 grid(short_blocks + medium_blocks + long_blocks), block(256);
+#define DCTR_SA(MODE_)                                                                                         \
+    scatter_apply_kernel<KIND, KQ, MODE_><<<grid, block, 0, st>>>(                                             \
+        g->perm, g->counters, g->seg_start, g->cnt, reinterpret_cast<const float4*>(dE), de_ld / 4,             \
+        reinterpret_cast<const float4*>(e), e_ld / 4, reinterpret_cast<const float4*>(S), coef, dy, vals, B, F, \
+        g->gemb, g->glin, dy_ld, short_blocks, medium_blocks, g->medium_list, (int)g->medium_cap, g->long_list, \
+        (int)g->long_cap, entry_row, T)
+    switch (mode) {
+        case DCTR_GATHER_RAW: DCTR_SA(DCTR_GATHER_RAW); break;
+        case DCTR_GATHER_FM:  DCTR_SA(DCTR_GATHER_FM); break;
+        case DCTR_GATHER_BI:  DCTR_SA(DCTR_GATHER_BI); break;
+        default: set_error("scatter: bad mode %d", mode); return DCTR_ERR_INVALID_ARG;
+    }
+#undef DCTR_SA
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+// the step's tail in one launch: segment sums of the row gradients + the optimizer step of the batch's distinct rows (and their
+// linear weights).  Requires a grouping made with group_ids(.., zero_gemb = false) on a group whose compact rows are all zero
+// (g->gemb_clean), and leaves them so.
+int embed_scatter_apply(Group* g, int kind, const Hyper* hdev, const Hyper& hval, float* emb, float* e0, float* e1, float* lin,
+                        float* l0, float* l1, float l2, float* sumsq_emb, float* sumsq_lin, const float* dE, int de_ld,
+                        const float* e, int e_ld, const float* S, const float* coef, const float* dy, const float* vals, int B, int F,
+                        int K, int mode, hipStream_t st, int dy_ld, const int32_t* entry_row) {
+    DCTR_REQUIRE(K == g->K, "scatter: K=%d but group was created with K=%d", K, g->K);
+    DCTR_REQUIRE(g->gemb_clean, "scatter_apply: the group's compact gradient rows are not known to be zero");
+    DCTR_REQUIRE(dE == nullptr || de_ld % 4 == 0, "scatter: de_ld must be a multiple of 4");
+    DCTR_REQUIRE(mode == DCTR_GATHER_RAW || (e != nullptr && S != nullptr && coef != nullptr && e_ld % 4 == 0),
+                 "scatter: FM/BI modes need e, S and coef");
+    DCTR_REQUIRE((lin != nullptr) == (dy != nullptr), "scatter_apply: linear weights and their gradient source go together");
+    TableStep T{reinterpret_cast<float4*>(emb), reinterpret_cast<float4*>(e0), reinterpret_cast<float4*>(e1), lin, l0, l1, hdev, hval,
+                l2, sumsq_emb, sumsq_lin, g->uniq, g->slot, g->done};
+    g->slots_clean = true;                  // (every distinct id of the grouping is visited exactly once, and each visit clears its slot word)
+#define DCTR_Q(KD, Q) case Q: return launch_scatter_apply<KD, Q>(g, dE, de_ld, e, e_ld, S, coef, dy, vals, B, F, mode, dy_ld, st, entry_row, T)
+#define DCTR_KD(KD) case KD: switch (K / 4) { DCTR_Q(KD, 1); DCTR_Q(KD, 2); DCTR_Q(KD, 4); DCTR_Q(KD, 8); DCTR_Q(KD, 16); DCTR_Q(KD, 32); DCTR_Q(KD, 64); \
+                              default: set_error("scatter: K=%d unsupported", K); return DCTR_ERR_UNSUPPORTED; }
+    switch (kind) {
+        DCTR_KD(DCTR_OPT_ADAM) DCTR_KD(DCTR_OPT_ADAGRAD) DCTR_KD(DCTR_OPT_MOMENTUM) DCTR_KD(DCTR_OPT_FTRL)
+        default: set_error("unknown optimizer kind %d", kind); return DCTR_ERR_INVALID_ARG;
+    }
+#undef DCTR_KD
+#undef DCTR_Q
+}
+
 int group_create(int64_t rows, int64_t max_entries, int K, Group** out) {
     DCTR_REQUIRE(rows > 0 && max_entries > 0 && K % 4 == 0 && K >= 4, "group_create: bad sizes rows=%lld n=%lld K=%d",
                  (long long)rows, (long long)max_entries, K);
@@ -444,10 +763,16 @@ int group_create(int64_t rows, int64_t max_entries, int K, Group** out) {
     DCTR_HIP_CHECK(hipMalloc(&g->cursor, n * 4));
     DCTR_HIP_CHECK(hipMalloc(&g->perm, n * 4));
     DCTR_HIP_CHECK(hipMalloc(&g->seg_of, n * 4));
-    DCTR_HIP_CHECK(hipMalloc(&g->counters, 16));
-    DCTR_HIP_CHECK(hipMemset(g->counters, 0, 16));
+    DCTR_HIP_CHECK(hipMalloc(&g->counters, 32));
+    DCTR_HIP_CHECK(hipMemset(g->counters, 0, 32));
     DCTR_HIP_CHECK(hipMalloc(&g->gemb, n * K * 4));
+    DCTR_HIP_CHECK(hipMemset(g->gemb, 0, n * K * 4));
+    g->gemb_clean = true;
+    g->slots_clean = true;
     DCTR_HIP_CHECK(hipMalloc(&g->glin, n * 4));
+    DCTR_HIP_CHECK(hipMalloc(&g->done, n * 4));
+    g->medium_cap = (int64_t)(n / (SHORT_SEGMENT + 1)) + 1;   // at most n / 9 segments are longer than SHORT_SEGMENT
+    DCTR_HIP_CHECK(hipMalloc(&g->medium_list, (size_t)g->medium_cap * 4));
     g->long_cap = (int64_t)(n / LONG_SEGMENT) + 1;        // at most n / LONG_SEGMENT segments can be that long
     DCTR_HIP_CHECK(hipMalloc(&g->long_list, (size_t)g->long_cap * 4));
     // the memsets above run on the null stream and may still be pending: a first use on a non-blocking stream must not overtake them
@@ -459,33 +784,43 @@ int group_create(int64_t rows, int64_t max_entries, int K, Group** out) {
 int group_destroy(Group* g) {
     if (!g) return DCTR_OK;
     hipFree(g->slot); hipFree(g->uniq); hipFree(g->cnt); hipFree(g->seg_start); hipFree(g->cursor);
-    hipFree(g->perm); hipFree(g->seg_of); hipFree(g->counters); hipFree(g->gemb); hipFree(g->glin); hipFree(g->long_list);
+    hipFree(g->perm); hipFree(g->seg_of); hipFree(g->counters); hipFree(g->gemb); hipFree(g->glin); hipFree(g->long_list); hipFree(g->done); hipFree(g->medium_list);
     delete g;
     return DCTR_OK;
 }
 
-int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st) {
+int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st, bool zero_gemb) {
     const int64_t n = (int64_t)B * F;
     DCTR_REQUIRE(n <= g->max_entries, "group_ids: B*F=%lld exceeds capacity %lld", (long long)n, (long long)g->max_entries);
-    // always forget the previous batch (slot words back to 0, U = 0), even for an empty one
-    group_reset_kernel<<<ceil_div(g->max_entries, 256), 256, 0, st>>>(g->slot, g->uniq, g->counters, (int)g->max_entries);
+    // always forget the previous batch (slot words back to 0, U = 0), even for an empty one -- unless the fused scatter + table step
+    // has already put every slot word back (then only the counters are cleared)
+    if (g->slots_clean) DCTR_HIP_CHECK(hipMemsetAsync(g->counters, 0, 32, st));
+    else group_reset_kernel<<<ceil_div(g->max_entries, 256), 256, 0, st>>>(g->slot, g->uniq, g->counters, (int)g->max_entries);
     if (n <= 0) { DCTR_LAUNCH_CHECK(); return DCTR_OK; }
+    g->slots_clean = false;
     const int nb = ceil_div(n, 256);
     static const bool no_hash = getenv("DCTR_GROUP_NO_HASH") != nullptr;       // A/B knob
     const bool hashed = F == 1 && n >= 4 * HCHUNK && !no_hash;                  // CSR-ordered ids: aggregate per 2048-entry chunk in LDS
     if (hashed) group_count_hash_kernel<<<ceil_div(n, HCHUNK), 256, 0, st>>>(ids, (int)n, g->rows, g->slot, g->uniq, g->counters);
     else group_count_kernel<<<nb, 256, 0, st>>>(ids, B, F, g->rows, g->slot, g->uniq, g->counters);
     group_segments_kernel<<<nb, 256, 0, st>>>(g->slot, g->uniq, g->cnt, g->seg_start, g->cursor, g->counters, g->glin, g->long_list,
-                                             (int)g->long_cap);
+                                             (int)g->long_cap, g->done, g->medium_list, (int)g->medium_cap);
     const int KQ = g->K / 4;
     dim3 fgrid(ceil_div(n * KQ, 256));
     float4* gemb4 = reinterpret_cast<float4*>(g->gemb);
-    switch (KQ) {
+    // (the fused scatter + optimizer launch leaves the compact rows zeroed itself: its groupings skip this pass -- unless a plain
+    //  scatter has written the rows since)
+    if (!zero_gemb) {
+        if (!g->gemb_clean) {       // a plain scatter has written compact rows since: zero them all once, the fused path keeps them so
+            DCTR_HIP_CHECK(hipMemsetAsync(g->gemb, 0, (size_t)g->max_entries * g->K * 4, st));
+            g->gemb_clean = true;
+        }
+    } else { switch (KQ) {
 #define DCTR_FIN(Q) case Q: group_finalize_kernel<Q><<<fgrid, 256, 0, st>>>(g->counters, gemb4); break
         DCTR_FIN(1); DCTR_FIN(2); DCTR_FIN(4); DCTR_FIN(8); DCTR_FIN(16); DCTR_FIN(32); DCTR_FIN(64);
 #undef DCTR_FIN
         default: set_error("group: K=%d unsupported", g->K); return DCTR_ERR_UNSUPPORTED;
-    }
+    } }
     if (hashed) group_fill_hash_kernel<<<ceil_div(n, HCHUNK), 256, 0, st>>>(ids, (int)n, g->rows, g->slot, g->cursor, g->perm, g->seg_of);
     else group_fill_kernel<<<nb, 256, 0, st>>>(ids, B, F, g->rows, g->slot, g->cursor, g->perm, g->seg_of);
     DCTR_LAUNCH_CHECK();
@@ -501,6 +836,7 @@ int embed_scatter_bwd(Group* g, const float* dE, int de_ld, const float* e, int 
                  "scatter: FM/BI modes need e, S and coef");
     if (gemb == nullptr) gemb = g->gemb;
     if (glin == nullptr && dy != nullptr) glin = g->glin;
+    if (gemb == g->gemb) g->gemb_clean = false;             // (the fused path's invariant: all-zero compact rows between batches)
     switch (K / 4) {
 #define DCTR_L(Q) case Q: return launch_scatter<Q>(g, dE, de_ld, e, e_ld, S, coef, dy, vals, B, F, mode, gemb, glin, dy_ld, st, entry_row)
         DCTR_L(1); DCTR_L(2); DCTR_L(4); DCTR_L(8); DCTR_L(16); DCTR_L(32); DCTR_L(64);

@@ -41,17 +41,26 @@ struct Group {
     int32_t* cursor = nullptr;    // [max_entries]
     int32_t* perm = nullptr;      // [max_entries]
     int32_t* seg_of = nullptr;    // [max_entries]
-    int32_t* counters = nullptr;  // [4]: 0 = U (distinct ids), 1 = total grouped entries, 2 = long segments, 3 = reset ticket
+    int32_t* counters = nullptr;  // [8]: 0 = U (distinct ids), 1 = total grouped entries, 2 = long segments, 3 = reset ticket, 4 = medium segments
     int32_t* long_list = nullptr; // [long_cap] distinct-id indices u of the segments with >= LONG_SEGMENT entries
     int64_t long_cap = 0;
     float* gemb = nullptr;        // [max_entries, K] compact gradient rows
     float* glin = nullptr;        // [max_entries]
+    int32_t* medium_list = nullptr; // [medium_cap] distinct-id indices of the segments with SHORT_SEGMENT < entries < LONG_SEGMENT
+    int64_t medium_cap = 0;
+    int32_t* done = nullptr;      // [max_entries] entries of each segment folded so far (embed_scatter_apply's completion tickets)
+    bool slots_clean = false;     // host-side: every slot word is 0 (embed_scatter_apply clears the words of the rows it visits)
+    bool gemb_clean = false;      // host-side: every compact gradient row is zero (kept so by embed_scatter_apply, broken by embed_scatter_bwd)
 };
 inline int64_t group_capacity(const Group* g) { return g->max_entries; }
 
 int group_create(int64_t rows, int64_t max_entries, int K, Group** out);
 int group_destroy(Group* g);
-int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st);
+int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st, bool zero_gemb = true);
+int embed_scatter_apply(Group* g, int kind, const Hyper* hdev, const Hyper& hval, float* emb, float* e0, float* e1, float* lin,
+                        float* l0, float* l1, float l2, float* sumsq_emb, float* sumsq_lin, const float* dE, int de_ld,
+                        const float* e, int e_ld, const float* S, const float* coef, const float* dy, const float* vals, int B, int F,
+                        int K, int mode, hipStream_t st, int dy_ld = 1, const int32_t* entry_row = nullptr);
 int embed_scatter_bwd(Group* g, const float* dE, int de_ld, const float* e, int e_ld, const float* S,
                       const float* coef, const float* dy, const float* vals, int B, int F, int K, int mode,
                       float* gemb, float* glin, hipStream_t st, int dy_ld = 1,     // dy_ld: stride (floats) between examples in dy
