@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=200)
     ap.add_argument("--uniform-ids", action="store_true", help="uniform ids instead of Zipf (cache-worst case)")
+    ap.add_argument("--sweep-period", type=int, default=0, help="dense_exact + Adam: period of the time-blocked table sweep (0 = library default, 1 = classic: every row every step)")
     args = ap.parse_args()
 
     import numpy as np
@@ -246,7 +247,7 @@ def main():
     else:
         eng = Engine(EngineConfig(model=w["model"], field_size=F, feature_size=V, embedding_size=K, deep_layers=w["deep_layers"],
                                   dropout=w["dropout"], l2_reg=w["l2_reg"], learning_rate=w["learning_rate"], optimizer=w["optimizer"],
-                                  table_mode=args.table_mode, max_batch=B, seed=1,
+                                  table_mode=args.table_mode, max_batch=B, seed=1, table_sweep_period=args.sweep_period,
                                   use_graph=os.environ.get("DCTR_USE_GRAPH", "0") == "1"))
         rng = np.random.default_rng(1)
         for name, shp in eng.param_shapes.items():
@@ -325,6 +326,8 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.steps):
         step(*batches[(args.warmup + s) % nb], batches[(args.warmup + s + 1) % nb][0])
+    if not sharded:
+        eng.sync_tables()                     # time-blocked table sweep: every row's updates of the timed steps are computed INSIDE the timed region
     t_enq = time.perf_counter() - t0          # host time to ENQUEUE the steps (the GPU may still be running)
     barrier()
     torch.cuda.synchronize()
@@ -348,7 +351,8 @@ def main():
                        "parallelism": "single GPU" if world == 1 else "row-sharded tables (id %% %d) + data-parallel dense" % world,
                        "driver": ("single-GPU engine" if not sharded else (driver_note or (args.driver + (" (C++ step driver over RCCL)" if args.driver == "native" else " (torch.distributed orchestration)")))),
                        "ids": "uniform" if args.uniform_ids else "zipf",
-                       "next_batch_hint": bool(not sharded and os.environ.get("DCTR_BENCH_PREFETCH", "1") == "1")},
+                       "next_batch_hint": bool(not sharded and os.environ.get("DCTR_BENCH_PREFETCH", "1") == "1"),
+                       "table_sweep_period": (args.sweep_period or int(os.environ.get("DCTR_SWEEP_PERIOD", "8"))) if (not sharded and args.table_mode == "dense_exact") else 1},
         }
         # ---- per-stage timing (hipEvents around a graph of back-to-back launches, on torch's current stream)
         e = eng

@@ -120,6 +120,14 @@ typedef struct dctr_config {
     int32_t n_att_pairs;
     int32_t att_user_slot[8];
     int32_t att_ad_slot[8];
+    /* dense_exact tables under Adam: period N of the TIME-BLOCKED table sweep (csrc/lag.h).  TF's Adam steps every table row every
+     * step because l2_loss(table) is in the loss (DeepFM.py:188-190); a row no batch touches follows a recurrence that needs
+     * nothing the step computes, so it may lag: each step the background sweep advances 1/N of the table, and a row is advanced
+     * through the steps it missed -- the same update calls with the same per-step lr_t, in order -- by whoever reads it next
+     * (the gather, the touched-rows step, a flush before predict / eval / parameter reads / a loss-reporting step).  Results are
+     * those of the classic sweep, row for row; the table step's HBM traffic drops N-fold.  0 = the library's default
+     * (DCTR_SWEEP_PERIOD, else 8), 1 = the classic sweep of every row every step; at most 24. */
+    int32_t table_sweep_period;
 } dctr_config;
 
 typedef struct dctr_engine* dctr_handle;
@@ -368,6 +376,11 @@ int dctr_input_slot(dctr_handle h, int slot, int32_t** d_ids, float** d_vals, fl
  * batch will not be trained).  dctr_input_slot_rewrite is safe to call from the input pipeline's thread. */
 int dctr_prefetch_ids(dctr_handle h, const int32_t* d_ids_next, int B);
 int dctr_prefetch_cancel(dctr_handle h);
+/* time-blocked table sweep (dctr_config.table_sweep_period > 1): advances every lagging table row to global_step, on `stream`.
+ * Implied by every entry point that reads the tables as a whole (predict, eval, parameter / slot access, a train step that reports
+ * its loss); a no-op when no row lags.  A benchmark calls it at the end of its timed region so that every update of the timed
+ * steps has been computed inside it. */
+int dctr_tables_sync(dctr_handle h, void* stream);
 int dctr_input_slot_rewrite(dctr_handle h, int slot);
 /* canned-estimator models: the dense (numeric-column) inputs [B, dense_size] f32 of the NEXT train/predict/eval call; the
  * buffer is read in place and must stay valid until that call's work has finished */

@@ -1,0 +1,127 @@
+"""Time-blocked dense-exact table sweep (csrc/lag.h, dctr_config.table_sweep_period): rows no batch touches may lag behind
+global_step and are advanced through the steps they missed -- the same Adam update calls with the same per-step lr_t, in order --
+when something reads them.  The scheme changes WHEN a row's updates are computed, never what they are, so a lagging engine must
+end where the classic one (every row every step, period 1) ends: compared here element for element at 1e-6 -- what two runs of the
+SAME engine differ by (the hot ids' segment sums meet through float atomics in no fixed order); a missed, doubled or mis-stamped
+step would show as ~lr = 1e-2 -- and against the oracle's dense Adam (DeepFM.py:188-190,204-213) at the usual 2e-6."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import deepctr_oracle as O
+from tests.util import dev_batch
+from tf_repos_amd import errors
+from tf_repos_amd.engine import Engine, EngineConfig
+
+pytestmark = pytest.mark.gpu
+
+
+def engine(model, period, V, B, K=8, layers=(32, 16), F=39, seed=5, l2=1e-3, lr=1e-2, keep=None, params=None, cross=2):
+    keep = keep or tuple(1.0 for _ in layers)
+    eng = Engine(EngineConfig(model=model, field_size=F, feature_size=V, embedding_size=K, deep_layers=layers, dropout=keep, cross_layers=cross,
+                              l2_reg=l2, learning_rate=lr, optimizer="Adam", max_batch=B, seed=seed, table_sweep_period=period))
+    if params is not None:
+        eng.set_params(params)
+    return eng
+
+
+def state_of(eng):
+    out = dict(eng.get_params())
+    for name in ("emb", "linear"):
+        if name in eng.param_shapes:
+            out[name + "/m"], out[name + "/v"] = eng.get_slot(name, 0), eng.get_slot(name, 1)
+    return out
+
+
+@pytest.mark.parametrize("model", ["deepfm", "dcn", "nfm"])
+@pytest.mark.parametrize("period", [2, 5, 8])
+def test_lagging_rows_end_where_the_classic_sweep_ends(model, period, dev):
+    """30 steps, most of them without a loss read (rows lag up to `period` steps), with a loss-reporting step, a predict and a
+    parameter read in the middle (each brings the rows to the present), a short last batch, dropout on: classic == lagging."""
+    F, V, B, K = 39, 20000, 192, 8
+    ocfg = O.Config(model=model, field_size=F, feature_size=V, embedding_size=K, deep_layers=(32, 16), dropout=(0.8, 0.8), cross_layers=2,
+                    l2_reg=1e-3, learning_rate=1e-2, optimizer="Adam")
+    params = O.init_params(ocfg, seed=2, scale=0.05)
+    runs = []
+    for p in (1, period):
+        eng = engine(model, p, V, B, params=params, keep=(0.8, 0.8))
+        losses = []
+        for step in range(30):
+            b = B if step != 17 else 77
+            ids, vals, labels = O.synth_batch(b, F, V, seed=900 + step)
+            want = step in (0, 11, 29)
+            losses.append(eng.train_step(*dev_batch(ids, vals, labels, dev), want_loss=want))
+            if step == 20:
+                pr = torch.empty(b, device=dev)
+                eng.predict(*dev_batch(ids, vals, labels, dev)[:2], pr)
+                losses.append(float(pr.sum()))
+            if step == 23:
+                losses.append(float(np.abs(eng.get_param("emb")).sum()))
+        runs.append((losses, state_of(eng), eng.global_step))
+        eng.close()
+    assert runs[0][2] == runs[1][2] == 30
+    for a, b_ in zip(runs[0][0], runs[1][0]):
+        assert (a is None) == (b_ is None)
+        if a is not None:
+            assert abs(a - b_) <= 1e-6 * max(1.0, abs(a)), (a, b_)
+    for k, v in runs[0][1].items():
+        assert np.abs(v - runs[1][1][k]).max() <= 1e-6, k
+
+
+def test_lagging_rows_match_the_oracle(dev):
+    """12 steps with no loss read at all, then every variable against the oracle's dense Adam over all rows"""
+    F, V, B, K = 39, 6000, 128, 8
+    ocfg = O.Config(model="deepfm", field_size=F, feature_size=V, embedding_size=K, deep_layers=(32, 16), dropout=(1.0, 1.0), l2_reg=1e-3,
+                    learning_rate=1e-2, optimizer="Adam")
+    params = O.init_params(ocfg, seed=4, scale=0.05)
+    eng = engine("deepfm", 8, V, B, params=params)
+    oopt = O.Optimizer(ocfg, params)
+    for step in range(12):
+        ids, vals, labels = O.synth_batch(B, F, V, seed=950 + step)
+        O.train_step(ocfg, params, oopt, ids, vals, labels)
+        eng.train_step(*dev_batch(ids, vals, labels, dev), want_loss=False)
+    got = eng.get_params()
+    for name, ref in params.items():
+        assert np.abs(got[name] - ref.numpy()).max() <= 2e-6, name
+    for name in ("emb", "linear"):
+        assert np.abs(eng.get_slot(name, 0) - oopt.slots[name]["m"].numpy()).max() <= 2e-6, name
+        assert np.abs(eng.get_slot(name, 1) - oopt.slots[name]["v"].numpy()).max() <= 2e-6, name
+    # a loss read after lagging steps: the l2 term covers the whole table as of the step
+    ids, vals, labels = O.synth_batch(B, F, V, seed=990)
+    ref_loss, _ = O.train_step(ocfg, params, oopt, ids, vals, labels)
+    loss = eng.train_step(*dev_batch(ids, vals, labels, dev))
+    assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+    eng.close()
+
+
+def test_restored_global_step_and_written_parameters(dev):
+    """set_global_step and set_param in the middle of training: rows are stamped relative to global_step and a written table is
+    taken as of the present.  (At step 300 with five steps of history Adam moves every element ~0.03 per step -- lr_t is no longer
+    bias-corrected down while v is still tiny -- and rounding noise grows with it: the yardstick is what two CLASSIC runs differ
+    by; a row advanced with a neighbouring step's lr_t would be off by ~2e-5, a missed step by ~3e-2.)"""
+    F, V, B, K = 39, 5000, 96, 8
+    ocfg = O.Config(model="deepfm", field_size=F, feature_size=V, embedding_size=K, deep_layers=(16,), dropout=(1.0,), l2_reg=1e-3,
+                    learning_rate=1e-2, optimizer="Adam")
+    params = O.init_params(ocfg, seed=6, scale=0.05)
+    runs = []
+    for p in (1, 1, 6):
+        eng = engine("deepfm", p, V, B, layers=(16,), params=params)
+        for step in range(14):
+            ids, vals, labels = O.synth_batch(B, F, V, seed=1000 + step)
+            eng.train_step(*dev_batch(ids, vals, labels, dev), want_loss=False)
+            if step == 4:
+                eng.global_step = 300                    # a restored checkpoint's step (255 < 300: the stamps wrap)
+            if step == 9:
+                eng.set_param("linear", np.full((V,), 0.01, np.float32))
+        runs.append(state_of(eng))
+        assert eng.global_step == 309
+        eng.close()
+    noise = max(float(np.abs(v - runs[1][k]).max()) for k, v in runs[0].items())
+    worst = max(float(np.abs(v - runs[2][k]).max()) for k, v in runs[0].items())
+    print("classic vs classic %.3g, classic vs lagging %.3g" % (noise, worst))
+    assert worst <= max(3e-6, 3 * noise), (worst, noise)
+
+
+def test_period_is_validated(dev):
+    with pytest.raises(errors.InvalidArgumentError):
+        engine("deepfm", 99, 1000, 16)

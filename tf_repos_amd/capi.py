@@ -43,6 +43,7 @@ class Config(C.Structure):
         ("use_graph", C.c_int32), ("dense_size", C.c_int32), ("lin_optimizer", C.c_int32),
         ("lin_learning_rate", C.c_float), ("loss_sum", C.c_int32), ("max_entries", C.c_int32), ("ctr_task_wgt", C.c_float),
         ("n_att_pairs", C.c_int32), ("att_user_slot", C.c_int32 * 8), ("att_ad_slot", C.c_int32 * 8),
+        ("table_sweep_period", C.c_int32),
     ]
 
 
@@ -120,6 +121,7 @@ _SIGS = {
     "dctr_parse_csv_mt": ([_P, C.c_size_t, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int64)], C.c_int),
     "dctr_prefetch_ids": ([_P, _P, C.c_int], C.c_int),
     "dctr_prefetch_cancel": ([_P], C.c_int),
+    "dctr_tables_sync": ([_P, _P], C.c_int),
     "dctr_input_slot_rewrite": ([_P, C.c_int], C.c_int),
     "dctr_crc32c": ([C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint32)], C.c_int),
     "dctr_tfrecord_scan": ([C.c_char_p, C.c_size_t, C.c_int64, C.c_int, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_size_t)], C.c_int),

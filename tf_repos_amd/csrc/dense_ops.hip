@@ -972,6 +972,7 @@ __global__ void step_state_kernel(StepState* s, float* zero, int n_zero) {
         h.lr_t = (float)((double)h.lr * sqrt(1.0 - pow((double)h.beta2, t)) / (1.0 - pow((double)h.beta1, t)));
     }
     s->seed_t = s->seed ^ ((uint64_t)s->t * STEP_SEED_MULT);
+    s->lr_hist[s->t & (LR_HIST - 1)] = s->hyper.lr_t;
 }
 
 // the NEXT step's state from the current one, into a second StepState (and a second set of loss scalars, zeroed): launched under
@@ -987,6 +988,7 @@ __global__ void step_state_next_kernel(const StepState* __restrict__ cur, StepSt
         h.lr_t = (float)((double)h.lr * sqrt(1.0 - pow((double)h.beta2, t)) / (1.0 - pow((double)h.beta1, t)));
     }
     s.seed_t = s.seed ^ ((uint64_t)s.t * STEP_SEED_MULT);
+    s.lr_hist[s.t & (LR_HIST - 1)] = s.hyper.lr_t;
     *nxt = s;
 }
 

@@ -59,6 +59,12 @@ struct dctr_engine {
 
     // tables
     float *emb = nullptr, *emb_s0 = nullptr, *emb_s1 = nullptr, *lin = nullptr, *lin_s0 = nullptr, *lin_s1 = nullptr;
+    // time-blocked dense-exact sweep (lag.h): rows may lag behind global_step; row_ts stamps how far each has been advanced
+    uint8_t* row_ts = nullptr;
+    int lag_period = 1;             // 1 = classic sweep (every row every step)
+    bool lag_suspended = false;     // dctr_time_kernel's single-stage replays do not advance global_step: they run the classic kernels
+    bool lag_dirty = false;         // some rows may be behind the present: lag_flush before anything reads the tables as a whole
+    bool want_loss = false;         // the step being enqueued reports its loss (needs sum theta^2 of every row)
     Group* group = nullptr;
     Group* group_alt = nullptr;     // second grouping state: owner side of the row-sharded path / the NEXT batch's ids grouped ahead
     // dctr_prefetch_ids: group_alt holds the grouping of `pre_ids` (an input slot), enqueued on s_group behind ev_tail

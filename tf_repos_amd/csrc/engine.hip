@@ -16,6 +16,7 @@
 #include <functional>
 
 #include "engine.h"
+#include "lag.h"
 
 using namespace dctr;
 
@@ -251,6 +252,16 @@ int build(dctr_engine* E) {
         DCTR_TRY(dmalloc(&E->lin_s0, (size_t)E->rows));
         DCTR_TRY(dmalloc(&E->lin_s1, (size_t)E->rows));
     }
+    // time-blocked dense-exact sweep (lag.h): Adam on the engine's own unsharded tables, eager steps, fixed-field batches
+    {
+        int period = c.table_sweep_period;
+        if (period == 0) { const char* v = getenv("DCTR_SWEEP_PERIOD"); period = v ? atoi(v) : 8; }
+        DCTR_REQUIRE(period >= 1 && period <= LAG_MAX_PERIOD, "table_sweep_period %d outside [1, %d]", period, LAG_MAX_PERIOD);
+        const bool can = c.table_mode == DCTR_TABLE_DENSE_EXACT && c.optimizer == DCTR_OPT_ADAM && !E->wnd && !E->csr && c.shard_world == 1 &&
+                         !c.use_graph;
+        E->lag_period = can ? period : 1;
+        if (E->lag_period > 1) DCTR_TRY(dmalloc(&E->row_ts, (size_t)E->rows));
+    }
     // owner side may receive rows from every rank; CSR models group up to max_entries ids per step
     DCTR_TRY(group_create(E->rows, E->csr ? E->max_entries : (int64_t)MB * F * c.shard_world, K, &E->group));
 
@@ -484,12 +495,12 @@ int build(dctr_engine* E) {
 // ---- forward (train=true: dropout on, DeepFM.py:161-162) ------------------------------------------------
 // the gather reads (emb, lin, rows, ids): the engine's own tables, or -- in the row-sharded path -- the buffer of rows
 // received from their owners with ids = positions in that buffer
-int gather_from(dctr_engine* E, const float* emb, const float* lin, int64_t rows, const int32_t* ids, int B, hipStream_t st) {
+int gather_from(dctr_engine* E, const float* emb, const float* lin, int64_t rows, const int32_t* ids, int B, hipStream_t st, const LagView* lag = nullptr) {
     const int F = E->F, K = E->K;
     const int mode = gather_mode(E);
     float* red = mode == DCTR_GATHER_FM ? E->yv : (mode == DCTR_GATHER_BI ? E->x_in : nullptr);
     DCTR_TRY(embed_gather_fwd(emb, lin, rows, ids, E->vals, B, F, K, mode, E->e, E->e_ld, lin ? E->yw : nullptr,
-                              E->S, red, E->status, st));
+                              E->S, red, E->status, st, lag));
     if (E->wnd && E->n_dense > 0)       // numeric columns: appended to the DNN input, and their linear_model term added to y_w
         DCTR_TRY(wnd_dense_fwd(E->dense, E->n_dense, E->p_lin_dense >= 0 ? E->pp(E->p_lin_dense) : nullptr, B,
                                E->wnd_deep ? E->x_in : nullptr, E->Din_ld, E->D, E->yw, st));
@@ -538,6 +549,21 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::f
 }
 
 int forward_gather(dctr_engine* E, int B, hipStream_t st) { return gather_from(E, E->emb, E->lin, E->rows, E->ids, B, st); }
+
+// the gather of a TRAINING step whose table rows may lag (lag.h): the step's state (t, lr history) must be in place on `st`.
+// A step that reports its loss first brings every row to t-1 -- its l2 term needs sum theta^2 over the whole table, which the
+// flush accumulates.
+int forward_gather_train(dctr_engine* E, int B, hipStream_t st);
+int lag_flush_tables(dctr_engine* E, hipStream_t st, int offset, bool with_sums);
+bool lag_on(const dctr_engine* E);
+LagView lag_view(const dctr_engine* E);
+
+int forward_gather_train(dctr_engine* E, int B, hipStream_t st) {
+    if (!lag_on(E)) return forward_gather(E, B, st);
+    if (E->want_loss) DCTR_TRY(lag_flush_tables(E, st, -1, true));
+    const LagView L = lag_view(E);
+    return gather_from(E, E->emb, E->lin, E->rows, E->ids, B, st, &L);
+}
 
 int forward(dctr_engine* E, int B, bool train, hipStream_t st) {
     DCTR_TRY(forward_gather(E, B, st));
@@ -756,16 +782,36 @@ bool tail_fused(const dctr_engine* E) {
     return !off && !E->wnd && E->cfg.shard_world == 1 && (split_table_on(E) || E->cfg.table_mode != DCTR_TABLE_DENSE_EXACT);
 }
 
+// time-blocked sweep (lag.h): is this handle's table allowed to lag in training steps?
+bool lag_on(const dctr_engine* E) { return E->lag_period > 1 && !E->lag_suspended && split_table_on(E) && tail_fused(E); }
+LagView lag_view(const dctr_engine* E) {
+    return LagView{E->row_ts, E->state, reinterpret_cast<float4*>(E->emb_s0), reinterpret_cast<float4*>(E->emb_s1), E->lin_s0, E->lin_s1, E->cfg.l2_reg};
+}
+// every row to step state->t + offset (0: the present, between steps; -1: inside a step whose state has already advanced);
+// with_sums: sum theta^2 of all rows (at that step) into the step's loss scalars
+int lag_flush_tables(dctr_engine* E, hipStream_t st, int offset, bool with_sums) {
+    if (E->lag_period <= 1) return DCTR_OK;
+    if (!E->lag_dirty && !with_sums) return DCTR_OK;
+    DCTR_TRY(lag_flush(E->K, E->rows, E->emb, E->emb_s0, E->emb_s1, E->lin, E->lin_s0, E->lin_s1, E->row_ts, E->state, E->cfg.l2_reg, offset,
+                       with_sums ? E->scalars + SUMSQ_SHARDS : nullptr, (with_sums && E->lin) ? E->scalars + 2 * SUMSQ_SHARDS : nullptr, st));
+    E->lag_dirty = false;
+    return DCTR_OK;
+}
+
 // ---- table side of the backward: segment-sum the row gradients (ids already grouped), step the tables ------------
 int scatter_and_step_tables(dctr_engine* E, int B, hipStream_t st, hipStream_t st_lin = nullptr, int pass = OPT_PASS_ALL) {
     const dctr_config& c = E->cfg;
     const int mode = gather_mode(E);
     const float* dE = mode == DCTR_GATHER_BI ? nullptr : E->dE;
     const float* coef = mode == DCTR_GATHER_FM ? E->dy : (mode == DCTR_GATHER_BI ? E->dx_in : nullptr);
-    if (tail_fused(E) && (pass == OPT_PASS_TOUCHED || c.table_mode != DCTR_TABLE_DENSE_EXACT))
+    if (tail_fused(E) && (pass == OPT_PASS_TOUCHED || c.table_mode != DCTR_TABLE_DENSE_EXACT)) {
+        const bool lag = lag_on(E) && pass == OPT_PASS_TOUCHED;
+        // (lagging rows: sum theta^2 of the visited rows alone means nothing -- a loss-reporting step takes it from the flush)
         return embed_scatter_apply(E->group, c.optimizer, &E->state->hyper, E->h_state.hyper, E->emb, E->emb_s0, E->emb_s1, E->lin, E->lin_s0,
-                                   E->lin_s1, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, dE, E->dE_ld, E->e, E->e_ld,
-                                   E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F, E->K, mode, st);
+                                   E->lin_s1, c.l2_reg, lag ? nullptr : E->scalars + SUMSQ_SHARDS, lag ? nullptr : E->scalars + 2 * SUMSQ_SHARDS,
+                                   dE, E->dE_ld, E->e, E->e_ld, E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F, E->K, mode, st, 1, nullptr,
+                                   lag ? E->row_ts : nullptr, lag ? E->state : nullptr);
+    }
     DCTR_TRY(embed_scatter_bwd(E->group, dE, E->dE_ld, E->e, E->e_ld, E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F,
                                E->K, mode, E->group->gemb, E->lin ? E->group->glin : nullptr, st));
     if (pass == OPT_PASS_TOUCHED) st_lin = nullptr;     // the touched-rows kernel steps the linear weights in the same launch
@@ -782,6 +828,11 @@ int scatter_and_step_tables(dctr_engine* E, int B, hipStream_t st, hipStream_t s
 // their optimizer step (90 % of the table pass) runs right after the grouping, under the MLP GEMMs, instead of at the end
 int step_untouched_rows(dctr_engine* E, hipStream_t st) {
     const dctr_config& c = E->cfg;
+    if (lag_on(E) && !E->csr) {       // one block of the table per step, its rows advanced through every step they missed (lag.h)
+        E->lag_dirty = true;
+        return lag_sweep(E->K, E->rows, E->emb, E->emb_s0, E->emb_s1, E->lin, E->lin_s0, E->lin_s1, E->group->slot, E->row_ts, E->state,
+                         c.l2_reg, E->lag_period, st);
+    }
     return opt_table(c.optimizer, &E->state->hyper, E->h_state.hyper, c.table_mode, E->rows, E->K, E->emb, E->emb_s0, E->emb_s1,
                      E->lin, E->lin_s0, E->lin_s1, E->group->slot, E->group->uniq, E->group->counters, E->group->max_entries,
                      E->group->gemb, E->group->glin, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, st, nullptr,
@@ -847,10 +898,10 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
         std::swap(E->state, E->state_alt);
         std::swap(E->scalars, E->scalars_alt);
         E->state_ready = false;
-        DCTR_TRY(forward_gather(E, B, st));
-    } else if (state_on_main) {
+        DCTR_TRY(forward_gather_train(E, B, st));
+    } else if (state_on_main || lag_on(E)) {
         DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, st));
-        DCTR_TRY(forward_gather(E, B, st));
+        DCTR_TRY(forward_gather_train(E, B, st));
     } else {
         DCTR_TRY(fork(E, st, sw));
         DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, sw));
@@ -1049,6 +1100,7 @@ int dctr_destroy(dctr_handle E) {
     if (E->eval_scalars) hipFree(E->eval_scalars);
     if (E->ones) hipFree(E->ones);
     if (E->group_alt) group_destroy(E->group_alt);
+    if (E->row_ts) hipFree(E->row_ts);
     if (E->xmvm) hipFree(E->xmvm);
     if (E->dxmvm) hipFree(E->dxmvm);
     for (auto& ev : E->timer_ev) if (ev) hipEventDestroy(ev);
@@ -1091,6 +1143,10 @@ static int copy_param(dctr_handle E, const char* name, int which, void* host, si
     float* d = which < 0 ? p->ptr : (which == 0 ? p->s0 : p->s1);
     DCTR_REQUIRE(d != nullptr, "parameter '%s' has no such slot", name);
     DCTR_HIP_CHECK(hipDeviceSynchronize());
+    if (p->is_table && E->lag_dirty) {           // lagging rows (lag.h): the table as of global_step is what is read -- and what a write replaces
+        DCTR_TRY(lag_flush_tables(E, nullptr, 0, false));
+        DCTR_HIP_CHECK(hipDeviceSynchronize());
+    }
     if (to_device) DCTR_HIP_CHECK(hipMemcpy(d, host, nbytes, hipMemcpyHostToDevice));
     else DCTR_HIP_CHECK(hipMemcpy(host, d, nbytes, hipMemcpyDeviceToHost));
     return DCTR_OK;
@@ -1112,6 +1168,11 @@ int dctr_param_device_ptr(dctr_handle E, const char* name, float** d_ptr) {
     DCTR_REQUIRE(E && d_ptr, "null argument");
     Param* p = find_param(E, name);
     if (!p) return DCTR_ERR_NOT_FOUND;
+    if (p->is_table && E->lag_dirty) {
+        DCTR_HIP_CHECK(hipDeviceSynchronize());
+        DCTR_TRY(lag_flush_tables(E, nullptr, 0, false));
+        DCTR_HIP_CHECK(hipDeviceSynchronize());
+    }
     *d_ptr = p->ptr;
     return DCTR_OK;
 }
@@ -1119,9 +1180,17 @@ int dctr_param_device_ptr(dctr_handle E, const char* name, float** d_ptr) {
 int dctr_set_global_step(dctr_handle E, int64_t step) {
     DCTR_REQUIRE(E && step >= 0, "bad argument");
     DCTR_HIP_CHECK(hipDeviceSynchronize());
+    if (E->lag_period > 1) {                // rows are stamped relative to global_step: bring them to the present under the old one,
+        DCTR_TRY(lag_flush_tables(E, nullptr, 0, false));
+        DCTR_HIP_CHECK(hipDeviceSynchronize());
+    }
     E->h_state.t = step;
     E->state_ready = false;                 // a state prepared ahead was derived from the old global_step
     DCTR_HIP_CHECK(hipMemcpy(&E->state->t, &step, sizeof(step), hipMemcpyHostToDevice));
+    if (E->lag_period > 1) {                // ... and stamp them with the new one
+        DCTR_TRY(lag_stamp(E->row_ts, E->rows, E->state, nullptr));
+        DCTR_HIP_CHECK(hipDeviceSynchronize());
+    }
     return DCTR_OK;
 }
 int dctr_get_global_step(dctr_handle E, int64_t* step) {
@@ -1137,6 +1206,7 @@ int dctr_train_step(dctr_handle E, const int32_t* d_ids, const float* d_vals, co
     DCTR_REQUIRE(!E->csr, "this handle's model takes CSR batches (dctr_train_step_csr)");
     hipStream_t st = as_stream(stream);
     DCTR_TRY(stage_inputs(E, d_ids, d_vals, d_labels, B, st));
+    E->want_loss = h_loss != nullptr;
     DCTR_TRY(run_graph(E, E->train_graphs, B, true, st));
     E->last_B = B;
     if (h_loss) {
@@ -1167,6 +1237,11 @@ int dctr_prefetch_ids(dctr_handle E, const int32_t* d_ids_next, int B) {
     return DCTR_OK;
 }
 
+int dctr_tables_sync(dctr_handle E, void* stream) {
+    DCTR_REQUIRE(E, "null argument");
+    return lag_flush_tables(E, as_stream(stream), 0, false);
+}
+
 int dctr_prefetch_cancel(dctr_handle E) {
     DCTR_REQUIRE(E, "null argument");
     E->pre_valid = false;
@@ -1184,6 +1259,7 @@ int dctr_predict(dctr_handle E, const int32_t* d_ids, const float* d_vals, int B
     DCTR_REQUIRE(!E->csr, "this handle's model takes CSR batches (dctr_predict_csr)");
     hipStream_t st = as_stream(stream);
     DCTR_TRY(stage_inputs(E, d_ids, d_vals, nullptr, B, st));
+    DCTR_TRY(lag_flush_tables(E, st, 0, false));        // (lagging rows, lag.h: the forward reads the tables as they are NOW)
     DCTR_TRY(run_graph(E, E->predict_graphs, B, false, st));
     E->last_B = B;
     if (d_prob) DCTR_HIP_CHECK(hipMemcpyAsync(d_prob, E->prob, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
@@ -1387,6 +1463,7 @@ int dctr_eval_batch(dctr_handle E, const int32_t* d_ids, const float* d_vals, co
     DCTR_REQUIRE(E && d_ids && d_vals && d_labels, "null argument");
     hipStream_t st = as_stream(stream);
     DCTR_TRY(stage_inputs(E, d_ids, d_vals, d_labels, B, st));
+    DCTR_TRY(lag_flush_tables(E, st, 0, false));
     DCTR_TRY(forward(E, B, false, st));
     DCTR_TRY(head(E, B, B, true, st, E->eval_scalars));      // dy is written too (unused in EVAL)
     DCTR_TRY(dctr_auc_update(E->labels, E->prob, B, E->auc_counts, stream));
@@ -1401,6 +1478,7 @@ int dctr_eval_result(dctr_handle E, float* h_auc, float* h_loss, int64_t* h_exam
     if (h_auc) DCTR_TRY(dctr_auc_result(E->auc_counts, h_auc, stream));
     if (h_loss) {
         // loss of DeepFM.py:188-190 over the eval set: mean xent + l2_reg * sum l2_loss(regularised variables)
+        DCTR_TRY(lag_flush_tables(E, st, 0, false));
         DCTR_HIP_CHECK(hipMemsetAsync(E->eval_scalars + SUMSQ_SHARDS, 0, sizeof(float), st));
         for (auto& p : E->params)
             if (p.l2 != 0.f) sumsq_kernel<<<256, 256, 0, st>>>(p.ptr, p.n, E->eval_scalars + SUMSQ_SHARDS);
@@ -1643,6 +1721,8 @@ int dctr_time_kernel(dctr_handle E, const char* kernel, int iters, float* h_ms_p
     const dctr_config& c = E->cfg;
     // the stages are captured once and REPLAYED: a grouping in them must not rely on what this enqueue knows about the slot words
     E->group->slots_clean = false;
+    DCTR_TRY(lag_flush_tables(E, st, 0, false));       // (lagging rows: the classic stages below assume every row is current)
+    E->lag_suspended = s != "train_step";              // (a replayed single stage does not advance global_step: classic kernels)
     auto stage = [&](hipStream_t cs) -> int {
         if (s == "embed_gather") {
             const int mode = gather_mode(E);
@@ -1695,6 +1775,7 @@ int dctr_time_kernel(dctr_handle E, const char* kernel, int iters, float* h_ms_p
     for (int i = 0; i < iters && rc == DCTR_OK; ++i) rc = stage(cs);
     hipError_t e = hipStreamEndCapture(cs, &graph);
     hipStreamDestroy(cs);
+    E->lag_suspended = false;
     if (rc != DCTR_OK) { if (graph) hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess) { set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return DCTR_ERR_HIP; }
     hipGraphExec_t exec = nullptr;
@@ -1714,6 +1795,11 @@ int dctr_time_kernel(dctr_handle E, const char* kernel, int iters, float* h_ms_p
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipGraphExecDestroy(exec);
     *h_ms_per_launch = ms / (float)iters;
+    if (E->lag_period > 1) {        // whatever the stages did to the tables: every row counts as current from here on
+        DCTR_TRY(lag_stamp(E->row_ts, E->rows, E->state, st));
+        DCTR_HIP_CHECK(hipStreamSynchronize(st));
+        E->lag_dirty = false;
+    }
     if (s == "scatter" && !E->group->gemb_clean) {      // the plain scatter wrote compact rows: back to the fused tail's all-zero invariant
         DCTR_HIP_CHECK(hipMemsetAsync(E->group->gemb, 0, (size_t)E->group->max_entries * E->group->K * 4, st));
         DCTR_HIP_CHECK(hipStreamSynchronize(st));

@@ -7,15 +7,18 @@
 // lane keeps ~F/FS independent 16-byte row loads in flight and the per-example reductions over the
 // fields are register-local plus log2(FS) cross-lane steps.  No LDS: nothing is reused across lanes.
 #include "common.h"
+#include "lag.h"
 
 namespace dctr {
 
-template <int KQ, int FS, int MODE, int U>
+// LAG: rows may lag behind the present (lag.h): a gathered row stamped earlier than step t-1 is advanced to t-1 in registers
+// (its Adam slots are read for that; nothing is written back -- the touched-rows step of this batch redoes it and stores)
+template <int KQ, int FS, int MODE, int U, bool LAG>
 __global__ __launch_bounds__(256) void gather_fwd_kernel(
     const float4* __restrict__ emb, const float* __restrict__ lin, int64_t rows, int emb_ld4, int lin_ld,
     const int32_t* __restrict__ ids, const float* __restrict__ vals, int B, int F,
     float* __restrict__ e_out, int e_ld, float* __restrict__ yw_out, float* __restrict__ sum_out,
-    float* __restrict__ red_out, int32_t* __restrict__ status) {
+    float* __restrict__ red_out, int32_t* __restrict__ status, LagView L) {
     constexpr int TPE = KQ * FS;           // lanes per example (power of two, <= 64)
     constexpr int EPB = 256 / TPE;         // examples per block
     const int tid = threadIdx.x;
@@ -38,6 +41,7 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(
             float v[U];
             float4 r[U];
             float w[U];
+            int nlag[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int f = f0 + u * FS;
@@ -54,6 +58,25 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(
                 }
                 r[u] = ok ? emb[(size_t)id[u] * emb_ld4 + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
                 w[u] = (ok && lin != nullptr && kq == 0) ? lin[(size_t)id[u] * lin_ld] : 0.f;
+                if (LAG) nlag[u] = ok ? lag_behind(L.state->t - 1, L.ts[id[u]]) : 0;
+            }
+            if (LAG) {
+                float4 m[U], vv[U];
+                float lm[U], lv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)          // (loads only: the U rows' slot reads overlap)
+                    if (nlag[u] > 0) {
+                        m[u] = L.s0[(size_t)id[u] * KQ + kq]; vv[u] = L.s1[(size_t)id[u] * KQ + kq];
+                        if (lin != nullptr && kq == 0) { lm[u] = L.l0[id[u]]; lv[u] = L.l1[id[u]]; }
+                    }
+                const Hyper hh = L.state->hyper;
+                const int64_t Tm1 = L.state->t - 1;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (nlag[u] > 0) {
+                        lag_catch_up4(L.state, hh, L.l2, Tm1 - nlag[u] + 1, nlag[u], r[u], m[u], vv[u]);
+                        if (lin != nullptr && kq == 0) lag_catch_up1(L.state, hh, L.l2, Tm1 - nlag[u] + 1, nlag[u], w[u], lm[u], lv[u]);
+                    }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -101,24 +124,23 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(
 template <int KQ, int FS, int U = 4>
 static int launch_gather(const float* emb, const float* lin, int64_t rows, int emb_ld, int lin_ld, const int32_t* ids,
                          const float* vals, int B, int F, int mode, float* e, int e_ld, float* yw,
-                         float* sum, float* red, int32_t* status, hipStream_t st) {
+                         float* sum, float* red, int32_t* status, hipStream_t st, const LagView* lag) {
     constexpr int EPB = 256 / (KQ * FS);
     dim3 grid(ceil_div(B, EPB)), block(256);
     const float4* emb4 = reinterpret_cast<const float4*>(emb);
+    const LagView L = lag ? *lag : LagView{};
+#define DCTR_GK(MODE_)                                                                                                                  \
+    if (lag) gather_fwd_kernel<KQ, FS, MODE_, U, true><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status, L); \
+    else gather_fwd_kernel<KQ, FS, MODE_, U, false><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status, L)
     switch (mode) {
-        case DCTR_GATHER_RAW:
-            gather_fwd_kernel<KQ, FS, DCTR_GATHER_RAW, U><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status);
-            break;
-        case DCTR_GATHER_FM:
-            gather_fwd_kernel<KQ, FS, DCTR_GATHER_FM, U><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status);
-            break;
-        case DCTR_GATHER_BI:
-            gather_fwd_kernel<KQ, FS, DCTR_GATHER_BI, U><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status);
-            break;
+        case DCTR_GATHER_RAW: DCTR_GK(DCTR_GATHER_RAW); break;
+        case DCTR_GATHER_FM: DCTR_GK(DCTR_GATHER_FM); break;
+        case DCTR_GATHER_BI: DCTR_GK(DCTR_GATHER_BI); break;
         default:
             set_error("gather: bad mode %d", mode);
             return DCTR_ERR_INVALID_ARG;
     }
+#undef DCTR_GK
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }
@@ -127,7 +149,8 @@ static int launch_gather(const float* emb, const float* lin, int64_t rows, int e
 // [row | linear weight | pad] buffer of rows received from their owners in the row-sharded path
 int embed_gather_strided(const float* emb, int emb_ld, const float* lin, int lin_ld, int64_t rows, const int32_t* ids,
                      const float* vals, int B, int F, int K, int mode, float* e, int e_ld, float* yw,
-                     float* sum, float* red, int32_t* status, hipStream_t st) {
+                     float* sum, float* red, int32_t* status, hipStream_t st, const LagView* lag) {
+    DCTR_REQUIRE(lag == nullptr || (emb_ld == K && lin_ld == 1), "gather: lagging rows live in the engine's own tables");
     DCTR_REQUIRE(K % 4 == 0 && K >= 4 && K <= 256, "embedding_size must be a multiple of 4 in [4,256], got %d", K);
     DCTR_REQUIRE(emb_ld % 4 == 0 && emb_ld >= K && lin_ld >= 1, "gather: bad table strides emb_ld=%d lin_ld=%d", emb_ld, lin_ld);
     DCTR_REQUIRE(e_ld % 4 == 0 && e_ld >= F * K, "gather: e_ld=%d must be a multiple of 4 and >= F*K=%d", e_ld, F * K);
@@ -137,7 +160,7 @@ int embed_gather_strided(const float* emb, int emb_ld, const float* lin, int lin
     // lanes per example = KQ*FS; U = row loads in flight per lane.  FS*U is chosen >= 39 (Criteo's F) with one trip through the
     // field loop where it fits: the gather is a latency-bound random read, so what matters is how many 16-byte row pieces are in
     // flight (measured on c2, cache-resident table: <4,4,4> 6.2 us, <4,8,5> 5.2 us, <4,16,3> 5.7 us)
-#define DCTR_G(Q, FS_, U_) return launch_gather<Q, FS_, U_>(emb, lin, rows, emb_ld, lin_ld, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st)
+#define DCTR_G(Q, FS_, U_) return launch_gather<Q, FS_, U_>(emb, lin, rows, emb_ld, lin_ld, ids, vals, B, F, mode, e, e_ld, yw, sum, red, status, st, lag)
     switch (K / 4) {
         case 1:  DCTR_G(1, 16, 3);
         case 2:  DCTR_G(2, 8, 5);
@@ -161,8 +184,8 @@ int embed_gather_strided(const float* emb, int emb_ld, const float* lin, int lin
 }
 
 int embed_gather_fwd(const float* emb, const float* lin, int64_t rows, const int32_t* ids, const float* vals, int B, int F, int K,
-                     int mode, float* e, int e_ld, float* yw, float* sum, float* red, int32_t* status, hipStream_t st) {
-    return embed_gather_strided(emb, K, lin, 1, rows, ids, vals, B, F, K, mode, e, e_ld, yw, sum, red, status, st);
+                     int mode, float* e, int e_ld, float* yw, float* sum, float* red, int32_t* status, hipStream_t st, const LagView* lag) {
+    return embed_gather_strided(emb, K, lin, 1, rows, ids, vals, B, F, K, mode, e, e_ld, yw, sum, red, status, st, lag);
 }
 
 }  // namespace dctr
@@ -172,5 +195,5 @@ extern "C" int dctr_embed_gather_fwd(const float* d_emb, const float* d_lin, int
                                      int mode, float* d_e, int e_ld, float* d_yw, float* d_sum,
                                      float* d_red, int32_t* d_status, void* stream) {
     return dctr::embed_gather_fwd(d_emb, d_lin, rows, d_ids, d_vals, B, F, K, mode, d_e, e_ld, d_yw,
-                                  d_sum, d_red, d_status, dctr::as_stream(stream));
+                                  d_sum, d_red, d_status, dctr::as_stream(stream), nullptr);
 }

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "ops.h"
 #include "opt_rules.h"
+#include "lag.h"
 
 namespace dctr {
 
@@ -478,11 +479,12 @@ struct TableStep {
     const int32_t* uniq;                        // distinct id u -> table row
     int32_t* slot;                              // the grouping's slot word of every visited row goes back to 0 (no group_reset pass)
     int32_t* done;                              // [U] completion tickets
+    uint8_t* ts; const StepState* state;        // lagging rows (lag.h; Adam): advanced to t-1 before this step's update, stamped t; nullptr = classic
 };
 
 // the row's pieces are LOADED as soon as the distinct id is known (before the gradient loads: one latency instead of two) and
 // stepped once the gradient sum is there
-struct RowRegs { float4 th, a, b; float lt, la, lb; int64_t r; };
+struct RowRegs { float4 th, a, b; float lt, la, lb; int64_t r; int nlag; };
 
 template <int KIND, int KQ>
 __device__ __forceinline__ RowRegs table_row_load(const TableStep& T, int u, int kq) {
@@ -493,6 +495,7 @@ __device__ __forceinline__ RowRegs table_row_load(const TableStep& T, int u, int
     R.th = T.emb[i4]; R.a = T.s0[i4]; R.b = TWO ? T.s1[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
     R.lt = R.la = R.lb = 0.f;
     if (kq == 0 && T.lin != nullptr) { R.lt = T.lin[R.r]; R.la = T.l0[R.r]; R.lb = TWO ? T.l1[R.r] : 0.f; }
+    R.nlag = (KIND == DCTR_OPT_ADAM && T.ts != nullptr) ? lag_behind(T.state->t - 1, T.ts[R.r]) : 0;
     return R;
 }
 
@@ -501,6 +504,11 @@ __device__ __forceinline__ void table_row_step(const TableStep& T, const Hyper& 
     constexpr bool TWO = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL);
     const size_t i4 = (size_t)R.r * KQ + kq;
     float4 th = R.th, a = R.a, b = R.b;
+    if (KIND == DCTR_OPT_ADAM && R.nlag > 0) {          // the steps no batch touched this row: replayed first (lag.h)
+        const int64_t first = T.state->t - R.nlag;
+        lag_catch_up4(T.state, h, T.l2, first, R.nlag, th, a, b);
+        if (kq == 0 && T.lin != nullptr) lag_catch_up1(T.state, h, T.l2, first, R.nlag, R.lt, R.la, R.lb);
+    }
     sq += th.x * th.x + th.y * th.y + th.z * th.z + th.w * th.w;
     float4 g = make_float4(T.l2 * th.x, T.l2 * th.y, T.l2 * th.z, T.l2 * th.w);
     g.x += gs.x; g.y += gs.y; g.z += gs.z; g.w += gs.w;
@@ -511,6 +519,7 @@ __device__ __forceinline__ void table_row_step(const TableStep& T, const Hyper& 
     T.emb[i4] = th; T.s0[i4] = a;
     if (TWO) T.s1[i4] = b;
     if (kq == 0) T.slot[R.r] = 0;
+    if (KIND == DCTR_OPT_ADAM && kq == 0 && T.ts != nullptr) T.ts[R.r] = (uint8_t)T.state->t;
     if (kq == 0 && T.lin != nullptr) {
         float lt = R.lt, la = R.la, lb = R.lb;
         sql += lt * lt;
@@ -728,15 +737,16 @@ static int launch_scatter_apply(Group* g, const float* dE, int de_ld, const floa
 int embed_scatter_apply(Group* g, int kind, const Hyper* hdev, const Hyper& hval, float* emb, float* e0, float* e1, float* lin,
                         float* l0, float* l1, float l2, float* sumsq_emb, float* sumsq_lin, const float* dE, int de_ld,
                         const float* e, int e_ld, const float* S, const float* coef, const float* dy, const float* vals, int B, int F,
-                        int K, int mode, hipStream_t st, int dy_ld, const int32_t* entry_row) {
+                        int K, int mode, hipStream_t st, int dy_ld, const int32_t* entry_row, uint8_t* lag_ts, const StepState* lag_state) {
     DCTR_REQUIRE(K == g->K, "scatter: K=%d but group was created with K=%d", K, g->K);
+    DCTR_REQUIRE(lag_ts == nullptr || (kind == DCTR_OPT_ADAM && lag_state != nullptr), "scatter_apply: lagging rows are an Adam-only scheme");
     DCTR_REQUIRE(g->gemb_clean, "scatter_apply: the group's compact gradient rows are not known to be zero");
     DCTR_REQUIRE(dE == nullptr || de_ld % 4 == 0, "scatter: de_ld must be a multiple of 4");
     DCTR_REQUIRE(mode == DCTR_GATHER_RAW || (e != nullptr && S != nullptr && coef != nullptr && e_ld % 4 == 0),
                  "scatter: FM/BI modes need e, S and coef");
     DCTR_REQUIRE((lin != nullptr) == (dy != nullptr), "scatter_apply: linear weights and their gradient source go together");
     TableStep T{reinterpret_cast<float4*>(emb), reinterpret_cast<float4*>(e0), reinterpret_cast<float4*>(e1), lin, l0, l1, hdev, hval,
-                l2, sumsq_emb, sumsq_lin, g->uniq, g->slot, g->done};
+                l2, sumsq_emb, sumsq_lin, g->uniq, g->slot, g->done, lag_ts, lag_state};
     g->slots_clean = true;                  // (every distinct id of the grouping is visited exactly once, and each visit clears its slot word)
 #define DCTR_Q(KD, Q) case Q: return launch_scatter_apply<KD, Q>(g, dE, de_ld, e, e_ld, S, coef, dy, vals, B, F, mode, dy_ld, st, entry_row, T)
 #define DCTR_KD(KD) case KD: switch (K / 4) { DCTR_Q(KD, 1); DCTR_Q(KD, 2); DCTR_Q(KD, 4); DCTR_Q(KD, 8); DCTR_Q(KD, 16); DCTR_Q(KD, 32); DCTR_Q(KD, 64); \

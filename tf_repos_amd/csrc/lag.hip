@@ -1,0 +1,147 @@
+// Time-blocked dense-exact table sweep: the background sweep over one block of the table per step, and the flush that brings
+// every row to the present.  See lag.h for the scheme; the row arithmetic is opt_update (opt_rules.h), call for call what
+// opt_table_untouched_kernel / opt_lin_dense_kernel (dense_ops.hip) apply to an untouched row in the classic sweep.
+#include "lag.h"
+
+namespace dctr {
+
+namespace {
+
+__device__ __forceinline__ float wave_sum_l(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// FLUSH = false: rows of block (t mod period) that the batch does not touch (slot word 0) advance to t.
+// FLUSH = true : every row advances to t + target_offset; sum theta^2 (at the target) goes to the sharded sums when asked for.
+// KQ lanes per row (a float4 piece each, lane kq == 0 also carries the row's linear weight), UNR rows in flight per lane.
+template <int KQ, bool FLUSH, int UNR>
+__global__ __launch_bounds__(256) void lag_advance_kernel(int64_t rows, float4* __restrict__ emb, float4* __restrict__ s0, float4* __restrict__ s1,
+                                                         float* __restrict__ lin, float* __restrict__ l0, float* __restrict__ l1,
+                                                         const int32_t* __restrict__ slot, uint8_t* __restrict__ ts,
+                                                         const StepState* __restrict__ S, float l2, int period, int target_offset,
+                                                         float* __restrict__ sumsq_emb, float* __restrict__ sumsq_lin) {
+    const int64_t T = S->t;
+    const Hyper h = S->hyper;
+    int64_t r0 = 0, r1 = rows, target = T + target_offset;
+    if (!FLUSH) {
+        const int64_t rpb = (rows + period - 1) / period;
+        r0 = (T % period) * rpb;
+        r1 = r0 + rpb < rows ? r0 + rpb : rows;
+        target = T;
+    }
+    const int64_t n_items = (r1 - r0) * KQ;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float sq = 0.f, sql = 0.f;
+    for (int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t0 < n_items; t0 += stride * UNR) {
+        float4 th[UNR], m[UNR], v[UNR];
+        float lt[UNR], lm[UNR], lv[UNR];
+        int n[UNR];
+        int64_t row[UNR];
+        bool live[UNR];
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            const int64_t t = t0 + j * stride;
+            live[j] = t < n_items;
+            row[j] = r0 + (live[j] ? t / KQ : 0);
+            if (live[j] && !FLUSH) live[j] = slot[row[j]] == 0;       // the batch's rows: stepped by the touched-rows pass, with their gradient
+            n[j] = live[j] ? lag_behind(target, ts[row[j]]) : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            const int kq = (int)((t0 + j * stride) % KQ);
+            // (a flush that reports sum theta^2 reads every row; otherwise rows already at the target are left alone)
+            if (live[j] && (n[j] > 0 || (FLUSH && sumsq_emb != nullptr))) {
+                const size_t i4 = (size_t)row[j] * KQ + kq;
+                th[j] = emb[i4];
+                if (n[j] > 0) { m[j] = s0[i4]; v[j] = s1[i4]; }
+                if (kq == 0 && lin != nullptr) {
+                    lt[j] = lin[row[j]];
+                    if (n[j] > 0) { lm[j] = l0[row[j]]; lv[j] = l1[row[j]]; }
+                }
+            } else {
+                live[j] = false;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            if (!live[j]) continue;
+            const int kq = (int)((t0 + j * stride) % KQ);
+            const size_t i4 = (size_t)row[j] * KQ + kq;
+            if (n[j] > 0) {
+                lag_catch_up4(S, h, l2, target - n[j] + 1, n[j], th[j], m[j], v[j]);
+                emb[i4] = th[j]; s0[i4] = m[j]; s1[i4] = v[j];
+            }
+            sq += th[j].x * th[j].x + th[j].y * th[j].y + th[j].z * th[j].z + th[j].w * th[j].w;
+            if (kq == 0) {
+                if (lin != nullptr) {
+                    if (n[j] > 0) {
+                        lag_catch_up1(S, h, l2, target - n[j] + 1, n[j], lt[j], lm[j], lv[j]);
+                        lin[row[j]] = lt[j]; l0[row[j]] = lm[j]; l1[row[j]] = lv[j];
+                    }
+                    sql += lt[j] * lt[j];
+                }
+                if (n[j] > 0) ts[row[j]] = (uint8_t)target;
+            }
+        }
+    }
+    if (FLUSH && sumsq_emb != nullptr) {
+        __shared__ float red[2][4];
+        sq = wave_sum_l(sq);
+        sql = wave_sum_l(sql);
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sq; red[1][threadIdx.x >> 6] = sql; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(sumsq_emb + (blockIdx.x & (SUMSQ_SHARDS - 1)), red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+            if (sumsq_lin != nullptr) atomicAdd(sumsq_lin + (blockIdx.x & (SUMSQ_SHARDS - 1)), red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void lag_stamp_kernel(uint8_t* __restrict__ ts, int64_t rows, const StepState* __restrict__ S) {
+    const uint8_t v = (uint8_t)S->t;
+    const uint32_t v4 = v * 0x01010101u;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 4 <= rows) *reinterpret_cast<uint32_t*>(ts + i) = v4;
+    else for (int64_t k = i; k < rows; ++k) ts[k] = v;
+}
+
+template <bool FLUSH>
+int launch_advance(int K, int64_t rows, float* emb, float* s0, float* s1, float* lin, float* l0, float* l1, const int32_t* slot, uint8_t* ts,
+                   const StepState* state, float l2, int period, int target_offset, float* sumsq_emb, float* sumsq_lin, hipStream_t st) {
+    const int KQ = K / 4;
+    const int64_t span = FLUSH ? rows : (rows + period - 1) / period;
+    // the sweep runs UNDER the MLP GEMMs like the classic background pass: a small grid (2 blocks per CU); the flush has the chip
+    const int grid = (int)std::min<int64_t>(ceil_div(span * KQ, 256 * 4), FLUSH ? 256 * 8 : 256 * 2);
+    float4 *e4 = reinterpret_cast<float4*>(emb), *a4 = reinterpret_cast<float4*>(s0), *b4 = reinterpret_cast<float4*>(s1);
+    switch (KQ) {
+#define DCTR_A(Q) case Q: lag_advance_kernel<Q, FLUSH, 4><<<grid, 256, 0, st>>>(rows, e4, a4, b4, lin, l0, l1, slot, ts, state, l2, period, target_offset, sumsq_emb, sumsq_lin); break
+        DCTR_A(1); DCTR_A(2); DCTR_A(4); DCTR_A(8); DCTR_A(16); DCTR_A(32); DCTR_A(64);
+#undef DCTR_A
+        default: set_error("lag: K=%d unsupported", K); return DCTR_ERR_UNSUPPORTED;
+    }
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+}  // namespace
+
+int lag_sweep(int K, int64_t rows, float* emb, float* s0, float* s1, float* lin, float* l0, float* l1, const int32_t* slot, uint8_t* ts,
+              const StepState* state, float l2, int period, hipStream_t st) {
+    DCTR_REQUIRE(period >= 2 && period <= LAG_MAX_PERIOD, "lag_sweep: period %d outside [2, %d]", period, LAG_MAX_PERIOD);
+    return launch_advance<false>(K, rows, emb, s0, s1, lin, l0, l1, slot, ts, state, l2, period, 0, nullptr, nullptr, st);
+}
+
+int lag_flush(int K, int64_t rows, float* emb, float* s0, float* s1, float* lin, float* l0, float* l1, uint8_t* ts, const StepState* state,
+              float l2, int target_offset, float* sumsq_emb, float* sumsq_lin, hipStream_t st) {
+    return launch_advance<true>(K, rows, emb, s0, s1, lin, l0, l1, nullptr, ts, state, l2, 1, target_offset, sumsq_emb, sumsq_lin, st);
+}
+
+int lag_stamp(uint8_t* ts, int64_t rows, const StepState* state, hipStream_t st) {
+    lag_stamp_kernel<<<ceil_div(ceil_div(rows, 4), 256), 256, 0, st>>>(ts, rows, state);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+}  // namespace dctr

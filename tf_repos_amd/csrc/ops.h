@@ -10,12 +10,14 @@ struct Hyper {
     float pad[2];
 };
 
+constexpr int LR_HIST = 32;     // per-step Adam lr_t of the last LR_HIST steps (lag.h: rows that lag replay their missed steps with them)
 struct StepState {
     int64_t t;          // global_step (number of optimizer steps applied so far)
     uint64_t seed;      // base dropout seed
     uint64_t seed_t;    // seed of the current step
     Hyper hyper;
     Hyper hyper_lin;    // canned-estimator models: the linear side's optimizer (wide_n_deep.py:144-149); else a copy of hyper
+    float lr_hist[LR_HIST];     // lr_hist[s % LR_HIST] = hyper.lr_t of step s
 };
 
 // sum-of-squares outputs (the l2_loss part of the reported loss) are SUMSQ_SHARDS-way sharded by block index: thousands of
@@ -60,20 +62,22 @@ int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st, bool z
 int embed_scatter_apply(Group* g, int kind, const Hyper* hdev, const Hyper& hval, float* emb, float* e0, float* e1, float* lin,
                         float* l0, float* l1, float l2, float* sumsq_emb, float* sumsq_lin, const float* dE, int de_ld,
                         const float* e, int e_ld, const float* S, const float* coef, const float* dy, const float* vals, int B, int F,
-                        int K, int mode, hipStream_t st, int dy_ld = 1, const int32_t* entry_row = nullptr);
+                        int K, int mode, hipStream_t st, int dy_ld = 1, const int32_t* entry_row = nullptr, uint8_t* lag_ts = nullptr,
+                        const StepState* lag_state = nullptr);
 int embed_scatter_bwd(Group* g, const float* dE, int de_ld, const float* e, int e_ld, const float* S,
                       const float* coef, const float* dy, const float* vals, int B, int F, int K, int mode,
                       float* gemb, float* glin, hipStream_t st, int dy_ld = 1,     // dy_ld: stride (floats) between examples in dy
                       const int32_t* entry_row = nullptr);                       // CSR batches: example of every entry (F == 1, vals per entry)
 
 // ---- K2 (gather.hip)
+struct LagView;     // lag.h
 int embed_gather_fwd(const float* emb, const float* lin, int64_t rows, const int32_t* ids, const float* vals,
                      int B, int F, int K, int mode, float* e, int e_ld, float* yw, float* sum, float* red,
-                     int32_t* status, hipStream_t st);
+                     int32_t* status, hipStream_t st, const LagView* lag = nullptr);
 
 int embed_gather_strided(const float* emb, int emb_ld, const float* lin, int lin_ld, int64_t rows, const int32_t* ids,
                          const float* vals, int B, int F, int K, int mode, float* e, int e_ld, float* yw, float* sum, float* red,
-                         int32_t* status, hipStream_t st);
+                         int32_t* status, hipStream_t st, const LagView* lag = nullptr);
 
 // ---- shard.hip: packed [K+4]-float row records for the row-sharded exchange
 int pack_table_rows(const float* emb, const float* lin, int64_t rows, int K, const int32_t* rows_idx, int n, float* out,

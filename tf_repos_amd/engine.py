@@ -50,6 +50,7 @@ class EngineConfig:
     # din with attention pooling (DIN.py:45,151-177): (user multi-hot slot, ad slot) pairs; the attention MLP takes its widths
     # from attention_layers and its keep_probs from dropout[i]
     att_pairs: Sequence[Tuple[int, int]] = ()
+    table_sweep_period: int = 0                # dense_exact + Adam: period of the time-blocked table sweep (include/deepctr_hip.h); 0 = default, 1 = classic
     use_graph: bool = False                    # False: eager launches on 3 HIP streams (measured faster: each stream keeps its own
                                                # hardware queue); True: one captured hipGraph per (batch size, input slot)
 
@@ -95,6 +96,7 @@ class EngineConfig:
         c.loss_sum = int(self.loss_sum)
         c.max_entries = int(self.max_entries)
         c.ctr_task_wgt = float(self.ctr_task_wgt)
+        c.table_sweep_period = int(self.table_sweep_period)
         c.n_att_pairs = len(self.att_pairs)
         for i, (u, a) in enumerate(list(self.att_pairs)[:8]):
             c.att_user_slot[i], c.att_ad_slot[i] = int(u), int(a)
@@ -233,6 +235,10 @@ class Engine:
         """Announces the next training batch's ids (a view of an input slot, unchanged until that train_step): grouped during the
         tail of the step in flight.  A scheduling hint only."""
         capi.check(self._lib.dctr_prefetch_ids(self._h, capi.ptr(ids_next), int(ids_next.shape[0])))
+
+    def sync_tables(self, stream=None) -> None:
+        """Advances every lagging table row to global_step (table_sweep_period > 1; a no-op otherwise)."""
+        capi.check(self._lib.dctr_tables_sync(self._h, stream if stream is not None else capi.current_stream()))
 
     def prefetch_cancel(self) -> None:
         """Drops a pending prefetch_ids hint (the announced batch will not be trained)."""
