@@ -37,7 +37,9 @@ CONFIGS = {
                name="DeepFM 39 fields, vocab 1e8 row-sharded, emb_dim 32, batch 8192/GPU (65536 at 8 GPUs), MLP 400-400-400 keep 0.5, "
                     "Adam (BASELINE configs[4])"),
 }
-PMC_FILE = os.path.join("profiles", "r02_pmc_traffic.txt")
+PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.txt")
+STATS_FILE = os.path.join("profiles", "r03_kernel_stats.txt")     # rocprofv3 --kernel-trace --stats of this same command
+LIB_FILE = os.path.join("tf_repos_amd", "_lib", "libdeepctr_hip.so")
 
 
 def cpu_baseline(w, steps=200, warmup=20):
@@ -131,6 +133,27 @@ def pmc_traffic_bytes(kernel_name):
     return None
 
 
+def profile_is_stale(rel):
+    """a committed profile older than the built library describes other kernels than the ones that just ran"""
+    a, b = os.path.join(ROOT, rel), os.path.join(ROOT, LIB_FILE)
+    return os.path.exists(a) and os.path.exists(b) and os.path.getmtime(a) < os.path.getmtime(b)
+
+
+def rocprof_avg_us(kernel_name):
+    """average duration (us) of one kernel in the committed rocprofv3 --stats summary of `python bench.py` (None if absent)"""
+    path = os.path.join(ROOT, STATS_FILE)
+    if not os.path.exists(path):
+        return None
+    for line in open(path):
+        if line.startswith(kernel_name[:60]):
+            f = line.split()
+            try:
+                return float(f[-2])
+            except (ValueError, IndexError):
+                return None
+    return None
+
+
 def fill_normal_(t, scale, seed):
     """In-place N(0, scale) on the device, in chunks (c5's 12.8 GB table never exists on the host)."""
     import torch
@@ -193,6 +216,7 @@ def main():
                     help="multi-GPU step driver: the C++ one over RCCL (default) or the torch.distributed orchestration; a native driver that cannot start falls back LOUDLY (stderr + config.driver), DCTR_BENCH_STRICT=1 forbids it")
     ap.add_argument("--selftest", action="store_true", help="multi-GPU: first check that the N-rank loss of step 0 equals one rank's on the same global batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-classic-reference", action="store_true", help="skip the 200-step reference run with the classic table sweep")
     ap.add_argument("--cpu-steps", type=int, default=200)
     ap.add_argument("--uniform-ids", action="store_true", help="uniform ids instead of Zipf (cache-worst case)")
     ap.add_argument("--sweep-period", type=int, default=0, help="dense_exact + Adam: period of the time-blocked table sweep (0 = library default, 1 = classic: every row every step)")
@@ -410,6 +434,18 @@ def main():
         # HBM bytes per launch of exactly this kernel (PMC passes of tools/profile_round.sh, committed under profiles/)
         r["traffic"] = pmc_traffic_bytes(gemm_name) if (not sharded and args.config == "c2") else None
         r["algorithmic_bytes"] = int(4 * (B * F * K + F * K * w["deep_layers"][0] + B * w["deep_layers"][0]))
+        # the PMC mean covers EVERY launch of this kernel template -- all three forward layers -- so the like-for-like algorithmic
+        # figure is their mean (X + W + Y of each layer), not layer 0's
+        dims = [F * K] + list(w["deep_layers"])
+        r["algorithmic_bytes_mean_of_the_launches_in_traffic"] = int(sum(4 * (B * dims[i] + dims[i] * dims[i + 1] + B * dims[i + 1]) for i in range(len(dims) - 1)) / (len(dims) - 1))
+        us = rocprof_avg_us(gemm_name) if (not sharded and args.config == "c2") else None
+        if us:      # the same launch by rocprofv3's kernel timestamps (no barrier packets inside the bracket): the optimistic reading
+            mean_flops = sum(2.0 * B * dims[i] * dims[i + 1] for i in range(len(dims) - 1)) / (len(dims) - 1)
+            r["frac_rocprof"] = round(mean_flops / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFS, 4)      # mean flops / mean duration of the three forward layers
+            r["rocprof_avg_us_all_layers"] = us
+        stale = [f for f in (PMC_FILE, STATS_FILE) if profile_is_stale(f)]
+        if stale:
+            r["profile_warning"] = "older than the built library, re-run tools/profile_round.sh: " + ", ".join(stale)
         hk = dict(kernels["opt_table_dense_adam"])
         hk["traffic"] = pmc_traffic_bytes("void dctr::opt_table_kernel<0, 4, true>") if (not sharded and args.config == "c2") else None
         r["hbm_kernel"] = hk
@@ -417,6 +453,28 @@ def main():
         out["roofline"] = r
         out["kernels"] = kernels
         out["stage_ms"] = {k: round(v, 5) for k, v in stages.items()}
+        if not sharded and not big and out["config"]["table_sweep_period"] > 1 and not args.no_classic_reference:
+            # the same workload with the classic sweep (every table row through HBM every step), for reference beside `value`
+            ref = Engine(EngineConfig(model=w["model"], field_size=F, feature_size=V, embedding_size=K, deep_layers=w["deep_layers"],
+                                      dropout=w["dropout"], l2_reg=w["l2_reg"], learning_rate=w["learning_rate"], optimizer=w["optimizer"],
+                                      table_mode=args.table_mode, max_batch=B, seed=1, table_sweep_period=1))
+            r1 = np.random.default_rng(1)
+            for name, shp in ref.param_shapes.items():
+                ref.set_param(name, r1.normal(0, 0.01, size=shp).astype(np.float32))
+            rb = []
+            for i in range(nb):
+                si, sv, sl = ref.input_slot(i)
+                si[:B].copy_(batches[i][0]); sv[:B].copy_(batches[i][1]); sl[:B].copy_(batches[i][2])
+                rb.append((si[:B], sv[:B], sl[:B]))
+            for s_ in range(20 + 200):
+                if s_ == 20:
+                    torch.cuda.synchronize()
+                    tr0 = time.perf_counter()
+                ref.train_step(*rb[s_ % nb], want_loss=False)
+                ref.prefetch_ids(rb[(s_ + 1) % nb][0])
+            torch.cuda.synchronize()
+            out["classic_sweep_ms_per_step"] = round(1e3 * (time.perf_counter() - tr0) / 200, 4)
+            ref.close()
         if not sharded and not args.no_cpu_baseline and not big:
             out["cpu_baseline"] = cpu_baseline(w, steps=args.cpu_steps)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)

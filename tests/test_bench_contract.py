@@ -1,4 +1,4 @@
-"""The bench line's contract, checked on the committed line of the round (profiles/r02_bench.json, produced by `python bench.py`
+"""The bench line's contract, checked on the committed line of the round (profiles/r03_bench.json, produced by `python bench.py`
 on the GPU box): the keys the driver and the judge read, their types, and the internal consistency of the derived figures."""
 import json
 import os
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_honours_the_contract():
-    lines = [l for l in open(os.path.join(ROOT, "profiles", "r02_bench.json")).read().splitlines() if l.strip()]
+    lines = [l for l in open(os.path.join(ROOT, "profiles", "r03_bench.json")).read().splitlines() if l.strip()]
     assert len(lines) == 1                                  # ONE JSON line on stdout
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -35,7 +35,7 @@ def test_committed_bench_line_honours_the_contract():
 
 
 def test_bench_kernel_names_exist_in_the_committed_pmc_summary():
-    """bench.py reads `roofline.traffic` from profiles/r02_pmc_traffic.txt by kernel name: a renamed template parameter list must
+    """bench.py reads `roofline.traffic` from profiles/r03_pmc_traffic.txt by kernel name: a renamed template parameter list must
     not turn the field into null on the next run."""
     import re
     import sys

@@ -63,20 +63,19 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(
             if (LAG) {
                 float4 m[U], vv[U];
                 float lm[U], lv[U];
+                int nl[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u)          // (loads only: the U rows' slot reads overlap)
+                for (int u = 0; u < U; ++u) {        // (loads only: the U rows' slot reads overlap)
+                    nl[u] = 0;
                     if (nlag[u] > 0) {
                         m[u] = L.s0[(size_t)id[u] * KQ + kq]; vv[u] = L.s1[(size_t)id[u] * KQ + kq];
-                        if (lin != nullptr && kq == 0) { lm[u] = L.l0[id[u]]; lv[u] = L.l1[id[u]]; }
+                        if (lin != nullptr && kq == 0) { lm[u] = L.l0[id[u]]; lv[u] = L.l1[id[u]]; nl[u] = nlag[u]; }
                     }
+                }
                 const Hyper hh = L.state->hyper;
                 const int64_t Tm1 = L.state->t - 1;
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (nlag[u] > 0) {
-                        lag_catch_up4(L.state, hh, L.l2, Tm1 - nlag[u] + 1, nlag[u], r[u], m[u], vv[u]);
-                        if (lin != nullptr && kq == 0) lag_catch_up1(L.state, hh, L.l2, Tm1 - nlag[u] + 1, nlag[u], w[u], lm[u], lv[u]);
-                    }
+                lag_catch_up4_rows<U>(L.state, hh, L.l2, Tm1, nlag, r, m, vv);
+                lag_catch_up1_rows<U>(L.state, hh, L.l2, Tm1, nl, w, lm, lv);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {

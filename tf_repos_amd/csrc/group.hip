@@ -50,11 +50,15 @@ __global__ void group_reset_kernel(int32_t* __restrict__ slot, const int32_t* __
 // same id (its "leader"), the number of lanes sharing the id and this lane's rank among them.  The loop runs once
 // per DISTINCT id in the wave and only does ballots/shuffles; the atomics are issued afterwards by all leaders at
 // once, so their latencies overlap instead of serialising.
+// (at most WAVE_GROUP_ROUNDS ids are looked for: a wave of 64 different ids -- most waves of a high-cardinality field -- would
+//  otherwise spend 64 rounds finding nothing to merge; lanes still pending after the rounds go on alone, which only costs the
+//  odd duplicate an atomic of its own.  The hot ids of a field sit in many lanes, so they come up as a leader early.)
+constexpr int WAVE_GROUP_ROUNDS = 12;
 struct WaveGroup { int leader; int count; int rank; };
 __device__ __forceinline__ WaveGroup wave_group(int id, bool valid, int lane) {
-    WaveGroup g{lane, 0, 0};
+    WaveGroup g{lane, valid ? 1 : 0, 0};
     bool pending = valid;
-    while (true) {
+    for (int round = 0; round < WAVE_GROUP_ROUNDS; ++round) {
         const unsigned long long m = __ballot(pending);
         if (m == 0ull) break;
         const int leader = __ffsll((long long)m) - 1;
@@ -72,7 +76,10 @@ __device__ __forceinline__ WaveGroup wave_group(int id, bool valid, int lane) {
 }
 
 // entry i <-> (f = i / B, b = i % B): field-major walk
-__global__ __launch_bounds__(256) void group_count_kernel(const int32_t* __restrict__ ids, int B, int F,
+// (blocks of GROUP_BLOCK = 1024 threads: every block ends with ONE atomic on a shared counter, and a single word sustains only
+//  ~90 atomics/us -- 624 blocks of 256 spent ~8 us of this kernel and of group_segments_kernel queueing on it)
+constexpr int GROUP_BLOCK = 1024;
+__global__ __launch_bounds__(GROUP_BLOCK) void group_count_kernel(const int32_t* __restrict__ ids, int B, int F,
                                                          int64_t rows, int32_t* __restrict__ slot,
                                                          int32_t* __restrict__ uniq, int32_t* __restrict__ counters) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -90,14 +97,15 @@ __global__ __launch_bounds__(256) void group_count_kernel(const int32_t* __restr
     if (valid && g.leader == lane) first = atomicAdd(&slot[id], g.count) == 0;
     // compact-slot allocation: ONE atomic on the shared counter per 256-thread block (a single word sustains only ~90
     // atomics/us, so one per wave -- 2500 per batch -- cost more than everything else in this kernel)
-    __shared__ int wcount[4];
+    __shared__ int wcount[GROUP_BLOCK / 64];
     __shared__ int bbase;
     const int wave = threadIdx.x >> 6;
     const unsigned long long fm = __ballot(first);
     if (lane == 0) wcount[wave] = __popcll(fm);
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        int tot = 0;
+        for (int w = 0; w < (int)blockDim.x / 64; ++w) tot += wcount[w];
         bbase = tot ? atomicAdd(&counters[0], tot) : 0;
     }
     __syncthreads();
@@ -210,15 +218,15 @@ constexpr int LONG_SEGMENT = 256;
 constexpr int LONG_CHUNK = 256;
 
 // one thread per distinct id: carve its segment of the grouped-entry array (one atomic per block on the running total)
-__global__ __launch_bounds__(256) void group_segments_kernel(int32_t* __restrict__ slot, const int32_t* __restrict__ uniq,
+__global__ __launch_bounds__(GROUP_BLOCK) void group_segments_kernel(int32_t* __restrict__ slot, const int32_t* __restrict__ uniq,
                                                             int32_t* __restrict__ cnt, int32_t* __restrict__ seg_start,
                                                             int32_t* __restrict__ cursor, int32_t* __restrict__ counters,
                                                             float* __restrict__ glin, int32_t* __restrict__ long_list, int long_cap,
                                                             int32_t* __restrict__ done, int32_t* __restrict__ medium_list, int medium_cap) {
-    __shared__ int wsum[4];
+    __shared__ int wsum[GROUP_BLOCK / 64];
     __shared__ int bbase;
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = (int)blockDim.x / 64;
     const int U = counters[0];
     int c = 0, id = 0;
     if (u < U) { id = uniq[u]; c = slot[id]; }
@@ -232,7 +240,8 @@ __global__ __launch_bounds__(256) void group_segments_kernel(int32_t* __restrict
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        int tot = 0;
+        for (int w = 0; w < n_waves; ++w) tot += wsum[w];
         bbase = tot ? atomicAdd(&counters[1], tot) : 0;
     }
     __syncthreads();
@@ -258,7 +267,8 @@ __global__ __launch_bounds__(256) void group_segments_kernel(int32_t* __restrict
     if (lane == 0) wsum[wave] = __popcll(mm);
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        int tot = 0;
+        for (int w = 0; w < n_waves; ++w) tot += wsum[w];
         bbase = tot ? atomicAdd(&counters[4], tot) : 0;
     }
     __syncthreads();
@@ -812,8 +822,8 @@ int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st, bool z
     static const bool no_hash = getenv("DCTR_GROUP_NO_HASH") != nullptr;       // A/B knob
     const bool hashed = F == 1 && n >= 4 * HCHUNK && !no_hash;                  // CSR-ordered ids: aggregate per 2048-entry chunk in LDS
     if (hashed) group_count_hash_kernel<<<ceil_div(n, HCHUNK), 256, 0, st>>>(ids, (int)n, g->rows, g->slot, g->uniq, g->counters);
-    else group_count_kernel<<<nb, 256, 0, st>>>(ids, B, F, g->rows, g->slot, g->uniq, g->counters);
-    group_segments_kernel<<<nb, 256, 0, st>>>(g->slot, g->uniq, g->cnt, g->seg_start, g->cursor, g->counters, g->glin, g->long_list,
+    else group_count_kernel<<<ceil_div(n, GROUP_BLOCK), GROUP_BLOCK, 0, st>>>(ids, B, F, g->rows, g->slot, g->uniq, g->counters);
+    group_segments_kernel<<<ceil_div(n, GROUP_BLOCK), GROUP_BLOCK, 0, st>>>(g->slot, g->uniq, g->cnt, g->seg_start, g->cursor, g->counters, g->glin, g->long_list,
                                              (int)g->long_cap, g->done, g->medium_list, (int)g->medium_cap);
     const int KQ = g->K / 4;
     dim3 fgrid(ceil_div(n * KQ, 256));

@@ -47,6 +47,40 @@ __device__ __forceinline__ void lag_catch_up1(const StepState* __restrict__ S, H
         opt_update(DCTR_OPT_ADAM, h, th, m, v, l2 * th);
     }
 }
+// R row pieces at once, each n[r] steps behind `last` (its steps last-n[r]+1 .. last are replayed): ONE loop over the steps, the
+// rows' recurrences side by side -- R independent dependency chains per lane instead of R loops in sequence (the Adam update is
+// a ~15-instruction chain through sqrt and rcp; alone it leaves the ALU waiting on itself)
+template <int R>
+__device__ __forceinline__ void lag_catch_up4_rows(const StepState* __restrict__ S, Hyper h, float l2, int64_t last, const int (&n)[R],
+                                                   float4 (&th)[R], float4 (&m)[R], float4 (&v)[R]) {
+    int nmax = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) nmax = n[r] > nmax ? n[r] : nmax;
+    for (int k = nmax; k >= 1; --k) {            // step last - k + 1
+        h.lr_t = S->lr_hist[(last - k + 1) & (LR_HIST - 1)];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (k <= n[r]) {
+                opt_update(DCTR_OPT_ADAM, h, th[r].x, m[r].x, v[r].x, l2 * th[r].x);
+                opt_update(DCTR_OPT_ADAM, h, th[r].y, m[r].y, v[r].y, l2 * th[r].y);
+                opt_update(DCTR_OPT_ADAM, h, th[r].z, m[r].z, v[r].z, l2 * th[r].z);
+                opt_update(DCTR_OPT_ADAM, h, th[r].w, m[r].w, v[r].w, l2 * th[r].w);
+            }
+    }
+}
+template <int R>
+__device__ __forceinline__ void lag_catch_up1_rows(const StepState* __restrict__ S, Hyper h, float l2, int64_t last, const int (&n)[R],
+                                                   float (&th)[R], float (&m)[R], float (&v)[R]) {
+    int nmax = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) nmax = n[r] > nmax ? n[r] : nmax;
+    for (int k = nmax; k >= 1; --k) {
+        h.lr_t = S->lr_hist[(last - k + 1) & (LR_HIST - 1)];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (k <= n[r]) opt_update(DCTR_OPT_ADAM, h, th[r], m[r], v[r], l2 * th[r]);
+    }
+}
 // steps a row stamped `ts` is behind `target` (both compared mod 256)
 __device__ __forceinline__ int lag_behind(int64_t target, uint8_t ts) { return (int)(uint8_t)((uint8_t)target - ts); }
 

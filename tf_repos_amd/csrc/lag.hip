@@ -64,22 +64,24 @@ __global__ __launch_bounds__(256) void lag_advance_kernel(int64_t rows, float4* 
                 live[j] = false;
             }
         }
+        int nn[UNR], nl[UNR];
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            nn[j] = live[j] ? n[j] : 0;
+            nl[j] = (live[j] && lin != nullptr && (int)((t0 + j * stride) % KQ) == 0) ? n[j] : 0;
+        }
+        lag_catch_up4_rows<UNR>(S, h, l2, target, nn, th, m, v);
+        lag_catch_up1_rows<UNR>(S, h, l2, target, nl, lt, lm, lv);
 #pragma unroll
         for (int j = 0; j < UNR; ++j) {
             if (!live[j]) continue;
             const int kq = (int)((t0 + j * stride) % KQ);
             const size_t i4 = (size_t)row[j] * KQ + kq;
-            if (n[j] > 0) {
-                lag_catch_up4(S, h, l2, target - n[j] + 1, n[j], th[j], m[j], v[j]);
-                emb[i4] = th[j]; s0[i4] = m[j]; s1[i4] = v[j];
-            }
+            if (n[j] > 0) { emb[i4] = th[j]; s0[i4] = m[j]; s1[i4] = v[j]; }
             sq += th[j].x * th[j].x + th[j].y * th[j].y + th[j].z * th[j].z + th[j].w * th[j].w;
             if (kq == 0) {
                 if (lin != nullptr) {
-                    if (n[j] > 0) {
-                        lag_catch_up1(S, h, l2, target - n[j] + 1, n[j], lt[j], lm[j], lv[j]);
-                        lin[row[j]] = lt[j]; l0[row[j]] = lm[j]; l1[row[j]] = lv[j];
-                    }
+                    if (n[j] > 0) { lin[row[j]] = lt[j]; l0[row[j]] = lm[j]; l1[row[j]] = lv[j]; }
                     sql += lt[j] * lt[j];
                 }
                 if (n[j] > 0) ts[row[j]] = (uint8_t)target;
