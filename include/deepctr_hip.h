@@ -128,6 +128,11 @@ typedef struct dctr_config {
      * those of the classic sweep, row for row; the table step's HBM traffic drops N-fold.  0 = the library's default
      * (DCTR_SWEEP_PERIOD, else 8), 1 = the classic sweep of every row every step; at most 24. */
     int32_t table_sweep_period;
+    /* contrib.layers.batch_norm on the rank-2 layer outputs takes TF-1.4's FUSED path (layers.py: fused defaults to True, rank 2 is
+     * fusable; the scripts pass updates_collections=None), whose kernel normalises with the biased batch variance but hands the
+     * moving average the Bessel-corrected one, var * B / (B - 1) (fused_batch_norm_op.cc `rest_size_adjust`).  0 = that (default);
+     * 1 = the biased variance in the moving average too (the non-fused nn.moments path). */
+    int32_t batch_norm_biased_moving_variance;
 } dctr_config;
 
 typedef struct dctr_engine* dctr_handle;

@@ -45,6 +45,7 @@ class Config:
     optimizer: str = "Adam"                         # Adam | Adagrad | Momentum | ftrl
     batch_norm: bool = False
     batch_norm_decay: float = 0.9
+    batch_norm_bessel: bool = True       # the moving variance is fed var * B/(B-1): TF-1.4's fused batch_norm (rank-2 inputs) [TF-1.4]
 
     @property
     def num_pairs(self) -> int:
@@ -158,7 +159,9 @@ def _bn(x, p, i, cfg, train):
         var = x.var(0, unbiased=False)
         d = cfg.batch_norm_decay
         new_mm = d * mm + (1 - d) * mean.detach()
-        new_mv = d * mv + (1 - d) * var.detach()
+        n = x.shape[0]
+        adj = n / max(n - 1, 1) if cfg.batch_norm_bessel else 1.0       # fused_batch_norm_op.cc `rest_size_adjust` [TF-1.4]
+        new_mv = d * mv + (1 - d) * var.detach() * adj
     else:
         mean, var, new_mm, new_mv = mm, mv, mm, mv
     y = (x - mean) / torch.sqrt(var + 1e-3) * g + bt

@@ -57,6 +57,7 @@ class GraphEval:
         self.val: Dict[int, np.ndarray] = {}
         self.aux: Dict[int, object] = {}
         self.bn_updates: Dict[str, np.ndarray] = {}
+        self.bn_bessel = True
 
     # ------------------------------------------------------------------------------------------------ forward
     def _in(self, n, i):
@@ -181,7 +182,9 @@ class GraphEval:
         return x * m
 
     # contrib.layers.batch_norm(decay, center, scale, eps = 1e-3, updates_collections=None) (Appendix B 7): training uses the
-    # batch mean / biased variance and moves the averages in place; inference uses the moving statistics
+    # batch mean / biased variance and moves the averages in place; inference uses the moving statistics.  Rank-2 inputs take
+    # TF-1.4's fused kernel, which hands the moving variance the Bessel-corrected batch variance var * B / (B - 1)
+    # (GraphEval.bn_bessel = False: the biased one, the non-fused path)
     def f_batch_norm(self, n):
         x = self._in(n, 0)
         a = n.attrs
@@ -194,7 +197,9 @@ class GraphEval:
             mean, var = x.mean(axis=0), x.var(axis=0)
             d = a["decay"]
             self.bn_updates[mm_name] = d * self.var[mm_name] + (1 - d) * mean
-            self.bn_updates[mv_name] = d * self.var[mv_name] + (1 - d) * var
+            nb = x.shape[0]
+            adj = nb / max(nb - 1, 1) if self.bn_bessel else 1.0
+            self.bn_updates[mv_name] = d * self.var[mv_name] + (1 - d) * var * adj
         else:
             mean, var = self.var[mm_name], self.var[mv_name]
         inv = 1.0 / np.sqrt(var + a["epsilon"])

@@ -52,6 +52,7 @@ class Config:
     attention_layers: Sequence[int] = ()
     batch_norm: bool = False             # --batch_norm: batch_norm_layer after every hidden ReLU (DIN.py:203-204, DeepCvrMTL.py:177-178)
     batch_norm_decay: float = 0.9
+    batch_norm_bessel: bool = True       # the moving variance is fed var * B/(B-1): TF-1.4's fused batch_norm (rank-2 inputs) [TF-1.4]
 
     @property
     def n_slots(self) -> int:
@@ -158,7 +159,9 @@ def _bn(cfg: Config, p, x, scope, train, new_stats):
         mean, var = x.mean(0), x.var(0, unbiased=False)
         d = cfg.batch_norm_decay
         new_stats[f"{scope}/moving_mean"] = d * mm + (1 - d) * mean.detach()
-        new_stats[f"{scope}/moving_variance"] = d * mv + (1 - d) * var.detach()
+        n = x.shape[0]
+        adj = n / max(n - 1, 1) if cfg.batch_norm_bessel else 1.0        # fused_batch_norm_op.cc `rest_size_adjust` [TF-1.4]
+        new_stats[f"{scope}/moving_variance"] = d * mv + (1 - d) * var.detach() * adj
     else:
         mean, var = mm, mv
     return (x - mean) / torch.sqrt(var + 1e-3) * g + bt

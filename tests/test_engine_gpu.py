@@ -391,3 +391,27 @@ def test_stale_prefetch_is_dropped(how, dev):
     assert abs(runs[0][0] - runs[1][0]) <= 1e-6 and abs(runs[0][1] - runs[1][1]) <= 1e-6
     for k in runs[0][2]:
         assert np.abs(runs[0][2][k] - runs[1][2][k]).max() <= 1e-6, k
+
+
+@pytest.mark.parametrize("K", [128, 256])
+def test_dcn_cross_wider_than_2560(K, dev):
+    """--embedding_size 128 / 256 with 39 fields: F*K = 4992 / 9984 inputs to the cross network (DCN.py:140-145) -- one BLOCK per
+    example instead of one wave (interact.hip)"""
+    F, V, B = 39, 600, 24
+    ocfg, params, eng = make_pair("dcn", B=B, F=F, V=V, K=K, layers=(32, 16), cross=3, opt="Adam", lr=1e-3, l2=1e-4, scale=0.02)
+    ids, vals, labels = O.synth_batch(B, F, V, seed=41)
+    d = dev_batch(ids, vals, labels, dev)
+    ref = O.forward(ocfg, params, ids, vals)
+    logit = torch.empty(B, device=dev)
+    eng.predict(d[0], d[1], torch.empty(B, device=dev), logit)
+    assert np.abs(logit.cpu().numpy() - ref["y"].numpy()).max() <= 1e-4
+    oopt = O.Optimizer(ocfg, params)
+    for step in range(2):
+        ids, vals, labels = O.synth_batch(B, F, V, seed=42 + step)
+        ref_loss, _ = O.train_step(ocfg, params, oopt, ids, vals, labels)
+        loss = eng.train_step(*dev_batch(ids, vals, labels, dev))
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+    got = eng.get_params()
+    for name, ref_p in params.items():
+        assert np.abs(got[name] - ref_p.numpy()).max() <= 2e-6, name
+    eng.close()

@@ -43,7 +43,7 @@ class Config(C.Structure):
         ("use_graph", C.c_int32), ("dense_size", C.c_int32), ("lin_optimizer", C.c_int32),
         ("lin_learning_rate", C.c_float), ("loss_sum", C.c_int32), ("max_entries", C.c_int32), ("ctr_task_wgt", C.c_float),
         ("n_att_pairs", C.c_int32), ("att_user_slot", C.c_int32 * 8), ("att_ad_slot", C.c_int32 * 8),
-        ("table_sweep_period", C.c_int32),
+        ("table_sweep_period", C.c_int32), ("batch_norm_biased_moving_variance", C.c_int32),
     ]
 
 

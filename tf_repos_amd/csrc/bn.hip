@@ -1,7 +1,9 @@
 // contrib.layers.batch_norm(decay, center=True, scale=True, epsilon=1e-3, updates_collections=None) as the reference's
 // batch_norm_layer applies it AFTER the ReLU of every hidden layer (DeepFM.py:159-160, 231-235), followed by dropout
 // (DeepFM.py:161-162).  TRAIN: batch statistics (biased variance) + in-place moving-average update
-// moving <- decay*moving + (1-decay)*batch [TF-1.4]; otherwise the moving statistics.
+// moving <- decay*moving + (1-decay)*batch [TF-1.4]; otherwise the moving statistics.  The moving VARIANCE is fed the
+// Bessel-corrected batch variance var * B/(B-1), as TF-1.4's fused batch-norm kernel does (the path contrib.layers.batch_norm
+// takes for rank-2 inputs); dctr_config.batch_norm_biased_moving_variance = 1 feeds it the biased one.
 // HBM-bound column reductions over [B, H]: S row-splits of partial sums per 64-column group, then a tiny finalize.
 #include "ops.h"
 
@@ -29,7 +31,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
 
 // mean / invstd of the batch (stats[0][c], stats[1][c]) and the moving-average update
 __global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int S, int64_t B, int H, float eps, float decay,
-                                         float* __restrict__ stats, float* __restrict__ mm, float* __restrict__ mv) {
+                                         float* __restrict__ stats, float* __restrict__ mm, float* __restrict__ mv, int bessel) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= H) return;
     double s = 0.0, q = 0.0;
@@ -40,7 +42,9 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int S, 
     stats[c] = (float)mean;
     stats[H + c] = (float)(1.0 / sqrt(var + (double)eps));
     mm[c] = decay * mm[c] + (1.0f - decay) * (float)mean;
-    mv[c] = decay * mv[c] + (1.0f - decay) * (float)var;
+    // fused_batch_norm_op.cc [TF-1.4]: rest_size_adjust = rest_size / max(rest_size - 1, 1) on the variance handed to the moving average
+    const double adj = bessel ? (double)B / (double)(B > 1 ? B - 1 : 1) : 1.0;
+    mv[c] = decay * mv[c] + (1.0f - decay) * (float)(var * adj);
 }
 
 // inference statistics: mean = moving_mean, invstd = 1/sqrt(moving_variance + eps)
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // cross-rank sum so that mean / variance (and, backward, the two gradient sums) are the global batch's: N ranks == 1 rank.
 int bn_forward(const float* y, int ldy, int B, int H, bool train, float eps, float decay, const float* gamma, const float* beta,
                float* mm, float* mv, float keep, const uint64_t* seed_ptr, uint64_t salt, float* stats, float* scratch, float* out,
-               int ldo, hipStream_t st, const BnSync* sync) {
+               int ldo, hipStream_t st, const BnSync* sync, bool bessel) {
     if (train) {
         const int S = BN_SPLITS;
         bn_stats_partial_kernel<<<dim3(ceil_div(H, 64), S), 256, 0, st>>>(y, ldy, B, H, ceil_div(B, S), scratch);
@@ -146,9 +150,9 @@ int bn_forward(const float* y, int ldy, int B, int H, bool train, float eps, flo
             bn_fold_kernel<<<ceil_div(H, 256), 256, 0, st>>>(scratch, S, H, folded);
             DCTR_LAUNCH_CHECK();
             DCTR_TRY(sync->all_reduce(sync->ctx, 0, folded, 2 * (int64_t)H, st));
-            bn_stats_finalize_kernel<<<ceil_div(H, 256), 256, 0, st>>>(folded, 1, (int64_t)B * sync->world, H, eps, decay, stats, mm, mv);
+            bn_stats_finalize_kernel<<<ceil_div(H, 256), 256, 0, st>>>(folded, 1, (int64_t)B * sync->world, H, eps, decay, stats, mm, mv, bessel ? 1 : 0);
         } else {
-            bn_stats_finalize_kernel<<<ceil_div(H, 256), 256, 0, st>>>(scratch, S, B, H, eps, decay, stats, mm, mv);
+            bn_stats_finalize_kernel<<<ceil_div(H, 256), 256, 0, st>>>(scratch, S, B, H, eps, decay, stats, mm, mv, bessel ? 1 : 0);
         }
     } else {
         bn_stats_moving_kernel<<<ceil_div(H, 256), 256, 0, st>>>(mm, mv, H, eps, stats);

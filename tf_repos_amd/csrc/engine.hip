@@ -541,7 +541,7 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::f
         if (E->bn) {
             DCTR_TRY(bn_forward(E->h[i], fc.out, B, fc.out, train, 1e-3f, c.batch_norm_decay, E->pp(fc.bn_gamma), E->pp(fc.bn_beta),
                                 E->pp(fc.bn_mm), E->pp(fc.bn_mv), fc.keep, seedp, fc.salt, E->bn_stats[i], E->bn_scratch,
-                                E->hbn[i], fc.out, st, E->bn_sync.world > 1 ? &E->bn_sync : nullptr));
+                                E->hbn[i], fc.out, st, E->bn_sync.world > 1 ? &E->bn_sync : nullptr, c.batch_norm_biased_moving_variance == 0));
             x = E->hbn[i];
         }
     }

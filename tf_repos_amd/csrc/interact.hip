@@ -318,19 +318,32 @@ int pnn_outer_bwd(const float* e, int e_ld, const float* dop, int64_t dop_ld, in
     return DCTR_OK;
 }
 
-// ---- DCN cross network.  One wave per example; x0 and x_l live in registers (NR = ceil(D/64) floats per lane);
-// all L layers are applied without leaving the CU.  xs[l] (l = 0..L) and s_l = x_l.w_l are kept for the backward.
-template <int NR>
+// sum over the G lanes that share an example: a wave (G = 64) or the whole 256-thread block (G = 256, F*K > 2560: --embedding_size
+// 128 / 256 with 39 fields)
+template <int G>
+__device__ __forceinline__ float dcn_group_sum(float v) {
+    v = wsum(v);
+    if (G == 64) return v;
+    __shared__ float part[4];
+    __syncthreads();                         // (the previous round's readers are done with part[])
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return part[0] + part[1] + part[2] + part[3];
+}
+
+// ---- DCN cross network.  One wave (or, for wide inputs, one block) per example; x0 and x_l live in registers (NR = ceil(D/G)
+// floats per lane); all L layers are applied without leaving the CU.  xs[l] (l = 0..L) and s_l = x_l.w_l are kept for the backward.
+template <int NR, int G = 64>
 __global__ __launch_bounds__(256) void dcn_cross_fwd_kernel(const float* __restrict__ x0, int x0_ld, const float* __restrict__ w,
                                                            const float* __restrict__ bias, int B, int D, int L,
                                                            float* __restrict__ xs, float* __restrict__ xlw) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x % G;
+    const int b = blockIdx.x * (256 / G) + threadIdx.x / G;
     if (b >= B) return;
     float a0[NR], xl[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-        const int d = lane + 64 * r;
+        const int d = lane + G * r;
         a0[r] = (d < D) ? x0[(size_t)b * x0_ld + d] : 0.f;
         xl[r] = a0[r];
         if (d < D) xs[(size_t)b * D + d] = a0[r];
@@ -341,14 +354,14 @@ __global__ __launch_bounds__(256) void dcn_cross_fwd_kernel(const float* __restr
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const int d = lane + 64 * r;
+            const int d = lane + G * r;
             if (d < D) s += xl[r] * wl[d];
         }
-        s = wsum(s);
+        s = dcn_group_sum<G>(s);
         if (lane == 0) xlw[(size_t)l * B + b] = s;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const int d = lane + 64 * r;
+            const int d = lane + G * r;
             if (d < D) {
                 xl[r] = a0[r] * s + xl[r] + bl[d];
                 xs[((size_t)(l + 1) * B + b) * D + d] = xl[r];
@@ -365,25 +378,27 @@ int dcn_cross_fwd(const float* x0, int x0_ld, const float* w, const float* b, in
     if (nr <= 10) dcn_cross_fwd_kernel<10><<<grid, 256, 0, st>>>(x0, x0_ld, w, b, B, D, L, xs, xlw);
     else if (nr <= 20) dcn_cross_fwd_kernel<20><<<grid, 256, 0, st>>>(x0, x0_ld, w, b, B, D, L, xs, xlw);
     else if (nr <= 40) dcn_cross_fwd_kernel<40><<<grid, 256, 0, st>>>(x0, x0_ld, w, b, B, D, L, xs, xlw);
-    else { set_error("dcn_cross: F*K=%d > 2560 unsupported", D); return DCTR_ERR_UNSUPPORTED; }
+    else if (D <= 256 * 20) dcn_cross_fwd_kernel<20, 256><<<B, 256, 0, st>>>(x0, x0_ld, w, b, B, D, L, xs, xlw);       // one block per example
+    else if (D <= 256 * 40) dcn_cross_fwd_kernel<40, 256><<<B, 256, 0, st>>>(x0, x0_ld, w, b, B, D, L, xs, xlw);
+    else { set_error("dcn_cross: F*K=%d > 10240 unsupported", D); return DCTR_ERR_UNSUPPORTED; }
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }
 
 // backward per example (g = dL/dx_{l+1}):  t_l = g.x0 ; dx0 += g s_l ; g <- g + t_l w_l ; finally dx0 += g.
 // G[l] = dL/dx_{l+1} and T[l] = t_l are written to scratch; db_l = colsum(G[l]), dw_l = colsum(T[l] * xs[l]).
-template <int NR>
+template <int NR, int GS = 64>
 __global__ __launch_bounds__(256) void dcn_cross_bwd_kernel(const float* __restrict__ xs, const float* __restrict__ xlw,
                                                            const float* __restrict__ w, const float* __restrict__ dxL, int dxl_ld,
                                                            int B, int D, int L, float* __restrict__ dx0, int dx0_ld,
                                                            float* __restrict__ G, float* __restrict__ T) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x % GS;
+    const int b = blockIdx.x * (256 / GS) + threadIdx.x / GS;
     if (b >= B) return;
     float a0[NR], g[NR], acc0[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-        const int d = lane + 64 * r;
+        const int d = lane + GS * r;
         a0[r] = (d < D) ? xs[(size_t)b * D + d] : 0.f;
         g[r] = (d < D) ? dxL[(size_t)b * dxl_ld + d] : 0.f;
         acc0[r] = 0.f;
@@ -394,11 +409,11 @@ __global__ __launch_bounds__(256) void dcn_cross_bwd_kernel(const float* __restr
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < NR; ++r) t += g[r] * a0[r];
-        t = wsum(t);
+        t = dcn_group_sum<GS>(t);
         if (lane == 0) T[(size_t)l * B + b] = t;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const int d = lane + 64 * r;
+            const int d = lane + GS * r;
             if (d < D) {
                 G[((size_t)l * B + b) * D + d] = g[r];
                 acc0[r] += g[r] * s;
@@ -408,7 +423,7 @@ __global__ __launch_bounds__(256) void dcn_cross_bwd_kernel(const float* __restr
     }
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-        const int d = lane + 64 * r;
+        const int d = lane + GS * r;
         if (d < D) dx0[(size_t)b * dx0_ld + d] += acc0[r] + g[r];
     }
 }
@@ -424,7 +439,9 @@ int dcn_cross_bwd(const float* xs, const float* xlw, const float* w, const float
     if (nr <= 10) dcn_cross_bwd_kernel<10><<<grid, 256, 0, st>>>(xs, xlw, w, dxL, dxl_ld, B, D, L, dx0, dx0_ld, G, T);
     else if (nr <= 20) dcn_cross_bwd_kernel<20><<<grid, 256, 0, st>>>(xs, xlw, w, dxL, dxl_ld, B, D, L, dx0, dx0_ld, G, T);
     else if (nr <= 40) dcn_cross_bwd_kernel<40><<<grid, 256, 0, st>>>(xs, xlw, w, dxL, dxl_ld, B, D, L, dx0, dx0_ld, G, T);
-    else { set_error("dcn_cross: F*K=%d > 2560 unsupported", D); return DCTR_ERR_UNSUPPORTED; }
+    else if (D <= 256 * 20) dcn_cross_bwd_kernel<20, 256><<<B, 256, 0, st>>>(xs, xlw, w, dxL, dxl_ld, B, D, L, dx0, dx0_ld, G, T);
+    else if (D <= 256 * 40) dcn_cross_bwd_kernel<40, 256><<<B, 256, 0, st>>>(xs, xlw, w, dxL, dxl_ld, B, D, L, dx0, dx0_ld, G, T);
+    else { set_error("dcn_cross: F*K=%d > 10240 unsupported", D); return DCTR_ERR_UNSUPPORTED; }
     DCTR_LAUNCH_CHECK();
     for (int l = 0; l < L; ++l) {
         // partial slabs: slab s of layer l at part + s*part_stride + l*D

@@ -167,7 +167,7 @@ struct BnSync {
 };
 int bn_forward(const float* y, int ldy, int B, int H, bool train, float eps, float decay, const float* gamma, const float* beta,
                float* mm, float* mv, float keep, const uint64_t* seed_ptr, uint64_t salt, float* stats, float* scratch, float* out,
-               int ldo, hipStream_t st, const BnSync* sync = nullptr);
+               int ldo, hipStream_t st, const BnSync* sync = nullptr, bool bessel = true);
 int bn_backward(const float* dout, int ldd, const float* y, int ldy, int B, int H, const float* stats, const float* gamma, float keep,
                 const uint64_t* seed_ptr, uint64_t salt, float* scratch, float* dbeta, float* dgamma, float* dpre, int ldp,
                 hipStream_t st, const BnSync* sync = nullptr);

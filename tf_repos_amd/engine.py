@@ -33,6 +33,7 @@ class EngineConfig:
     table_mode: str = "dense_exact"            # dense_exact (TF semantics) | touched_rows (lazy)
     batch_norm: bool = False
     batch_norm_decay: float = 0.9
+    batch_norm_bessel: bool = True             # moving variance fed var * B/(B-1) (TF-1.4's fused batch_norm); False: the biased batch variance
     max_batch: int = 4096
     seed: int = 0
     shard_rank: int = 0
@@ -85,6 +86,7 @@ class EngineConfig:
         c.table_mode = capi.TABLE_MODES[self.table_mode]
         c.batch_norm = int(self.batch_norm)
         c.batch_norm_decay = self.batch_norm_decay
+        c.batch_norm_biased_moving_variance = int(not self.batch_norm_bessel)
         c.max_batch = self.max_batch
         c.seed = self.seed
         c.shard_rank = self.shard_rank
