@@ -415,3 +415,40 @@ def test_dcn_cross_wider_than_2560(K, dev):
     for name, ref_p in params.items():
         assert np.abs(got[name] - ref_p.numpy()).max() <= 2e-6, name
     eng.close()
+
+
+@pytest.mark.parametrize("model", MODELS)
+@pytest.mark.parametrize("K", [10, 12, 24])
+def test_any_embedding_size(model, K, dev):
+    """--embedding_size is any integer in the reference (DeepFM.py:43); sizes the kernels do not take (K/4 not a power of two) run on
+    the next one that they do, the extra columns held at zero, and every parameter is read and written in its logical shape."""
+    F, V, B = (39, 2000, 64) if model != "afm" else (12, 800, 48)
+    ocfg, params, eng = make_pair(model, B=B, F=F, V=V, K=K, layers=(32, 16), opt="Adam", lr=1e-2, l2=1e-3)
+    assert eng.param_shapes["emb"] == (V, K)
+    ids, vals, labels = O.synth_batch(B, F, V, seed=60)
+    d = dev_batch(ids, vals, labels, dev)
+    ref = O.forward(ocfg, params, ids, vals)
+    logit = torch.empty(B, device=dev)
+    eng.predict(d[0], d[1], torch.empty(B, device=dev), logit)
+    assert np.abs(logit.cpu().numpy() - ref["y"].numpy()).max() <= 1e-4
+    oopt = O.Optimizer(ocfg, params)
+    for step in range(3):
+        ids, vals, labels = O.synth_batch(B, F, V, seed=61 + step)
+        ref_loss, _ = O.train_step(ocfg, params, oopt, ids, vals, labels)
+        loss = eng.train_step(*dev_batch(ids, vals, labels, dev))
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (step, loss, ref_loss)
+    got = eng.get_params()
+    for name, ref_p in params.items():
+        assert got[name].shape == tuple(ref_p.shape), name
+        assert np.abs(got[name] - ref_p.numpy()).max() <= 3e-6, name     # (936-wide DCN inputs at K = 24: 2.2e-6 after three lr = 1e-2 Adam steps)
+    assert np.abs(eng.get_slot("emb", 0) - oopt.slots["emb"]["m"].numpy()).max() <= 2e-6
+    eng.close()
+
+
+def test_unsupported_embedding_sizes_say_so(dev):
+    from tf_repos_amd import errors
+    from tf_repos_amd.engine import Engine, EngineConfig
+    with pytest.raises(errors.UnimplementedError):
+        Engine(EngineConfig(model="opnn", field_size=6, feature_size=100, embedding_size=10, deep_layers=(8,), dropout=(1.0,), max_batch=8))
+    with pytest.raises(errors.InvalidArgumentError):
+        Engine(EngineConfig(model="deepfm", field_size=6, feature_size=100, embedding_size=300, deep_layers=(8,), dropout=(1.0,), max_batch=8))

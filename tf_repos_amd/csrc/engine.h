@@ -25,6 +25,15 @@ struct Param {
     int n_part = 1;
     float l2 = 0.f;
     bool frozen = false;         // not trainable (BN moving statistics): the optimizer skips its blocks
+    // --embedding_size values the kernels do not take (K/4 not a power of two): the engine runs on K padded to the next such size,
+    // the padded columns / rows held at zero (they stay zero: every gradient into them is a product with a zero), and the
+    // parameter is shown to the caller in its logical shape.  kseg maps runs of `blk` logical rows (of row_elems floats) to their
+    // physical place; empty = the layout does not depend on K.
+    struct KSeg { int64_t log_off, phys_off, n_blocks, blk, stride; };
+    std::vector<KSeg> kseg;
+    int64_t k_row_elems = 1;
+    int64_t log_n = 0;
+    int64_t log_dims[4] = {1, 1, 1, 1};
 };
 
 struct Fc {
@@ -47,7 +56,8 @@ using dctr::StepState;
 
 struct dctr_engine {
     dctr_config cfg{};
-    int F = 0, K = 0, P = 0, D = 0;      // D = F*K
+    int F = 0, K = 0, P = 0, D = 0;      // D = F*K (K = the physical embedding width the kernels run on)
+    int K_log = 0;                       // --embedding_size as the caller gave it (<= K; see Param::kseg)
     int64_t rows = 0;
     int MB = 0;
     int Din = 0, Din_ld = 0;

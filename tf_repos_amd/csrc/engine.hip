@@ -1056,6 +1056,61 @@ Param* find_param(dctr_engine* E, const char* name) {
 
 }  // namespace
 
+
+// ---- parameters of a padded-K engine in their logical shape (Param::kseg) -----------------------------------------------------
+struct KSegs { Param::KSeg s[4]; int n; };
+__global__ __launch_bounds__(256) void kpad_copy_kernel(float* __restrict__ phys, float* __restrict__ logi, KSegs S, int64_t row_elems,
+                                                       int64_t log_n, int to_phys) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < log_n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / row_elems, c = i - r * row_elems;
+        int64_t pr = -1;
+        for (int k = 0; k < S.n; ++k) {
+            const Param::KSeg& g = S.s[k];
+            const int64_t q = r - g.log_off;
+            if (q >= 0 && q < g.n_blocks * g.blk) { pr = g.phys_off + (q / g.blk) * g.stride + q % g.blk; break; }
+        }
+        if (pr < 0) continue;
+        if (to_phys) phys[pr * row_elems + c] = logi[i];
+        else logi[i] = phys[pr * row_elems + c];
+    }
+}
+
+// which parameters' layouts depend on K, per model: runs of K logical rows sit at stride Kp
+static int build_k_layouts(dctr_engine* E) {
+    const int K = E->K_log, Kp = E->K, F = E->F;
+    const dctr_config& c = E->cfg;
+    for (auto& p : E->params) {
+        p.log_n = p.n;
+        for (int i = 0; i < 4; ++i) p.log_dims[i] = p.dims[i];
+        if (K == Kp) continue;
+        auto blocks = [&](int64_t n_blocks, int64_t rest, int64_t row_elems) {
+            p.k_row_elems = row_elems;
+            p.kseg.push_back({0, 0, n_blocks, K, Kp});
+            if (rest > 0) p.kseg.push_back({n_blocks * K, n_blocks * Kp, 1, rest, rest});
+            p.log_n = (n_blocks * K + rest) * row_elems;
+        };
+        const std::string& nm = p.name;
+        const bool first_layer = nm == "mlp0/weights" || nm == "ctr_mlp0/weights" || nm == "cvr_mlp0/weights";
+        if (nm == "emb") { blocks(p.dims[0], 0, 1); p.log_dims[1] = K; }
+        else if (nm == "cross_w" || nm == "cross_b") { blocks(p.dims[0] * F, 0, 1); p.log_dims[1] = (int64_t)F * K; }
+        else if (nm == "mvm_b") { blocks(F, 0, 1); p.log_dims[1] = K; }
+        else if (first_layer) {
+            const int64_t H = p.dims[1];
+            if (c.model == DCTR_MODEL_NFM) { blocks(1, 0, H); p.log_dims[0] = K; }
+            else {
+                const int64_t rest = p.dims[0] - (int64_t)F * Kp;          // IPNN's P inner products behind the flat embeddings
+                blocks(F, rest, H); p.log_dims[0] = (int64_t)F * K + rest;
+            }
+        }
+        else if (nm == "out_layer/weights" && c.model == DCTR_MODEL_DCN) { const int64_t rest = p.dims[0] - (int64_t)F * Kp; blocks(F, rest, 1); p.log_dims[0] = (int64_t)F * K + rest; }
+        else if (nm == "deep_out/weights" && c.model == DCTR_MODEL_MVM) { const int64_t rest = p.dims[0] - Kp; blocks(1, rest, 1); p.log_dims[0] = K + rest; }
+        else if (nm == "deep_out/weights" && c.model == DCTR_MODEL_AFM) { blocks(1, 0, 1); p.log_dims[0] = K; }
+        else if (nm == "att_mlp0/weights") { blocks(1, 0, p.dims[1]); p.log_dims[0] = K; }
+        else if (nm == "att_fc0/weights") { blocks(3, 0, p.dims[1]); p.log_dims[0] = 3 * (int64_t)K; }
+    }
+    return DCTR_OK;
+}
+
 extern "C" {
 
 int dctr_create(const dctr_config* cfg, dctr_handle* h) {
@@ -1063,7 +1118,29 @@ int dctr_create(const dctr_config* cfg, dctr_handle* h) {
     dctr_engine* E = new dctr_engine();
     E->cfg = *cfg;
     if (E->cfg.shard_world <= 0) { E->cfg.shard_world = 1; E->cfg.shard_rank = 0; }
-    const int rc = build(E);
+    // the reference takes any --embedding_size (DeepFM.py:43); the kernels take K/4 a power of two: other sizes run on the next
+    // such size with the extra columns held at zero (Param::kseg), at that size's cost
+    E->K_log = cfg->embedding_size;
+    if (cfg->embedding_size < 1 || cfg->embedding_size > 256) {
+        set_error("embedding_size %d outside [1, 256]", cfg->embedding_size);
+        delete E;
+        return DCTR_ERR_INVALID_ARG;
+    }
+    {
+        int kp = 4;
+        while (kp < cfg->embedding_size) kp *= 2;
+        if (kp != cfg->embedding_size) {
+            const bool ok = cfg->model != DCTR_MODEL_OPNN && !(cfg->model >= DCTR_MODEL_WIDE && cfg->model <= DCTR_MODEL_WND) && E->cfg.shard_world == 1;
+            if (!ok) {
+                set_error("embedding_size %d: Outer-PNN, the canned wide_n_deep models and row-sharded tables take K/4 a power of two (4..256)", cfg->embedding_size);
+                delete E;
+                return DCTR_ERR_UNSUPPORTED;
+            }
+            E->cfg.embedding_size = kp;
+        }
+    }
+    int rc = build(E);
+    if (rc == DCTR_OK) rc = build_k_layouts(E);
     if (rc != DCTR_OK) { dctr_destroy(E); return rc; }
     *h = E;
     return DCTR_OK;
@@ -1130,7 +1207,7 @@ int dctr_param_info(dctr_handle E, int index, const char** name, int* rank, int6
     const Param& p = E->params[index];
     if (name) *name = p.name.c_str();
     if (rank) *rank = p.rank;
-    if (dims) for (int i = 0; i < 4; ++i) dims[i] = p.dims[i];
+    if (dims) for (int i = 0; i < 4; ++i) dims[i] = p.log_dims[i];
     return DCTR_OK;
 }
 
@@ -1138,14 +1215,33 @@ static int copy_param(dctr_handle E, const char* name, int which, void* host, si
     DCTR_REQUIRE(E && host, "null argument");
     Param* p = find_param(E, name);
     if (!p) return DCTR_ERR_NOT_FOUND;
-    DCTR_REQUIRE(nbytes == (size_t)p->n * sizeof(float), "parameter '%s' holds %lld floats, caller passed %zu bytes", name,
-                 (long long)p->n, nbytes);
+    DCTR_REQUIRE(nbytes == (size_t)p->log_n * sizeof(float), "parameter '%s' holds %lld floats, caller passed %zu bytes", name,
+                 (long long)p->log_n, nbytes);
     float* d = which < 0 ? p->ptr : (which == 0 ? p->s0 : p->s1);
     DCTR_REQUIRE(d != nullptr, "parameter '%s' has no such slot", name);
     DCTR_HIP_CHECK(hipDeviceSynchronize());
     if (p->is_table && E->lag_dirty) {           // lagging rows (lag.h): the table as of global_step is what is read -- and what a write replaces
         DCTR_TRY(lag_flush_tables(E, nullptr, 0, false));
         DCTR_HIP_CHECK(hipDeviceSynchronize());
+    }
+    if (!p->kseg.empty()) {       // padded K: through a staging buffer in the logical layout
+        float* stage = nullptr;
+        DCTR_HIP_CHECK(hipMalloc(&stage, nbytes));
+        KSegs S{};
+        S.n = (int)p->kseg.size();
+        for (int k = 0; k < S.n; ++k) S.s[k] = p->kseg[k];
+        const int grid = (int)std::min<int64_t>(ceil_div(p->log_n, 256), 4096);
+        hipError_t e = hipSuccess;
+        if (to_device) {
+            e = hipMemcpy(stage, host, nbytes, hipMemcpyHostToDevice);
+            if (e == hipSuccess) { kpad_copy_kernel<<<grid, 256>>>(d, stage, S, p->k_row_elems, p->log_n, 1); e = hipDeviceSynchronize(); }
+        } else {
+            kpad_copy_kernel<<<grid, 256>>>(d, stage, S, p->k_row_elems, p->log_n, 0);
+            e = hipMemcpy(host, stage, nbytes, hipMemcpyDeviceToHost);
+        }
+        hipFree(stage);
+        if (e != hipSuccess) { set_error("parameter copy failed: %s", hipGetErrorString(e)); return DCTR_ERR_HIP; }
+        return DCTR_OK;
     }
     if (to_device) DCTR_HIP_CHECK(hipMemcpy(d, host, nbytes, hipMemcpyHostToDevice));
     else DCTR_HIP_CHECK(hipMemcpy(host, d, nbytes, hipMemcpyDeviceToHost));
@@ -1168,6 +1264,7 @@ int dctr_param_device_ptr(dctr_handle E, const char* name, float** d_ptr) {
     DCTR_REQUIRE(E && d_ptr, "null argument");
     Param* p = find_param(E, name);
     if (!p) return DCTR_ERR_NOT_FOUND;
+    if (!p->kseg.empty()) { set_error("parameter '%s' lives in a padded layout (embedding_size %d runs as %d): use dctr_param_get / _set", name, E->K_log, E->K); return DCTR_ERR_UNSUPPORTED; }
     if (p->is_table && E->lag_dirty) {
         DCTR_HIP_CHECK(hipDeviceSynchronize());
         DCTR_TRY(lag_flush_tables(E, nullptr, 0, false));
