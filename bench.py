@@ -409,6 +409,9 @@ def main():
                 g_ms, g_bytes = hbm_resident_gather(dev, K=K, B=B, F=F)
                 kernels["embed_gather_fwd"] = {"bound": "hbm", "ms": g_ms, "achieved": g_bytes / g_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                "note": "HBM-resident: 64 M-row table (4.3 GB), uniform ids, the op through the C ABI, back-to-back launches"}
+                g_ms, g_bytes = hbm_resident_gather(dev, K=32, V=32 * 1024 * 1024, B=B, F=F)
+                kernels["embed_gather_fwd_k32_hbm"] = {"bound": "hbm", "ms": g_ms, "achieved": g_bytes / g_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                       "note": "c5's row shape: K = 32 (a row = one 128-byte granule), 32 M-row table (4.4 GB), uniform ids; layouts compared in profiles/r03_gather_layouts.txt"}
         copy_gbps = e.measure_copy_bandwidth(1 << 30, 20)          # this box's measured HBM roofline (1 GiB float4 copy, read + write)
         out["hbm_measured_copy_GBps"] = round(copy_gbps, 1)
         for k in kernels.values():

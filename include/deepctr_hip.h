@@ -191,6 +191,12 @@ int dctr_embed_gather_fwd(const float* d_emb, const float* d_lin, int64_t rows,
                           int B, int F, int K, int mode,
                           float* d_e, int e_ld, float* d_yw, float* d_sum, float* d_red,
                           int32_t* d_status, void* stream);
+/* the same gather from a table held as RECORDS: row r of the embedding table starts at d_emb + r * emb_ld floats, its linear weight
+ * sits at d_lin + r * lin_ld (e.g. [row | weight | pad] records of emb_ld = lin_ld = K + 4 or 32 floats with d_lin = d_emb + K: the
+ * row-sharded exchange's packed rows, and the layouts compared in profiles/r03_gather_layouts.txt).  emb_ld % 4 == 0, emb_ld >= K. */
+int dctr_embed_gather_strided(const float* d_emb, int emb_ld, const float* d_lin, int lin_ld, int64_t rows,
+                              const int32_t* d_ids, const float* d_vals, int B, int F, int K, int mode, float* d_e, int e_ld,
+                              float* d_yw, float* d_sum, float* d_red, int32_t* d_status, void* stream);
 
 /* dctr_parse_csv over a whole buffer with `threads` workers inside the library (h_f == h_i == NULL: count the records only) */
 int dctr_parse_csv_mt(const char* h_text, size_t nbytes, int n_cols, const int8_t* kinds, const float* f_defaults,

@@ -73,6 +73,8 @@ _SIGS = {
                         C.POINTER(C.c_size_t)], C.c_int),
     "dctr_embed_gather_fwd": ([_P, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
                                _P, C.c_int, _P, _P, _P, _P, _P], C.c_int),
+    "dctr_embed_gather_strided": ([_P, C.c_int, _P, C.c_int, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   _P, C.c_int, _P, _P, _P, _P, _P], C.c_int),
     "dctr_group_create": ([C.c_int64, C.c_int64, C.c_int, C.POINTER(_P)], C.c_int),
     "dctr_group_destroy": ([_P], C.c_int),
     "dctr_group_ids": ([_P, _P, C.c_int, C.c_int, _P], C.c_int),

@@ -196,3 +196,10 @@ extern "C" int dctr_embed_gather_fwd(const float* d_emb, const float* d_lin, int
     return dctr::embed_gather_fwd(d_emb, d_lin, rows, d_ids, d_vals, B, F, K, mode, d_e, e_ld, d_yw,
                                   d_sum, d_red, d_status, dctr::as_stream(stream), nullptr);
 }
+
+extern "C" int dctr_embed_gather_strided(const float* d_emb, int emb_ld, const float* d_lin, int lin_ld, int64_t rows,
+                                         const int32_t* d_ids, const float* d_vals, int B, int F, int K, int mode, float* d_e, int e_ld,
+                                         float* d_yw, float* d_sum, float* d_red, int32_t* d_status, void* stream) {
+    return dctr::embed_gather_strided(d_emb, emb_ld, d_lin, lin_ld, rows, d_ids, d_vals, B, F, K, mode, d_e, e_ld, d_yw, d_sum, d_red,
+                                      d_status, dctr::as_stream(stream), nullptr);
+}
