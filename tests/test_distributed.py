@@ -80,6 +80,8 @@ def _shard_worker(rank, world, port, model, overlap, driver, ret):
         dev = torch.device("cuda:0")
         F, V, K, Bg = 39, 2003, 8, 128
         bn = model.endswith("+bn")          # batch_norm: the statistics are the GLOBAL batch's (cross-rank sums, dctr_set_stat_sync)
+        # "+lag": 9 steps of which only the first and the last report their loss -- in between the owners' rows lag (csrc/lag.h)
+        n_steps, loss_steps = (9, (0, 8)) if model.endswith("+lag") else (3, (0, 1, 2))
         model = model.split("+")[0]
         # (batch_norm cases step with Momentum: Adam's g / (|g| + 1e-8) turns the rounding of a nearly dead unit's 1e-9 gradient into
         #  a step of either sign -- the golden-fixture test masks such elements; a linear rule keeps the comparison at 1e-6)
@@ -93,12 +95,14 @@ def _shard_worker(rank, world, port, model, overlap, driver, ret):
         losses = []
         sl = slice(rank * (Bg // world), (rank + 1) * (Bg // world))
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a[sl])).to(dev)
-        batches = [tuple(t(a) for a in O.synth_batch(Bg, F, V, seed=300 + step)) for step in range(3)]
+        batches = [tuple(t(a) for a in O.synth_batch(Bg, F, V, seed=300 + step)) for step in range(n_steps)]
         torch.cuda.synchronize()
-        for step in range(3):
+        for step in range(n_steps):
             # with overlap, the next batch's ids are routed on the side stream while this step runs
-            nxt = batches[step + 1][0] if (overlap and step + 1 < 3) else None
-            losses.append(tr.train_step(*batches[step], want_loss=True, next_ids=nxt))
+            nxt = batches[step + 1][0] if (overlap and step + 1 < n_steps) else None
+            loss = tr.train_step(*batches[step], want_loss=step in loss_steps, next_ids=nxt)
+            if step in loss_steps:
+                losses.append(loss)
         full = tr.gather_full_params()
         ids, vals, labels = O.synth_batch(Bg, F, V, seed=999)
         prob = tr.predict(t(ids), t(vals)).cpu().numpy()
@@ -114,7 +118,8 @@ def _shard_worker(rank, world, port, model, overlap, driver, ret):
 @pytest.mark.gpu
 @pytest.mark.parametrize("model,overlap,driver", [("deepfm", False, "python"), ("deepfm", True, "python"), ("deepfm", True, "native"),
                                                   ("dcn", True, "native"), ("nfm", False, "native"),
-                                                  ("deepfm+bn", True, "native"), ("nfm+bn", False, "python")])
+                                                  ("deepfm+bn", True, "native"), ("nfm+bn", False, "python"),
+                                                  ("deepfm+lag", True, "native"), ("dcn+lag", False, "native")])
 def test_two_ranks_equal_one_rank(model, overlap, driver, dev):
     from oracle import deepctr_oracle as O
     from tests.util import dev_batch, make_pair
@@ -128,9 +133,12 @@ def test_two_ranks_equal_one_rank(model, overlap, driver, dev):
     ocfg, params, eng = make_pair(model.split("+")[0], B=Bg, F=F, V=V, K=K, layers=(32, 16), cross=2,
                                   opt="Momentum" if model.endswith("+bn") else "Adam", l2=1e-3, lr=1e-2, seed=4, batch_norm=model.endswith("+bn"))
     ref_losses = []
-    for step in range(3):
+    n_steps, loss_steps = (9, (0, 8)) if model.endswith("+lag") else (3, (0, 1, 2))
+    for step in range(n_steps):
         ids, vals, labels = O.synth_batch(Bg, F, V, seed=300 + step)
-        ref_losses.append(eng.train_step(*dev_batch(ids, vals, labels, dev)))
+        loss = eng.train_step(*dev_batch(ids, vals, labels, dev), want_loss=step in loss_steps)
+        if step in loss_steps:
+            ref_losses.append(loss)
     one = eng.get_params()
     for k in one:
         # tolerance: N ranks == 1 rank within 1e-6 (batch_norm: 5e-6, the statistics are summed in a different order)

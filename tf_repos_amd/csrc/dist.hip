@@ -474,6 +474,7 @@ int dctr_dist_train_step(dctr_dist_t D, const int32_t* d_ids, const float* d_val
     DCTR_REQUIRE(B > 0 && B <= E->MB && next_B >= 0 && next_B <= E->MB, "batch %d (next %d) outside (0, max_batch=%d]", B, next_B, E->MB);
     hipStream_t M = as_stream(stream);
     int w = 0;
+    E->want_loss = h_loss != nullptr;         // (a loss-reporting step sweeps the whole shard: its l2 term needs every row, lag.h)
     PhaseClock clk(D);
     DCTR_TRY(take_route(D, d_ids, B, M, &w));
     RouteState& r = D->rs[w];

@@ -257,8 +257,7 @@ int build(dctr_engine* E) {
         int period = c.table_sweep_period;
         if (period == 0) { const char* v = getenv("DCTR_SWEEP_PERIOD"); period = v ? atoi(v) : 8; }
         DCTR_REQUIRE(period >= 1 && period <= LAG_MAX_PERIOD, "table_sweep_period %d outside [1, %d]", period, LAG_MAX_PERIOD);
-        const bool can = c.table_mode == DCTR_TABLE_DENSE_EXACT && c.optimizer == DCTR_OPT_ADAM && !E->wnd && !E->csr && c.shard_world == 1 &&
-                         !c.use_graph;
+        const bool can = c.table_mode == DCTR_TABLE_DENSE_EXACT && c.optimizer == DCTR_OPT_ADAM && !E->wnd && !E->csr && !c.use_graph;
         E->lag_period = can ? period : 1;
         if (E->lag_period > 1) DCTR_TRY(dmalloc(&E->row_ts, (size_t)E->rows));
     }
@@ -556,6 +555,7 @@ int forward_gather(dctr_engine* E, int B, hipStream_t st) { return gather_from(E
 int forward_gather_train(dctr_engine* E, int B, hipStream_t st);
 int lag_flush_tables(dctr_engine* E, hipStream_t st, int offset, bool with_sums);
 bool lag_on(const dctr_engine* E);
+bool owner_lag(const dctr_engine* E);
 LagView lag_view(const dctr_engine* E);
 
 int forward_gather_train(dctr_engine* E, int B, hipStream_t st) {
@@ -784,6 +784,12 @@ bool tail_fused(const dctr_engine* E) {
 
 // time-blocked sweep (lag.h): is this handle's table allowed to lag in training steps?
 bool lag_on(const dctr_engine* E) { return E->lag_period > 1 && !E->lag_suspended && split_table_on(E) && tail_fused(E); }
+// the owner side of the row-sharded path (dctr_table_gather_packed / dctr_table_apply_packed) under the same scheme: its
+// shard's rows lag and are replayed exactly like the unsharded table's
+bool owner_lag(const dctr_engine* E) {
+    static const bool off = [] { const char* v = getenv("DCTR_OWNER_LAG"); return v != nullptr && v[0] == '0'; }();     // A/B knob
+    return !off && E->lag_period > 1 && !E->lag_suspended && split_table_on(E);
+}
 LagView lag_view(const dctr_engine* E) {
     return LagView{E->row_ts, E->state, reinterpret_cast<float4*>(E->emb_s0), reinterpret_cast<float4*>(E->emb_s1), E->lin_s0, E->lin_s1, E->cfg.l2_reg};
 }
@@ -1683,6 +1689,10 @@ static Group* owner_group(dctr_engine* E, int which) {
 int dctr_table_gather_packed(dctr_handle E, const int32_t* d_rows, int n, float* d_out, void* stream) {
     DCTR_REQUIRE(E && (n == 0 || (d_rows && d_out)), "null argument");
     DCTR_REQUIRE(n >= 0 && (int64_t)n <= E->group->max_entries, "too many rows requested (%d)", n);
+    if (owner_lag(E)) {           // rows may lag (lag.h): shipped as of the present
+        const LagView L = lag_view(E);
+        return pack_table_rows(E->emb, E->lin, E->rows, E->K, d_rows, n, d_out, E->status, as_stream(stream), &L);
+    }
     return pack_table_rows(E->emb, E->lin, E->rows, E->K, d_rows, n, d_out, E->status, as_stream(stream));
 }
 
@@ -1691,7 +1701,7 @@ int dctr_table_group_rows(dctr_handle E, int which, const int32_t* d_rows, int n
     Group* G = owner_group(E, which);
     DCTR_REQUIRE(G != nullptr, "owner group allocation failed");
     DCTR_REQUIRE(n >= 0 && (int64_t)n <= G->max_entries, "too many rows (%d)", n);
-    return group_ids(G, n > 0 ? d_rows : E->ids, n, 1, as_stream(stream));
+    return group_ids(G, n > 0 ? d_rows : E->ids, n, 1, as_stream(stream), !owner_lag(E));
 }
 
 int dctr_table_apply_packed(dctr_handle E, int which, int n, const float* d_grads, void* stream) {
@@ -1702,6 +1712,25 @@ int dctr_table_apply_packed(dctr_handle E, int which, int n, const float* d_grad
     hipStream_t st = as_stream(stream);
     const dctr_config& c = E->cfg;
     const int P = E->K + 4;
+    const bool lag = owner_lag(E);
+    if (lag && !E->want_loss && G->gemb_clean) {
+        // time-blocked sweep (lag.h): one block of this shard's untouched rows advances to the step, the rows that received
+        // gradients are advanced to t-1, stepped and stamped by the fused scatter + optimizer launch
+        E->lag_dirty = true;
+        DCTR_TRY(lag_sweep(E->K, E->rows, E->emb, E->emb_s0, E->emb_s1, E->lin, E->lin_s0, E->lin_s1, G->slot, E->row_ts, E->state, c.l2_reg,
+                           E->lag_period, st));
+        if (n > 0)
+            DCTR_TRY(embed_scatter_apply(G, c.optimizer, &E->state->hyper, E->h_state.hyper, E->emb, E->emb_s0, E->emb_s1, E->lin, E->lin_s0,
+                                         E->lin_s1, c.l2_reg, nullptr, nullptr, d_grads, P, nullptr, 0, nullptr, nullptr,
+                                         E->lin ? d_grads + E->K : nullptr, E->ones, n, 1, E->K, DCTR_GATHER_RAW, st, P, nullptr, E->row_ts, E->state));
+        return DCTR_OK;
+    }
+    // a loss-reporting step needs sum theta^2 of every row (and a group whose compact rows a plain scatter has used cannot take the
+    // fused launch): all rows to t-1, the classic sweep below (which sums), all stamped t
+    if (lag) {
+        DCTR_TRY(lag_flush_tables(E, st, -1, false));
+        DCTR_TRY(lag_stamp(E->row_ts, E->rows, E->state, st));
+    }
     if (n > 0)      // n "examples" of one field each, value 1: dE = the record's K gradient floats, dy = its linear-weight gradient
         DCTR_TRY(embed_scatter_bwd(G, d_grads, P, nullptr, 0, nullptr, nullptr, E->lin ? d_grads + E->K : nullptr, E->ones, n, 1, E->K,
                                    DCTR_GATHER_RAW, G->gemb, E->lin ? G->glin : nullptr, st, P));

@@ -81,7 +81,7 @@ int embed_gather_strided(const float* emb, int emb_ld, const float* lin, int lin
 
 // ---- shard.hip: packed [K+4]-float row records for the row-sharded exchange
 int pack_table_rows(const float* emb, const float* lin, int64_t rows, int K, const int32_t* rows_idx, int n, float* out,
-                    int32_t* status, hipStream_t st);
+                    int32_t* status, hipStream_t st, const LagView* lag = nullptr);
 int pack_unique_grads(const Group* g, const float* glin, const int32_t* upos, float* out, hipStream_t st);
 
 // ---- K6 (gemm.hip)

@@ -5,6 +5,7 @@
 // every example).
 #include "common.h"
 #include "ops.h"
+#include "lag.h"
 
 namespace dctr {
 
@@ -101,6 +102,40 @@ __global__ __launch_bounds__(256) void pack_table_rows_kernel(const float4* __re
     out[(size_t)i * Q + q] = v;
 }
 
+// the same from a table whose rows may lag (lag.h): the row is advanced to the present (state->t) in registers before it is
+// shipped; nothing is written back (the touched-rows step of the batch redoes it and stores)
+__global__ __launch_bounds__(256) void pack_table_rows_lag_kernel(const float4* __restrict__ emb, const float* __restrict__ lin,
+                                                                 int64_t rows, const int32_t* __restrict__ rows_idx, int n, int KQ,
+                                                                 float4* __restrict__ out, int32_t* __restrict__ status, LagView L) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Q = KQ + 1;
+    const int i = (int)(t / Q), q = (int)(t % Q);
+    if (i >= n) return;
+    const int r = rows_idx[i];
+    const bool ok = r >= 0 && (int64_t)r < rows;
+    if (!ok && q == 0) { atomicExch(&status[1], r); atomicExch(&status[0], 1); }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+        const int64_t T = L.state->t;
+        const int nl = lag_behind(T, L.ts[r]);
+        const Hyper h = L.state->hyper;
+        if (q < KQ) {
+            v = emb[(size_t)r * KQ + q];
+            if (nl > 0) {
+                float4 m = L.s0[(size_t)r * KQ + q], vv = L.s1[(size_t)r * KQ + q];
+                lag_catch_up4(L.state, h, L.l2, T - nl + 1, nl, v, m, vv);
+            }
+        } else if (lin != nullptr) {
+            v.x = lin[r];
+            if (nl > 0) {
+                float m = L.l0[r], vv = L.l1[r];
+                lag_catch_up1(L.state, h, L.l2, T - nl + 1, nl, v.x, m, vv);
+            }
+        }
+    }
+    out[(size_t)i * Q + q] = v;
+}
+
 // requester side: out[upos[u]] = { gemb[u, :], glin[u], 0, 0, 0 } for u < U (U read from device memory)
 __global__ __launch_bounds__(256) void pack_unique_grads_kernel(const float4* __restrict__ gemb, const float* __restrict__ glin,
                                                                const int32_t* __restrict__ upos, const int32_t* __restrict__ counters,
@@ -116,9 +151,15 @@ __global__ __launch_bounds__(256) void pack_unique_grads_kernel(const float4* __
 }
 
 int pack_table_rows(const float* emb, const float* lin, int64_t rows, int K, const int32_t* rows_idx, int n, float* out,
-                    int32_t* status, hipStream_t st) {
+                    int32_t* status, hipStream_t st, const LagView* lag) {
     if (n <= 0) return DCTR_OK;
     const int KQ = K / 4;
+    if (lag != nullptr) {
+        pack_table_rows_lag_kernel<<<ceil_div((int64_t)n * (KQ + 1), 256), 256, 0, st>>>(reinterpret_cast<const float4*>(emb), lin, rows, rows_idx,
+                                                                                       n, KQ, reinterpret_cast<float4*>(out), status, *lag);
+        DCTR_LAUNCH_CHECK();
+        return DCTR_OK;
+    }
     pack_table_rows_kernel<<<ceil_div((int64_t)n * (KQ + 1), 256), 256, 0, st>>>(reinterpret_cast<const float4*>(emb), lin, rows, rows_idx,
                                                                                n, KQ, reinterpret_cast<float4*>(out), status);
     DCTR_LAUNCH_CHECK();

@@ -178,7 +178,10 @@ class ShardedTrainer:
                                        l2_reg=w["l2_reg"], learning_rate=w["learning_rate"], optimizer=w["optimizer"],
                                        table_mode=table_mode, max_batch=self.B, seed=seed, shard_rank=rank, shard_world=world,
                                        use_graph=False, batch_norm=bool(w.get("batch_norm", False)),
-                                       batch_norm_decay=float(w.get("batch_norm_decay", 0.9))))
+                                       batch_norm_decay=float(w.get("batch_norm_decay", 0.9)),
+                                       # (the Python orchestration is the readable reference of the protocol: it keeps the classic
+                                       #  sweep of every owned row every step; the native driver's owner side lags, csrc/lag.h)
+                                       table_sweep_period=(int(w.get("table_sweep_period", 0)) if self.driver == "native" else 1)))
         self._lib = capi.lib()
         self._h = self.eng._h
         self.init_params(params, init_scale, seed)
