@@ -54,6 +54,7 @@ for name, c in CONFIGS.items():
     t0 = time.perf_counter()
     for s in range(steps_c):
         eng.train_step(*batches[s % 4], want_loss=False)
+    eng.sync_tables()          # (time-blocked table sweep: every row's updates of the timed steps computed inside the timed region)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     print(json.dumps({"config": name, "ms_per_step": round(1e3 * el / steps_c, 4), "examples_per_sec": round(c["B"] * steps_c / el, 1)}), flush=True)
