@@ -43,12 +43,19 @@ __global__ __launch_bounds__(256) void afm_pair_fwd_kernel(const float4* __restr
 }
 
 // one block per example: softmax over the P scores, attention dropout, pooling over the pairs, y_emb dropout
+// (ee != nullptr: the pair products are rebuilt from the example's embeddings, staged in LDS behind the weights -- 40 KB read per
+//  example instead of its 759 KB slice of the [B P, K] pair tensor, K = 256)
 __global__ __launch_bounds__(256) void afm_pool_fwd_kernel(const float* __restrict__ sc, const float* __restrict__ pp, int P, int K,
                                                           float keep_att, float keep_emb, const uint64_t* __restrict__ seed_ptr,
-                                                          int train, float* __restrict__ att, float* __restrict__ yemb) {
-    extern __shared__ float sm[];        // [P] attention weights (after dropout)
+                                                          int train, float* __restrict__ att, float* __restrict__ yemb,
+                                                          const float4* __restrict__ ee, int e_ld4, int F, const int16_t* __restrict__ pi,
+                                                          const int16_t* __restrict__ pj) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];        // [P] attention weights (after dropout) | [F][K] embeddings (ee)
     __shared__ float red[4];
     const int b = blockIdx.x, t = threadIdx.x;
+    float4* es = reinterpret_cast<float4*>(sm + ((P + 3) & ~3));
+    if (ee != nullptr)
+        for (int x = t; x < F * (K >> 2); x += 256) es[x] = ee[(size_t)b * e_ld4 + x];
     const float* s = sc + (size_t)b * P;
     float m = -3.0e38f;
     for (int p = t; p < P; p += 256) m = fmaxf(m, s[p]);
@@ -78,7 +85,13 @@ __global__ __launch_bounds__(256) void afm_pool_fwd_kernel(const float* __restri
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int p = slice; p < P; p += n_slices) {
         const float a = sm[p];
-        const float4 v = pp4[(size_t)p * KQ + q];
+        float4 v;
+        if (ee != nullptr) {
+            const float4 x = es[pi[p] * KQ + q], y = es[pj[p] * KQ + q];
+            v = make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
+        } else {
+            v = pp4[(size_t)p * KQ + q];
+        }
         acc.x += a * v.x; acc.y += a * v.y; acc.z += a * v.z; acc.w += a * v.w;
     }
     acc4[t] = acc;
@@ -98,12 +111,16 @@ __global__ __launch_bounds__(256) void afm_pool_fwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void afm_pool_bwd_kernel(float* __restrict__ dy, int dy_ld, const float* __restrict__ pp,
                                                           const float* __restrict__ att, int P, int K, float keep_att, float keep_emb,
                                                           const uint64_t* __restrict__ seed_ptr, float* __restrict__ dsc,
-                                                          float* __restrict__ att_drop) {
-    extern __shared__ float sm[];        // [K] dyemb (pre-dropout gradient) | [P] da
+                                                          float* __restrict__ att_drop, const float4* __restrict__ ee, int e_ld4, int F,
+                                                          const int16_t* __restrict__ pi, const int16_t* __restrict__ pj) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];        // [K] dyemb (pre-dropout gradient) | [P] da | [F][K] embeddings (ee)
     __shared__ float red[4];
     float* dye = sm;
     float* da = sm + K;
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float4* es = reinterpret_cast<float4*>(sm + ((K + P + 3) & ~3));
+    if (ee != nullptr)
+        for (int x = t; x < F * (K >> 2); x += 256) es[x] = ee[(size_t)b * e_ld4 + x];
     const uint64_t seed = (keep_att < 1.f || keep_emb < 1.f) ? *seed_ptr : 0ull;
     for (int k = t; k < K; k += 256) {
         float g = dy[(size_t)b * dy_ld + k];
@@ -120,7 +137,13 @@ __global__ __launch_bounds__(256) void afm_pool_bwd_kernel(float* __restrict__ d
     float part = 0.f;                                          // sum_q att[q] * da[q]
     for (int i = t; i < P * KQ; i += 256) {
         const int p = i / KQ;
-        const float4 v = pp4[i];
+        float4 v;
+        if (ee != nullptr) {
+            const float4 x = es[pi[p] * KQ + q], y = es[pj[p] * KQ + q];
+            v = make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
+        } else {
+            v = pp4[i];
+        }
         float s = d4.x * v.x + d4.y * v.y + d4.z * v.z + d4.w * v.w;
         for (int o = 1; o < KQ; o <<= 1) s += __shfl_xor(s, o);
         if (q == 0) {
@@ -160,6 +183,64 @@ __global__ __launch_bounds__(256) void afm_pair_bwd_kernel(const float* __restri
         s += (ad[p] * dk + c[(size_t)p * K + k]) * eb[j * K + k];
     }
     dE[(size_t)b * de_ld + x] = s;
+}
+
+// The same with float4 pieces and four pairs in flight per thread (the loop above issues one 4-byte load per pair and waits for
+// it: 1.1 TB/s on 6 GB at the reference's K = 256, B = 4096).  Thread = (field i, piece kq) of one example; every row of g2 is
+// still read twice (once from each of its fields' side) -- a one-pass variant that folded both contributions into an LDS
+// accumulator with ds_add_f32 measured 2x SLOWER than the loop above (the float atomics serialise).
+template <int KQ>
+__global__ __launch_bounds__(256) void afm_pair_bwd_v4_kernel(const float4* __restrict__ e, int e_ld4, const float* __restrict__ att_drop,
+                                                             const float* __restrict__ dye, int dye_ld, const float4* __restrict__ g2,
+                                                             int F, int P, float4* __restrict__ dE, int de_ld4) {
+    const int b = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= F * KQ) return;
+    const int i = x / KQ, kq = x - i * KQ;
+    const float4* eb = e + (size_t)b * e_ld4;
+    const float* ad = att_drop + (size_t)b * P;
+    const float4* c = g2 + (size_t)b * P * KQ;
+    const float4 dk = reinterpret_cast<const float4*>(dye + (size_t)b * dye_ld)[kq];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    // partner fields j = 0 .. F-1 except i, four at a time
+    for (int j0 = 0; j0 < F; j0 += 4) {
+        float4 v[4], ej[4]; float a[4]; bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u;
+            on[u] = j < F && j != i;
+            const int jc = on[u] ? j : (i == 0 ? 1 : 0);                 // (clamped to a valid partner: the loads carry no branch)
+            const int lo = jc < i ? jc : i, hi = jc < i ? i : jc;
+            const int p = lo * F - (lo * (lo + 1)) / 2 + (hi - lo - 1);
+            v[u] = c[(size_t)p * KQ + kq];
+            a[u] = ad[p];
+            ej[u] = eb[jc * KQ + kq];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (on[u]) {
+                s.x += (a[u] * dk.x + v[u].x) * ej[u].x; s.y += (a[u] * dk.y + v[u].y) * ej[u].y;
+                s.z += (a[u] * dk.z + v[u].z) * ej[u].z; s.w += (a[u] * dk.w + v[u].w) * ej[u].w;
+            }
+    }
+    dE[(size_t)b * de_ld4 + x] = s;
+}
+
+int afm_pair_bwd(const float* e, int e_ld, const float* att_drop, const float* dye, int dye_ld, const float* g2, const int16_t* pair_i,
+                 const int16_t* pair_j, int B, int F, int K, int P, float* dE, int de_ld, hipStream_t st) {
+    (void)pair_i; (void)pair_j;
+    static const bool old = getenv("DCTR_AFM_PAIR_BWD_OLD") != nullptr;          // A/B knob: the one-load-per-pair kernel
+    if (!old && F >= 2 && e_ld % 4 == 0 && de_ld % 4 == 0 && dye_ld % 4 == 0) {
+        dim3 grid(ceil_div(F * (K / 4), 256), B);
+#define DCTR_PB(Q) case Q: afm_pair_bwd_v4_kernel<Q><<<grid, 256, 0, st>>>(reinterpret_cast<const float4*>(e), e_ld / 4, att_drop, dye, dye_ld, \
+                                     reinterpret_cast<const float4*>(g2), F, P, reinterpret_cast<float4*>(dE), de_ld / 4); DCTR_LAUNCH_CHECK(); return DCTR_OK;
+        switch (K / 4) { DCTR_PB(1) DCTR_PB(2) DCTR_PB(4) DCTR_PB(8) DCTR_PB(16) DCTR_PB(32) DCTR_PB(64) default: break; }
+#undef DCTR_PB
+    }
+    dim3 grid(ceil_div(F * K, 256), B);
+    afm_pair_bwd_kernel<<<grid, 256, 0, st>>>(e, e_ld, att_drop, dye, dye_ld, g2, F, K, P, dE, de_ld);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
 }
 
 }  // namespace dctr
@@ -258,7 +339,6 @@ int afm_forward(dctr_engine* E, int B, bool train, hipStream_t st) {
     afm_pair_fwd_kernel<<<ceil_div(n4, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(E->e), E->e_ld / 4, E->pair_i, E->pair_j, B,
                                                             P, KQ, reinterpret_cast<float4*>(E->pairp));
     DCTR_LAUNCH_CHECK();
-    (void)F;
     if (E->afm_fused) {
         // scores straight from the pair products (the hidden layer never leaves the registers; the backward recomputes it)
         DCTR_TRY(afm_att_fwd(E->pairp, E->pp(E->p_att_w), E->pp(E->p_att_b), E->pp(E->p_ao_w), E->pp(E->p_ao_b), (int64_t)B * P, K, A, E->sc, st));
@@ -271,9 +351,17 @@ int afm_forward(dctr_engine* E, int B, bool train, hipStream_t st) {
         }
         DCTR_TRY(rowdot(E->ah, A, E->pp(E->p_ao_w), E->pp(E->p_ao_b), B * P, A, E->sc, 0, st));
     }
-    afm_pool_fwd_kernel<<<B, 256, (size_t)P * sizeof(float), st>>>(E->sc, E->pairp, P, K, E->keep_att, E->keep_emb, &E->state->seed_t,
-                                                                   train ? 1 : 0, E->att, E->x_in);
-    DCTR_LAUNCH_CHECK();
+    {
+        // the pooling rebuilds the pair products from the example's embeddings when they fit LDS beside its working set
+        const size_t lds_pp = (size_t)P * sizeof(float), lds_e = (size_t)(((P + 3) & ~3) + F * K) * sizeof(float);
+        const bool from_e = lds_e <= 150 * 1024 && E->e_ld % 4 == 0;
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(afm_pool_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        DCTR_HIP_CHECK(attr);
+        afm_pool_fwd_kernel<<<B, 256, from_e ? lds_e : lds_pp, st>>>(E->sc, E->pairp, P, K, E->keep_att, E->keep_emb, &E->state->seed_t,
+                                                                     train ? 1 : 0, E->att, E->x_in,
+                                                                     from_e ? reinterpret_cast<const float4*>(E->e) : nullptr, E->e_ld / 4, F, E->pair_i, E->pair_j);
+        DCTR_LAUNCH_CHECK();
+    }
     return DCTR_OK;      // the fc(K -> 1) output layer is fused into the head kernel
 }
 
@@ -286,9 +374,19 @@ int afm_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
     DCTR_TRY(out_layer_bwd(E->x_in, E->Din_ld, E->dy, E->pp(E->p_out_w), B, K, pw.n_part, 0, 1.f, E->dx_in, E->Din_ld,
                            E->part(E->p_out_w), pw.padded, E->part(E->p_out_b), pb.padded, st));
     // (E->sc, the forward's scores, is free by now: it takes the post-dropout attention)
-    afm_pool_bwd_kernel<<<B, 256, (size_t)(K + P) * sizeof(float), st>>>(E->dx_in, E->Din_ld, E->pairp, E->att, P, K, E->keep_att, E->keep_emb,
-                                                                         &E->state->seed_t, E->dsc, E->sc);
-    DCTR_LAUNCH_CHECK();
+    {
+        const size_t lds_pp = (size_t)(K + P) * sizeof(float), lds_e = (size_t)(((K + P + 3) & ~3) + F * K) * sizeof(float);
+        // (rebuilding the pair products from LDS-staged embeddings pays in the forward pooling, 0.51 -> 0.24 ms at K = 256, but not
+        //  here: 0.66 -> 0.85 ms, the 40 KB of LDS per block cost more occupancy than the 759 KB read saves; DCTR_AFM_POOL_BWD_E=1)
+        static const bool want_e = getenv("DCTR_AFM_POOL_BWD_E") != nullptr;
+        const bool from_e = want_e && lds_e <= 150 * 1024 && E->e_ld % 4 == 0;
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(afm_pool_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        DCTR_HIP_CHECK(attr);
+        afm_pool_bwd_kernel<<<B, 256, from_e ? lds_e : lds_pp, st>>>(E->dx_in, E->Din_ld, E->pairp, E->att, P, K, E->keep_att, E->keep_emb,
+                                                                     &E->state->seed_t, E->dsc, E->sc,
+                                                                     from_e ? reinterpret_cast<const float4*>(E->e) : nullptr, E->e_ld / 4, F, E->pair_i, E->pair_j);
+        DCTR_LAUNCH_CHECK();
+    }
     const Param& aw = E->params[E->p_ao_w];
     const Param& ab = E->params[E->p_ao_b];
     if (E->afm_fused) {
@@ -297,10 +395,7 @@ int afm_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
         DCTR_TRY(afm_att_bwd(E->pairp, E->pp(E->p_att_w), E->pp(E->p_att_b), E->pp(E->p_ao_w), E->dsc, (int64_t)B * P, K, A, E->dpairp2,
                              E->part(E->p_att_w), w.padded, E->part(E->p_att_b), b.padded, E->part(E->p_ao_w), aw.padded,
                              E->part(E->p_ao_b), ab.padded, AFM_SLABS, st));
-        dim3 grid(ceil_div(F * K, 256), B);
-        afm_pair_bwd_kernel<<<grid, 256, 0, st>>>(E->e, E->e_ld, E->sc, E->dx_in, E->Din_ld, E->dpairp2, F, K, P, E->dE_buf, E->D);
-        DCTR_LAUNCH_CHECK();
-        return DCTR_OK;
+        return afm_pair_bwd(E->e, E->e_ld, E->sc, E->dx_in, E->Din_ld, E->dpairp2, E->pair_i, E->pair_j, B, F, K, P, E->dE_buf, E->D, st);
     }
     // attention_out (A -> 1) over the B*P rows: d ah = dsc (x) w_o masked by relu, dW_o / db_o partial slabs
     DCTR_TRY(out_layer_bwd(E->ah, A, E->dsc, E->pp(E->p_ao_w), B * P, A, aw.n_part, 1, 1.f, E->dah, A, E->part(E->p_ao_w), aw.padded,
@@ -317,8 +412,5 @@ int afm_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
         if (l > 0) DCTR_TRY(fc_bwd_data(E->dahs[l], fc.out, E->pp(fc.w), E->dahs[l - 1], fc.in, B * P, fc.in, fc.out, E->ahs[l - 1], fc.in, 1.f, st));
         else DCTR_TRY(fc_bwd_data(E->dahs[0], fc.out, E->pp(fc.w), E->dpairp2, K, B * P, K, fc.out, nullptr, 0, 1.f, st));
     }
-    dim3 grid(ceil_div(F * K, 256), B);
-    afm_pair_bwd_kernel<<<grid, 256, 0, st>>>(E->e, E->e_ld, E->sc, E->dx_in, E->Din_ld, E->dpairp2, F, K, P, E->dE_buf, E->D);
-    DCTR_LAUNCH_CHECK();
-    return DCTR_OK;
+    return afm_pair_bwd(E->e, E->e_ld, E->sc, E->dx_in, E->Din_ld, E->dpairp2, E->pair_i, E->pair_j, B, F, K, P, E->dE_buf, E->D, st);
 }

@@ -139,8 +139,11 @@ __device__ __forceinline__ void dr_reduce_tiles(f32x4 (&acc)[TM][TN], float* lds
     }
 }
 
+// (the 2 x 8 weight-gradient variant is compiled for TWO blocks per CU: it is the tile of choice when the reduction runs over
+//  millions of rows that stream from HBM -- AFM's attention weight over 3 M pair rows -- where one resident block per CU, one
+//  16-row group of prefetch ahead of its MFMAs, spends more time waiting for memory than multiplying)
 template <int TM, int TN, bool A_RC, bool B_RC, bool CS, int EPI, int AGEN = DR_AGEN_NONE>
-__global__ __launch_bounds__(256, 1) void gemm_dr_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+__global__ __launch_bounds__(256, (CS && TM * TN <= 16) ? 2 : 1) void gemm_dr_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                          float* __restrict__ C, int ldc, int M, int N, int K, int kchunk, int nbn,
                                                          DrEpilogue ep, DrOuter og) {
     static_assert(AGEN == DR_AGEN_NONE || (AGEN == DR_AGEN_OUTER_FWD && A_RC) || (AGEN == DR_AGEN_OUTER_WGRAD && !A_RC), "generated A: fwd is RC, wgrad is NC");
@@ -151,19 +154,25 @@ __global__ __launch_bounds__(256, 1) void gemm_dr_kernel(const float* __restrict
     extern __shared__ __attribute__((aligned(16))) float dr_lds[];
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int c = lane & 15, q = lane >> 4;
-    int bm, bn;
-    {   // XCD-aware order: hardware puts linear block b on XCD b % 8; every XCD gets a contiguous run of tiles (n fastest) so the
-        // blocks sharing an A row-panel sit behind the same L2.  Speed only: any placement computes the same result.
-        const int nwg = gridDim.x, b = blockIdx.x;
+    int bm, bn, split;
+    {   // XCD-aware order: hardware puts linear block b (x fastest, then y) on XCD b % 8; every XCD gets a contiguous run of
+        // (split, tile) pairs -- split slowest, n fastest -- so the blocks sharing an A row-panel, and the tiles of one reduction
+        // split (which all stream the SAME rows of both operands: the weight gradients), sit behind the same L2.  Before round 3
+        // only x was remapped: XCD k then held tile column k of EVERY split and each operand row crossed the fabric once per XCD
+        // (PMC: 69 MB per launch for 20 MB of operands at c2's first layer; AFM's 3 M-row weight gradient re-read its 3.1 GB
+        // operand 8 times).  Speed only: any placement computes the same result.
+        const int nwg = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
         const int qq = nwg / 8, r = nwg % 8, xcd = b % 8, idx = b / 8;
         const int lb = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
-        bn = lb % nbn;
-        bm = lb / nbn;
+        split = __builtin_amdgcn_readfirstlane(lb / (int)gridDim.x);
+        const int tile = lb - split * (int)gridDim.x;
+        bn = tile % nbn;
+        bm = tile / nbn;
     }
     DR_STAMP(0);
     __builtin_amdgcn_s_setprio(3);          // the step runs background kernels beside the MLP: GEMM waves go first at the issue arbiter
     const int m0 = bm * 16 * TM, n0 = bn * 16 * TN;
-    const int kb0 = blockIdx.y * kchunk, kb1 = min(K, kb0 + kchunk);
+    const int kb0 = split * kchunk, kb1 = min(K, kb0 + kchunk);
     // (wave-uniform by construction; the readfirstlane's make the compiler believe it -- a scalar offset or descriptor it cannot
     // PROVE uniform gets every buffer load wrapped in a waterfall loop: ~10 instructions per load, no overlap between loads)
     const int kw = ((max(kb1 - kb0, 0) + 15) / 16) * 4;                 // k per wave, a multiple of 4
@@ -431,7 +440,7 @@ __global__ __launch_bounds__(256, 1) void gemm_dr_kernel(const float* __restrict
         }
         __syncthreads();
         if (t < 16 * TN && n0 + t < N)
-            ep.colsum[(size_t)blockIdx.y * ep.colsum_stride + n0 + t] = dr_lds[t] + dr_lds[16 * TN + t] + dr_lds[32 * TN + t] + dr_lds[48 * TN + t];
+            ep.colsum[(size_t)split * ep.colsum_stride + n0 + t] = dr_lds[t] + dr_lds[16 * TN + t] + dr_lds[32 * TN + t] + dr_lds[48 * TN + t];
         __syncthreads();
     }
 
@@ -462,7 +471,7 @@ __global__ __launch_bounds__(256, 1) void gemm_dr_kernel(const float* __restrict
     // dropout or the ReLU mask are applied here.
     constexpr int NIT = (16 * TM + RPI - 1) / RPI;
     const int gn = n0 + 4 * tc;
-    float* Cz = C + (EPI == DR_STORE ? (size_t)blockIdx.y * ep.split_stride : 0);
+    float* Cz = C + (EPI == DR_STORE ? (size_t)split * ep.split_stride : 0);
     uint64_t seed = 0;
     if (EPI == DR_BIAS_ACT) seed = ep.seed ^ (ep.seed_ptr ? *ep.seed_ptr : 0ull);
     // fast path: every float4 of the tile is either whole or absent, and 16-byte aligned on both sides

@@ -125,6 +125,14 @@ constexpr Tile WGRAD_TILES[] = {{2, 13}, {2, 16}, {2, 8}};
 
 // Which kernel a layer product of this shape takes (host logic only, no launch): "ws" (gemm_ws.hip), "dr TMxTN[ xS]" or "lds[ xS]".  Alignment is
 // assumed (16-byte bases, leading dimensions multiples of 4), as the engine's buffers have it.
+// a reduction over this many rows streams its operands from HBM (no cache holds them): the 2 x 8 tile, two blocks per CU
+inline bool streaming_rows(int64_t M, int K = 32, int N = 128) {
+    // measured on AFM's attention weight (3 M pair rows, 256 x 256): 8.5 ms against 6.5 ms for the 2 x 16 tile at one block per CU --
+    // the second column block re-reads the 3.1 GB operand; kept as an A/B knob (DCTR_WGRAD_STREAM=1)
+    static const bool on = getenv("DCTR_WGRAD_STREAM") != nullptr;
+    return on && M >= (1 << 20) && K >= 32 && N >= 128;                         // (whole 32 x 128 tiles)
+}
+int dr_wgrad_splits(int M, int K, int N);
 int gemm_plan(char op, int M, int K, int N, char* out, int out_len) {
     double eff = 0.0;
     int t = -1, s = 1;
@@ -141,7 +149,10 @@ int gemm_plan(char op, int M, int K, int N, char* out, int out_len) {
         }
     } else if (op == 'w') {
         s = choose_wgrad_splits(M, K, N);
-        if (dr_wgrad_splits(M, K, N) == s && s > 0 && (int64_t)ceil_div(M, s) >= 64 && (N & 3) == 0) {
+        if (dr_wgrad_splits(M, K, N) == s && s > 0 && (int64_t)ceil_div(M, s) >= 64 && (N & 3) == 0 && streaming_rows(M, K, N) &&
+            (int64_t)ceil_div(K, 32) * ceil_div(N, 128) * s <= 2 * CUS) {
+            tile = &WGRAD_TILES[2];           // millions of rows from HBM: 2 x 8, two blocks per CU
+        } else if (dr_wgrad_splits(M, K, N) == s && s > 0 && (int64_t)ceil_div(M, s) >= 64 && (N & 3) == 0) {
             t = pick(WGRAD_TILES, K, N, M, s, &eff);
             int blocks = 0;
             if (t >= 0) dr_efficiency(K, N, M, s, WGRAD_TILES[t], &blocks);
@@ -210,6 +221,10 @@ int dr_fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int ldd
 // the chip (0: no tile of the list fits this shape well -> the LDS-tiled kernel and its own split rule)
 int dr_wgrad_splits(int M, int K, int N) {
     if (!dr_enabled('w') || M < 256) return 0;
+    if (streaming_rows(M, K, N)) {
+        const int tiles = ceil_div(K, 32) * ceil_div(N, 128);
+        if (tiles <= 2 * CUS) return std::max(1, 2 * CUS / tiles);
+    }
     int best_s = 0;
     double best = 0.0;
     for (const Tile& t : WGRAD_TILES) {
@@ -232,11 +247,15 @@ int dr_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int ldd
         !al16(dw_part) || (dw_stride & 3))
         return DCTR_OK;
     double eff;
-    const int t = pick(WGRAD_TILES, K, N, M, splits, &eff);
-    if (t < 0 || eff < dr_threshold()) return DCTR_OK;
-    int blocks = 0;
-    dr_efficiency(K, N, M, splits, WGRAD_TILES[t], &blocks);
-    if (blocks > CUS) return DCTR_OK;
+    int t = pick(WGRAD_TILES, K, N, M, splits, &eff);
+    const bool stream = streaming_rows(M, K, N) && (int64_t)ceil_div(K, 32) * ceil_div(N, 128) * splits <= 2 * CUS;
+    if (stream) t = 2;
+    else {
+        if (t < 0 || eff < dr_threshold()) return DCTR_OK;
+        int blocks = 0;
+        dr_efficiency(K, N, M, splits, WGRAD_TILES[t], &blocks);
+        if (blocks > CUS) return DCTR_OK;
+    }
     DrEpilogue ep{};
     ep.split_stride = dw_stride;
     ep.colsum = db_part;

@@ -10,9 +10,9 @@ export TMPDIR=/tmp
 cd /tmp
 # PMC="FETCH_SIZE" (one counter set per run, never together with other trace domains): mean counter value per dispatch instead
 if [ -n "${PMC:-}" ]; then
-    timeout $LIM rocprofv3 --kernel-trace --pmc $PMC -d $OUT/trace -o $TAG -- "$@" > $OUT/cmd.out 2> $OUT/trace.err
+    timeout $LIM rocprofv3 --kernel-trace --pmc $PMC -d $OUT/trace -o $TAG -- env -C $R "$@" > $OUT/cmd.out 2> $OUT/trace.err
 else
-    timeout $LIM rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG -- "$@" > $OUT/cmd.out 2> $OUT/trace.err
+    timeout $LIM rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG -- env -C $R "$@" > $OUT/cmd.out 2> $OUT/trace.err
 fi
 cd $R
 if [ -f $OUT/trace/${TAG}_results.db ]; then
