@@ -55,7 +55,11 @@ def test_slot_names_follow_tf(tmp_path):
     st = T.bundle_to_state(t, "Adam")
     assert "fm_v/slot0" in st and "fm_v/slot1" in st and "fm_v/Adam" not in st and "fm_w" in st
     back = T.state_to_bundle(st, "Adam")
-    assert set(back) == set(t) and np.array_equal(back["fm_v/Adam_1"], t["fm_v/Adam_1"])
+    # AdamOptimizer's non-slot variables travel too (a TF training graph's Saver asks for them): beta^global_step
+    assert set(back) == set(t) | {"beta1_power", "beta2_power"} and np.array_equal(back["fm_v/Adam_1"], t["fm_v/Adam_1"])
+    gs = int(np.asarray(t["global_step"]))
+    assert abs(float(back["beta1_power"]) - 0.9 ** gs) < 1e-6 and abs(float(back["beta2_power"]) - 0.999 ** gs) < 1e-6
+    assert "beta1_power" not in T.bundle_to_state(back, "Adam")
     ftrl = T.state_to_bundle({"w": np.ones(3, np.float32), "w/slot0": np.ones(3, np.float32), "w/slot1": np.zeros(3, np.float32)}, "ftrl")
     assert set(ftrl) == {"w", "w/Ftrl", "w/Ftrl_1"}
     assert set(T.state_to_bundle({"w": np.ones(3, np.float32), "w/slot0": np.ones(3, np.float32), "w/slot1": np.zeros(3, np.float32)}, "Adagrad")) == {"w", "w/Adagrad"}

@@ -216,6 +216,9 @@ class ShardedTrainer:
 
         def cb(ctx, ch, d_buf, n, stream):
             try:
+                # the reduction runs on torch's current stream: that must be the stream the engine enqueues the step on
+                if int(stream or 0) != int(torch.cuda.current_stream().cuda_stream):
+                    raise RuntimeError("batch_norm statistics: the engine's stream is not torch's current stream")
                 self.comm.all_reduce_sum(_as_tensor(d_buf, int(n), self.dev))
                 return 0
             except BaseException as e:      # never let an exception unwind through the C frames
@@ -328,8 +331,12 @@ class ShardedTrainer:
         par = r.parity
         capi.check(L.dctr_table_gather_packed(self._h, capi.ptr(self.recv_rows[par]), r.n_recv, capi.ptr(self.rows_out), st))
         rows = self.x.fetch(r, self.rows_out, out=self.rows_back)
-        capi.check(L.dctr_sharded_forward_backward(self._h, capi.ptr(rows), r.n_send, capi.ptr(self.idx[par]), capi.ptr(vals),
-                                                   capi.ptr(labels), B, B * self.world, int(train), st))
+        rc = L.dctr_sharded_forward_backward(self._h, capi.ptr(rows), r.n_send, capi.ptr(self.idx[par]), capi.ptr(vals),
+                                             capi.ptr(labels), B, B * self.world, int(train), st)
+        exc, self._stat_exc = getattr(self, "_stat_exc", None), None
+        if exc is not None:           # the batch_norm statistics callback failed: surface ITS error, not the engine's generic status
+            raise exc
+        capi.check(rc)
 
     def _finish(self, r: Route) -> None:
         ev = torch.cuda.Event()

@@ -38,7 +38,10 @@ def parse_file(path: str, field_size: int, threads: int = 10):
     parsed straight into its rows of the result -- no Python per chunk, no concatenation)."""
     # the file is MAPPED, not read: f.read() is a serial 150 MB copy out of the page cache (30-50 ms, as long as the whole 32-thread
     # parse); mapped pages are first touched by the parse threads themselves
-    size = os.path.getsize(path)
+    # (the mapping is read live by both passes: the file must not change underneath them -- a dataset that is being rewritten is
+    #  refused below instead of surfacing as a SIGBUS or as two passes that disagree)
+    st0 = os.stat(path)
+    size = st0.st_size
     buf = np.memmap(path, dtype=np.uint8, mode="r") if size > 0 else np.zeros(0, dtype=np.uint8)
     lib = capi.lib()
     n = C.c_int64()
@@ -50,6 +53,10 @@ def parse_file(path: str, field_size: int, threads: int = 10):
     capi.check(lib.dctr_parse_libsvm_mt(capi.ptr(buf), size, field_size, int(threads), capi.ptr(ids), capi.ptr(vals), capi.ptr(labels), rows,
                                         C.byref(n)))
     del buf
+    st1 = os.stat(path)
+    if (st1.st_size, st1.st_mtime_ns) != (st0.st_size, st0.st_mtime_ns):
+        raise errors.InvalidArgumentError("%s changed while it was being parsed (size %d -> %d): parse a file that is not being written" % (
+            path, st0.st_size, st1.st_size))
     return ids[:rows], vals[:rows], labels[:rows]
 
 

@@ -315,6 +315,8 @@ def bundle_to_state(tensors: Dict[str, np.ndarray], optimizer: str) -> Dict[str,
     s0, s1 = SLOT_NAMES.get(optimizer, (None, None))
     out = {}
     for k, v in tensors.items():
+        if k in ("beta1_power", "beta2_power"):      # Adam's non-slot variables: implied by global_step here
+            continue
         base, _, last = k.rpartition("/")
         if s0 and last == s0 and base in tensors:
             out[base + "/slot0"] = v
@@ -337,4 +339,10 @@ def state_to_bundle(state: Dict[str, np.ndarray], optimizer: str) -> Dict[str, n
                 out[k[:-6] + "/" + s1] = np.asarray(v)
         else:
             out[k] = np.asarray(v, dtype=np.int64) if k == "global_step" else np.asarray(v)
+    if optimizer == "Adam" and "global_step" in state:
+        # AdamOptimizer's two non-slot variables [TF-1.x]: a TRAINING graph's Saver looks for them (eval / predict graphs do not).
+        # The engine derives Adam's bias correction from global_step, so they are beta^global_step (DeepFM.py:205: 0.9, 0.999)
+        t = int(np.asarray(state["global_step"]))
+        out["beta1_power"] = np.float32(0.9 ** t)
+        out["beta2_power"] = np.float32(0.999 ** t)
     return out

@@ -213,7 +213,11 @@ class Estimator:
             # one by one costs the host 0.2-0.3 ms per step -- more than the GPU needs.  One captured hipGraph per (batch size, input
             # slot) is 13 % slower on the GPU and immune to the host (measured through DeepFM.py, B = 256, same box: 0.79 M
             # examples/s eager, 1.18 M replayed).  Large batches keep the eager path and its next-batch id grouping.
-            extra["use_graph"] = int(batch_size) * int(cfg_src.config_kwargs.get("field_size", 0)) < 65536
+            # (decided ONCE per Estimator, from the first engine it builds: a later evaluate() with a larger batch must not flip the
+            #  training path between rebuilds)
+            if getattr(self, "_use_graph", None) is None:
+                self._use_graph = int(batch_size) * int(cfg_src.config_kwargs.get("field_size", 0)) < 65536
+            extra["use_graph"] = self._use_graph
         cfg = cfg_src.engine_config(max_batch=batch_size, table_mode=self.table_mode,
                                     seed=int(self._config.tf_random_seed or 0), **extra)
         self._engine = Engine(cfg)
