@@ -235,6 +235,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     w = dict(CONFIGS[args.config])
+    w["table_sweep_period"] = args.sweep_period          # (row-sharded runs: the native driver's owner side, csrc/lag.h)
     if args.selftest:
         w["dropout"] = tuple(1.0 for _ in w["dropout"])     # (a dropout mask is indexed by the LOCAL row: N ranks and one rank draw different masks)
     B, F, K, V = w["batch"], w["field_size"], w["embedding_size"], w["feature_size"]
@@ -350,8 +351,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.steps):
         step(*batches[(args.warmup + s) % nb], batches[(args.warmup + s + 1) % nb][0])
-    if not sharded:
-        eng.sync_tables()                     # time-blocked table sweep: every row's updates of the timed steps are computed INSIDE the timed region
+    eng.sync_tables()                         # time-blocked table sweep: every row's updates of the timed steps are computed INSIDE the timed region
     t_enq = time.perf_counter() - t0          # host time to ENQUEUE the steps (the GPU may still be running)
     barrier()
     torch.cuda.synchronize()
@@ -376,7 +376,7 @@ def main():
                        "driver": ("single-GPU engine" if not sharded else (driver_note or (args.driver + (" (C++ step driver over RCCL)" if args.driver == "native" else " (torch.distributed orchestration)")))),
                        "ids": "uniform" if args.uniform_ids else "zipf",
                        "next_batch_hint": bool(not sharded and os.environ.get("DCTR_BENCH_PREFETCH", "1") == "1"),
-                       "table_sweep_period": (args.sweep_period or int(os.environ.get("DCTR_SWEEP_PERIOD", "8"))) if (not sharded and args.table_mode == "dense_exact") else 1},
+                       "table_sweep_period": (args.sweep_period or int(os.environ.get("DCTR_SWEEP_PERIOD", "8"))) if (args.table_mode == "dense_exact" and (not sharded or args.driver == "native")) else 1},
         }
         # ---- per-stage timing (hipEvents around a graph of back-to-back launches, on torch's current stream)
         e = eng
