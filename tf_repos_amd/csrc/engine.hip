@@ -956,7 +956,10 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
         if (E->p_bias >= 0) DCTR_TRY(opt_dense_range(E, E->p_bias, E->p_bias, sg));
     }
     const bool out_done = fused_opt && E->head_did_out_bwd;
-    DCTR_TRY(backward_dense(E, B, st, sw, fused_opt, have_head_ev ? &head_ev : nullptr));
+    // A/B knob DCTR_WGRAD_SERIAL=1: the weight gradients (and the per-layer optimizer steps) on the main stream, right behind their
+    // layer's dgrad, instead of beside it on sw
+    static const bool wgrad_serial = getenv("DCTR_WGRAD_SERIAL") != nullptr;
+    DCTR_TRY(backward_dense(E, B, st, wgrad_serial ? st : sw, fused_opt, have_head_ev ? &head_ev : nullptr));
     if (!fused_opt) DCTR_TRY(fork(E, st, sw));          // (fused_opt: backward_dense ends with that fork)
     // where a prefetched grouping of the next batch may start (beside scatter + table step): the record of that last st -> sw
     // fork serves -- one more record here is one more barrier packet (~5 us) in front of the scatter

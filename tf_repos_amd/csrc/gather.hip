@@ -42,6 +42,8 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(
             float4 r[U];
             float w[U];
             int nlag[U];
+            float4 m[LAG ? U : 1], vv[LAG ? U : 1];
+            float lm[LAG ? U : 1], lv[LAG ? U : 1];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int f = f0 + u * FS;
@@ -58,20 +60,20 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(
                 }
                 r[u] = ok ? emb[(size_t)id[u] * emb_ld4 + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
                 w[u] = (ok && lin != nullptr && kq == 0) ? lin[(size_t)id[u] * lin_ld] : 0.f;
-                if (LAG) nlag[u] = ok ? lag_behind(L.state->t - 1, L.ts[id[u]]) : 0;
+                if constexpr (LAG) {
+                    // the Adam slots are read WITH the row, not after its stamp has come back: the gather is a chain of dependent
+                    // random reads, and one stage less is worth more than the bytes of the rows that turn out to be current
+                    nlag[u] = ok ? lag_behind(L.state->t - 1, L.ts[id[u]]) : 0;
+                    m[u] = ok ? L.s0[(size_t)id[u] * KQ + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    vv[u] = ok ? L.s1[(size_t)id[u] * KQ + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    lm[u] = lv[u] = 0.f;
+                    if (ok && lin != nullptr && kq == 0) { lm[u] = L.l0[id[u]]; lv[u] = L.l1[id[u]]; }
+                }
             }
-            if (LAG) {
-                float4 m[U], vv[U];
-                float lm[U], lv[U];
+            if constexpr (LAG) {
                 int nl[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {        // (loads only: the U rows' slot reads overlap)
-                    nl[u] = 0;
-                    if (nlag[u] > 0) {
-                        m[u] = L.s0[(size_t)id[u] * KQ + kq]; vv[u] = L.s1[(size_t)id[u] * KQ + kq];
-                        if (lin != nullptr && kq == 0) { lm[u] = L.l0[id[u]]; lv[u] = L.l1[id[u]]; nl[u] = nlag[u]; }
-                    }
-                }
+                for (int u = 0; u < U; ++u) nl[u] = (lin != nullptr && kq == 0) ? nlag[u] : 0;
                 const Hyper hh = L.state->hyper;
                 const int64_t Tm1 = L.state->t - 1;
                 lag_catch_up4_rows<U>(L.state, hh, L.l2, Tm1, nlag, r, m, vv);
