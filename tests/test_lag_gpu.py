@@ -125,3 +125,43 @@ def test_restored_global_step_and_written_parameters(dev):
 def test_period_is_validated(dev):
     with pytest.raises(errors.InvalidArgumentError):
         engine("deepfm", 99, 1000, 16)
+
+
+@pytest.mark.parametrize("model,att", [("din", ()), ("esmm", ()), ("din", (16,))])
+def test_csr_models_lag_like_the_classic_sweep(model, att, dev):
+    """DIN (sum and attention pooling) and ESMM over CSR batches (DIN.py:143-222, DeepCvrMTL.py:153-225): every entry's row is
+    advanced to step t-1 when the multi-hot lookup (and the attention units' input) reads it; 14 steps, loss read at the ends and
+    once in the middle, a predict in between."""
+    from oracle import multihot_oracle as M
+    B, Fc, V, K = 64, 6, 3000, 8
+    ocfg = M.Config(model=model, field_size=Fc, feature_size=V, embedding_size=K, deep_layers=(32, 16), dropout=(0.8, 0.8), l2_reg=1e-3,
+                    learning_rate=1e-2, optimizer="Adam", ctr_task_wgt=0.4, attention_layers=att)
+    params = M.init_params(ocfg, seed=4, scale=0.2 if att else 0.05)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    runs = []
+    for period in (1, 6):
+        eng = Engine(EngineConfig(model=model, field_size=ocfg.n_slots, feature_size=V, embedding_size=K, deep_layers=(32, 16), dropout=(0.8, 0.8),
+                                  l2_reg=1e-3, learning_rate=1e-2, optimizer="Adam", max_batch=B, max_entries=B * (ocfg.n_slots + 40),
+                                  ctr_task_wgt=0.4, attention_layers=att or (256,), att_pairs=[(Fc + i, Fc + 4 + i) for i in range(4)] if att else (),
+                                  seed=9, table_sweep_period=period))
+        eng.set_params(params)
+        out = []
+        for step in range(14):
+            batch = M.synth_batch(ocfg, B, seed=1100 + step)
+            off, ids, wts = M.slot_csr(ocfg, batch)
+            out.append(eng.train_step_csr(t(off), t(ids), t(wts), t(batch["y"]), t(batch["z"]) if model == "esmm" else None,
+                                          want_loss=step in (0, 6, 13)))
+            if step == 9:
+                p = torch.empty(B, device=dev)
+                eng.predict_csr(t(off), t(ids), t(wts), B, p)
+                out.append(float(p.sum()))
+        st = dict(eng.get_params())
+        st["emb/m"], st["emb/v"] = eng.get_slot("emb", 0), eng.get_slot("emb", 1)
+        runs.append((out, st))
+        eng.close()
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (a, b)
+    for k, v in runs[0][1].items():
+        assert np.abs(v - runs[1][1][k]).max() <= 2e-6, k

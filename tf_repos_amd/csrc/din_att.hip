@@ -9,6 +9,7 @@
 // without a device round trip.
 //   entry_off[j] = float4 offset of entry j's slot in x / dx  (b * ld4 + s * KQ);  pair_ad[s] = a(s) or -1
 #include "ops.h"
+#include "lag.h"
 
 namespace dctr {
 
@@ -16,7 +17,7 @@ template <int KQ>
 __global__ __launch_bounds__(256) void att_build_x_kernel(const float4* __restrict__ emb, int64_t rows, const int32_t* __restrict__ ids,
                                                          const float* __restrict__ weights, const int32_t* __restrict__ entry_off,
                                                          const int32_t* __restrict__ pair_ad, int nnz, const float4* __restrict__ x,
-                                                         int ld4, float4* __restrict__ X) {
+                                                         int ld4, float4* __restrict__ X, LagView L) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int j = (int)(t / KQ), kq = (int)(t % KQ);
     if (j >= nnz) return;
@@ -27,7 +28,15 @@ __global__ __launch_bounds__(256) void att_build_x_kernel(const float4* __restri
         const int id = ids[j];
         if (id >= 0 && (int64_t)id < rows) {
             const float w = weights != nullptr ? weights[j] : 1.0f;
-            const float4 r = emb[(size_t)id * KQ + kq];
+            float4 r = emb[(size_t)id * KQ + kq];
+            if (L.ts != nullptr) {              // lagging rows (lag.h): as of step t-1, in registers
+                const int64_t Tm1 = L.state->t - 1;
+                const int nl = lag_behind(Tm1, L.ts[id]);
+                if (nl > 0) {
+                    float4 m = L.s0[(size_t)id * KQ + kq], vv = L.s1[(size_t)id * KQ + kq];
+                    lag_catch_up4(L.state, L.state->hyper, L.l2, Tm1 - nl + 1, nl, r, m, vv);
+                }
+            }
             ub = make_float4(w * r.x, w * r.y, w * r.z, w * r.w);
         }
         ax = x[(size_t)b * ld4 + (size_t)ad * KQ + kq];
@@ -145,12 +154,13 @@ __global__ __launch_bounds__(256) void att_bwd_dax_kernel(const int32_t* __restr
     }
 
 int att_build_x(const float* emb, int64_t rows, int K, const int32_t* ids, const float* weights, const int32_t* entry_off,
-                const int32_t* pair_ad, int nnz, const float* x, int ld, float* X, hipStream_t st) {
+                const int32_t* pair_ad, int nnz, const float* x, int ld, float* X, hipStream_t st, const LagView* lag) {
     if (nnz <= 0) return DCTR_OK;
     const int KQ = K / 4;
+    const LagView LV = lag ? *lag : LagView{};
     DCTR_KQ_SWITCH(KQ, (void)L; (att_build_x_kernel<Q><<<ceil_div((int64_t)nnz * Q, 256), 256, 0, st>>>(
                                    reinterpret_cast<const float4*>(emb), rows, ids, weights, entry_off, pair_ad, nnz,
-                                   reinterpret_cast<const float4*>(x), ld / 4, reinterpret_cast<float4*>(X))));
+                                   reinterpret_cast<const float4*>(x), ld / 4, reinterpret_cast<float4*>(X), LV)));
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }

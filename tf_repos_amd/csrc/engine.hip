@@ -257,7 +257,7 @@ int build(dctr_engine* E) {
         int period = c.table_sweep_period;
         if (period == 0) { const char* v = getenv("DCTR_SWEEP_PERIOD"); period = v ? atoi(v) : 8; }
         DCTR_REQUIRE(period >= 1 && period <= LAG_MAX_PERIOD, "table_sweep_period %d outside [1, %d]", period, LAG_MAX_PERIOD);
-        const bool can = c.table_mode == DCTR_TABLE_DENSE_EXACT && c.optimizer == DCTR_OPT_ADAM && !E->wnd && !E->csr && !c.use_graph;
+        const bool can = c.table_mode == DCTR_TABLE_DENSE_EXACT && c.optimizer == DCTR_OPT_ADAM && !E->wnd && !c.use_graph;
         E->lag_period = can ? period : 1;
         if (E->lag_period > 1) DCTR_TRY(dmalloc(&E->row_ts, (size_t)E->rows));
     }
@@ -834,7 +834,7 @@ int scatter_and_step_tables(dctr_engine* E, int B, hipStream_t st, hipStream_t s
 // their optimizer step (90 % of the table pass) runs right after the grouping, under the MLP GEMMs, instead of at the end
 int step_untouched_rows(dctr_engine* E, hipStream_t st) {
     const dctr_config& c = E->cfg;
-    if (lag_on(E) && !E->csr) {       // one block of the table per step, its rows advanced through every step they missed (lag.h)
+    if (lag_on(E)) {       // one block of the table per step, its rows advanced through every step they missed (lag.h)
         E->lag_dirty = true;
         return lag_sweep(E->K, E->rows, E->emb, E->emb_s0, E->emb_s1, E->lin, E->lin_s0, E->lin_s1, E->group->slot, E->row_ts, E->state,
                          c.l2_reg, E->lag_period, st);
@@ -1411,11 +1411,16 @@ int csr_forward(dctr_engine* E, const int32_t* off, const int32_t* ids, const fl
                 bool train, hipStream_t st, float* loss_shards = nullptr) {
     if (loss_shards == nullptr) loss_shards = E->scalars;
     const dctr_config& c = E->cfg;
-    DCTR_TRY(lookup_sparse_slots_fwd(E->emb, E->rows, E->K, off, ids, wts, B * E->F, E->F, E->x_in, E->Din_ld, E->status, st, nnz));
+    // a TRAINING step reads rows that may lag (lag.h) as of step t-1; everything else reads a flushed table
+    const bool lag = train && lag_on(E);
+    const LagView LV = lag_view(E);
+    const LagView* Lp = lag ? &LV : nullptr;
+    if (!train) DCTR_TRY(lag_flush_tables(E, st, 0, false));
+    DCTR_TRY(lookup_sparse_slots_fwd(E->emb, E->rows, E->K, off, ids, wts, B * E->F, E->F, E->x_in, E->Din_ld, E->status, st, nnz, Lp));
     if (E->att_on && nnz > 0) {
         // attention units (DIN.py:152-177): the user slots' plain sums just written are replaced by attention-weighted sums
         DCTR_TRY(csr_entry_offsets(off, B * E->F, nnz, E->F, E->Din_ld, E->K, E->entry_off, st));
-        DCTR_TRY(att_build_x(E->emb, E->rows, E->K, ids, wts, E->entry_off, E->pair_ad, nnz, E->x_in, E->Din_ld, E->x_att, st));
+        DCTR_TRY(att_build_x(E->emb, E->rows, E->K, ids, wts, E->entry_off, E->pair_ad, nnz, E->x_in, E->Din_ld, E->x_att, st, Lp));
         swap_att(E);
         int rc = forward_rest(E, nnz, train, st);
         swap_att(E);
@@ -1450,6 +1455,8 @@ int dctr_train_step_csr(dctr_handle E, const int32_t* d_offsets, const int32_t* 
     DCTR_REQUIRE(d_y != nullptr && (!esmm || d_z != nullptr), "labels missing (ESMM takes y and z)");
     hipStream_t st = as_stream(stream), sg = E->s_group, sw = E->s_wgrad;
     DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, st));
+    E->want_loss = h_loss != nullptr;
+    if (lag_on(E) && E->want_loss) DCTR_TRY(lag_flush_tables(E, st, -1, true));     // (the loss's l2 term: sum theta^2 of every row, as of t-1)
     // grouping of the batch's ids + the entries' slot offsets: beside the forward pass
     DCTR_TRY(fork(E, st, sg));
     const bool split_table = split_table_on(E);
@@ -1490,8 +1497,9 @@ int dctr_train_step_csr(dctr_handle E, const int32_t* d_offsets, const int32_t* 
     if (fused) {
         if (nnz > 0)
             DCTR_TRY(embed_scatter_apply(E->group, c.optimizer, &E->state->hyper, E->h_state.hyper, E->emb, E->emb_s0, E->emb_s1, nullptr, nullptr,
-                                         nullptr, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, E->dx_in, 4, nullptr, 0,
-                                         nullptr, nullptr, nullptr, d_weights, nnz, 1, E->K, DCTR_GATHER_RAW, st, 1, goff));
+                                         nullptr, c.l2_reg, lag_on(E) ? nullptr : E->scalars + SUMSQ_SHARDS, lag_on(E) ? nullptr : E->scalars + 2 * SUMSQ_SHARDS,
+                                         E->dx_in, 4, nullptr, 0, nullptr, nullptr, nullptr, d_weights, nnz, 1, E->K, DCTR_GATHER_RAW, st, 1, goff,
+                                         lag_on(E) ? E->row_ts : nullptr, lag_on(E) ? E->state : nullptr));
     } else {
     if (nnz > 0)
         DCTR_TRY(embed_scatter_bwd(E->group, E->dx_in, 4, nullptr, 0, nullptr, nullptr, nullptr, d_weights, nnz, 1, E->K, DCTR_GATHER_RAW,

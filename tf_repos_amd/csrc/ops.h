@@ -188,7 +188,8 @@ int dcn_cross_bwd(const float* xs, const float* xlw, const float* w, const float
 
 // sparse.hip / mtl.hip: the CSR (multi-hot) models DIN / ESMM
 int lookup_sparse_slots_fwd(const float* emb, int64_t rows, int K, const int32_t* offsets, const int32_t* ids, const float* weights,
-                            int n_seg, int S, float* out, int out_ld, int32_t* status, hipStream_t st, int64_t nnz_hint = -1);
+                            int n_seg, int S, float* out, int out_ld, int32_t* status, hipStream_t st, int64_t nnz_hint = -1,
+                            const LagView* lag = nullptr);
 int csr_entry_offsets(const int32_t* offsets, int n_seg, int nnz, int S, int ld, int K, int32_t* entry_off, hipStream_t st);
 int esmm_head(const float* h_ctr, int ld_ctr, const float* w_ctr, const float* b_ctr, int n_ctr, const float* h_cvr, int ld_cvr,
               const float* w_cvr, const float* b_cvr, int n_cvr, const float* y, const float* z, int B, float inv_b, float wgt,
@@ -198,7 +199,7 @@ int add_inplace(float* a, const float* b, int64_t n, hipStream_t st);
 
 // din_att.hip: DIN attention pooling over CSR batches (DIN.py:152-172)
 int att_build_x(const float* emb, int64_t rows, int K, const int32_t* ids, const float* weights, const int32_t* entry_off,
-                const int32_t* pair_ad, int nnz, const float* x, int ld, float* X, hipStream_t st);
+                const int32_t* pair_ad, int nnz, const float* x, int ld, float* X, hipStream_t st, const LagView* lag = nullptr);
 int att_pool_fwd(const int32_t* offsets, const int32_t* ids, const int32_t* pair_ad, const float* sc, int n_seg, int S, int K,
                  const float* X, float* att, float* x, int ld, hipStream_t st);
 int att_bwd_scores(const int32_t* ids, const int32_t* entry_off, const int32_t* pair_ad, int nnz, int K, const float* dx, int ld,

@@ -6,15 +6,18 @@
 //   backward: the IndexedSlices gradient, segment-summed per distinct id into a dctr_group's compact rows (group.hip),
 //             ready for dctr_opt_table -- the same machinery as the fixed-F path, with a per-entry example index
 #include "ops.h"
+#include "lag.h"
 
 namespace dctr {
 
 // EL lanes walk a segment's entries side by side (KQ float4 pieces each), then fold their partial sums with shuffles: a
 // multi-hot slot of ~60 ids keeps 16 row loads in flight instead of one dependent chain.  EL = 1: one lane per (segment, piece).
-template <int KQ, int EL>
+// LAG: table rows may lag (lag.h): an entry's row is advanced to step t-1 in registers before it is summed (nothing written back)
+template <int KQ, int EL, bool LAG>
 __global__ __launch_bounds__(256) void lookup_sparse_fwd_kernel(const float4* __restrict__ emb, int64_t rows, const int32_t* __restrict__ offsets,
                                                                const int32_t* __restrict__ ids, const float* __restrict__ weights, int B,
-                                                               int S, float4* __restrict__ out, int out_ld4, int32_t* __restrict__ status) {
+                                                               int S, float4* __restrict__ out, int out_ld4, int32_t* __restrict__ status,
+                                                               LagView L) {
     // B segments; segment b is slot b % S of output row b / S (S == 1: one K-wide output per row)
     static_assert(KQ * EL <= 64, "a segment's lanes must sit in one wave");
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -30,7 +33,15 @@ __global__ __launch_bounds__(256) void lookup_sparse_fwd_kernel(const float4* __
             continue;
         }
         const float w = weights != nullptr ? weights[j] : 1.0f;
-        const float4 v = emb[(size_t)id * KQ + kq];
+        float4 v = emb[(size_t)id * KQ + kq];
+        if constexpr (LAG) {
+            const int64_t Tm1 = L.state->t - 1;
+            const int nl = lag_behind(Tm1, L.ts[id]);
+            if (nl > 0) {
+                float4 m = L.s0[(size_t)id * KQ + kq], vv = L.s1[(size_t)id * KQ + kq];
+                lag_catch_up4(L.state, L.state->hyper, L.l2, Tm1 - nl + 1, nl, v, m, vv);
+            }
+        }
         acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
     }
 #pragma unroll
@@ -55,7 +66,7 @@ __global__ __launch_bounds__(256) void entry_row_kernel(const int32_t* __restric
 }
 
 int lookup_sparse_slots_fwd(const float* emb, int64_t rows, int K, const int32_t* offsets, const int32_t* ids, const float* weights,
-                            int n_seg, int S, float* out, int out_ld, int32_t* status, hipStream_t st, int64_t nnz_hint) {
+                            int n_seg, int S, float* out, int out_ld, int32_t* status, hipStream_t st, int64_t nnz_hint, const LagView* lag) {
     if (n_seg <= 0) return DCTR_OK;
     const int KQ = K / 4;
     // entry lanes per segment from the average segment length (nnz_hint < 0: unknown -> one lane)
@@ -64,9 +75,12 @@ int lookup_sparse_slots_fwd(const float* emb, int64_t rows, int K, const int32_t
     while (EL > 1 && KQ * EL > 64) EL >>= 2;
     const float4* e4 = reinterpret_cast<const float4*>(emb);
     float4* o4 = reinterpret_cast<float4*>(out);
+    const LagView LV = lag ? *lag : LagView{};
 #define DCTR_S2(Q, L)                                                                                                            \
-    lookup_sparse_fwd_kernel<Q, L><<<ceil_div((int64_t)n_seg * Q * L, 256), 256, 0, st>>>(e4, rows, offsets, ids, weights, n_seg, S, o4, \
-                                                                                           out_ld / 4, status)
+    do {                                                                                                                         \
+        if (lag) lookup_sparse_fwd_kernel<Q, L, true><<<ceil_div((int64_t)n_seg * Q * L, 256), 256, 0, st>>>(e4, rows, offsets, ids, weights, n_seg, S, o4, out_ld / 4, status, LV); \
+        else lookup_sparse_fwd_kernel<Q, L, false><<<ceil_div((int64_t)n_seg * Q * L, 256), 256, 0, st>>>(e4, rows, offsets, ids, weights, n_seg, S, o4, out_ld / 4, status, LV); \
+    } while (0)
 #define DCTR_S(Q)                                                                        \
     case Q:                                                                              \
         if (EL == 16 && Q * 16 <= 64) DCTR_S2(Q, (Q * 16 <= 64 ? 16 : 1));               \

@@ -60,6 +60,7 @@ for model in ("din", "esmm", "din_att"):
         for i in range(steps):
             off, ids, wts, y, z = batches[i % 4]
             eng.train_step_csr(off, ids, wts, y, z if model == "esmm" else None, want_loss=False)
+        eng.sync_tables()          # (time-blocked table sweep: the timed steps' updates are all computed inside the timed region)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         eng.check_ids()
