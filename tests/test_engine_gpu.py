@@ -298,6 +298,25 @@ def test_afm_attention_widths(K, A, dev):
     eng.predict(d_ids, d_vals, torch.empty(B, device=dev), logit)
     torch.cuda.synchronize()
     assert np.abs(logit.cpu().numpy() - O.forward(ocfg, params, ids, vals)["y"].numpy()).max() <= 1e-4
+
+
+@pytest.mark.parametrize("K,F", [(64, 13), (64, 12), (128, 9), (256, 39), (256, 6), (72, 7)])
+def test_afm_wide_embeddings_pair_backward(K, F, dev):
+    """K >= 64 (the reference runs AFM at K = 256, run.sh:18): the pair backward walks the pairs of an example in round-robin
+    order (every row of d(pair tensor) read once, odd field counts have a bye); K = 72 pads to 128 physical columns."""
+    V, B = 1500, 37
+    ocfg, params, eng = make_pair("afm", B=B, F=F, V=V, K=K, layers=(1,), att=(24,), opt="Adagrad", lr=1e-2)
+    oopt = O.Optimizer(ocfg, params)
+    for step in range(2):
+        ids, vals, labels = O.synth_batch(B, F, V, seed=500 + step)
+        ref_loss, _ = O.train_step(ocfg, params, oopt, ids, vals, labels)
+        loss = eng.train_step(*dev_batch(ids, vals, labels, dev))
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (step, loss, ref_loss)
+    got = eng.get_params()
+    for name, ref in params.items():
+        diff = np.abs(got[name] - ref.numpy()).max()
+        assert diff <= 3e-6, (name, diff)
+    eng.close()
     eng.close()
 
 

@@ -27,19 +27,35 @@ __device__ __forceinline__ float wmax64(float v) {
     return v;
 }
 
-// pp4[(b*P + p)*KQ + kq] = e4[b,i_p,kq] * e4[b,j_p,kq]
+// pp4[(b*P + p)*KQ + kq] = e4[b,i_p,kq] * e4[b,j_p,kq]: blockIdx.y = example, a thread writes PAIR_FWD_U float4 pieces of its
+// example's slice (32-bit index arithmetic, the loads of all pieces issued before the first store)
+constexpr int PAIR_FWD_U = 4;
+template <bool NT>
 __global__ __launch_bounds__(256) void afm_pair_fwd_kernel(const float4* __restrict__ e, int e_ld4, const int16_t* __restrict__ pi,
                                                           const int16_t* __restrict__ pj, int B, int P, int KQ,
                                                           float4* __restrict__ pp) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n = (int64_t)B * P * KQ;
-    if (t >= n) return;
-    const int kq = (int)(t % KQ);
-    const int64_t bp = t / KQ;
-    const int p = (int)(bp % P), b = (int)(bp / P);
-    const float4 a = e[(size_t)b * e_ld4 + (size_t)pi[p] * KQ + kq];
-    const float4 c = e[(size_t)b * e_ld4 + (size_t)pj[p] * KQ + kq];
-    pp[t] = make_float4(a.x * c.x, a.y * c.y, a.z * c.z, a.w * c.w);
+    const int b = blockIdx.y, n = P * KQ;
+    const float4* eb = e + (size_t)b * e_ld4;
+    float4* out = pp + (size_t)b * n;
+    const int x0 = blockIdx.x * (256 * PAIR_FWD_U) + threadIdx.x;
+    float4 a[PAIR_FWD_U], c[PAIR_FWD_U];
+#pragma unroll
+    for (int u = 0; u < PAIR_FWD_U; ++u) {
+        const int x = min(x0 + u * 256, n - 1);
+        const int p = x / KQ, kq = x - p * KQ;
+        a[u] = eb[pi[p] * KQ + kq];
+        c[u] = eb[pj[p] * KQ + kq];
+    }
+#pragma unroll
+    for (int u = 0; u < PAIR_FWD_U; ++u) {
+        const int x = x0 + u * 256;
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f r = {a[u].x * c[u].x, a[u].y * c[u].y, a[u].z * c[u].z, a[u].w * c[u].w};
+        if (x < n) {
+            if (NT) __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(out + x));
+            else *reinterpret_cast<v4f*>(out + x) = r;
+        }
+    }
 }
 
 // one block per example: softmax over the P scores, attention dropout, pooling over the pairs, y_emb dropout
@@ -49,10 +65,10 @@ __global__ __launch_bounds__(256) void afm_pool_fwd_kernel(const float* __restri
                                                           float keep_att, float keep_emb, const uint64_t* __restrict__ seed_ptr,
                                                           int train, float* __restrict__ att, float* __restrict__ yemb,
                                                           const float4* __restrict__ ee, int e_ld4, int F, const int16_t* __restrict__ pi,
-                                                          const int16_t* __restrict__ pj) {
+                                                          const int16_t* __restrict__ pj, int b0) {
     extern __shared__ __attribute__((aligned(16))) float sm[];        // [P] attention weights (after dropout) | [F][K] embeddings (ee)
     __shared__ float red[4];
-    const int b = blockIdx.x, t = threadIdx.x;
+    const int b = b0 + blockIdx.x, t = threadIdx.x;
     float4* es = reinterpret_cast<float4*>(sm + ((P + 3) & ~3));
     if (ee != nullptr)
         for (int x = t; x < F * (K >> 2); x += 256) es[x] = ee[(size_t)b * e_ld4 + x];
@@ -112,12 +128,12 @@ __global__ __launch_bounds__(256) void afm_pool_bwd_kernel(float* __restrict__ d
                                                           const float* __restrict__ att, int P, int K, float keep_att, float keep_emb,
                                                           const uint64_t* __restrict__ seed_ptr, float* __restrict__ dsc,
                                                           float* __restrict__ att_drop, const float4* __restrict__ ee, int e_ld4, int F,
-                                                          const int16_t* __restrict__ pi, const int16_t* __restrict__ pj) {
+                                                          const int16_t* __restrict__ pi, const int16_t* __restrict__ pj, int b0) {
     extern __shared__ __attribute__((aligned(16))) float sm[];        // [K] dyemb (pre-dropout gradient) | [P] da | [F][K] embeddings (ee)
     __shared__ float red[4];
     float* dye = sm;
     float* da = sm + K;
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b = b0 + blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     float4* es = reinterpret_cast<float4*>(sm + ((K + P + 3) & ~3));
     if (ee != nullptr)
         for (int x = t; x < F * (K >> 2); x += 256) es[x] = ee[(size_t)b * e_ld4 + x];
@@ -185,10 +201,11 @@ __global__ __launch_bounds__(256) void afm_pair_bwd_kernel(const float* __restri
     dE[(size_t)b * de_ld + x] = s;
 }
 
-// The same with float4 pieces and four pairs in flight per thread (the loop above issues one 4-byte load per pair and waits for
+// The same with float4 pieces and eight pairs in flight per thread (the loop above issues one 4-byte load per pair and waits for
 // it: 1.1 TB/s on 6 GB at the reference's K = 256, B = 4096).  Thread = (field i, piece kq) of one example; every row of g2 is
-// still read twice (once from each of its fields' side) -- a one-pass variant that folded both contributions into an LDS
-// accumulator with ds_add_f32 measured 2x SLOWER than the loop above (the float atomics serialise).
+// still read twice (once from each of its fields' side) -- the one-pass variant below, which folds both contributions into an LDS
+// accumulator with ds_add_f32, measured 2x SLOWER than the loop above: LDS float atomics retire about one LANE per clock per CU
+// (1.5 G lane-atomics at K = 256, B = 4096 = ~6 ms of LDS time however the banks are laid out).
 template <int KQ>
 __global__ __launch_bounds__(256) void afm_pair_bwd_v4_kernel(const float4* __restrict__ e, int e_ld4, const float* __restrict__ att_drop,
                                                              const float* __restrict__ dye, int dye_ld, const float4* __restrict__ g2,
@@ -202,34 +219,189 @@ __global__ __launch_bounds__(256) void afm_pair_bwd_v4_kernel(const float4* __re
     const float4* c = g2 + (size_t)b * P * KQ;
     const float4 dk = reinterpret_cast<const float4*>(dye + (size_t)b * dye_ld)[kq];
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    // partner fields j = 0 .. F-1 except i, four at a time
-    for (int j0 = 0; j0 < F; j0 += 4) {
-        float4 v[4], ej[4]; float a[4]; bool on[4];
+    // the F-1 partner fields jj -> j = jj + (jj >= i), eight at a time; the tail is clamped and weighted 0 (no branch between the
+    // loads: a predicated load in the middle of the batch makes the compiler wait for everything before it)
+    constexpr int UN = 8;
+    for (int j0 = 0; j0 < F - 1; j0 += UN) {
+        float4 v[UN], ej[UN]; float a[UN], on[UN];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u;
-            on[u] = j < F && j != i;
-            const int jc = on[u] ? j : (i == 0 ? 1 : 0);                 // (clamped to a valid partner: the loads carry no branch)
-            const int lo = jc < i ? jc : i, hi = jc < i ? i : jc;
+        for (int u = 0; u < UN; ++u) {
+            const int jj = j0 + u;
+            on[u] = jj < F - 1 ? 1.f : 0.f;
+            const int jc = jj < F - 1 ? jj : F - 2;
+            const int j = jc + (jc >= i ? 1 : 0);
+            const int lo = j < i ? j : i, hi = j < i ? i : j;
             const int p = lo * F - (lo * (lo + 1)) / 2 + (hi - lo - 1);
             v[u] = c[(size_t)p * KQ + kq];
             a[u] = ad[p];
-            ej[u] = eb[jc * KQ + kq];
+            ej[u] = eb[j * KQ + kq];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (on[u]) {
-                s.x += (a[u] * dk.x + v[u].x) * ej[u].x; s.y += (a[u] * dk.y + v[u].y) * ej[u].y;
-                s.z += (a[u] * dk.z + v[u].z) * ej[u].z; s.w += (a[u] * dk.w + v[u].w) * ej[u].w;
-            }
+        for (int u = 0; u < UN; ++u) {
+            s.x += on[u] * (a[u] * dk.x + v[u].x) * ej[u].x; s.y += on[u] * (a[u] * dk.y + v[u].y) * ej[u].y;
+            s.z += on[u] * (a[u] * dk.z + v[u].z) * ej[u].z; s.w += on[u] * (a[u] * dk.w + v[u].w) * ej[u].w;
+        }
     }
     dE[(size_t)b * de_ld4 + x] = s;
 }
 
+// One-pass variant: a block per example, every row of g2 read ONCE (float4 pieces, eight pairs in flight per lane group), both of its
+// contributions -- dE[i] += v e_j and dE[j] += v e_i -- added into an LDS accumulator laid out [F][4][KQ] (component-major: the
+// KQ lanes of a row piece hit consecutive banks; a [F][K] layout makes ds_add_f32 an 8-way bank conflict), the partner rows of e
+// read from global memory (40 KB per example, L2-resident).  LDS: F K floats (39 x 256: 39 KB -> three blocks per CU).
+template <int KQ>
+__global__ __launch_bounds__(256) void afm_pair_bwd_once_kernel(const float4* __restrict__ e, int e_ld4, const float* __restrict__ att_drop,
+                                                               const float* __restrict__ dye, int dye_ld, const float4* __restrict__ g2,
+                                                               const int16_t* __restrict__ pair_i, const int16_t* __restrict__ pair_j,
+                                                               int F, int P, float4* __restrict__ dE, int de_ld4) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];             // [F][4][KQ]
+    constexpr int G = 256 / KQ;                 // pairs walked side by side by the block
+    constexpr int UN = 8;
+    const int b = blockIdx.x, t = threadIdx.x, kq = t % KQ, grp = t / KQ;
+    for (int x = t; x < F * 4 * KQ; x += 256) sm[x] = 0.f;
+    const float4 dk = reinterpret_cast<const float4*>(dye + (size_t)b * dye_ld)[kq];
+    const float4* eb = e + (size_t)b * e_ld4;
+    const float4* gb = g2 + (size_t)b * P * KQ;
+    const float* ad = att_drop + (size_t)b * P;
+    __syncthreads();
+    for (int p0 = grp; p0 < P; p0 += UN * G) {
+        float4 v[UN], ei[UN], ej[UN]; float a[UN]; int pi[UN], pj[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int p = p0 + u * G;
+            const int pc = p < P ? p : P - 1;                   // (clamped: the loads carry no branch)
+            pi[u] = pair_i[pc]; pj[u] = pair_j[pc];
+            v[u] = gb[(size_t)pc * KQ + kq];
+            a[u] = ad[pc];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { ei[u] = eb[pi[u] * KQ + kq]; ej[u] = eb[pj[u] * KQ + kq]; }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (p0 + u * G < P) {
+                const float4 w = make_float4(v[u].x + a[u] * dk.x, v[u].y + a[u] * dk.y, v[u].z + a[u] * dk.z, v[u].w + a[u] * dk.w);
+                float* di = sm + pi[u] * 4 * KQ + kq;
+                float* dj = sm + pj[u] * 4 * KQ + kq;
+                atomicAdd(di, w.x * ej[u].x); atomicAdd(di + KQ, w.y * ej[u].y); atomicAdd(di + 2 * KQ, w.z * ej[u].z); atomicAdd(di + 3 * KQ, w.w * ej[u].w);
+                atomicAdd(dj, w.x * ei[u].x); atomicAdd(dj + KQ, w.y * ei[u].y); atomicAdd(dj + 2 * KQ, w.z * ei[u].z); atomicAdd(dj + 3 * KQ, w.w * ei[u].w);
+            }
+        }
+    }
+    __syncthreads();
+    for (int x = t; x < F * KQ; x += 256) {
+        const int f = x / KQ, q = x - f * KQ;
+        const float* r = sm + f * 4 * KQ + q;
+        dE[(size_t)b * de_ld4 + x] = make_float4(r[0], r[KQ], r[2 * KQ], r[3 * KQ]);
+    }
+}
+
+// Every row of g2 read ONCE, without atomics: the pairs of one example are walked in round-robin-tournament order (the circle
+// method: n = F rounded up to even, n - 1 rounds of n/2 pairs, no field twice in a round), so within a round every pair updates
+// two accumulator rows nobody else touches -- plain LDS read-modify-write, a barrier between rounds.  Block = one example (4
+// waves); a wave carries 64/KQ pairs at a time (lane = piece kq of its pair's rows), UN of them per round, and the rows of the
+// NEXT round are in flight while this one is folded (the barrier waits for LDS only: a __syncthreads() would drain the loads).
+// LDS: the accumulator and the example's embeddings, 2 * F * K floats (78 KB at F = 39, K = 256: two blocks per CU).
+__device__ __forceinline__ bool rr_pair(int n, int F, int r, int m, int half, int& lo, int& hi) {
+    int a = n - 1, c = r;
+    if (m > 0) {
+        a = r + m; if (a >= n - 1) a -= n - 1;
+        c = r - m; if (c < 0) c += n - 1;
+    }
+    lo = a < c ? a : c;
+    hi = a < c ? c : a;
+    return m < half && hi < F;                     // (hi == F: the bye of an odd field count)
+}
+
+template <int KQ, int UN>
+__global__ __launch_bounds__(256) void afm_pair_bwd_rr_kernel(const float4* __restrict__ e, int e_ld4, const float* __restrict__ att_drop,
+                                                             const float* __restrict__ dye, int dye_ld, const float4* __restrict__ g2,
+                                                             int F, int P, float4* __restrict__ dE, int de_ld4) {
+    extern __shared__ float4 rr_sm[];
+    float4* acc = rr_sm;
+    float4* es = rr_sm + F * KQ;
+    constexpr int S = 64 / KQ, G = 4 * S;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int g = (t >> 6) * S + (t & 63) / KQ, kq = (t & 63) % KQ;
+    for (int x = t; x < F * KQ; x += 256) {
+        es[x] = e[(size_t)b * e_ld4 + x];
+        acc[x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float4 dk = reinterpret_cast<const float4*>(dye + (size_t)b * dye_ld)[kq];
+    const float* ad = att_drop + (size_t)b * P;
+    const float4* c = g2 + (size_t)b * P * KQ;
+    const int n = (F + 1) & ~1, half = n / 2;
+    const int chunks = (half + G * UN - 1) / (G * UN), n_steps = (n - 1) * chunks;
+    float4 v[UN], vn[UN];
+    float a[UN], an[UN];
+    auto fetch = [&](int s, float4* vv, float* aa) {
+        const int r = s / chunks, m0 = (s - r * chunks) * G * UN + g;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            int lo, hi;
+            const bool ok = rr_pair(n, F, r, m0 + u * G, half, lo, hi);
+            const int p = ok ? lo * F - (lo * (lo + 1)) / 2 + (hi - lo - 1) : 0;
+            vv[u] = c[(size_t)p * KQ + kq];
+            aa[u] = ad[p];
+        }
+    };
+    fetch(0, v, a);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int s = 0; s < n_steps; ++s) {
+        if (s + 1 < n_steps) fetch(s + 1, vn, an);
+        const int r = s / chunks, m0 = (s - r * chunks) * G * UN + g;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            int lo, hi;
+            if (rr_pair(n, F, r, m0 + u * G, half, lo, hi)) {
+                const float4 w = make_float4(v[u].x + a[u] * dk.x, v[u].y + a[u] * dk.y, v[u].z + a[u] * dk.z, v[u].w + a[u] * dk.w);
+                const float4 el = es[lo * KQ + kq], eh = es[hi * KQ + kq];
+                float4 al = acc[lo * KQ + kq], ah = acc[hi * KQ + kq];
+                al.x += w.x * eh.x; al.y += w.y * eh.y; al.z += w.z * eh.z; al.w += w.w * eh.w;
+                ah.x += w.x * el.x; ah.y += w.y * el.y; ah.z += w.z * el.z; ah.w += w.w * el.w;
+                acc[lo * KQ + kq] = al;
+                acc[hi * KQ + kq] = ah;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { v[u] = vn[u]; a[u] = an[u]; }
+    }
+    for (int x = t; x < F * KQ; x += 256) dE[(size_t)b * de_ld4 + x] = acc[x];
+}
+
+template <int KQ, int UN>
+int launch_pair_bwd_rr(const float* e, int e_ld, const float* att_drop, const float* dye, int dye_ld, const float* g2, int B, int F, int P,
+                       float* dE, int de_ld, size_t lds, hipStream_t st) {
+    auto kern = afm_pair_bwd_rr_kernel<KQ, UN>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    DCTR_HIP_CHECK(attr);
+    kern<<<B, 256, lds, st>>>(reinterpret_cast<const float4*>(e), e_ld / 4, att_drop, dye, dye_ld, reinterpret_cast<const float4*>(g2), F, P,
+                              reinterpret_cast<float4*>(dE), de_ld / 4);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
 int afm_pair_bwd(const float* e, int e_ld, const float* att_drop, const float* dye, int dye_ld, const float* g2, const int16_t* pair_i,
                  const int16_t* pair_j, int B, int F, int K, int P, float* dE, int de_ld, hipStream_t st) {
-    (void)pair_i; (void)pair_j;
     static const bool old = getenv("DCTR_AFM_PAIR_BWD_OLD") != nullptr;          // A/B knob: the one-load-per-pair kernel
+    static const bool once = getenv("DCTR_AFM_PAIR_BWD_ONCE") != nullptr;        // A/B knob: the one-pass LDS-accumulator kernel
+    const size_t lds_once = (size_t)F * K * sizeof(float);
+    if (once && !old && lds_once <= 64 * 1024 && e_ld % 4 == 0 && de_ld % 4 == 0 && dye_ld % 4 == 0) {
+#define DCTR_PO(Q) case Q: afm_pair_bwd_once_kernel<Q><<<B, 256, lds_once, st>>>(reinterpret_cast<const float4*>(e), e_ld / 4, att_drop, dye, dye_ld, \
+                              reinterpret_cast<const float4*>(g2), pair_i, pair_j, F, P, reinterpret_cast<float4*>(dE), de_ld / 4); DCTR_LAUNCH_CHECK(); return DCTR_OK;
+        switch (K / 4) { DCTR_PO(1) DCTR_PO(2) DCTR_PO(4) DCTR_PO(8) DCTR_PO(16) DCTR_PO(32) DCTR_PO(64) default: break; }
+#undef DCTR_PO
+    }
+    static const bool no_rr = getenv("DCTR_AFM_PAIR_BWD_TWICE") != nullptr;      // A/B knob: the two-reads kernel at every K
+    const size_t lds_rr = (size_t)2 * F * K * sizeof(float);
+    if (!old && !no_rr && F >= 2 && K >= 64 && lds_rr <= 160 * 1024 && e_ld % 4 == 0 && de_ld % 4 == 0 && dye_ld % 4 == 0) {
+        switch (K / 4) {
+            case 16: return launch_pair_bwd_rr<16, 2>(e, e_ld, att_drop, dye, dye_ld, g2, B, F, P, dE, de_ld, lds_rr, st);
+            case 32: return launch_pair_bwd_rr<32, 3>(e, e_ld, att_drop, dye, dye_ld, g2, B, F, P, dE, de_ld, lds_rr, st);
+            case 64: return launch_pair_bwd_rr<64, 5>(e, e_ld, att_drop, dye, dye_ld, g2, B, F, P, dE, de_ld, lds_rr, st);
+            default: break;
+        }
+    }
     if (!old && F >= 2 && e_ld % 4 == 0 && de_ld % 4 == 0 && dye_ld % 4 == 0) {
         dim3 grid(ceil_div(F * (K / 4), 256), B);
 #define DCTR_PB(Q) case Q: afm_pair_bwd_v4_kernel<Q><<<grid, 256, 0, st>>>(reinterpret_cast<const float4*>(e), e_ld / 4, att_drop, dye, dye_ld, \
@@ -246,6 +418,16 @@ int afm_pair_bwd(const float* e, int e_ld, const float* att_drop, const float* d
 }  // namespace dctr
 
 using namespace dctr;
+
+constexpr int AFM_MAX_CHUNKS = 8;
+static int afm_chunks_wanted(int B, int P) {
+    // OFF by default: measured at the reference point (B = 4096, K = A = 256) 2 / 4 / 8 chunks = 14.4 / 14.9 / 16.6 ms against 14.0
+    // whole-batch -- the products stream their tall operand from HBM and every one of them slows down by about what the pass
+    // running beside it takes (forward product 3.3 -> 5.6 ms per step under the other lane's elementwise passes).
+    static const int forced = getenv("DCTR_AFM_CHUNKS") ? atoi(getenv("DCTR_AFM_CHUNKS")) : 1;     // A/B knob
+    (void)P;
+    return std::max(1, std::min(forced, std::min(B, AFM_MAX_CHUNKS)));
+}
 
 int afm_declare_params(dctr_engine* E) {
     auto add = engine_add_param;
@@ -266,7 +448,9 @@ int afm_declare_params(dctr_engine* E) {
     for (int l = 0; l < nl; ++l) {
         Fc fc;
         fc.in = d; fc.out = c.attention_layers[l];
-        fc.splits = E->afm_fused ? AFM_SLABS : choose_wgrad_splits(E->MB * E->P, fc.in, fc.out);
+        // (the unfused path runs in up to AFM_MAX_CHUNKS chunks of examples, each with a full set of weight-gradient slabs)
+        const int nc_max = afm_chunks_wanted(E->MB, E->P);
+        fc.splits = E->afm_fused ? AFM_SLABS : nc_max * choose_wgrad_splits(ceil_div(E->MB, nc_max) * E->P, fc.in, fc.out);
         char nm[64];
         snprintf(nm, sizeof(nm), "att_mlp%d/weights", l);
         fc.w = add(E, nm, {fc.in, fc.out}, false, fc.splits, 0.f);
@@ -307,6 +491,7 @@ int afm_alloc(dctr_engine* E) {
         }
         E->ah = E->ahs.back();
         E->dah = E->dahs.back();
+        DCTR_HIP_CHECK(hipStreamCreateWithFlags(&E->s_afm, hipStreamNonBlocking));
     }
     (void)A;
     DCTR_TRY(dm(&E->sc, MB * P));
@@ -330,39 +515,90 @@ void afm_free(dctr_engine* E) {
     for (float* p : E->dahs) hipFree(p);
     if (E->pair_i) hipFree(E->pair_i);
     if (E->pair_j) hipFree(E->pair_j);
+    if (E->s_afm) hipStreamDestroy(E->s_afm);
+}
+
+// The unfused path (K > 32: the reference's K = 256) CAN run the step's passes over the pair rows in chunks of examples on two
+// lanes (streams): every pass is per example, so chunk c+1's elementwise passes (HBM-bound: pair products, score dot, pooling,
+// ReLU mask, pair backward) would run under chunk c's products instead of between them (DCTR_AFM_CHUNKS=n; see afm_chunks_wanted).  Weight-gradient slabs are split
+// between the chunks (n_part / chunks each), dropout masks are keyed by the example's global index.
+static int afm_chunks(const dctr_engine* E, int B) {
+    int nc = afm_chunks_wanted(B, E->P);
+    if (E->afm_fused || E->s_afm == nullptr) return 1;
+    auto divides = [&](int n) {
+        if (E->params[E->p_ao_w].n_part % n || E->params[E->p_ao_b].n_part % n) return false;
+        for (const Fc& fc : E->att_fc) if (fc.splits % n || E->params[fc.w].n_part % n || E->params[fc.b].n_part % n) return false;
+        return true;
+    };
+    while (nc > 1 && (!divides(nc) || (nc - 1) * ceil_div(B, nc) >= B)) --nc;
+    return nc;
+}
+
+static int afm_pool_fwd(dctr_engine* E, int b0, int n, bool train, hipStream_t st) {
+    const int F = E->F, K = E->K, P = E->P;
+    // the pooling rebuilds the pair products from the example's embeddings when they fit LDS beside its working set
+    const size_t lds_pp = (size_t)P * sizeof(float), lds_e = (size_t)(((P + 3) & ~3) + F * K) * sizeof(float);
+    const bool from_e = lds_e <= 150 * 1024 && E->e_ld % 4 == 0;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(afm_pool_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    DCTR_HIP_CHECK(attr);
+    afm_pool_fwd_kernel<<<n, 256, from_e ? lds_e : lds_pp, st>>>(E->sc, E->pairp, P, K, E->keep_att, E->keep_emb, &E->state->seed_t,
+                                                                 train ? 1 : 0, E->att, E->x_in,
+                                                                 from_e ? reinterpret_cast<const float4*>(E->e) : nullptr, E->e_ld / 4, F, E->pair_i, E->pair_j, b0);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
 }
 
 // after the gather (mode RAW + linear) has filled E->e / E->yw
 int afm_forward(dctr_engine* E, int B, bool train, hipStream_t st) {
-    const int F = E->F, K = E->K, P = E->P, A = E->A, KQ = K / 4;
-    const int64_t n4 = (int64_t)B * P * KQ;
-    afm_pair_fwd_kernel<<<ceil_div(n4, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(E->e), E->e_ld / 4, E->pair_i, E->pair_j, B,
-                                                            P, KQ, reinterpret_cast<float4*>(E->pairp));
-    DCTR_LAUNCH_CHECK();
+    const int K = E->K, P = E->P, A = E->A, KQ = K / 4;
     if (E->afm_fused) {
+        afm_pair_fwd_kernel<false><<<dim3(ceil_div(P * KQ, 256 * PAIR_FWD_U), B), 256, 0, st>>>(reinterpret_cast<const float4*>(E->e), E->e_ld / 4, E->pair_i, E->pair_j, B,
+                                                                P, KQ, reinterpret_cast<float4*>(E->pairp));
+        DCTR_LAUNCH_CHECK();
         // scores straight from the pair products (the hidden layer never leaves the registers; the backward recomputes it)
         DCTR_TRY(afm_att_fwd(E->pairp, E->pp(E->p_att_w), E->pp(E->p_att_b), E->pp(E->p_ao_w), E->pp(E->p_ao_b), (int64_t)B * P, K, A, E->sc, st));
-    } else {
-        const float* x = E->pairp;
-        for (size_t l = 0; l < E->att_fc.size(); ++l) {     // relu(x W_l + b_l) over the B*P pair rows
-            const Fc& fc = E->att_fc[l];
-            DCTR_TRY(fc_fwd(x, fc.in, E->pp(fc.w), E->pp(fc.b), E->ahs[l], fc.out, B * P, fc.in, fc.out, 1, 1.f, nullptr, 0, st));
-            x = E->ahs[l];
-        }
-        DCTR_TRY(rowdot(E->ah, A, E->pp(E->p_ao_w), E->pp(E->p_ao_b), B * P, A, E->sc, 0, st));
+        return afm_pool_fwd(E, 0, B, train, st);
     }
-    {
-        // the pooling rebuilds the pair products from the example's embeddings when they fit LDS beside its working set
-        const size_t lds_pp = (size_t)P * sizeof(float), lds_e = (size_t)(((P + 3) & ~3) + F * K) * sizeof(float);
-        const bool from_e = lds_e <= 150 * 1024 && E->e_ld % 4 == 0;
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(afm_pool_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        DCTR_HIP_CHECK(attr);
-        afm_pool_fwd_kernel<<<B, 256, from_e ? lds_e : lds_pp, st>>>(E->sc, E->pairp, P, K, E->keep_att, E->keep_emb, &E->state->seed_t,
-                                                                     train ? 1 : 0, E->att, E->x_in,
-                                                                     from_e ? reinterpret_cast<const float4*>(E->e) : nullptr, E->e_ld / 4, F, E->pair_i, E->pair_j);
+    const int nc = afm_chunks(E, B), bc = ceil_div(B, nc);
+    if (nc > 1) DCTR_TRY(fork(E, st, E->s_afm));
+    for (int c = 0; c < nc; ++c) {
+        hipStream_t s = (c & 1) ? E->s_afm : st;
+        const int b0 = c * bc, n = std::min(bc, B - b0);
+        const size_t r0 = (size_t)b0 * P;
+        // nontemporal stores once the pair tensor cannot stay in the caches anyway (3.1 GB at the reference point: 13.52 -> 13.42 ms/step)
+        static const bool nt_off = getenv("DCTR_AFM_PAIR_FWD_NT") != nullptr && atoi(getenv("DCTR_AFM_PAIR_FWD_NT")) == 0;       // A/B knob
+        const bool nt = !nt_off && (size_t)n * P * K * sizeof(float) > ((size_t)512 << 20);
+        (nt ? afm_pair_fwd_kernel<true> : afm_pair_fwd_kernel<false>)<<<dim3(ceil_div(P * KQ, 256 * PAIR_FWD_U), n), 256, 0, s>>>(reinterpret_cast<const float4*>(E->e + (size_t)b0 * E->e_ld), E->e_ld / 4, E->pair_i,
+                                                               E->pair_j, n, P, KQ, reinterpret_cast<float4*>(E->pairp + r0 * K));
         DCTR_LAUNCH_CHECK();
+        const float* x = E->pairp + r0 * K;
+        for (size_t l = 0; l < E->att_fc.size(); ++l) {     // relu(x W_l + b_l) over the chunk's pair rows
+            const Fc& fc = E->att_fc[l];
+            float* y = E->ahs[l] + r0 * fc.out;
+            DCTR_TRY(fc_fwd(x, fc.in, E->pp(fc.w), E->pp(fc.b), y, fc.out, n * P, fc.in, fc.out, 1, 1.f, nullptr, 0, s));
+            x = y;
+        }
+        DCTR_TRY(rowdot(E->ah + r0 * A, A, E->pp(E->p_ao_w), E->pp(E->p_ao_b), n * P, A, E->sc + r0, 0, s));
+        DCTR_TRY(afm_pool_fwd(E, b0, n, train, s));
     }
+    if (nc > 1) DCTR_TRY(fork(E, E->s_afm, st));
     return DCTR_OK;      // the fc(K -> 1) output layer is fused into the head kernel
+}
+
+static int afm_pool_bwd(dctr_engine* E, int b0, int n, hipStream_t st) {
+    const int F = E->F, K = E->K, P = E->P;
+    const size_t lds_pp = (size_t)(K + P) * sizeof(float), lds_e = (size_t)(((K + P + 3) & ~3) + F * K) * sizeof(float);
+    // (rebuilding the pair products from LDS-staged embeddings pays in the forward pooling, 0.51 -> 0.24 ms at K = 256, but not
+    //  here: 0.66 -> 0.85 ms, the 40 KB of LDS per block cost more occupancy than the 759 KB read saves; DCTR_AFM_POOL_BWD_E=1)
+    static const bool want_e = getenv("DCTR_AFM_POOL_BWD_E") != nullptr;
+    const bool from_e = want_e && lds_e <= 150 * 1024 && E->e_ld % 4 == 0;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(afm_pool_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    DCTR_HIP_CHECK(attr);
+    afm_pool_bwd_kernel<<<n, 256, from_e ? lds_e : lds_pp, st>>>(E->dx_in, E->Din_ld, E->pairp, E->att, P, K, E->keep_att, E->keep_emb,
+                                                                 &E->state->seed_t, E->dsc, E->sc,
+                                                                 from_e ? reinterpret_cast<const float4*>(E->e) : nullptr, E->e_ld / 4, F, E->pair_i, E->pair_j, b0);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
 }
 
 // leaves dL/de in E->dE_buf; dense-gradient partial slabs in E->parts
@@ -374,22 +610,10 @@ int afm_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
     DCTR_TRY(out_layer_bwd(E->x_in, E->Din_ld, E->dy, E->pp(E->p_out_w), B, K, pw.n_part, 0, 1.f, E->dx_in, E->Din_ld,
                            E->part(E->p_out_w), pw.padded, E->part(E->p_out_b), pb.padded, st));
     // (E->sc, the forward's scores, is free by now: it takes the post-dropout attention)
-    {
-        const size_t lds_pp = (size_t)(K + P) * sizeof(float), lds_e = (size_t)(((K + P + 3) & ~3) + F * K) * sizeof(float);
-        // (rebuilding the pair products from LDS-staged embeddings pays in the forward pooling, 0.51 -> 0.24 ms at K = 256, but not
-        //  here: 0.66 -> 0.85 ms, the 40 KB of LDS per block cost more occupancy than the 759 KB read saves; DCTR_AFM_POOL_BWD_E=1)
-        static const bool want_e = getenv("DCTR_AFM_POOL_BWD_E") != nullptr;
-        const bool from_e = want_e && lds_e <= 150 * 1024 && E->e_ld % 4 == 0;
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(afm_pool_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        DCTR_HIP_CHECK(attr);
-        afm_pool_bwd_kernel<<<B, 256, from_e ? lds_e : lds_pp, st>>>(E->dx_in, E->Din_ld, E->pairp, E->att, P, K, E->keep_att, E->keep_emb,
-                                                                     &E->state->seed_t, E->dsc, E->sc,
-                                                                     from_e ? reinterpret_cast<const float4*>(E->e) : nullptr, E->e_ld / 4, F, E->pair_i, E->pair_j);
-        DCTR_LAUNCH_CHECK();
-    }
     const Param& aw = E->params[E->p_ao_w];
     const Param& ab = E->params[E->p_ao_b];
     if (E->afm_fused) {
+        DCTR_TRY(afm_pool_bwd(E, 0, B, st));
         const Param& w = E->params[E->p_att_w];
         const Param& b = E->params[E->p_att_b];
         DCTR_TRY(afm_att_bwd(E->pairp, E->pp(E->p_att_w), E->pp(E->p_att_b), E->pp(E->p_ao_w), E->dsc, (int64_t)B * P, K, A, E->dpairp2,
@@ -397,20 +621,41 @@ int afm_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
                              E->part(E->p_ao_b), ab.padded, AFM_SLABS, st));
         return afm_pair_bwd(E->e, E->e_ld, E->sc, E->dx_in, E->Din_ld, E->dpairp2, E->pair_i, E->pair_j, B, F, K, P, E->dE_buf, E->D, st);
     }
-    // attention_out (A -> 1) over the B*P rows: d ah = dsc (x) w_o masked by relu, dW_o / db_o partial slabs
-    DCTR_TRY(out_layer_bwd(E->ah, A, E->dsc, E->pp(E->p_ao_w), B * P, A, aw.n_part, 1, 1.f, E->dah, A, E->part(E->p_ao_w), aw.padded,
-                           E->part(E->p_ao_b), ab.padded, st));
-    // attention layers, last to first: wgrad on the side stream, dgrad (x the ReLU mask of the layer below) on the critical path
-    for (int l = (int)E->att_fc.size() - 1; l >= 0; --l) {
-        const Fc& fc = E->att_fc[l];
-        const Param& w = E->params[fc.w];
-        const Param& b = E->params[fc.b];
-        const float* xin = l > 0 ? E->ahs[l - 1] : E->pairp;
-        DCTR_TRY(fork(E, st, sw));              // dahs[l] is complete on st
-        DCTR_TRY(fc_bwd_weights_partials(xin, fc.in, E->dahs[l], fc.out, E->part(fc.w), w.padded, E->part(fc.b), b.padded, B * P, fc.in, fc.out,
-                                         fc.splits, sw));
-        if (l > 0) DCTR_TRY(fc_bwd_data(E->dahs[l], fc.out, E->pp(fc.w), E->dahs[l - 1], fc.in, B * P, fc.in, fc.out, E->ahs[l - 1], fc.in, 1.f, st));
-        else DCTR_TRY(fc_bwd_data(E->dahs[0], fc.out, E->pp(fc.w), E->dpairp2, K, B * P, K, fc.out, nullptr, 0, 1.f, st));
+    const int nc = afm_chunks(E, B), bc = ceil_div(B, nc);
+    if (nc > 1) DCTR_TRY(fork(E, st, E->s_afm));
+    for (int c = 0; c < nc; ++c) {
+        hipStream_t s = (c & 1) ? E->s_afm : st;
+        const int b0 = c * bc, n = std::min(bc, B - b0);
+        const size_t r0 = (size_t)b0 * P;
+        DCTR_TRY(afm_pool_bwd(E, b0, n, s));
+        // attention_out (A -> 1) over the chunk's rows: d ah = dsc (x) w_o masked by relu, dW_o / db_o partial slabs
+        const int ao_n = aw.n_part / nc, ab_n = ab.n_part / nc;
+        DCTR_REQUIRE(ao_n == ab_n, "AFM: attention_out weight / bias slab counts differ");
+        DCTR_TRY(out_layer_bwd(E->ah + r0 * A, A, E->dsc + r0, E->pp(E->p_ao_w), n * P, A, ao_n, 1, 1.f, E->dah + r0 * A, A,
+                               E->part(E->p_ao_w) + (size_t)c * ao_n * aw.padded, aw.padded, E->part(E->p_ao_b) + (size_t)c * ab_n * ab.padded,
+                               ab.padded, s));
+        // attention layers, last to first: wgrad on the side stream (one chunk: beside its dgrad; several: the other lane's passes
+        // are what runs beside it), dgrad (x the ReLU mask of the layer below) on the lane
+        for (int l = (int)E->att_fc.size() - 1; l >= 0; --l) {
+            const Fc& fc = E->att_fc[l];
+            const Param& w = E->params[fc.w];
+            const Param& b = E->params[fc.b];
+            const float* xin = l > 0 ? E->ahs[l - 1] + r0 * fc.in : E->pairp + r0 * K;
+            const float* dy = E->dahs[l] + r0 * fc.out;
+            const int sp = fc.splits / nc;
+            hipStream_t swl = nc > 1 ? s : sw;
+            if (nc == 1) DCTR_TRY(fork(E, st, sw));              // dahs[l] is complete on st
+            float* dwp = E->part(fc.w) + (size_t)c * sp * w.padded;
+            float* dbp = E->part(fc.b) + (size_t)c * sp * b.padded;
+            if (nc == 1) DCTR_TRY(fc_bwd_weights_partials(xin, fc.in, dy, fc.out, dwp, w.padded, dbp, b.padded, n * P, fc.in, fc.out, sp, swl));
+            if (l > 0) DCTR_TRY(fc_bwd_data(dy, fc.out, E->pp(fc.w), E->dahs[l - 1] + r0 * fc.in, fc.in, n * P, fc.in, fc.out, E->ahs[l - 1] + r0 * fc.in, fc.in, 1.f, s));
+            else DCTR_TRY(fc_bwd_data(dy, fc.out, E->pp(fc.w), E->dpairp2 + r0 * K, K, n * P, K, fc.out, nullptr, 0, 1.f, s));
+            if (l == 0)
+                DCTR_TRY(afm_pair_bwd(E->e + (size_t)b0 * E->e_ld, E->e_ld, E->sc + r0, E->dx_in + (size_t)b0 * E->Din_ld, E->Din_ld, E->dpairp2 + r0 * K,
+                                      E->pair_i, E->pair_j, n, F, K, P, E->dE_buf + (size_t)b0 * E->D, E->D, s));
+            if (nc > 1) DCTR_TRY(fc_bwd_weights_partials(xin, fc.in, dy, fc.out, dwp, w.padded, dbp, b.padded, n * P, fc.in, fc.out, sp, swl));
+        }
     }
-    return afm_pair_bwd(E->e, E->e_ld, E->sc, E->dx_in, E->Din_ld, E->dpairp2, E->pair_i, E->pair_j, B, F, K, P, E->dE_buf, E->D, st);
+    if (nc > 1) DCTR_TRY(fork(E, E->s_afm, st));
+    return DCTR_OK;
 }

@@ -135,6 +135,7 @@ struct dctr_engine {
     uint64_t timer_tick = 0;
     hipStream_t s_group = nullptr, s_wgrad = nullptr;   // side streams of the step DAG
     hipStream_t s_opt = nullptr;                          // dense optimizer steps behind the deferred weight gradients (wgrad_late)
+    hipStream_t s_afm = nullptr;                          // AFM's unfused path: the second lane of its chunked passes (afm.hip)
     bool opt_pending = false;                             // s_opt holds work of this step: joined at the end of record_train
     int64_t* auc_counts = nullptr;   // [4*200] tp,fn,tn,fp per threshold (tf.metrics.auc)
     float* eval_scalars = nullptr;   // [0] sum xent over the eval set, [1..] scratch

@@ -119,7 +119,10 @@ constexpr Tile FWD_TILES[] = {{2, 13}, {4, 7}, {2, 8}, {1, 4}};
 constexpr Tile DGRAD_TILES[] = {{2, 13}, {4, 10}, {2, 8}, {1, 4}};
 // (no 3x13 here: 392 VGPRs -- a wgrad runs beside the background table pass, whose two waves per SIMD leave room for 320)
 // (2x16: a 256-wide output in one column block -- AFM's attention weight over 3 M pair rows, 8 row tiles x 32 batch splits)
-constexpr Tile WGRAD_TILES[] = {{2, 13}, {2, 16}, {2, 8}};
+// (4x8: 64 x 128 per block -- a reduction over millions of rows streams BOTH operands, and every wave loads its whole tile's rows:
+//  16 (16 TM + 16 TN) 4 bytes per 16-row group, i.e. 14 flop/byte for 2x16 but 21 for 4x8; at the MFMA rate the 2x16 tile asks the
+//  L2s for 9 TB/s)
+constexpr Tile WGRAD_TILES[] = {{2, 13}, {2, 16}, {2, 8}, {4, 8}};
 
 }  // namespace
 
@@ -133,6 +136,11 @@ inline bool streaming_rows(int64_t M, int K = 32, int N = 128) {
     return on && M >= (1 << 20) && K >= 32 && N >= 128;                         // (whole 32 x 128 tiles)
 }
 int dr_wgrad_splits(int M, int K, int N);
+// a weight gradient over millions of rows whose output is whole 64 x 128 tiles: the 4 x 8 tile (A/B knob DCTR_WGRAD_48=0)
+inline bool tall_square(int64_t M, int K, int N) {
+    static const bool off = [] { const char* v = getenv("DCTR_WGRAD_48"); return v != nullptr && v[0] == '0'; }();
+    return !off && M >= (1 << 20) && K % 64 == 0 && N % 128 == 0;
+}
 int gemm_plan(char op, int M, int K, int N, char* out, int out_len) {
     double eff = 0.0;
     int t = -1, s = 1;
@@ -152,6 +160,8 @@ int gemm_plan(char op, int M, int K, int N, char* out, int out_len) {
         if (dr_wgrad_splits(M, K, N) == s && s > 0 && (int64_t)ceil_div(M, s) >= 64 && (N & 3) == 0 && streaming_rows(M, K, N) &&
             (int64_t)ceil_div(K, 32) * ceil_div(N, 128) * s <= 2 * CUS) {
             tile = &WGRAD_TILES[2];           // millions of rows from HBM: 2 x 8, two blocks per CU
+        } else if (dr_wgrad_splits(M, K, N) == s && s > 0 && (int64_t)ceil_div(M, s) >= 64 && tall_square(M, K, N) && (int64_t)(K / 64) * (N / 128) * s <= CUS) {
+            tile = &WGRAD_TILES[3];
         } else if (dr_wgrad_splits(M, K, N) == s && s > 0 && (int64_t)ceil_div(M, s) >= 64 && (N & 3) == 0) {
             t = pick(WGRAD_TILES, K, N, M, s, &eff);
             int blocks = 0;
@@ -225,6 +235,7 @@ int dr_wgrad_splits(int M, int K, int N) {
         const int tiles = ceil_div(K, 32) * ceil_div(N, 128);
         if (tiles <= 2 * CUS) return std::max(1, 2 * CUS / tiles);
     }
+    if (tall_square(M, K, N) && (K / 64) * (N / 128) <= CUS) return std::max(1, CUS / ((K / 64) * (N / 128)));
     int best_s = 0;
     double best = 0.0;
     for (const Tile& t : WGRAD_TILES) {
@@ -250,6 +261,7 @@ int dr_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int ldd
     int t = pick(WGRAD_TILES, K, N, M, splits, &eff);
     const bool stream = streaming_rows(M, K, N) && (int64_t)ceil_div(K, 32) * ceil_div(N, 128) * splits <= 2 * CUS;
     if (stream) t = 2;
+    else if (tall_square(M, K, N) && (int64_t)(K / 64) * (N / 128) * splits <= CUS) t = 3;
     else {
         if (t < 0 || eff < dr_threshold()) return DCTR_OK;
         int blocks = 0;
@@ -264,7 +276,8 @@ int dr_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int ldd
     switch (t) {
         case 0: return dr_launch<2, 13, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
         case 1: return dr_launch<2, 16, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
-        default: return dr_launch<2, 8, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
+        case 2: return dr_launch<2, 8, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
+        default: return dr_launch<4, 8, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
     }
 }
 
