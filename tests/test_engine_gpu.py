@@ -300,11 +300,12 @@ def test_afm_attention_widths(K, A, dev):
     assert np.abs(logit.cpu().numpy() - O.forward(ocfg, params, ids, vals)["y"].numpy()).max() <= 1e-4
 
 
-@pytest.mark.parametrize("K,F", [(64, 13), (64, 12), (128, 9), (256, 39), (256, 6), (72, 7)])
-def test_afm_wide_embeddings_pair_backward(K, F, dev):
-    """K >= 64 (the reference runs AFM at K = 256, run.sh:18): the pair backward walks the pairs of an example in round-robin
-    order (every row of d(pair tensor) read once, odd field counts have a bye); K = 72 pads to 128 physical columns."""
-    V, B = 1500, 37
+@pytest.mark.parametrize("K,F,B", [(64, 13, 37), (64, 12, 520), (128, 9, 513), (256, 39, 37), (256, 6, 600), (72, 7, 530)])
+def test_afm_wide_embeddings_pair_backward(K, F, B, dev):
+    """K >= 64 (the reference runs AFM at K = 256, run.sh:18).  From 512 examples on the pair backward walks the pairs of an example
+    in round-robin order (every row of d(pair tensor) read once; odd field counts have a bye), below that the two-reads kernel
+    and the 1024-thread pooling kernels run; K = 72 pads to 128 physical columns."""
+    V = 1500
     ocfg, params, eng = make_pair("afm", B=B, F=F, V=V, K=K, layers=(1,), att=(24,), opt="Adagrad", lr=1e-2)
     oopt = O.Optimizer(ocfg, params)
     for step in range(2):

@@ -61,42 +61,47 @@ __global__ __launch_bounds__(256) void afm_pair_fwd_kernel(const float4* __restr
 // one block per example: softmax over the P scores, attention dropout, pooling over the pairs, y_emb dropout
 // (ee != nullptr: the pair products are rebuilt from the example's embeddings, staged in LDS behind the weights -- 40 KB read per
 //  example instead of its 759 KB slice of the [B P, K] pair tensor, K = 256)
-__global__ __launch_bounds__(256) void afm_pool_fwd_kernel(const float* __restrict__ sc, const float* __restrict__ pp, int P, int K,
+template <int NT>
+__global__ __launch_bounds__(NT) void afm_pool_fwd_kernel(const float* __restrict__ sc, const float* __restrict__ pp, int P, int K,
                                                           float keep_att, float keep_emb, const uint64_t* __restrict__ seed_ptr,
                                                           int train, float* __restrict__ att, float* __restrict__ yemb,
                                                           const float4* __restrict__ ee, int e_ld4, int F, const int16_t* __restrict__ pi,
                                                           const int16_t* __restrict__ pj, int b0) {
     extern __shared__ __attribute__((aligned(16))) float sm[];        // [P] attention weights (after dropout) | [F][K] embeddings (ee)
-    __shared__ float red[4];
+    __shared__ float red[NT / 64];
     const int b = b0 + blockIdx.x, t = threadIdx.x;
     float4* es = reinterpret_cast<float4*>(sm + ((P + 3) & ~3));
     if (ee != nullptr)
-        for (int x = t; x < F * (K >> 2); x += 256) es[x] = ee[(size_t)b * e_ld4 + x];
+        for (int x = t; x < F * (K >> 2); x += NT) es[x] = ee[(size_t)b * e_ld4 + x];
     const float* s = sc + (size_t)b * P;
     float m = -3.0e38f;
-    for (int p = t; p < P; p += 256) m = fmaxf(m, s[p]);
+    for (int p = t; p < P; p += NT) m = fmaxf(m, s[p]);
     m = wmax64(m);
     if ((t & 63) == 0) red[t >> 6] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    m = red[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, red[w]);
     __syncthreads();
     float z = 0.f;
-    for (int p = t; p < P; p += 256) { const float ex = expf(s[p] - m); sm[p] = ex; z += ex; }
+    for (int p = t; p < P; p += NT) { const float ex = expf(s[p] - m); sm[p] = ex; z += ex; }
     z = wsum64(z);
     if ((t & 63) == 0) red[t >> 6] = z;
     __syncthreads();
-    z = red[0] + red[1] + red[2] + red[3];
+    z = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) z += red[w];
     const float inv = 1.0f / z;
     const uint64_t seed = (train && (keep_att < 1.f || keep_emb < 1.f)) ? *seed_ptr : 0ull;
-    for (int p = t; p < P; p += 256) {
+    for (int p = t; p < P; p += NT) {
         const float a = sm[p] * inv;
         att[(size_t)b * P + p] = a;                                            // softmax output (before dropout): kept for the backward
         sm[p] = (train && keep_att < 1.f) ? a * dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_ATT, (uint64_t)b * P + p, keep_att) : a;
     }
     __syncthreads();
     // y_emb[k] = sum_p a'[p] pp[p,k]: thread = (pair slice, float4 piece), slices summed through LDS
-    __shared__ float4 acc4[256];
-    const int KQ = K >> 2, q = t % KQ, slice = t / KQ, n_slices = 256 / KQ;
+    __shared__ float4 acc4[NT];
+    const int KQ = K >> 2, q = t % KQ, slice = t / KQ, n_slices = NT / KQ;
     const float4* pp4 = reinterpret_cast<const float4*>(pp) + (size_t)b * P * KQ;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int p = slice; p < P; p += n_slices) {
@@ -124,21 +129,22 @@ __global__ __launch_bounds__(256) void afm_pool_fwd_kernel(const float* __restri
 // backward of dropout[1] -> pooling -> dropout[0] -> softmax.  in: dy [B, dy_ld] = d y_emb (post-dropout); out: dsc [B,P], the
 // post-dropout attention a' [B,P] and, in place of dy, the pre-dropout d y_emb.  d pp = a' (x) d y_emb is NOT materialised: the
 // pair backward below forms it from these two.
-__global__ __launch_bounds__(256) void afm_pool_bwd_kernel(float* __restrict__ dy, int dy_ld, const float* __restrict__ pp,
+template <int NT>
+__global__ __launch_bounds__(NT) void afm_pool_bwd_kernel(float* __restrict__ dy, int dy_ld, const float* __restrict__ pp,
                                                           const float* __restrict__ att, int P, int K, float keep_att, float keep_emb,
                                                           const uint64_t* __restrict__ seed_ptr, float* __restrict__ dsc,
                                                           float* __restrict__ att_drop, const float4* __restrict__ ee, int e_ld4, int F,
                                                           const int16_t* __restrict__ pi, const int16_t* __restrict__ pj, int b0) {
     extern __shared__ __attribute__((aligned(16))) float sm[];        // [K] dyemb (pre-dropout gradient) | [P] da | [F][K] embeddings (ee)
-    __shared__ float red[4];
+    __shared__ float red[NT / 64];
     float* dye = sm;
     float* da = sm + K;
     const int b = b0 + blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     float4* es = reinterpret_cast<float4*>(sm + ((K + P + 3) & ~3));
     if (ee != nullptr)
-        for (int x = t; x < F * (K >> 2); x += 256) es[x] = ee[(size_t)b * e_ld4 + x];
+        for (int x = t; x < F * (K >> 2); x += NT) es[x] = ee[(size_t)b * e_ld4 + x];
     const uint64_t seed = (keep_att < 1.f || keep_emb < 1.f) ? *seed_ptr : 0ull;
-    for (int k = t; k < K; k += 256) {
+    for (int k = t; k < K; k += NT) {
         float g = dy[(size_t)b * dy_ld + k];
         if (keep_emb < 1.f) g *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + k, keep_emb);
         dye[k] = g;
@@ -151,30 +157,41 @@ __global__ __launch_bounds__(256) void afm_pool_bwd_kernel(float* __restrict__ d
     const float4 d4 = reinterpret_cast<const float4*>(dye)[q];
     const float* ab = att + (size_t)b * P;
     float part = 0.f;                                          // sum_q att[q] * da[q]
-    for (int i = t; i < P * KQ; i += 256) {
-        const int p = i / KQ;
-        float4 v;
-        if (ee != nullptr) {
-            const float4 x = es[pi[p] * KQ + q], y = es[pj[p] * KQ + q];
-            v = make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
-        } else {
-            v = pp4[i];
+    // (PB_U rows in flight per thread: one load per trip leaves a lone block per CU -- a small batch -- waiting out every latency)
+    constexpr int PB_U = 4;
+    for (int i0 = t; i0 < P * KQ; i0 += NT * PB_U) {
+        float4 v[PB_U];
+#pragma unroll
+        for (int u = 0; u < PB_U; ++u) {
+            const int i = min(i0 + u * NT, P * KQ - 1), p = i / KQ;
+            if (ee != nullptr) {
+                const float4 x = es[pi[p] * KQ + q], y = es[pj[p] * KQ + q];
+                v[u] = make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
+            } else {
+                v[u] = pp4[i];
+            }
         }
-        float s = d4.x * v.x + d4.y * v.y + d4.z * v.z + d4.w * v.w;
-        for (int o = 1; o < KQ; o <<= 1) s += __shfl_xor(s, o);
-        if (q == 0) {
-            const float msk = keep_att < 1.f ? dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_ATT, (uint64_t)b * P + p, keep_att) : 1.f;
-            const float d = s * msk, a = ab[p];                // d att[p]
-            da[p] = d;
-            att_drop[(size_t)b * P + p] = a * msk;
-            part += a * d;
+#pragma unroll
+        for (int u = 0; u < PB_U; ++u) {
+            const int i = i0 + u * NT, p = min(i, P * KQ - 1) / KQ;
+            float s = d4.x * v[u].x + d4.y * v[u].y + d4.z * v[u].z + d4.w * v[u].w;
+            for (int o = 1; o < KQ; o <<= 1) s += __shfl_xor(s, o);
+            if (q == 0 && i < P * KQ) {
+                const float msk = keep_att < 1.f ? dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_ATT, (uint64_t)b * P + p, keep_att) : 1.f;
+                const float d = s * msk, a = ab[p];                // d att[p]
+                da[p] = d;
+                att_drop[(size_t)b * P + p] = a * msk;
+                part += a * d;
+            }
         }
     }
     part = wsum64(part);
     if (lane == 0) red[wave] = part;
     __syncthreads();
-    const float tot = red[0] + red[1] + red[2] + red[3];
-    for (int p = t; p < P; p += 256) dsc[(size_t)b * P + p] = ab[p] * (da[p] - tot);      // softmax backward
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) tot += red[w];
+    for (int p = t; p < P; p += NT) dsc[(size_t)b * P + p] = ab[p] * (da[p] - tot);      // softmax backward
 }
 
 // dE[b,i,:] = sum_{j != i} (a'[b,pair(i,j)] * dyemb[b,:] + g2[b,pair(i,j),:]) * e[b,j,:]      (pooling path + attention path)
@@ -394,7 +411,8 @@ int afm_pair_bwd(const float* e, int e_ld, const float* att_drop, const float* d
     }
     static const bool no_rr = getenv("DCTR_AFM_PAIR_BWD_TWICE") != nullptr;      // A/B knob: the two-reads kernel at every K
     const size_t lds_rr = (size_t)2 * F * K * sizeof(float);
-    if (!old && !no_rr && F >= 2 && K >= 64 && lds_rr <= 160 * 1024 && e_ld % 4 == 0 && de_ld % 4 == 0 && dye_ld % 4 == 0) {
+    // (a block per example: below two blocks per CU the two-reads kernel, ten blocks per example at K = 256, is the faster one)
+    if (!old && !no_rr && B >= 512 && F >= 2 && K >= 64 && lds_rr <= 160 * 1024 && e_ld % 4 == 0 && de_ld % 4 == 0 && dye_ld % 4 == 0) {
         switch (K / 4) {
             case 16: return launch_pair_bwd_rr<16, 2>(e, e_ld, att_drop, dye, dye_ld, g2, B, F, P, dE, de_ld, lds_rr, st);
             case 32: return launch_pair_bwd_rr<32, 3>(e, e_ld, att_drop, dye, dye_ld, g2, B, F, P, dE, de_ld, lds_rr, st);
@@ -443,6 +461,11 @@ int afm_declare_params(dctr_engine* E) {
     // then never materialised, and the four attention parameters take their gradient from AFM_SLABS atomically filled slabs
     // (one hidden layer, the reference's default; the AFM.py:143-145 loop with more widths runs layer by layer)
     E->afm_fused = nl == 1 && getenv("DCTR_AFM_UNFUSED") == nullptr && afm_fused_supported(K, A);        // (the env knob is the A/B switch)
+    // attention_out's gradient slabs: one per ~512 pair rows (1024 at the reference's B = 4096; at B = 128 that many slabs made the
+    // optimizer's slab sum, 1024 dependent strided reads per element, a 98 us kernel)
+    int ao_rows = 128;
+    while (ao_rows < 1024 && (int64_t)ao_rows * 512 < (int64_t)E->MB * E->P) ao_rows *= 2;
+    E->ao_splits = ao_rows;
     const int ao = E->afm_fused ? AFM_SLABS : E->ao_splits;
     int d = K;
     for (int l = 0; l < nl; ++l) {
@@ -538,10 +561,15 @@ static int afm_pool_fwd(dctr_engine* E, int b0, int n, bool train, hipStream_t s
     const int F = E->F, K = E->K, P = E->P;
     // the pooling rebuilds the pair products from the example's embeddings when they fit LDS beside its working set
     const size_t lds_pp = (size_t)P * sizeof(float), lds_e = (size_t)(((P + 3) & ~3) + F * K) * sizeof(float);
-    const bool from_e = lds_e <= 150 * 1024 && E->e_ld % 4 == 0;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(afm_pool_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    const bool from_e = lds_e <= 128 * 1024 && E->e_ld % 4 == 0;
+    // (a small batch is fewer blocks than CUs: 16 waves per example then)
+    const bool wide = n < 512 && K >= 64;
+    auto kern = wide ? afm_pool_fwd_kernel<1024> : afm_pool_fwd_kernel<256>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(afm_pool_fwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    static const hipError_t attr_w = hipFuncSetAttribute(reinterpret_cast<const void*>(afm_pool_fwd_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     DCTR_HIP_CHECK(attr);
-    afm_pool_fwd_kernel<<<n, 256, from_e ? lds_e : lds_pp, st>>>(E->sc, E->pairp, P, K, E->keep_att, E->keep_emb, &E->state->seed_t,
+    DCTR_HIP_CHECK(attr_w);
+    kern<<<n, wide ? 1024 : 256, from_e ? lds_e : lds_pp, st>>>(E->sc, E->pairp, P, K, E->keep_att, E->keep_emb, &E->state->seed_t,
                                                                  train ? 1 : 0, E->att, E->x_in,
                                                                  from_e ? reinterpret_cast<const float4*>(E->e) : nullptr, E->e_ld / 4, F, E->pair_i, E->pair_j, b0);
     DCTR_LAUNCH_CHECK();
@@ -592,9 +620,13 @@ static int afm_pool_bwd(dctr_engine* E, int b0, int n, hipStream_t st) {
     //  here: 0.66 -> 0.85 ms, the 40 KB of LDS per block cost more occupancy than the 759 KB read saves; DCTR_AFM_POOL_BWD_E=1)
     static const bool want_e = getenv("DCTR_AFM_POOL_BWD_E") != nullptr;
     const bool from_e = want_e && lds_e <= 150 * 1024 && E->e_ld % 4 == 0;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(afm_pool_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    const bool wide = n < 512 && K >= 64;
+    auto kern = wide ? afm_pool_bwd_kernel<1024> : afm_pool_bwd_kernel<256>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(afm_pool_bwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    static const hipError_t attr_w = hipFuncSetAttribute(reinterpret_cast<const void*>(afm_pool_bwd_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     DCTR_HIP_CHECK(attr);
-    afm_pool_bwd_kernel<<<n, 256, from_e ? lds_e : lds_pp, st>>>(E->dx_in, E->Din_ld, E->pairp, E->att, P, K, E->keep_att, E->keep_emb,
+    DCTR_HIP_CHECK(attr_w);
+    kern<<<n, wide ? 1024 : 256, from_e ? lds_e : lds_pp, st>>>(E->dx_in, E->Din_ld, E->pairp, E->att, P, K, E->keep_att, E->keep_emb,
                                                                  &E->state->seed_t, E->dsc, E->sc,
                                                                  from_e ? reinterpret_cast<const float4*>(E->e) : nullptr, E->e_ld / 4, F, E->pair_i, E->pair_j, b0);
     DCTR_LAUNCH_CHECK();
@@ -644,12 +676,23 @@ int afm_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
             const float* dy = E->dahs[l] + r0 * fc.out;
             const int sp = fc.splits / nc;
             hipStream_t swl = nc > 1 ? s : sw;
-            if (nc == 1) DCTR_TRY(fork(E, st, sw));              // dahs[l] is complete on st
+            // Below ~1 M pair rows the two products of a layer must NOT run side by side: at the reference's B = 128 (95 k rows) the
+            // weight gradient took 384 us beside the 131 us input gradient and 106 us alone -- each of them fills the chip, and the
+            // pair backward / table step behind the dgrad ran 5x slower under it (step 0.81 -> 0.69 ms serial).  There the weight
+            // gradient starts after the dgrad, beside the HBM-bound passes that follow it.
+            const bool beside_dgrad = nc == 1 && (int64_t)n * P >= (1 << 20);
             float* dwp = E->part(fc.w) + (size_t)c * sp * w.padded;
             float* dbp = E->part(fc.b) + (size_t)c * sp * b.padded;
-            if (nc == 1) DCTR_TRY(fc_bwd_weights_partials(xin, fc.in, dy, fc.out, dwp, w.padded, dbp, b.padded, n * P, fc.in, fc.out, sp, swl));
+            if (beside_dgrad) {
+                DCTR_TRY(fork(E, st, sw));              // dahs[l] is complete on st
+                DCTR_TRY(fc_bwd_weights_partials(xin, fc.in, dy, fc.out, dwp, w.padded, dbp, b.padded, n * P, fc.in, fc.out, sp, swl));
+            }
             if (l > 0) DCTR_TRY(fc_bwd_data(dy, fc.out, E->pp(fc.w), E->dahs[l - 1] + r0 * fc.in, fc.in, n * P, fc.in, fc.out, E->ahs[l - 1] + r0 * fc.in, fc.in, 1.f, s));
             else DCTR_TRY(fc_bwd_data(dy, fc.out, E->pp(fc.w), E->dpairp2 + r0 * K, K, n * P, K, fc.out, nullptr, 0, 1.f, s));
+            if (nc == 1 && !beside_dgrad) {
+                DCTR_TRY(fork(E, st, sw));              // the dgrad is enqueued: the weight gradient runs behind it, beside what follows
+                DCTR_TRY(fc_bwd_weights_partials(xin, fc.in, dy, fc.out, dwp, w.padded, dbp, b.padded, n * P, fc.in, fc.out, sp, swl));
+            }
             if (l == 0)
                 DCTR_TRY(afm_pair_bwd(E->e + (size_t)b0 * E->e_ld, E->e_ld, E->sc + r0, E->dx_in + (size_t)b0 * E->Din_ld, E->Din_ld, E->dpairp2 + r0 * K,
                                       E->pair_i, E->pair_j, n, F, K, P, E->dE_buf + (size_t)b0 * E->D, E->D, s));

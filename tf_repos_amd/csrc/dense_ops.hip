@@ -184,32 +184,35 @@ __global__ __launch_bounds__(256) void out_layer_bwd_kernel(const float* __restr
     }
 }
 
-// float4 variant: 128 column groups x 2 row lanes per block, 4 rows in flight per thread
+// float4 variant: CG column groups x 256/CG row lanes per block (CG = the power of two covering n/4, at most 128: a 256-wide layer
+// -- AFM's attention_out -- keeps every lane busy with 64 x 4), 4 rows in flight per thread
+template <int CG>
 __global__ __launch_bounds__(256) void out_layer_bwd_v4_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy,
                                                               const float* __restrict__ w, int M, int n, int rows_per_block,
                                                               int masked, float inv_keep, float* __restrict__ dx, int lddx,
                                                               float* __restrict__ dw_part, int64_t dw_stride,
                                                               float* __restrict__ db_part, int64_t db_stride) {
-    __shared__ float4 red[128];
+    constexpr int RL = 256 / CG;
+    __shared__ float4 red[RL > 1 ? (RL - 1) * CG : 1];
     const int rbeg = blockIdx.x * rows_per_block, rend = min(M, rbeg + rows_per_block);
-    const int cg = threadIdx.x & 127, rl = threadIdx.x >> 7;
-    for (int c0 = 0; c0 < n; c0 += 512) {
+    const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
+    for (int c0 = 0; c0 < n; c0 += 4 * CG) {
         const int c = c0 + cg * 4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < n) {
             const float4 wc = *reinterpret_cast<const float4*>(w + c);
-            for (int r = rbeg + rl; r < rend; r += 8) {
+            for (int r = rbeg + rl; r < rend; r += 4 * RL) {
                 float4 xv[4];
                 float d[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int rr = r + 2 * u;
+                    const int rr = r + RL * u;
                     d[u] = rr < rend ? dy[rr] : 0.f;
                     xv[u] = rr < rend ? *reinterpret_cast<const float4*>(x + (size_t)rr * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int rr = r + 2 * u;
+                    const int rr = r + RL * u;
                     acc.x += d[u] * xv[u].x; acc.y += d[u] * xv[u].y; acc.z += d[u] * xv[u].z; acc.w += d[u] * xv[u].w;
                     if (dx != nullptr && rr < rend) {
                         float4 g = make_float4(d[u] * wc.x, d[u] * wc.y, d[u] * wc.z, d[u] * wc.w);
@@ -222,11 +225,15 @@ __global__ __launch_bounds__(256) void out_layer_bwd_v4_kernel(const float* __re
                 }
             }
         }
-        if (rl == 1) red[cg] = acc;
+        if (rl > 0) red[(rl - 1) * CG + cg] = acc;
         __syncthreads();
         if (rl == 0 && c < n) {
-            const float4 o = red[cg];
-            *reinterpret_cast<float4*>(dw_part + (size_t)blockIdx.x * dw_stride + c) = make_float4(acc.x + o.x, acc.y + o.y, acc.z + o.z, acc.w + o.w);
+#pragma unroll
+            for (int k = 0; k + 1 < RL; ++k) {
+                const float4 o = red[k * CG + cg];
+                acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+            }
+            *reinterpret_cast<float4*>(dw_part + (size_t)blockIdx.x * dw_stride + c) = acc;
         }
         __syncthreads();
     }
@@ -245,10 +252,10 @@ int out_layer_bwd(const float* x, int ldx, const float* dy, const float* w, int 
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool v4 = n % 4 == 0 && ldx % 4 == 0 && (dx == nullptr || lddx % 4 == 0) && dw_stride % 4 == 0 && al(x) && al(w) && al(dw_part) &&
                     (dx == nullptr || al(dx));
-    if (v4)
-        out_layer_bwd_v4_kernel<<<splits, 256, 0, st>>>(x, ldx, dy, w, M, n, ceil_div(M, splits), masked, 1.0f / keep, dx, lddx,
-                                                         dw_part, dw_stride, db_part, db_stride);
-    else
+    if (v4) {
+        auto kern = n > 256 ? out_layer_bwd_v4_kernel<128> : n > 128 ? out_layer_bwd_v4_kernel<64> : n > 64 ? out_layer_bwd_v4_kernel<32> : out_layer_bwd_v4_kernel<16>;
+        kern<<<splits, 256, 0, st>>>(x, ldx, dy, w, M, n, ceil_div(M, splits), masked, 1.0f / keep, dx, lddx, dw_part, dw_stride, db_part, db_stride);
+    } else
         out_layer_bwd_kernel<<<splits, 256, 0, st>>>(x, ldx, dy, w, M, n, ceil_div(M, splits), masked, 1.0f / keep, dx, lddx,
                                                       dw_part, dw_stride, db_part, db_stride);
     DCTR_LAUNCH_CHECK();

@@ -214,15 +214,17 @@ __global__ __launch_bounds__(256) void group_fill_hash_kernel(const int32_t* __r
 // entries in runs of 16 = 256 flushes x 17 floats serialised at ~90 atomics/us -- 48 us, the whole scatter); a block reduces
 // chunks of them in registers + LDS and flushes once per chunk
 constexpr int SHORT_SEGMENT = 8;        // embed_scatter_apply: segments up to this long take one walker (KQ lanes), entries loaded together
-constexpr int LONG_SEGMENT = 256;
-constexpr int LONG_CHUNK = 256;
+// segments from this many entries on are cut into chunks of as many, reduced by a block each and joined by atomics.  A wave
+// covers 64/KQ entries per load, so the wave-per-segment path below this bound costs up to bound * KQ / 256 dependent trips of
+// four loads: 4 at K = 16, but 64 at the K = 256 AFM runs at (a 128-example batch's hot ids: 124 us of latency) -- hence by width
+__host__ __device__ constexpr int long_segment(int KQ) { return KQ >= 64 ? 64 : KQ >= 32 ? 128 : 256; }
 
 // one thread per distinct id: carve its segment of the grouped-entry array (one atomic per block on the running total)
 __global__ __launch_bounds__(GROUP_BLOCK) void group_segments_kernel(int32_t* __restrict__ slot, const int32_t* __restrict__ uniq,
                                                             int32_t* __restrict__ cnt, int32_t* __restrict__ seg_start,
                                                             int32_t* __restrict__ cursor, int32_t* __restrict__ counters,
                                                             float* __restrict__ glin, int32_t* __restrict__ long_list, int long_cap,
-                                                            int32_t* __restrict__ done, int32_t* __restrict__ medium_list, int medium_cap) {
+                                                            int32_t* __restrict__ done, int32_t* __restrict__ medium_list, int medium_cap, int LONG_SEGMENT) {
     __shared__ int wsum[GROUP_BLOCK / 64];
     __shared__ int bbase;
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -354,6 +356,7 @@ __global__ __launch_bounds__(256) void scatter_bwd_kernel(
     const float4* __restrict__ S, const float* __restrict__ coef, const float* __restrict__ dy,
     const float* __restrict__ vals, int B, int F, float* __restrict__ gemb, float* __restrict__ glin, int dy_ld, int run,
     int walker_blocks, const int32_t* __restrict__ long_list, int long_cap, const int32_t* __restrict__ entry_row) {
+    constexpr int LONG_SEGMENT = long_segment(KQ), LONG_CHUNK = long_segment(KQ);
     if ((int)blockIdx.x >= walker_blocks) {
         // ---- long segments, cut into chunks of LONG_CHUNK entries dealt round-robin to these blocks: KQ lanes per entry,
         // 256/KQ entries in flight per pass, tree reduction in LDS, ONE atomic flush per (chunk, row piece)
@@ -450,7 +453,7 @@ static int launch_scatter(Group* g, const float* dE, int de_ld, const float* e, 
     static const int run = getenv("DCTR_SCATTER_RUN") ? atoi(getenv("DCTR_SCATTER_RUN")) : 8;
     const int walkers = ceil_div(n, run);
     const int walker_blocks = ceil_div((int64_t)walkers * KQ, 256);
-    const int long_blocks = (int)std::min<int64_t>(ceil_div(n, LONG_CHUNK), 256);
+    const int long_blocks = (int)std::min<int64_t>(ceil_div(n, long_segment(KQ)), 256);
     dim3 grid(walker_blocks + long_blocks), block(256);
 #define DCTR_SC(MODE_)                                                                                         \
     scatter_bwd_kernel<KQ, MODE_><<<grid, block, 0, st>>>(                                                     \
@@ -473,7 +476,7 @@ static int launch_scatter(Group* g, const float* dE, int de_ld, const float* e, 
 // of into the compact [U, K] buffer that a second launch (opt_table_kernel<.., false>) used to re-read:
 //   * segments of up to SHORT_SEGMENT entries (most ids occur once per batch): one walker of K/4 lanes per distinct id, the
 //     entries' gradients loaded together, summed in registers, applied at once;
-//   * up to LONG_SEGMENT: one wave per segment (a compacted list built by group_segments_kernel), folded with shuffles;
+//   * up to long_segment(KQ): one wave per segment (a compacted list built by group_segments_kernel), folded with shuffles;
 //   * longer ones, reduced chunk-wise by blocks of their own: partial sums meet in the compact row by float atomics, every
 //     chunk then adds its entry count to done[u]; the block that completes cnt[u] takes the total back out with
 //     atomicExch(.., 0) -- which also leaves the row zeroed for the next batch, so the fused path needs no group_finalize
@@ -579,6 +582,7 @@ __global__ __launch_bounds__(256) void scatter_apply_kernel(
     };
     // (block order = dispatch order: the long segments' blocks -- the longest dependent chains -- start first, the many short
     //  walkers fill in behind them)
+    constexpr int LONG_CHUNK = long_segment(KQ);
     const int long_blocks = (int)gridDim.x - short_blocks - medium_blocks;
     if ((int)blockIdx.x >= long_blocks + medium_blocks) {
         // ---- short segments (most ids occur once or twice per batch): walker u owns distinct id u, its entries' gradients are
@@ -722,7 +726,7 @@ static int launch_scatter_apply(Group* g, const float* dE, int de_ld, const floa
     const int64_t n = (int64_t)B * F;
     const int short_blocks = ceil_div(n * KQ, 256);                                 // one walker per possible distinct id
     const int medium_blocks = (int)std::min<int64_t>(ceil_div(g->medium_cap, 4), 512);
-    const int long_blocks = (int)std::min<int64_t>(ceil_div(n, LONG_CHUNK), 256);
+    const int long_blocks = (int)std::min<int64_t>(ceil_div(n, long_segment(KQ)), 256);
     dim3 grid(short_blocks + medium_blocks + long_blocks), block(256);
 #define DCTR_SA(MODE_)                                                                                         \
     scatter_apply_kernel<KIND, KQ, MODE_><<<grid, block, 0, st>>>(                                             \
@@ -793,7 +797,7 @@ int group_create(int64_t rows, int64_t max_entries, int K, Group** out) {
     DCTR_HIP_CHECK(hipMalloc(&g->done, n * 4));
     g->medium_cap = (int64_t)(n / (SHORT_SEGMENT + 1)) + 1;   // at most n / 9 segments are longer than SHORT_SEGMENT
     DCTR_HIP_CHECK(hipMalloc(&g->medium_list, (size_t)g->medium_cap * 4));
-    g->long_cap = (int64_t)(n / LONG_SEGMENT) + 1;        // at most n / LONG_SEGMENT segments can be that long
+    g->long_cap = (int64_t)(n / long_segment(K / 4)) + 1;        // at most n / long_segment segments can be that long
     DCTR_HIP_CHECK(hipMalloc(&g->long_list, (size_t)g->long_cap * 4));
     // the memsets above run on the null stream and may still be pending: a first use on a non-blocking stream must not overtake them
     DCTR_HIP_CHECK(hipDeviceSynchronize());
@@ -824,7 +828,7 @@ int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st, bool z
     if (hashed) group_count_hash_kernel<<<ceil_div(n, HCHUNK), 256, 0, st>>>(ids, (int)n, g->rows, g->slot, g->uniq, g->counters);
     else group_count_kernel<<<ceil_div(n, GROUP_BLOCK), GROUP_BLOCK, 0, st>>>(ids, B, F, g->rows, g->slot, g->uniq, g->counters);
     group_segments_kernel<<<ceil_div(n, GROUP_BLOCK), GROUP_BLOCK, 0, st>>>(g->slot, g->uniq, g->cnt, g->seg_start, g->cursor, g->counters, g->glin, g->long_list,
-                                             (int)g->long_cap, g->done, g->medium_list, (int)g->medium_cap);
+                                             (int)g->long_cap, g->done, g->medium_list, (int)g->medium_cap, long_segment(g->K / 4));
     const int KQ = g->K / 4;
     dim3 fgrid(ceil_div(n * KQ, 256));
     float4* gemb4 = reinterpret_cast<float4*>(g->gemb);

@@ -44,11 +44,11 @@ struct Group {
     int32_t* perm = nullptr;      // [max_entries]
     int32_t* seg_of = nullptr;    // [max_entries]
     int32_t* counters = nullptr;  // [8]: 0 = U (distinct ids), 1 = total grouped entries, 2 = long segments, 3 = reset ticket, 4 = medium segments
-    int32_t* long_list = nullptr; // [long_cap] distinct-id indices u of the segments with >= LONG_SEGMENT entries
+    int32_t* long_list = nullptr; // [long_cap] distinct-id indices u of the segments with >= long_segment(K/4) entries (group.hip)
     int64_t long_cap = 0;
     float* gemb = nullptr;        // [max_entries, K] compact gradient rows
     float* glin = nullptr;        // [max_entries]
-    int32_t* medium_list = nullptr; // [medium_cap] distinct-id indices of the segments with SHORT_SEGMENT < entries < LONG_SEGMENT
+    int32_t* medium_list = nullptr; // [medium_cap] distinct-id indices of the segments with SHORT_SEGMENT < entries < long_segment(K/4)
     int64_t medium_cap = 0;
     int32_t* done = nullptr;      // [max_entries] entries of each segment folded so far (embed_scatter_apply's completion tickets)
     bool slots_clean = false;     // host-side: every slot word is 0 (embed_scatter_apply clears the words of the rows it visits)
