@@ -300,6 +300,36 @@ def test_afm_attention_widths(K, A, dev):
     assert np.abs(logit.cpu().numpy() - O.forward(ocfg, params, ids, vals)["y"].numpy()).max() <= 1e-4
 
 
+@pytest.mark.parametrize("K,A,F,B", [(128, 128, 12, 1100), (256, 128, 9, 1900), (128, 256, 12, 1000)])
+def test_afm_attention_out_inside_the_products(K, A, F, B, dev):
+    """From 65536 pair rows on (and K, A in {128, 256}) the score dot comes out of the attention product's epilogue, and the
+    backward never writes d ah = dsc (x) w_o . 1[ah > 0]: the input gradient gates its operand loads on ah's sign, the weight
+    gradient does the same and its second column sums are attention_out's dW (AFM.py:142-148).  Ragged last tiles on purpose."""
+    V = 3000
+    assert B * F * (F - 1) // 2 >= 65536
+    ocfg, params, eng = make_pair("afm", B=B, F=F, V=V, K=K, layers=(1,), att=(A,), opt="Adagrad", lr=1e-2, l2=1e-3)
+    oopt = O.Optimizer(ocfg, params)
+    for step in range(2):
+        ids, vals, labels = O.synth_batch(B, F, V, seed=700 + step)
+        ref_loss, _ = O.train_step(ocfg, params, oopt, ids, vals, labels)
+        loss = eng.train_step(*dev_batch(ids, vals, labels, dev))
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (step, loss, ref_loss)
+    got = eng.get_params()
+    for name, ref in params.items():
+        diff = np.abs(got[name] - ref.numpy()).max()
+        assert diff <= 3e-6, (name, diff)
+    # a smaller batch on the same engine falls back to the materialising passes (the slabs are laid out for the products)
+    ids, vals, labels = O.synth_batch(200, F, V, seed=702)
+    ref_loss, _ = O.train_step(ocfg, params, oopt, ids, vals, labels)
+    loss = eng.train_step(*dev_batch(ids, vals, labels, dev))
+    assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+    got = eng.get_params()
+    for name, ref in params.items():
+        diff = np.abs(got[name] - ref.numpy()).max()
+        assert diff <= 4e-6, (name, diff)
+    eng.close()
+
+
 @pytest.mark.parametrize("K,F,B", [(64, 13, 37), (64, 12, 520), (128, 9, 513), (256, 39, 37), (256, 6, 600), (72, 7, 530)])
 def test_afm_wide_embeddings_pair_backward(K, F, B, dev):
     """K >= 64 (the reference runs AFM at K = 256, run.sh:18).  From 512 examples on the pair backward walks the pairs of an example

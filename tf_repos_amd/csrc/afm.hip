@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void afm_pair_fwd_kernel(const float4* __restr
 // (ee != nullptr: the pair products are rebuilt from the example's embeddings, staged in LDS behind the weights -- 40 KB read per
 //  example instead of its 759 KB slice of the [B P, K] pair tensor, K = 256)
 template <int NT>
-__global__ __launch_bounds__(NT) void afm_pool_fwd_kernel(const float* __restrict__ sc, const float* __restrict__ pp, int P, int K,
+__global__ __launch_bounds__(NT) void afm_pool_fwd_kernel(const float* __restrict__ sc, const float* __restrict__ sc1, const float* __restrict__ sc_bias,
+                                                         const float* __restrict__ pp, int P, int K,
                                                           float keep_att, float keep_emb, const uint64_t* __restrict__ seed_ptr,
                                                           int train, float* __restrict__ att, float* __restrict__ yemb,
                                                           const float4* __restrict__ ee, int e_ld4, int F, const int16_t* __restrict__ pi,
@@ -73,9 +74,11 @@ __global__ __launch_bounds__(NT) void afm_pool_fwd_kernel(const float* __restric
     float4* es = reinterpret_cast<float4*>(sm + ((P + 3) & ~3));
     if (ee != nullptr)
         for (int x = t; x < F * (K >> 2); x += NT) es[x] = ee[(size_t)b * e_ld4 + x];
-    const float* s = sc + (size_t)b * P;
+    // the scores: whole (sc), or the two column-slab parts of the product's epilogue + the bias (parts first: the order is fixed)
+    const float sbias = sc_bias != nullptr ? sc_bias[0] : 0.f;
+    auto score = [&](int p) { const size_t i = (size_t)b * P + p; return sc1 != nullptr ? (sc[i] + sc1[i]) + sbias : sc[i] + sbias; };
     float m = -3.0e38f;
-    for (int p = t; p < P; p += NT) m = fmaxf(m, s[p]);
+    for (int p = t; p < P; p += NT) m = fmaxf(m, score(p));
     m = wmax64(m);
     if ((t & 63) == 0) red[t >> 6] = m;
     __syncthreads();
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(NT) void afm_pool_fwd_kernel(const float* __restric
     for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, red[w]);
     __syncthreads();
     float z = 0.f;
-    for (int p = t; p < P; p += NT) { const float ex = expf(s[p] - m); sm[p] = ex; z += ex; }
+    for (int p = t; p < P; p += NT) { const float ex = expf(score(p) - m); sm[p] = ex; z += ex; }
     z = wsum64(z);
     if ((t & 63) == 0) red[t >> 6] = z;
     __syncthreads();
@@ -437,6 +440,12 @@ int afm_pair_bwd(const float* e, int e_ld, const float* att_drop, const float* d
 
 using namespace dctr;
 
+// A/B knob DCTR_AFM_IN_PRODUCTS=0: the score dot, the ReLU-masked rank-one gradient of the last attention layer and attention_out's
+// weight gradient as passes of their own (rowdot / out_layer_bwd) instead of inside the three products
+static bool afm_in_products() {
+    static const bool off = [] { const char* v = getenv("DCTR_AFM_IN_PRODUCTS"); return v != nullptr && v[0] == '0'; }();
+    return !off;
+}
 constexpr int AFM_MAX_CHUNKS = 8;
 static int afm_chunks_wanted(int B, int P) {
     // OFF by default: measured at the reference point (B = 4096, K = A = 256) 2 / 4 / 8 chunks = 14.4 / 14.9 / 16.6 ms against 14.0
@@ -461,12 +470,6 @@ int afm_declare_params(dctr_engine* E) {
     // then never materialised, and the four attention parameters take their gradient from AFM_SLABS atomically filled slabs
     // (one hidden layer, the reference's default; the AFM.py:143-145 loop with more widths runs layer by layer)
     E->afm_fused = nl == 1 && getenv("DCTR_AFM_UNFUSED") == nullptr && afm_fused_supported(K, A);        // (the env knob is the A/B switch)
-    // attention_out's gradient slabs: one per ~512 pair rows (1024 at the reference's B = 4096; at B = 128 that many slabs made the
-    // optimizer's slab sum, 1024 dependent strided reads per element, a 98 us kernel)
-    int ao_rows = 128;
-    while (ao_rows < 1024 && (int64_t)ao_rows * 512 < (int64_t)E->MB * E->P) ao_rows *= 2;
-    E->ao_splits = ao_rows;
-    const int ao = E->afm_fused ? AFM_SLABS : E->ao_splits;
     int d = K;
     for (int l = 0; l < nl; ++l) {
         Fc fc;
@@ -483,6 +486,14 @@ int afm_declare_params(dctr_engine* E) {
         E->att_fc.push_back(fc);
         d = fc.out;
     }
+    // attention_out's gradient slabs: one per ~512 pair rows (1024 at the reference's B = 4096; at B = 128 that many slabs made the
+    // optimizer's slab sum, 1024 dependent strided reads per element, a 98 us kernel) -- or, when the last attention layer's weight
+    // gradient also produces them (DR_BGATE_WGRAD, afm_backward), one per batch split of that product
+    int ao_rows = 128;
+    while (ao_rows < 1024 && (int64_t)ao_rows * 512 < (int64_t)E->MB * E->P) ao_rows *= 2;
+    E->ao_splits = ao_rows;
+    E->afm_gate_slabs = nl == 1 && !E->afm_fused && afm_in_products() && ws_takes((int64_t)E->MB * E->P, A, K);
+    const int ao = E->afm_fused ? AFM_SLABS : E->afm_gate_slabs ? E->att_fc[0].splits : E->ao_splits;
     E->att_splits = E->att_fc[0].splits;
     E->p_att_w = E->att_fc[0].w;
     E->p_att_b = E->att_fc[0].b;
@@ -515,6 +526,7 @@ int afm_alloc(dctr_engine* E) {
         E->ah = E->ahs.back();
         E->dah = E->dahs.back();
         DCTR_HIP_CHECK(hipStreamCreateWithFlags(&E->s_afm, hipStreamNonBlocking));
+        DCTR_TRY(dm(&E->sc_parts, 2 * MB * P));
     }
     (void)A;
     DCTR_TRY(dm(&E->sc, MB * P));
@@ -532,13 +544,31 @@ int afm_alloc(dctr_engine* E) {
 }
 
 void afm_free(dctr_engine* E) {
-    float* fl[] = {E->pairp, E->dpairp2, E->sc, E->dsc, E->att, E->dE_buf};
+    float* fl[] = {E->pairp, E->dpairp2, E->sc, E->dsc, E->att, E->dE_buf, E->sc_parts};
     for (float* p : fl) if (p) hipFree(p);
     for (float* p : E->ahs) hipFree(p);
     for (float* p : E->dahs) hipFree(p);
     if (E->pair_i) hipFree(E->pair_i);
     if (E->pair_j) hipFree(E->pair_j);
     if (E->s_afm) hipStreamDestroy(E->s_afm);
+}
+
+// out[s * stride] = sum of x over the s-th of `splits` equal ranges (attention_out's bias gradient = sum of d score, AFM.py:147-148)
+__global__ __launch_bounds__(256) void vec_sum_partials_kernel(const float* __restrict__ x, int64_t n, int64_t per, float* __restrict__ out, int64_t stride) {
+    __shared__ float red[4];
+    const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+    float s = 0.f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = i + u * 256 < i1 ? x[i + u * 256] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    s = wsum64(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[(size_t)blockIdx.x * stride] = red[0] + red[1] + red[2] + red[3];
 }
 
 // The unfused path (K > 32: the reference's K = 256) CAN run the step's passes over the pair rows in chunks of examples on two
@@ -557,7 +587,7 @@ static int afm_chunks(const dctr_engine* E, int B) {
     return nc;
 }
 
-static int afm_pool_fwd(dctr_engine* E, int b0, int n, bool train, hipStream_t st) {
+static int afm_pool_fwd(dctr_engine* E, int b0, int n, bool train, hipStream_t st, int score_parts = 0) {
     const int F = E->F, K = E->K, P = E->P;
     // the pooling rebuilds the pair products from the example's embeddings when they fit LDS beside its working set
     const size_t lds_pp = (size_t)P * sizeof(float), lds_e = (size_t)(((P + 3) & ~3) + F * K) * sizeof(float);
@@ -569,7 +599,10 @@ static int afm_pool_fwd(dctr_engine* E, int b0, int n, bool train, hipStream_t s
     static const hipError_t attr_w = hipFuncSetAttribute(reinterpret_cast<const void*>(afm_pool_fwd_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     DCTR_HIP_CHECK(attr);
     DCTR_HIP_CHECK(attr_w);
-    kern<<<n, wide ? 1024 : 256, from_e ? lds_e : lds_pp, st>>>(E->sc, E->pairp, P, K, E->keep_att, E->keep_emb, &E->state->seed_t,
+    const float* s0 = score_parts > 0 ? E->sc_parts : E->sc;
+    const float* s1 = score_parts > 1 ? E->sc_parts + (size_t)E->MB * P : nullptr;
+    const float* sb = score_parts > 0 ? E->pp(E->p_ao_b) : nullptr;
+    kern<<<n, wide ? 1024 : 256, from_e ? lds_e : lds_pp, st>>>(s0, s1, sb, E->pairp, P, K, E->keep_att, E->keep_emb, &E->state->seed_t,
                                                                  train ? 1 : 0, E->att, E->x_in,
                                                                  from_e ? reinterpret_cast<const float4*>(E->e) : nullptr, E->e_ld / 4, F, E->pair_i, E->pair_j, b0);
     DCTR_LAUNCH_CHECK();
@@ -600,14 +633,21 @@ int afm_forward(dctr_engine* E, int B, bool train, hipStream_t st) {
                                                                E->pair_j, n, P, KQ, reinterpret_cast<float4*>(E->pairp + r0 * K));
         DCTR_LAUNCH_CHECK();
         const float* x = E->pairp + r0 * K;
+        int score_parts = 0;
         for (size_t l = 0; l < E->att_fc.size(); ++l) {     // relu(x W_l + b_l) over the chunk's pair rows
             const Fc& fc = E->att_fc[l];
             float* y = E->ahs[l] + r0 * fc.out;
-            DCTR_TRY(fc_fwd(x, fc.in, E->pp(fc.w), E->pp(fc.b), y, fc.out, n * P, fc.in, fc.out, 1, 1.f, nullptr, 0, s));
+            bool done = false;
+            // the last layer's product also takes the score dot <ah[row, :], w_o> (AFM.py:147) from its accumulators, one part per
+            // 128-column slab, when it is the tall-operand kernel with at most two slabs (a two-term sum is order-free)
+            if (l + 1 == E->att_fc.size() && fc.out <= 256 && afm_in_products())
+                DCTR_TRY(ws_fc_fwd_dot(x, fc.in, E->pp(fc.w), E->pp(fc.b), y, fc.out, n * P, fc.in, fc.out, 1, E->pp(E->p_ao_w), E->sc_parts + r0,
+                                       (int64_t)E->MB * P, &score_parts, s, &done));
+            if (!done) DCTR_TRY(fc_fwd(x, fc.in, E->pp(fc.w), E->pp(fc.b), y, fc.out, n * P, fc.in, fc.out, 1, 1.f, nullptr, 0, s));
             x = y;
         }
-        DCTR_TRY(rowdot(E->ah + r0 * A, A, E->pp(E->p_ao_w), E->pp(E->p_ao_b), n * P, A, E->sc + r0, 0, s));
-        DCTR_TRY(afm_pool_fwd(E, b0, n, train, s));
+        if (score_parts == 0) DCTR_TRY(rowdot(E->ah + r0 * A, A, E->pp(E->p_ao_w), E->pp(E->p_ao_b), n * P, A, E->sc + r0, 0, s));
+        DCTR_TRY(afm_pool_fwd(E, b0, n, train, s, score_parts));
     }
     if (nc > 1) DCTR_TRY(fork(E, E->s_afm, st));
     return DCTR_OK;      // the fc(K -> 1) output layer is fused into the head kernel
@@ -660,6 +700,40 @@ int afm_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
         const int b0 = c * bc, n = std::min(bc, B - b0);
         const size_t r0 = (size_t)b0 * P;
         DCTR_TRY(afm_pool_bwd(E, b0, n, s));
+        // One attention layer, tall enough for the weights-stationary kernel: d ah = dsc (x) w_o . 1[ah > 0] is never written -- the
+        // layer's two backward products form it from ah on their operand loads (gemm_ws WS_GATE, gemm_dr DR_BGATE_WGRAD), and the
+        // weight gradient's second column sums are attention_out's dW_o.  out_layer_bwd's 6.2 GB pass (1.05 ms at B = 4096) is gone.
+        if (nc == 1 && E->afm_gate_slabs && ws_takes((int64_t)n * P, A, K) && aw.n_part == E->att_fc[0].splits && ab.n_part == aw.n_part) {
+            const Fc& fc = E->att_fc[0];
+            const Param& w = E->params[fc.w];
+            const Param& bb = E->params[fc.b];
+            // The two products cannot share a CU (128 KB + 98 KB of LDS): enqueued together they interleave block by block and end
+            // together, with the pair backward exposed behind both.  dgrad first, then the weight gradient beside the pair backward
+            // and the table step (12.42 -> 12.28 ms at B = 4096; at B = 128 the side-by-side form cost 0.81 against 0.67 ms).
+            static const bool beside = getenv("DCTR_AFM_WGRAD_BESIDE") != nullptr;                       // A/B knob
+            bool wdone = false, ddone = false;
+            auto wgrad = [&]() -> int {
+                DCTR_TRY(fork(E, st, sw));
+                // db_o = sum of d score first (a 32-block kernel behind the product would end the stream 0.3 ms later at B = 4096; on a
+                // third stream, joined behind the product, it measured WORSE: 12.1 -> 12.5 ms, 0.62 -> 0.83 ms at B = 128)
+                const int64_t rows = (int64_t)n * P;
+                vec_sum_partials_kernel<<<ab.n_part, 256, 0, sw>>>(E->dsc, rows, ceil_div(rows, ab.n_part), E->part(E->p_ao_b), ab.padded);
+                DCTR_LAUNCH_CHECK();
+                DCTR_TRY(dr_fc_bwd_weights_partials_gate(E->pairp, K, E->ah, A, E->dsc, E->pp(E->p_ao_w), E->part(fc.w), w.padded, E->part(fc.b),
+                                                         bb.padded, E->part(E->p_ao_w), aw.padded, n * P, K, A, fc.splits, sw, &wdone));
+                return DCTR_OK;
+            };
+            if (beside) DCTR_TRY(wgrad());
+            if (!beside || wdone) {
+                DCTR_TRY(ws_fc_bwd_data_gate(E->ah, A, E->dsc, E->pp(E->p_ao_w), E->pp(fc.w), E->dpairp2, K, n * P, K, A, st, &ddone));
+                DCTR_REQUIRE(ddone, "AFM: the gated input gradient was not taken for a shape ws_takes() accepts");
+                if (!beside) DCTR_TRY(wgrad());
+                if (wdone) {
+                    return afm_pair_bwd(E->e, E->e_ld, E->sc, E->dx_in, E->Din_ld, E->dpairp2, E->pair_i, E->pair_j, n, F, K, P, E->dE_buf, E->D, st);
+                }
+                // (the weight gradient's shape was not the direct kernel's: the materialising path below redoes both products)
+            }
+        }
         // attention_out (A -> 1) over the chunk's rows: d ah = dsc (x) w_o masked by relu, dW_o / db_o partial slabs
         const int ao_n = aw.n_part / nc, ab_n = ab.n_part / nc;
         DCTR_REQUIRE(ao_n == ab_n, "AFM: attention_out weight / bias slab counts differ");

@@ -178,6 +178,8 @@ struct dctr_engine {
     std::vector<float*> ahs, dahs;   // their activations / gradients over the B*P pair rows (unfused path); ah / dah = the last ones
     bool afm_fused = false;          // attention network fused over the pair rows (afm_fused.hip)
     float keep_att = 1.f, keep_emb = 1.f;
+    float* sc_parts = nullptr;      // AFM: per-column-slab partial score dots out of the last attention product's epilogue [2][MB * P]
+    bool afm_gate_slabs = false;    // AFM: attention_out's gradient slabs are laid out for the gated weight gradient (one per batch split)
     float *pairp = nullptr, *dpairp2 = nullptr, *ah = nullptr, *dah = nullptr, *sc = nullptr, *dsc = nullptr,
           *att = nullptr, *dE_buf = nullptr;
     int16_t *pair_i = nullptr, *pair_j = nullptr;

@@ -41,7 +41,12 @@ enum { DR_STORE = 0, DR_BIAS_ACT = 1, DR_MASK = 2 };
 // A operand generated on the fly (Outer-PNN, PNN.py:139-153 'Outer': the [B, P K K] product tensor is never written):
 //   DR_AGEN_OUTER_FWD    A[b][(p,a,c)] = e[b][i_p][a] e[b][j_p][c], reduction over (p,a,c)   (first MLP layer forward)
 //   DR_AGEN_OUTER_WGRAD  A^T[(p,a,c)][b], reduction over b                                   (its weight gradient)
-enum { DR_AGEN_NONE = 0, DR_AGEN_OUTER_FWD = 1, DR_AGEN_OUTER_WGRAD = 2 };
+//   DR_BGATE_WGRAD       B (NC, = the layer's ReLU OUTPUT h [rows, N]) enters as the gradient it implies under a rank-one output
+//                        gradient: B'[row][n] = rowscale[row] 1[h[row][n] > 0]; the stores scale column n by colscale[n]; besides
+//                        the column sums of B' (the bias gradient / colscale) a second set, sum_row rowscale[row] h[row][n], leaves
+//                        in colsum2 -- the weight gradient of the (N -> 1) layer above.  AFM's last attention layer at K = 256:
+//                        d ah = d score (x) w_o . 1[ah > 0] (AFM.py:147) is 3.1 GB that is neither written nor read.
+enum { DR_AGEN_NONE = 0, DR_AGEN_OUTER_FWD = 1, DR_AGEN_OUTER_WGRAD = 2, DR_BGATE_WGRAD = 3 };
 
 struct DrOuter {
     const float* e;             // gathered embeddings [rows][F K], row stride e_ld
@@ -63,6 +68,10 @@ struct DrEpilogue {
     int64_t split_stride;       // DR_STORE with gridDim.y > 1: C + y * split_stride
     float* colsum;              // wgrad: column sums of B (= dY) over this block's reduction range -> colsum[y * colsum_stride + n]
     int64_t colsum_stride;
+    const float* rowscale;      // DR_BGATE_WGRAD: [K] (the reduction runs over rows)
+    const float* colscale;      // DR_BGATE_WGRAD: [N]
+    float* colsum2;             // DR_BGATE_WGRAD: -> colsum2[y * colsum2_stride + n]
+    int64_t colsum2_stride;
 };
 
 __device__ __forceinline__ float dr_dropout_scale(uint64_t seed, uint64_t idx, float keep);   // = dropout_scale of common.h (defined by the includer)
@@ -146,8 +155,11 @@ template <int TM, int TN, bool A_RC, bool B_RC, bool CS, int EPI, int AGEN = DR_
 __global__ __launch_bounds__(256, (CS && TM * TN <= 16) ? 2 : 1) void gemm_dr_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                          float* __restrict__ C, int ldc, int M, int N, int K, int kchunk, int nbn,
                                                          DrEpilogue ep, DrOuter og) {
-    static_assert(AGEN == DR_AGEN_NONE || (AGEN == DR_AGEN_OUTER_FWD && A_RC) || (AGEN == DR_AGEN_OUTER_WGRAD && !A_RC), "generated A: fwd is RC, wgrad is NC");
-    constexpr bool A_PLAIN = A_RC || AGEN != DR_AGEN_NONE;   // tile i = rows 16 i .. 16 i + 15 (no interleave)
+    static_assert(AGEN == DR_AGEN_NONE || (AGEN == DR_AGEN_OUTER_FWD && A_RC) || (AGEN == DR_AGEN_OUTER_WGRAD && !A_RC) ||
+                  (AGEN == DR_BGATE_WGRAD && !A_RC && !B_RC && CS && EPI == DR_STORE), "generated A: fwd is RC, wgrad is NC; gated B: a weight gradient");
+    constexpr bool OUTER = AGEN == DR_AGEN_OUTER_FWD || AGEN == DR_AGEN_OUTER_WGRAD;
+    constexpr bool GATE = AGEN == DR_BGATE_WGRAD;
+    constexpr bool A_PLAIN = A_RC || OUTER;                  // tile i = rows 16 i .. 16 i + 15 (no interleave)
     constexpr int TQ = B_RC ? 0 : TN / 4;                    // quads of B tiles sharing one dwordx4 per lane (NC only)
     constexpr int VA = A_PLAIN ? 1 : (TM % 4 == 0 ? 4 : (TM % 2 == 0 ? 2 : 1));
     constexpr int AG = TM / VA;                              // A load groups per step (NC only)
@@ -224,7 +236,7 @@ __global__ __launch_bounds__(256, (CS && TM * TN <= 16) ? 2 : 1) void gemm_dr_ke
                   : 4 * (A_RC ? (16 * i + c) * lda + 4 * q : 4 * q * lda + 16 * VA * i + VA * c);
     // generated A: lane offset of the e_i factor (fwd: this lane's row, one scalar for its 4 steps; wgrad: row 4 q + s, per step) and,
     // wgrad, the block's fixed (pair, a, c0) per tile as scalar offsets
-    int aoffI[AGEN != DR_AGEN_NONE ? NA : 1];
+    int aoffI[OUTER ? NA : 1];
     unsigned sJt[AGEN == DR_AGEN_OUTER_WGRAD ? TM : 1], sIt[AGEN == DR_AGEN_OUTER_WGRAD ? TM : 1];
     if constexpr (AGEN == DR_AGEN_OUTER_FWD) {
 #pragma unroll
@@ -247,7 +259,9 @@ __global__ __launch_bounds__(256, (CS && TM * TN <= 16) ? 2 : 1) void gemm_dr_ke
         boff[j] = 4 * (B_RC ? (16 * j + c) * ldb + 4 * q : 4 * q * ldb + (j < TQ ? 64 * j + 4 * c : 64 * TQ + 16 * (j - TQ) + c));
     const unsigned strideA = 4u * (unsigned)lda, strideB = 4u * (unsigned)ldb;    // bytes per k step of an NC operand
 
-    struct Frag { float a[TM][4]; float b[TN][4]; float ai[AGEN != DR_AGEN_NONE ? TM : 1][AGEN == DR_AGEN_OUTER_WGRAD ? 4 : 1]; };
+    struct Frag { float a[TM][4]; float b[TN][4]; float ai[OUTER ? TM : 1][AGEN == DR_AGEN_OUTER_WGRAD ? 4 : 1]; float rs[GATE ? 4 : 1]; };
+    // gated B: the row scales of this wave's reduction rows behind their own descriptor (lane (c, q), step s <-> row 16 g + 4 q + s)
+    const auto rr = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(GATE ? ep.rowscale + kbeg : nullptr), 0, __builtin_amdgcn_readfirstlane(GATE ? max(kend - kbeg, 0) * 4 : 0), 0x00020000);
     auto ldv = [](auto rs, int voff, unsigned soff_, auto nt, float* d, int stride) {      // nt dwords -> d[0], d[stride], ...
         constexpr int NV = decltype(nt)::value;
         const unsigned soff = __builtin_amdgcn_readfirstlane(soff_);
@@ -293,6 +307,7 @@ __global__ __launch_bounds__(256, (CS && TM * TN <= 16) ? 2 : 1) void gemm_dr_ke
                 }
             return;
         }
+        if constexpr (GATE) ldv(rr, 16 * q, 64u * g, I4{}, &f.rs[0], 1);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if (A_RC) ldv(ra, aoff[i], sA, I4{}, &f.a[i][0], 1);
@@ -308,8 +323,11 @@ __global__ __launch_bounds__(256, (CS && TM * TN <= 16) ? 2 : 1) void gemm_dr_ke
         else if (u < TQ) ldv(rb, boff[u], sB, I4{}, &f.b[4 * u][s], 4);
         else ldv(rb, boff[u], sB, I1{}, &f.b[4 * TQ + (u - TQ)][s], 4);
     };
+    float cs2[GATE ? TN : 1];                       // gated B: sum_row rowscale[row] h[row][n]
+#pragma unroll
+    for (int j = 0; j < (GATE ? TN : 1); ++j) cs2[j] = 0.f;
     auto fin = [&](Frag& f) {                       // generated A: the products, once per fragment set, right before its MFMAs
-        if constexpr (AGEN != DR_AGEN_NONE) {
+        if constexpr (OUTER) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -320,16 +338,23 @@ __global__ __launch_bounds__(256, (CS && TM * TN <= 16) ? 2 : 1) void gemm_dr_ke
 #pragma unroll
     for (int j = 0; j < TN; ++j) cs[j] = 0.f;
     auto mma_tile = [&](const Frag& f, int j, int s) {
+        // gated B: the element becomes the gradient it stands for right before its MFMAs (three VALU ops that issue under the
+        // matrix pipe's passes; done for the whole fragment set ahead of the MFMAs they cost the weight gradient 19 %)
+        float bv = f.b[j][s];
+        if constexpr (GATE) {
+            cs2[j] += bv * f.rs[s];
+            bv = bv > 0.f ? f.rs[s] : 0.f;
+        }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[i][s], f.b[j][s], acc[i][j], 0, 0, 0);
-        if (CS) cs[j] += f.b[j][s];
+        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[i][s], bv, acc[i][j], 0, 0, 0);
+        if (CS) cs[j] += bv;
     };
     auto gA = [&](int g) -> unsigned { return A_RC ? 64u * g : 16u * g * strideA; };
     auto gB = [&](int g) -> unsigned { return B_RC ? 64u * g : 16u * g * strideB; };
     // one pipeline half: prefetch group gn into nxt while the MFMAs of cur run.  The sched_group_barrier pipeline asks for the
     // issue order  A loads, then {1 B load, the MFMAs of the tiles it feeds} repeated, so the VMEM issue slots hide inside the
     // matrix pipe's 32-cycle passes instead of forming a burst during which the pipe drains.
-    constexpr int A_LOADS = AGEN == DR_AGEN_OUTER_FWD ? 2 * TM : AGEN == DR_AGEN_OUTER_WGRAD ? 8 * TM : (A_RC ? TM : 4 * AG);
+    constexpr int A_LOADS = AGEN == DR_AGEN_OUTER_FWD ? 2 * TM : AGEN == DR_AGEN_OUTER_WGRAD ? 8 * TM : (A_RC ? TM : 4 * AG) + (GATE ? 1 : 0);
     auto half = [&](Frag& nxt, int gn, Frag& cur) {
         __builtin_amdgcn_sched_barrier(0);
         fin(cur);
@@ -400,7 +425,7 @@ __global__ __launch_bounds__(256, (CS && TM * TN <= 16) ? 2 : 1) void gemm_dr_ke
             half(f0, min(g + 2, Gf - 1), f1);      // the last prefetch re-reads a loaded group; nobody consumes it
         }
     }
-    if (AGEN == DR_AGEN_NONE && ns > 0) {       // (generated A: the host rounds the reduction length so that no wave has a tail)
+    if (!OUTER && ns > 0) {       // (generated A: the host rounds the reduction length so that no wave has a tail)
         // ---- tail (< 16 k), after the main loop and into f0's registers: a third fragment set alive across the loop would push the
         // kernel past 304 VGPRs, the most that still shares a SIMD with two waves of the background table pass (104 each) -- and a
         // GEMM block that cannot be placed beside them waits for them to END.  Its load latency (~0.7 us) is exposed instead.
@@ -411,6 +436,7 @@ __global__ __launch_bounds__(256, (CS && TM * TN <= 16) ? 2 : 1) void gemm_dr_ke
             const int k = kt + 4 * s + q;
             const bool ok = k < kend;
             const int kr = k - kbeg;
+            if constexpr (GATE) ldv(rr, ok ? 4 * kr : 0x7ffffff0, 0u, I1{}, &f0.rs[s], 1);
     #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int off = 4 * (A_RC ? (16 * i + c) * lda + kr : kr * lda + 16 * VA * i + VA * c);
@@ -440,8 +466,24 @@ __global__ __launch_bounds__(256, (CS && TM * TN <= 16) ? 2 : 1) void gemm_dr_ke
         }
         __syncthreads();
         if (t < 16 * TN && n0 + t < N)
-            ep.colsum[(size_t)split * ep.colsum_stride + n0 + t] = dr_lds[t] + dr_lds[16 * TN + t] + dr_lds[32 * TN + t] + dr_lds[48 * TN + t];
+            ep.colsum[(size_t)split * ep.colsum_stride + n0 + t] = (dr_lds[t] + dr_lds[16 * TN + t] + dr_lds[32 * TN + t] + dr_lds[48 * TN + t]) *
+                                                                     (GATE ? ep.colscale[n0 + t] : 1.f);
         __syncthreads();
+    }
+    if constexpr (GATE) {
+        if (ep.colsum2 != nullptr && bm == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float v = cs2[j];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (q == 0) dr_lds[w * 16 * TN + dr_col<TN, B_RC>(j, c)] = v;
+            }
+            __syncthreads();
+            if (t < 16 * TN && n0 + t < N)
+                ep.colsum2[(size_t)split * ep.colsum2_stride + n0 + t] = dr_lds[t] + dr_lds[16 * TN + t] + dr_lds[32 * TN + t] + dr_lds[48 * TN + t];
+            __syncthreads();
+        }
     }
 
     // this thread's output column (store phase below) and its bias, loaded here so that the latency hides behind the reduction
@@ -453,6 +495,12 @@ __global__ __launch_bounds__(256, (CS && TM * TN <= 16) ? 2 : 1) void gemm_dr_ke
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (n0 + 4 * tc + e < N) bias4[e] = ep.bias[n0 + 4 * tc + e];
+    }
+    float cscale4[4] = {1.f, 1.f, 1.f, 1.f};
+    if (GATE && t < RPI * C4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n0 + 4 * tc + e < N) cscale4[e] = ep.colscale[n0 + 4 * tc + e];
     }
     // ---- cross-wave reduction + row-major staging (dr_reduce_tiles), one instantiation per wave id
     constexpr int LDS_ = 16 * TN + 4;           // staged row stride
@@ -503,6 +551,8 @@ __global__ __launch_bounds__(256, (CS && TM * TN <= 16) ? 2 : 1) void gemm_dr_ke
                         if (ep.keep < 1.0f) v[e] *= dr_dropout_scale(seed, (uint64_t)gm * (uint64_t)N + gn + e, ep.keep);
                     } else if (EPI == DR_MASK) {
                         v[e] = (a[e] > 0.f) ? v[e] * ep.inv_keep : 0.f;
+                    } else if (GATE) {
+                        v[e] *= cscale4[e];
                     }
                 }
                 *reinterpret_cast<float4*>(Cz + (size_t)gm * ldc + gn) = make_float4(v[0], v[1], v[2], v[3]);
@@ -520,6 +570,8 @@ __global__ __launch_bounds__(256, (CS && TM * TN <= 16) ? 2 : 1) void gemm_dr_ke
                     if (ep.keep < 1.0f) v *= dr_dropout_scale(seed, (uint64_t)gm * (uint64_t)N + gc, ep.keep);
                 } else if (EPI == DR_MASK) {
                     v = (ep.act[(size_t)gm * ep.ldact + gc] > 0.f) ? v * ep.inv_keep : 0.f;
+                } else if (GATE) {
+                    v *= ep.colscale[gc];
                 }
                 Cz[(size_t)gm * ldc + gc] = v;
             }

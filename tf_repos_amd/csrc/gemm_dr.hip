@@ -59,10 +59,10 @@ double dr_threshold() {
     return th;
 }
 
-template <int TM, int TN, bool A_RC, bool B_RC, bool CS, int EPI>
+template <int TM, int TN, bool A_RC, bool B_RC, bool CS, int EPI, int AGEN = DR_AGEN_NONE>
 int dr_launch(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, int splits, const DrEpilogue& ep,
               hipStream_t st) {
-    auto kern = gemm_dr_kernel<TM, TN, A_RC, B_RC, CS, EPI>;
+    auto kern = gemm_dr_kernel<TM, TN, A_RC, B_RC, CS, EPI, AGEN>;
     constexpr size_t lds = gemm_dr_lds_bytes<TM, TN>();
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     DCTR_HIP_CHECK(attr);
@@ -249,25 +249,32 @@ int dr_wgrad_splits(int M, int K, int N) {
     return best >= dr_threshold() ? best_s : 0;
 }
 
-// dW partial slabs (split over the batch) + bias-gradient partials; A = X^T stored as X [M,K], B = dY [M,N]: both "NC"
-int dr_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int lddy, float* dw_part, int64_t dw_stride, float* db_part,
-                               int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, bool* done) {
-    *done = false;
-    if (!dr_enabled('w') || M <= 0 || splits < 1 || (int64_t)ceil_div(M, splits) < 64) return DCTR_OK;
+// which weight-gradient tile (index into WGRAD_TILES) a shape takes with this many splits, -1: not the direct kernel's
+static int wgrad_tile(const float* x, int ldx, const float* dy, int lddy, const float* dw_part, int64_t dw_stride, int M, int K, int N, int splits) {
+    if (!dr_enabled('w') || M <= 0 || splits < 1 || (int64_t)ceil_div(M, splits) < 64) return -1;
     if (!al16(x) || !al16(dy) || (ldx & 3) || (lddy & 3) || (N & 3) || !fits31(wave_rows(M, splits), ldx) || !fits31(wave_rows(M, splits), lddy) ||
         !al16(dw_part) || (dw_stride & 3))
-        return DCTR_OK;
+        return -1;
     double eff;
     int t = pick(WGRAD_TILES, K, N, M, splits, &eff);
     const bool stream = streaming_rows(M, K, N) && (int64_t)ceil_div(K, 32) * ceil_div(N, 128) * splits <= 2 * CUS;
     if (stream) t = 2;
     else if (tall_square(M, K, N) && (int64_t)(K / 64) * (N / 128) * splits <= CUS) t = 3;
     else {
-        if (t < 0 || eff < dr_threshold()) return DCTR_OK;
+        if (t < 0 || eff < dr_threshold()) return -1;
         int blocks = 0;
         dr_efficiency(K, N, M, splits, WGRAD_TILES[t], &blocks);
-        if (blocks > CUS) return DCTR_OK;
+        if (blocks > CUS) return -1;
     }
+    return t;
+}
+
+// dW partial slabs (split over the batch) + bias-gradient partials; A = X^T stored as X [M,K], B = dY [M,N]: both "NC"
+int dr_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int lddy, float* dw_part, int64_t dw_stride, float* db_part,
+                               int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, bool* done) {
+    *done = false;
+    const int t = wgrad_tile(x, ldx, dy, lddy, dw_part, dw_stride, M, K, N, splits);
+    if (t < 0) return DCTR_OK;
     DrEpilogue ep{};
     ep.split_stride = dw_stride;
     ep.colsum = db_part;
@@ -278,6 +285,32 @@ int dr_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int ldd
         case 1: return dr_launch<2, 16, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
         case 2: return dr_launch<2, 8, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
         default: return dr_launch<4, 8, false, false, true, DR_STORE>(x, ldx, dy, lddy, dw_part, N, K, N, M, splits, ep, st);
+    }
+}
+
+// The same for a layer whose output gradient is rank one under its ReLU mask, dY = rowscale (x) colscale . 1[H > 0] (H [M,N] the
+// layer's stored output), formed on the B-operand loads (gemm_dr.h DR_BGATE_WGRAD) instead of read from memory; dwo_part takes the
+// second column sums, sum_row rowscale[row] H[row, n] -- the weight gradient of the (N -> 1) layer that produced the rank-one form.
+int dr_fc_bwd_weights_partials_gate(const float* x, int ldx, const float* h, int ldh, const float* rowscale, const float* colscale,
+                                    float* dw_part, int64_t dw_stride, float* db_part, int64_t db_stride, float* dwo_part, int64_t dwo_stride,
+                                    int M, int K, int N, int splits, hipStream_t st, bool* done) {
+    *done = false;
+    const int t = wgrad_tile(x, ldx, h, ldh, dw_part, dw_stride, M, K, N, splits);
+    if (t < 0 || !al16(rowscale)) return DCTR_OK;
+    DrEpilogue ep{};
+    ep.split_stride = dw_stride;
+    ep.colsum = db_part;
+    ep.colsum_stride = db_stride;
+    ep.rowscale = rowscale;
+    ep.colscale = colscale;
+    ep.colsum2 = dwo_part;
+    ep.colsum2_stride = dwo_stride;
+    *done = true;
+    switch (t) {
+        case 0: return dr_launch<2, 13, false, false, true, DR_STORE, DR_BGATE_WGRAD>(x, ldx, h, ldh, dw_part, N, K, N, M, splits, ep, st);
+        case 1: return dr_launch<2, 16, false, false, true, DR_STORE, DR_BGATE_WGRAD>(x, ldx, h, ldh, dw_part, N, K, N, M, splits, ep, st);
+        case 2: return dr_launch<2, 8, false, false, true, DR_STORE, DR_BGATE_WGRAD>(x, ldx, h, ldh, dw_part, N, K, N, M, splits, ep, st);
+        default: return dr_launch<4, 8, false, false, true, DR_STORE, DR_BGATE_WGRAD>(x, ldx, h, ldh, dw_part, N, K, N, M, splits, ep, st);
     }
 }
 

@@ -25,7 +25,11 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-enum { WS_STORE = 0, WS_BIAS_ACT = 1, WS_MASK = 2 };
+// WS_GATE: the tall operand is a ReLU OUTPUT and only its sign enters the product (1 where > 0) --
+//   C[row, :] = rowscale[row] * sum_k 1[A[row, k] > 0] * (kscale[k] B[k, :])
+// i.e. the input gradient of a layer whose own output gradient is rank one under the ReLU mask, d h = rowscale (x) kscale . 1[h > 0]
+// (AFM's last attention layer: rowscale = d score, kscale = attention_out's weight), without that [M, R] gradient in memory.
+enum { WS_STORE = 0, WS_BIAS_ACT = 1, WS_MASK = 2, WS_GATE = 3 };
 
 struct WsEpilogue {
     const float* bias;
@@ -36,6 +40,11 @@ struct WsEpilogue {
     const float* act;
     int ldact;
     float inv_keep;
+    const float* rowscale;   // WS_GATE
+    const float* kscale;     // WS_GATE
+    const float* dot_w;      // WS_BIAS_ACT: also dot_out[blockIdx.y * dot_stride + row] = sum over this block's columns of C[row, col] * dot_w[col]
+    float* dot_out;
+    int64_t dot_stride;
 };
 
 constexpr int WS_NT = 8;            // 16-column tiles per block: a 128-column slab of the stationary operand
@@ -58,6 +67,7 @@ __global__ __launch_bounds__(64 * WS_WAVES) void gemm_ws_kernel(const float* __r
         const int k = idx / (16 * WS_NT), n = idx - k * (16 * WS_NT);
         float v = 0.f;
         if (k < R && n0 + n < N) v = b_trans ? Bm[(size_t)(n0 + n) * ldb + k] : Bm[(size_t)k * ldb + n0 + n];
+        if (EPI == WS_GATE && k < R) v *= ep.kscale[k];
         const int g = k >> 4, qq = (k >> 2) & 3, s = k & 3, tt = n >> 4, cc = n & 15;
         ws_lds[((((g * 4 + qq) * WS_NT + tt) * 16 + cc) << 2) + s] = v;
     }
@@ -107,12 +117,16 @@ __global__ __launch_bounds__(64 * WS_WAVES) void gemm_ws_kernel(const float* __r
 #pragma unroll
                 for (int tt = 0; tt < WS_NT; ++tt)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ck.a[i][g][s], b[tt][s], acc[i][tt], 0, 0, 0);
+                    for (int i = 0; i < 2; ++i)
+                        acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(EPI == WS_GATE ? (ck.a[i][g][s] > 0.f ? 1.f : 0.f) : ck.a[i][g][s], b[tt][s], acc[i][tt], 0, 0, 0);
         }
     };
     float bias[WS_NT];
 #pragma unroll
     for (int tt = 0; tt < WS_NT; ++tt) bias[tt] = (EPI == WS_BIAS_ACT && ep.bias != nullptr && n0 + 16 * tt + c < N) ? ep.bias[n0 + 16 * tt + c] : 0.f;
+    float dotw[WS_NT];
+#pragma unroll
+    for (int tt = 0; tt < WS_NT; ++tt) dotw[tt] = (EPI == WS_BIAS_ACT && ep.dot_w != nullptr && n0 + 16 * tt + c < N) ? ep.dot_w[n0 + 16 * tt + c] : 0.f;
 
     Chunk c0, c1;
     auto rs = tile_rsrc(tile);
@@ -127,6 +141,18 @@ __global__ __launch_bounds__(64 * WS_WAVES) void gemm_ws_kernel(const float* __r
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int tt = 0; tt < WS_NT; ++tt) acc[i][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // WS_GATE: this tile's row scales, asked for BEFORE the products -- loaded in the epilogue they sit behind the next tile's
+        // first A chunk in the (in-order) load queue, and every tile waited out an HBM latency for them (3.33 -> 3.88 ms over 3 M rows)
+        float rsc[2][4];
+        if (EPI == WS_GATE) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = tile * 32 + 16 * i + 4 * q + r;
+                    rsc[i][r] = row < M ? ep.rowscale[row] : 0.f;
+                }
+        }
 #pragma unroll
         for (int x = 0; x < NCH; x += 2) {
             load_chunk(c1, rs, x + 1);
@@ -137,28 +163,47 @@ __global__ __launch_bounds__(64 * WS_WAVES) void gemm_ws_kernel(const float* __r
         }
         // ---- epilogue on the accumulators: register r of lane (c, q) is row 16 i + 4 q + r, column 16 tt + c
         const int64_t m0 = tile * 32;
+        float dots[2][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t row = m0 + 16 * i + 4 * q + r;
-                if (row < M) {
+                const bool live = row < M;
+                const float rs = EPI == WS_GATE ? rsc[i][r] : 1.f;
+                float dot = 0.f;
 #pragma unroll
-                    for (int tt = 0; tt < WS_NT; ++tt) {
-                        const int col = n0 + 16 * tt + c;
-                        if (col < N) {
-                            float v = acc[i][tt][r];
-                            if (EPI == WS_BIAS_ACT) {
-                                v += bias[tt];
-                                if (ep.relu) v = fmaxf(v, 0.f);
-                            } else if (EPI == WS_MASK) {
-                                v = ep.act[(size_t)row * ep.ldact + col] > 0.f ? v * ep.inv_keep : 0.f;
-                            }
-                            C[(size_t)row * ldc + col] = v;
-                        }
+                for (int tt = 0; tt < WS_NT; ++tt) {
+                    const int col = n0 + 16 * tt + c;
+                    float v = acc[i][tt][r];
+                    if (EPI == WS_BIAS_ACT) {
+                        v += bias[tt];
+                        if (ep.relu) v = fmaxf(v, 0.f);
+                        dot += v * dotw[tt];
+                    } else if (EPI == WS_MASK) {
+                        if (live && col < N) v = ep.act[(size_t)row * ep.ldact + col] > 0.f ? v * ep.inv_keep : 0.f;
+                    } else if (EPI == WS_GATE) {
+                        v *= rs;
                     }
+                    if (live && col < N) C[(size_t)row * ldc + col] = v;
                 }
+                dots[i][r] = dot;
             }
+        if (EPI == WS_BIAS_ACT && ep.dot_out != nullptr) {       // (wave-uniform branch)
+            // the 16 lanes of quarter q hold pieces of the same 8 rows: butterfly sums leave every lane with all 8 totals; lane
+            // c < 8 keeps total (i, r) = (c >> 2, c & 3) -- ONE store of 32 rows per tile instead of eight 4-lane ones
+            float mine = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float d = dots[i][r];
+                    d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4); d += __shfl_xor(d, 8);
+                    if (c == 4 * i + r) mine = d;
+                }
+            const int64_t row = m0 + 16 * (c >> 2) + 4 * q + (c & 3);
+            if (c < 8 && row < M) ep.dot_out[(size_t)blockIdx.y * ep.dot_stride + row] = mine;
+        }
         if (!more) break;
         tile = next;
         rs = rs_next;
@@ -210,6 +255,30 @@ int ws_fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y,
     ep.bias = b; ep.relu = relu; ep.keep = keep; ep.seed = seed; ep.seed_ptr = seed_ptr;
     *done = true;
     return dispatch_ws<WS_BIAS_ACT>(x, ldx, w, N, 0, y, ldy, M, N, K, ep, st);
+}
+
+// the same with the score dot of the NEXT (N -> 1) layer taken from the accumulators: dot_parts[j * dot_stride + row] = sum over
+// column slab j (128 columns each, *n_parts of them) of Y[row, col] * dot_w[col] -- the caller adds the parts (and the bias)
+int ws_fc_fwd_dot(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N, int relu,
+                  const float* dot_w, float* dot_parts, int64_t dot_stride, int* n_parts, hipStream_t st, bool* done) {
+    *done = false;
+    if (!ws_enabled() || !ws_shape_ok(M, K, N) || !al16(x) || (ldx & 3) != 0 || (int64_t)32 * ldx * 4 >= (int64_t)0x7fff0000) return DCTR_OK;
+    WsEpilogue ep{};
+    ep.bias = b; ep.relu = relu; ep.keep = 1.f; ep.dot_w = dot_w; ep.dot_out = dot_parts; ep.dot_stride = dot_stride;
+    *n_parts = ceil_div(N, 16 * WS_NT);
+    *done = true;
+    return dispatch_ws<WS_BIAS_ACT>(x, ldx, w, N, 0, y, ldy, M, N, K, ep, st);
+}
+
+// dX[M,K] = (rowscale (x) kscale . 1[H > 0]) W[K,N]^T with H [M,N] the layer's ReLU output (WS_GATE above)
+int ws_fc_bwd_data_gate(const float* h, int ldh, const float* rowscale, const float* kscale, const float* w, float* dx, int lddx, int M, int K,
+                        int N, hipStream_t st, bool* done) {
+    *done = false;
+    if (!ws_enabled() || !ws_shape_ok(M, N, K) || !al16(h) || (ldh & 3) != 0 || (int64_t)32 * ldh * 4 >= (int64_t)0x7fff0000) return DCTR_OK;
+    WsEpilogue ep{};
+    ep.rowscale = rowscale; ep.kscale = kscale;
+    *done = true;
+    return dispatch_ws<WS_GATE>(h, ldh, w, N, 1, dx, lddx, M, K, N, ep, st);
 }
 
 // dX[M,K] = dY[M,N] W[K,N]^T (x ReLU mask of the producing layer): the stationary operand is W^T

@@ -102,12 +102,19 @@ int dr_fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int ldd
                    float keep_prev, hipStream_t st, bool* done);
 int dr_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int lddy, float* dw_part, int64_t dw_stride, float* db_part,
                                int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, bool* done);
+int dr_fc_bwd_weights_partials_gate(const float* x, int ldx, const float* h, int ldh, const float* rowscale, const float* colscale,
+                                    float* dw_part, int64_t dw_stride, float* db_part, int64_t db_stride, float* dwo_part, int64_t dwo_stride,
+                                    int M, int K, int N, int splits, hipStream_t st, bool* done);
 // tall operands, the small one resident in LDS (gemm_ws.hip; DCTR_GEMM_WS=0 turns it off)
 bool ws_takes(int64_t M, int R, int N);
 int ws_fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N, int relu, float keep,
               const uint64_t* seed_ptr, uint64_t seed, hipStream_t st, bool* done);
 int ws_fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int K, int N, const float* act, int ldact,
                    float keep_prev, hipStream_t st, bool* done);
+int ws_fc_fwd_dot(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N, int relu,
+                  const float* dot_w, float* dot_parts, int64_t dot_stride, int* n_parts, hipStream_t st, bool* done);
+int ws_fc_bwd_data_gate(const float* h, int ldh, const float* rowscale, const float* kscale, const float* w, float* dx, int lddx, int M, int K,
+                        int N, hipStream_t st, bool* done);
 int dr_wgrad_splits(int M, int K, int N);
 // Outer-PNN first layer with the pair products formed in the MFMA fragments (gemm_dr.hip)
 bool opnn_fused_ok(int F, int K, int H);
