@@ -115,7 +115,9 @@ bool small_problem(int Mo, int No) { return (int64_t)ceil_div(Mo, 64) * ceil_div
 
 // (1x4: small batches -- c1's B = 256, serving -- where the output has too few big tiles for the chip: 16 x 64 patches, 112 blocks
 //  for 256 x 400, each wave a quarter of the reduction; see small_problem())
-constexpr Tile FWD_TILES[] = {{2, 13}, {4, 7}, {2, 8}, {1, 4}};
+// (4x8: a 256-wide layer over a long reduction -- c4's first PNN layer, 8192 x 1989 -> 256 -- in ONE round of 64 x 128 tiles where
+//  2x8 takes two and loads every weight column block twice as often)
+constexpr Tile FWD_TILES[] = {{2, 13}, {4, 7}, {2, 8}, {1, 4}, {4, 8}};
 constexpr Tile DGRAD_TILES[] = {{2, 13}, {4, 10}, {2, 8}, {1, 4}};
 // (no 3x13 here: 392 VGPRs -- a wgrad runs beside the background table pass, whose two waves per SIMD leave room for 320)
 // (2x16: a 256-wide output in one column block -- AFM's attention weight over 3 M pair rows, 8 row tiles x 32 batch splits)
@@ -194,6 +196,7 @@ int dr_fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y,
         case 0: return dr_launch<2, 13, true, false, false, DR_BIAS_ACT>(x, ldx, w, N, y, ldy, M, N, K, 1, ep, st);
         case 1: return dr_launch<4, 7, true, false, false, DR_BIAS_ACT>(x, ldx, w, N, y, ldy, M, N, K, 1, ep, st);
         case 2: return dr_launch<2, 8, true, false, false, DR_BIAS_ACT>(x, ldx, w, N, y, ldy, M, N, K, 1, ep, st);
+        case 4: return dr_launch<4, 8, true, false, false, DR_BIAS_ACT>(x, ldx, w, N, y, ldy, M, N, K, 1, ep, st);
         default: return dr_launch<1, 4, true, false, false, DR_BIAS_ACT>(x, ldx, w, N, y, ldy, M, N, K, 1, ep, st);
     }
 }
