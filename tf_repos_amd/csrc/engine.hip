@@ -758,13 +758,19 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
     }
     if (c.model == DCTR_MODEL_DCN) {
         const Param& cw = E->params[E->p_cross_w];
+        // (fused_opt: the cross parameters' 2 L column-sum launches go to the side stream behind the fork below -- 37 us of small
+        //  kernels that stood between the cross backward and the table step at c3)
         DCTR_TRY(dcn_cross_bwd(E->xs, E->xlw, E->pp(E->p_cross_w), E->dxL, D, B, D, c.cross_layers, E->dx_in, E->Din_ld,
-                               E->part(E->p_cross_w), E->part(E->p_cross_b), cw.n_part, cw.padded, E->cross_scratch, st));
+                               fused_opt && sw != st ? nullptr : E->part(E->p_cross_w), E->part(E->p_cross_b), cw.n_part, cw.padded, E->cross_scratch, st));
     }
     if (fused_opt) {
         // everything the dense side reads or writes on st is enqueued: the first layer's step (its dgrad is done) and, for the
         // caller, the cross-network / output-layer partial slabs
         DCTR_TRY(fork(E, st, sw));
+        if (c.model == DCTR_MODEL_DCN && sw != st) {
+            const Param& cw = E->params[E->p_cross_w];
+            DCTR_TRY(dcn_cross_param_grads(E->xs, B, D, c.cross_layers, E->part(E->p_cross_w), E->part(E->p_cross_b), cw.n_part, cw.padded, E->cross_scratch, sw));
+        }
         if (!wgrad_late) DCTR_TRY(opt_dense_range(E, E->mlp[0].w, E->mlp[0].last, sw));
     }
     return DCTR_OK;

@@ -428,6 +428,22 @@ __global__ __launch_bounds__(256) void dcn_cross_bwd_kernel(const float* __restr
     }
 }
 
+// the cross parameters' gradient slabs out of what dcn_cross_bwd_kernel left in the scratch: column sums over the batch, 2 L small
+// launches -- nothing on the way to dL/de needs them, so the training step runs them on its side stream
+int dcn_cross_param_grads(const float* xs, int B, int D, int L, float* dw_part, float* db_part, int splits, int64_t part_stride,
+                          const float* scratch, hipStream_t st) {
+    if (B <= 0) return DCTR_OK;
+    const float* G = scratch;                          // [L,B,D]
+    const float* T = scratch + (size_t)L * B * D;      // [L,B]
+    for (int l = 0; l < L; ++l) {
+        // partial slabs: slab s of layer l at part + s*part_stride + l*D
+        DCTR_TRY(colsum_partials(G + (size_t)l * B * D, D, nullptr, B, D, splits, db_part + (size_t)l * D, part_stride, st));
+        DCTR_TRY(colsum_partials(xs + (size_t)l * B * D, D, T + (size_t)l * B, B, D, splits, dw_part + (size_t)l * D, part_stride, st));
+    }
+    return DCTR_OK;
+}
+
+// (dw_part == nullptr: the caller runs dcn_cross_param_grads itself, on a stream of its choice, behind this one)
 int dcn_cross_bwd(const float* xs, const float* xlw, const float* w, const float* dxL, int dxl_ld, int B, int D, int L,
                   float* dx0, int dx0_ld, float* dw_part, float* db_part, int splits, int64_t part_stride,
                   float* scratch, hipStream_t st) {
@@ -443,12 +459,8 @@ int dcn_cross_bwd(const float* xs, const float* xlw, const float* w, const float
     else if (D <= 256 * 40) dcn_cross_bwd_kernel<40, 256><<<B, 256, 0, st>>>(xs, xlw, w, dxL, dxl_ld, B, D, L, dx0, dx0_ld, G, T);
     else { set_error("dcn_cross: F*K=%d > 10240 unsupported", D); return DCTR_ERR_UNSUPPORTED; }
     DCTR_LAUNCH_CHECK();
-    for (int l = 0; l < L; ++l) {
-        // partial slabs: slab s of layer l at part + s*part_stride + l*D
-        DCTR_TRY(colsum_partials(G + (size_t)l * B * D, D, nullptr, B, D, splits, db_part + (size_t)l * D, part_stride, st));
-        DCTR_TRY(colsum_partials(xs + (size_t)l * B * D, D, T + (size_t)l * B, B, D, splits, dw_part + (size_t)l * D, part_stride, st));
-    }
-    return DCTR_OK;
+    if (dw_part == nullptr) return DCTR_OK;
+    return dcn_cross_param_grads(xs, B, D, L, dw_part, db_part, splits, part_stride, scratch, st);
 }
 
 // ---- DeepMVM "all-order" product (DeepMVM.py:144-150): x_mvm[b,k] = prod_f (e[b,f,k] + mvm_b[f,k]) -----------------------------

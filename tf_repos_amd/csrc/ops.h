@@ -192,6 +192,8 @@ int dcn_cross_fwd(const float* x0, int x0_ld, const float* w, const float* b, in
 int dcn_cross_bwd(const float* xs, const float* xlw, const float* w, const float* dxL, int dxl_ld, int B, int D, int L,
                   float* dx0, int dx0_ld, float* dw_part, float* db_part, int splits, int64_t part_stride,
                   float* scratch, hipStream_t st);
+int dcn_cross_param_grads(const float* xs, int B, int D, int L, float* dw_part, float* db_part, int splits, int64_t part_stride,
+                          const float* scratch, hipStream_t st);
 
 // sparse.hip / mtl.hip: the CSR (multi-hot) models DIN / ESMM
 int lookup_sparse_slots_fwd(const float* emb, int64_t rows, int K, const int32_t* offsets, const int32_t* ids, const float* weights,
