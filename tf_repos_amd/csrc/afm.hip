@@ -137,7 +137,8 @@ __global__ __launch_bounds__(NT) void afm_pool_bwd_kernel(float* __restrict__ dy
                                                           const float* __restrict__ att, int P, int K, float keep_att, float keep_emb,
                                                           const uint64_t* __restrict__ seed_ptr, float* __restrict__ dsc,
                                                           float* __restrict__ att_drop, const float4* __restrict__ ee, int e_ld4, int F,
-                                                          const int16_t* __restrict__ pi, const int16_t* __restrict__ pj, int b0) {
+                                                          const int16_t* __restrict__ pi, const int16_t* __restrict__ pj, int b0,
+                                                          float* __restrict__ dsum) {
     extern __shared__ __attribute__((aligned(16))) float sm[];        // [K] dyemb (pre-dropout gradient) | [P] da | [F][K] embeddings (ee)
     __shared__ float red[NT / 64];
     float* dye = sm;
@@ -194,7 +195,24 @@ __global__ __launch_bounds__(NT) void afm_pool_bwd_kernel(float* __restrict__ dy
     float tot = 0.f;
 #pragma unroll
     for (int w = 0; w < NT / 64; ++w) tot += red[w];
-    for (int p = t; p < P; p += NT) dsc[(size_t)b * P + p] = ab[p] * (da[p] - tot);      // softmax backward
+    float ds = 0.f;
+    for (int p = t; p < P; p += NT) {
+        const float d = ab[p] * (da[p] - tot);      // softmax backward
+        dsc[(size_t)b * P + p] = d;
+        ds += d;
+    }
+    if (dsum != nullptr) {                          // the example's share of attention_out's bias gradient (= sum of d score; ~0 by construction)
+        __syncthreads();
+        ds = wsum64(ds);
+        if (lane == 0) red[wave] = ds;
+        __syncthreads();
+        if (t == 0) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) a += red[w];
+            dsum[b] = a;
+        }
+    }
 }
 
 // dE[b,i,:] = sum_{j != i} (a'[b,pair(i,j)] * dyemb[b,:] + g2[b,pair(i,j),:]) * e[b,j,:]      (pooling path + attention path)
@@ -668,7 +686,8 @@ static int afm_pool_bwd(dctr_engine* E, int b0, int n, hipStream_t st) {
     DCTR_HIP_CHECK(attr_w);
     kern<<<n, wide ? 1024 : 256, from_e ? lds_e : lds_pp, st>>>(E->dx_in, E->Din_ld, E->pairp, E->att, P, K, E->keep_att, E->keep_emb,
                                                                  &E->state->seed_t, E->dsc, E->sc,
-                                                                 from_e ? reinterpret_cast<const float4*>(E->e) : nullptr, E->e_ld / 4, F, E->pair_i, E->pair_j, b0);
+                                                                 from_e ? reinterpret_cast<const float4*>(E->e) : nullptr, E->e_ld / 4, F, E->pair_i, E->pair_j, b0,
+                                                                 E->sc_parts);        // (the forward's score parts are free: [0, B) takes the per-example sums of d score)
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }
@@ -714,10 +733,8 @@ int afm_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
             bool wdone = false, ddone = false;
             auto wgrad = [&]() -> int {
                 DCTR_TRY(fork(E, st, sw));
-                // db_o = sum of d score first (a 32-block kernel behind the product would end the stream 0.3 ms later at B = 4096; on a
-                // third stream, joined behind the product, it measured WORSE: 12.1 -> 12.5 ms, 0.62 -> 0.83 ms at B = 128)
-                const int64_t rows = (int64_t)n * P;
-                vec_sum_partials_kernel<<<ab.n_part, 256, 0, sw>>>(E->dsc, rows, ceil_div(rows, ab.n_part), E->part(E->p_ao_b), ab.padded);
+                // db_o = sum of d score, from the per-example sums the backward pooling left (B values, not B P)
+                vec_sum_partials_kernel<<<ab.n_part, 256, 0, sw>>>(E->sc_parts, n, ceil_div(n, ab.n_part), E->part(E->p_ao_b), ab.padded);
                 DCTR_LAUNCH_CHECK();
                 DCTR_TRY(dr_fc_bwd_weights_partials_gate(E->pairp, K, E->ah, A, E->dsc, E->pp(E->p_ao_w), E->part(fc.w), w.padded, E->part(fc.b),
                                                          bb.padded, E->part(E->p_ao_w), aw.padded, n * P, K, A, fc.splits, sw, &wdone));
