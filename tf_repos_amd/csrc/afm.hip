@@ -215,6 +215,117 @@ __global__ __launch_bounds__(NT) void afm_pool_bwd_kernel(float* __restrict__ dy
     }
 }
 
+// The same from the example's EMBEDDINGS on the matrix cores: d a'[pair(i,j)] = <d y_emb, e_i . e_j> is entry (i, j) of
+// G = (E diag(d y_emb)) E^T, an [F, F] product over K per example -- 384 MFMAs of 16x16x4 at F = 39, K = 256, against reading the
+// example's 759 KB slice of the pair tensor (0.66 ms over B = 4096; this one 164 MB of embeddings in all).  One WAVE per example:
+// lane (c, q) loads a float4 of field 16 t + c at k = 16 g + 4 q .. + 3 for each field tile t -- the same registers are the B
+// fragments (E^T) and, scaled by d y_emb, the A fragments of the group's four MFMA steps; only tiles on or above the diagonal
+// are formed.  Softmax / dropout backward on the accumulators, the example-wide sum by wave shuffles.
+typedef float afm_f32x4 __attribute__((ext_vector_type(4)));
+template <int K, int TF>
+__global__ __launch_bounds__(256) void afm_pool_bwd_mfma_kernel(float* __restrict__ dy, int dy_ld, const float* __restrict__ att, int P, int F,
+                                                               float keep_att, float keep_emb, const uint64_t* __restrict__ seed_ptr,
+                                                               float* __restrict__ dsc, float* __restrict__ att_drop,
+                                                               const float4* __restrict__ ee, int e_ld4, int b0, int n, float* __restrict__ dsum) {
+    constexpr int KG = K / 16, KQ = K / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+    const int bi = blockIdx.x * 4 + wave;
+    if (bi >= n) return;
+    const int b = b0 + bi;
+    const uint64_t seed = (keep_att < 1.f || keep_emb < 1.f) ? *seed_ptr : 0ull;
+    // d y_emb before its dropout, this lane's 4 k of every group; written back in place (the pair backward reads it) by the c == 0 lanes
+    float4 dk[KG];
+    float* dyb = dy + (size_t)b * dy_ld;
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+        const int k = 16 * g + 4 * q;
+        float4 v = *reinterpret_cast<const float4*>(dyb + k);
+        if (keep_emb < 1.f) {
+            v.x *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + k + 0, keep_emb);
+            v.y *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + k + 1, keep_emb);
+            v.z *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + k + 2, keep_emb);
+            v.w *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + k + 3, keep_emb);
+        }
+        dk[g] = v;
+    }
+    afm_f32x4 acc[TF][TF];
+#pragma unroll
+    for (int i = 0; i < TF; ++i)
+#pragma unroll
+        for (int j = 0; j < TF; ++j) acc[i][j] = afm_f32x4{0.f, 0.f, 0.f, 0.f};
+    const float4* eb = ee + (size_t)b * e_ld4;
+    float4 ev[2][TF];
+    auto load = [&](float4* d, int g) {
+#pragma unroll
+        for (int t = 0; t < TF; ++t) {
+            const int f = 16 * t + c;
+            d[t] = f < F ? eb[f * KQ + 4 * g + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    load(ev[0], 0);
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+        if (g + 1 < KG) load(ev[(g + 1) & 1], g + 1);
+        const float4* e4 = ev[g & 1];
+        const float dks[4] = {dk[g].x, dk[g].y, dk[g].z, dk[g].w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float bs[TF];
+#pragma unroll
+            for (int t = 0; t < TF; ++t) bs[t] = s == 0 ? e4[t].x : s == 1 ? e4[t].y : s == 2 ? e4[t].z : e4[t].w;
+#pragma unroll
+            for (int i = 0; i < TF; ++i)
+#pragma unroll
+                for (int j = i; j < TF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bs[i] * dks[s], bs[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (c == 0) {
+#pragma unroll
+        for (int g = 0; g < KG; ++g) *reinterpret_cast<float4*>(dyb + 16 * g + 4 * q) = dk[g];
+    }
+    // register r of lane (c, q) in tile (i, j): row 16 i + 4 q + r, column 16 j + c
+    const float* ab = att + (size_t)b * P;
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < TF; ++i)
+#pragma unroll
+        for (int j = i; j < TF; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * i + 4 * q + r, col = 16 * j + c;
+                float d = 0.f;
+                if (row < col && col < F) {
+                    const int p = row * F - (row * (row + 1)) / 2 + (col - row - 1);
+                    const float msk = keep_att < 1.f ? dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_ATT, (uint64_t)b * P + p, keep_att) : 1.f;
+                    const float a = ab[p];
+                    d = acc[i][j][r] * msk;                         // d att[p]
+                    att_drop[(size_t)b * P + p] = a * msk;
+                    part += a * d;
+                }
+                acc[i][j][r] = d;
+            }
+    const float tot = wsum64(part);
+    float ds = 0.f;
+#pragma unroll
+    for (int i = 0; i < TF; ++i)
+#pragma unroll
+        for (int j = i; j < TF; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * i + 4 * q + r, col = 16 * j + c;
+                if (row < col && col < F) {
+                    const int p = row * F - (row * (row + 1)) / 2 + (col - row - 1);
+                    const float v = ab[p] * (acc[i][j][r] - tot);      // softmax backward
+                    dsc[(size_t)b * P + p] = v;
+                    ds += v;
+                }
+            }
+    if (dsum != nullptr) {
+        ds = wsum64(ds);
+        if (lane == 0) dsum[b] = ds;
+    }
+}
+
 // dE[b,i,:] = sum_{j != i} (a'[b,pair(i,j)] * dyemb[b,:] + g2[b,pair(i,j),:]) * e[b,j,:]      (pooling path + attention path)
 __global__ __launch_bounds__(256) void afm_pair_bwd_kernel(const float* __restrict__ e, int e_ld, const float* __restrict__ att_drop,
                                                           const float* __restrict__ dye, int dye_ld, const float* __restrict__ g2, int F,
@@ -673,6 +784,18 @@ int afm_forward(dctr_engine* E, int B, bool train, hipStream_t st) {
 
 static int afm_pool_bwd(dctr_engine* E, int b0, int n, hipStream_t st) {
     const int F = E->F, K = E->K, P = E->P;
+    static const bool no_mfma = getenv("DCTR_AFM_POOL_BWD_PP") != nullptr;       // A/B knob: the pass over the pair tensor
+    if (!no_mfma && F <= 48 && (K == 64 || K == 128 || K == 256) && E->e_ld % 4 == 0 && E->Din_ld % 4 == 0) {
+        const int tf = ceil_div(F, 16);
+#define DCTR_PBM(K_, T_) afm_pool_bwd_mfma_kernel<K_, T_><<<ceil_div(n, 4), 256, 0, st>>>(E->dx_in, E->Din_ld, E->att, P, F, E->keep_att, E->keep_emb, \
+            &E->state->seed_t, E->dsc, E->sc, reinterpret_cast<const float4*>(E->e), E->e_ld / 4, b0, n, E->sc_parts)
+#define DCTR_PBK(K_) if (tf == 1) DCTR_PBM(K_, 1); else if (tf == 2) DCTR_PBM(K_, 2); else DCTR_PBM(K_, 3)
+        if (K == 64) { DCTR_PBK(64); } else if (K == 128) { DCTR_PBK(128); } else { DCTR_PBK(256); }
+#undef DCTR_PBK
+#undef DCTR_PBM
+        DCTR_LAUNCH_CHECK();
+        return DCTR_OK;
+    }
     const size_t lds_pp = (size_t)(K + P) * sizeof(float), lds_e = (size_t)(((K + P + 3) & ~3) + F * K) * sizeof(float);
     // (rebuilding the pair products from LDS-staged embeddings pays in the forward pooling, 0.51 -> 0.24 ms at K = 256, but not
     //  here: 0.66 -> 0.85 ms, the 40 KB of LDS per block cost more occupancy than the 759 KB read saves; DCTR_AFM_POOL_BWD_E=1)
