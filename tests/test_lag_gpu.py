@@ -1,7 +1,7 @@
 """Time-blocked dense-exact table sweep (csrc/lag.h, dctr_config.table_sweep_period): rows no batch touches may lag behind
 global_step and are advanced through the steps they missed -- the same Adam update calls with the same per-step lr_t, in order --
 when something reads them.  The scheme changes WHEN a row's updates are computed, never what they are, so a lagging engine must
-end where the classic one (every row every step, period 1) ends: compared here element for element at 1e-6 -- what two runs of the
+end where the classic one (every row every step, period 1) ends: compared here element for element at 2e-6 or 4x what two runs of the
 SAME engine differ by (the hot ids' segment sums meet through float atomics in no fixed order); a missed, doubled or mis-stamped
 step would show as ~lr = 1e-2 -- and against the oracle's dense Adam (DeepFM.py:188-190,204-213) at the usual 2e-6."""
 import numpy as np
@@ -43,7 +43,7 @@ def test_lagging_rows_end_where_the_classic_sweep_ends(model, period, dev):
                     l2_reg=1e-3, learning_rate=1e-2, optimizer="Adam")
     params = O.init_params(ocfg, seed=2, scale=0.05)
     runs = []
-    for p in (1, period):
+    for p in (1, 1, period):        # (classic twice: what two runs of the SAME schedule differ by -- float atomics in the table step, amplified by Adam)
         eng = engine(model, p, V, B, params=params, keep=(0.8, 0.8))
         losses = []
         for step in range(30):
@@ -59,13 +59,15 @@ def test_lagging_rows_end_where_the_classic_sweep_ends(model, period, dev):
                 losses.append(float(np.abs(eng.get_param("emb")).sum()))
         runs.append((losses, state_of(eng), eng.global_step))
         eng.close()
-    assert runs[0][2] == runs[1][2] == 30
-    for a, b_ in zip(runs[0][0], runs[1][0]):
+    assert runs[0][2] == runs[1][2] == runs[2][2] == 30
+    noise_l = max([abs(a - b_) / max(1.0, abs(a)) for a, b_ in zip(runs[0][0], runs[1][0]) if a is not None] + [0.0])
+    noise_v = max(float(np.abs(v - runs[1][1][k]).max()) for k, v in runs[0][1].items())
+    for a, b_ in zip(runs[0][0], runs[2][0]):
         assert (a is None) == (b_ is None)
         if a is not None:
-            assert abs(a - b_) <= 1e-6 * max(1.0, abs(a)), (a, b_)
+            assert abs(a - b_) <= max(2e-6, 4 * noise_l) * max(1.0, abs(a)), (a, b_, noise_l)
     for k, v in runs[0][1].items():
-        assert np.abs(v - runs[1][1][k]).max() <= 1e-6, k
+        assert np.abs(v - runs[2][1][k]).max() <= max(2e-6, 4 * noise_v), (k, noise_v)
 
 
 def test_lagging_rows_match_the_oracle(dev):
