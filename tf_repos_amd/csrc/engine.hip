@@ -922,7 +922,14 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     }
     const bool split_table = split_table_on(E);
     static const bool bg_late = getenv("DCTR_BG_LATE") != nullptr;              // A/B knob: background table pass beside the backward
-    static const int group_after = getenv("DCTR_GROUP_AFTER") ? atoi(getenv("DCTR_GROUP_AFTER")) : 0;   // A/B knob: 0 = after the gather, 1 = after MLP layer 0
+    // where the grouping stream starts (id grouping unless prefetched, then the background table pass): 0 = after the gather,
+    // 1 = after MLP layer 0.  Round 3: behind a first layer worth waiting for (c2: 624 x 400) -- the background pass is ALU-bound
+    // now (lagging rows replayed in registers) and beside layer 0 it cost that product 7 us of its 36 (in-step 0.36 -> 0.45 of the
+    // MFMA peak by the hipEvent bracket; step 0.2668 -> 0.2646 ms, c3 0.312 -> 0.307, c4 inner 0.502 -> 0.494); NFM's K-wide
+    // first layer is over before the pass could start, and the table step would wait for it (0.233 -> 0.247): there, 0.
+    static const int group_after_env = getenv("DCTR_GROUP_AFTER") ? atoi(getenv("DCTR_GROUP_AFTER")) : -1;   // A/B knob
+    const int group_after = group_after_env >= 0 ? group_after_env
+                            : (!E->mlp.empty() && (int64_t)E->mlp[0].in * E->mlp[0].out >= (1 << 16) ? 1 : 0);
     // the id grouping (and the background table pass behind it) on the grouping stream
     // ids grouped ahead (dctr_prefetch_ids, during the tail of the previous step): the two grouping states change roles
     const bool pregrouped = E->pre_valid && E->pre_ids == E->ids && E->pre_B == B && E->group_alt != nullptr && !E->cfg.use_graph &&
