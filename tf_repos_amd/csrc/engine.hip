@@ -507,7 +507,7 @@ int gather_from(dctr_engine* E, const float* emb, const float* lin, int64_t rows
 }
 
 // after_layer0: called once the first MLP layer has been enqueued (the step uses it to start the id grouping there)
-int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::function<int()>* after_layer0 = nullptr) {
+int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::function<int()>* after_layer0 = nullptr, int after_idx = 0) {
     const dctr_config& c = E->cfg;
     const int F = E->F, K = E->K, D = E->D;
     if (c.model == DCTR_MODEL_AFM) return afm_forward(E, B, train, st);
@@ -535,7 +535,7 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::f
         DCTR_TRY(fc_fwd(x, ldx, E->pp(fc.w), E->pp(fc.b), E->h[i], fc.out, B, fc.in, fc.out, 1, (train && !E->bn) ? fc.keep : 1.f,
                         seedp, fc.salt, st, 1));
         if (timed) { DCTR_HIP_CHECK(hipEventRecord(E->timer_ev[E->timer_n + 1], st)); E->timer_n += 2; }
-        if (i == 0 && after_layer0 != nullptr) DCTR_TRY((*after_layer0)());
+        if ((int)i == std::min(after_idx, (int)E->mlp.size() - 1) && after_layer0 != nullptr) DCTR_TRY((*after_layer0)());
         x = E->h[i]; ldx = fc.out;
         if (E->bn) {
             DCTR_TRY(bn_forward(E->h[i], fc.out, B, fc.out, train, 1e-3f, c.batch_norm_decay, E->pp(fc.bn_gamma), E->pp(fc.bn_beta),
@@ -923,19 +923,24 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     const bool split_table = split_table_on(E);
     static const bool bg_late = getenv("DCTR_BG_LATE") != nullptr;              // A/B knob: background table pass beside the backward
     // where the grouping stream starts (id grouping unless prefetched, then the background table pass): 0 = after the gather,
-    // 1 = after MLP layer 0.  Round 3: behind a first layer worth waiting for (c2: 624 x 400) -- the background pass is ALU-bound
+    // i = after MLP layer i - 1.  Round 3: behind a first layer worth waiting for (c2: 624 x 400) -- the background pass is ALU-bound
     // now (lagging rows replayed in registers) and beside layer 0 it cost that product 7 us of its 36 (in-step 0.36 -> 0.45 of the
     // MFMA peak by the hipEvent bracket; step 0.2668 -> 0.2646 ms, c3 0.312 -> 0.307, c4 inner 0.502 -> 0.494); NFM's K-wide
     // first layer is over before the pass could start, and the table step would wait for it (0.233 -> 0.247): there, 0.
+    // With the ids grouped ahead (next-batch hint) only the background pass is left for this stream and nothing but the table step
+    // waits for it: it starts behind the LAST forward layer (n = number of MLP layers) -- c2 0.2650 -> 0.2605, NFM 0.232 -> 0.221,
+    // c3 / c4 inner / DeepMVM -1 %; without the hint that is too late for the grouping itself at c4's sizes (0.493 -> 0.512).
     static const int group_after_env = getenv("DCTR_GROUP_AFTER") ? atoi(getenv("DCTR_GROUP_AFTER")) : -1;   // A/B knob
-    const int group_after = group_after_env >= 0 ? group_after_env
-                            : (!E->mlp.empty() && (int64_t)E->mlp[0].in * E->mlp[0].out >= (1 << 16) ? 1 : 0);
     // the id grouping (and the background table pass behind it) on the grouping stream
     // ids grouped ahead (dctr_prefetch_ids, during the tail of the previous step): the two grouping states change roles
     const bool pregrouped = E->pre_valid && E->pre_ids == E->ids && E->pre_B == B && E->group_alt != nullptr && !E->cfg.use_graph &&
                             E->pre_gen == E->slot_gen[E->pre_slot].load();     // (the slot still holds what was grouped)
     E->pre_valid = false;
     if (pregrouped) std::swap(E->group, E->group_alt);
+    const int group_after = group_after_env >= 0 ? group_after_env
+                            : E->mlp.empty() ? 0
+                            : pregrouped ? (int)E->mlp.size()
+                            : ((int64_t)E->mlp[0].in * E->mlp[0].out >= (1 << 16) ? 1 : 0);
     hipEvent_t tables_ev = nullptr;
     bool have_tables_ev = false;
     const std::function<int()> start_grouping = [&]() -> int {
@@ -950,8 +955,8 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
         return DCTR_OK;
     };
     const bool have_mlp = !E->mlp.empty() && E->cfg.model != DCTR_MODEL_AFM;
-    if (!(group_after == 1 && have_mlp)) DCTR_TRY(start_grouping());
-    DCTR_TRY(forward_rest(E, B, true, st, (group_after == 1 && have_mlp) ? &start_grouping : nullptr));
+    if (!(group_after >= 1 && have_mlp)) DCTR_TRY(start_grouping());
+    DCTR_TRY(forward_rest(E, B, true, st, (group_after >= 1 && have_mlp) ? &start_grouping : nullptr, group_after - 1));
     DCTR_TRY(head(E, B, B, true, st, nullptr, true));
     const bool fused_opt = E->cfg.model != DCTR_MODEL_AFM;
     hipEvent_t head_ev = nullptr;

@@ -48,12 +48,15 @@ for name, c in CONFIGS.items():
         si[:c["B"]].copy_(torch.from_numpy(ids)); sv[:c["B"]].copy_(torch.from_numpy(vals)); sl[:c["B"]].copy_(torch.from_numpy(labels))
         batches.append((si[:c["B"]], sv[:c["B"]], sl[:c["B"]]))
     steps_c = c.get("steps", steps)
+    hint = os.environ.get("DCTR_CFG_HINT", "0") == "1"        # announce the next batch's ids after every step, as the input pipeline does
     for s in range(min(10, steps_c)):
         eng.train_step(*batches[s % 4], want_loss=False)
+        if hint: eng.prefetch_ids(batches[(s + 1) % 4][0])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(steps_c):
         eng.train_step(*batches[s % 4], want_loss=False)
+        if hint: eng.prefetch_ids(batches[(s + 1) % 4][0])
     eng.sync_tables()          # (time-blocked table sweep: every row's updates of the timed steps computed inside the timed region)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
