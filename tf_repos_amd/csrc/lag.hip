@@ -115,7 +115,8 @@ int launch_advance(int K, int64_t rows, float* emb, float* s0, float* s1, float*
     const int KQ = K / 4;
     const int64_t span = FLUSH ? rows : (rows + period - 1) / period;
     // the sweep runs UNDER the MLP GEMMs like the classic background pass: a small grid (2 blocks per CU); the flush has the chip
-    const int grid = (int)std::min<int64_t>(ceil_div(span * KQ, 256 * 4), FLUSH ? 256 * 8 : 256 * 2);
+    static const int bpc = getenv("DCTR_LAG_BLOCKS_PER_CU") ? atoi(getenv("DCTR_LAG_BLOCKS_PER_CU")) : 2;     // A/B knob
+    const int grid = (int)std::min<int64_t>(ceil_div(span * KQ, 256 * 4), FLUSH ? 256 * 8 : 256 * bpc);
     float4 *e4 = reinterpret_cast<float4*>(emb), *a4 = reinterpret_cast<float4*>(s0), *b4 = reinterpret_cast<float4*>(s1);
     switch (KQ) {
 #define DCTR_A(Q) case Q: lag_advance_kernel<Q, FLUSH, 4><<<grid, 256, 0, st>>>(rows, e4, a4, b4, lin, l0, l1, slot, ts, state, l2, period, target_offset, sumsq_emb, sumsq_lin); break
