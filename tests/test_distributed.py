@@ -142,11 +142,12 @@ def test_two_ranks_equal_one_rank(model, overlap, driver, dev):
     one = eng.get_params()
     for k in one:
         # tolerance: N ranks == 1 rank within 1e-6 (batch_norm: 5e-6, the statistics are summed in a different order)
-        assert np.abs(one[k] - got[k]).max() <= (5e-6 if model.endswith("+bn") else 1e-6), k
+        # (+lag: nine Adam steps instead of three -- what two runs of ONE engine differ by reaches 1.5e-6 there, test_lag_gpu.py)
+        assert np.abs(one[k] - got[k]).max() <= (5e-6 if model.endswith("+bn") else 3e-6 if model.endswith("+lag") else 1e-6), k
     assert np.allclose(losses, ref_losses, rtol=1e-5, atol=1e-6)
     ids, vals, labels = O.synth_batch(Bg, F, V, seed=999)
     d = dev_batch(ids, vals, labels, dev)
     p1 = torch.empty(Bg, device=dev)
     eng.predict(d[0], d[1], p1, None)
-    assert np.abs(p1.cpu().numpy() - probs).max() <= (5e-6 if model.endswith("+bn") else 1e-6)
+    assert np.abs(p1.cpu().numpy() - probs).max() <= (5e-6 if model.endswith("+bn") else 3e-6 if model.endswith("+lag") else 1e-6)
     eng.close()

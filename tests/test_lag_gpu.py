@@ -1,7 +1,7 @@
 """Time-blocked dense-exact table sweep (csrc/lag.h, dctr_config.table_sweep_period): rows no batch touches may lag behind
 global_step and are advanced through the steps they missed -- the same Adam update calls with the same per-step lr_t, in order --
 when something reads them.  The scheme changes WHEN a row's updates are computed, never what they are, so a lagging engine must
-end where the classic one (every row every step, period 1) ends: compared here element for element at 2e-6 or 4x what two runs of the
+end where the classic one (every row every step, period 1) ends: compared here element for element at 3e-6 or 4x what two runs of the
 SAME engine differ by (the hot ids' segment sums meet through float atomics in no fixed order); a missed, doubled or mis-stamped
 step would show as ~lr = 1e-2 -- and against the oracle's dense Adam (DeepFM.py:188-190,204-213) at the usual 2e-6."""
 import numpy as np
@@ -65,9 +65,9 @@ def test_lagging_rows_end_where_the_classic_sweep_ends(model, period, dev):
     for a, b_ in zip(runs[0][0], runs[2][0]):
         assert (a is None) == (b_ is None)
         if a is not None:
-            assert abs(a - b_) <= max(2e-6, 4 * noise_l) * max(1.0, abs(a)), (a, b_, noise_l)
+            assert abs(a - b_) <= max(3e-6, 4 * noise_l) * max(1.0, abs(a)), (a, b_, noise_l)
     for k, v in runs[0][1].items():
-        assert np.abs(v - runs[2][1][k]).max() <= max(2e-6, 4 * noise_v), (k, noise_v)
+        assert np.abs(v - runs[2][1][k]).max() <= max(3e-6, 4 * noise_v), (k, noise_v)
 
 
 def test_lagging_rows_match_the_oracle(dev):
@@ -141,7 +141,7 @@ def test_csr_models_lag_like_the_classic_sweep(model, att, dev):
     params = M.init_params(ocfg, seed=4, scale=0.2 if att else 0.05)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     runs = []
-    for period in (1, 6):
+    for period in (1, 1, 6):       # (classic twice: the yardstick is what two runs of the same schedule differ by)
         eng = Engine(EngineConfig(model=model, field_size=ocfg.n_slots, feature_size=V, embedding_size=K, deep_layers=(32, 16), dropout=(0.8, 0.8),
                                   l2_reg=1e-3, learning_rate=1e-2, optimizer="Adam", max_batch=B, max_entries=B * (ocfg.n_slots + 40),
                                   ctr_task_wgt=0.4, attention_layers=att or (256,), att_pairs=[(Fc + i, Fc + 4 + i) for i in range(4)] if att else (),
@@ -161,9 +161,10 @@ def test_csr_models_lag_like_the_classic_sweep(model, att, dev):
         st["emb/m"], st["emb/v"] = eng.get_slot("emb", 0), eng.get_slot("emb", 1)
         runs.append((out, st))
         eng.close()
-    for a, b in zip(runs[0][0], runs[1][0]):
+    noise = max(float(np.abs(v - runs[1][1][k]).max()) for k, v in runs[0][1].items())
+    for a, b in zip(runs[0][0], runs[2][0]):
         assert (a is None) == (b is None)
         if a is not None:
             assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (a, b)
     for k, v in runs[0][1].items():
-        assert np.abs(v - runs[1][1][k]).max() <= 2e-6, k
+        assert np.abs(v - runs[2][1][k]).max() <= max(3e-6, 4 * noise), (k, noise)      # (a missed or doubled step: ~1e-2)
