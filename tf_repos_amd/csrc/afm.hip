@@ -352,8 +352,8 @@ __global__ __launch_bounds__(256) void afm_pair_bwd_kernel(const float* __restri
 
 // The same with float4 pieces and eight pairs in flight per thread (the loop above issues one 4-byte load per pair and waits for
 // it: 1.1 TB/s on 6 GB at the reference's K = 256, B = 4096).  Thread = (field i, piece kq) of one example; every row of g2 is
-// still read twice (once from each of its fields' side) -- the one-pass variant below, which folds both contributions into an LDS
-// accumulator with ds_add_f32, measured 2x SLOWER than the loop above: LDS float atomics retire about one LANE per clock per CU
+// still read twice (once from each of its fields' side) -- a one-pass variant that folded both contributions into an LDS
+// accumulator with ds_add_f32 (removed) measured 2x SLOWER than the loop above: LDS float atomics retire about one LANE per clock per CU
 // (1.5 G lane-atomics at K = 256, B = 4096 = ~6 ms of LDS time however the banks are laid out).
 template <int KQ>
 __global__ __launch_bounds__(256) void afm_pair_bwd_v4_kernel(const float4* __restrict__ e, int e_ld4, const float* __restrict__ att_drop,
@@ -392,56 +392,6 @@ __global__ __launch_bounds__(256) void afm_pair_bwd_v4_kernel(const float4* __re
         }
     }
     dE[(size_t)b * de_ld4 + x] = s;
-}
-
-// One-pass variant: a block per example, every row of g2 read ONCE (float4 pieces, eight pairs in flight per lane group), both of its
-// contributions -- dE[i] += v e_j and dE[j] += v e_i -- added into an LDS accumulator laid out [F][4][KQ] (component-major: the
-// KQ lanes of a row piece hit consecutive banks; a [F][K] layout makes ds_add_f32 an 8-way bank conflict), the partner rows of e
-// read from global memory (40 KB per example, L2-resident).  LDS: F K floats (39 x 256: 39 KB -> three blocks per CU).
-template <int KQ>
-__global__ __launch_bounds__(256) void afm_pair_bwd_once_kernel(const float4* __restrict__ e, int e_ld4, const float* __restrict__ att_drop,
-                                                               const float* __restrict__ dye, int dye_ld, const float4* __restrict__ g2,
-                                                               const int16_t* __restrict__ pair_i, const int16_t* __restrict__ pair_j,
-                                                               int F, int P, float4* __restrict__ dE, int de_ld4) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];             // [F][4][KQ]
-    constexpr int G = 256 / KQ;                 // pairs walked side by side by the block
-    constexpr int UN = 8;
-    const int b = blockIdx.x, t = threadIdx.x, kq = t % KQ, grp = t / KQ;
-    for (int x = t; x < F * 4 * KQ; x += 256) sm[x] = 0.f;
-    const float4 dk = reinterpret_cast<const float4*>(dye + (size_t)b * dye_ld)[kq];
-    const float4* eb = e + (size_t)b * e_ld4;
-    const float4* gb = g2 + (size_t)b * P * KQ;
-    const float* ad = att_drop + (size_t)b * P;
-    __syncthreads();
-    for (int p0 = grp; p0 < P; p0 += UN * G) {
-        float4 v[UN], ei[UN], ej[UN]; float a[UN]; int pi[UN], pj[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int p = p0 + u * G;
-            const int pc = p < P ? p : P - 1;                   // (clamped: the loads carry no branch)
-            pi[u] = pair_i[pc]; pj[u] = pair_j[pc];
-            v[u] = gb[(size_t)pc * KQ + kq];
-            a[u] = ad[pc];
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) { ei[u] = eb[pi[u] * KQ + kq]; ej[u] = eb[pj[u] * KQ + kq]; }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            if (p0 + u * G < P) {
-                const float4 w = make_float4(v[u].x + a[u] * dk.x, v[u].y + a[u] * dk.y, v[u].z + a[u] * dk.z, v[u].w + a[u] * dk.w);
-                float* di = sm + pi[u] * 4 * KQ + kq;
-                float* dj = sm + pj[u] * 4 * KQ + kq;
-                atomicAdd(di, w.x * ej[u].x); atomicAdd(di + KQ, w.y * ej[u].y); atomicAdd(di + 2 * KQ, w.z * ej[u].z); atomicAdd(di + 3 * KQ, w.w * ej[u].w);
-                atomicAdd(dj, w.x * ei[u].x); atomicAdd(dj + KQ, w.y * ei[u].y); atomicAdd(dj + 2 * KQ, w.z * ei[u].z); atomicAdd(dj + 3 * KQ, w.w * ei[u].w);
-            }
-        }
-    }
-    __syncthreads();
-    for (int x = t; x < F * KQ; x += 256) {
-        const int f = x / KQ, q = x - f * KQ;
-        const float* r = sm + f * 4 * KQ + q;
-        dE[(size_t)b * de_ld4 + x] = make_float4(r[0], r[KQ], r[2 * KQ], r[3 * KQ]);
-    }
 }
 
 // Every row of g2 read ONCE, without atomics: the pairs of one example are walked in round-robin-tournament order (the circle
@@ -533,14 +483,6 @@ int launch_pair_bwd_rr(const float* e, int e_ld, const float* att_drop, const fl
 int afm_pair_bwd(const float* e, int e_ld, const float* att_drop, const float* dye, int dye_ld, const float* g2, const int16_t* pair_i,
                  const int16_t* pair_j, int B, int F, int K, int P, float* dE, int de_ld, hipStream_t st) {
     static const bool old = getenv("DCTR_AFM_PAIR_BWD_OLD") != nullptr;          // A/B knob: the one-load-per-pair kernel
-    static const bool once = getenv("DCTR_AFM_PAIR_BWD_ONCE") != nullptr;        // A/B knob: the one-pass LDS-accumulator kernel
-    const size_t lds_once = (size_t)F * K * sizeof(float);
-    if (once && !old && lds_once <= 64 * 1024 && e_ld % 4 == 0 && de_ld % 4 == 0 && dye_ld % 4 == 0) {
-#define DCTR_PO(Q) case Q: afm_pair_bwd_once_kernel<Q><<<B, 256, lds_once, st>>>(reinterpret_cast<const float4*>(e), e_ld / 4, att_drop, dye, dye_ld, \
-                              reinterpret_cast<const float4*>(g2), pair_i, pair_j, F, P, reinterpret_cast<float4*>(dE), de_ld / 4); DCTR_LAUNCH_CHECK(); return DCTR_OK;
-        switch (K / 4) { DCTR_PO(1) DCTR_PO(2) DCTR_PO(4) DCTR_PO(8) DCTR_PO(16) DCTR_PO(32) DCTR_PO(64) default: break; }
-#undef DCTR_PO
-    }
     static const bool no_rr = getenv("DCTR_AFM_PAIR_BWD_TWICE") != nullptr;      // A/B knob: the two-reads kernel at every K
     const size_t lds_rr = (size_t)2 * F * K * sizeof(float);
     // (a block per example: below two blocks per CU the two-reads kernel, ten blocks per example at K = 256, is the faster one)
