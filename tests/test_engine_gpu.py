@@ -330,11 +330,12 @@ def test_afm_attention_out_inside_the_products(K, A, F, B, dev):
     eng.close()
 
 
-@pytest.mark.parametrize("K,F,B", [(64, 13, 37), (64, 12, 520), (128, 9, 513), (256, 39, 37), (256, 6, 600), (72, 7, 530)])
+@pytest.mark.parametrize("K,F,B", [(64, 13, 37), (64, 12, 520), (128, 9, 513), (256, 39, 37), (256, 6, 600), (72, 7, 530), (64, 6, 2100), (128, 20, 2050)])
 def test_afm_wide_embeddings_pair_backward(K, F, B, dev):
     """K >= 64 (the reference runs AFM at K = 256, run.sh:18).  From 512 examples on the pair backward walks the pairs of an example
     in round-robin order (every row of d(pair tensor) read once; odd field counts have a bye), below that the two-reads kernel
-    and the 1024-thread pooling kernels run; K = 72 pads to 128 physical columns."""
+    and the 1024-thread pooling kernels run; K = 72 pads to 128 physical columns; from 2048 examples on the forward pooling is the
+    per-example U E product on the matrix cores (the backward pooling's G = (E diag(dy)) E^T runs at every size)."""
     V = 1500
     ocfg, params, eng = make_pair("afm", B=B, F=F, V=V, K=K, layers=(1,), att=(24,), opt="Adagrad", lr=1e-2)
     oopt = O.Optimizer(ocfg, params)

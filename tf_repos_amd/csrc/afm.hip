@@ -129,6 +129,88 @@ __global__ __launch_bounds__(NT) void afm_pool_fwd_kernel(const float* __restric
     }
 }
 
+typedef float afm_f32x4 __attribute__((ext_vector_type(4)));
+// The pooling as a product on the matrix cores, one WAVE per example: y_emb[k] = sum_{i<j} a'[pair(i,j)] e_i[k] e_j[k]
+// = sum_i e_i[k] Z[i][k] with Z = U E, U the [F, F] upper-triangular matrix of the (dropped-out) attention weights.  The wave
+// builds U in LDS while it normalises the softmax (12 KB per wave at F = 39), then per 64 columns of K: 4 F/16 x F/4 MFMAs of
+// 16x16x4 with A fragments from U and B fragments float4 loads of e (element e of lane c is column 64 tq + 4 c + e: the product's
+// column order is free), the row-wise products with e and the sum over the rows on the accumulators.  576 MFMAs per example at
+// F = 39, K = 256, 40 KB of embeddings read once; the per-pair loop above walks 741 x 64 LDS float4 pairs.
+template <int K, int TF>
+__global__ __launch_bounds__(256) void afm_pool_fwd_mfma_kernel(const float* __restrict__ sc, const float* __restrict__ sc1, const float* __restrict__ sc_bias,
+                                                               int P, int F, float keep_att, float keep_emb, const uint64_t* __restrict__ seed_ptr,
+                                                               int train, float* __restrict__ att, float* __restrict__ yemb,
+                                                               const float4* __restrict__ ee, int e_ld4, const int16_t* __restrict__ pi,
+                                                               const int16_t* __restrict__ pj, int b0, int n) {
+    constexpr int KQ = K / 4, NF = 16 * TF, LDU = NF + 1;
+    extern __shared__ __attribute__((aligned(16))) float pf_sm[];        // per wave: U [NF][LDU]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+    const int bi = blockIdx.x * 4 + wave;
+    if (bi >= n) return;
+    const int b = b0 + bi;
+    float* U = pf_sm + (size_t)wave * NF * LDU;
+    for (int x = lane; x < NF * LDU; x += 64) U[x] = 0.f;
+    const float sbias = sc_bias != nullptr ? sc_bias[0] : 0.f;
+    auto score = [&](int p) { const size_t i = (size_t)b * P + p; return sc1 != nullptr ? (sc[i] + sc1[i]) + sbias : sc[i] + sbias; };
+    float m = -3.0e38f;
+    for (int p = lane; p < P; p += 64) m = fmaxf(m, score(p));
+    m = wmax64(m);
+    float z = 0.f;
+    for (int p = lane; p < P; p += 64) z += expf(score(p) - m);
+    z = wsum64(z);
+    const float inv = 1.0f / z;
+    const uint64_t seed = (train && (keep_att < 1.f || keep_emb < 1.f)) ? *seed_ptr : 0ull;
+    for (int p = lane; p < P; p += 64) {
+        const float a = expf(score(p) - m) * inv;
+        att[(size_t)b * P + p] = a;                                            // softmax output (before dropout): kept for the backward
+        U[pi[p] * LDU + pj[p]] = (train && keep_att < 1.f) ? a * dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_ATT, (uint64_t)b * P + p, keep_att) : a;
+    }
+    const float4* eb = ee + (size_t)b * e_ld4;
+    for (int tq = 0; tq < K / 64; ++tq) {
+        afm_f32x4 acc[TF][4];
+#pragma unroll
+        for (int i = 0; i < TF; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][e] = afm_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int step = 0; step < 4 * TF; ++step) {
+            const int f = 4 * step + q;
+            const float4 bv = f < F ? eb[f * KQ + 16 * tq + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float bs[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int i = 0; i < TF; ++i) {
+                const float av = U[(16 * i + c) * LDU + f];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bs[e], acc[i][e], 0, 0, 0);
+            }
+        }
+        // register r of lane (c, q) in (i, e): Z[row 16 i + 4 q + r][column 64 tq + 4 c + e]
+        float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < TF; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * i + 4 * q + r;
+                if (row < F) {
+                    const float4 ev = eb[row * KQ + 16 * tq + c];
+                    y.x += ev.x * acc[i][0][r]; y.y += ev.y * acc[i][1][r]; y.z += ev.z * acc[i][2][r]; y.w += ev.w * acc[i][3][r];
+                }
+            }
+        y.x += __shfl_xor(y.x, 16); y.y += __shfl_xor(y.y, 16); y.z += __shfl_xor(y.z, 16); y.w += __shfl_xor(y.w, 16);
+        y.x += __shfl_xor(y.x, 32); y.y += __shfl_xor(y.y, 32); y.z += __shfl_xor(y.z, 32); y.w += __shfl_xor(y.w, 32);
+        if (q == 0) {
+            const int k = 64 * tq + 4 * c;
+            if (train && keep_emb < 1.f) {
+                y.x *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + k + 0, keep_emb);
+                y.y *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + k + 1, keep_emb);
+                y.z *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + k + 2, keep_emb);
+                y.w *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + k + 3, keep_emb);
+            }
+            *reinterpret_cast<float4*>(yemb + (size_t)b * K + k) = y;
+        }
+    }
+}
+
 // backward of dropout[1] -> pooling -> dropout[0] -> softmax.  in: dy [B, dy_ld] = d y_emb (post-dropout); out: dsc [B,P], the
 // post-dropout attention a' [B,P] and, in place of dy, the pre-dropout d y_emb.  d pp = a' (x) d y_emb is NOT materialised: the
 // pair backward below forms it from these two.
@@ -221,7 +303,6 @@ __global__ __launch_bounds__(NT) void afm_pool_bwd_kernel(float* __restrict__ dy
 // lane (c, q) loads a float4 of field 16 t + c at k = 16 g + 4 q .. + 3 for each field tile t -- the same registers are the B
 // fragments (E^T) and, scaled by d y_emb, the A fragments of the group's four MFMA steps; only tiles on or above the diagonal
 // are formed.  Softmax / dropout backward on the accumulators, the example-wide sum by wave shuffles.
-typedef float afm_f32x4 __attribute__((ext_vector_type(4)));
 template <int K, int TF>
 __global__ __launch_bounds__(256) void afm_pool_bwd_mfma_kernel(float* __restrict__ dy, int dy_ld, const float* __restrict__ att, int P, int F,
                                                                float keep_att, float keep_emb, const uint64_t* __restrict__ seed_ptr,
@@ -660,6 +741,23 @@ static int afm_chunks(const dctr_engine* E, int B) {
 
 static int afm_pool_fwd(dctr_engine* E, int b0, int n, bool train, hipStream_t st, int score_parts = 0) {
     const int F = E->F, K = E->K, P = E->P;
+    static const bool no_mfma = getenv("DCTR_AFM_POOL_FWD_LOOP") != nullptr;       // A/B knob: the per-pair loop
+    // (one wave per example is a chain of latencies: below two waves per SIMD of them -- B = 128: 0.585 -> 0.68 ms -- the 1024-thread loop)
+    if (!no_mfma && n >= 2048 && F <= 48 && (K == 64 || K == 128 || K == 256) && E->e_ld % 4 == 0) {
+        const float* s0 = score_parts > 0 ? E->sc_parts : E->sc;
+        const float* s1 = score_parts > 1 ? E->sc_parts + (size_t)E->MB * P : nullptr;
+        const float* sb = score_parts > 0 ? E->pp(E->p_ao_b) : nullptr;
+        const int tf = ceil_div(F, 16);
+        const size_t lds = (size_t)4 * (16 * tf) * (16 * tf + 1) * sizeof(float);
+#define DCTR_PFM(K_, T_) afm_pool_fwd_mfma_kernel<K_, T_><<<ceil_div(n, 4), 256, lds, st>>>(s0, s1, sb, P, F, E->keep_att, E->keep_emb, &E->state->seed_t, \
+            train ? 1 : 0, E->att, E->x_in, reinterpret_cast<const float4*>(E->e), E->e_ld / 4, E->pair_i, E->pair_j, b0, n)
+#define DCTR_PFK(K_) if (tf == 1) DCTR_PFM(K_, 1); else if (tf == 2) DCTR_PFM(K_, 2); else DCTR_PFM(K_, 3)
+        if (K == 64) { DCTR_PFK(64); } else if (K == 128) { DCTR_PFK(128); } else { DCTR_PFK(256); }
+#undef DCTR_PFK
+#undef DCTR_PFM
+        DCTR_LAUNCH_CHECK();
+        return DCTR_OK;
+    }
     // the pooling rebuilds the pair products from the example's embeddings when they fit LDS beside its working set
     const size_t lds_pp = (size_t)P * sizeof(float), lds_e = (size_t)(((P + 3) & ~3) + F * K) * sizeof(float);
     const bool from_e = lds_e <= 128 * 1024 && E->e_ld % 4 == 0;
