@@ -236,6 +236,7 @@ def test_gemm_kernel_choice_per_shape():
     assert [plan(o, 4096, 400, 400) for o in "fdw"] == ["dr 2x13", "dr 2x13", "dr 2x13 x9"]            # c2 layers 1, 2
     assert [plan(o, 256, 312, 400) for o in "fd"] == ["dr 1x4", "dr 1x4"]                              # c1 (README.md:49), B = 256
     assert plan("f", 1, 312, 400) == "dr 1x4"                                                          # one serving example
+    assert [plan(o, 8192, 1989, 256) for o in "fdw"] == ["dr 4x8", "lds", "dr 2x16 x4"]                 # c4 inner-PNN layer 0: one round of 64 x 128 tiles forward
     assert [plan(o, 4096 * 741, 256, 256) for o in "fdw"] == ["ws", "ws", "dr 4x8 x32"]                # AFM.py:44,52 attention layer (64 x 128 tiles: 1.5x the flops per operand byte of 32 x 256)
     assert plan("w", 4096 * 741, 16, 256).startswith("lds")                                            # (K = 16: the fused AFM path anyway)
     with pytest.raises(Exception):
