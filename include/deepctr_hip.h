@@ -393,6 +393,23 @@ int dctr_prefetch_cancel(dctr_handle h);
  * steps has been computed inside it. */
 int dctr_tables_sync(dctr_handle h, void* stream);
 int dctr_input_slot_rewrite(dctr_handle h, int slot);
+/* The host -> device leg of the input pipeline (Dataset.prefetch, DeepFM.py:84, at device granularity) inside the library, so that
+ * a Python input thread pays one call per batch and the training thread two trivial ones:
+ *   fill          (input thread)    B rows of ids / vals / labels from HOST buffers (pinned for real overlap) into slot `slot`: three
+ *                                   async copies on the handle's own copy stream and a "filled" event; advances the slot's generation
+ *                                   like dctr_input_slot_rewrite.  h_labels may be NULL.  A whole batch (B = max_batch) whose three
+ *                                   host arrays are laid out like the slot -- ids, vals each padded to a multiple of 64 elements,
+ *                                   then labels -- goes in one copy.
+ *   acquire       (training thread) `stream` waits, on the device, for the slot's last fill
+ *   release       (training thread) records "consumed" behind everything enqueued on `stream` so far
+ *   wait_released (input thread)    blocks the calling host thread until that record has been reached: slot and host buffers are free
+ *   ready                           *ready = 1 when the slot's last fill has landed (never filled: 1)
+ * fill and wait_released are safe to call from another thread than the one that runs the steps. */
+int dctr_input_slot_fill(dctr_handle h, int slot, const int32_t* h_ids, const float* h_vals, const float* h_labels, int B);
+int dctr_input_slot_acquire(dctr_handle h, int slot, void* stream);
+int dctr_input_slot_release(dctr_handle h, int slot, void* stream);
+int dctr_input_slot_wait_released(dctr_handle h, int slot);
+int dctr_input_slot_ready(dctr_handle h, int slot, int* ready);
 /* canned-estimator models: the dense (numeric-column) inputs [B, dense_size] f32 of the NEXT train/predict/eval call; the
  * buffer is read in place and must stay valid until that call's work has finished */
 int dctr_set_dense_input(dctr_handle h, const float* d_dense);

@@ -125,6 +125,11 @@ _SIGS = {
     "dctr_prefetch_cancel": ([_P], C.c_int),
     "dctr_tables_sync": ([_P, _P], C.c_int),
     "dctr_input_slot_rewrite": ([_P, C.c_int], C.c_int),
+    "dctr_input_slot_fill": ([_P, C.c_int, _P, _P, _P, C.c_int], C.c_int),
+    "dctr_input_slot_acquire": ([_P, C.c_int, _P], C.c_int),
+    "dctr_input_slot_release": ([_P, C.c_int, _P], C.c_int),
+    "dctr_input_slot_wait_released": ([_P, C.c_int], C.c_int),
+    "dctr_input_slot_ready": ([_P, C.c_int, C.POINTER(C.c_int)], C.c_int),
     "dctr_crc32c": ([C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint32)], C.c_int),
     "dctr_tfrecord_scan": ([C.c_char_p, C.c_size_t, C.c_int64, C.c_int, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_size_t)], C.c_int),
     "dctr_tfrecord_frame": ([C.c_char_p, C.c_size_t, _P], C.c_int),

@@ -84,6 +84,12 @@ struct dctr_engine {
     int pre_slot = 0;               // ... of input slot `pre_slot` at generation `pre_gen`: a slot rewritten since (dctr_input_slot_rewrite,
     uint32_t pre_gen = 0;           // or a staging copy into it) no longer matches and the hint is dropped
     std::atomic<uint32_t> slot_gen[DCTR_INPUT_SLOTS] = {};
+    // dctr_input_slot_fill / acquire / release: the library's own H2D leg (created on first use)
+    int device = 0;
+    hipStream_t s_copy = nullptr;
+    hipEvent_t slot_filled[DCTR_INPUT_SLOTS] = {}, slot_released[DCTR_INPUT_SLOTS] = {};
+    std::atomic<int> slot_fill_pending[DCTR_INPUT_SLOTS] = {}, slot_release_valid[DCTR_INPUT_SLOTS] = {};
+    std::atomic<int> slot_feed_ready = {0};
     hipEvent_t ev_tail = nullptr;   // = the event of the main stream's last fork when the dense backward was enqueued (ring of 64: one step uses ~12)
     hipEvent_t last_fork_ev = nullptr;
     bool have_tail = false;

@@ -8,6 +8,7 @@
 //   parts     gradient partial slabs (split-K wgrad / column sums); the optimizer kernel sums them
 //   acts      x_in [B, Din_ld] (the scaled embeddings e are its first F*K columns), h_i [B,H_i], dh_i, ...
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -381,10 +382,14 @@ int build(dctr_engine* E) {
     // ---- activations
     // DCTR_INPUT_SLOTS sets of input staging buffers: a caller that fills a slot directly (dctr_input_slot) pays no copy,
     // and each slot has its own captured graph, so batches can be staged while earlier steps run
+    // (one allocation per slot, [ids | vals | labels]: a whole batch arrives in ONE host-to-device copy, dctr_input_slot_fill)
     for (int k = 0; k < DCTR_INPUT_SLOTS; ++k) {
-        DCTR_TRY(dmalloc(&E->slot_ids[k], (size_t)MB * F));
-        DCTR_TRY(dmalloc(&E->slot_vals[k], (size_t)MB * F));
-        DCTR_TRY(dmalloc(&E->slot_labels[k], (size_t)MB));
+        const size_t region = round_up((size_t)MB * F, 64);        // (floats; every array starts 256-byte aligned)
+        float* base = nullptr;
+        DCTR_TRY(dmalloc(&base, 2 * region + MB));
+        E->slot_ids[k] = reinterpret_cast<int32_t*>(base);
+        E->slot_vals[k] = base + region;
+        E->slot_labels[k] = base + 2 * region;
     }
     E->ids = E->slot_ids[0]; E->vals = E->slot_vals[0]; E->labels = E->slot_labels[0];
     DCTR_TRY(dmalloc(&E->x_in, (size_t)(MB + GEMM_SLACK_ROWS) * E->Din_ld));      // (+ slack rows: see gemm.hip `over`)
@@ -1143,6 +1148,7 @@ extern "C" {
 int dctr_create(const dctr_config* cfg, dctr_handle* h) {
     DCTR_REQUIRE(cfg != nullptr && h != nullptr, "null argument");
     dctr_engine* E = new dctr_engine();
+    (void)hipGetDevice(&E->device);          // the device current at creation: the input thread's copies (dctr_input_slot_fill) select it
     E->cfg = *cfg;
     if (E->cfg.shard_world <= 0) { E->cfg.shard_world = 1; E->cfg.shard_rank = 0; }
     // the reference takes any --embedding_size (DeepFM.py:43); the kernels take K/4 a power of two: other sizes run on the next
@@ -1193,7 +1199,9 @@ int dctr_destroy(dctr_handle E) {
     if (E->entry_goff) hipFree(E->entry_goff);
     if (E->pair_ad) hipFree(E->pair_ad);
     { float* f3[] = {E->x_att, E->att_sc, E->att_w}; for (float* p : f3) if (p) hipFree(p); }
-    for (int k = 0; k < DCTR_INPUT_SLOTS; ++k) { if (E->slot_ids[k]) hipFree(E->slot_ids[k]); if (E->slot_vals[k]) hipFree(E->slot_vals[k]); if (E->slot_labels[k]) hipFree(E->slot_labels[k]); }
+    if (E->s_copy) { hipStreamSynchronize(E->s_copy); hipStreamDestroy(E->s_copy); }
+    for (int k = 0; k < DCTR_INPUT_SLOTS; ++k) { if (E->slot_filled[k]) hipEventDestroy(E->slot_filled[k]); if (E->slot_released[k]) hipEventDestroy(E->slot_released[k]); }
+    for (int k = 0; k < DCTR_INPUT_SLOTS; ++k) if (E->slot_ids[k]) hipFree(E->slot_ids[k]);       // (vals and labels live in the same block)
     if (E->status) hipFree(E->status);
     if (E->state) hipFree(E->state);
     if (E->state_alt) hipFree(E->state_alt);
@@ -1355,6 +1363,8 @@ int dctr_prefetch_ids(dctr_handle E, const int32_t* d_ids_next, int B) {
     // or as soon as the grouping stream has drained its own work of the step (DCTR_PREGROUP_WAIT=none: beside the dense backward)
     static const bool wait_tail = [] { const char* v = getenv("DCTR_PREGROUP_WAIT"); return v == nullptr || strcmp(v, "none") != 0; }();
     if (E->have_tail && wait_tail) DCTR_HIP_CHECK(hipStreamWaitEvent(E->s_group, E->ev_tail, 0));
+    // (a slot filled by dctr_input_slot_fill whose copies may still be in flight: the grouping stream waits for them on the device)
+    if (E->slot_fill_pending[slot].load(std::memory_order_acquire)) DCTR_HIP_CHECK(hipStreamWaitEvent(E->s_group, E->slot_filled[slot], 0));
     DCTR_TRY(group_ids(E->group_alt, d_ids_next, B, E->F, E->s_group, !tail_fused(E)));
     E->pre_ids = d_ids_next; E->pre_B = B; E->pre_valid = true;
     E->pre_slot = slot; E->pre_gen = E->slot_gen[slot].load();
@@ -1375,6 +1385,83 @@ int dctr_prefetch_cancel(dctr_handle E) {
 int dctr_input_slot_rewrite(dctr_handle E, int slot) {
     DCTR_REQUIRE(E && slot >= 0 && slot < DCTR_INPUT_SLOTS, "input slot %d outside [0, %d)", slot, DCTR_INPUT_SLOTS);
     E->slot_gen[slot]++;                    // (atomic: the input pipeline's thread calls this while the training thread enqueues steps)
+    return DCTR_OK;
+}
+
+// ---- the H2D leg of the input pipeline (see the header): events and the copy stream are made on first use, under a lock -- the input
+// thread and the training thread may both arrive first
+static int slot_feed_init(dctr_engine* E) {
+    if (E->slot_feed_ready.load(std::memory_order_acquire)) return DCTR_OK;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (E->slot_feed_ready.load(std::memory_order_acquire)) return DCTR_OK;
+    DCTR_HIP_CHECK(hipSetDevice(E->device));
+    DCTR_HIP_CHECK(hipStreamCreateWithFlags(&E->s_copy, hipStreamNonBlocking));
+    // no system-scope fence on either record: "filled" orders a copy before kernels of the same device, "released" tells the host
+    // that kernels have finished READING -- nothing they wrote is for the host to see.  (A plain event's record writes the L2s
+    // back: with the tables' dirty lines in them that was worth 60 us per step through the feeder.)
+    for (int k = 0; k < DCTR_INPUT_SLOTS; ++k) {
+        DCTR_HIP_CHECK(hipEventCreateWithFlags(&E->slot_filled[k], hipEventDisableTiming | hipEventDisableSystemFence));
+        DCTR_HIP_CHECK(hipEventCreateWithFlags(&E->slot_released[k], hipEventDisableTiming | hipEventDisableSystemFence));
+    }
+    E->slot_feed_ready.store(1, std::memory_order_release);
+    return DCTR_OK;
+}
+
+int dctr_input_slot_fill(dctr_handle E, int slot, const int32_t* h_ids, const float* h_vals, const float* h_labels, int B) {
+    DCTR_REQUIRE(E && h_ids && h_vals, "null argument");
+    DCTR_REQUIRE(slot >= 0 && slot < DCTR_INPUT_SLOTS, "input slot %d outside [0, %d)", slot, DCTR_INPUT_SLOTS);
+    DCTR_REQUIRE(B > 0 && B <= E->MB, "batch %d outside (0, max_batch=%d]", B, E->MB);
+    DCTR_REQUIRE(!E->csr, "CSR handles take their batches through dctr_train_step_csr");
+    DCTR_TRY(slot_feed_init(E));
+    DCTR_HIP_CHECK(hipSetDevice(E->device));                       // (the input thread's current device is its own affair)
+    E->slot_gen[slot]++;                                           // a grouping prefetched from the slot's old contents is stale from here on
+    const size_t n = (size_t)B * E->F;
+    // a whole batch laid out like the slot ([ids | vals | labels], the first two padded to a multiple of 64 elements) is ONE copy: every host-to-device copy
+    // brings its own system-scope acquire, and the step running beside it pays for each
+    const size_t region = round_up((size_t)E->MB * E->F, 64);
+    if (B == E->MB && h_labels != nullptr && reinterpret_cast<const char*>(h_vals) == reinterpret_cast<const char*>(h_ids) + region * 4 &&
+        reinterpret_cast<const char*>(h_labels) == reinterpret_cast<const char*>(h_vals) + region * 4) {
+        DCTR_HIP_CHECK(hipMemcpyAsync(E->slot_ids[slot], h_ids, (2 * region + (size_t)B) * 4, hipMemcpyHostToDevice, E->s_copy));
+    } else {
+        DCTR_HIP_CHECK(hipMemcpyAsync(E->slot_ids[slot], h_ids, n * 4, hipMemcpyHostToDevice, E->s_copy));
+        DCTR_HIP_CHECK(hipMemcpyAsync(E->slot_vals[slot], h_vals, n * 4, hipMemcpyHostToDevice, E->s_copy));
+        if (h_labels != nullptr) DCTR_HIP_CHECK(hipMemcpyAsync(E->slot_labels[slot], h_labels, (size_t)B * 4, hipMemcpyHostToDevice, E->s_copy));
+    }
+    DCTR_HIP_CHECK(hipEventRecord(E->slot_filled[slot], E->s_copy));
+    E->slot_fill_pending[slot].store(1, std::memory_order_release);
+    return DCTR_OK;
+}
+
+int dctr_input_slot_acquire(dctr_handle E, int slot, void* stream) {
+    DCTR_REQUIRE(E && slot >= 0 && slot < DCTR_INPUT_SLOTS, "input slot %d outside [0, %d)", slot, DCTR_INPUT_SLOTS);
+    if (E->slot_fill_pending[slot].load(std::memory_order_acquire))
+        DCTR_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), E->slot_filled[slot], 0));
+    return DCTR_OK;
+}
+
+int dctr_input_slot_release(dctr_handle E, int slot, void* stream) {
+    DCTR_REQUIRE(E && slot >= 0 && slot < DCTR_INPUT_SLOTS, "input slot %d outside [0, %d)", slot, DCTR_INPUT_SLOTS);
+    DCTR_TRY(slot_feed_init(E));
+    DCTR_HIP_CHECK(hipEventRecord(E->slot_released[slot], as_stream(stream)));
+    E->slot_release_valid[slot].store(1, std::memory_order_release);
+    return DCTR_OK;
+}
+
+int dctr_input_slot_wait_released(dctr_handle E, int slot) {
+    DCTR_REQUIRE(E && slot >= 0 && slot < DCTR_INPUT_SLOTS, "input slot %d outside [0, %d)", slot, DCTR_INPUT_SLOTS);
+    if (E->slot_release_valid[slot].load(std::memory_order_acquire)) DCTR_HIP_CHECK(hipEventSynchronize(E->slot_released[slot]));
+    return DCTR_OK;
+}
+
+int dctr_input_slot_ready(dctr_handle E, int slot, int* ready) {
+    DCTR_REQUIRE(E && ready && slot >= 0 && slot < DCTR_INPUT_SLOTS, "input slot %d outside [0, %d)", slot, DCTR_INPUT_SLOTS);
+    *ready = 1;
+    if (E->slot_fill_pending[slot].load(std::memory_order_acquire)) {
+        const hipError_t q = hipEventQuery(E->slot_filled[slot]);
+        if (q == hipErrorNotReady) *ready = 0;
+        else DCTR_HIP_CHECK(q);
+    }
     return DCTR_OK;
 }
 

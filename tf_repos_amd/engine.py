@@ -250,6 +250,29 @@ class Engine:
         """Call before refilling input slot `slot`: a grouping prefetched from its old contents is dropped (thread-safe)."""
         capi.check(self._lib.dctr_input_slot_rewrite(self._h, int(slot)))
 
+    # ---- the H2D leg of the input pipeline inside the library (feeder.py; csrc/engine.hip dctr_input_slot_fill ...)
+    def input_slot_fill(self, slot: int, h_ids: int, h_vals: int, h_labels: int, B: int) -> None:
+        """B rows from HOST buffers (raw addresses; pinned for overlap) into input slot `slot` on the engine's copy stream.  Input thread."""
+        capi.check(self._lib.dctr_input_slot_fill(self._h, int(slot), h_ids, h_vals, h_labels, int(B)))
+
+    def input_slot_acquire(self, slot: int, stream=None) -> None:
+        """`stream` (default: torch's current) waits on the device for the slot's last fill."""
+        capi.check(self._lib.dctr_input_slot_acquire(self._h, int(slot), stream if stream is not None else capi.current_stream()))
+
+    def input_slot_release(self, slot: int, stream=None) -> None:
+        """Records "slot consumed" behind what has been enqueued on `stream`."""
+        capi.check(self._lib.dctr_input_slot_release(self._h, int(slot), stream if stream is not None else capi.current_stream()))
+
+    def input_slot_wait_released(self, slot: int) -> None:
+        """Blocks the calling thread until the slot's last release has been reached on the device.  Input thread."""
+        capi.check(self._lib.dctr_input_slot_wait_released(self._h, int(slot)))
+
+    def input_slot_ready(self, slot: int) -> bool:
+        import ctypes
+        r = ctypes.c_int(1)
+        capi.check(self._lib.dctr_input_slot_ready(self._h, int(slot), ctypes.byref(r)))
+        return bool(r.value)
+
     def predict(self, ids, vals, out_prob=None, out_logit=None, stream=None, dense=None):
         self._set_dense(dense)
         B = int(ids.shape[0])

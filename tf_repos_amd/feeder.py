@@ -2,8 +2,8 @@
 the engine's own input slots (dctr_input_slot) on a copy stream, up to DCTR_INPUT_SLOTS - 1 batches ahead of the step that
 consumes them; the training loop then passes the slot tensors to train_step, which reads them in place (no staging copy, no
 allocation per step).  This is the prefetch(500000) of the reference pipeline (DeepFM.py:84) at device granularity: at
-~11 M examples/s a step lasts 0.37 ms, the feeder needs ~0.15 ms of one host thread per batch (one memcpy into pinned memory +
-three async H2D copies, 1.3 MB at B=4096) and ~3.5 GB/s of the link."""
+~15 M examples/s a step lasts 0.26 ms, the feeder needs ~0.05 ms of one host thread per batch (one memcpy into pinned memory +
+one library call that enqueues the three async H2D copies, 1.3 MB at B=4096) and ~5 GB/s of the link."""
 from __future__ import annotations
 
 import queue
@@ -24,13 +24,22 @@ class DeviceFeeder:
         MB, F = engine.cfg.max_batch, engine.cfg.field_size
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self.slot = [engine.input_slot(k) for k in range(self.n_slots)]                 # (ids, vals, labels) device views
-        self.pin = [(torch.empty((MB, F), dtype=torch.int32).pin_memory(), torch.empty((MB, F), dtype=torch.float32).pin_memory(),
-                     torch.empty((MB,), dtype=torch.float32).pin_memory()) for _ in range(self.n_slots)]
-        self.copy_stream = torch.cuda.Stream(device=self.dev)
-        self.copied = [torch.cuda.Event() for _ in range(self.n_slots)]                 # H2D of the slot's batch is complete
-        self.consumed = [None] * self.n_slots                                           # the step that read the slot has finished
+        # pinned staging, one block per slot laid out like the device slot ([ids | vals | labels]): a whole batch is one H2D copy
+        # (ids and vals padded to a multiple of 64 elements, as dctr_create lays the slot out)
+        R = -(-MB * F // 64) * 64
+        self._pin_block = [torch.zeros((2 * R + MB,), dtype=torch.float32).pin_memory() for _ in range(self.n_slots)]
+        self.pin = [(blk[:MB * F].view(torch.int32).view(MB, F), blk[R:R + MB * F].view(MB, F), blk[2 * R:])
+                    for blk in self._pin_block]
+        self.pin_ptr = [(p[0].data_ptr(), p[1].data_ptr(), p[2].data_ptr()) for p in self.pin]
+        self.pin_np = [(p[0].numpy(), p[1].numpy(), p[2].numpy()) for p in self.pin]
+        self.full = [tuple(t[:MB] for t in s) for s in self.slot]                       # views of a whole-batch slot, made once
+        self.MB = MB
+        # The copies, their "filled" event, the consumer's device-side wait and its "consumed" record live in the library
+        # (dctr_input_slot_fill / acquire / release / wait_released): per batch the feeder thread pays one C call instead of three
+        # torch copies under a stream context, the training thread two ~3 us calls instead of a torch Event made per step (40 us)
+        # and a wait_event -- at c2 the training thread was the bottleneck: 290 us of host time per 260 us step.
         # host-side handshake per slot: the feeder may refill slot k only after the consumer has ENQUEUED the step that reads
-        # it (release) -- taking the item off the queue is not enough -- and then waits for that step's event on the device
+        # it (release) -- taking the item off the queue is not enough -- and then waits for that step's record on the device
         self.free = [threading.Semaphore(1) for _ in range(self.n_slots)]
         self._q: "queue.Queue" = queue.Queue(maxsize=self.n_slots - 1)
         self._err = None
@@ -39,9 +48,7 @@ class DeviceFeeder:
         self._thread.start()
 
     def _run(self, it):
-        torch = self._torch
         try:
-            torch.cuda.set_device(self.dev)
             k = 0
             for ids, vals, labels in it:
                 if self._stop:
@@ -50,20 +57,13 @@ class DeviceFeeder:
                 while not self.free[k].acquire(timeout=0.2):
                     if self._stop:
                         return
-                ev = self.consumed[k]
-                if ev is not None:
-                    ev.synchronize()                      # the slot (and its pinned buffer) is free again
-                p_i, p_v, p_l = self.pin[k]
-                np.copyto(p_i.numpy()[:B], ids, casting="same_kind")
-                np.copyto(p_v.numpy()[:B], vals, casting="same_kind")
-                np.copyto(p_l.numpy()[:B], labels, casting="same_kind")
-                s_i, s_v, s_l = self.slot[k]
-                self.eng.input_slot_rewrite(k)            # a grouping prefetched from the slot's old contents is stale from here on
-                with torch.cuda.stream(self.copy_stream):
-                    s_i[:B].copy_(p_i[:B], non_blocking=True)
-                    s_v[:B].copy_(p_v[:B], non_blocking=True)
-                    s_l[:B].copy_(p_l[:B], non_blocking=True)
-                    self.copied[k].record(self.copy_stream)
+                self.eng.input_slot_wait_released(k)      # the slot (and its pinned buffer) is free again
+                p_i, p_v, p_l = self.pin_np[k]
+                np.copyto(p_i[:B], ids, casting="same_kind")
+                np.copyto(p_v[:B], vals, casting="same_kind")
+                np.copyto(p_l[:B], labels, casting="same_kind")
+                # (advances the slot's generation: a grouping prefetched from its old contents is stale from here on)
+                self.eng.input_slot_fill(k, self.pin_ptr[k][0], self.pin_ptr[k][1], self.pin_ptr[k][2], B)
                 self._q.put((k, B))
                 k = (k + 1) % self.n_slots
         except BaseException as e:                        # noqa: BLE001  (surfaced in the consumer)
@@ -72,7 +72,6 @@ class DeviceFeeder:
             self._q.put(None)
 
     def __iter__(self) -> Iterator[Tuple["object", "object", "object", int]]:
-        torch = self._torch
         while True:
             item = self._q.get()
             if item is None:
@@ -80,27 +79,32 @@ class DeviceFeeder:
                     raise self._err
                 return
             k, B = item
-            torch.cuda.current_stream().wait_event(self.copied[k])
-            s_i, s_v, s_l = self.slot[k]
-            yield s_i[:B], s_v[:B], s_l[:B], k
+            self.eng.input_slot_acquire(k)                # the current stream waits for the slot's copies
+            if B == self.MB:
+                s_i, s_v, s_l = self.full[k]
+                yield s_i, s_v, s_l, k
+            else:
+                s_i, s_v, s_l = self.slot[k]
+                yield s_i[:B], s_v[:B], s_l[:B], k
 
-    def peek_next_ids(self):
-        """ids view of the NEXT staged batch if its H2D copy has already completed, else None -- what Engine.prefetch_ids wants
-        right after the step that consumes the current batch has been enqueued (a hint: skipped when the copy is still in flight)."""
-        with self._q.mutex:
+    def peek_next_ids(self, wait: float = 0.0):
+        """ids view of the NEXT staged batch, or None at the end of the stream -- what Engine.prefetch_ids wants right after the step
+        that consumes the current batch has been enqueued.  With the consumer enqueueing faster than the device runs (c2: 0.15 ms
+        of host time per 0.26 ms step) the queue is EMPTY at that moment -- every staged batch has been taken -- so the hint would
+        never be given: `wait` > 0 blocks up to that many seconds for the feeder to stage one (the consumer could not go on without
+        it anyway).  Its H2D copy may still be in flight: dctr_prefetch_ids makes the grouping stream wait for it."""
+        with self._q.not_empty:
+            if not self._q.queue and wait > 0.0:
+                self._q.not_empty.wait(timeout=wait)
             item = self._q.queue[0] if self._q.queue else None
         if item is None:
             return None
         k, B = item
-        if not self.copied[k].query():
-            return None
-        return self.slot[k][0][:B]
+        return self.full[k][0] if B == self.MB else self.slot[k][0][:B]
 
     def release(self, k: int) -> None:
         """call after enqueueing the step that reads slot k (on the current stream)"""
-        ev = self._torch.cuda.Event()
-        ev.record(self._torch.cuda.current_stream())
-        self.consumed[k] = ev
+        self.eng.input_slot_release(k)
         self.free[k].release()
 
     def close(self) -> None:

@@ -357,9 +357,33 @@ class Estimator:
         loss = None
         # fixed-field libsvm pipelines: batches are staged into the engine's input slots by a background feeder
         feeder = None
+        side = None
         if not csr and pipeline.csv is None and not getattr(e.cfg, "dense_size", 0):
             from ..feeder import DeviceFeeder
+            import torch
+            # A/B knob DCTR_EST_SIDE_STREAM=1: the feeder-driven loop on a torch stream of its own.  In tools/feeder_breakdown.py that
+            # saves the step 40 us (the per-step waits / records that tie the steps to the feeder's copies are dearer on the
+            # legacy default stream: 312 vs 272 us); through THIS loop it measured 0.87 ms/step against 0.31 -- unexplained, so off.
+            if os.environ.get("DCTR_EST_SIDE_STREAM", "0") == "1":
+                side = getattr(self, "_side_stream", None)
+                if side is None:
+                    side = self._side_stream = torch.cuda.Stream()
+                torch.cuda.synchronize()              # (what built the engine and loaded its variables is complete)
+                self._side_ctx = torch.cuda.stream(side)
+                self._side_ctx.__enter__()
             feeder = DeviceFeeder(e, pipeline.numpy_batches())
+        try:
+            return self._train_loop(e, csr, feeder, pipeline, steps, max_steps, start_step, log_every)
+        finally:
+            if side is not None:
+                side.synchronize()
+                self._side_ctx.__exit__(None, None, None)
+
+    def _train_loop(self, e, csr, feeder, pipeline, steps, max_steps, start_step, log_every):
+        from . import logging as L
+        t0, n0 = time.time(), 0
+        done = 0
+        loss = None
         for batch in (self._csr_batches(pipeline) if csr else (feeder if feeder is not None else self._device_batches(pipeline))):
             if steps is not None and done >= steps:
                 break
@@ -374,7 +398,7 @@ class Estimator:
                 loss = e.train_step(ids, vals, labels, want_loss=want)
                 feeder.release(slot)
                 if not e.cfg.use_graph:                # (a replayed graph groups the ids inside the step)
-                    nxt = feeder.peek_next_ids()      # the next batch is already in its input slot: group its ids a step ahead
+                    nxt = feeder.peek_next_ids(wait=0.05)      # the next batch, staged (or being staged) in its input slot: group its ids a step ahead
                     if nxt is not None:
                         e.prefetch_ids(nxt)
             else:
