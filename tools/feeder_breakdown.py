@@ -11,10 +11,11 @@ B, F, V = 4096, 39, 1_000_000
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 eng = Engine(EngineConfig(model="deepfm", field_size=F, feature_size=V, embedding_size=16, deep_layers=(400, 400, 400), dropout=(0.5, 0.5, 0.5),
                           l2_reg=1e-4, learning_rate=5e-4, optimizer="Adam", max_batch=B, seed=1))
-src = [synth_batch(B, F, V, seed=10 + i) for i in range(6)]
+NSRC = int(os.environ.get("PROBE_DISTINCT", "6"))
+src = [synth_batch(B, F, V, seed=10 + i) for i in range(NSRC)]
 def gen():
     for s in range(steps):
-        yield src[s % 6]
+        yield src[s % NSRC]
 
 acc = {}
 def timed(name, fn):
