@@ -365,9 +365,7 @@ class Estimator:
             # saves the step 40 us (the per-step waits / records that tie the steps to the feeder's copies are dearer on the
             # legacy default stream: 312 vs 272 us); through THIS loop it measured 0.87 ms/step against 0.31 -- unexplained, so off.
             if os.environ.get("DCTR_EST_SIDE_STREAM", "0") == "1":
-                side = getattr(self, "_side_stream", None)
-                if side is None:
-                    side = self._side_stream = torch.cuda.Stream()
+                side = self._side_stream = torch.cuda.Stream()        # (a fresh one per call: made AFTER the engine's own streams)
                 torch.cuda.synchronize()              # (what built the engine and loaded its variables is complete)
                 self._side_ctx = torch.cuda.stream(side)
                 self._side_ctx.__enter__()
