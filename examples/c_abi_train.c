@@ -74,7 +74,22 @@ int main(int argc, char** argv) {
 
     for (int s = 0; s < steps; ++s) {
         float loss = 0.f;
-        CHECK(dctr_train_step(h, (const int32_t*)d_ids, (const float*)d_vals, (const float*)d_labels, B, &loss, NULL));
+        if (s & 1) {
+            /* the same batch from HOST memory through an input slot: the library copies (async when the buffers are pinned), the
+             * step waits for the copy on the device and reads the slot in place -- what an input thread does per batch */
+            const int k = s % DCTR_INPUT_SLOTS;
+            int ready = 0;
+            int32_t* s_ids; float *s_vals, *s_labels;
+            CHECK(dctr_input_slot_wait_released(h, k));                 /* (nothing has used slot k yet: returns at once) */
+            CHECK(dctr_input_slot_fill(h, k, ids, vals, labels, B));
+            CHECK(dctr_input_slot_ready(h, k, &ready));                 /* 0 while the copies are in flight */
+            CHECK(dctr_input_slot_acquire(h, k, NULL));
+            CHECK(dctr_input_slot(h, k, &s_ids, &s_vals, &s_labels));
+            CHECK(dctr_train_step(h, s_ids, s_vals, s_labels, B, &loss, NULL));
+            CHECK(dctr_input_slot_release(h, k, NULL));
+        } else {
+            CHECK(dctr_train_step(h, (const int32_t*)d_ids, (const float*)d_vals, (const float*)d_labels, B, &loss, NULL));
+        }
         printf("step %d loss %.7f\n", s, loss);
     }
     CHECK(dctr_check_ids(h, NULL));
