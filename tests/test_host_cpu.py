@@ -279,3 +279,36 @@ def test_dropout_mask_is_the_documented_function():
     assert abs(np.corrcoef(a[:-1], a[1:])[0, 1]) < 0.05                        # neighbours independent
     with pytest.raises(Exception):
         mask(0, 1, 0, 4, 0.0)
+
+
+def test_round_robin_pair_schedule_covers_every_pair_once():
+    """afm_pair_bwd_rr_kernel (csrc/afm.hip rr_pair) walks the F (F - 1) / 2 pairs of an example in round-robin-tournament order so
+    that no field is touched twice inside a round (plain LDS read-modify-write, no atomics).  The same arithmetic here: every pair
+    exactly once, rounds field-disjoint, for every field count the kernel can meet."""
+    def rr_pair(n, F, r, m, half):
+        a, c = n - 1, r
+        if m > 0:
+            a = r + m
+            if a >= n - 1:
+                a -= n - 1
+            c = r - m
+            if c < 0:
+                c += n - 1
+        lo, hi = (a, c) if a < c else (c, a)
+        return (m < half and hi < F), lo, hi
+
+    for F in range(2, 70):
+        n = (F + 1) & ~1
+        half = n // 2
+        seen = set()
+        for r in range(n - 1):
+            fields = set()
+            for m in range(half):
+                ok, lo, hi = rr_pair(n, F, r, m, half)
+                if not ok:
+                    continue
+                assert lo < hi < F and (lo, hi) not in seen
+                assert lo not in fields and hi not in fields           # the round's pairs share no field
+                seen.add((lo, hi))
+                fields.update((lo, hi))
+        assert len(seen) == F * (F - 1) // 2
