@@ -49,12 +49,15 @@ def _run(self, it):
     _orig_run(self, src())
     acc["feeder: thread total"] = time.perf_counter() - t
 F_.DeviceFeeder._run = _run
-pr = cProfile.Profile(); t0 = time.perf_counter(); pr.enable()
+pr = cProfile.Profile(); t0 = time.perf_counter()
+if not os.environ.get("NO_CPROFILE"): pr.enable()
 est.train(input_fn=lambda: mod.input_fn([path], num_epochs=epochs, batch_size=B))
-torch.cuda.synchronize(); pr.disable(); dt = time.perf_counter() - t0
+torch.cuda.synchronize()
+if not os.environ.get("NO_CPROFILE"): pr.disable()
+dt = time.perf_counter() - t0
 print("total %.2f s for %d steps" % (dt, lines * epochs // B))
 for k, v in sorted(acc.items()): print("  %-28s %.3f s" % (k, v))
-pstats.Stats(pr).sort_stats("cumulative").print_stats(8)
+if not os.environ.get("NO_CPROFILE"): pstats.Stats(pr).sort_stats("cumulative").print_stats(8)
 # the same engine driven directly (no feeder, no estimator loop)
 e = est._engine
 print("engine cfg:", {k: getattr(e.cfg, k) for k in ("model", "max_batch", "table_mode", "use_graph", "table_sweep_period", "dropout", "deep_layers", "optimizer", "l2_reg") if hasattr(e.cfg, k)})
