@@ -261,6 +261,20 @@ int dctr_embed_scatter_bwd(dctr_group_t g, const float* d_dE, int de_ld,
                            int B, int F, int K, int mode,
                            float* d_gemb, float* d_glin, void* stream);
 
+/* ---- K8b + K9 in ONE launch (the step's tail): the segment sum of every distinct id goes straight into that row's optimizer
+ * step -- UnsortedSegmentSum (the gradient of DeepFM.py:126,130's gathers) followed by the sparse half of
+ * optimizer.minimize (DeepFM.py:204-213) -- without the compact-gradient round trip of dctr_embed_scatter_bwd + dctr_opt_table.
+ * Visits ONLY the batch's distinct rows (grad = segment sum + l2*theta; the dense-exact step of the untouched rows is
+ * dctr_opt_table's / the engine's background sweep).  `hyper` as for dctr_opt_table; d_sumsq as there (pre-update sums over
+ * the visited rows) or NULL.  Call dctr_group_ids(g, ids, B, F) first; leaves g's slot words and compact rows zeroed.
+ * Segments of >= 256 entries (Criteo's 13 numeric ids: every example) are reduced by several blocks whose partial sums meet
+ * through returned float atomics and a completion ticket -- tests/test_scatter_stress_gpu.py hammers exactly that path. */
+int dctr_embed_scatter_apply(dctr_group_t g, int kind, const float* hyper,
+                             float* d_emb, float* d_emb_s0, float* d_emb_s1,
+                             float* d_lin, float* d_lin_s0, float* d_lin_s1, float l2, float* d_sumsq,
+                             const float* d_dE, int de_ld, const float* d_e, int e_ld, const float* d_sum, const float* d_coef,
+                             const float* d_dy, const float* d_vals, int B, int F, int K, int mode, void* stream);
+
 /* ---- K2/K8 over CSR batches: tf.nn.embedding_lookup_sparse(params, sp_ids, sp_weights, combiner="sum") of the DIN / ESMM
  * scripts (DIN.py:148,180-183; DeepCvrMTL.py:155-159).  d_offsets [B+1] row pointers into d_ids / d_weights [nnz]
  * (d_weights NULL = all ones, DIN.py:148).

@@ -82,6 +82,8 @@ _SIGS = {
     "dctr_group_buffers": ([_P] + [C.POINTER(_P)] * 8, C.c_int),
     "dctr_embed_scatter_bwd": ([_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P,
                                 C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P], C.c_int),
+    "dctr_embed_scatter_apply": ([_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, _P], C.c_int),
     "dctr_embed_lookup_sparse_fwd": ([_P, C.c_int64, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int, _P, _P], C.c_int),
     "dctr_embed_lookup_sparse_bwd": ([_P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P], C.c_int),
     "dctr_opt_dense": ([C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int64, C.c_int64, C.c_float, _P], C.c_int),

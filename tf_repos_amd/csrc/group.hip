@@ -917,4 +917,32 @@ int dctr_embed_scatter_bwd(dctr_group_t g, const float* d_dE, int de_ld, const f
                              mode, d_gemb, d_glin, as_stream(stream));
 }
 
+// the step's tail as an op: segment sums of the row gradients straight into the optimizer step of the batch's distinct rows
+// (scatter_apply_kernel).  `hyper` as for dctr_opt_table.  The group must have been filled by dctr_group_ids for these ids.
+int dctr_embed_scatter_apply(dctr_group_t g, int kind, const float* hyper, float* d_emb, float* d_emb_s0, float* d_emb_s1, float* d_lin,
+                             float* d_lin_s0, float* d_lin_s1, float l2, float* d_sumsq, const float* d_dE, int de_ld, const float* d_e,
+                             int e_ld, const float* d_sum, const float* d_coef, const float* d_dy, const float* d_vals, int B, int F, int K,
+                             int mode, void* stream) {
+    DCTR_REQUIRE(g != nullptr && hyper != nullptr && d_emb != nullptr && d_emb_s0 != nullptr, "group, hyper, table and its first slot required");
+    Group* G = reinterpret_cast<Group*>(g);
+    Hyper h{};
+    h.lr = hyper[0];
+    h.beta1 = 0.9f; h.beta2 = 0.999f; h.eps = 1e-8f; h.momentum = 0.95f; h.lr_t = h.lr;
+    if (kind == DCTR_OPT_ADAM) {
+        h.beta1 = hyper[1]; h.beta2 = hyper[2]; h.eps = hyper[3];
+        const double t = (double)hyper[4];
+        h.lr_t = (float)((double)h.lr * sqrt(1.0 - pow((double)h.beta2, t)) / (1.0 - pow((double)h.beta1, t)));
+    } else if (kind == DCTR_OPT_MOMENTUM) {
+        h.momentum = hyper[1];
+    }
+    hipStream_t st = as_stream(stream);
+    if (!G->gemb_clean) {           // a plain dctr_embed_scatter_bwd has used the compact rows since: the fused launch needs them zero
+        DCTR_HIP_CHECK(hipMemsetAsync(G->gemb, 0, (size_t)G->max_entries * G->K * 4, st));
+        G->gemb_clean = true;
+    }
+    return embed_scatter_apply(G, kind, nullptr, h, d_emb, d_emb_s0, d_emb_s1, d_lin, d_lin_s0, d_lin_s1, l2, d_sumsq,
+                               d_sumsq ? d_sumsq + SUMSQ_SHARDS : nullptr, d_dE, de_ld, d_e, e_ld, d_sum, d_coef, d_dy, d_vals, B, F, K, mode, st);
+}
+
+
 }  // extern "C"
