@@ -485,7 +485,11 @@ int dctr_table_gather_packed(dctr_handle h, const int32_t* d_rows, int n, float*
  * `which` (0 or 1: two states, so the rows of step t+1 can be grouped while step t still uses its own) */
 int dctr_table_group_rows(dctr_handle h, int which, const int32_t* d_rows, int n, void* stream);
 /* owner side: segment-sum the n received packed row gradients d_grads [n, K+4] (same order as the rows given to
- * dctr_table_group_rows(which)) and step the shard's tables with the configured optimizer / table_mode */
+ * dctr_table_group_rows(which)) and step the shard's tables with the configured optimizer / table_mode.
+ * Called directly, these three entry points always run the CLASSIC dense-exact sweep (every row of the shard every step,
+ * sum theta^2 of the tables accumulated into dctr_read_scalars' [1], [2]) whatever table_sweep_period says: the time-blocked
+ * sweep needs to know per step whether the loss is read, which only a step driver knows -- dctr_dist_train_step opts its handle
+ * in and passes that along (h_loss == NULL: rows lag; else flush + classic sweep with the sums). */
 int dctr_table_apply_packed(dctr_handle h, int which, int n, const float* d_grads, void* stream);
 /* requester side: forward (+ backward through head, MLP, interaction when train != 0) on the packed rows received from
  * the owners: d_rows [n_rows, K+4] is the table the gather reads, d_idx [B,F] its ids (dctr_entry_index).  train != 0

@@ -8,7 +8,21 @@ steady state the headline number is measured in.
 
 The oracle (oracle/deepctr_oracle.py: DeepFM.py:100-221 / DCN.py:105-230 restated, dense Adam over all rows) takes the engine's own
 dropout masks (dctr_dropout_mask, a pure function of seed / step / site / element).  Compared at the end: EVERY variable and both
-Adam slots of both tables, <= 5e-6 absolute."""
+Adam slots of both tables.
+
+Tolerance.  One step agrees to 2e-6 (tests/test_fullsize_gpu.py).  Over many steps two fp32 trajectories of THIS graph do not stay
+that close, whoever computes them: a hidden unit whose pre-activation lands within rounding of zero (|z| ~ 1e-10: the fp64 oracle
+finds one such (example, unit) every few steps among the 4096 x 400 x 3 per step -- tools/bench_path_diag.py lists them) has its
+ReLU mask decided by the last bit; when the two sides decide differently, that example's whole term enters or leaves the unit's
+weight-gradient column, Adam's m / sqrt(v) turns the ~2 % change into ~2 % of lr = 1e-5 on that column, its bias and the 39 embedding
+rows of the example -- and the 1e-5 shift makes the next coin flip likelier.  Measured (diag tool, c2, 17 steps): 108 of 249 600
+elements of mlp0/weights beyond 5e-6, all in two columns, max 2e-5, identical to three digits for the classic sweep, the lagging
+sweep, with and without the hint.  So the comparison is against the fp64 trajectory of the oracle with two bounds:
+  * max |difference| <= 5e-5 = lr / 10 for EVERY element.  What this must catch moves an element by ~lr = 5e-4: Adam under a constant
+    gradient (an untouched row: l2 theta) steps lr per step, so a missed, doubled or mis-stamped step of a lagging row, a row grouped
+    under the wrong batch, a stale input slot are all ten times above the bound;
+  * the elements beyond 5e-6 are few (a flipped unit is a column, a systematic error is everywhere): <= 2 % of a dense variable,
+    <= 0.02 % of a table (39 rows per event)."""
 import numpy as np
 import pytest
 import torch
@@ -43,6 +57,7 @@ def test_bench_path_matches_oracle(name, dev):
         kw["cross_layers"] = cross
     ocfg = O.Config(**kw)
     params = O.init_params(ocfg, seed=20260925, scale=0.01)
+    p64 = {k: v.double() for k, v in params.items()}
     eng = Engine(EngineConfig(max_batch=B, seed=1, table_sweep_period=0, use_graph=False, **kw))     # 0 = the library default, as bench.py passes it
     eng.set_params(params)
     nb = capi.INPUT_SLOTS
@@ -53,22 +68,31 @@ def test_bench_path_matches_oracle(name, dev):
         si, sv, sl = eng.input_slot(i)
         si[:B].copy_(torch.from_numpy(ids)); sv[:B].copy_(torch.from_numpy(vals)); sl[:B].copy_(torch.from_numpy(labels))
         slots.append((si[:B], sv[:B], sl[:B]))
-    oopt = O.Optimizer(ocfg, params)
+    oopt64 = O.Optimizer(ocfg, p64)
     for s in range(steps):
         eng.train_step(*slots[s % nb], want_loss=False)
         eng.prefetch_ids(slots[(s + 1) % nb][0])
-        O.train_step(ocfg, params, oopt, *host[s % nb], masks=_masks(eng, layers, keep, B, s + 1))      # (under the GPU's step)
+        masks = _masks(eng, layers, keep, B, s + 1)
+        O.train_step(ocfg, p64, oopt64, *host[s % nb], masks={k: v.double() for k, v in masks.items()})     # (under the GPU's step)
     assert eng.global_step == steps
-    got = eng.get_params()                              # (reads flush the lagging rows)
-    worst = {}
-    for k, v in params.items():
-        worst[k] = float(np.abs(got[k] - v.numpy()).max())
+    got = dict(eng.get_params())                        # (reads flush the lagging rows)
+    o64 = {k: v.numpy() for k, v in p64.items()}
     for tname in ("emb", "linear"):
         if tname in eng.param_shapes:
-            worst[tname + "/m"] = float(np.abs(eng.get_slot(tname, 0) - oopt.slots[tname]["m"].numpy()).max())
-            worst[tname + "/v"] = float(np.abs(eng.get_slot(tname, 1) - oopt.slots[tname]["v"].numpy()).max())
+            for which, sl in enumerate(("m", "v")):
+                got[tname + "/" + sl] = eng.get_slot(tname, which)
+                o64[tname + "/" + sl] = oopt64.slots[tname][sl].numpy()
     eng.check_ids()
     eng.close()
-    print(name, {k: "%.2e" % v for k, v in worst.items()})
-    bad = {k: v for k, v in worst.items() if v > 5e-6}
+    bad = {}
+    for k, truth in o64.items():
+        err = np.abs(got[k].astype(np.float64) - truth)
+        # (Adam's slots are gradient-sized, ~1e-6: their bounds are relative to the largest element -- the sharp check is theta)
+        unit = float(np.abs(truth).max()) / 5e-4 if k.endswith(("/m", "/v")) else 1.0
+        n_off = int((err > 5e-6 * unit).sum())
+        is_table = k.split("/")[0] in ("emb", "linear") and truth.shape[0] == V
+        allowed = max(16, int((2e-4 if is_table else 2e-2) * err.size))
+        print("%-10s %-16s vs the fp64 oracle: max %.2e, elements > %.1e: %d of %d (allowed %d)" % (name, k, err.max(), 5e-6 * unit, n_off, err.size, allowed))
+        if float(err.max()) > 5e-5 * unit or n_off > allowed:
+            bad[k] = (float(err.max()), n_off, allowed)
     assert not bad, bad

@@ -55,11 +55,16 @@ def test_slot_names_follow_tf(tmp_path):
     st = T.bundle_to_state(t, "Adam")
     assert "fm_v/slot0" in st and "fm_v/slot1" in st and "fm_v/Adam" not in st and "fm_w" in st
     back = T.state_to_bundle(st, "Adam")
-    # AdamOptimizer's non-slot variables travel too (a TF training graph's Saver asks for them): beta^global_step
+    # AdamOptimizer's non-slot variables travel too (a TF training graph's Saver asks for them): beta^(global_step + 1): TF starts them at beta and multiplies after each apply
     assert set(back) == set(t) | {"beta1_power", "beta2_power"} and np.array_equal(back["fm_v/Adam_1"], t["fm_v/Adam_1"])
     gs = int(np.asarray(t["global_step"]))
-    assert abs(float(back["beta1_power"]) - 0.9 ** gs) < 1e-6 and abs(float(back["beta2_power"]) - 0.999 ** gs) < 1e-6
+    assert abs(float(back["beta1_power"]) - 0.9 ** (gs + 1)) < 1e-6 and abs(float(back["beta2_power"]) - 0.999 ** (gs + 1)) < 1e-6
     assert "beta1_power" not in T.bundle_to_state(back, "Adam")
+    # a checkpoint of an untrained model: TF's initial values (beta, not 1 -- lr_t = lr sqrt(1 - beta2_power) / (1 - beta1_power) must be finite)
+    fresh = T.state_to_bundle({"w": np.ones(3, np.float32), "global_step": np.int64(0)}, "Adam")
+    assert float(fresh["beta1_power"]) == np.float32(0.9) and float(fresh["beta2_power"]) == np.float32(0.999)
+    custom = T.state_to_bundle({"w": np.ones(3, np.float32), "global_step": np.int64(2)}, "Adam", beta1=0.8, beta2=0.99)
+    assert abs(float(custom["beta1_power"]) - 0.8 ** 3) < 1e-7 and abs(float(custom["beta2_power"]) - 0.99 ** 3) < 1e-7
     ftrl = T.state_to_bundle({"w": np.ones(3, np.float32), "w/slot0": np.ones(3, np.float32), "w/slot1": np.zeros(3, np.float32)}, "ftrl")
     assert set(ftrl) == {"w", "w/Ftrl", "w/Ftrl_1"}
     assert set(T.state_to_bundle({"w": np.ones(3, np.float32), "w/slot0": np.ones(3, np.float32), "w/slot1": np.zeros(3, np.float32)}, "Adagrad")) == {"w", "w/Adagrad"}

@@ -34,12 +34,12 @@ def _headers_mtime():
     return m
 
 
-def _compile(src: str, hdr_m: float, force: bool, verbose: bool) -> str:
-    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+def _compile(src: str, hdr_m: float, force: bool, verbose: bool, objdir: str = OBJDIR, extra=()) -> str:
+    obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), hdr_m)):
         return obj
-    cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", path, "-o", obj]
+    cmd = [HIPCC] + FLAGS + list(extra) + ["-x", "hip", "-c", path, "-o", obj]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -50,21 +50,32 @@ def _compile(src: str, hdr_m: float, force: bool, verbose: bool) -> str:
     return obj
 
 
-def build_library(force: bool = False, verbose: bool = True) -> str:
-    os.makedirs(OBJDIR, exist_ok=True)
+def build_library(force: bool = False, verbose: bool = True, variant: str = "", extra_flags=()) -> str:
+    """variant: an experimental build beside the product library (A/B runs on the GPU box): objects in _lib/obj_<variant>, library
+    _lib/libdeepctr_hip_<variant>.so, compiled with extra_flags (e.g. -DNAME); selected at run time with DCTR_LIB_VARIANT=<variant>."""
+    objdir = OBJDIR + ("_" + variant if variant else "")
+    lib = LIB if not variant else os.path.join(LIBDIR, "libdeepctr_hip_%s.so" % variant)
+    os.makedirs(objdir, exist_ok=True)
     srcs = _sources()
     hdr_m = _headers_mtime()
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, hdr_m, force, verbose), srcs))
-    if (force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"]
+        objs = list(ex.map(lambda s: _compile(s, hdr_m, force, verbose, objdir, extra_flags), srcs))
+    if (force or not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs)):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-lpthread"]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stdout)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv))
+    # python -m tf_repos_amd.build [--force] [--variant NAME -DFLAG ...]
+    args = [a for a in sys.argv[1:] if a != "--force"]
+    variant = ""
+    if "--variant" in args:
+        i = args.index("--variant")
+        variant = args[i + 1]
+        del args[i:i + 2]
+    print(build_library(force="--force" in sys.argv, variant=variant, extra_flags=tuple(args)))

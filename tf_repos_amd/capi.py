@@ -14,7 +14,8 @@ from typing import Optional
 from . import errors
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libdeepctr_hip.so")
+# (DCTR_LIB_VARIANT=<name>: an experimental build made by `python -m tf_repos_amd.build --variant <name> ...`, for A/B runs)
+LIB_PATH = os.path.join(_HERE, "_lib", "libdeepctr_hip%s.so" % ("_" + os.environ["DCTR_LIB_VARIANT"] if os.environ.get("DCTR_LIB_VARIANT") else ""))
 
 DCTR_OK = 0
 MODELS = {"deepfm": 0, "fnn": 1, "ipnn": 2, "opnn": 3, "nfm": 4, "afm": 5, "dcn": 6, "wide": 7, "deep": 8, "wide_n_deep": 9, "mvm": 10,

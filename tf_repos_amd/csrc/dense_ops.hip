@@ -630,10 +630,10 @@ __global__ __launch_bounds__(256) void opt_dense_kernel(const Hyper* __restrict_
     }
     float4 a = s0[i4];
     float4 b = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) ? s1[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
-    opt_update(KIND, h, th.x, a.x, b.x, g.x);
-    opt_update(KIND, h, th.y, a.y, b.y, g.y);
-    opt_update(KIND, h, th.z, a.z, b.z, g.z);
-    opt_update(KIND, h, th.w, a.w, b.w, g.w);
+    opt_update<true>(KIND, h, th.x, a.x, b.x, g.x);
+    opt_update<true>(KIND, h, th.y, a.y, b.y, g.y);
+    opt_update<true>(KIND, h, th.z, a.z, b.z, g.z);
+    opt_update<true>(KIND, h, th.w, a.w, b.w, g.w);
     theta[i4] = th;
     s0[i4] = a;
     if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) s1[i4] = b;
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) void opt_flat_kernel(const Hyper* __restrict__
         g += l2 * th;
         float a = s0[i];
         float b = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) ? s1[i] : 0.f;
-        opt_update(KIND, h, th, a, b, g);
+        opt_update<true>(KIND, h, th, a, b, g);
         theta[i] = th;
         s0[i] = a;
         if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) s1[i] = b;
@@ -1045,6 +1045,7 @@ using namespace dctr;
 static Hyper hyper_from_host(int kind, const float* hyper) {
     Hyper h{};
     h.lr = hyper[0];
+    h.ieee = adam_ieee_default();
     h.beta1 = 0.9f; h.beta2 = 0.999f; h.eps = 1e-8f; h.momentum = 0.95f; h.lr_t = h.lr;
     if (kind == DCTR_OPT_ADAM) {
         h.beta1 = hyper[1]; h.beta2 = hyper[2]; h.eps = hyper[3];

@@ -395,6 +395,7 @@ int dctr_dist_create(dctr_handle E, int rank, int world, const dctr_transport* t
                  E->cfg.shard_rank, E->cfg.shard_world, rank, world);
     dctr_dist* D = new dctr_dist();
     D->E = E; D->world = world; D->rank = rank; D->t = *t;
+    E->owner_lag_opt_in = true;       // (this driver sets E->want_loss on every step: the owner side may run the time-blocked sweep, lag.h)
     // batch_norm: the column sums of every BN layer go through the transport's all-reduce on the main stream's channel
     E->bn_sync.all_reduce = D->t.all_reduce_f32; E->bn_sync.ctx = D->t.ctx; E->bn_sync.world = world;
     int rc = dist_alloc(D);

@@ -75,6 +75,8 @@ struct dctr_engine {
     bool lag_suspended = false;     // dctr_time_kernel's single-stage replays do not advance global_step: they run the classic kernels
     bool lag_dirty = false;         // some rows may be behind the present: lag_flush before anything reads the tables as a whole
     bool want_loss = false;         // the step being enqueued reports its loss (needs sum theta^2 of every row)
+    bool owner_lag_opt_in = false;  // the owner-side split API (dctr_table_*_packed) may let this shard's rows lag: set by the native step
+                                    // driver (dist.hip), which tells every step whether its loss is read; direct callers get the classic sweep
     Group* group = nullptr;
     Group* group_alt = nullptr;     // second grouping state: owner side of the row-sharded path / the NEXT batch's ids grouped ahead
     // dctr_prefetch_ids: group_alt holds the grouping of `pre_ids` (an input slot), enqueued on s_group behind ev_tail

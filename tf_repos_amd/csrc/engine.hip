@@ -322,6 +322,7 @@ int build(dctr_engine* E) {
     s.hyper.lr = c.learning_rate; s.hyper.beta1 = 0.9f; s.hyper.beta2 = 0.999f; s.hyper.eps = 1e-8f;   // DeepFM.py:205
     s.hyper.momentum = 0.95f;                                                                          // DeepFM.py:209
     s.hyper.lr_t = c.learning_rate;
+    s.hyper.ieee = adam_ieee_default();
     s.hyper_lin = s.hyper;
     if (E->wnd) { s.hyper_lin.lr = c.lin_learning_rate; s.hyper_lin.lr_t = c.lin_learning_rate; }
     E->h_state = s;
@@ -799,7 +800,7 @@ bool lag_on(const dctr_engine* E) { return E->lag_period > 1 && !E->lag_suspende
 // shard's rows lag and are replayed exactly like the unsharded table's
 bool owner_lag(const dctr_engine* E) {
     static const bool off = [] { const char* v = getenv("DCTR_OWNER_LAG"); return v != nullptr && v[0] == '0'; }();     // A/B knob
-    return !off && E->lag_period > 1 && !E->lag_suspended && split_table_on(E);
+    return !off && E->owner_lag_opt_in && E->lag_period > 1 && !E->lag_suspended && split_table_on(E);
 }
 LagView lag_view(const dctr_engine* E) {
     return LagView{E->row_ts, E->state, reinterpret_cast<float4*>(E->emb_s0), reinterpret_cast<float4*>(E->emb_s1), E->lin_s0, E->lin_s1, E->cfg.l2_reg};

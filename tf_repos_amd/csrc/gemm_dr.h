@@ -151,8 +151,17 @@ __device__ __forceinline__ void dr_reduce_tiles(f32x4 (&acc)[TM][TN], float* lds
 // (the 2 x 8 weight-gradient variant is compiled for TWO blocks per CU: it is the tile of choice when the reduction runs over
 //  millions of rows that stream from HBM -- AFM's attention weight over 3 M pair rows -- where one resident block per CU, one
 //  16-row group of prefetch ahead of its MFMAs, spends more time waiting for memory than multiplying)
+// Waves per SIMD the register allocation is held to (launch bounds).  DR_WAVES2 (a build-time experiment): every tile
+// of up to 28 accumulator tiles is compiled for TWO blocks per CU (<= 256 registers per lane, <= 80 KB of LDS), so that two
+// products that run side by side in the step -- a layer's dgrad and the weight gradient of the layer above -- share each CU's
+// matrix pipes instead of taking turns at whole CUs: one block's prologue, cross-wave reduction and stores run under the other's MFMAs.
+#ifdef DR_WAVES2
+#define DR_MIN_WAVES(TM, TN, CS, AGEN) ((((TM) * (TN) <= 28 && (AGEN) == DR_AGEN_NONE) || ((CS) && (TM) * (TN) <= 16)) ? 2 : 1)
+#else
+#define DR_MIN_WAVES(TM, TN, CS, AGEN) (((CS) && (TM) * (TN) <= 16) ? 2 : 1)
+#endif
 template <int TM, int TN, bool A_RC, bool B_RC, bool CS, int EPI, int AGEN = DR_AGEN_NONE>
-__global__ __launch_bounds__(256, (CS && TM * TN <= 16) ? 2 : 1) void gemm_dr_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+__global__ __launch_bounds__(256, DR_MIN_WAVES(TM, TN, CS, AGEN)) void gemm_dr_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                          float* __restrict__ C, int ldc, int M, int N, int K, int kchunk, int nbn,
                                                          DrEpilogue ep, DrOuter og) {
     static_assert(AGEN == DR_AGEN_NONE || (AGEN == DR_AGEN_OUTER_FWD && A_RC) || (AGEN == DR_AGEN_OUTER_WGRAD && !A_RC) ||
@@ -416,6 +425,31 @@ __global__ __launch_bounds__(256, (CS && TM * TN <= 16) ? 2 : 1) void gemm_dr_ke
         if (Gf & 1) load_all(f1, 0);
         load_all(f0, min(g, Gf - 1));
     }
+    // ---- dropout keep bits of the elements this thread will store (forward epilogue), computed HERE, while the first operand
+    // loads are in flight: the mask is a 64-bit hash per element (common.h dropout_scale: three 64-bit multiplies, quarter-rate
+    // integer ops) -- 26 elements per thread in a 2 x 13 tile -- and in the epilogue it was most of the store phase (cycle stamps:
+    // ~2.6 k of the 3.2 k cycles between the reduction and the end of the kernel); here it costs nothing, the wave is waiting
+    // for memory anyway.  Same function, same element index, same bits.
+    constexpr int C4_ = 4 * TN, RPI_ = 256 / C4_, NIT_ = (16 * TM + RPI_ - 1) / RPI_;
+    static_assert(NIT_ * 4 <= 64, "keep bits of a thread's output elements fit two words");
+    uint32_t keep_lo = 0xffffffffu, keep_hi = 0xffffffffu;
+    if constexpr (EPI == DR_BIAS_ACT) {
+        if (ep.keep < 1.0f) {
+            const uint64_t sd = ep.seed ^ (ep.seed_ptr ? *ep.seed_ptr : 0ull);
+            const int tr_ = t / C4_, tc_ = t - tr_ * C4_;
+            keep_lo = keep_hi = 0u;
+#pragma unroll
+            for (int it = 0; it < NIT_; ++it) {
+                const uint64_t base = (uint64_t)(m0 + tr_ + RPI_ * it) * (uint64_t)N + (uint64_t)(n0 + 4 * tc_);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t bit = dr_dropout_scale(sd, base + e, ep.keep) != 0.f ? 1u : 0u;
+                    if (it * 4 + e < 32) keep_lo |= bit << ((it * 4 + e) & 31);
+                    else keep_hi |= bit << ((it * 4 + e) & 31);
+                }
+            }
+        }
+    }
     DR_STAMP(1);
     __builtin_amdgcn_sched_barrier(0);
     if (Gf > 0) {
@@ -548,7 +582,7 @@ __global__ __launch_bounds__(256, (CS && TM * TN <= 16) ? 2 : 1) void gemm_dr_ke
                     if (EPI == DR_BIAS_ACT) {
                         v[e] += bias4[e];
                         if (ep.relu) v[e] = fmaxf(v[e], 0.f);
-                        if (ep.keep < 1.0f) v[e] *= dr_dropout_scale(seed, (uint64_t)gm * (uint64_t)N + gn + e, ep.keep);
+                        if (ep.keep < 1.0f) v[e] *= (((it * 4 + e < 32 ? keep_lo : keep_hi) >> ((it * 4 + e) & 31)) & 1u) ? 1.0f / ep.keep : 0.0f;
                     } else if (EPI == DR_MASK) {
                         v[e] = (a[e] > 0.f) ? v[e] * ep.inv_keep : 0.f;
                     } else if (GATE) {

@@ -97,10 +97,19 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 inline bool fits31(int64_t rows, int64_t ld) { return rows * ld * 4 < (int64_t)0x7fff0000; }
 inline int64_t wave_rows(int64_t R, int S) { return (round_up(ceil_div(R, S), 16) + 15) / 16 * 4 + 16; }
 
+// A/B knob DCTR_DR_TILE="<op><index>[,<op><index>...]" (op in f, d, w): that product takes tile `index` of its list whatever the model says
+int forced_tile(char op) {
+    static const std::string spec = [] { const char* e = getenv("DCTR_DR_TILE"); return std::string(e ? e : ""); }();
+    for (size_t i = 0; i + 1 < spec.size(); ++i)
+        if (spec[i] == op && spec[i + 1] >= '0' && spec[i + 1] <= '9') return spec[i + 1] - '0';
+    return -1;
+}
 template <size_t NT>
-int pick(const Tile (&list)[NT], int Mo, int No, int64_t R, int S, double* eff) {
+int pick(const Tile (&list)[NT], int Mo, int No, int64_t R, int S, double* eff, char op = 0) {
     int best = -1;
     *eff = 0.0;
+    const int forced = op ? forced_tile(op) : -1;
+    if (forced >= 0 && forced < (int)NT) { *eff = 1.0; return forced; }
     for (size_t i = 0; i < NT; ++i) {
         const double e = dr_efficiency(Mo, No, R, S, list[i], nullptr);
         if (e > *eff) { *eff = e; best = (int)i; }
@@ -149,12 +158,12 @@ int gemm_plan(char op, int M, int K, int N, char* out, int out_len) {
     const Tile* tile = nullptr;
     if (op == 'f') {
         if (dr_enabled('f') && M > 0 && N > 0 && K >= 64 && (N & 3) == 0) {
-            t = pick(FWD_TILES, M, N, K, 1, &eff);
+            t = pick(FWD_TILES, M, N, K, 1, &eff, 'f');
             if (t >= 0 && (eff >= dr_threshold() || small_problem(M, N))) tile = &FWD_TILES[t];
         }
     } else if (op == 'd') {
         if (dr_enabled('d') && M > 0 && K > 0 && N >= 64 && (N & 3) == 0) {
-            t = pick(DGRAD_TILES, M, K, N, 1, &eff);
+            t = pick(DGRAD_TILES, M, K, N, 1, &eff, 'd');
             if (t >= 0 && (eff >= dr_threshold() || small_problem(M, K))) tile = &DGRAD_TILES[t];
         }
     } else if (op == 'w') {
@@ -187,7 +196,7 @@ int dr_fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y,
     if (!dr_enabled('f') || M <= 0 || N <= 0 || K < 64) return DCTR_OK;
     if (!al16(x) || !al16(w) || (ldx & 3) || (N & 3) || !fits31(64, ldx) || !fits31(wave_rows(K, 1), N)) return DCTR_OK;
     double eff;
-    const int t = pick(FWD_TILES, M, N, K, 1, &eff);
+    const int t = pick(FWD_TILES, M, N, K, 1, &eff, 'f');
     if (t < 0 || (eff < dr_threshold() && !small_problem(M, N))) return DCTR_OK;
     DrEpilogue ep{};
     ep.bias = b; ep.relu = relu; ep.keep = keep; ep.seed = seed; ep.seed_ptr = seed_ptr;
@@ -209,7 +218,7 @@ int dr_fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int ldd
     if (!dr_enabled('d') || M <= 0 || K <= 0 || N < 64) return DCTR_OK;
     if (!al16(dy) || !al16(w) || (lddy & 3) || (N & 3) || !fits31(64, lddy) || !fits31(256, N)) return DCTR_OK;
     double eff;
-    const int t = pick(DGRAD_TILES, M, K, N, 1, &eff);
+    const int t = pick(DGRAD_TILES, M, K, N, 1, &eff, 'd');
     if (t < 0 || (eff < dr_threshold() && !small_problem(M, K))) return DCTR_OK;
     DrEpilogue ep{};
     ep.act = act; ep.ldact = ldact; ep.inv_keep = act ? 1.0f / keep_prev : 1.f;

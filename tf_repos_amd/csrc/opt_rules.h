@@ -4,20 +4,25 @@
 
 namespace dctr {
 
+// EXACT = true: Adam's update term with the correctly rounded sqrtf and division, whatever h.ieee says -- the dense arena (the MLP /
+// cross / attention weights: ~1e6 elements, not ALU-bound) always takes it.  EXACT = false: the table kernels (dense-exact sweep,
+// replay of lagging rows, fused tail) take the fast forms unless h.ieee is set (environment DCTR_IEEE_ADAM=1, a run-time knob:
+// tests/test_ieee_adam_gpu.py runs the fixtures both ways).
+template <bool EXACT = false>
 __device__ __forceinline__ void opt_update(int kind, const Hyper& h, float& th, float& s0, float& s1, float g) {
     switch (kind) {
         case DCTR_OPT_ADAM: {           // m,v ; theta -= lr_t m/(sqrt(v)+eps), lr_t = lr sqrt(1-b2^t)/(1-b1^t)
             s0 = h.beta1 * s0 + (1.0f - h.beta1) * g;
             s1 = h.beta2 * s1 + (1.0f - h.beta2) * g * g;
-#ifdef DCTR_IEEE_ADAM
-            th = th - h.lr_t * s0 / (sqrtf(s1) + h.eps);
-#else
-            // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the correctly rounded sqrtf and division (~10 instructions each):
-            // the update term lr_t m / (sqrt(v) + eps) is ~1e-3 of theta, so its 2-3 ulp change theta by < 1e-9 relative -- three
-            // orders below the parity tolerances -- while the dense Adam over every table row (and the replay of lagging rows,
-            // lag.h) is ALU work the step pays for: ~40 -> ~15 instructions per element
-            th = th - (h.lr_t * s0) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(s1) + h.eps);
-#endif
+            if (EXACT || h.ieee) {
+                th = th - h.lr_t * s0 / (sqrtf(s1) + h.eps);
+            } else {
+                // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the correctly rounded sqrtf and division (~10 instructions each):
+                // the update term lr_t m / (sqrt(v) + eps) is ~1e-3 of theta, so its 2-3 ulp change theta by < 1e-9 relative --
+                // three orders below the parity tolerances -- while the dense Adam over every table row (and the replay of lagging
+                // rows, lag.h) is ALU work the step pays for: ~40 -> ~15 instructions per element
+                th = th - (h.lr_t * s0) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(s1) + h.eps);
+            }
         } break;
         case DCTR_OPT_ADAGRAD: {        // accum += g^2 ; theta -= lr g / sqrt(accum)
             s0 = s0 + g * g;

@@ -327,7 +327,7 @@ def bundle_to_state(tensors: Dict[str, np.ndarray], optimizer: str) -> Dict[str,
     return out
 
 
-def state_to_bundle(state: Dict[str, np.ndarray], optimizer: str) -> Dict[str, np.ndarray]:
+def state_to_bundle(state: Dict[str, np.ndarray], optimizer: str, beta1: float = 0.9, beta2: float = 0.999) -> Dict[str, np.ndarray]:
     s0, s1 = SLOT_NAMES.get(optimizer, (None, None))
     out = {}
     for k, v in state.items():
@@ -341,8 +341,11 @@ def state_to_bundle(state: Dict[str, np.ndarray], optimizer: str) -> Dict[str, n
             out[k] = np.asarray(v, dtype=np.int64) if k == "global_step" else np.asarray(v)
     if optimizer == "Adam" and "global_step" in state:
         # AdamOptimizer's two non-slot variables [TF-1.x]: a TRAINING graph's Saver looks for them (eval / predict graphs do not).
-        # The engine derives Adam's bias correction from global_step, so they are beta^global_step (DeepFM.py:205: 0.9, 0.999)
+        # TF creates them at beta (not 1) and multiplies by beta AFTER each apply (`_finish`), reading the current value for
+        # lr_t = lr sqrt(1 - beta2_power) / (1 - beta1_power): after global_step = t applies they hold beta^(t+1), which is what
+        # the NEXT step (the engine's step t+1, bias-corrected with beta^(t+1)) needs.  beta^t here would make a resumed TF graph
+        # one step off, and at t = 0 divide by zero.  The betas are the engine's (DeepFM.py:205 passes TF's defaults 0.9 / 0.999).
         t = int(np.asarray(state["global_step"]))
-        out["beta1_power"] = np.float32(0.9 ** t)
-        out["beta2_power"] = np.float32(0.999 ** t)
+        out["beta1_power"] = np.float32(float(beta1) ** (t + 1))
+        out["beta2_power"] = np.float32(float(beta2) ** (t + 1))
     return out
