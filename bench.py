@@ -236,8 +236,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     w = dict(CONFIGS[args.config])
     w["table_sweep_period"] = args.sweep_period          # (row-sharded runs: the native driver's owner side, csrc/lag.h)
-    if args.selftest:
-        w["dropout"] = tuple(1.0 for _ in w["dropout"])     # (a dropout mask is indexed by the LOCAL row: N ranks and one rank draw different masks)
+    # (--selftest keeps the workload's dropout: a mask is a function of the GLOBAL example row -- StepState::row0 -- so N ranks draw
+    #  exactly what one rank draws on the same global batch)
     B, F, K, V = w["batch"], w["field_size"], w["embedding_size"], w["feature_size"]
     big = V * (K + 1) * 4 > (2 << 30)           # tables that must be initialised on the device
 
@@ -316,7 +316,7 @@ def main():
         batches.append((si[:B], sv[:B], sl[:B]))
 
     if args.selftest:
-        # N ranks on the global batch of step 0 == ONE rank on the same global batch, over the real transport (keep_prob 1; both
+        # N ranks on the global batch of step 0 == ONE rank on the same global batch, over the real transport (the workload's own keep_prob; both
         # sides draw the weights from seed 1).  A check, not a measurement: prints its own JSON line and exits.
         if not sharded or big:
             raise SystemExit("--selftest needs --gpus N > 1 (or DCTR_FORCE_SHARDED=1) and a config whose table fits one GPU twice (c2)")

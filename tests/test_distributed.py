@@ -80,6 +80,9 @@ def _shard_worker(rank, world, port, model, overlap, driver, ret):
         dev = torch.device("cuda:0")
         F, V, K, Bg = 39, 2003, 8, 128
         bn = model.endswith("+bn")          # batch_norm: the statistics are the GLOBAL batch's (cross-rank sums, dctr_set_stat_sync)
+        # "+dropout": keep_prob 0.5 -- the reference's training mode (DeepFM.py:161-162).  A mask is a function of the GLOBAL example row
+        # (StepState::row0), so the two ranks draw rows [0, 64) and [64, 128) of the mask one rank draws on the 128-example batch
+        keep = (0.5, 0.5) if model.endswith("+dropout") else (1.0, 1.0)
         # "+lag": 9 steps of which only the first and the last report their loss -- in between the owners' rows lag (csrc/lag.h)
         n_steps, loss_steps = (9, (0, 8)) if model.endswith("+lag") else (3, (0, 1, 2))
         model = model.split("+")[0]
@@ -87,11 +90,11 @@ def _shard_worker(rank, world, port, model, overlap, driver, ret):
         #  a step of either sign -- the golden-fixture test masks such elements; a linear rule keeps the comparison at 1e-6)
         opt = "Momentum" if bn else "Adam"
         w = dict(model=model, field_size=F, feature_size=V, embedding_size=K, batch=Bg // world, deep_layers=(32, 16),
-                 dropout=(1.0, 1.0), cross_layers=2, l2_reg=1e-3, learning_rate=1e-2, optimizer=opt, batch_norm=bn)
-        ocfg = O.Config(model=model, field_size=F, feature_size=V, embedding_size=K, deep_layers=(32, 16), dropout=(1.0, 1.0),
+                 dropout=keep, cross_layers=2, l2_reg=1e-3, learning_rate=1e-2, optimizer=opt, batch_norm=bn)
+        ocfg = O.Config(model=model, field_size=F, feature_size=V, embedding_size=K, deep_layers=(32, 16), dropout=keep,
                         cross_layers=2, l2_reg=1e-3, learning_rate=1e-2, optimizer=opt, batch_norm=bn)
         params = {k: v.numpy() for k, v in O.init_params(ocfg, seed=5, scale=0.05).items()}
-        tr = ShardedTrainer(w, rank, world, dev, params=params, overlap=overlap, driver=driver)
+        tr = ShardedTrainer(w, rank, world, dev, params=params, overlap=overlap, driver=driver, seed=4)     # (the one-rank engine's dropout seed)
         losses = []
         sl = slice(rank * (Bg // world), (rank + 1) * (Bg // world))
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a[sl])).to(dev)
@@ -119,7 +122,9 @@ def _shard_worker(rank, world, port, model, overlap, driver, ret):
 @pytest.mark.parametrize("model,overlap,driver", [("deepfm", False, "python"), ("deepfm", True, "python"), ("deepfm", True, "native"),
                                                   ("dcn", True, "native"), ("nfm", False, "native"),
                                                   ("deepfm+bn", True, "native"), ("nfm+bn", False, "python"),
-                                                  ("deepfm+lag", True, "native"), ("dcn+lag", False, "native")])
+                                                  ("deepfm+lag", True, "native"), ("dcn+lag", False, "native"),
+                                                  ("deepfm+dropout", True, "native"), ("nfm+dropout", False, "native"),
+                                                  ("dcn+dropout", True, "python")])
 def test_two_ranks_equal_one_rank(model, overlap, driver, dev):
     from oracle import deepctr_oracle as O
     from tests.util import dev_batch, make_pair
@@ -131,7 +136,8 @@ def test_two_ranks_equal_one_rank(model, overlap, driver, dev):
         probs = np.concatenate([ret["prob0"], ret["prob1"]])
     F, V, K, Bg = 39, 2003, 8, 128
     ocfg, params, eng = make_pair(model.split("+")[0], B=Bg, F=F, V=V, K=K, layers=(32, 16), cross=2,
-                                  opt="Momentum" if model.endswith("+bn") else "Adam", l2=1e-3, lr=1e-2, seed=4, batch_norm=model.endswith("+bn"))
+                                  opt="Momentum" if model.endswith("+bn") else "Adam", l2=1e-3, lr=1e-2, seed=4, batch_norm=model.endswith("+bn"),
+                                  keep=(0.5, 0.5) if model.endswith("+dropout") else None)
     ref_losses = []
     n_steps, loss_steps = (9, (0, 8)) if model.endswith("+lag") else (3, (0, 1, 2))
     for step in range(n_steps):

@@ -2,7 +2,7 @@
 v_sqrt_f32 / v_rcp_f32 (1 ulp each) by default; the environment knob DCTR_IEEE_ADAM=1 selects the correctly rounded sqrtf and
 division (csrc/opt_rules.h).  The dense arena (MLP / cross / attention weights) always takes the correctly rounded forms.
 Here: the parity suites that pin Adam pass in BOTH modes (child processes: the knob is read once per process), and the two modes
-agree with each other to 1e-7 after 40 steps of lagging rows while not being bit-identical (the knob does something)."""
+agree with each other to 1e-6 after 40 steps (lr 1e-2: forty updates of ~1e-2 each, a few ulp apart per step) of lagging rows while not being bit-identical (the knob does something)."""
 import os
 import subprocess
 import sys
@@ -58,5 +58,5 @@ def test_the_two_modes_agree_but_are_not_the_same_code(dev, tmp_path):
     for k in out[False]:
         d = float(np.abs(out[False][k] - out[True][k]).max())
         same = same and d == 0.0
-        assert d <= 1e-7, (k, d)
+        assert d <= 1e-6, (k, d)
     assert not same, "DCTR_IEEE_ADAM=1 changed nothing: is the knob wired?"

@@ -96,10 +96,11 @@ __global__ __launch_bounds__(NT) void afm_pool_fwd_kernel(const float* __restric
     for (int w = 0; w < NT / 64; ++w) z += red[w];
     const float inv = 1.0f / z;
     const uint64_t seed = (train && (keep_att < 1.f || keep_emb < 1.f)) ? *seed_ptr : 0ull;
+    const uint64_t row0 = dropout_row0(seed_ptr);        // (global row of this rank's first example, common.h)
     for (int p = t; p < P; p += NT) {
         const float a = sm[p] * inv;
         att[(size_t)b * P + p] = a;                                            // softmax output (before dropout): kept for the backward
-        sm[p] = (train && keep_att < 1.f) ? a * dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_ATT, (uint64_t)b * P + p, keep_att) : a;
+        sm[p] = (train && keep_att < 1.f) ? a * dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_ATT, (row0 + (uint64_t)b) * P + p, keep_att) : a;
     }
     __syncthreads();
     // y_emb[k] = sum_p a'[p] pp[p,k]: thread = (pair slice, float4 piece), slices summed through LDS
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(NT) void afm_pool_fwd_kernel(const float* __restric
         const float* accf = reinterpret_cast<const float*>(acc4);
         float y = 0.f;
         for (int sl = 0; sl < n_slices; ++sl) y += accf[(size_t)sl * K + t];
-        if (train && keep_emb < 1.f) y *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + t, keep_emb);
+        if (train && keep_emb < 1.f) y *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (row0 + (uint64_t)b) * K + t, keep_emb);
         yemb[(size_t)b * K + t] = y;
     }
 }
@@ -160,10 +161,11 @@ __global__ __launch_bounds__(256) void afm_pool_fwd_mfma_kernel(const float* __r
     z = wsum64(z);
     const float inv = 1.0f / z;
     const uint64_t seed = (train && (keep_att < 1.f || keep_emb < 1.f)) ? *seed_ptr : 0ull;
+    const uint64_t row0 = dropout_row0(seed_ptr);        // (global row of this rank's first example, common.h)
     for (int p = lane; p < P; p += 64) {
         const float a = expf(score(p) - m) * inv;
         att[(size_t)b * P + p] = a;                                            // softmax output (before dropout): kept for the backward
-        U[pi[p] * LDU + pj[p]] = (train && keep_att < 1.f) ? a * dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_ATT, (uint64_t)b * P + p, keep_att) : a;
+        U[pi[p] * LDU + pj[p]] = (train && keep_att < 1.f) ? a * dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_ATT, (row0 + (uint64_t)b) * P + p, keep_att) : a;
     }
     const float4* eb = ee + (size_t)b * e_ld4;
     for (int tq = 0; tq < K / 64; ++tq) {
@@ -201,10 +203,10 @@ __global__ __launch_bounds__(256) void afm_pool_fwd_mfma_kernel(const float* __r
         if (q == 0) {
             const int k = 64 * tq + 4 * c;
             if (train && keep_emb < 1.f) {
-                y.x *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + k + 0, keep_emb);
-                y.y *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + k + 1, keep_emb);
-                y.z *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + k + 2, keep_emb);
-                y.w *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + k + 3, keep_emb);
+                y.x *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (row0 + (uint64_t)b) * K + k + 0, keep_emb);
+                y.y *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (row0 + (uint64_t)b) * K + k + 1, keep_emb);
+                y.z *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (row0 + (uint64_t)b) * K + k + 2, keep_emb);
+                y.w *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (row0 + (uint64_t)b) * K + k + 3, keep_emb);
             }
             *reinterpret_cast<float4*>(yemb + (size_t)b * K + k) = y;
         }
@@ -230,9 +232,10 @@ __global__ __launch_bounds__(NT) void afm_pool_bwd_kernel(float* __restrict__ dy
     if (ee != nullptr)
         for (int x = t; x < F * (K >> 2); x += NT) es[x] = ee[(size_t)b * e_ld4 + x];
     const uint64_t seed = (keep_att < 1.f || keep_emb < 1.f) ? *seed_ptr : 0ull;
+    const uint64_t row0 = dropout_row0(seed_ptr);        // (global row of this rank's first example, common.h)
     for (int k = t; k < K; k += NT) {
         float g = dy[(size_t)b * dy_ld + k];
-        if (keep_emb < 1.f) g *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + k, keep_emb);
+        if (keep_emb < 1.f) g *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (row0 + (uint64_t)b) * K + k, keep_emb);
         dye[k] = g;
         dy[(size_t)b * dy_ld + k] = g;
     }
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(NT) void afm_pool_bwd_kernel(float* __restrict__ dy
             float s = d4.x * v[u].x + d4.y * v[u].y + d4.z * v[u].z + d4.w * v[u].w;
             for (int o = 1; o < KQ; o <<= 1) s += __shfl_xor(s, o);
             if (q == 0 && i < P * KQ) {
-                const float msk = keep_att < 1.f ? dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_ATT, (uint64_t)b * P + p, keep_att) : 1.f;
+                const float msk = keep_att < 1.f ? dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_ATT, (row0 + (uint64_t)b) * P + p, keep_att) : 1.f;
                 const float d = s * msk, a = ab[p];                // d att[p]
                 da[p] = d;
                 att_drop[(size_t)b * P + p] = a * msk;
@@ -314,6 +317,7 @@ __global__ __launch_bounds__(256) void afm_pool_bwd_mfma_kernel(float* __restric
     if (bi >= n) return;
     const int b = b0 + bi;
     const uint64_t seed = (keep_att < 1.f || keep_emb < 1.f) ? *seed_ptr : 0ull;
+    const uint64_t row0 = dropout_row0(seed_ptr);        // (global row of this rank's first example, common.h)
     // d y_emb before its dropout, this lane's 4 k of every group; written back in place (the pair backward reads it) by the c == 0 lanes
     float4 dk[KG];
     float* dyb = dy + (size_t)b * dy_ld;
@@ -322,10 +326,10 @@ __global__ __launch_bounds__(256) void afm_pool_bwd_mfma_kernel(float* __restric
         const int k = 16 * g + 4 * q;
         float4 v = *reinterpret_cast<const float4*>(dyb + k);
         if (keep_emb < 1.f) {
-            v.x *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + k + 0, keep_emb);
-            v.y *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + k + 1, keep_emb);
-            v.z *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + k + 2, keep_emb);
-            v.w *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (uint64_t)b * K + k + 3, keep_emb);
+            v.x *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (row0 + (uint64_t)b) * K + k + 0, keep_emb);
+            v.y *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (row0 + (uint64_t)b) * K + k + 1, keep_emb);
+            v.z *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (row0 + (uint64_t)b) * K + k + 2, keep_emb);
+            v.w *= dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_YEMB, (row0 + (uint64_t)b) * K + k + 3, keep_emb);
         }
         dk[g] = v;
     }
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(256) void afm_pool_bwd_mfma_kernel(float* __restric
                 float d = 0.f;
                 if (row < col && col < F) {
                     const int p = row * F - (row * (row + 1)) / 2 + (col - row - 1);
-                    const float msk = keep_att < 1.f ? dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_ATT, (uint64_t)b * P + p, keep_att) : 1.f;
+                    const float msk = keep_att < 1.f ? dropout_scale(seed ^ DCTR_DROPOUT_SITE_AFM_ATT, (row0 + (uint64_t)b) * P + p, keep_att) : 1.f;
                     const float a = ab[p];
                     d = acc[i][j][r] * msk;                         // d att[p]
                     att_drop[(size_t)b * P + p] = a * msk;

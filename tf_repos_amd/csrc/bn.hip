@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     if (i >= (int64_t)B * H) return;
     const int r = (int)(i / H), c = (int)(i % H);
     float z = (y[(size_t)r * ldy + c] - stats[c]) * stats[H + c] * gamma[c] + beta[c];
-    if (keep < 1.0f) z *= dropout_scale(*seed_ptr ^ salt, (uint64_t)i, keep);
+    if (keep < 1.0f) z *= dropout_scale(*seed_ptr ^ salt, dropout_row0(seed_ptr) * (uint64_t)H + (uint64_t)i, keep);
     out[(size_t)r * ldo + c] = z;
 }
 
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         const uint64_t seed = keep < 1.0f ? (*seed_ptr ^ salt) : 0ull;
         for (int r = rbeg + rl; r < rend; r += 4) {
             float dz = dout[(size_t)r * ldd + c];
-            if (keep < 1.0f) dz *= dropout_scale(seed, (uint64_t)r * H + c, keep);
+            if (keep < 1.0f) dz *= dropout_scale(seed, (dropout_row0(seed_ptr) + (uint64_t)r) * H + c, keep);
             s += dz;
             q += dz * (y[(size_t)r * ldy + c] - mean) * inv;
         }
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const int r = (int)(i / H), c = (int)(i % H);
     const float yv = y[(size_t)r * ldy + c];
     float dz = dout[(size_t)r * ldd + c];
-    if (keep < 1.0f) dz *= dropout_scale(*seed_ptr ^ salt, (uint64_t)i, keep);
+    if (keep < 1.0f) dz *= dropout_scale(*seed_ptr ^ salt, dropout_row0(seed_ptr) * (uint64_t)H + (uint64_t)i, keep);
     const float inv = stats[H + c];
     const float xhat = (yv - stats[c]) * inv;
     const float invB = 1.0f / (float)Bstat;

@@ -61,6 +61,10 @@ __host__ __device__ __forceinline__ uint32_t hash32(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
     return (uint32_t)x;
 }
+// Every kernel that draws a dropout mask gets `seed_ptr` = &StepState::seed_t (ops.h) or null (op-level calls with an explicit
+// seed); the word behind it is StepState::row0, the global row of this rank's first example: element (row, col) of a [rows, width]
+// site is drawn at index (row0 + row) * width + col.
+__device__ __forceinline__ uint64_t dropout_row0(const uint64_t* seed_ptr) { return seed_ptr != nullptr ? seed_ptr[1] : 0ull; }
 __host__ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float keep) {
     const float u = (float)(hash32(seed ^ (idx * 0x9E3779B97F4A7C15ULL)) >> 8) * (1.0f / 16777216.0f);
     return (u >= 1.0f - keep) ? 1.0f / keep : 0.0f;

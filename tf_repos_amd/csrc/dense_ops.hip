@@ -969,10 +969,11 @@ int opt_table(int kind, const Hyper* hdev, const Hyper& hval, int table_mode, in
 
 // ---- per-step device state: global_step, Adam's lr_t, the dropout seed of this step.  Lives in device memory
 // so that a captured hipGraph sees fresh values on every replay.
-__global__ void step_state_kernel(StepState* s, float* zero, int n_zero) {
+__global__ void step_state_kernel(StepState* s, float* zero, int n_zero, uint64_t row0) {
     for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero[i] = 0.f;     // the step's loss scalars
     if (threadIdx.x != 0) return;
     s->t += 1;
+    s->row0 = row0;
     const double t = (double)s->t;
     for (Hyper* hp : {&s->hyper, &s->hyper_lin}) {
         Hyper& h = *hp;
@@ -1005,8 +1006,8 @@ int step_state_next(const StepState* cur, StepState* nxt, float* zero, int n_zer
     return DCTR_OK;
 }
 
-int step_state_advance(StepState* s, float* zero, int n_zero, hipStream_t st) {
-    step_state_kernel<<<1, 256, 0, st>>>(s, zero, n_zero);
+int step_state_advance(StepState* s, float* zero, int n_zero, hipStream_t st, uint64_t row0) {
+    step_state_kernel<<<1, 256, 0, st>>>(s, zero, n_zero, row0);
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }

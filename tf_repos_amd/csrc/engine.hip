@@ -75,15 +75,16 @@ int dmalloc(T** p, size_t n_elems, bool zero = true) {
 }
 
 // in-place dropout on an arbitrary-sign tensor (NFM's bi-interaction, NFM.py:136-137): mask recomputed from the counter RNG
-__global__ void dropout_inplace_kernel(float* __restrict__ x, int64_t n, float keep, const uint64_t* __restrict__ seed_ptr, uint64_t salt) {
+// (x is [rows, width] contiguous, n = rows * width; the mask index counts from this rank's first GLOBAL row, common.h dropout_row0)
+__global__ void dropout_inplace_kernel(float* __restrict__ x, int64_t n, int width, float keep, const uint64_t* __restrict__ seed_ptr, uint64_t salt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    x[i] *= dropout_scale(*seed_ptr ^ salt, (uint64_t)i, keep);
+    x[i] *= dropout_scale(*seed_ptr ^ salt, dropout_row0(seed_ptr) * (uint64_t)width + (uint64_t)i, keep);
 }
 
-int dropout_inplace(float* x, int64_t n, float keep, const uint64_t* seed_ptr, uint64_t salt, hipStream_t st) {
+int dropout_inplace(float* x, int64_t n, int width, float keep, const uint64_t* seed_ptr, uint64_t salt, hipStream_t st) {
     if (n <= 0 || keep >= 1.f) return DCTR_OK;
-    dropout_inplace_kernel<<<ceil_div(n, 256), 256, 0, st>>>(x, n, keep, seed_ptr, salt);
+    dropout_inplace_kernel<<<ceil_div(n, 256), 256, 0, st>>>(x, n, width, keep, seed_ptr, salt);
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }
@@ -520,7 +521,7 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::f
     const uint64_t* seedp = &E->state->seed_t;
     if (c.model == DCTR_MODEL_IPNN) DCTR_TRY(pnn_inner_fwd(E->e, E->e_ld, B, F, K, E->x_in + D, E->Din_ld, st));
     if (c.model == DCTR_MODEL_OPNN && !E->opnn_fused) DCTR_TRY(pnn_outer_fwd(E->e, E->e_ld, B, F, K, E->x_in + D, E->Din_ld, st));
-    if (c.model == DCTR_MODEL_NFM && train) DCTR_TRY(dropout_inplace(E->x_in, (int64_t)B * K, c.keep_prob[0], seedp, DCTR_DROPOUT_SITE_NFM_BI, st));   // NFM.py:136-137
+    if (c.model == DCTR_MODEL_NFM && train) DCTR_TRY(dropout_inplace(E->x_in, (int64_t)B * K, K, c.keep_prob[0], seedp, DCTR_DROPOUT_SITE_NFM_BI, st));   // NFM.py:136-137
     if (c.model == DCTR_MODEL_DCN)
         DCTR_TRY(dcn_cross_fwd(E->x_in, E->Din_ld, E->pp(E->p_cross_w), E->pp(E->p_cross_b), B, D, c.cross_layers, E->xs, E->xlw, st));
     if (c.model == DCTR_MODEL_MVM) DCTR_TRY(mvm_fwd(E->e, E->e_ld, E->pp(E->p_mvm_b), B, F, K, E->xmvm, st));
@@ -757,7 +758,7 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
     const uint64_t* seedp = &E->state->seed_t;
     if (c.model == DCTR_MODEL_IPNN) DCTR_TRY(pnn_inner_bwd(E->e, E->e_ld, E->dx_in + D, E->Din_ld, B, F, K, E->dx_in, E->Din_ld, st));
     if (c.model == DCTR_MODEL_OPNN && !E->opnn_fused) DCTR_TRY(pnn_outer_bwd(E->e, E->e_ld, E->dx_in + D, E->Din_ld, B, F, K, E->dx_in, E->Din_ld, st));
-    if (c.model == DCTR_MODEL_NFM) DCTR_TRY(dropout_inplace(E->dx_in, (int64_t)B * K, c.keep_prob[0], seedp, DCTR_DROPOUT_SITE_NFM_BI, st));
+    if (c.model == DCTR_MODEL_NFM) DCTR_TRY(dropout_inplace(E->dx_in, (int64_t)B * K, K, c.keep_prob[0], seedp, DCTR_DROPOUT_SITE_NFM_BI, st));
     if (c.model == DCTR_MODEL_MVM) {         // after the MLP's dgrad wrote dx_in: the product layer adds its share of dL/de
         const Param& pm = E->params[E->p_mvm_b];
         DCTR_TRY(mvm_bwd(E->e, E->e_ld, E->pp(E->p_mvm_b), E->dxmvm, B, F, K, E->dx_in, E->Din_ld, E->part(E->p_mvm_b), pm.padded, pm.n_part, st));
@@ -1874,7 +1875,11 @@ int sharded_forward_backward(dctr_engine* E, const float* d_rows, int n_rows, co
     const size_t n = (size_t)B * E->F;
     const int P = E->K + 4;
     E->state_ready = false;
-    if (train) DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, st));    // (on st: see record_train)
+    // (on st: see record_train.)  row0: dropout masks are a function of the GLOBAL example row (common.h dropout_row0) -- with equal
+    // per-rank batches this rank's examples are rows [rank B, (rank + 1) B) of the step's global batch, and N ranks draw exactly the
+    // masks one rank draws on that batch (tests/test_distributed.py "+dropout"); unequal batches: the local row, as before
+    if (train) DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, st,
+                                           (int64_t)B * E->cfg.shard_world == (int64_t)global_batch ? (uint64_t)E->cfg.shard_rank * (uint64_t)B : 0ull));
     // inputs that already live in one of the engine's input slots are read in place (no staging copy at the head of the step)
     for (int k = 0; k < DCTR_INPUT_SLOTS; ++k)
         if (d_vals == E->slot_vals[k] && (d_labels == nullptr || d_labels == E->slot_labels[k])) {

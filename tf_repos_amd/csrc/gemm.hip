@@ -258,10 +258,11 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(
     if (col >= N || !wave_live) return;
     float* Cz = Cm + (EPI == EPI_STORE ? (size_t)blockIdx.z * ep.split_stride : 0);
     float bias = 0.f;
-    uint64_t seed = 0;
+    uint64_t seed = 0, row0 = 0;
     if (EPI == EPI_BIAS_ACT) {
         if (ep.bias != nullptr) bias = ep.bias[col];
         seed = ep.seed ^ (ep.seed_ptr ? *ep.seed_ptr : 0ull);
+        row0 = dropout_row0(ep.seed_ptr);
     }
     const int rbase = m0 + wm * 32 + 4 * (lane >> 5);
     float* crow = Cz + (size_t)rbase * ldc + col;
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(
         if (EPI == EPI_BIAS_ACT) {
             v += bias;
             if (ep.relu) v = fmaxf(v, 0.f);
-            if (ep.keep < 1.0f) v *= dropout_scale(seed, (uint64_t)(rbase + roff) * (uint64_t)N + col, ep.keep);
+            if (ep.keep < 1.0f) v *= dropout_scale(seed, (row0 + (uint64_t)(rbase + roff)) * (uint64_t)N + col, ep.keep);
         } else if (EPI == EPI_MASK) {
             v = (arow_p[(size_t)roff * ep.ldact] > 0.f) ? v * ep.inv_keep : 0.f;
         }

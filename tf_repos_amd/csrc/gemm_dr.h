@@ -436,11 +436,12 @@ __global__ __launch_bounds__(256, DR_MIN_WAVES(TM, TN, CS, AGEN)) void gemm_dr_k
     if constexpr (EPI == DR_BIAS_ACT) {
         if (ep.keep < 1.0f) {
             const uint64_t sd = ep.seed ^ (ep.seed_ptr ? *ep.seed_ptr : 0ull);
+            const uint64_t row0 = ep.seed_ptr ? ep.seed_ptr[1] : 0ull;          // (StepState::row0: this rank's first example in the global batch)
             const int tr_ = t / C4_, tc_ = t - tr_ * C4_;
             keep_lo = keep_hi = 0u;
 #pragma unroll
             for (int it = 0; it < NIT_; ++it) {
-                const uint64_t base = (uint64_t)(m0 + tr_ + RPI_ * it) * (uint64_t)N + (uint64_t)(n0 + 4 * tc_);
+                const uint64_t base = (row0 + (uint64_t)(m0 + tr_ + RPI_ * it)) * (uint64_t)N + (uint64_t)(n0 + 4 * tc_);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t bit = dr_dropout_scale(sd, base + e, ep.keep) != 0.f ? 1u : 0u;
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(256, DR_MIN_WAVES(TM, TN, CS, AGEN)) void gemm_dr_k
                 if (EPI == DR_BIAS_ACT) {
                     if (ep.bias != nullptr) v += ep.bias[gc];
                     if (ep.relu) v = fmaxf(v, 0.f);
-                    if (ep.keep < 1.0f) v *= dr_dropout_scale(seed, (uint64_t)gm * (uint64_t)N + gc, ep.keep);
+                    if (ep.keep < 1.0f) v *= dr_dropout_scale(seed, ((ep.seed_ptr ? ep.seed_ptr[1] : 0ull) + (uint64_t)gm) * (uint64_t)N + gc, ep.keep);
                 } else if (EPI == DR_MASK) {
                     v = (ep.act[(size_t)gm * ep.ldact + gc] > 0.f) ? v * ep.inv_keep : 0.f;
                 } else if (GATE) {

@@ -356,12 +356,12 @@ __global__ __launch_bounds__(256) void opnn_finish_kernel(float* __restrict__ y,
         v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
     }
     float o[4] = {v.x, v.y, v.z, v.w};
-    const uint64_t sd = seed ^ (seed_ptr ? *seed_ptr : 0ull);
+    const uint64_t sd = seed ^ (seed_ptr ? *seed_ptr : 0ull), row0 = dropout_row0(seed_ptr);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         if (bias != nullptr) o[e] += bias[col + e];
         if (relu) o[e] = fmaxf(o[e], 0.f);
-        if (keep < 1.0f) o[e] *= dropout_scale(sd, (uint64_t)b * (uint64_t)H + col + e, keep);
+        if (keep < 1.0f) o[e] *= dropout_scale(sd, (row0 + (uint64_t)b) * (uint64_t)H + col + e, keep);
     }
     *reinterpret_cast<float4*>(y + (size_t)b * ldy + col) = make_float4(o[0], o[1], o[2], o[3]);
 }

@@ -21,6 +21,8 @@ struct StepState {
     int64_t t;          // global_step (number of optimizer steps applied so far)
     uint64_t seed;      // base dropout seed
     uint64_t seed_t;    // seed of the current step
+    uint64_t row0;      // MUST follow seed_t (dropout_row0, common.h): index of this rank's first example in the GLOBAL batch of the step --
+                        // a dropout mask is a function of the global example row, so N data-parallel ranks draw what one rank would
     Hyper hyper;
     Hyper hyper_lin;    // canned-estimator models: the linear side's optimizer (wide_n_deep.py:144-149); else a copy of hyper
     float lr_hist[LR_HIST];     // lr_hist[s % LR_HIST] = hyper.lr_t of step s
@@ -155,7 +157,7 @@ int opt_table(int kind, const Hyper* hdev, const Hyper& hval, int table_mode, in
               const int32_t* counters, int64_t max_entries, const float* gemb, const float* glin, float l2,
               float* sumsq_emb, float* sumsq_lin, hipStream_t st, hipStream_t st_lin = nullptr, int pass = 0);
 enum { OPT_PASS_ALL = 0, OPT_PASS_UNTOUCHED = 1, OPT_PASS_TOUCHED = 2 };
-int step_state_advance(StepState* s, float* zero, int n_zero, hipStream_t st);
+int step_state_advance(StepState* s, float* zero, int n_zero, hipStream_t st, uint64_t row0 = 0);
 int step_state_next(const StepState* cur, StepState* nxt, float* zero, int n_zero, hipStream_t st);
 int head_out_bwd(const float* x1, int ld1, const float* w1, int n1, int masked1, float* dx1, int lddx1,
                  const float* x2, int ld2, const float* w2, int n2, int masked2, float* dx2, int lddx2,
