@@ -1,7 +1,8 @@
 """Adam's update term lr_t m / (sqrt(v) + eps) in the TABLE kernels (dense-exact sweep, replay of lagging rows, fused tail) uses
-v_sqrt_f32 / v_rcp_f32 (1 ulp each) by default; the environment knob DCTR_IEEE_ADAM=1 selects the correctly rounded sqrtf and
-division (csrc/opt_rules.h).  The dense arena (MLP / cross / attention weights) always takes the correctly rounded forms.
-Here: the parity suites that pin Adam pass in BOTH modes (child processes: the knob is read once per process), and the two modes
+v_sqrt_f32 / v_rcp_f32 (1 ulp each) by default; DCTR_IEEE_ADAM=1 in the environment loads the second library that
+__graft_entry__.build() makes from the same sources with -DDCTR_IEEE_ADAM: the correctly rounded sqrtf and division there too
+(csrc/opt_rules.h).  The dense arena (MLP / cross / attention weights) always takes the correctly rounded forms.
+Here: the parity suites that pin Adam pass on BOTH libraries (child processes: the library is chosen at import), and the two modes
 agree with each other to 1e-6 after 40 steps (lr 1e-2: forty updates of ~1e-2 each, a few ulp apart per step) of lagging rows while not being bit-identical (the knob does something)."""
 import os
 import subprocess

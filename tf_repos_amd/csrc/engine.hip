@@ -323,7 +323,6 @@ int build(dctr_engine* E) {
     s.hyper.lr = c.learning_rate; s.hyper.beta1 = 0.9f; s.hyper.beta2 = 0.999f; s.hyper.eps = 1e-8f;   // DeepFM.py:205
     s.hyper.momentum = 0.95f;                                                                          // DeepFM.py:209
     s.hyper.lr_t = c.learning_rate;
-    s.hyper.ieee = adam_ieee_default();
     s.hyper_lin = s.hyper;
     if (E->wnd) { s.hyper_lin.lr = c.lin_learning_rate; s.hyper_lin.lr_t = c.lin_learning_rate; }
     E->h_state = s;
@@ -950,7 +949,13 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
                             : ((int64_t)E->mlp[0].in * E->mlp[0].out >= (1 << 16) ? 1 : 0);
     hipEvent_t tables_ev = nullptr;
     bool have_tables_ev = false;
+    // A/B knob DCTR_SWEEP_AFTER_HEAD=1: with the ids grouped ahead the grouping stream has only the background sweep to start, and the
+    // fork that starts it behind the last forward layer is a record on st -- a barrier packet between that GEMM and the head (~5 us in
+    // the timeline).  Here the sweep starts behind the record the head needs anyway (head_ev below).
+    static const bool sweep_after_head_env = getenv("DCTR_SWEEP_AFTER_HEAD") != nullptr;
+    const bool late_sweep = sweep_after_head_env && pregrouped && split_table && !bg_late && E->cfg.model != DCTR_MODEL_AFM && !E->mlp.empty();
     const std::function<int()> start_grouping = [&]() -> int {
+        if (late_sweep) return DCTR_OK;
         DCTR_TRY(fork(E, st, sg));          // not before the gather (its atomics slow a concurrent gather 4x)
         // (a captured step is replayed from states this enqueue cannot see: it always carries the slot-reset kernel)
         if (E->cfg.use_graph) E->group->slots_clean = false;
@@ -976,9 +981,20 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
         DCTR_TRY(record_on(E, st, &head_ev));
         have_head_ev = true;
         DCTR_HIP_CHECK(hipStreamWaitEvent(sg, head_ev, 0));
+        if (late_sweep) {
+            DCTR_TRY(step_untouched_rows(E, sg));
+            DCTR_TRY(record_on(E, sg, &tables_ev));
+            have_tables_ev = true;
+        }
         if (split_table && bg_late) DCTR_TRY(step_untouched_rows(E, sg));
         DCTR_TRY(opt_dense_range(E, E->p_out_w, E->p_out_b, sg));
         if (E->p_bias >= 0) DCTR_TRY(opt_dense_range(E, E->p_bias, E->p_bias, sg));
+    }
+    if (late_sweep && !have_tables_ev) {      // (no fused head on this model: the ordinary fork)
+        DCTR_TRY(fork(E, st, sg));
+        DCTR_TRY(step_untouched_rows(E, sg));
+        DCTR_TRY(record_on(E, sg, &tables_ev));
+        have_tables_ev = true;
     }
     const bool out_done = fused_opt && E->head_did_out_bwd;
     // A/B knob DCTR_WGRAD_SERIAL=1: the weight gradients (and the per-layer optimizer steps) on the main stream, right behind their

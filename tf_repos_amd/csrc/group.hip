@@ -927,7 +927,6 @@ int dctr_embed_scatter_apply(dctr_group_t g, int kind, const float* hyper, float
     Group* G = reinterpret_cast<Group*>(g);
     Hyper h{};
     h.lr = hyper[0];
-    h.ieee = adam_ieee_default();
     h.beta1 = 0.9f; h.beta2 = 0.999f; h.eps = 1e-8f; h.momentum = 0.95f; h.lr_t = h.lr;
     if (kind == DCTR_OPT_ADAM) {
         h.beta1 = hyper[1]; h.beta2 = hyper[2]; h.eps = hyper[3];

@@ -7,14 +7,8 @@ namespace dctr {
 // ---- optimizer scalars; a copy lives in device memory inside StepState so graphs replay correctly
 struct Hyper {
     float lr, beta1, beta2, eps, lr_t, momentum;
-    int ieee;           // Adam's update term in the table kernels: 0 = v_sqrt_f32 / v_rcp_f32 (1 ulp each), 1 = correctly rounded (opt_rules.h)
-    float pad;
+    float pad[2];
 };
-// process-wide default of Hyper::ieee: environment DCTR_IEEE_ADAM=1 (read once)
-inline int adam_ieee_default() {
-    static const int v = [] { const char* e = getenv("DCTR_IEEE_ADAM"); return (e != nullptr && e[0] == '1') ? 1 : 0; }();
-    return v;
-}
 
 constexpr int LR_HIST = 32;     // per-step Adam lr_t of the last LR_HIST steps (lag.h: rows that lag replay their missed steps with them)
 struct StepState {

@@ -4,17 +4,24 @@
 
 namespace dctr {
 
-// EXACT = true: Adam's update term with the correctly rounded sqrtf and division, whatever h.ieee says -- the dense arena (the MLP /
-// cross / attention weights: ~1e6 elements, not ALU-bound) always takes it.  EXACT = false: the table kernels (dense-exact sweep,
-// replay of lagging rows, fused tail) take the fast forms unless h.ieee is set (environment DCTR_IEEE_ADAM=1, a run-time knob:
-// tests/test_ieee_adam_gpu.py runs the fixtures both ways).
-template <bool EXACT = false>
+// EXACT = true: Adam's update term with the correctly rounded sqrtf and division -- the dense arena (the MLP / cross / attention
+// weights: ~1e6 elements, not ALU-bound) always takes it.  The table kernels (dense-exact sweep, replay of lagging rows, fused
+// tail) take the default: the fast forms, or the exact ones in a library built with -DDCTR_IEEE_ADAM.  That second library IS built
+// (tf_repos_amd/build.py: libdeepctr_hip_ieee.so) and DCTR_IEEE_ADAM=1 in the environment loads it (capi.py); tests/test_ieee_adam_gpu.py
+// runs the Adam parity suites on it.  (A run-time flag in Hyper was tried first: a branch per element inside the replay loops, which the
+// compiler can no longer interleave across rows -- the flag belongs at compile time.)
+#ifdef DCTR_IEEE_ADAM
+constexpr bool ADAM_TABLES_EXACT = true;
+#else
+constexpr bool ADAM_TABLES_EXACT = false;
+#endif
+template <bool EXACT = ADAM_TABLES_EXACT>
 __device__ __forceinline__ void opt_update(int kind, const Hyper& h, float& th, float& s0, float& s1, float g) {
     switch (kind) {
         case DCTR_OPT_ADAM: {           // m,v ; theta -= lr_t m/(sqrt(v)+eps), lr_t = lr sqrt(1-b2^t)/(1-b1^t)
             s0 = h.beta1 * s0 + (1.0f - h.beta1) * g;
             s1 = h.beta2 * s1 + (1.0f - h.beta2) * g * g;
-            if (EXACT || h.ieee) {
+            if constexpr (EXACT) {
                 th = th - h.lr_t * s0 / (sqrtf(s1) + h.eps);
             } else {
                 // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the correctly rounded sqrtf and division (~10 instructions each):
