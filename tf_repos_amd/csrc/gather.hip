@@ -76,8 +76,7 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(
                 for (int u = 0; u < U; ++u) nl[u] = (lin != nullptr && kq == 0) ? nlag[u] : 0;
                 const Hyper hh = L.state->hyper;
                 const int64_t Tm1 = L.state->t - 1;
-                lag_catch_up4_rows<U>(L.state, hh, L.l2, Tm1, nlag, r, m, vv);
-                lag_catch_up1_rows<U>(L.state, hh, L.l2, Tm1, nl, w, lm, lv);
+                lag_catch_up_rows_lin<U, true>(L.state, hh, L.l2, Tm1, nlag, r, m, vv, nl, w, lm, lv);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {

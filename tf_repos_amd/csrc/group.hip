@@ -519,8 +519,7 @@ __device__ __forceinline__ void table_row_step(const TableStep& T, const Hyper& 
     float4 th = R.th, a = R.a, b = R.b;
     if (KIND == DCTR_OPT_ADAM && R.nlag > 0) {          // the steps no batch touched this row: replayed first (lag.h)
         const int64_t first = T.state->t - R.nlag;
-        lag_catch_up4(T.state, h, T.l2, first, R.nlag, th, a, b);
-        if (kq == 0 && T.lin != nullptr) lag_catch_up1(T.state, h, T.l2, first, R.nlag, R.lt, R.la, R.lb);
+        lag_catch_up4_lin(T.state, h, T.l2, first + R.nlag - 1, R.nlag, th, a, b, (kq == 0 && T.lin != nullptr) ? R.nlag : 0, R.lt, R.la, R.lb);
     }
     sq += th.x * th.x + th.y * th.y + th.z * th.z + th.w * th.w;
     float4 g = make_float4(T.l2 * th.x, T.l2 * th.y, T.l2 * th.z, T.l2 * th.w);

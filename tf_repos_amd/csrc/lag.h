@@ -31,6 +31,7 @@ struct LagView {
     float l2;
 };
 
+#ifdef DCTR_LAG_LANE_LOOPS      // (A/B: round 3's lane-own loops, tf_repos_amd.build --variant lanelag -DDCTR_LAG_LANE_LOOPS)
 // replay steps first .. first+n-1 of a row piece that no batch touched: g = l2 * theta (what opt_table_untouched_kernel computes)
 __device__ __forceinline__ void lag_catch_up4(const StepState* __restrict__ S, Hyper h, float l2, int64_t first, int n, float4& th, float4& m, float4& v) {
     for (int k = 0; k < n; ++k) {
@@ -81,6 +82,126 @@ __device__ __forceinline__ void lag_catch_up1_rows(const StepState* __restrict__
             if (k <= n[r]) opt_update(DCTR_OPT_ADAM, h, th[r], m[r], v[r], l2 * th[r]);
     }
 }
+template <int R, bool SKIP = false>
+__device__ __forceinline__ void lag_catch_up_rows_lin(const StepState* __restrict__ S, Hyper h, float l2, int64_t last, const int (&n)[R],
+                                                      float4 (&th)[R], float4 (&m)[R], float4 (&v)[R], const int (&nl)[R], float (&lt)[R],
+                                                      float (&lm)[R], float (&lv)[R]) {
+    lag_catch_up4_rows<R>(S, h, l2, last, n, th, m, v);
+    lag_catch_up1_rows<R>(S, h, l2, last, nl, lt, lm, lv);
+}
+__device__ __forceinline__ void lag_catch_up4_lin(const StepState* __restrict__ S, Hyper h, float l2, int64_t last, int n, float4& th, float4& m, float4& v,
+                                                  int nlin, float& lt, float& lm, float& lv) {
+    lag_catch_up4(S, h, l2, last - n + 1, n, th, m, v);
+    if (nlin > 0) lag_catch_up1(S, h, l2, last - nlin + 1, nlin, lt, lm, lv);
+}
+#else
+// ---- the replay loop.  Every caller has lanes that are behind by DIFFERENT numbers of steps (a gather's rows, a sweep block's
+// recently touched rows), and the step to replay fixes the Adam lr_t to use.  The loop therefore runs over the STEPS, wave-uniformly
+// (k = kmax .. 1 <-> step last - k + 1, kmax the largest lag among the wave's active lanes), so that
+//   * lr_t of a step is ONE scalar load for the wave, issued an iteration ahead of its use (a lane-indexed load of the history ring
+//     was a vector load plus a full wait in every iteration of every lane's own loop: the loop was a chain of memory latencies);
+//   * the R rows' (and the linear weight's) updates of a step sit side by side in one basic block -- 4 R + 1 independent dependency
+//     chains through sqrt and rcp for the scheduler to interleave -- and a lane that is not behind that far takes the update and
+//     throws it away with a select (`k <= n`), instead of each row's update sitting in its own divergent branch.
+// What is computed for a lane that takes part is, call for call, what the lane-own loops computed: opt_update with the step's lr_t
+// and g = l2 * theta, oldest missed step first.
+__device__ __forceinline__ int lag_wave_max_lag(int nmax) {          // largest lag among the active lanes (wave-uniform), 0 if none is behind
+    for (int k = LAG_MAX_PERIOD; k >= 1; --k)
+        if (__any(k <= nmax)) return k;
+    return 0;
+}
+// SKIP: a row slot that NO lane of the wave needs at step k is skipped by a wave-uniform branch -- the gather's slots are fields, and
+// Criteo's numeric fields (always-hit ids) are current on every lane: a third of the work (measured, same box: the LAG gather 15.8 us
+// with lane-own loops, 20.6 with every slot computed and selected away).  The price is a basic block per slot: the sweep, whose rows
+// all lag alike, leaves it off and gets 4 R + 1 interleaved chains (lag_advance_kernel 41 -> 31 us).
+template <int R, bool LIN, bool SKIP = false>
+__device__ __forceinline__ void lag_replay_rows(const StepState* __restrict__ S, Hyper h, float l2, int64_t last, const int (&n)[R],
+                                                float4 (&th)[R], float4 (&m)[R], float4 (&v)[R], const int (&nl)[R], float (&lt)[R],
+                                                float (&lm)[R], float (&lv)[R]) {
+    int nmax = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) nmax = n[r] > nmax ? n[r] : nmax;
+    if (LIN) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) nmax = nl[r] > nmax ? nl[r] : nmax;
+    }
+    const int kmax = lag_wave_max_lag(nmax);
+    if (kmax == 0) return;
+    // (`last` is the same on every lane -- callers derive it from StepState::t; readfirstlane says so to the compiler, which would
+    //  otherwise index the ring per lane: a vector load.  The ring index needs the low bits only.)
+    const int ilast = __builtin_amdgcn_readfirstlane((int)last);
+    float lr = S->lr_hist[(ilast - kmax + 1) & (LR_HIST - 1)];
+    for (int k = kmax; k >= 1; --k) {                               // step last - k + 1
+        const float lr_next = S->lr_hist[(ilast - k + 2) & (LR_HIST - 1)];     // (of step last - k + 2: the next iteration's; k = 1 reads one entry past `last`, unused)
+        h.lr_t = lr;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (SKIP && !__any(k <= n[r] || (LIN && k <= nl[r]))) continue;
+            float4 t = th[r], a = m[r], b = v[r];
+            opt_update(DCTR_OPT_ADAM, h, t.x, a.x, b.x, l2 * t.x);
+            opt_update(DCTR_OPT_ADAM, h, t.y, a.y, b.y, l2 * t.y);
+            opt_update(DCTR_OPT_ADAM, h, t.z, a.z, b.z, l2 * t.z);
+            opt_update(DCTR_OPT_ADAM, h, t.w, a.w, b.w, l2 * t.w);
+            const bool on = k <= n[r];
+            th[r].x = on ? t.x : th[r].x; th[r].y = on ? t.y : th[r].y; th[r].z = on ? t.z : th[r].z; th[r].w = on ? t.w : th[r].w;
+            m[r].x = on ? a.x : m[r].x; m[r].y = on ? a.y : m[r].y; m[r].z = on ? a.z : m[r].z; m[r].w = on ? a.w : m[r].w;
+            v[r].x = on ? b.x : v[r].x; v[r].y = on ? b.y : v[r].y; v[r].z = on ? b.z : v[r].z; v[r].w = on ? b.w : v[r].w;
+            if (LIN) {
+                float t1 = lt[r], a1 = lm[r], b1 = lv[r];
+                opt_update(DCTR_OPT_ADAM, h, t1, a1, b1, l2 * t1);
+                const bool on1 = k <= nl[r];
+                lt[r] = on1 ? t1 : lt[r]; lm[r] = on1 ? a1 : lm[r]; lv[r] = on1 ? b1 : lv[r];
+            }
+        }
+        lr = lr_next;
+    }
+}
+// R row pieces, each n[r] steps behind `last` (its steps last - n[r] + 1 .. last are replayed)
+template <int R>
+__device__ __forceinline__ void lag_catch_up4_rows(const StepState* __restrict__ S, Hyper h, float l2, int64_t last, const int (&n)[R],
+                                                   float4 (&th)[R], float4 (&m)[R], float4 (&v)[R]) {
+    int nl[R]; float a[R], b[R], c[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { nl[r] = 0; a[r] = b[r] = c[r] = 0.f; }
+    lag_replay_rows<R, false>(S, h, l2, last, n, th, m, v, nl, a, b, c);
+}
+// ... together with the rows' linear weights (nl[r]: the same lag on the lane that owns the weight, 0 elsewhere)
+template <int R, bool SKIP = false>
+__device__ __forceinline__ void lag_catch_up_rows_lin(const StepState* __restrict__ S, Hyper h, float l2, int64_t last, const int (&n)[R],
+                                                      float4 (&th)[R], float4 (&m)[R], float4 (&v)[R], const int (&nl)[R], float (&lt)[R],
+                                                      float (&lm)[R], float (&lv)[R]) {
+    lag_replay_rows<R, true, SKIP>(S, h, l2, last, n, th, m, v, nl, lt, lm, lv);
+}
+// one row piece: steps first .. first + n - 1 (what opt_table_untouched_kernel computes for a row no batch touched, step by step)
+__device__ __forceinline__ void lag_catch_up4(const StepState* __restrict__ S, Hyper h, float l2, int64_t first, int n, float4& th, float4& m, float4& v) {
+    int nn[1] = {n}, nl[1] = {0};
+    float4 t[1] = {th}, a[1] = {m}, b[1] = {v};
+    float x[1] = {0.f}, y[1] = {0.f}, z[1] = {0.f};
+    lag_replay_rows<1, false>(S, h, l2, first + n - 1, nn, t, a, b, nl, x, y, z);
+    th = t[0]; m = a[0]; v = b[0];
+}
+// one row piece and its linear weight (nlin = n on the lane that owns the weight, else 0)
+__device__ __forceinline__ void lag_catch_up4_lin(const StepState* __restrict__ S, Hyper h, float l2, int64_t last, int n, float4& th, float4& m, float4& v,
+                                                  int nlin, float& lt, float& lm, float& lv) {
+    int nn[1] = {n}, nl[1] = {nlin};
+    float4 t[1] = {th}, a[1] = {m}, b[1] = {v};
+    float x[1] = {lt}, y[1] = {lm}, z[1] = {lv};
+    lag_replay_rows<1, true>(S, h, l2, last, nn, t, a, b, nl, x, y, z);
+    th = t[0]; m = a[0]; v = b[0]; lt = x[0]; lm = y[0]; lv = z[0];
+}
+__device__ __forceinline__ void lag_catch_up1(const StepState* __restrict__ S, Hyper h, float l2, int64_t first, int n, float& th, float& m, float& v) {
+    // (a linear weight alone: the row-sharded pack of a lin-only record)
+    const int kmax = lag_wave_max_lag(n);
+    const int ilast = __builtin_amdgcn_readfirstlane((int)(first + n - 1));      // (callers pass first = last - n + 1: the same `last` on every lane)
+    for (int k = kmax; k >= 1; --k) {
+        h.lr_t = S->lr_hist[(ilast - k + 1) & (LR_HIST - 1)];
+        float t = th, a = m, b = v;
+        opt_update(DCTR_OPT_ADAM, h, t, a, b, l2 * t);
+        const bool on = k <= n;
+        th = on ? t : th; m = on ? a : m; v = on ? b : v;
+    }
+}
+#endif
 // steps a row stamped `ts` is behind `target` (both compared mod 256)
 __device__ __forceinline__ int lag_behind(int64_t target, uint8_t ts) { return (int)(uint8_t)((uint8_t)target - ts); }
 

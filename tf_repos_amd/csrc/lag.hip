@@ -70,8 +70,7 @@ __global__ __launch_bounds__(256) void lag_advance_kernel(int64_t rows, float4* 
             nn[j] = live[j] ? n[j] : 0;
             nl[j] = (live[j] && lin != nullptr && (int)((t0 + j * stride) % KQ) == 0) ? n[j] : 0;
         }
-        lag_catch_up4_rows<UNR>(S, h, l2, target, nn, th, m, v);
-        lag_catch_up1_rows<UNR>(S, h, l2, target, nl, lt, lm, lv);
+        lag_catch_up_rows_lin<UNR>(S, h, l2, target, nn, th, m, v, nl, lt, lm, lv);
 #pragma unroll
         for (int j = 0; j < UNR; ++j) {
             if (!live[j]) continue;

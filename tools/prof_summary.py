@@ -44,11 +44,13 @@ def timeline(path, anchor="gather_fwd_kernel", which=40):
     if len(marks) < which + 2:
         which = max(0, len(marks) - 2)
     a, b = marks[which], marks[which + 1]
+    c = marks[which + 2] if which + 2 < len(marks) else b
     t0 = rows[a][si]
-    print("one step: %d kernels, %.1f us from first start to last end" % (b - a, (max(r[ei] for r in rows[a:b]) - t0) / 1e3))
-    print("%10s %10s %6s  %s" % ("start_us", "dur_us", "queue", "kernel"))
-    for r in rows[a:b]:
-        print("%10.1f %10.1f %6s  %s" % ((r[si] - t0) / 1e3, (r[ei] - r[si]) / 1e3, r[qi] if qi is not None else "-", r[ni][:70]))
+    print("one step: %d kernels, %.1f us from first start to last end; gather to next gather %.1f us" % (
+        b - a, (max(r[ei] for r in rows[a:b]) - t0) / 1e3, (rows[b][si] - t0) / 1e3))
+    print("%10s %10s %10s %6s  %s" % ("start_us", "dur_us", "end_us", "queue", "kernel"))
+    for r in rows[a:c]:           # two consecutive steps: what trails a step runs under the head of the next
+        print("%10.1f %10.1f %10.1f %6s  %s" % ((r[si] - t0) / 1e3, (r[ei] - r[si]) / 1e3, (r[ei] - t0) / 1e3, r[qi] if qi is not None else "-", r[ni][:70]))
 
 
 if __name__ == "__main__":
