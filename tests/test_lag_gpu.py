@@ -124,6 +124,49 @@ def test_restored_global_step_and_written_parameters(dev):
     assert worst <= max(3e-6, 3 * noise), (worst, noise)
 
 
+@pytest.mark.parametrize("preadvance", ["0", "1"])
+@pytest.mark.parametrize("model", ["deepfm", "dcn"])
+def test_announced_batches(model, preadvance, dev, monkeypatch):
+    """The input pipeline's hint (dctr_prefetch_ids after every step, batches in the engine's input slots): the next batch's ids are
+    grouped during the step in flight and -- with DCTR_PREADVANCE=1 when the handle is created (lag.h lag_preadvance; off by default,
+    it does not pay) -- its rows that the step in flight does not touch are advanced to the present beside that step's table step, so
+    that the next gather reads current rows only.  Same results as the classic sweep without any hint; a step in the middle without a
+    hint, one with a hint that is not honoured (another batch trained), a loss read and a short batch included."""
+    from tf_repos_amd import capi
+    monkeypatch.setenv("DCTR_PREADVANCE", preadvance)
+    F, V, B, K = 39, 30000, 256, 8
+    ocfg = O.Config(model=model, field_size=F, feature_size=V, embedding_size=K, deep_layers=(32, 16), dropout=(0.8, 0.8), cross_layers=2,
+                    l2_reg=1e-3, learning_rate=1e-2, optimizer="Adam")
+    params = O.init_params(ocfg, seed=8, scale=0.05)
+    nb = capi.INPUT_SLOTS
+    host = [O.synth_batch(B if i != 5 else 100, F, V, seed=1200 + i) for i in range(nb)]
+    runs = []
+    for period, hint in ((1, False), (1, False), (8, True)):
+        eng = engine(model, period, V, B, params=params, keep=(0.8, 0.8))
+        slots = []
+        for i, (ids, vals, labels) in enumerate(host):
+            si, sv, sl = eng.input_slot(i)
+            b = len(labels)
+            si[:b].copy_(torch.from_numpy(ids)); sv[:b].copy_(torch.from_numpy(vals)); sl[:b].copy_(torch.from_numpy(labels))
+            slots.append((si[:b], sv[:b], sl[:b]))
+        order = [s % nb for s in range(26)]
+        losses = []
+        for s, i in enumerate(order):
+            losses.append(eng.train_step(*slots[i], want_loss=s in (0, 13, 25)))
+            if hint and s + 1 < len(order) and s != 9:          # (step 10 comes unannounced)
+                nxt = order[s + 1] if s != 17 else (order[s + 1] + 3) % nb      # (after step 17 the WRONG batch is announced)
+                eng.prefetch_ids(slots[nxt][0])
+        runs.append((losses, state_of(eng)))
+        eng.close()
+    noise = max(float(np.abs(v - runs[1][1][k]).max()) for k, v in runs[0][1].items())
+    for a, b_ in zip(runs[0][0], runs[2][0]):
+        assert (a is None) == (b_ is None)
+        if a is not None:
+            assert abs(a - b_) <= 1e-5 * max(1.0, abs(a)), (a, b_)
+    for k, v in runs[0][1].items():
+        assert np.abs(v - runs[2][1][k]).max() <= max(3e-6, 4 * noise), (k, noise)
+
+
 def test_period_is_validated(dev):
     with pytest.raises(errors.InvalidArgumentError):
         engine("deepfm", 99, 1000, 16)

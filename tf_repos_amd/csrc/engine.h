@@ -83,6 +83,20 @@ struct dctr_engine {
     const int32_t* pre_ids = nullptr;
     int pre_B = 0;
     bool pre_valid = false;
+    // ... and its rows PRE-ADVANCED (lag.h lag_preadvance): every row that batch reads is current when its step starts -- the rows the
+    // batch in flight shares with it by that batch's own table step, the others by a background kernel beside it -- so the gather takes
+    // the plain path (no Adam slots read, nothing replayed on the critical path)
+    bool pre_advanced = false;
+    hipEvent_t ev_preadv = nullptr;
+    bool preadv_unjoined = false;   // a pre-advance may still be running on s_group: whoever touches the tables next waits for ev_preadv
+    hipEvent_t sweep_ev = nullptr;  // the background sweep of the step in flight has been enqueued up to this record (the pre-advance is ordered behind it)
+    bool have_sweep_ev = false;
+    hipEvent_t alt_ready_ev = nullptr;  // group_alt's slot words have been cleared (on s_group): whoever regroups into it next waits
+    bool have_alt_ready_ev = false;
+    bool pre_on_hint_stream = false;    // the pending grouping was made on s_opt (the hint stream), not on s_group
+    bool preadvance = false;        // DCTR_PREADVANCE=1 when the handle was created (off by default: measured, it loses -- DESIGN 5)
+    bool slots_kept = false;        // the table step in flight was launched with keep_slots: its grouping's slot words are valid membership until the next grouping
+    bool hint_streak = false;       // this step's ids were announced ahead: the next step's probably will be -- the table step keeps its slot words for the pre-advance
     int pre_slot = 0;               // ... of input slot `pre_slot` at generation `pre_gen`: a slot rewritten since (dctr_input_slot_rewrite,
     uint32_t pre_gen = 0;           // or a staging copy into it) no longer matches and the hint is dropped
     std::atomic<uint32_t> slot_gen[DCTR_INPUT_SLOTS] = {};

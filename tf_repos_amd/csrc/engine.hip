@@ -262,6 +262,7 @@ int build(dctr_engine* E) {
         const bool can = c.table_mode == DCTR_TABLE_DENSE_EXACT && c.optimizer == DCTR_OPT_ADAM && !E->wnd && !c.use_graph;
         E->lag_period = can ? period : 1;
         if (E->lag_period > 1) DCTR_TRY(dmalloc(&E->row_ts, (size_t)E->rows));
+        { const char* v = getenv("DCTR_PREADVANCE"); E->preadvance = v != nullptr && v[0] == '1'; }
     }
     // owner side may receive rows from every rank; CSR models group up to max_entries ids per step
     DCTR_TRY(group_create(E->rows, E->csr ? E->max_entries : (int64_t)MB * F * c.shard_world, K, &E->group));
@@ -558,15 +559,20 @@ int forward_gather(dctr_engine* E, int B, hipStream_t st) { return gather_from(E
 // the gather of a TRAINING step whose table rows may lag (lag.h): the step's state (t, lr history) must be in place on `st`.
 // A step that reports its loss first brings every row to t-1 -- its l2 term needs sum theta^2 over the whole table, which the
 // flush accumulates.
-int forward_gather_train(dctr_engine* E, int B, hipStream_t st);
+int forward_gather_train(dctr_engine* E, int B, hipStream_t st, bool rows_current);
 int lag_flush_tables(dctr_engine* E, hipStream_t st, int offset, bool with_sums);
 bool lag_on(const dctr_engine* E);
+bool preadvance_on(const dctr_engine* E);
 bool owner_lag(const dctr_engine* E);
 LagView lag_view(const dctr_engine* E);
 
-int forward_gather_train(dctr_engine* E, int B, hipStream_t st) {
+int join_preadvance(dctr_engine* E, hipStream_t st);
+// rows_current: every row this batch reads is known to be current as of step t-1 (pre-advanced, dctr_prefetch_ids)
+int forward_gather_train(dctr_engine* E, int B, hipStream_t st, bool rows_current = false) {
     if (!lag_on(E)) return forward_gather(E, B, st);
+    DCTR_TRY(join_preadvance(E, st));
     if (E->want_loss) DCTR_TRY(lag_flush_tables(E, st, -1, true));
+    if (rows_current) return forward_gather(E, B, st);
     const LagView L = lag_view(E);
     return gather_from(E, E->emb, E->lin, E->rows, E->ids, B, st, &L);
 }
@@ -794,6 +800,10 @@ bool tail_fused(const dctr_engine* E) {
     return !off && !E->wnd && E->cfg.shard_world == 1 && (split_table_on(E) || E->cfg.table_mode != DCTR_TABLE_DENSE_EXACT);
 }
 
+// DCTR_PREADVANCE=1 (read when the handle is created): the next batch's rows are advanced ahead of its step (lag.h lag_preadvance) and
+// its gather takes the plain path.  OFF by default: the gather drops from ~16 to ~8 us, but the extra launches / event waits cost the
+// enqueueing thread more than that and the grouping + pre-advance chain lands on the step boundary (c2: 0.265-0.289 vs 0.260 ms/step)
+bool preadvance_on(const dctr_engine* E) { return E->preadvance; }
 // time-blocked sweep (lag.h): is this handle's table allowed to lag in training steps?
 bool lag_on(const dctr_engine* E) { return E->lag_period > 1 && !E->lag_suspended && split_table_on(E) && tail_fused(E); }
 // the owner side of the row-sharded path (dctr_table_gather_packed / dctr_table_apply_packed) under the same scheme: its
@@ -807,8 +817,18 @@ LagView lag_view(const dctr_engine* E) {
 }
 // every row to step state->t + offset (0: the present, between steps; -1: inside a step whose state has already advanced);
 // with_sums: sum theta^2 of all rows (at that step) into the step's loss scalars
+// a pre-advance (dctr_prefetch_ids) may still be running on the grouping stream: anything that reads or steps table rows on `st` waits
+int join_preadvance(dctr_engine* E, hipStream_t st) {
+    if (E->preadv_unjoined) {
+        DCTR_HIP_CHECK(hipStreamWaitEvent(st, E->ev_preadv, 0));
+        E->preadv_unjoined = false;
+    }
+    return DCTR_OK;
+}
+
 int lag_flush_tables(dctr_engine* E, hipStream_t st, int offset, bool with_sums) {
     if (E->lag_period <= 1) return DCTR_OK;
+    DCTR_TRY(join_preadvance(E, st));
     if (!E->lag_dirty && !with_sums) return DCTR_OK;
     DCTR_TRY(lag_flush(E->K, E->rows, E->emb, E->emb_s0, E->emb_s1, E->lin, E->lin_s0, E->lin_s1, E->row_ts, E->state, E->cfg.l2_reg, offset,
                        with_sums ? E->scalars + SUMSQ_SHARDS : nullptr, (with_sums && E->lin) ? E->scalars + 2 * SUMSQ_SHARDS : nullptr, st));
@@ -824,11 +844,12 @@ int scatter_and_step_tables(dctr_engine* E, int B, hipStream_t st, hipStream_t s
     const float* coef = mode == DCTR_GATHER_FM ? E->dy : (mode == DCTR_GATHER_BI ? E->dx_in : nullptr);
     if (tail_fused(E) && (pass == OPT_PASS_TOUCHED || c.table_mode != DCTR_TABLE_DENSE_EXACT)) {
         const bool lag = lag_on(E) && pass == OPT_PASS_TOUCHED;
+        E->slots_kept = lag && E->hint_streak && preadvance_on(E);
         // (lagging rows: sum theta^2 of the visited rows alone means nothing -- a loss-reporting step takes it from the flush)
         return embed_scatter_apply(E->group, c.optimizer, &E->state->hyper, E->h_state.hyper, E->emb, E->emb_s0, E->emb_s1, E->lin, E->lin_s0,
                                    E->lin_s1, c.l2_reg, lag ? nullptr : E->scalars + SUMSQ_SHARDS, lag ? nullptr : E->scalars + 2 * SUMSQ_SHARDS,
                                    dE, E->dE_ld, E->e, E->e_ld, E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F, E->K, mode, st, 1, nullptr,
-                                   lag ? E->row_ts : nullptr, lag ? E->state : nullptr);
+                                   lag ? E->row_ts : nullptr, lag ? E->state : nullptr, E->slots_kept);
     }
     DCTR_TRY(embed_scatter_bwd(E->group, dE, E->dE_ld, E->e, E->e_ld, E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F,
                                E->K, mode, E->group->gemb, E->lin ? E->group->glin : nullptr, st));
@@ -911,15 +932,21 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     // the per-step state kernel (5 us) runs on st: handing it to a side stream costs st a record AND a wait on a fresh
     // dependency -- two cross-queue hops of ~10 us each, measured 0.374 -> 0.351 ms/step.  DCTR_STATE_ON_SIDE=1 is the old placement
     static const bool state_on_main = getenv("DCTR_STATE_ON_SIDE") == nullptr;
+    // ids grouped ahead (dctr_prefetch_ids, during the tail of the previous step) -- and, with lagging rows, their rows pre-advanced
+    const bool pregrouped = E->pre_valid && E->pre_ids == E->ids && E->pre_B == B && E->group_alt != nullptr && !E->cfg.use_graph &&
+                            E->pre_gen == E->slot_gen[E->pre_slot].load();     // (the slot still holds what was grouped)
+    const bool rows_current = pregrouped && E->pre_advanced;
+    E->pre_advanced = false;
+    E->hint_streak = pregrouped;
     if (E->state_ready) {
         // prepared under the tail of the previous step (below): the two states / scalar sets change roles
         std::swap(E->state, E->state_alt);
         std::swap(E->scalars, E->scalars_alt);
         E->state_ready = false;
-        DCTR_TRY(forward_gather_train(E, B, st));
+        DCTR_TRY(forward_gather_train(E, B, st, rows_current));
     } else if (state_on_main || lag_on(E)) {
         DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, st));
-        DCTR_TRY(forward_gather_train(E, B, st));
+        DCTR_TRY(forward_gather_train(E, B, st, rows_current));
     } else {
         DCTR_TRY(fork(E, st, sw));
         DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, sw));
@@ -939,10 +966,11 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     static const int group_after_env = getenv("DCTR_GROUP_AFTER") ? atoi(getenv("DCTR_GROUP_AFTER")) : -1;   // A/B knob
     // the id grouping (and the background table pass behind it) on the grouping stream
     // ids grouped ahead (dctr_prefetch_ids, during the tail of the previous step): the two grouping states change roles
-    const bool pregrouped = E->pre_valid && E->pre_ids == E->ids && E->pre_B == B && E->group_alt != nullptr && !E->cfg.use_graph &&
-                            E->pre_gen == E->slot_gen[E->pre_slot].load();     // (the slot still holds what was grouped)
     E->pre_valid = false;
     if (pregrouped) std::swap(E->group, E->group_alt);
+    const bool pre_hint_stream = pregrouped && E->pre_on_hint_stream && E->ev_preadv != nullptr;
+    E->pre_on_hint_stream = false;
+    const bool clear_alt = pregrouped && E->group_alt != nullptr && !E->group_alt->slots_clean;      // (kept for the pre-advance; cleared below, on sg)
     const int group_after = group_after_env >= 0 ? group_after_env
                             : E->mlp.empty() ? 0
                             : pregrouped ? (int)E->mlp.size()
@@ -957,15 +985,25 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     const std::function<int()> start_grouping = [&]() -> int {
         if (late_sweep) return DCTR_OK;
         DCTR_TRY(fork(E, st, sg));          // not before the gather (its atomics slow a concurrent gather 4x)
+        // the previous step's grouping state kept its slot words for the pre-advance (lag.h): cleared a step before it is reused, on
+        // the stream that reuses it; this step's grouping came from that stream too: the sweep reads its slot words
+        if (pre_hint_stream) DCTR_HIP_CHECK(hipStreamWaitEvent(sg, E->ev_preadv, 0));
+        E->have_alt_ready_ev = false;
+        if (clear_alt) {        // (on sg: behind the previous step's sweep, the last reader of these slot words on this stream)
+            DCTR_TRY(group_clear_slots(E->group_alt, sg));
+            DCTR_TRY(record_on(E, sg, &E->alt_ready_ev));
+            E->have_alt_ready_ev = true;
+        }
         // (a captured step is replayed from states this enqueue cannot see: it always carries the slot-reset kernel)
         if (E->cfg.use_graph) E->group->slots_clean = false;
         if (!pregrouped) DCTR_TRY(group_ids(E->group, E->ids, B, E->F, sg, !tail_fused(E)));
         if (split_table && !bg_late) DCTR_TRY(step_untouched_rows(E, sg));
         // what the scatter needs from this stream ends here: it waits for THIS record, not for the output layer's optimizer
         // launches that follow on sg (two latency-bound kernels, ~80 us in the step: they used to hold the scatter back ~10 us)
-        if (!bg_late) { DCTR_TRY(record_on(E, sg, &tables_ev)); have_tables_ev = true; }
+        if (!bg_late) { DCTR_TRY(record_on(E, sg, &tables_ev)); have_tables_ev = true; E->sweep_ev = tables_ev; E->have_sweep_ev = true; }
         return DCTR_OK;
     };
+    E->have_sweep_ev = false;
     const bool have_mlp = !E->mlp.empty() && E->cfg.model != DCTR_MODEL_AFM;
     if (!(group_after >= 1 && have_mlp)) DCTR_TRY(start_grouping());
     DCTR_TRY(forward_rest(E, B, true, st, (group_after >= 1 && have_mlp) ? &start_grouping : nullptr, group_after - 1));
@@ -1379,13 +1417,40 @@ int dctr_prefetch_ids(dctr_handle E, const int32_t* d_ids_next, int B) {
     if (E->group_alt == nullptr) DCTR_TRY(group_create(E->rows, E->group->max_entries, E->K, &E->group_alt));
     // where the grouping of the next batch may start: behind the step's last st -> sw fork (beside scatter + table step, default),
     // or as soon as the grouping stream has drained its own work of the step (DCTR_PREGROUP_WAIT=none: beside the dense backward)
-    static const bool wait_tail = [] { const char* v = getenv("DCTR_PREGROUP_WAIT"); return v == nullptr || strcmp(v, "none") != 0; }();
-    if (E->have_tail && wait_tail) DCTR_HIP_CHECK(hipStreamWaitEvent(E->s_group, E->ev_tail, 0));
+    // With the pre-advance (lag.h) the chain grouping -> pre-advance gates the NEXT gather: it starts as soon as the grouping stream
+    // is free (it touches nothing the step in flight touches: disjoint rows, the other grouping state).
+    static const int wait_mode = [] { const char* v = getenv("DCTR_PREGROUP_WAIT"); return v == nullptr ? -1 : (strcmp(v, "none") == 0 ? 0 : 1); }();
+    const bool will_preadvance = lag_on(E) && preadvance_on(E) && E->slots_kept && E->have_sweep_ev && E->s_opt != nullptr;
+    const bool wait_tail = wait_mode == 1 || (wait_mode == -1 && !will_preadvance);
+    // ... and on a stream of its own (s_opt): the grouping stream is a serial chain of small latency-bound kernels (slot clearing, the
+    // background sweep, the output layer's optimizer launches: ~100 us at c2), behind which the four grouping kernels and the
+    // pre-advance would end AFTER the step's table step
+    hipStream_t sh = will_preadvance ? E->s_opt : E->s_group;
+    if (E->have_tail && wait_tail) DCTR_HIP_CHECK(hipStreamWaitEvent(sh, E->ev_tail, 0));
+    // (the grouping state being refilled: its slot words were cleared on s_group this step; its last pre-advance ran on s_opt)
+    if (E->have_alt_ready_ev && sh != E->s_group) DCTR_HIP_CHECK(hipStreamWaitEvent(sh, E->alt_ready_ev, 0));
+    if (E->ev_preadv != nullptr && sh != E->s_opt) DCTR_HIP_CHECK(hipStreamWaitEvent(sh, E->ev_preadv, 0));
     // (a slot filled by dctr_input_slot_fill whose copies may still be in flight: the grouping stream waits for them on the device)
-    if (E->slot_fill_pending[slot].load(std::memory_order_acquire)) DCTR_HIP_CHECK(hipStreamWaitEvent(E->s_group, E->slot_filled[slot], 0));
-    DCTR_TRY(group_ids(E->group_alt, d_ids_next, B, E->F, E->s_group, !tail_fused(E)));
+    if (E->slot_fill_pending[slot].load(std::memory_order_acquire)) DCTR_HIP_CHECK(hipStreamWaitEvent(sh, E->slot_filled[slot], 0));
+    DCTR_TRY(group_ids(E->group_alt, d_ids_next, B, E->F, sh, !tail_fused(E)));
     E->pre_ids = d_ids_next; E->pre_B = B; E->pre_valid = true;
     E->pre_slot = slot; E->pre_gen = E->slot_gen[slot].load();
+    E->pre_advanced = false;
+    // lagging rows: the rows that batch will read and the step in flight does not touch advance to the present NOW, beside that step's
+    // table step (disjoint rows: membership in the batch in flight = its grouping's slot words, which its table step was told to keep)
+    if (will_preadvance) {
+        E->slots_kept = false;
+        if (E->ev_preadv == nullptr) DCTR_HIP_CHECK(hipEventCreateWithFlags(&E->ev_preadv, hipEventDisableTiming | hipEventDisableSystemFence));
+        // (behind the step's background sweep: both replay rows no batch touched, and a row of the sweep's block may be one of these)
+        DCTR_HIP_CHECK(hipStreamWaitEvent(sh, E->sweep_ev, 0));
+        DCTR_TRY(lag_preadvance(E->K, E->rows, E->emb, E->emb_s0, E->emb_s1, E->lin, E->lin_s0, E->lin_s1, E->group_alt->uniq, E->group_alt->counters,
+                                E->group_alt->max_entries, E->group->slot, E->row_ts, E->state, E->cfg.l2_reg, sh));
+        DCTR_HIP_CHECK(hipEventRecord(E->ev_preadv, sh));
+        E->pre_on_hint_stream = true;
+        E->pre_advanced = true;
+        E->preadv_unjoined = true;
+        E->lag_dirty = true;
+    }
     return DCTR_OK;
 }
 

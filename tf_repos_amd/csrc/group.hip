@@ -530,7 +530,7 @@ __device__ __forceinline__ void table_row_step(const TableStep& T, const Hyper& 
     opt_update(KIND, h, th.w, a.w, b.w, g.w);
     T.emb[i4] = th; T.s0[i4] = a;
     if (TWO) T.s1[i4] = b;
-    if (kq == 0) T.slot[R.r] = 0;
+    if (kq == 0 && T.slot != nullptr) T.slot[R.r] = 0;
     if (KIND == DCTR_OPT_ADAM && kq == 0 && T.ts != nullptr) T.ts[R.r] = (uint8_t)T.state->t;
     if (kq == 0 && T.lin != nullptr) {
         float lt = R.lt, la = R.la, lb = R.lb;
@@ -750,7 +750,7 @@ static int launch_scatter_apply(Group* g, const float* dE, int de_ld, const floa
 int embed_scatter_apply(Group* g, int kind, const Hyper* hdev, const Hyper& hval, float* emb, float* e0, float* e1, float* lin,
                         float* l0, float* l1, float l2, float* sumsq_emb, float* sumsq_lin, const float* dE, int de_ld,
                         const float* e, int e_ld, const float* S, const float* coef, const float* dy, const float* vals, int B, int F,
-                        int K, int mode, hipStream_t st, int dy_ld, const int32_t* entry_row, uint8_t* lag_ts, const StepState* lag_state) {
+                        int K, int mode, hipStream_t st, int dy_ld, const int32_t* entry_row, uint8_t* lag_ts, const StepState* lag_state, bool keep_slots) {
     DCTR_REQUIRE(K == g->K, "scatter: K=%d but group was created with K=%d", K, g->K);
     DCTR_REQUIRE(lag_ts == nullptr || (kind == DCTR_OPT_ADAM && lag_state != nullptr), "scatter_apply: lagging rows are an Adam-only scheme");
     DCTR_REQUIRE(g->gemb_clean, "scatter_apply: the group's compact gradient rows are not known to be zero");
@@ -759,8 +759,8 @@ int embed_scatter_apply(Group* g, int kind, const Hyper* hdev, const Hyper& hval
                  "scatter: FM/BI modes need e, S and coef");
     DCTR_REQUIRE((lin != nullptr) == (dy != nullptr), "scatter_apply: linear weights and their gradient source go together");
     TableStep T{reinterpret_cast<float4*>(emb), reinterpret_cast<float4*>(e0), reinterpret_cast<float4*>(e1), lin, l0, l1, hdev, hval,
-                l2, sumsq_emb, sumsq_lin, g->uniq, g->slot, g->done, lag_ts, lag_state};
-    g->slots_clean = true;                  // (every distinct id of the grouping is visited exactly once, and each visit clears its slot word)
+                l2, sumsq_emb, sumsq_lin, g->uniq, keep_slots ? nullptr : g->slot, g->done, lag_ts, lag_state};
+    g->slots_clean = !keep_slots;           // (every distinct id of the grouping is visited exactly once, and each visit clears its slot word)
 #define DCTR_Q(KD, Q) case Q: return launch_scatter_apply<KD, Q>(g, dE, de_ld, e, e_ld, S, coef, dy, vals, B, F, mode, dy_ld, st, entry_row, T)
 #define DCTR_KD(KD) case KD: switch (K / 4) { DCTR_Q(KD, 1); DCTR_Q(KD, 2); DCTR_Q(KD, 4); DCTR_Q(KD, 8); DCTR_Q(KD, 16); DCTR_Q(KD, 32); DCTR_Q(KD, 64); \
                               default: set_error("scatter: K=%d unsupported", K); return DCTR_ERR_UNSUPPORTED; }
@@ -809,6 +809,14 @@ int group_destroy(Group* g) {
     hipFree(g->slot); hipFree(g->uniq); hipFree(g->cnt); hipFree(g->seg_start); hipFree(g->cursor);
     hipFree(g->perm); hipFree(g->seg_of); hipFree(g->counters); hipFree(g->gemb); hipFree(g->glin); hipFree(g->long_list); hipFree(g->done); hipFree(g->medium_list);
     delete g;
+    return DCTR_OK;
+}
+
+int group_clear_slots(Group* g, hipStream_t st) {
+    if (g->slots_clean) return DCTR_OK;
+    group_reset_kernel<<<ceil_div(g->max_entries, 256), 256, 0, st>>>(g->slot, g->uniq, g->counters, (int)g->max_entries);
+    DCTR_LAUNCH_CHECK();
+    g->slots_clean = true;
     return DCTR_OK;
 }
 

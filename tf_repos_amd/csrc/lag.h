@@ -210,5 +210,9 @@ int lag_sweep(int K, int64_t rows, float* emb, float* s0, float* s1, float* lin,
 int lag_flush(int K, int64_t rows, float* emb, float* s0, float* s1, float* lin, float* l0, float* l1, uint8_t* ts, const StepState* state,
               float l2, int target_offset, float* sumsq_emb, float* sumsq_lin, hipStream_t st);
 int lag_stamp(uint8_t* ts, int64_t rows, const StepState* state, hipStream_t st);
+// the distinct rows of the NEXT batch (uniq_next[0 : *n_next)) that the batch in flight does not touch (cur_slot word 0) advance to the
+// step in flight, so that the next step's gather finds every row it reads current and takes the plain path (lag.h, header)
+int lag_preadvance(int K, int64_t rows, float* emb, float* s0, float* s1, float* lin, float* l0, float* l1, const int32_t* uniq_next,
+                   const int32_t* n_next, int64_t cap, const int32_t* cur_slot, uint8_t* ts, const StepState* state, float l2, hipStream_t st);
 
 }  // namespace dctr

@@ -108,6 +108,59 @@ __global__ __launch_bounds__(256) void lag_stamp_kernel(uint8_t* __restrict__ ts
     else for (int64_t k = i; k < rows; ++k) ts[k] = v;
 }
 
+// one row piece per lane (KQ lanes per row), 2 rows in flight per lane: the next batch's distinct rows, minus the ones the batch in
+// flight steps itself, to the step in flight -- the row arithmetic of lag_advance_kernel
+template <int KQ>
+__global__ __launch_bounds__(256) void lag_preadvance_kernel(float4* __restrict__ emb, float4* __restrict__ s0, float4* __restrict__ s1,
+                                                            float* __restrict__ lin, float* __restrict__ l0, float* __restrict__ l1,
+                                                            const int32_t* __restrict__ uniq, const int32_t* __restrict__ n_ptr, int64_t cap,
+                                                            const int32_t* __restrict__ cur_slot, uint8_t* __restrict__ ts,
+                                                            const StepState* __restrict__ S, float l2) {
+    constexpr int UNR = 2;
+    const int64_t T = S->t;
+    const Hyper h = S->hyper;
+    const int64_t U = min((int64_t)n_ptr[0], cap);
+    const int64_t n_items = U * KQ;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t0 < n_items; t0 += stride * UNR) {
+        float4 th[UNR], m[UNR], v[UNR];
+        float lt[UNR], lm[UNR], lv[UNR];
+        int n[UNR], nl[UNR];
+        int64_t row[UNR];
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            const int64_t t = t0 + j * stride;
+            const bool live = t < n_items;
+            row[j] = live ? uniq[t / KQ] : 0;
+            n[j] = (live && cur_slot[row[j]] == 0) ? lag_behind(T, ts[row[j]]) : 0;     // (rows of the batch in flight: its own table step stamps them T)
+        }
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            const int kq = (int)((t0 + j * stride) % KQ);
+            th[j] = m[j] = v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            lt[j] = lm[j] = lv[j] = 0.f;
+            nl[j] = 0;
+            if (n[j] > 0) {
+                const size_t i4 = (size_t)row[j] * KQ + kq;
+                th[j] = emb[i4]; m[j] = s0[i4]; v[j] = s1[i4];
+                if (kq == 0 && lin != nullptr) { lt[j] = lin[row[j]]; lm[j] = l0[row[j]]; lv[j] = l1[row[j]]; nl[j] = n[j]; }
+            }
+        }
+        lag_catch_up_rows_lin<UNR>(S, h, l2, T, n, th, m, v, nl, lt, lm, lv);
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            if (n[j] <= 0) continue;
+            const int kq = (int)((t0 + j * stride) % KQ);
+            const size_t i4 = (size_t)row[j] * KQ + kq;
+            emb[i4] = th[j]; s0[i4] = m[j]; s1[i4] = v[j];
+            if (kq == 0) {
+                if (lin != nullptr) { lin[row[j]] = lt[j]; l0[row[j]] = lm[j]; l1[row[j]] = lv[j]; }
+                ts[row[j]] = (uint8_t)T;
+            }
+        }
+    }
+}
+
 template <bool FLUSH>
 int launch_advance(int K, int64_t rows, float* emb, float* s0, float* s1, float* lin, float* l0, float* l1, const int32_t* slot, uint8_t* ts,
                    const StepState* state, float l2, int period, int target_offset, float* sumsq_emb, float* sumsq_lin, hipStream_t st) {
@@ -138,6 +191,22 @@ int lag_sweep(int K, int64_t rows, float* emb, float* s0, float* s1, float* lin,
 int lag_flush(int K, int64_t rows, float* emb, float* s0, float* s1, float* lin, float* l0, float* l1, uint8_t* ts, const StepState* state,
               float l2, int target_offset, float* sumsq_emb, float* sumsq_lin, hipStream_t st) {
     return launch_advance<true>(K, rows, emb, s0, s1, lin, l0, l1, nullptr, ts, state, l2, 1, target_offset, sumsq_emb, sumsq_lin, st);
+}
+
+int lag_preadvance(int K, int64_t rows, float* emb, float* s0, float* s1, float* lin, float* l0, float* l1, const int32_t* uniq_next,
+                   const int32_t* n_next, int64_t cap, const int32_t* cur_slot, uint8_t* ts, const StepState* state, float l2, hipStream_t st) {
+    const int KQ = K / 4;
+    // (a background kernel beside the table step: a small grid; the distinct rows of a batch are ~1e5 at c2)
+    const int grid = (int)std::min<int64_t>(ceil_div(cap * KQ, 256 * 2), 256 * 2);
+    float4 *e4 = reinterpret_cast<float4*>(emb), *a4 = reinterpret_cast<float4*>(s0), *b4 = reinterpret_cast<float4*>(s1);
+    switch (KQ) {
+#define DCTR_P(Q) case Q: lag_preadvance_kernel<Q><<<grid, 256, 0, st>>>(e4, a4, b4, lin, l0, l1, uniq_next, n_next, cap, cur_slot, ts, state, l2); break
+        DCTR_P(1); DCTR_P(2); DCTR_P(4); DCTR_P(8); DCTR_P(16); DCTR_P(32); DCTR_P(64);
+#undef DCTR_P
+        default: set_error("lag: K=%d unsupported", K); return DCTR_ERR_UNSUPPORTED;
+    }
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
 }
 
 int lag_stamp(uint8_t* ts, int64_t rows, const StepState* state, hipStream_t st) {

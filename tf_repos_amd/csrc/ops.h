@@ -61,11 +61,12 @@ inline int64_t group_capacity(const Group* g) { return g->max_entries; }
 int group_create(int64_t rows, int64_t max_entries, int K, Group** out);
 int group_destroy(Group* g);
 int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st, bool zero_gemb = true);
+int group_clear_slots(Group* g, hipStream_t st);     // slot words of the last grouped batch back to 0 (a table step that was told to keep them)
 int embed_scatter_apply(Group* g, int kind, const Hyper* hdev, const Hyper& hval, float* emb, float* e0, float* e1, float* lin,
                         float* l0, float* l1, float l2, float* sumsq_emb, float* sumsq_lin, const float* dE, int de_ld,
                         const float* e, int e_ld, const float* S, const float* coef, const float* dy, const float* vals, int B, int F,
                         int K, int mode, hipStream_t st, int dy_ld = 1, const int32_t* entry_row = nullptr, uint8_t* lag_ts = nullptr,
-                        const StepState* lag_state = nullptr);
+                        const StepState* lag_state = nullptr, bool keep_slots = false);     // keep_slots: the grouping's slot words stay (something reads them beside this launch)
 int embed_scatter_bwd(Group* g, const float* dE, int de_ld, const float* e, int e_ld, const float* S,
                       const float* coef, const float* dy, const float* vals, int B, int F, int K, int mode,
                       float* gemb, float* glin, hipStream_t st, int dy_ld = 1,     // dy_ld: stride (floats) between examples in dy
