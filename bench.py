@@ -37,8 +37,8 @@ CONFIGS = {
                name="DeepFM 39 fields, vocab 1e8 row-sharded, emb_dim 32, batch 8192/GPU (65536 at 8 GPUs), MLP 400-400-400 keep 0.5, "
                     "Adam (BASELINE configs[4])"),
 }
-PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.txt")
-STATS_FILE = os.path.join("profiles", "r03_kernel_stats.txt")     # rocprofv3 --kernel-trace --stats of this same command
+PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.txt")
+STATS_FILE = os.path.join("profiles", "r04_kernel_stats.txt")     # rocprofv3 --kernel-trace --stats of this same command
 LIB_FILE = os.path.join("tf_repos_amd", "_lib", "libdeepctr_hip.so")
 
 
@@ -200,6 +200,49 @@ def hbm_resident_gather(dev, K=16, V=64 * 1024 * 1024, B=4096, F=39, iters=200):
     return ms, B * (F * (12 + 8 * K) + 8)
 
 
+def end_to_end(w, epochs=40, lines=32768 * 12):
+    """What a user of the reference runs: `tf.estimator.Estimator(model_fn, ...).train(input_fn)` over a libsvm TEXT file
+    (examples/ctr_estimator.py: the model_fn / input_fn of DeepFM.py:63-221 written against the tensorflow surface of tf_shim) --
+    parse (C parser, threads), batching, H2D through the engine's input slots, train steps, checkpoint save; one short call first so
+    that the timed one does not carry the first-use costs (library load, engine allocation).  examples/s = examples / wall time
+    of the whole train() call.  Never `value`: a reported product-level rate beside it."""
+    import importlib.util
+    import tempfile
+    import torch
+    from tf_repos_amd.synth import synth_batch, to_libsvm
+    import tf_repos_amd.tf_shim as shim
+    d = tempfile.mkdtemp(prefix="dctr_e2e_")
+    B, F, V = w["batch"], w["field_size"], w["feature_size"]
+    chunk = "".join(to_libsvm(*synth_batch(4096, F, V, seed=77 + i)) for i in range(8))        # 32 768 distinct lines
+    path, small = os.path.join(d, "tr.libsvm"), os.path.join(d, "warm.libsvm")
+    with open(path, "w") as f:
+        for _ in range(max(1, lines // 32768)):
+            f.write(chunk)
+    with open(small, "w") as f:
+        f.write(chunk)
+    n_lines = 32768 * max(1, lines // 32768)
+    shim.install()
+    spec = importlib.util.spec_from_file_location("ctr_estimator_example", os.path.join(ROOT, "examples", "ctr_estimator.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    p = dict(model=w["model"], field_size=F, feature_size=V, embedding_size=w["embedding_size"], learning_rate=w["learning_rate"], l2_reg=w["l2_reg"],
+             deep_layers=",".join(str(h) for h in w["deep_layers"]), dropout=",".join(str(k) for k in w["dropout"]), cross_layers=3,
+             optimizer=w["optimizer"])
+    est = mod.build_estimator(p, os.path.join(d, "ckpt"), log_steps=10 ** 9)
+    est.train(input_fn=lambda: mod.input_fn([small], num_epochs=1, batch_size=B))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    est.train(input_fn=lambda: mod.input_fn([path], num_epochs=epochs, batch_size=B))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps = n_lines * epochs // B
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
+    return {"examples_per_sec": round(n_lines * epochs / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps, "wall_s": round(dt, 3),
+            "what": "tf.estimator.Estimator.train (tf_shim) over a %d-line libsvm text file x %d epochs, batch %d: text parse + batching + H2D into the "
+                    "engine's input slots + train steps + checkpoint save; wall time of the whole call" % (n_lines, epochs, B)}
+
+
 def main():
     # stdout carries exactly ONE line, the JSON: everything else that native libraries print there (RCCL writes a version banner
     # to stdout at exit) is sent to stderr by pointing fd 1 at fd 2 and keeping the real stdout aside for the final line
@@ -217,8 +260,10 @@ def main():
     ap.add_argument("--selftest", action="store_true", help="multi-GPU: first check that the N-rank loss of step 0 equals one rank's on the same global batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-classic-reference", action="store_true", help="skip the 200-step reference run with the classic table sweep")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the Estimator.train block (text parse + H2D + steps)")
     ap.add_argument("--cpu-steps", type=int, default=200)
     ap.add_argument("--uniform-ids", action="store_true", help="uniform ids instead of Zipf (cache-worst case)")
+    ap.add_argument("--feature-size", type=int, default=0, help="override the config's vocabulary (tools/c5_shard_projection.py: ONE shard of c5's table, V / 8 rows, on one GPU)")
     ap.add_argument("--sweep-period", type=int, default=0, help="dense_exact + Adam: period of the time-blocked table sweep (0 = library default, 1 = classic: every row every step)")
     args = ap.parse_args()
 
@@ -235,6 +280,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     w = dict(CONFIGS[args.config])
+    if args.feature_size > 0:
+        w["feature_size"] = args.feature_size
+        w["name"] += " [feature_size overridden: %d]" % args.feature_size
     w["table_sweep_period"] = args.sweep_period          # (row-sharded runs: the native driver's owner side, csrc/lag.h)
     # (--selftest keeps the workload's dropout: a mask is a function of the GLOBAL example row -- StepState::row0 -- so N ranks draw
     #  exactly what one rank draws on the same global batch)
@@ -392,8 +440,10 @@ def main():
         table_bytes = 6 * rows * (K + 1) * 4 + 4 * rows
         mlp0_flops = 2.0 * B * (F * K) * w["deep_layers"][0]
         kernels = {
-            "opt_table_dense_adam": {"bound": "hbm", "ms": stages["opt_table"], "achieved": table_bytes / stages["opt_table"] / 1e6,
-                                     "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+            # (the CLASSIC sweep -- every row of the table through HBM -- timed alone; the timed steps run the time-blocked sweep instead:
+            #  roofline.hbm_kernel below)
+            "opt_table_dense_adam_classic": {"bound": "hbm", "ms": stages["opt_table"], "achieved": table_bytes / stages["opt_table"] / 1e6,
+                                             "peak": HBM_PEAK_GBS, "unit": "GB/s"},
             "mlp0_fwd_gemm": {"bound": "mfma", "ms": stages["mlp0_fwd"], "achieved": mlp0_flops / stages["mlp0_fwd"] / 1e9,
                               "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s"},
             "mlp0_dgrad_gemm": {"bound": "mfma", "ms": stages["mlp0_dgrad"], "achieved": mlp0_flops / stages["mlp0_dgrad"] / 1e9,
@@ -449,9 +499,28 @@ def main():
         stale = [f for f in (PMC_FILE, STATS_FILE) if profile_is_stale(f)]
         if stale:
             r["profile_warning"] = "older than the built library, re-run tools/profile_round.sh: " + ", ".join(stale)
-        hk = dict(kernels["opt_table_dense_adam"])
-        hk["traffic"] = pmc_traffic_bytes("void dctr::opt_table_kernel<0, 4, true>") if (not sharded and args.config == "c2") else None
+        # the step's largest HBM stream AS THE TIMED STEPS RUN IT: the background sweep over 1/N of the table per step (csrc/lag.h),
+        # by rocprofv3's in-step duration and PMC bytes of exactly that kernel (committed summaries of this same command)
+        period = out["config"]["table_sweep_period"]
+        sweep_name = "void dctr::(anonymous namespace)::lag_advance_kernel<%d, false, 4>" % (K // 4)
+        if period > 1 and not sharded:
+            sweep_bytes = (6 * (K + 1) * 4 + 4 + 1) * ((rows + period - 1) // period)      # theta, m, v read + write of 1/N of the rows, slot word, stamp
+            sweep_us = rocprof_avg_us(sweep_name) if args.config == "c2" else None
+            hk = {"kernel": "lag_advance_kernel<%d, false, 4> (background sweep of 1/%d of the table per step, lagging rows replayed in registers)" % (K // 4, period),
+                  "bound": "hbm", "algorithmic_bytes": int(sweep_bytes), "traffic": pmc_traffic_bytes(sweep_name) if args.config == "c2" else None,
+                  "us_in_step": sweep_us, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "achieved": round(sweep_bytes / sweep_us / 1e3, 2) if sweep_us else None,
+                  "frac": round(sweep_bytes / sweep_us / 1e3 / HBM_PEAK_GBS, 4) if sweep_us else None,
+                  "note": "ALU-bound, not HBM-bound: every row replays up to %d Adam steps in registers (V (K+1) element-updates per step however "
+                          "scheduled); it runs under the backward GEMMs.  The classic sweep it replaces: kernels.opt_table_dense_adam_classic" % period}
+        else:
+            hk = dict(kernels["opt_table_dense_adam_classic"])
+            hk["traffic"] = pmc_traffic_bytes("void dctr::opt_table_kernel<0, 4, true>") if (not sharded and args.config == "c2") else None
         r["hbm_kernel"] = hk
+        # the whole step against the matrix pipes: forward + dgrad + wgrad flops of the MLP over ms_per_step
+        step_flops = 3 * sum(2.0 * B * dims[i] * dims[i + 1] for i in range(len(dims) - 1))
+        r["step_mfma_frac"] = round(step_flops / (out["ms_per_step"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFS, 4)
+        r["step_gemm_gflop"] = round(step_flops / 1e9, 3)
         r["traffic_source"] = PMC_FILE + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch of the exactly named kernel (gfx950 FETCH_SIZE counts 1/2 of 16-B/lane streams; MI355X_MICROARCH.md HBM section)"
         out["roofline"] = r
         out["kernels"] = kernels
@@ -478,6 +547,11 @@ def main():
             torch.cuda.synchronize()
             out["classic_sweep_ms_per_step"] = round(1e3 * (time.perf_counter() - tr0) / 200, 4)
             ref.close()
+        if not sharded and not big and not args.no_end_to_end:
+            try:
+                out["end_to_end"] = end_to_end(w)
+            except Exception as e:                                                     # noqa: BLE001  (a reported extra, never `value`)
+                out["end_to_end"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if not sharded and not args.no_cpu_baseline and not big:
             out["cpu_baseline"] = cpu_baseline(w, steps=args.cpu_steps)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)

@@ -319,6 +319,18 @@ int dctr_fc_bwd_weights(const float* d_x, int ldx, const float* d_dy, int lddy, 
                         int M, int K, int N, float* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K3/K5/K4: interaction layers ------------------------------------------------------ */
+/* AFM's attention-weighted pairwise interaction (AFM.py:127-158) as an op.  It needs the attention network's variables and ~B P (K + A)
+ * floats of workspace, so it runs ON AN AFM HANDLE (dctr_create with model afm: attention_layers, keep_prob[0] = attention dropout,
+ * keep_prob[1] = pooled-embedding dropout; the variables are set with dctr_param_set under the handle's names (dctr_param_info):
+ * "att_mlp0/weights" [K,A], "att_mlp0/biases" [A] (AFM.py:145, TF scope mlp0), "attention_out/weights" [A,1], "attention_out/biases" [1]
+ * (AFM.py:147)).
+ *   fwd: d_e [B, e_ld] the value-scaled embeddings e[b,f,:] (AFM.py:129-130) -> d_y_emb [B, y_ld]: sum_p a'[b,p] e_i (.) e_j after both
+ *        dropouts when train != 0 (masks of the handle's seed / global_step: include "dropout sites"); d_att [B, P] (optional): the
+ *        softmax weights (AFM.py:151, before their dropout), pairs in the reference's (i < j) double-loop order (AFM.py:134-136).
+ *   bwd: d_dy_emb [B, dy_ld] = dL/d y_emb -> d_dE [B, de_ld] = dL/de through pair products, attention network and softmax; the
+ *        attention variables' gradients are read with dctr_param_grad_get.  Must follow dctr_afm_fwd of the same batch. */
+int dctr_afm_fwd(dctr_handle h, const float* d_e, int e_ld, int B, int train, float* d_y_emb, int y_ld, float* d_att, void* stream);
+int dctr_afm_bwd(dctr_handle h, const float* d_dy_emb, int dy_ld, int B, float* d_dE, int de_ld, void* stream);
 /* PNN inner product (PNN.py:141-152): ip[b,p] = <e[b,i_p,:], e[b,j_p,:]>, pairs lexicographic i<j. */
 int dctr_pnn_inner_fwd(const float* d_e, int e_ld, int B, int F, int K, float* d_ip, int ip_ld, void* stream);
 /* dE[b,i,:] += sum_j dip[b,pair(i,j)] e[b,j,:]   (accumulates into d_dE) */
@@ -374,6 +386,9 @@ int dctr_param_info(dctr_handle h, int index, const char** name, int* rank, int6
 int dctr_param_set(dctr_handle h, const char* name, const float* h_src, size_t nbytes);
 int dctr_param_get(dctr_handle h, const char* name, float* h_dst, size_t nbytes);
 /* optimizer slots: which = 0/1 (see dctr_opt_dense) */
+/* gradient of a dense (non-table) variable as of the last backward pass: its partial slabs summed (what the optimizer step consumes),
+ * logical shape, host destination.  For gradient-level parity (tests/test_afm_grad_gpu.py) and the op-level interaction entries. */
+int dctr_param_grad_get(dctr_handle h, const char* name, float* h_dst, size_t nbytes);
 int dctr_slot_get(dctr_handle h, const char* name, int which, float* h_dst, size_t nbytes);
 int dctr_slot_set(dctr_handle h, const char* name, int which, const float* h_src, size_t nbytes);
 int dctr_param_device_ptr(dctr_handle h, const char* name, float** d_ptr);

@@ -53,6 +53,10 @@ def test_afm_gradients_at_the_run_sh_operating_point(dev):
         err_o32 = float(np.abs(g32[name].double().numpy() - truth).max())
         report[name] = (err_eng / scale, err_o32 / scale)
         assert err_eng <= max(4.0 * err_o32, 1e-6 * scale), (name, err_eng, err_o32, scale)
+        if name not in ("emb", "linear"):       # the same gradient read directly (dctr_param_grad_get: the partial slabs of the backward, summed)
+            g_direct = eng.get_grad(name).astype(np.float64).reshape(truth.shape)
+            l2_term = 0.0                       # (AFM's loss regularises the two tables only, AFM.py:180-181)
+            assert float(np.abs(g_direct + l2_term - truth).max()) <= max(4.0 * err_o32, 1e-6 * scale), name
     print("AFM K=256 A=128 Adam, |g_engine - g_fp64| / max|g| (fp32 oracle beside it):",
           {k: "%.1e (%.1e)" % v for k, v in report.items()})
     # four more steps under Adam; elements whose gradient was rounding noise at any step are left out (Adam amplifies their noise in

@@ -124,6 +124,57 @@ def test_outer_pnn_first_layer_ops_through_the_c_abi(K, H, B, F, dev):
     assert (dEg.cpu().double() - dE.reshape(B, F * K)).abs().max() <= 1e-5
 
 
+@pytest.mark.parametrize("K,A,B,F,keep", [(16, 32, 96, 39, (1.0, 1.0)), (16, 32, 64, 12, (0.7, 0.6)), (256, 128, 24, 39, (0.5, 0.5)), (8, 16, 50, 10, (1.0, 1.0))])
+def test_afm_interaction_ops_through_the_c_abi(K, A, B, F, keep, dev):
+    """dctr_afm_fwd / dctr_afm_bwd (AFM.py:127-158: pair products, attention network, softmax over the pairs, both dropouts, pooling)
+    against the same lines written out in fp64 with autograd; the attention variables' gradients through dctr_param_grad_get.
+    K = 16 takes the fused attention kernels, K = 256 / A = 128 (run.sh:18) the layer-by-layer path with the products carrying
+    attention_out, K = 8 the small-row forms."""
+    from tf_repos_amd import capi
+    from tf_repos_amd.engine import Engine, EngineConfig
+    P = F * (F - 1) // 2
+    g = torch.Generator().manual_seed(11)
+    e = torch.randn(B, F, K, generator=g) * 0.3
+    W = torch.randn(K, A, generator=g) * 0.2
+    b = torch.randn(A, generator=g) * 0.1
+    wo = torch.randn(A, 1, generator=g) * 0.3
+    bo = torch.randn(1, generator=g) * 0.1
+    dy = torch.randn(B, K, generator=g) * 0.1
+    eng = Engine(EngineConfig(model="afm", field_size=F, feature_size=100, embedding_size=K, deep_layers=(1,), attention_layers=(A,), dropout=keep,
+                              l2_reg=0.0, learning_rate=1e-3, optimizer="Adam", max_batch=B, seed=5))
+    for name, v in (("att_mlp0/weights", W), ("att_mlp0/biases", b), ("attention_out/weights", wo), ("attention_out/biases", bo)):
+        eng.set_param(name, v.numpy())
+    train = min(keep) < 1.0
+    # (the op draws its masks at the handle's CURRENT step state: a fresh handle stands at global_step 0, seed_t = seed)
+    m_att = torch.from_numpy(eng.dropout_mask(capi.SITE_AFM_ATT, (B, P, 1), keep[0], step=0).astype(np.float64)) if train else torch.ones(B, P, 1, dtype=torch.float64)
+    m_emb = torch.from_numpy(eng.dropout_mask(capi.SITE_AFM_YEMB, (B, K), keep[1], step=0).astype(np.float64)) if train else torch.ones(B, K, dtype=torch.float64)
+    if train:
+        assert 0.05 < float(m_att.mean()) < 0.95 and 0.05 < float(m_emb.mean()) < 0.95
+    # fp64 reference with autograd
+    e64 = e.double().requires_grad_(True)
+    prm = [t.double().requires_grad_(True) for t in (W, b, wo, bo)]
+    row = [i for i in range(F - 1) for _ in range(i + 1, F)]
+    col = [j for i in range(F - 1) for j in range(i + 1, F)]
+    pp = e64[:, row, :] * e64[:, col, :]                                        # AFM.py:134-138
+    ah = torch.relu(pp.reshape(-1, K) @ prm[0] + prm[1])                        # AFM.py:142-145
+    sc = (ah @ prm[2] + prm[3]).reshape(B, P, 1)                                # AFM.py:147
+    soft = torch.softmax(sc, dim=1)                                             # AFM.py:151
+    a_d = soft * m_att / keep[0]                                                # AFM.py:152-153
+    y = (a_d * pp).sum(1) * m_emb / keep[1]                                     # AFM.py:156-158
+    y.backward(dy.double())
+    y_gpu, att = eng.afm_fwd(e.reshape(B, F * K).to(dev), train=train, want_att=True)
+    assert (y_gpu.cpu().double() - y.detach()).abs().max() <= 2e-6 * max(1.0, float(y.detach().abs().max()))
+    assert (att.cpu().double() - soft.detach().reshape(B, P)).abs().max() <= 1e-6         # (the softmax weights, before their dropout)
+    dE = eng.afm_bwd(dy.to(dev))
+    assert (dE.cpu().double() - e64.grad.reshape(B, F * K)).abs().max() <= 2e-6 * max(1.0, float(e64.grad.abs().max()))
+    for name, t in zip(("att_mlp0/weights", "att_mlp0/biases", "attention_out/weights", "attention_out/biases"), prm):
+        got = eng.get_grad(name).astype(np.float64).reshape(t.shape)
+        scale = max(1e-3, float(t.grad.abs().max()))
+        # (attention_out's bias has gradient exactly 0 -- the softmax is shift-invariant -- and fp32 leaves ~1e-8 of rounding there)
+        assert np.abs(got - t.grad.numpy()).max() <= max(3e-6 * scale, 1e-7), (name, np.abs(got - t.grad.numpy()).max(), scale)
+    eng.close()
+
+
 @pytest.mark.parametrize("att", [(16, 8), (24, 12, 8)])
 def test_afm_multi_layer_attention(att, dev):
     """AFM.py:143-145 loops over --attention_layers: more than one width runs layer by layer over the B*P pair rows."""

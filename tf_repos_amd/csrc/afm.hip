@@ -861,12 +861,19 @@ static int afm_pool_bwd(dctr_engine* E, int b0, int n, hipStream_t st) {
 
 // leaves dL/de in E->dE_buf; dense-gradient partial slabs in E->parts
 int afm_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
-    const int F = E->F, K = E->K, P = E->P, A = E->A;
+    const int K = E->K;
     const Param& pw = E->params[E->p_out_w];
     const Param& pb = E->params[E->p_out_b];
     // deep_out (K -> 1): d y_emb(post-dropout) = dy (x) w_d into dx_in; dW/db partial slabs
     DCTR_TRY(out_layer_bwd(E->x_in, E->Din_ld, E->dy, E->pp(E->p_out_w), B, K, pw.n_part, 0, 1.f, E->dx_in, E->Din_ld,
                            E->part(E->p_out_w), pw.padded, E->part(E->p_out_b), pb.padded, st));
+    return afm_interaction_backward(E, B, st, sw);
+}
+
+// the interaction layer alone (AFM.py:127-158 backward): dx_in [B, K] holds dL/d y_emb (after its dropout) on entry; leaves dL/de in
+// dE_buf and the attention variables' partial slabs
+int afm_interaction_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t sw) {
+    const int F = E->F, K = E->K, P = E->P, A = E->A;
     // (E->sc, the forward's scores, is free by now: it takes the post-dropout attention)
     const Param& aw = E->params[E->p_ao_w];
     const Param& ab = E->params[E->p_ao_b];

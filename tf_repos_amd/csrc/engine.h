@@ -225,3 +225,4 @@ int afm_alloc(dctr_engine* E);
 void afm_free(dctr_engine* E);
 int afm_forward(dctr_engine* E, int B, bool train, hipStream_t st);
 int afm_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t sw);
+int afm_interaction_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t sw);

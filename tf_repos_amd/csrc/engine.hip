@@ -1309,6 +1309,13 @@ static int copy_param(dctr_handle E, const char* name, int which, void* host, si
     DCTR_REQUIRE(nbytes == (size_t)p->log_n * sizeof(float), "parameter '%s' holds %lld floats, caller passed %zu bytes", name,
                  (long long)p->log_n, nbytes);
     float* d = which < 0 ? p->ptr : (which == 0 ? p->s0 : p->s1);
+    if (which == 2) {           // the gradient of a dense variable: its partial slabs of the last backward pass, summed
+        DCTR_REQUIRE(!p->is_table && !to_device, "dctr_param_grad_get: dense variables only (a table's gradient lives in the compact rows of the grouping)");
+        DCTR_HIP_CHECK(hipDeviceSynchronize());
+        DCTR_TRY(opt_dense_arena(E->cfg.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->parts, E->meta, E->n_blocks,
+                                 E->gflat, 0, nullptr, nullptr));
+        d = E->gflat + p->arena_off;
+    }
     DCTR_REQUIRE(d != nullptr, "parameter '%s' has no such slot", name);
     DCTR_HIP_CHECK(hipDeviceSynchronize());
     if (p->is_table && E->lag_dirty) {           // lagging rows (lag.h): the table as of global_step is what is read -- and what a write replaces
@@ -1343,6 +1350,7 @@ int dctr_param_set(dctr_handle h, const char* name, const float* h_src, size_t n
     return copy_param(h, name, -1, const_cast<float*>(h_src), nbytes, true);
 }
 int dctr_param_get(dctr_handle h, const char* name, float* h_dst, size_t nbytes) { return copy_param(h, name, -1, h_dst, nbytes, false); }
+int dctr_param_grad_get(dctr_handle h, const char* name, float* h_dst, size_t nbytes) { return copy_param(h, name, 2, h_dst, nbytes, false); }
 int dctr_slot_get(dctr_handle h, const char* name, int which, float* h_dst, size_t nbytes) {
     DCTR_REQUIRE(which == 0 || which == 1, "slot index must be 0 or 1");
     return copy_param(h, name, which, h_dst, nbytes, false);
@@ -2029,6 +2037,33 @@ int dctr_dense_apply(dctr_handle E, void* stream) {
 int dctr_read_scalars(dctr_handle E, float h_out[4], void* stream) {
     DCTR_REQUIRE(E && h_out, "null argument");
     return read_scalars(E, h_out, as_stream(stream));
+}
+
+// ---- AFM's interaction layer as an op (AFM.py:127-158), on an AFM handle: the attention variables are the handle's (dctr_param_set by
+// their TF names), the workspace too.
+int dctr_afm_fwd(dctr_handle E, const float* d_e, int e_ld, int B, int train, float* d_y_emb, int y_ld, float* d_att, void* stream) {
+    DCTR_REQUIRE(E && d_e && d_y_emb, "null argument");
+    DCTR_REQUIRE(E->cfg.model == DCTR_MODEL_AFM, "dctr_afm_fwd: the handle's model is not afm");
+    DCTR_REQUIRE(B > 0 && B <= E->MB && e_ld >= E->D && y_ld >= E->K, "dctr_afm_fwd: bad sizes B=%d e_ld=%d y_ld=%d", B, e_ld, y_ld);
+    hipStream_t st = as_stream(stream);
+    DCTR_HIP_CHECK(hipMemcpy2DAsync(E->e, (size_t)E->e_ld * 4, d_e, (size_t)e_ld * 4, (size_t)E->D * 4, B, hipMemcpyDeviceToDevice, st));
+    DCTR_TRY(afm_forward(E, B, train != 0, st));
+    DCTR_HIP_CHECK(hipMemcpy2DAsync(d_y_emb, (size_t)y_ld * 4, E->x_in, (size_t)E->Din_ld * 4, (size_t)E->K * 4, B, hipMemcpyDeviceToDevice, st));
+    if (d_att != nullptr) DCTR_HIP_CHECK(hipMemcpyAsync(d_att, E->att, (size_t)B * E->P * 4, hipMemcpyDeviceToDevice, st));
+    E->last_B = B;
+    return DCTR_OK;
+}
+
+int dctr_afm_bwd(dctr_handle E, const float* d_dy_emb, int dy_ld, int B, float* d_dE, int de_ld, void* stream) {
+    DCTR_REQUIRE(E && d_dy_emb && d_dE, "null argument");
+    DCTR_REQUIRE(E->cfg.model == DCTR_MODEL_AFM, "dctr_afm_bwd: the handle's model is not afm");
+    DCTR_REQUIRE(B > 0 && B == E->last_B && dy_ld >= E->K && de_ld >= E->D, "dctr_afm_bwd: call dctr_afm_fwd on the same batch first (B=%d, last %d)", B, E->last_B);
+    hipStream_t st = as_stream(stream);
+    DCTR_HIP_CHECK(hipMemcpy2DAsync(E->dx_in, (size_t)E->Din_ld * 4, d_dy_emb, (size_t)dy_ld * 4, (size_t)E->K * 4, B, hipMemcpyDeviceToDevice, st));
+    DCTR_TRY(afm_interaction_backward(E, B, st, E->s_wgrad));
+    DCTR_TRY(fork(E, E->s_wgrad, st));
+    DCTR_HIP_CHECK(hipMemcpy2DAsync(d_dE, (size_t)de_ld * 4, E->dE_buf, (size_t)E->D * 4, (size_t)E->D * 4, B, hipMemcpyDeviceToDevice, st));
+    return DCTR_OK;
 }
 
 int dctr_last_outputs(dctr_handle E, float** d_prob, float** d_logit) {

@@ -161,6 +161,31 @@ class Engine:
     def get_params(self) -> Dict[str, np.ndarray]:
         return {k: self.get_param(k) for k in self._shapes}
 
+    def get_grad(self, name: str) -> np.ndarray:
+        """Gradient of a dense variable as of the last backward pass (dctr_param_grad_get)."""
+        a = np.empty(self._shapes[name], dtype=np.float32)
+        capi.check(self._lib.dctr_param_grad_get(self._h, name.encode(), capi.ptr(a), a.nbytes))
+        return a
+
+    def afm_fwd(self, e, train: bool = False, want_att: bool = False, stream=None):
+        """AFM.py:127-158 as an op on an afm handle: e [B, F*K] device tensor -> (y_emb [B, K], att [B, P] or None)."""
+        import torch
+        B, K, F = int(e.shape[0]), self.cfg.embedding_size, self.cfg.field_size
+        y = torch.empty(B, K, device=e.device)
+        att = torch.empty(B, F * (F - 1) // 2, device=e.device) if want_att else None
+        st = stream if stream is not None else capi.current_stream()
+        capi.check(self._lib.dctr_afm_fwd(self._h, capi.ptr(e), int(e.shape[1]), B, int(train), capi.ptr(y), K, capi.ptr(att), st))
+        return y, att
+
+    def afm_bwd(self, dy_emb, stream=None):
+        """dL/d y_emb [B, K] -> dL/de [B, F*K]; the attention variables' gradients: get_grad(name)."""
+        import torch
+        B, K, F = int(dy_emb.shape[0]), self.cfg.embedding_size, self.cfg.field_size
+        dE = torch.empty(B, F * K, device=dy_emb.device)
+        st = stream if stream is not None else capi.current_stream()
+        capi.check(self._lib.dctr_afm_bwd(self._h, capi.ptr(dy_emb), K, B, capi.ptr(dE), F * K, st))
+        return dE
+
     def get_slot(self, name: str, which: int) -> np.ndarray:
         a = np.empty(self._shapes[name], dtype=np.float32)
         capi.check(self._lib.dctr_slot_get(self._h, name.encode(), which, capi.ptr(a), a.nbytes))

@@ -6,7 +6,7 @@ out=gpurun_out/${1:-ab_knobs}.txt
 while IFS='|' read -r label envs; do
   [ -z "$label" ] && continue
   for rep in 1 2; do
-    r=$(env $envs python bench.py --steps ${STEPS:-400} --warmup 40 --no-cpu-baseline --no-classic-reference ${BENCH_ARGS:-} 2>/dev/null | python -c "
+    r=$(env $envs python bench.py --steps ${STEPS:-400} --warmup 40 --no-cpu-baseline --no-classic-reference --no-end-to-end ${BENCH_ARGS:-} 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline())
 s = d['stage_ms']

@@ -6,7 +6,7 @@ out=gpurun_out/ab_w2.txt
 run() {   # label, env...
   label=$1; shift
   for rep in 1 2; do
-    r=$(env "$@" python bench.py --steps 400 --warmup 40 --no-cpu-baseline --no-classic-reference 2>/dev/null | python -c "
+    r=$(env "$@" python bench.py --steps 400 --warmup 40 --no-cpu-baseline --no-classic-reference --no-end-to-end 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline())
 s = d['stage_ms']

@@ -8,10 +8,10 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-DCTR_BENCH_TIMEOUT=200 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-classic-reference ${BENCH_ARGS:-} > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o $TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-classic-reference > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o $TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-classic-reference > /dev/null 2> $OUT/pmc_write.err
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_sq -o $TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-classic-reference > /dev/null 2> $OUT/pmc_sq.err
+DCTR_BENCH_TIMEOUT=200 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-classic-reference --no-end-to-end ${BENCH_ARGS:-} > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o $TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-classic-reference --no-end-to-end > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o $TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-classic-reference --no-end-to-end > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_sq -o $TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-classic-reference --no-end-to-end > /dev/null 2> $OUT/pmc_sq.err
 cd $R
 python tools/prof_summary.py stats $OUT/trace/${TAG}_results.db > $OUT/${TAG}_kernel_stats.txt 2>&1
 python tools/prof_summary.py timeline $OUT/trace/${TAG}_results.db > $OUT/${TAG}_step_timeline.txt 2>&1
