@@ -231,16 +231,25 @@ def end_to_end(w, epochs=40, lines=32768 * 12):
     est = mod.build_estimator(p, os.path.join(d, "ckpt"), log_steps=10 ** 9)
     est.train(input_fn=lambda: mod.input_fn([small], num_epochs=1, batch_size=B))
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    est.train(input_fn=lambda: mod.input_fn([path], num_epochs=epochs, batch_size=B))
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    steps = n_lines * epochs // B
+
+    def timed(ep):
+        t0 = time.perf_counter()
+        est.train(input_fn=lambda: mod.input_fn([path], num_epochs=ep, batch_size=B))
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    short = max(1, epochs // 10)
+    dt_short, dt = timed(short), timed(epochs)
+    steps, steps_short = n_lines * epochs // B, n_lines * short // B
+    per_step = (dt - dt_short) / max(1, steps - steps_short)          # what a step costs once the call's fixed costs are paid
     import shutil
     shutil.rmtree(d, ignore_errors=True)
     return {"examples_per_sec": round(n_lines * epochs / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps, "wall_s": round(dt, 3),
+            "steady_examples_per_sec": round(B / per_step, 1), "steady_ms_per_step": round(1e3 * per_step, 4),
+            "fixed_cost_s": round(dt - per_step * steps, 3),
             "what": "tf.estimator.Estimator.train (tf_shim) over a %d-line libsvm text file x %d epochs, batch %d: text parse + batching + H2D into the "
-                    "engine's input slots + train steps + checkpoint save; wall time of the whole call" % (n_lines, epochs, B)}
+                    "engine's input slots + train steps + checkpoint save (204 MB of variables and Adam slots); examples_per_sec = wall time of the "
+                    "whole call, steady_* = the slope between a %d-epoch and a %d-epoch call (the per-call fixed costs -- graph trace, lowering, "
+                    "checkpoint -- cancel)" % (n_lines, epochs, B, short, epochs)}
 
 
 def main():

@@ -439,6 +439,10 @@ int dctr_input_slot_acquire(dctr_handle h, int slot, void* stream);
 int dctr_input_slot_release(dctr_handle h, int slot, void* stream);
 int dctr_input_slot_wait_released(dctr_handle h, int slot);
 int dctr_input_slot_ready(dctr_handle h, int slot, int* ready);
+/* a non-blocking stream owned by the handle (created on first call, destroyed with it) for the caller's step calls: pass it as `stream`
+ * instead of the legacy default stream (0), on which every event of the step and of the slot handshake costs more.  The caller orders
+ * its own work against it (hipStreamSynchronize / events) as with any stream. */
+int dctr_main_stream(dctr_handle h, void** stream);
 /* canned-estimator models: the dense (numeric-column) inputs [B, dense_size] f32 of the NEXT train/predict/eval call; the
  * buffer is read in place and must stay valid until that call's work has finished */
 int dctr_set_dense_input(dctr_handle h, const float* d_dense);

@@ -121,6 +121,7 @@ _SIGS = {
     "dctr_param_grad_get": ([_P, C.c_char_p, _P, C.c_size_t], C.c_int),
     "dctr_afm_fwd": ([_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P], C.c_int),
     "dctr_afm_bwd": ([_P, _P, C.c_int, C.c_int, _P, C.c_int, _P], C.c_int),
+    "dctr_main_stream": ([_P, C.POINTER(_P)], C.c_int),
     "dctr_slot_get": ([_P, C.c_char_p, C.c_int, _P, C.c_size_t], C.c_int),
     "dctr_slot_set": ([_P, C.c_char_p, C.c_int, _P, C.c_size_t], C.c_int),
     "dctr_param_device_ptr": ([_P, C.c_char_p, C.POINTER(_P)], C.c_int),

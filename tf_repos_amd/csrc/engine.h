@@ -102,6 +102,7 @@ struct dctr_engine {
     std::atomic<uint32_t> slot_gen[DCTR_INPUT_SLOTS] = {};
     // dctr_input_slot_fill / acquire / release: the library's own H2D leg (created on first use)
     int device = 0;
+    hipStream_t s_main = nullptr;   // dctr_main_stream: a stream of the engine's own for the caller's train / predict calls (created on first use)
     hipStream_t s_copy = nullptr;
     hipEvent_t slot_filled[DCTR_INPUT_SLOTS] = {}, slot_released[DCTR_INPUT_SLOTS] = {};
     std::atomic<int> slot_fill_pending[DCTR_INPUT_SLOTS] = {}, slot_release_valid[DCTR_INPUT_SLOTS] = {};

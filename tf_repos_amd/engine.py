@@ -306,6 +306,13 @@ class Engine:
                                           capi.ptr(out_logit), st))
         return out_prob
 
+    def main_stream(self):
+        """torch view (ExternalStream) of the engine-owned stream for step calls (dctr_main_stream)."""
+        import torch
+        p = C.c_void_p()
+        capi.check(self._lib.dctr_main_stream(self._h, C.byref(p)))
+        return torch.cuda.ExternalStream(p.value)
+
     def input_slot(self, slot: int):
         """Zero-copy torch views (ids i32 [max_batch,F], vals f32 [max_batch,F], labels f32 [max_batch]) of engine-owned
         input staging set `slot`; batches written there are consumed by train_step/predict without a staging copy."""

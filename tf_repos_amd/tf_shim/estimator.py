@@ -361,18 +361,20 @@ class Estimator:
         if not csr and pipeline.csv is None and not getattr(e.cfg, "dense_size", 0):
             from ..feeder import DeviceFeeder
             import torch
-            # A/B knob DCTR_EST_SIDE_STREAM=1: the feeder-driven loop on a torch stream of its own.  In tools/feeder_breakdown.py that
-            # saves the step 40 us (the per-step waits / records that tie the steps to the feeder's copies are dearer on the
-            # legacy default stream: 312 vs 272 us); through THIS loop it measured 0.87 ms/step against 0.31 -- unexplained, so off.
-            if os.environ.get("DCTR_EST_SIDE_STREAM", "0") == "1":
-                side = self._side_stream = torch.cuda.Stream()        # (a fresh one per call: made AFTER the engine's own streams)
+            # The feeder-driven loop runs on the ENGINE'S OWN stream (dctr_main_stream), not on the legacy default stream: there every
+            # record / wait that ties the steps to the feeder's copies costs more (tools/feeder_breakdown.py: 312 vs 272 us per step at
+            # c2).  A/B knob DCTR_EST_MAIN_STREAM=0: the default stream (round 3).
+            if os.environ.get("DCTR_EST_MAIN_STREAM", "1") == "1":
                 torch.cuda.synchronize()              # (what built the engine and loaded its variables is complete)
+                side = self._side_stream = e.main_stream()
                 self._side_ctx = torch.cuda.stream(side)
                 self._side_ctx.__enter__()
             feeder = DeviceFeeder(e, pipeline.numpy_batches())
         try:
             return self._train_loop(e, csr, feeder, pipeline, steps, max_steps, start_step, log_every)
         finally:
+            if feeder is not None:                    # (also on an exception in train_step / check_ids: the thread stops, its pending hint is dropped)
+                feeder.close()
             if side is not None:
                 side.synchronize()
                 self._side_ctx.__exit__(None, None, None)
@@ -409,8 +411,6 @@ class Estimator:
                 dt = time.time() - t0
                 L.info("global_step/sec: %.4g  examples/sec: %.4g  loss = %.7g, step = %d" % (log_every / dt, n0 / dt, loss, start_step + done))
                 t0, n0 = time.time(), 0
-        if feeder is not None:
-            feeder.close()
         e.check_ids()
         path = self._save()
         L.info("Saving checkpoints for %d into %s." % (e.global_step, path))
