@@ -698,6 +698,10 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
     // the scatter a one-block-per-CU GEMM and the scatter's many small blocks get in each other's way, 23 -> 42 us and 32 -> 47 us)
     static const bool wgrad_late_env = getenv("DCTR_WGRAD_LATE") != nullptr;
     const bool wgrad_late = wgrad_late_env && E->s_opt != nullptr && sw != st && !E->opnn_fused;
+    // A/B knob DCTR_WGRAD_LATE_LAYERS=k: the weight gradients of layers 0 .. k-1 (and their optimizer steps) start behind the WHOLE dgrad
+    // chain, beside the table step, with no per-layer record on st; the others stay beside their layer's dgrad
+    static const int late_layers_env = getenv("DCTR_WGRAD_LATE_LAYERS") ? atoi(getenv("DCTR_WGRAD_LATE_LAYERS")) : 0;
+    const int late_layers = (!wgrad_late && fused_opt && sw != st && !E->opnn_fused && !E->bn) ? std::min(late_layers_env, nl) : 0;
     for (int i = nl - 1; i >= 0; --i) {
         const Fc& fc = E->mlp[i];
         const float* x = i > 0 ? (E->bn ? E->hbn[i - 1] : E->h[i - 1]) : E->x_in;
@@ -708,7 +712,7 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
             DCTR_TRY(bn_backward(E->dh[i], fc.out, E->h[i], fc.out, B, fc.out, E->bn_stats[i], E->pp(fc.bn_gamma), fc.keep, bn_seedp,
                                  fc.salt, E->bn_scratch, E->part(fc.bn_beta), E->part(fc.bn_gamma), E->dh[i], fc.out, st,
                                  E->bn_sync.world > 1 ? &E->bn_sync : nullptr));
-        if (!wgrad_late) {
+        if (!wgrad_late && i >= late_layers) {
             // dh[i] is complete on st -- and so is dgrad_{i+1}, the last reader of W_{i+1}: ONE record serves the weight gradient of
             // this layer and (fused_opt) the optimizer step of the layer above, whose wgrad is already queued on sw
             if (i == nl - 1 && head_ev != nullptr && !E->bn && E->head_did_out_bwd) DCTR_HIP_CHECK(hipStreamWaitEvent(sw, *head_ev, 0));
@@ -782,6 +786,14 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
         if (c.model == DCTR_MODEL_DCN && sw != st) {
             const Param& cw = E->params[E->p_cross_w];
             DCTR_TRY(dcn_cross_param_grads(E->xs, B, D, c.cross_layers, E->part(E->p_cross_w), E->part(E->p_cross_b), cw.n_part, cw.padded, E->cross_scratch, sw));
+        }
+        for (int i = late_layers - 1; i >= 0; --i) {        // (DCTR_WGRAD_LATE_LAYERS: every dgrad has read its weights by now)
+            const Fc& fc = E->mlp[i];
+            const float* x = i > 0 ? E->h[i - 1] : E->x_in;
+            const int ldx = i > 0 ? E->mlp[i - 1].out : E->Din_ld;
+            if (i + 1 < nl) DCTR_TRY(opt_dense_range(E, E->mlp[i + 1].w, E->mlp[i + 1].last, sw));
+            DCTR_TRY(fc_bwd_weights_partials(x, ldx, E->dh[i], fc.out, E->part(fc.w), E->params[fc.w].padded, E->part(fc.b), E->params[fc.b].padded, B,
+                                             fc.in, fc.out, fc.splits, sw, 1));
         }
         if (!wgrad_late) DCTR_TRY(opt_dense_range(E, E->mlp[0].w, E->mlp[0].last, sw));
     }
