@@ -133,13 +133,26 @@ def part2():
         dt = time.time() - t0
         opt = O.Optimizer(ocfg, p)
         ids, vals, labels = O.parse_libsvm(open(small).read(), F)
+        # AFM: the attention network sits behind a softmax over 741 pairs -- most of its gradient elements are ~1e-8, and Adam's
+        # 1/sqrt(v) turns their fp32 rounding into a visible fraction of lr on either side.  As in the golden-fixture tests
+        # (tests/test_model_golden.py var_err) the elements whose gradient was rounding noise at ANY step are left out of the
+        # comparison -- element by element, not the whole model (round 3 divided AFM's error by 400)
+        live = None
         for s in range(0, len(labels), 256):
+            if lowered.model == "afm":
+                _, g, _ = O.grads(ocfg, p, ids[s:s + 256], vals[s:s + 256], labels[s:s + 256], train=True)
+                now = {k: (v.abs() >= 1e-4 * v.abs().max()).numpy() for k, v in g.items()}
+                live = now if live is None else {k: live[k] & now[k] for k in now}
             O.train_step(ocfg, p, opt, ids[s:s + 256], vals[s:s + 256], labels[s:s + 256])
-        worst = max(float(np.abs(est.get_variable_value(tfname) - p[ename].numpy()).max()) for ename, tfname in lowered.name_map.items())
+
+        def err(ename, tfname):
+            d = np.abs(est.get_variable_value(tfname) - p[ename].numpy())
+            if live is not None and ename in live:
+                return float(d[live[ename]].max()) if live[ename].any() else 0.0
+            return float(d.max())
+        worst = max(err(ename, tfname) for ename, tfname in lowered.name_map.items())
         res = est.evaluate(input_fn=lambda: mod.input_fn([os.path.join(DATA, "va.libsvm")], num_epochs=1, batch_size=256))
-        # AFM: six Adam steps on the attention network's near-zero gradients (softmax over 741 pairs) -- Adam's 1/sqrt(v) turns
-        # fp32 rounding of a 1e-8 gradient into a visible fraction of lr on either side; the golden-fixture test masks such elements
-        worst_all = max(worst_all, worst / (400.0 if lowered.model == "afm" else 1.0))
+        worst_all = max(worst_all, worst)
         print("parity %-10s model=%-6s steps=%d  max |variable - oracle| = %.2e  eval auc %.4f loss %.5f  (train %.2f s)" % (
             script, lowered.model, est._engine.global_step, worst, res["auc"], res["loss"], dt), flush=True)
         est._engine.close()
