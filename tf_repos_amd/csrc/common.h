@@ -12,6 +12,14 @@
 namespace dctr {
 
 void set_error(const char* fmt, ...);
+// A record that would follow a kernel launch on the same stream (hipEventRecord = a barrier packet of its own: the stream's pipeline
+// drains, ~5 us in the step's timeline) can ride on the launch instead: hipExtLaunchKernel's stopEvent is bound to the dispatch packet's
+// own completion signal.  The engine ARMS an event (arm_stop_event) right before calling the op whose kernel is the last thing the fork
+// depends on; the launch site that supports it TAKES it (take_stop_event, at most once); the engine then checks stop_event_taken().
+void arm_stop_event(hipEvent_t ev);
+hipEvent_t take_stop_event();          // the armed event (and disarms), or nullptr
+bool stop_event_pending();             // still armed: nobody took it (the caller records it the ordinary way and disarms)
+void disarm_stop_event();
 const char* get_error();
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

@@ -3,6 +3,11 @@
 
 namespace dctr {
 static thread_local char g_err[1024] = "";
+static thread_local hipEvent_t g_stop_event = nullptr;
+void arm_stop_event(hipEvent_t ev) { g_stop_event = ev; }
+hipEvent_t take_stop_event() { hipEvent_t e = g_stop_event; g_stop_event = nullptr; return e; }
+bool stop_event_pending() { return g_stop_event != nullptr; }
+void disarm_stop_event() { g_stop_event = nullptr; }
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);

@@ -2,6 +2,8 @@
 // All HBM-bound streaming kernels: float4 / 16-byte-per-lane coalesced accesses, grid-stride loops,
 // reductions in registers -> wave shuffles -> one atomic per block.
 #include "opt_rules.h"
+#include <hip/hip_ext.h>
+
 #include "common.h"
 #include "ops.h"
 
@@ -570,7 +572,14 @@ int head_out_bwd(const float* x1, int ld1, const float* w1, int n1, int masked1,
     static const bool two_pass = getenv("DCTR_HEAD_TWO_PASS") != nullptr;       // A/B knob: the 256-thread two-pass kernel
     const int n4 = (n1 + (x2 ? n2 : 0)) / 4;
     if (!two_pass && n4 <= 256) {
-        if (n4 <= 128)
+        hipEvent_t stop = take_stop_event();         // (the engine's record behind the head rides on this launch: common.h)
+        if (stop != nullptr && n4 <= 128)
+            hipExtLaunchKernelGGL(head_out_bwd_rows_kernel<4>, dim3(splits), dim3(256), 0u, st, nullptr, stop, 0, s1, s2, b_out, bias, yw, yv, labels, B, inv_batch,
+                                  1.0f / keep, rpb, yd, y, prob, dy, loss_shards, dw_part, dw_stride, db_part, db_stride);
+        else if (stop != nullptr)
+            hipExtLaunchKernelGGL(head_out_bwd_rows_kernel<8>, dim3(splits), dim3(256), 0u, st, nullptr, stop, 0, s1, s2, b_out, bias, yw, yv, labels, B, inv_batch,
+                                  1.0f / keep, rpb, yd, y, prob, dy, loss_shards, dw_part, dw_stride, db_part, db_stride);
+        else if (n4 <= 128)
             head_out_bwd_rows_kernel<4><<<splits, 256, 0, st>>>(s1, s2, b_out, bias, yw, yv, labels, B, inv_batch, 1.0f / keep, rpb, yd, y, prob,
                                                                  dy, loss_shards, dw_part, dw_stride, db_part, db_stride);
         else

@@ -109,6 +109,7 @@ struct dctr_engine {
     std::atomic<int> slot_feed_ready = {0};
     hipEvent_t ev_tail = nullptr;   // = the event of the main stream's last fork when the dense backward was enqueued (ring of 64: one step uses ~12)
     hipEvent_t last_fork_ev = nullptr;
+    hipEvent_t armed_ev = nullptr;  // stop_arm: the ring event armed for the next launch (engine.hip stop_arm / stop_fork)
     bool have_tail = false;
     // arena
     float *theta = nullptr, *as0 = nullptr, *as1 = nullptr, *gflat = nullptr, *parts = nullptr;
@@ -218,6 +219,9 @@ struct dctr_engine {
 // shared between engine.hip and afm.hip
 int engine_add_param(dctr_engine* E, const std::string& name, std::initializer_list<int64_t> dims, bool table, int n_part, float l2);
 int fork(dctr_engine* E, hipStream_t from, hipStream_t to);
+void stop_arm(dctr_engine* E);
+int stop_record(dctr_engine* E, hipStream_t from, hipEvent_t* ev);
+int stop_fork(dctr_engine* E, hipStream_t from, hipStream_t to);
 // row-sharded path (engine.hip), used by the native step driver (dist.hip)
 int sharded_forward_backward(dctr_engine* E, const float* d_rows, int n_rows, const int32_t* d_idx, const float* d_vals,
                              const float* d_labels, int B, int global_batch, bool train, bool join_wgrad, hipStream_t st);

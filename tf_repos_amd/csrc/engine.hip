@@ -46,6 +46,40 @@ int fork(dctr_engine* E, hipStream_t from, hipStream_t to) {
     return DCTR_OK;
 }
 
+// ---- records that ride on a kernel launch (common.h arm_stop_event).  Usage in the step:
+//     stop_arm(E);  <enqueue the op whose LAST kernel the fork depends on>;  stop_fork(E, st, to)  /  stop_record(E, st, &ev)
+// If the op's launch site took the armed event (the direct GEMM kernels and the fused head do), the event completes with that
+// kernel and no barrier packet is enqueued on `st`; otherwise it is recorded the ordinary way.  A/B knob DCTR_STOP_EVENTS=0.
+static bool stop_events_on() {
+    static const bool off = [] { const char* v = getenv("DCTR_STOP_EVENTS"); return v != nullptr && v[0] == '0'; }();
+    return !off;
+}
+void stop_arm(dctr_engine* E) {
+    if (!stop_events_on() || E->cfg.use_graph) { E->armed_ev = nullptr; return; }
+    E->armed_ev = E->events[E->ev_next++ % E->events.size()];
+    arm_stop_event(E->armed_ev);
+}
+// -> the event that covers everything enqueued on `from` up to and including the armed op
+int stop_record(dctr_engine* E, hipStream_t from, hipEvent_t* ev) {
+    if (E->armed_ev != nullptr && !stop_event_pending()) {      // taken: bound to the op's kernel
+        *ev = E->armed_ev;
+    } else {
+        disarm_stop_event();
+        *ev = E->armed_ev != nullptr ? E->armed_ev : E->events[E->ev_next++ % E->events.size()];
+        DCTR_HIP_CHECK(hipEventRecord(*ev, from));
+    }
+    E->armed_ev = nullptr;
+    return DCTR_OK;
+}
+int stop_fork(dctr_engine* E, hipStream_t from, hipStream_t to) {
+    if (from == to) { disarm_stop_event(); E->armed_ev = nullptr; return DCTR_OK; }
+    hipEvent_t ev = nullptr;
+    DCTR_TRY(stop_record(E, from, &ev));
+    E->last_fork_ev = ev;
+    DCTR_HIP_CHECK(hipStreamWaitEvent(to, ev, 0));
+    return DCTR_OK;
+}
+
 // one record, several waiters (an event record is a barrier packet on the recording stream: ~5 us of the critical path each)
 int record_on(dctr_engine* E, hipStream_t from, hipEvent_t* ev) {
     *ev = E->events[E->ev_next++ % E->events.size()];
@@ -533,6 +567,8 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::f
         // (every 8th step only: the two extra event records cost the step ~15 us, which the bench's `value` should not carry)
         const bool timed = E->timer_on && train && i == 0 && E->timer_n + 2 <= E->timer_ev.size() && (E->timer_tick++ % 8) == 0;
         if (timed) DCTR_HIP_CHECK(hipEventRecord(E->timer_ev[E->timer_n], st));
+        const bool fork_here = (int)i == std::min(after_idx, (int)E->mlp.size() - 1) && after_layer0 != nullptr;
+        if (fork_here && !E->bn && !(i == 0 && E->opnn_fused)) stop_arm(E);      // (the fork behind this layer rides on its GEMM launch)
         if (i == 0 && E->opnn_fused) {
             // flat rows of W0 as an ordinary product (raw sums), then the pair-product rows with A formed in registers + bias/ReLU/dropout
             DCTR_TRY(fc_fwd(x, ldx, E->pp(fc.w), nullptr, E->h[0], fc.out, B, D, fc.out, 0, 1.f, nullptr, 0, st, 1));
@@ -542,7 +578,7 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::f
         DCTR_TRY(fc_fwd(x, ldx, E->pp(fc.w), E->pp(fc.b), E->h[i], fc.out, B, fc.in, fc.out, 1, (train && !E->bn) ? fc.keep : 1.f,
                         seedp, fc.salt, st, 1));
         if (timed) { DCTR_HIP_CHECK(hipEventRecord(E->timer_ev[E->timer_n + 1], st)); E->timer_n += 2; }
-        if ((int)i == std::min(after_idx, (int)E->mlp.size() - 1) && after_layer0 != nullptr) DCTR_TRY((*after_layer0)());
+        if (fork_here) DCTR_TRY((*after_layer0)());
         x = E->h[i]; ldx = fc.out;
         if (E->bn) {
             DCTR_TRY(bn_forward(E->h[i], fc.out, B, fc.out, train, 1e-3f, c.batch_norm_decay, E->pp(fc.bn_gamma), E->pp(fc.bn_beta),
@@ -716,7 +752,7 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
             // dh[i] is complete on st -- and so is dgrad_{i+1}, the last reader of W_{i+1}: ONE record serves the weight gradient of
             // this layer and (fused_opt) the optimizer step of the layer above, whose wgrad is already queued on sw
             if (i == nl - 1 && head_ev != nullptr && !E->bn && E->head_did_out_bwd) DCTR_HIP_CHECK(hipStreamWaitEvent(sw, *head_ev, 0));
-            else DCTR_TRY(fork(E, st, sw));
+            else DCTR_TRY(stop_fork(E, st, sw));        // (rides on the dgrad launch of the layer above when that one was armed)
             // A/B knob DCTR_OPT_SIDE=1: the optimizer step of the layer above on a stream of its own instead of in front of this
             // layer's weight gradient (measured at c2: 0.3052 vs 0.3062 ms/step -- nothing; every kernel here fills the chip, the
             // step is the sum of their solo times whatever the order)
@@ -735,6 +771,12 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
             if (i == 0 && E->opnn_fused)
                 DCTR_TRY(opnn_outer_wgrad(E->e, E->e_ld, B, F, K, E->opnn_pairs, E->dh[0], fc.out, fc.out, E->part(fc.w) + (size_t)D * fc.out, sw));
         }
+        // the NEXT cross-stream record on st -- the fork of the layer below, or the one that ends this function -- depends on this dgrad's
+        // kernel and on nothing enqueued after it: it rides on the launch (not with batch_norm, whose backward kernels follow; not
+        // when an interaction backward follows the last dgrad)
+        const bool tail_plain = c.model == DCTR_MODEL_DEEPFM || c.model == DCTR_MODEL_FNN || c.model == DCTR_MODEL_WIDE || c.model == DCTR_MODEL_DEEP ||
+                                c.model == DCTR_MODEL_WND;
+        if (!wgrad_late && late_layers == 0 && !E->bn && !E->opnn_fused && sw != st && (i > 0 || (fused_opt && tail_plain))) stop_arm(E);
         if (i > 0)
             DCTR_TRY(fc_bwd_data(E->dh[i], fc.out, E->pp(fc.w), E->dh[i - 1], E->mlp[i - 1].out, B, fc.in, fc.out,
                                  E->bn ? nullptr : E->h[i - 1], E->mlp[i - 1].out, E->bn ? 1.f : E->mlp[i - 1].keep, st, 1));
@@ -782,7 +824,7 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
     if (fused_opt) {
         // everything the dense side reads or writes on st is enqueued: the first layer's step (its dgrad is done) and, for the
         // caller, the cross-network / output-layer partial slabs
-        DCTR_TRY(fork(E, st, sw));
+        DCTR_TRY(stop_fork(E, st, sw));
         if (c.model == DCTR_MODEL_DCN && sw != st) {
             const Param& cw = E->params[E->p_cross_w];
             DCTR_TRY(dcn_cross_param_grads(E->xs, B, D, c.cross_layers, E->part(E->p_cross_w), E->part(E->p_cross_b), cw.n_part, cw.padded, E->cross_scratch, sw));
@@ -996,7 +1038,7 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     const bool late_sweep = sweep_after_head_env && pregrouped && split_table && !bg_late && E->cfg.model != DCTR_MODEL_AFM && !E->mlp.empty();
     const std::function<int()> start_grouping = [&]() -> int {
         if (late_sweep) return DCTR_OK;
-        DCTR_TRY(fork(E, st, sg));          // not before the gather (its atomics slow a concurrent gather 4x)
+        DCTR_TRY(stop_fork(E, st, sg));     // not before the gather (its atomics slow a concurrent gather 4x); rides on the layer's launch when armed
         // the previous step's grouping state kept its slot words for the pre-advance (lag.h): cleared a step before it is reused, on
         // the stream that reuses it; this step's grouping came from that stream too: the sweep reads its slot words
         if (pre_hint_stream) DCTR_HIP_CHECK(hipStreamWaitEvent(sg, E->ev_preadv, 0));
@@ -1019,8 +1061,9 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     const bool have_mlp = !E->mlp.empty() && E->cfg.model != DCTR_MODEL_AFM;
     if (!(group_after >= 1 && have_mlp)) DCTR_TRY(start_grouping());
     DCTR_TRY(forward_rest(E, B, true, st, (group_after >= 1 && have_mlp) ? &start_grouping : nullptr, group_after - 1));
-    DCTR_TRY(head(E, B, B, true, st, nullptr, true));
     const bool fused_opt = E->cfg.model != DCTR_MODEL_AFM;
+    if (fused_opt) stop_arm(E);             // (the record behind the head rides on the fused head kernel's launch when that path is taken)
+    DCTR_TRY(head(E, B, B, true, st, nullptr, true));
     hipEvent_t head_ev = nullptr;
     bool have_head_ev = false;
     if (fused_opt && E->head_did_out_bwd) {
@@ -1028,7 +1071,7 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
         // head kernel: step it now, beside the MLP backward, instead of at the end of the step beside the scatter
         // (on the grouping stream, idle since the MLP forward: on the wgrad stream these two latency-bound launches -- 128 slabs
         //  summed by one block each, ~35 us -- would delay the whole weight-gradient chain behind them)
-        DCTR_TRY(record_on(E, st, &head_ev));
+        DCTR_TRY(stop_record(E, st, &head_ev));
         have_head_ev = true;
         DCTR_HIP_CHECK(hipStreamWaitEvent(sg, head_ev, 0));
         if (late_sweep) {
@@ -1046,6 +1089,7 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
         DCTR_TRY(record_on(E, sg, &tables_ev));
         have_tables_ev = true;
     }
+    if (E->armed_ev != nullptr) { disarm_stop_event(); E->armed_ev = nullptr; }      // (armed for the head, not used)
     const bool out_done = fused_opt && E->head_did_out_bwd;
     // A/B knob DCTR_WGRAD_SERIAL=1: the weight gradients (and the per-layer optimizer steps) on the main stream, right behind their
     // layer's dgrad, instead of beside it on sw

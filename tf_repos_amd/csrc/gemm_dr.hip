@@ -6,6 +6,8 @@
 #include <cstring>
 #include <string>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 #include "gemm_dr.h"
 #include "ops.h"
@@ -68,7 +70,12 @@ int dr_launch(const float* A, int lda, const float* B, int ldb, float* C, int ld
     DCTR_HIP_CHECK(attr);
     const int nbm = ceil_div(M, 16 * TM), nbn = ceil_div(N, 16 * TN);
     const int kchunk = (int)round_up(ceil_div(K, splits), 16);
-    kern<<<dim3((unsigned)(nbm * nbn), (unsigned)splits), 256, lds, st>>>(A, lda, B, ldb, C, ldc, M, N, K, kchunk, nbn, ep, DrOuter{});
+    if (hipEvent_t stop = take_stop_event()) {      // (the engine's next cross-stream record rides on this launch: common.h)
+        hipExtLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn), (unsigned)splits), dim3(256), (uint32_t)lds, st, nullptr, stop, 0, A, lda, B, ldb, C, ldc, M, N, K,
+                              kchunk, nbn, ep, DrOuter{});
+    } else {
+        kern<<<dim3((unsigned)(nbm * nbn), (unsigned)splits), 256, lds, st>>>(A, lda, B, ldb, C, ldc, M, N, K, kchunk, nbn, ep, DrOuter{});
+    }
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }
