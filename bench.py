@@ -159,6 +159,11 @@ def fill_normal_(t, scale, seed):
     import torch
     g = torch.Generator(device=t.device)
     g.manual_seed(seed)
+    if not t.is_contiguous():            # a table kept as row records (Engine.param_tensor): by blocks of rows
+        rows = max(1, (1 << 26) // max(1, t[0].numel()))
+        for s in range(0, t.shape[0], rows):
+            t[s:s + rows].normal_(0.0, scale, generator=g)
+        return
     flat = t.view(-1)
     step = 1 << 28
     for s in range(0, flat.numel(), step):

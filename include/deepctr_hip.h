@@ -391,7 +391,18 @@ int dctr_param_get(dctr_handle h, const char* name, float* h_dst, size_t nbytes)
 int dctr_param_grad_get(dctr_handle h, const char* name, float* h_dst, size_t nbytes);
 int dctr_slot_get(dctr_handle h, const char* name, int which, float* h_dst, size_t nbytes);
 int dctr_slot_set(dctr_handle h, const char* name, int which, const float* h_src, size_t nbytes);
+/* raw device pointer of a variable (device-side initialisation of tables too large to stage through the host).  For a TABLE of a
+ * handle whose rows may lag (table_sweep_period > 1, csrc/lag.h) the call first brings every row to global_step, and the pointer is a
+ * view of the table AS OF THIS CALL: it is valid until the next train step (rows then lag again behind what the pointer shows).  After
+ * WRITING through it, call dctr_set_global_step(h, current step) before training on -- that re-stamps every row as current, so the
+ * written values are not replayed through steps they were never part of.  (dctr_param_set / dctr_slot_set do all of this themselves.) */
 int dctr_param_device_ptr(dctr_handle h, const char* name, float** d_ptr);
+/* the same with the distance (floats) between consecutive rows of the variable's first dimension.  With DCTR_TABLE_RECORDS=1 in the
+ * environment when it is created, a handle whose table rows may lag keeps each row of `emb` / `linear` together with its Adam slots
+ * in one RECORD (csrc/engine.h tab_ld: a lagging row's catch-up and its touched-rows step then read one or two adjacent cache lines
+ * instead of six scattered ones; opt-in -- measured, the step as a whole does not gain, profiles/r04_table_records.txt): such a
+ * table is a strided view (*row_stride > the row's own width), which dctr_param_device_ptr refuses. */
+int dctr_param_device_view(dctr_handle h, const char* name, float** d_ptr, int64_t* row_stride);
 int dctr_set_global_step(dctr_handle h, int64_t step);
 int dctr_get_global_step(dctr_handle h, int64_t* step);
 

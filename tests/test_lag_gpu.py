@@ -124,16 +124,14 @@ def test_restored_global_step_and_written_parameters(dev):
     assert worst <= max(3e-6, 3 * noise), (worst, noise)
 
 
-@pytest.mark.parametrize("preadvance", ["0", "1"])
 @pytest.mark.parametrize("model", ["deepfm", "dcn"])
-def test_announced_batches(model, preadvance, dev, monkeypatch):
+def test_announced_batches(model, dev):
     """The input pipeline's hint (dctr_prefetch_ids after every step, batches in the engine's input slots): the next batch's ids are
-    grouped during the step in flight and -- with DCTR_PREADVANCE=1 when the handle is created (lag.h lag_preadvance; off by default,
-    it does not pay) -- its rows that the step in flight does not touch are advanced to the present beside that step's table step, so
-    that the next gather reads current rows only.  Same results as the classic sweep without any hint; a step in the middle without a
-    hint, one with a hint that is not honoured (another batch trained), a loss read and a short batch included."""
+    grouped during the step in flight, into the alternate grouping state.  Same results as the classic sweep without any hint; a step
+    in the middle without a hint, one with a hint that is not honoured (another batch trained), a loss read and a short batch included.
+    (Round 4 also tried advancing the announced batch's lagging rows ahead of its step -- profiles/r04_preadvance.txt: slower in every
+    placement, and removed.)"""
     from tf_repos_amd import capi
-    monkeypatch.setenv("DCTR_PREADVANCE", preadvance)
     F, V, B, K = 39, 30000, 256, 8
     ocfg = O.Config(model=model, field_size=F, feature_size=V, embedding_size=K, deep_layers=(32, 16), dropout=(0.8, 0.8), cross_layers=2,
                     l2_reg=1e-3, learning_rate=1e-2, optimizer="Adam")

@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void opt_table_kernel(const Hyper* __restrict_
                                                        const int32_t* __restrict__ slot, const int32_t* __restrict__ uniq,
                                                        const int32_t* __restrict__ counters, const float4* __restrict__ gemb,
                                                        const float* __restrict__ glin, float l2, float* __restrict__ sumsq_emb,
-                                                       float* __restrict__ sumsq_lin, int nt, int untouched_only) {
+                                                       float* __restrict__ sumsq_lin, int nt, int untouched_only, int ld4, int lin_ld) {
     // KQ lanes per row (one float4 each); lane kq == 0 also steps the row's linear weight (same slot word, one launch)
     const Hyper h = load_hyper(hdev, hval);
     const int64_t n_items = DENSE ? rows : (int64_t)counters[0];
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(256) void opt_table_kernel(const Hyper* __restrict_
         int u;
         if (DENSE) { r = item; u = slot[r] - 1; } else { u = (int)item; r = uniq[u]; }
         if (DENSE && untouched_only && u >= 0) continue;    // the batch's rows are stepped later, once their gradients exist
-        const size_t i4 = (size_t)r * KQ + kq;
+        const size_t i4 = (size_t)r * ld4 + kq, il = (size_t)r * lin_ld;
         float4 th, a, b = make_float4(0.f, 0.f, 0.f, 0.f);
         if (nt) {
             th = ntload4(emb + i4); a = ntload4(s0 + i4);
@@ -763,16 +763,16 @@ __global__ __launch_bounds__(256) void opt_table_kernel(const Hyper* __restrict_
             if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) s1[i4] = b;
         }
         if (kq == 0 && lin != nullptr) {
-            float lt = lin[r];
-            float la = l0[r];
-            float lb = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) ? l1[r] : 0.f;
+            float lt = lin[il];
+            float la = l0[il];
+            float lb = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) ? l1[il] : 0.f;
             sql += lt * lt;
             float lg = l2 * lt;
             if (u >= 0) lg += glin[u];
             opt_update(KIND, h, lt, la, lb, lg);
-            lin[r] = lt;
-            l0[r] = la;
-            if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) l1[r] = lb;
+            lin[il] = lt;
+            l0[il] = la;
+            if (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL) l1[il] = lb;
         }
     }
     if (sumsq_emb != nullptr) {
@@ -900,12 +900,15 @@ template <int KIND, bool DENSE>
 static int launch_table(const Hyper* hdev, const Hyper& hval, int64_t rows, int K, float* emb, float* e0, float* e1,
                         float* lin, float* l0, float* l1, const int32_t* slot, const int32_t* uniq,
                         const int32_t* counters, int64_t max_entries, const float* gemb, const float* glin, float l2,
-                        float* sumsq_emb, float* sumsq_lin, hipStream_t st, hipStream_t st_lin, int untouched_only) {
+                        float* sumsq_emb, float* sumsq_lin, hipStream_t st, hipStream_t st_lin, int untouched_only, int tab_ld, int tab_lin_ld) {
     const int KQ = K / 4;
+    // row records (engine.h): the table and its slots interleaved -- the generic kernel with row strides, linear weights in the same launch
+    const bool strided = (tab_ld != 0 && tab_ld != K) || tab_lin_ld != 1;
+    const int ld4 = tab_ld != 0 ? tab_ld / 4 : KQ;
     // dense mode: the linear table gets its own vectorised kernel (on st_lin, beside the embedding pass); touched-rows
     // mode keeps it fused (lane kq == 0 of each visited row)
     float* lin_f = lin; float* l0_f = l0; float* l1_f = l1;
-    const bool split_lin = DENSE && lin != nullptr && ((reinterpret_cast<uintptr_t>(lin) | reinterpret_cast<uintptr_t>(l0) |
+    const bool split_lin = !strided && DENSE && lin != nullptr && ((reinterpret_cast<uintptr_t>(lin) | reinterpret_cast<uintptr_t>(l0) |
                                                        reinterpret_cast<uintptr_t>(l1) | reinterpret_cast<uintptr_t>(slot)) & 15) == 0;
     if (split_lin) { lin = nullptr; l0 = nullptr; l1 = nullptr; }
     const int64_t items = DENSE ? rows : max_entries;
@@ -916,7 +919,7 @@ static int launch_table(const Hyper* hdev, const Hyper& hval, int64_t rows, int 
     float4* a4 = reinterpret_cast<float4*>(e0);
     float4* b4 = reinterpret_cast<float4*>(e1);
     const float4* g4 = reinterpret_cast<const float4*>(gemb);
-    if (DENSE && untouched_only) {
+    if (DENSE && untouched_only && !strided) {
         static const int bg = getenv("DCTR_OPT_BG_GRID") ? atoi(getenv("DCTR_OPT_BG_GRID")) : 2;     // blocks per CU of the background pass
         const int g2 = (int)std::min<int64_t>(ceil_div(items * KQ, 256 * 4), 256 * bg);
         switch (KQ) {
@@ -939,7 +942,7 @@ static int launch_table(const Hyper* hdev, const Hyper& hval, int64_t rows, int 
         return DCTR_OK;
     }
     switch (KQ) {
-#define DCTR_T(Q) case Q: opt_table_kernel<KIND, Q, DENSE><<<grid, 256, 0, st>>>(hdev, hval, rows, e4, a4, b4, lin, l0, l1, slot, uniq, counters, g4, glin, l2, sumsq_emb, sumsq_lin, nt, untouched_only); break
+#define DCTR_T(Q) case Q: opt_table_kernel<KIND, Q, DENSE><<<grid, 256, 0, st>>>(hdev, hval, rows, e4, a4, b4, lin, l0, l1, slot, uniq, counters, g4, glin, l2, sumsq_emb, sumsq_lin, nt, untouched_only, ld4, tab_lin_ld); break
         DCTR_T(1); DCTR_T(2); DCTR_T(4); DCTR_T(8); DCTR_T(16); DCTR_T(32); DCTR_T(64);
 #undef DCTR_T
         default: set_error("opt_table: K=%d unsupported", K); return DCTR_ERR_UNSUPPORTED;
@@ -955,7 +958,8 @@ static int launch_table(const Hyper* hdev, const Hyper& hval, int64_t rows, int 
 int opt_table(int kind, const Hyper* hdev, const Hyper& hval, int table_mode, int64_t rows, int K, float* emb, float* e0,
               float* e1, float* lin, float* l0, float* l1, const int32_t* slot, const int32_t* uniq,
               const int32_t* counters, int64_t max_entries, const float* gemb, const float* glin, float l2,
-              float* sumsq_emb, float* sumsq_lin, hipStream_t st, hipStream_t st_lin, int pass) {
+              float* sumsq_emb, float* sumsq_lin, hipStream_t st, hipStream_t st_lin, int pass, int tab_ld, int tab_lin_ld) {
+    DCTR_REQUIRE(tab_ld % 4 == 0 && (tab_ld == 0 || tab_ld >= K) && tab_lin_ld >= 1, "opt_table: row strides %d / %d", tab_ld, tab_lin_ld);
     // pass (dense-exact only): OPT_PASS_ALL = every row in one sweep; OPT_PASS_UNTOUCHED = rows the batch does not touch
     // (gradient = l2*theta: needs the grouping, not the backward pass); OPT_PASS_TOUCHED = the batch's distinct rows (the
     // touched-rows kernel computes the same l2*theta + segment sum).  UNTOUCHED then TOUCHED == ALL, row for row.
@@ -966,9 +970,9 @@ int opt_table(int kind, const Hyper* hdev, const Hyper& hval, int table_mode, in
 #define DCTR_K(KD)                                                                                                      \
     case KD:                                                                                                            \
         return dense ? launch_table<KD, true>(hdev, hval, rows, K, emb, e0, e1, lin, l0, l1, slot, uniq, counters,      \
-                                              max_entries, gemb, glin, l2, sumsq_emb, sumsq_lin, st, st_lin, untouched_only) \
+                                              max_entries, gemb, glin, l2, sumsq_emb, sumsq_lin, st, st_lin, untouched_only, tab_ld, tab_lin_ld) \
                      : launch_table<KD, false>(hdev, hval, rows, K, emb, e0, e1, lin, l0, l1, slot, uniq, counters,     \
-                                               max_entries, gemb, glin, l2, sumsq_emb, sumsq_lin, st, st_lin, 0)
+                                               max_entries, gemb, glin, l2, sumsq_emb, sumsq_lin, st, st_lin, 0, tab_ld, tab_lin_ld)
     switch (kind) {
         DCTR_K(DCTR_OPT_ADAM); DCTR_K(DCTR_OPT_ADAGRAD); DCTR_K(DCTR_OPT_MOMENTUM); DCTR_K(DCTR_OPT_FTRL);
         default: set_error("unknown optimizer kind %d", kind); return DCTR_ERR_INVALID_ARG;

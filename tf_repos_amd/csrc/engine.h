@@ -69,6 +69,16 @@ struct dctr_engine {
 
     // tables
     float *emb = nullptr, *emb_s0 = nullptr, *emb_s1 = nullptr, *lin = nullptr, *lin_s0 = nullptr, *lin_s1 = nullptr;
+    // Row strides (floats) of emb / emb_s0 / emb_s1 and of lin / lin_s0 / lin_s1.  Separate dense arrays (the default): (K, 1).
+    // ROW RECORDS (table_rec != nullptr: DCTR_TABLE_RECORDS=1 in the environment when the handle is created, on an engine whose rows
+    // may lag, unsharded, fixed-field batches): the six pointers point into ONE buffer of `rows` records
+    //     [ theta K | w . . . | m K | w_m . . . | v K | w_v . . . ]        (the three 4-float linear groups only when the model has a linear table)
+    // padded to a multiple of 16 floats (64 B) -- a row's step state is one or two adjacent 128-byte lines instead of six scattered
+    // sectors.  Every kernel that touches a table row takes the two strides.  Measured in the step (profiles/r04_table_records.txt,
+    // second part): the fused tail 40.7 -> 33.4 us, the catch-up gather unchanged (c2's table sits in the Infinity Cache), the sweep
+    // 30.5 -> 32.2 us (+25 % bytes), the step 0.2655 -> 0.2667 ms: the tail is not what the step waits for.  Hence opt-in.
+    int tab_ld = 0, lin_ld = 1;
+    float* table_rec = nullptr;
     // time-blocked dense-exact sweep (lag.h): rows may lag behind global_step; row_ts stamps how far each has been advanced
     uint8_t* row_ts = nullptr;
     int lag_period = 1;             // 1 = classic sweep (every row every step)
@@ -83,20 +93,6 @@ struct dctr_engine {
     const int32_t* pre_ids = nullptr;
     int pre_B = 0;
     bool pre_valid = false;
-    // ... and its rows PRE-ADVANCED (lag.h lag_preadvance): every row that batch reads is current when its step starts -- the rows the
-    // batch in flight shares with it by that batch's own table step, the others by a background kernel beside it -- so the gather takes
-    // the plain path (no Adam slots read, nothing replayed on the critical path)
-    bool pre_advanced = false;
-    hipEvent_t ev_preadv = nullptr;
-    bool preadv_unjoined = false;   // a pre-advance may still be running on s_group: whoever touches the tables next waits for ev_preadv
-    hipEvent_t sweep_ev = nullptr;  // the background sweep of the step in flight has been enqueued up to this record (the pre-advance is ordered behind it)
-    bool have_sweep_ev = false;
-    hipEvent_t alt_ready_ev = nullptr;  // group_alt's slot words have been cleared (on s_group): whoever regroups into it next waits
-    bool have_alt_ready_ev = false;
-    bool pre_on_hint_stream = false;    // the pending grouping was made on s_opt (the hint stream), not on s_group
-    bool preadvance = false;        // DCTR_PREADVANCE=1 when the handle was created (off by default: measured, it loses -- DESIGN 5)
-    bool slots_kept = false;        // the table step in flight was launched with keep_slots: its grouping's slot words are valid membership until the next grouping
-    bool hint_streak = false;       // this step's ids were announced ahead: the next step's probably will be -- the table step keeps its slot words for the pre-advance
     int pre_slot = 0;               // ... of input slot `pre_slot` at generation `pre_gen`: a slot rewritten since (dctr_input_slot_rewrite,
     uint32_t pre_gen = 0;           // or a staging copy into it) no longer matches and the hint is dropped
     std::atomic<uint32_t> slot_gen[DCTR_INPUT_SLOTS] = {};

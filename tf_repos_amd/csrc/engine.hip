@@ -280,23 +280,40 @@ int build(dctr_engine* E) {
     }
 
     // ---- tables
-    DCTR_TRY(dmalloc(&E->emb, (size_t)E->rows * K));
-    DCTR_TRY(dmalloc(&E->emb_s0, (size_t)E->rows * K));
-    DCTR_TRY(dmalloc(&E->emb_s1, (size_t)E->rows * K));
-    if (has_lin) {
-        DCTR_TRY(dmalloc(&E->lin, (size_t)E->rows));
-        DCTR_TRY(dmalloc(&E->lin_s0, (size_t)E->rows));
-        DCTR_TRY(dmalloc(&E->lin_s1, (size_t)E->rows));
-    }
     // time-blocked dense-exact sweep (lag.h): Adam on the engine's own unsharded tables, eager steps, fixed-field batches
+    int lag_period_cfg = 1;
     {
         int period = c.table_sweep_period;
         if (period == 0) { const char* v = getenv("DCTR_SWEEP_PERIOD"); period = v ? atoi(v) : 8; }
         DCTR_REQUIRE(period >= 1 && period <= LAG_MAX_PERIOD, "table_sweep_period %d outside [1, %d]", period, LAG_MAX_PERIOD);
         const bool can = c.table_mode == DCTR_TABLE_DENSE_EXACT && c.optimizer == DCTR_OPT_ADAM && !E->wnd && !c.use_graph;
-        E->lag_period = can ? period : 1;
+        lag_period_cfg = can ? period : 1;
+    }
+    E->tab_ld = K; E->lin_ld = 1;
+    {
+        const char* v = getenv("DCTR_TABLE_RECORDS");
+        const bool records = v != nullptr && v[0] == '1' && lag_period_cfg > 1 && !E->csr && c.shard_world == 1 && E->K == E->K_log;
+        if (records) {          // row records (engine.h): one buffer, six views
+            const int grp = has_lin ? K + 4 : K;
+            const int R = (int)round_up(3 * grp, 16);
+            DCTR_TRY(dmalloc(&E->table_rec, (size_t)E->rows * R));
+            E->emb = E->table_rec; E->emb_s0 = E->table_rec + grp; E->emb_s1 = E->table_rec + 2 * grp;
+            if (has_lin) { E->lin = E->emb + K; E->lin_s0 = E->emb_s0 + K; E->lin_s1 = E->emb_s1 + K; }
+            E->tab_ld = R; E->lin_ld = R;
+        } else {
+            DCTR_TRY(dmalloc(&E->emb, (size_t)E->rows * K));
+            DCTR_TRY(dmalloc(&E->emb_s0, (size_t)E->rows * K));
+            DCTR_TRY(dmalloc(&E->emb_s1, (size_t)E->rows * K));
+            if (has_lin) {
+                DCTR_TRY(dmalloc(&E->lin, (size_t)E->rows));
+                DCTR_TRY(dmalloc(&E->lin_s0, (size_t)E->rows));
+                DCTR_TRY(dmalloc(&E->lin_s1, (size_t)E->rows));
+            }
+        }
+    }
+    {
+        E->lag_period = lag_period_cfg;
         if (E->lag_period > 1) DCTR_TRY(dmalloc(&E->row_ts, (size_t)E->rows));
-        { const char* v = getenv("DCTR_PREADVANCE"); E->preadvance = v != nullptr && v[0] == '1'; }
     }
     // owner side may receive rows from every rank; CSR models group up to max_entries ids per step
     DCTR_TRY(group_create(E->rows, E->csr ? E->max_entries : (int64_t)MB * F * c.shard_world, K, &E->group));
@@ -539,8 +556,9 @@ int gather_from(dctr_engine* E, const float* emb, const float* lin, int64_t rows
     const int F = E->F, K = E->K;
     const int mode = gather_mode(E);
     float* red = mode == DCTR_GATHER_FM ? E->yv : (mode == DCTR_GATHER_BI ? E->x_in : nullptr);
-    DCTR_TRY(embed_gather_fwd(emb, lin, rows, ids, E->vals, B, F, K, mode, E->e, E->e_ld, lin ? E->yw : nullptr,
-                              E->S, red, E->status, st, lag));
+    const bool own = emb == E->emb;         // (the engine's own tables may be row records: engine.h tab_ld)
+    DCTR_TRY(embed_gather_strided(emb, own ? E->tab_ld : K, lin, own ? E->lin_ld : 1, rows, ids, E->vals, B, F, K, mode, E->e, E->e_ld,
+                                  lin ? E->yw : nullptr, E->S, red, E->status, st, lag));
     if (E->wnd && E->n_dense > 0)       // numeric columns: appended to the DNN input, and their linear_model term added to y_w
         DCTR_TRY(wnd_dense_fwd(E->dense, E->n_dense, E->p_lin_dense >= 0 ? E->pp(E->p_lin_dense) : nullptr, B,
                                E->wnd_deep ? E->x_in : nullptr, E->Din_ld, E->D, E->yw, st));
@@ -595,20 +613,15 @@ int forward_gather(dctr_engine* E, int B, hipStream_t st) { return gather_from(E
 // the gather of a TRAINING step whose table rows may lag (lag.h): the step's state (t, lr history) must be in place on `st`.
 // A step that reports its loss first brings every row to t-1 -- its l2 term needs sum theta^2 over the whole table, which the
 // flush accumulates.
-int forward_gather_train(dctr_engine* E, int B, hipStream_t st, bool rows_current);
+int forward_gather_train(dctr_engine* E, int B, hipStream_t st);
 int lag_flush_tables(dctr_engine* E, hipStream_t st, int offset, bool with_sums);
 bool lag_on(const dctr_engine* E);
-bool preadvance_on(const dctr_engine* E);
 bool owner_lag(const dctr_engine* E);
 LagView lag_view(const dctr_engine* E);
 
-int join_preadvance(dctr_engine* E, hipStream_t st);
-// rows_current: every row this batch reads is known to be current as of step t-1 (pre-advanced, dctr_prefetch_ids)
-int forward_gather_train(dctr_engine* E, int B, hipStream_t st, bool rows_current = false) {
+int forward_gather_train(dctr_engine* E, int B, hipStream_t st) {
     if (!lag_on(E)) return forward_gather(E, B, st);
-    DCTR_TRY(join_preadvance(E, st));
     if (E->want_loss) DCTR_TRY(lag_flush_tables(E, st, -1, true));
-    if (rows_current) return forward_gather(E, B, st);
     const LagView L = lag_view(E);
     return gather_from(E, E->emb, E->lin, E->rows, E->ids, B, st, &L);
 }
@@ -854,10 +867,6 @@ bool tail_fused(const dctr_engine* E) {
     return !off && !E->wnd && E->cfg.shard_world == 1 && (split_table_on(E) || E->cfg.table_mode != DCTR_TABLE_DENSE_EXACT);
 }
 
-// DCTR_PREADVANCE=1 (read when the handle is created): the next batch's rows are advanced ahead of its step (lag.h lag_preadvance) and
-// its gather takes the plain path.  OFF by default: the gather drops from ~16 to ~8 us, but the extra launches / event waits cost the
-// enqueueing thread more than that and the grouping + pre-advance chain lands on the step boundary (c2: 0.265-0.289 vs 0.260 ms/step)
-bool preadvance_on(const dctr_engine* E) { return E->preadvance; }
 // time-blocked sweep (lag.h): is this handle's table allowed to lag in training steps?
 bool lag_on(const dctr_engine* E) { return E->lag_period > 1 && !E->lag_suspended && split_table_on(E) && tail_fused(E); }
 // the owner side of the row-sharded path (dctr_table_gather_packed / dctr_table_apply_packed) under the same scheme: its
@@ -867,25 +876,17 @@ bool owner_lag(const dctr_engine* E) {
     return !off && E->owner_lag_opt_in && E->lag_period > 1 && !E->lag_suspended && split_table_on(E);
 }
 LagView lag_view(const dctr_engine* E) {
-    return LagView{E->row_ts, E->state, reinterpret_cast<float4*>(E->emb_s0), reinterpret_cast<float4*>(E->emb_s1), E->lin_s0, E->lin_s1, E->cfg.l2_reg};
+    return LagView{E->row_ts, E->state, reinterpret_cast<float4*>(E->emb_s0), reinterpret_cast<float4*>(E->emb_s1), E->lin_s0, E->lin_s1, E->cfg.l2_reg,
+                   E->tab_ld / 4, E->lin_ld};
 }
 // every row to step state->t + offset (0: the present, between steps; -1: inside a step whose state has already advanced);
 // with_sums: sum theta^2 of all rows (at that step) into the step's loss scalars
-// a pre-advance (dctr_prefetch_ids) may still be running on the grouping stream: anything that reads or steps table rows on `st` waits
-int join_preadvance(dctr_engine* E, hipStream_t st) {
-    if (E->preadv_unjoined) {
-        DCTR_HIP_CHECK(hipStreamWaitEvent(st, E->ev_preadv, 0));
-        E->preadv_unjoined = false;
-    }
-    return DCTR_OK;
-}
-
 int lag_flush_tables(dctr_engine* E, hipStream_t st, int offset, bool with_sums) {
     if (E->lag_period <= 1) return DCTR_OK;
-    DCTR_TRY(join_preadvance(E, st));
     if (!E->lag_dirty && !with_sums) return DCTR_OK;
     DCTR_TRY(lag_flush(E->K, E->rows, E->emb, E->emb_s0, E->emb_s1, E->lin, E->lin_s0, E->lin_s1, E->row_ts, E->state, E->cfg.l2_reg, offset,
-                       with_sums ? E->scalars + SUMSQ_SHARDS : nullptr, (with_sums && E->lin) ? E->scalars + 2 * SUMSQ_SHARDS : nullptr, st));
+                       with_sums ? E->scalars + SUMSQ_SHARDS : nullptr, (with_sums && E->lin) ? E->scalars + 2 * SUMSQ_SHARDS : nullptr, st,
+                       E->tab_ld, E->lin_ld));
     E->lag_dirty = false;
     return DCTR_OK;
 }
@@ -898,12 +899,11 @@ int scatter_and_step_tables(dctr_engine* E, int B, hipStream_t st, hipStream_t s
     const float* coef = mode == DCTR_GATHER_FM ? E->dy : (mode == DCTR_GATHER_BI ? E->dx_in : nullptr);
     if (tail_fused(E) && (pass == OPT_PASS_TOUCHED || c.table_mode != DCTR_TABLE_DENSE_EXACT)) {
         const bool lag = lag_on(E) && pass == OPT_PASS_TOUCHED;
-        E->slots_kept = lag && E->hint_streak && preadvance_on(E);
         // (lagging rows: sum theta^2 of the visited rows alone means nothing -- a loss-reporting step takes it from the flush)
         return embed_scatter_apply(E->group, c.optimizer, &E->state->hyper, E->h_state.hyper, E->emb, E->emb_s0, E->emb_s1, E->lin, E->lin_s0,
                                    E->lin_s1, c.l2_reg, lag ? nullptr : E->scalars + SUMSQ_SHARDS, lag ? nullptr : E->scalars + 2 * SUMSQ_SHARDS,
                                    dE, E->dE_ld, E->e, E->e_ld, E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F, E->K, mode, st, 1, nullptr,
-                                   lag ? E->row_ts : nullptr, lag ? E->state : nullptr, E->slots_kept);
+                                   lag ? E->row_ts : nullptr, lag ? E->state : nullptr, E->tab_ld, E->lin_ld);
     }
     DCTR_TRY(embed_scatter_bwd(E->group, dE, E->dE_ld, E->e, E->e_ld, E->S, coef, E->lin ? E->dy : nullptr, E->vals, B, E->F,
                                E->K, mode, E->group->gemb, E->lin ? E->group->glin : nullptr, st));
@@ -912,7 +912,7 @@ int scatter_and_step_tables(dctr_engine* E, int B, hipStream_t st, hipStream_t s
     DCTR_TRY(opt_table(c.optimizer, &E->state->hyper, E->h_state.hyper, c.table_mode, E->rows, E->K, E->emb, E->emb_s0, E->emb_s1,
                        E->lin, E->lin_s0, E->lin_s1, E->group->slot, E->group->uniq, E->group->counters, E->group->max_entries,
                        E->group->gemb, E->group->glin, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, st, st_lin,
-                       pass));
+                       pass, E->tab_ld, E->lin_ld));
     if (st_lin != nullptr && st_lin != st) DCTR_TRY(fork(E, st_lin, st));
     return DCTR_OK;
 }
@@ -924,12 +924,12 @@ int step_untouched_rows(dctr_engine* E, hipStream_t st) {
     if (lag_on(E)) {       // one block of the table per step, its rows advanced through every step they missed (lag.h)
         E->lag_dirty = true;
         return lag_sweep(E->K, E->rows, E->emb, E->emb_s0, E->emb_s1, E->lin, E->lin_s0, E->lin_s1, E->group->slot, E->row_ts, E->state,
-                         c.l2_reg, E->lag_period, st);
+                         c.l2_reg, E->lag_period, st, E->tab_ld, E->lin_ld);
     }
     return opt_table(c.optimizer, &E->state->hyper, E->h_state.hyper, c.table_mode, E->rows, E->K, E->emb, E->emb_s0, E->emb_s1,
                      E->lin, E->lin_s0, E->lin_s1, E->group->slot, E->group->uniq, E->group->counters, E->group->max_entries,
                      E->group->gemb, E->group->glin, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, st, nullptr,
-                     OPT_PASS_UNTOUCHED);
+                     OPT_PASS_UNTOUCHED, E->tab_ld, E->lin_ld);
 }
 
 // The step as a small DAG over three streams (captured into one hipGraph):
@@ -986,21 +986,18 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     // the per-step state kernel (5 us) runs on st: handing it to a side stream costs st a record AND a wait on a fresh
     // dependency -- two cross-queue hops of ~10 us each, measured 0.374 -> 0.351 ms/step.  DCTR_STATE_ON_SIDE=1 is the old placement
     static const bool state_on_main = getenv("DCTR_STATE_ON_SIDE") == nullptr;
-    // ids grouped ahead (dctr_prefetch_ids, during the tail of the previous step) -- and, with lagging rows, their rows pre-advanced
+    // ids grouped ahead (dctr_prefetch_ids, during the tail of the previous step)
     const bool pregrouped = E->pre_valid && E->pre_ids == E->ids && E->pre_B == B && E->group_alt != nullptr && !E->cfg.use_graph &&
                             E->pre_gen == E->slot_gen[E->pre_slot].load();     // (the slot still holds what was grouped)
-    const bool rows_current = pregrouped && E->pre_advanced;
-    E->pre_advanced = false;
-    E->hint_streak = pregrouped;
     if (E->state_ready) {
         // prepared under the tail of the previous step (below): the two states / scalar sets change roles
         std::swap(E->state, E->state_alt);
         std::swap(E->scalars, E->scalars_alt);
         E->state_ready = false;
-        DCTR_TRY(forward_gather_train(E, B, st, rows_current));
+        DCTR_TRY(forward_gather_train(E, B, st));
     } else if (state_on_main || lag_on(E)) {
         DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, st));
-        DCTR_TRY(forward_gather_train(E, B, st, rows_current));
+        DCTR_TRY(forward_gather_train(E, B, st));
     } else {
         DCTR_TRY(fork(E, st, sw));
         DCTR_TRY(step_state_advance(E->state, E->scalars, 4 * SUMSQ_SHARDS, sw));
@@ -1022,9 +1019,6 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     // ids grouped ahead (dctr_prefetch_ids, during the tail of the previous step): the two grouping states change roles
     E->pre_valid = false;
     if (pregrouped) std::swap(E->group, E->group_alt);
-    const bool pre_hint_stream = pregrouped && E->pre_on_hint_stream && E->ev_preadv != nullptr;
-    E->pre_on_hint_stream = false;
-    const bool clear_alt = pregrouped && E->group_alt != nullptr && !E->group_alt->slots_clean;      // (kept for the pre-advance; cleared below, on sg)
     const int group_after = group_after_env >= 0 ? group_after_env
                             : E->mlp.empty() ? 0
                             : pregrouped ? (int)E->mlp.size()
@@ -1039,25 +1033,15 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     const std::function<int()> start_grouping = [&]() -> int {
         if (late_sweep) return DCTR_OK;
         DCTR_TRY(stop_fork(E, st, sg));     // not before the gather (its atomics slow a concurrent gather 4x); rides on the layer's launch when armed
-        // the previous step's grouping state kept its slot words for the pre-advance (lag.h): cleared a step before it is reused, on
-        // the stream that reuses it; this step's grouping came from that stream too: the sweep reads its slot words
-        if (pre_hint_stream) DCTR_HIP_CHECK(hipStreamWaitEvent(sg, E->ev_preadv, 0));
-        E->have_alt_ready_ev = false;
-        if (clear_alt) {        // (on sg: behind the previous step's sweep, the last reader of these slot words on this stream)
-            DCTR_TRY(group_clear_slots(E->group_alt, sg));
-            DCTR_TRY(record_on(E, sg, &E->alt_ready_ev));
-            E->have_alt_ready_ev = true;
-        }
         // (a captured step is replayed from states this enqueue cannot see: it always carries the slot-reset kernel)
         if (E->cfg.use_graph) E->group->slots_clean = false;
         if (!pregrouped) DCTR_TRY(group_ids(E->group, E->ids, B, E->F, sg, !tail_fused(E)));
         if (split_table && !bg_late) DCTR_TRY(step_untouched_rows(E, sg));
         // what the scatter needs from this stream ends here: it waits for THIS record, not for the output layer's optimizer
         // launches that follow on sg (two latency-bound kernels, ~80 us in the step: they used to hold the scatter back ~10 us)
-        if (!bg_late) { DCTR_TRY(record_on(E, sg, &tables_ev)); have_tables_ev = true; E->sweep_ev = tables_ev; E->have_sweep_ev = true; }
+        if (!bg_late) { DCTR_TRY(record_on(E, sg, &tables_ev)); have_tables_ev = true; }
         return DCTR_OK;
     };
-    E->have_sweep_ev = false;
     const bool have_mlp = !E->mlp.empty() && E->cfg.model != DCTR_MODEL_AFM;
     if (!(group_after >= 1 && have_mlp)) DCTR_TRY(start_grouping());
     DCTR_TRY(forward_rest(E, B, true, st, (group_after >= 1 && have_mlp) ? &start_grouping : nullptr, group_after - 1));
@@ -1295,6 +1279,10 @@ int dctr_destroy(dctr_handle E) {
     if (!E) return DCTR_OK;
     for (auto& kv : E->train_graphs) hipGraphExecDestroy(kv.second);
     for (auto& kv : E->predict_graphs) hipGraphExecDestroy(kv.second);
+    if (E->table_rec != nullptr) {          // row records: the six table pointers are views into this one buffer
+        hipFree(E->table_rec);
+        E->emb = E->emb_s0 = E->emb_s1 = E->lin = E->lin_s0 = E->lin_s1 = nullptr;
+    }
     float* fl[] = {E->emb, E->emb_s0, E->emb_s1, E->lin, E->lin_s0, E->lin_s1, E->theta, E->as0, E->as1, E->gflat, E->parts,
                    E->scalars, E->x_in, E->dx_in, E->e_buf, E->S, E->yw, E->yv, E->yd, E->y, E->prob, E->dy,
                    E->xs, E->xlw, E->dxL, E->cross_scratch};
@@ -1359,6 +1347,14 @@ int dctr_param_info(dctr_handle E, int index, const char** name, int* rank, int6
     return DCTR_OK;
 }
 
+// rows of `width` floats, `ld` apart in `strided`, back to back in `dense` (to_strided: dense -> strided)
+__global__ void strided_copy_kernel(float* __restrict__ strided, float* __restrict__ dense, int64_t n, int width, int ld, int to_strided) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float* s = strided + (i / width) * ld + (i % width);
+        if (to_strided) *s = dense[i]; else dense[i] = *s;
+    }
+}
+
 static int copy_param(dctr_handle E, const char* name, int which, void* host, size_t nbytes, bool to_device) {
     DCTR_REQUIRE(E && host, "null argument");
     Param* p = find_param(E, name);
@@ -1398,6 +1394,24 @@ static int copy_param(dctr_handle E, const char* name, int which, void* host, si
         if (e != hipSuccess) { set_error("parameter copy failed: %s", hipGetErrorString(e)); return DCTR_ERR_HIP; }
         return DCTR_OK;
     }
+    if (p->is_table && E->table_rec != nullptr) {       // row records (engine.h): the variable is a strided view -- through a dense staging buffer
+        const int width = p->name == "emb" ? E->K : 1;
+        const int64_t n = p->log_n;
+        float* stage = nullptr;
+        DCTR_HIP_CHECK(hipMalloc(&stage, nbytes));
+        const int grid = (int)std::min<int64_t>(ceil_div(n, 256), 8192);
+        hipError_t e = hipSuccess;
+        if (to_device) {
+            e = hipMemcpy(stage, host, nbytes, hipMemcpyHostToDevice);
+            if (e == hipSuccess) { strided_copy_kernel<<<grid, 256>>>(d, stage, n, width, E->tab_ld, 1); e = hipDeviceSynchronize(); }
+        } else {
+            strided_copy_kernel<<<grid, 256>>>(d, stage, n, width, E->tab_ld, 0);
+            e = hipMemcpy(host, stage, nbytes, hipMemcpyDeviceToHost);
+        }
+        hipFree(stage);
+        if (e != hipSuccess) { set_error("parameter copy failed: %s", hipGetErrorString(e)); return DCTR_ERR_HIP; }
+        return DCTR_OK;
+    }
     if (to_device) DCTR_HIP_CHECK(hipMemcpy(d, host, nbytes, hipMemcpyHostToDevice));
     else DCTR_HIP_CHECK(hipMemcpy(host, d, nbytes, hipMemcpyDeviceToHost));
     return DCTR_OK;
@@ -1416,7 +1430,21 @@ int dctr_slot_set(dctr_handle h, const char* name, int which, const float* h_src
     DCTR_REQUIRE(which == 0 || which == 1, "slot index must be 0 or 1");
     return copy_param(h, name, which, const_cast<float*>(h_src), nbytes, true);
 }
+static int param_device_view(dctr_handle E, const char* name, float** d_ptr, int64_t* row_stride);
 int dctr_param_device_ptr(dctr_handle E, const char* name, float** d_ptr) {
+    DCTR_REQUIRE(E && d_ptr, "null argument");
+    Param* p0 = find_param(E, name);
+    if (p0 != nullptr && p0->is_table && E->table_rec != nullptr) {
+        set_error("parameter '%s' lives in row records (rows %d floats apart): use dctr_param_device_view, or dctr_param_get / _set", name, E->tab_ld);
+        return DCTR_ERR_UNSUPPORTED;
+    }
+    return param_device_view(E, name, d_ptr, nullptr);
+}
+int dctr_param_device_view(dctr_handle E, const char* name, float** d_ptr, int64_t* row_stride) {
+    DCTR_REQUIRE(row_stride != nullptr, "null argument");
+    return param_device_view(E, name, d_ptr, row_stride);
+}
+static int param_device_view(dctr_handle E, const char* name, float** d_ptr, int64_t* row_stride) {
     DCTR_REQUIRE(E && d_ptr, "null argument");
     Param* p = find_param(E, name);
     if (!p) return DCTR_ERR_NOT_FOUND;
@@ -1427,6 +1455,8 @@ int dctr_param_device_ptr(dctr_handle E, const char* name, float** d_ptr) {
         DCTR_HIP_CHECK(hipDeviceSynchronize());
     }
     *d_ptr = p->ptr;
+    if (row_stride != nullptr)      // floats between consecutive rows of the variable's first dimension
+        *row_stride = p->is_table ? (p->name == "emb" ? E->tab_ld : E->lin_ld) : (p->rank > 0 ? p->log_n / std::max<int64_t>(p->log_dims[0], 1) : 1);
     return DCTR_OK;
 }
 
@@ -1482,40 +1512,14 @@ int dctr_prefetch_ids(dctr_handle E, const int32_t* d_ids_next, int B) {
     if (E->group_alt == nullptr) DCTR_TRY(group_create(E->rows, E->group->max_entries, E->K, &E->group_alt));
     // where the grouping of the next batch may start: behind the step's last st -> sw fork (beside scatter + table step, default),
     // or as soon as the grouping stream has drained its own work of the step (DCTR_PREGROUP_WAIT=none: beside the dense backward)
-    // With the pre-advance (lag.h) the chain grouping -> pre-advance gates the NEXT gather: it starts as soon as the grouping stream
-    // is free (it touches nothing the step in flight touches: disjoint rows, the other grouping state).
     static const int wait_mode = [] { const char* v = getenv("DCTR_PREGROUP_WAIT"); return v == nullptr ? -1 : (strcmp(v, "none") == 0 ? 0 : 1); }();
-    const bool will_preadvance = lag_on(E) && preadvance_on(E) && E->slots_kept && E->have_sweep_ev && E->s_opt != nullptr;
-    const bool wait_tail = wait_mode == 1 || (wait_mode == -1 && !will_preadvance);
-    // ... and on a stream of its own (s_opt): the grouping stream is a serial chain of small latency-bound kernels (slot clearing, the
-    // background sweep, the output layer's optimizer launches: ~100 us at c2), behind which the four grouping kernels and the
-    // pre-advance would end AFTER the step's table step
-    hipStream_t sh = will_preadvance ? E->s_opt : E->s_group;
-    if (E->have_tail && wait_tail) DCTR_HIP_CHECK(hipStreamWaitEvent(sh, E->ev_tail, 0));
-    // (the grouping state being refilled: its slot words were cleared on s_group this step; its last pre-advance ran on s_opt)
-    if (E->have_alt_ready_ev && sh != E->s_group) DCTR_HIP_CHECK(hipStreamWaitEvent(sh, E->alt_ready_ev, 0));
-    if (E->ev_preadv != nullptr && sh != E->s_opt) DCTR_HIP_CHECK(hipStreamWaitEvent(sh, E->ev_preadv, 0));
+    hipStream_t sh = E->s_group;
+    if (E->have_tail && wait_mode != 0) DCTR_HIP_CHECK(hipStreamWaitEvent(sh, E->ev_tail, 0));
     // (a slot filled by dctr_input_slot_fill whose copies may still be in flight: the grouping stream waits for them on the device)
     if (E->slot_fill_pending[slot].load(std::memory_order_acquire)) DCTR_HIP_CHECK(hipStreamWaitEvent(sh, E->slot_filled[slot], 0));
     DCTR_TRY(group_ids(E->group_alt, d_ids_next, B, E->F, sh, !tail_fused(E)));
     E->pre_ids = d_ids_next; E->pre_B = B; E->pre_valid = true;
     E->pre_slot = slot; E->pre_gen = E->slot_gen[slot].load();
-    E->pre_advanced = false;
-    // lagging rows: the rows that batch will read and the step in flight does not touch advance to the present NOW, beside that step's
-    // table step (disjoint rows: membership in the batch in flight = its grouping's slot words, which its table step was told to keep)
-    if (will_preadvance) {
-        E->slots_kept = false;
-        if (E->ev_preadv == nullptr) DCTR_HIP_CHECK(hipEventCreateWithFlags(&E->ev_preadv, hipEventDisableTiming | hipEventDisableSystemFence));
-        // (behind the step's background sweep: both replay rows no batch touched, and a row of the sweep's block may be one of these)
-        DCTR_HIP_CHECK(hipStreamWaitEvent(sh, E->sweep_ev, 0));
-        DCTR_TRY(lag_preadvance(E->K, E->rows, E->emb, E->emb_s0, E->emb_s1, E->lin, E->lin_s0, E->lin_s1, E->group_alt->uniq, E->group_alt->counters,
-                                E->group_alt->max_entries, E->group->slot, E->row_ts, E->state, E->cfg.l2_reg, sh));
-        DCTR_HIP_CHECK(hipEventRecord(E->ev_preadv, sh));
-        E->pre_on_hint_stream = true;
-        E->pre_advanced = true;
-        E->preadv_unjoined = true;
-        E->lag_dirty = true;
-    }
     return DCTR_OK;
 }
 
@@ -1773,7 +1777,7 @@ int dctr_train_step_csr(dctr_handle E, const int32_t* d_offsets, const int32_t* 
             DCTR_TRY(embed_scatter_apply(E->group, c.optimizer, &E->state->hyper, E->h_state.hyper, E->emb, E->emb_s0, E->emb_s1, nullptr, nullptr,
                                          nullptr, c.l2_reg, lag_on(E) ? nullptr : E->scalars + SUMSQ_SHARDS, lag_on(E) ? nullptr : E->scalars + 2 * SUMSQ_SHARDS,
                                          E->dx_in, 4, nullptr, 0, nullptr, nullptr, nullptr, d_weights, nnz, 1, E->K, DCTR_GATHER_RAW, st, 1, goff,
-                                         lag_on(E) ? E->row_ts : nullptr, lag_on(E) ? E->state : nullptr));
+                                         lag_on(E) ? E->row_ts : nullptr, lag_on(E) ? E->state : nullptr, E->tab_ld, E->lin_ld));
     } else {
     if (nnz > 0)
         DCTR_TRY(embed_scatter_bwd(E->group, E->dx_in, 4, nullptr, 0, nullptr, nullptr, nullptr, d_weights, nnz, 1, E->K, DCTR_GATHER_RAW,
@@ -1781,7 +1785,7 @@ int dctr_train_step_csr(dctr_handle E, const int32_t* d_offsets, const int32_t* 
     DCTR_TRY(opt_table(c.optimizer, &E->state->hyper, E->h_state.hyper, c.table_mode, E->rows, E->K, E->emb, E->emb_s0, E->emb_s1,
                        nullptr, nullptr, nullptr, E->group->slot, E->group->uniq, E->group->counters, E->group->max_entries,
                        E->group->gemb, nullptr, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, st, nullptr,
-                       split_table ? OPT_PASS_TOUCHED : OPT_PASS_ALL));
+                       split_table ? OPT_PASS_TOUCHED : OPT_PASS_ALL, E->tab_ld, E->lin_ld));
     }
     DCTR_TRY(fork(E, sw, st));
     E->last_B = B;
@@ -1831,9 +1835,13 @@ int dctr_eval_auc_extra(dctr_handle E, int which, float* h_auc, void* stream) {
 }
 
 // ---- mode EVAL (DeepFM.py:193-201): streaming loss + tf.metrics.auc over an eval set --------------------------------------
-__global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+// (x: n floats in rows of `width`, `ld` apart -- a dense variable is one row)
+__global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out, int width = 0, int ld = 0) {
     float s = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += x[i] * x[i];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = width > 0 ? x[(i / width) * ld + (i % width)] : x[i];
+        s += v * v;
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
@@ -1869,7 +1877,11 @@ int dctr_eval_result(dctr_handle E, float* h_auc, float* h_loss, int64_t* h_exam
         DCTR_TRY(lag_flush_tables(E, st, 0, false));
         DCTR_HIP_CHECK(hipMemsetAsync(E->eval_scalars + SUMSQ_SHARDS, 0, sizeof(float), st));
         for (auto& p : E->params)
-            if (p.l2 != 0.f) sumsq_kernel<<<256, 256, 0, st>>>(p.ptr, p.n, E->eval_scalars + SUMSQ_SHARDS);
+            if (p.l2 != 0.f) {
+                const bool rec = p.is_table && E->table_rec != nullptr;
+                sumsq_kernel<<<256, 256, 0, st>>>(p.ptr, p.n, E->eval_scalars + SUMSQ_SHARDS, rec ? (p.name == "emb" ? E->K : 1) : 0,
+                                                  rec ? E->tab_ld : 0);
+            }
         float sc[SUMSQ_SHARDS + 1];
         DCTR_HIP_CHECK(hipMemcpyAsync(sc, E->eval_scalars, sizeof(sc), hipMemcpyDeviceToHost, st));
         DCTR_HIP_CHECK(hipStreamSynchronize(st));
@@ -1976,9 +1988,9 @@ int dctr_table_gather_packed(dctr_handle E, const int32_t* d_rows, int n, float*
     DCTR_REQUIRE(n >= 0 && (int64_t)n <= E->group->max_entries, "too many rows requested (%d)", n);
     if (owner_lag(E)) {           // rows may lag (lag.h): shipped as of the present
         const LagView L = lag_view(E);
-        return pack_table_rows(E->emb, E->lin, E->rows, E->K, d_rows, n, d_out, E->status, as_stream(stream), &L);
+        return pack_table_rows(E->emb, E->lin, E->rows, E->K, d_rows, n, d_out, E->status, as_stream(stream), &L, E->tab_ld, E->lin_ld);
     }
-    return pack_table_rows(E->emb, E->lin, E->rows, E->K, d_rows, n, d_out, E->status, as_stream(stream));
+    return pack_table_rows(E->emb, E->lin, E->rows, E->K, d_rows, n, d_out, E->status, as_stream(stream), nullptr, E->tab_ld, E->lin_ld);
 }
 
 int dctr_table_group_rows(dctr_handle E, int which, const int32_t* d_rows, int n, void* stream) {
@@ -2003,11 +2015,12 @@ int dctr_table_apply_packed(dctr_handle E, int which, int n, const float* d_grad
         // gradients are advanced to t-1, stepped and stamped by the fused scatter + optimizer launch
         E->lag_dirty = true;
         DCTR_TRY(lag_sweep(E->K, E->rows, E->emb, E->emb_s0, E->emb_s1, E->lin, E->lin_s0, E->lin_s1, G->slot, E->row_ts, E->state, c.l2_reg,
-                           E->lag_period, st));
+                           E->lag_period, st, E->tab_ld, E->lin_ld));
         if (n > 0)
             DCTR_TRY(embed_scatter_apply(G, c.optimizer, &E->state->hyper, E->h_state.hyper, E->emb, E->emb_s0, E->emb_s1, E->lin, E->lin_s0,
                                          E->lin_s1, c.l2_reg, nullptr, nullptr, d_grads, P, nullptr, 0, nullptr, nullptr,
-                                         E->lin ? d_grads + E->K : nullptr, E->ones, n, 1, E->K, DCTR_GATHER_RAW, st, P, nullptr, E->row_ts, E->state));
+                                         E->lin ? d_grads + E->K : nullptr, E->ones, n, 1, E->K, DCTR_GATHER_RAW, st, P, nullptr, E->row_ts, E->state,
+                                         E->tab_ld, E->lin_ld));
         return DCTR_OK;
     }
     // a loss-reporting step needs sum theta^2 of every row (and a group whose compact rows a plain scatter has used cannot take the
@@ -2021,7 +2034,7 @@ int dctr_table_apply_packed(dctr_handle E, int which, int n, const float* d_grad
                                    DCTR_GATHER_RAW, G->gemb, E->lin ? G->glin : nullptr, st, P));
     return opt_table(c.optimizer, &E->state->hyper, E->h_state.hyper, c.table_mode, E->rows, E->K, E->emb, E->emb_s0, E->emb_s1,
                      E->lin, E->lin_s0, E->lin_s1, G->slot, G->uniq, G->counters, G->max_entries, G->gemb, G->glin, c.l2_reg,
-                     E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, st);
+                     E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, st, nullptr, OPT_PASS_ALL, E->tab_ld, E->lin_ld);
 }
 
 }  // extern "C"
@@ -2169,8 +2182,8 @@ int dctr_time_kernel(dctr_handle E, const char* kernel, int iters, float* h_ms_p
         if (s == "embed_gather") {
             const int mode = gather_mode(E);
             float* red = mode == DCTR_GATHER_FM ? E->yv : (mode == DCTR_GATHER_BI ? E->x_in : nullptr);
-            return embed_gather_fwd(E->emb, E->lin, E->rows, E->ids, E->vals, B, E->F, E->K, mode, E->e, E->e_ld,
-                                    E->lin ? E->yw : nullptr, E->S, red, E->status, cs);
+            return embed_gather_strided(E->emb, E->tab_ld, E->lin, E->lin_ld, E->rows, E->ids, E->vals, B, E->F, E->K, mode, E->e, E->e_ld,
+                                        E->lin ? E->yw : nullptr, E->S, red, E->status, cs);
         }
         if (s == "forward") return forward(E, B, true, cs);
         if (s == "head") return head(E, B, B, true, cs, nullptr, true);
@@ -2190,7 +2203,8 @@ int dctr_time_kernel(dctr_handle E, const char* kernel, int iters, float* h_ms_p
         if (s == "opt_table")
             return opt_table(c.optimizer, &E->state->hyper, E->h_state.hyper, c.table_mode, E->rows, E->K, E->emb, E->emb_s0,
                              E->emb_s1, E->lin, E->lin_s0, E->lin_s1, E->group->slot, E->group->uniq, E->group->counters,
-                             E->group->max_entries, E->group->gemb, E->group->glin, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, cs);
+                             E->group->max_entries, E->group->gemb, E->group->glin, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, cs,
+                             nullptr, OPT_PASS_ALL, E->tab_ld, E->lin_ld);
         if (s == "opt_dense")
             return opt_dense_arena(c.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->parts, E->meta,
                                    E->n_blocks, nullptr, 1, E->scalars + 3 * SUMSQ_SHARDS, cs);

@@ -64,10 +64,10 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(
                     // the Adam slots are read WITH the row, not after its stamp has come back: the gather is a chain of dependent
                     // random reads, and one stage less is worth more than the bytes of the rows that turn out to be current
                     nlag[u] = ok ? lag_behind(L.state->t - 1, L.ts[id[u]]) : 0;
-                    m[u] = ok ? L.s0[(size_t)id[u] * KQ + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    vv[u] = ok ? L.s1[(size_t)id[u] * KQ + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    m[u] = ok ? L.s0[(size_t)id[u] * L.ld4 + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    vv[u] = ok ? L.s1[(size_t)id[u] * L.ld4 + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
                     lm[u] = lv[u] = 0.f;
-                    if (ok && lin != nullptr && kq == 0) { lm[u] = L.l0[id[u]]; lv[u] = L.l1[id[u]]; }
+                    if (ok && lin != nullptr && kq == 0) { lm[u] = L.l0[(size_t)id[u] * L.lin_ld]; lv[u] = L.l1[(size_t)id[u] * L.lin_ld]; }
                 }
             }
             if constexpr (LAG) {
@@ -128,7 +128,8 @@ static int launch_gather(const float* emb, const float* lin, int64_t rows, int e
     constexpr int EPB = 256 / (KQ * FS);
     dim3 grid(ceil_div(B, EPB)), block(256);
     const float4* emb4 = reinterpret_cast<const float4*>(emb);
-    const LagView L = lag ? *lag : LagView{};
+    LagView L = lag ? *lag : LagView{};
+    if (L.ld4 == 0) L.ld4 = KQ;
 #define DCTR_GK(MODE_)                                                                                                                  \
     if (lag) gather_fwd_kernel<KQ, FS, MODE_, U, true><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status, L); \
     else gather_fwd_kernel<KQ, FS, MODE_, U, false><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status, L)
@@ -150,7 +151,8 @@ static int launch_gather(const float* emb, const float* lin, int64_t rows, int e
 int embed_gather_strided(const float* emb, int emb_ld, const float* lin, int lin_ld, int64_t rows, const int32_t* ids,
                      const float* vals, int B, int F, int K, int mode, float* e, int e_ld, float* yw,
                      float* sum, float* red, int32_t* status, hipStream_t st, const LagView* lag) {
-    DCTR_REQUIRE(lag == nullptr || (emb_ld == K && lin_ld == 1), "gather: lagging rows live in the engine's own tables");
+    DCTR_REQUIRE(lag == nullptr || (lag->ld4 == 0 ? (emb_ld == K && lin_ld == 1) : (emb_ld == 4 * lag->ld4 && lin_ld == lag->lin_ld)),
+                 "gather: lagging rows live in the engine's own tables (the Adam slots share the table's row strides)");
     DCTR_REQUIRE(K % 4 == 0 && K >= 4 && K <= 256, "embedding_size must be a multiple of 4 in [4,256], got %d", K);
     DCTR_REQUIRE(emb_ld % 4 == 0 && emb_ld >= K && lin_ld >= 1, "gather: bad table strides emb_ld=%d lin_ld=%d", emb_ld, lin_ld);
     DCTR_REQUIRE(e_ld % 4 == 0 && e_ld >= F * K, "gather: e_ld=%d must be a multiple of 4 and >= F*K=%d", e_ld, F * K);

@@ -493,6 +493,7 @@ struct TableStep {
     int32_t* slot;                              // the grouping's slot word of every visited row goes back to 0 (no group_reset pass)
     int32_t* done;                              // [U] completion tickets
     uint8_t* ts; const StepState* state;        // lagging rows (lag.h; Adam): advanced to t-1 before this step's update, stamped t; nullptr = classic
+    int ld4; int lin_ld;                        // row strides of emb / s0 / s1 (float4 units) and of lin / l0 / l1 (floats): KQ and 1, or the record stride (engine.h)
 };
 
 // the row's pieces are LOADED as soon as the distinct id is known (before the gradient loads: one latency instead of two) and
@@ -504,10 +505,10 @@ __device__ __forceinline__ RowRegs table_row_load(const TableStep& T, int u, int
     constexpr bool TWO = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL);
     RowRegs R;
     R.r = T.uniq[u];
-    const size_t i4 = (size_t)R.r * KQ + kq;
+    const size_t i4 = (size_t)R.r * T.ld4 + kq, il = (size_t)R.r * T.lin_ld;
     R.th = T.emb[i4]; R.a = T.s0[i4]; R.b = TWO ? T.s1[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
     R.lt = R.la = R.lb = 0.f;
-    if (kq == 0 && T.lin != nullptr) { R.lt = T.lin[R.r]; R.la = T.l0[R.r]; R.lb = TWO ? T.l1[R.r] : 0.f; }
+    if (kq == 0 && T.lin != nullptr) { R.lt = T.lin[il]; R.la = T.l0[il]; R.lb = TWO ? T.l1[il] : 0.f; }
     R.nlag = (KIND == DCTR_OPT_ADAM && T.ts != nullptr) ? lag_behind(T.state->t - 1, T.ts[R.r]) : 0;
     return R;
 }
@@ -515,7 +516,7 @@ __device__ __forceinline__ RowRegs table_row_load(const TableStep& T, int u, int
 template <int KIND, int KQ>
 __device__ __forceinline__ void table_row_step(const TableStep& T, const Hyper& h, RowRegs& R, int kq, float4 gs, float gl, float& sq, float& sql) {
     constexpr bool TWO = (KIND == DCTR_OPT_ADAM || KIND == DCTR_OPT_FTRL);
-    const size_t i4 = (size_t)R.r * KQ + kq;
+    const size_t i4 = (size_t)R.r * T.ld4 + kq, il = (size_t)R.r * T.lin_ld;
     float4 th = R.th, a = R.a, b = R.b;
     if (KIND == DCTR_OPT_ADAM && R.nlag > 0) {          // the steps no batch touched this row: replayed first (lag.h)
         const int64_t first = T.state->t - R.nlag;
@@ -530,7 +531,7 @@ __device__ __forceinline__ void table_row_step(const TableStep& T, const Hyper& 
     opt_update(KIND, h, th.w, a.w, b.w, g.w);
     T.emb[i4] = th; T.s0[i4] = a;
     if (TWO) T.s1[i4] = b;
-    if (kq == 0 && T.slot != nullptr) T.slot[R.r] = 0;
+    if (kq == 0) T.slot[R.r] = 0;
     if (KIND == DCTR_OPT_ADAM && kq == 0 && T.ts != nullptr) T.ts[R.r] = (uint8_t)T.state->t;
     if (kq == 0 && T.lin != nullptr) {
         float lt = R.lt, la = R.la, lb = R.lb;
@@ -538,8 +539,8 @@ __device__ __forceinline__ void table_row_step(const TableStep& T, const Hyper& 
         float lg = T.l2 * lt;
         lg += gl;
         opt_update(KIND, h, lt, la, lb, lg);
-        T.lin[R.r] = lt; T.l0[R.r] = la;
-        if (TWO) T.l1[R.r] = lb;
+        T.lin[il] = lt; T.l0[il] = la;
+        if (TWO) T.l1[il] = lb;
     }
 }
 
@@ -750,7 +751,9 @@ static int launch_scatter_apply(Group* g, const float* dE, int de_ld, const floa
 int embed_scatter_apply(Group* g, int kind, const Hyper* hdev, const Hyper& hval, float* emb, float* e0, float* e1, float* lin,
                         float* l0, float* l1, float l2, float* sumsq_emb, float* sumsq_lin, const float* dE, int de_ld,
                         const float* e, int e_ld, const float* S, const float* coef, const float* dy, const float* vals, int B, int F,
-                        int K, int mode, hipStream_t st, int dy_ld, const int32_t* entry_row, uint8_t* lag_ts, const StepState* lag_state, bool keep_slots) {
+                        int K, int mode, hipStream_t st, int dy_ld, const int32_t* entry_row, uint8_t* lag_ts, const StepState* lag_state,
+                        int tab_ld, int tab_lin_ld) {
+    DCTR_REQUIRE(tab_ld % 4 == 0 && (tab_ld == 0 || tab_ld >= K), "scatter_apply: table row stride %d", tab_ld);
     DCTR_REQUIRE(K == g->K, "scatter: K=%d but group was created with K=%d", K, g->K);
     DCTR_REQUIRE(lag_ts == nullptr || (kind == DCTR_OPT_ADAM && lag_state != nullptr), "scatter_apply: lagging rows are an Adam-only scheme");
     DCTR_REQUIRE(g->gemb_clean, "scatter_apply: the group's compact gradient rows are not known to be zero");
@@ -759,8 +762,8 @@ int embed_scatter_apply(Group* g, int kind, const Hyper* hdev, const Hyper& hval
                  "scatter: FM/BI modes need e, S and coef");
     DCTR_REQUIRE((lin != nullptr) == (dy != nullptr), "scatter_apply: linear weights and their gradient source go together");
     TableStep T{reinterpret_cast<float4*>(emb), reinterpret_cast<float4*>(e0), reinterpret_cast<float4*>(e1), lin, l0, l1, hdev, hval,
-                l2, sumsq_emb, sumsq_lin, g->uniq, keep_slots ? nullptr : g->slot, g->done, lag_ts, lag_state};
-    g->slots_clean = !keep_slots;           // (every distinct id of the grouping is visited exactly once, and each visit clears its slot word)
+                l2, sumsq_emb, sumsq_lin, g->uniq, g->slot, g->done, lag_ts, lag_state, tab_ld > 0 ? tab_ld / 4 : K / 4, tab_lin_ld};
+    g->slots_clean = true;                  // (every distinct id of the grouping is visited exactly once, and each visit clears its slot word)
 #define DCTR_Q(KD, Q) case Q: return launch_scatter_apply<KD, Q>(g, dE, de_ld, e, e_ld, S, coef, dy, vals, B, F, mode, dy_ld, st, entry_row, T)
 #define DCTR_KD(KD) case KD: switch (K / 4) { DCTR_Q(KD, 1); DCTR_Q(KD, 2); DCTR_Q(KD, 4); DCTR_Q(KD, 8); DCTR_Q(KD, 16); DCTR_Q(KD, 32); DCTR_Q(KD, 64); \
                               default: set_error("scatter: K=%d unsupported", K); return DCTR_ERR_UNSUPPORTED; }
@@ -809,14 +812,6 @@ int group_destroy(Group* g) {
     hipFree(g->slot); hipFree(g->uniq); hipFree(g->cnt); hipFree(g->seg_start); hipFree(g->cursor);
     hipFree(g->perm); hipFree(g->seg_of); hipFree(g->counters); hipFree(g->gemb); hipFree(g->glin); hipFree(g->long_list); hipFree(g->done); hipFree(g->medium_list);
     delete g;
-    return DCTR_OK;
-}
-
-int group_clear_slots(Group* g, hipStream_t st) {
-    if (g->slots_clean) return DCTR_OK;
-    group_reset_kernel<<<ceil_div(g->max_entries, 256), 256, 0, st>>>(g->slot, g->uniq, g->counters, (int)g->max_entries);
-    DCTR_LAUNCH_CHECK();
-    g->slots_clean = true;
     return DCTR_OK;
 }
 

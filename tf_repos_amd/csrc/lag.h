@@ -29,6 +29,8 @@ struct LagView {
     float4* s0; float4* s1;     // the table's Adam slots (the gather needs them only for lagging rows)
     float* l0; float* l1;       // the linear table's
     float l2;
+    int ld4 = 0;                // row stride of s0 / s1 in float4 units (0: K / 4 -- separate [rows, K] arrays); the table's own stride
+    int lin_ld = 1;             // row stride of l0 / l1 in floats (records: engine.h table layout)
 };
 
 #ifdef DCTR_LAG_LANE_LOOPS      // (A/B: round 3's lane-own loops, tf_repos_amd.build --variant lanelag -DDCTR_LAG_LANE_LOOPS)
@@ -205,14 +207,11 @@ __device__ __forceinline__ void lag_catch_up1(const StepState* __restrict__ S, H
 // steps a row stamped `ts` is behind `target` (both compared mod 256)
 __device__ __forceinline__ int lag_behind(int64_t target, uint8_t ts) { return (int)(uint8_t)((uint8_t)target - ts); }
 
+// (ld / lin_ld: row strides in floats of emb, s0, s1 / lin, l0, l1; 0 / 1 = separate dense arrays [rows, K] / [rows])
 int lag_sweep(int K, int64_t rows, float* emb, float* s0, float* s1, float* lin, float* l0, float* l1, const int32_t* slot, uint8_t* ts,
-              const StepState* state, float l2, int period, hipStream_t st);
+              const StepState* state, float l2, int period, hipStream_t st, int ld = 0, int lin_ld = 1);
 int lag_flush(int K, int64_t rows, float* emb, float* s0, float* s1, float* lin, float* l0, float* l1, uint8_t* ts, const StepState* state,
-              float l2, int target_offset, float* sumsq_emb, float* sumsq_lin, hipStream_t st);
+              float l2, int target_offset, float* sumsq_emb, float* sumsq_lin, hipStream_t st, int ld = 0, int lin_ld = 1);
 int lag_stamp(uint8_t* ts, int64_t rows, const StepState* state, hipStream_t st);
-// the distinct rows of the NEXT batch (uniq_next[0 : *n_next)) that the batch in flight does not touch (cur_slot word 0) advance to the
-// step in flight, so that the next step's gather finds every row it reads current and takes the plain path (lag.h, header)
-int lag_preadvance(int K, int64_t rows, float* emb, float* s0, float* s1, float* lin, float* l0, float* l1, const int32_t* uniq_next,
-                   const int32_t* n_next, int64_t cap, const int32_t* cur_slot, uint8_t* ts, const StepState* state, float l2, hipStream_t st);
 
 }  // namespace dctr

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void lag_advance_kernel(int64_t rows, float4* 
                                                          float* __restrict__ lin, float* __restrict__ l0, float* __restrict__ l1,
                                                          const int32_t* __restrict__ slot, uint8_t* __restrict__ ts,
                                                          const StepState* __restrict__ S, float l2, int period, int target_offset,
-                                                         float* __restrict__ sumsq_emb, float* __restrict__ sumsq_lin) {
+                                                         float* __restrict__ sumsq_emb, float* __restrict__ sumsq_lin, int ld4, int lin_ld) {
     const int64_t T = S->t;
     const Hyper h = S->hyper;
     int64_t r0 = 0, r1 = rows, target = T + target_offset;
@@ -53,12 +53,13 @@ __global__ __launch_bounds__(256) void lag_advance_kernel(int64_t rows, float4* 
             const int kq = (int)((t0 + j * stride) % KQ);
             // (a flush that reports sum theta^2 reads every row; otherwise rows already at the target are left alone)
             if (live[j] && (n[j] > 0 || (FLUSH && sumsq_emb != nullptr))) {
-                const size_t i4 = (size_t)row[j] * KQ + kq;
+                const size_t i4 = (size_t)row[j] * ld4 + kq;
                 th[j] = emb[i4];
                 if (n[j] > 0) { m[j] = s0[i4]; v[j] = s1[i4]; }
                 if (kq == 0 && lin != nullptr) {
-                    lt[j] = lin[row[j]];
-                    if (n[j] > 0) { lm[j] = l0[row[j]]; lv[j] = l1[row[j]]; }
+                    const size_t il = (size_t)row[j] * lin_ld;
+                    lt[j] = lin[il];
+                    if (n[j] > 0) { lm[j] = l0[il]; lv[j] = l1[il]; }
                 }
             } else {
                 live[j] = false;
@@ -75,12 +76,13 @@ __global__ __launch_bounds__(256) void lag_advance_kernel(int64_t rows, float4* 
         for (int j = 0; j < UNR; ++j) {
             if (!live[j]) continue;
             const int kq = (int)((t0 + j * stride) % KQ);
-            const size_t i4 = (size_t)row[j] * KQ + kq;
+            const size_t i4 = (size_t)row[j] * ld4 + kq;
             if (n[j] > 0) { emb[i4] = th[j]; s0[i4] = m[j]; s1[i4] = v[j]; }
             sq += th[j].x * th[j].x + th[j].y * th[j].y + th[j].z * th[j].z + th[j].w * th[j].w;
             if (kq == 0) {
                 if (lin != nullptr) {
-                    if (n[j] > 0) { lin[row[j]] = lt[j]; l0[row[j]] = lm[j]; l1[row[j]] = lv[j]; }
+                    const size_t il = (size_t)row[j] * lin_ld;
+                    if (n[j] > 0) { lin[il] = lt[j]; l0[il] = lm[j]; l1[il] = lv[j]; }
                     sql += lt[j] * lt[j];
                 }
                 if (n[j] > 0) ts[row[j]] = (uint8_t)target;
@@ -108,70 +110,18 @@ __global__ __launch_bounds__(256) void lag_stamp_kernel(uint8_t* __restrict__ ts
     else for (int64_t k = i; k < rows; ++k) ts[k] = v;
 }
 
-// one row piece per lane (KQ lanes per row), 2 rows in flight per lane: the next batch's distinct rows, minus the ones the batch in
-// flight steps itself, to the step in flight -- the row arithmetic of lag_advance_kernel
-template <int KQ>
-__global__ __launch_bounds__(256) void lag_preadvance_kernel(float4* __restrict__ emb, float4* __restrict__ s0, float4* __restrict__ s1,
-                                                            float* __restrict__ lin, float* __restrict__ l0, float* __restrict__ l1,
-                                                            const int32_t* __restrict__ uniq, const int32_t* __restrict__ n_ptr, int64_t cap,
-                                                            const int32_t* __restrict__ cur_slot, uint8_t* __restrict__ ts,
-                                                            const StepState* __restrict__ S, float l2) {
-    constexpr int UNR = 2;
-    const int64_t T = S->t;
-    const Hyper h = S->hyper;
-    const int64_t U = min((int64_t)n_ptr[0], cap);
-    const int64_t n_items = U * KQ;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t0 < n_items; t0 += stride * UNR) {
-        float4 th[UNR], m[UNR], v[UNR];
-        float lt[UNR], lm[UNR], lv[UNR];
-        int n[UNR], nl[UNR];
-        int64_t row[UNR];
-#pragma unroll
-        for (int j = 0; j < UNR; ++j) {
-            const int64_t t = t0 + j * stride;
-            const bool live = t < n_items;
-            row[j] = live ? uniq[t / KQ] : 0;
-            n[j] = (live && cur_slot[row[j]] == 0) ? lag_behind(T, ts[row[j]]) : 0;     // (rows of the batch in flight: its own table step stamps them T)
-        }
-#pragma unroll
-        for (int j = 0; j < UNR; ++j) {
-            const int kq = (int)((t0 + j * stride) % KQ);
-            th[j] = m[j] = v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            lt[j] = lm[j] = lv[j] = 0.f;
-            nl[j] = 0;
-            if (n[j] > 0) {
-                const size_t i4 = (size_t)row[j] * KQ + kq;
-                th[j] = emb[i4]; m[j] = s0[i4]; v[j] = s1[i4];
-                if (kq == 0 && lin != nullptr) { lt[j] = lin[row[j]]; lm[j] = l0[row[j]]; lv[j] = l1[row[j]]; nl[j] = n[j]; }
-            }
-        }
-        lag_catch_up_rows_lin<UNR>(S, h, l2, T, n, th, m, v, nl, lt, lm, lv);
-#pragma unroll
-        for (int j = 0; j < UNR; ++j) {
-            if (n[j] <= 0) continue;
-            const int kq = (int)((t0 + j * stride) % KQ);
-            const size_t i4 = (size_t)row[j] * KQ + kq;
-            emb[i4] = th[j]; s0[i4] = m[j]; s1[i4] = v[j];
-            if (kq == 0) {
-                if (lin != nullptr) { lin[row[j]] = lt[j]; l0[row[j]] = lm[j]; l1[row[j]] = lv[j]; }
-                ts[row[j]] = (uint8_t)T;
-            }
-        }
-    }
-}
-
 template <bool FLUSH>
 int launch_advance(int K, int64_t rows, float* emb, float* s0, float* s1, float* lin, float* l0, float* l1, const int32_t* slot, uint8_t* ts,
-                   const StepState* state, float l2, int period, int target_offset, float* sumsq_emb, float* sumsq_lin, hipStream_t st) {
+                   const StepState* state, float l2, int period, int target_offset, float* sumsq_emb, float* sumsq_lin, hipStream_t st, int ld, int lin_ld) {
     const int KQ = K / 4;
+    const int ld4 = ld > 0 ? ld / 4 : KQ;
     const int64_t span = FLUSH ? rows : (rows + period - 1) / period;
     // the sweep runs UNDER the MLP GEMMs like the classic background pass: a small grid (2 blocks per CU); the flush has the chip
     static const int bpc = getenv("DCTR_LAG_BLOCKS_PER_CU") ? atoi(getenv("DCTR_LAG_BLOCKS_PER_CU")) : 2;     // A/B knob
     const int grid = (int)std::min<int64_t>(ceil_div(span * KQ, 256 * 4), FLUSH ? 256 * 8 : 256 * bpc);
     float4 *e4 = reinterpret_cast<float4*>(emb), *a4 = reinterpret_cast<float4*>(s0), *b4 = reinterpret_cast<float4*>(s1);
     switch (KQ) {
-#define DCTR_A(Q) case Q: lag_advance_kernel<Q, FLUSH, 4><<<grid, 256, 0, st>>>(rows, e4, a4, b4, lin, l0, l1, slot, ts, state, l2, period, target_offset, sumsq_emb, sumsq_lin); break
+#define DCTR_A(Q) case Q: lag_advance_kernel<Q, FLUSH, 4><<<grid, 256, 0, st>>>(rows, e4, a4, b4, lin, l0, l1, slot, ts, state, l2, period, target_offset, sumsq_emb, sumsq_lin, ld4, lin_ld); break
         DCTR_A(1); DCTR_A(2); DCTR_A(4); DCTR_A(8); DCTR_A(16); DCTR_A(32); DCTR_A(64);
 #undef DCTR_A
         default: set_error("lag: K=%d unsupported", K); return DCTR_ERR_UNSUPPORTED;
@@ -183,30 +133,14 @@ int launch_advance(int K, int64_t rows, float* emb, float* s0, float* s1, float*
 }  // namespace
 
 int lag_sweep(int K, int64_t rows, float* emb, float* s0, float* s1, float* lin, float* l0, float* l1, const int32_t* slot, uint8_t* ts,
-              const StepState* state, float l2, int period, hipStream_t st) {
+              const StepState* state, float l2, int period, hipStream_t st, int ld, int lin_ld) {
     DCTR_REQUIRE(period >= 2 && period <= LAG_MAX_PERIOD, "lag_sweep: period %d outside [2, %d]", period, LAG_MAX_PERIOD);
-    return launch_advance<false>(K, rows, emb, s0, s1, lin, l0, l1, slot, ts, state, l2, period, 0, nullptr, nullptr, st);
+    return launch_advance<false>(K, rows, emb, s0, s1, lin, l0, l1, slot, ts, state, l2, period, 0, nullptr, nullptr, st, ld, lin_ld);
 }
 
 int lag_flush(int K, int64_t rows, float* emb, float* s0, float* s1, float* lin, float* l0, float* l1, uint8_t* ts, const StepState* state,
-              float l2, int target_offset, float* sumsq_emb, float* sumsq_lin, hipStream_t st) {
-    return launch_advance<true>(K, rows, emb, s0, s1, lin, l0, l1, nullptr, ts, state, l2, 1, target_offset, sumsq_emb, sumsq_lin, st);
-}
-
-int lag_preadvance(int K, int64_t rows, float* emb, float* s0, float* s1, float* lin, float* l0, float* l1, const int32_t* uniq_next,
-                   const int32_t* n_next, int64_t cap, const int32_t* cur_slot, uint8_t* ts, const StepState* state, float l2, hipStream_t st) {
-    const int KQ = K / 4;
-    // (a background kernel beside the table step: a small grid; the distinct rows of a batch are ~1e5 at c2)
-    const int grid = (int)std::min<int64_t>(ceil_div(cap * KQ, 256 * 2), 256 * 2);
-    float4 *e4 = reinterpret_cast<float4*>(emb), *a4 = reinterpret_cast<float4*>(s0), *b4 = reinterpret_cast<float4*>(s1);
-    switch (KQ) {
-#define DCTR_P(Q) case Q: lag_preadvance_kernel<Q><<<grid, 256, 0, st>>>(e4, a4, b4, lin, l0, l1, uniq_next, n_next, cap, cur_slot, ts, state, l2); break
-        DCTR_P(1); DCTR_P(2); DCTR_P(4); DCTR_P(8); DCTR_P(16); DCTR_P(32); DCTR_P(64);
-#undef DCTR_P
-        default: set_error("lag: K=%d unsupported", K); return DCTR_ERR_UNSUPPORTED;
-    }
-    DCTR_LAUNCH_CHECK();
-    return DCTR_OK;
+              float l2, int target_offset, float* sumsq_emb, float* sumsq_lin, hipStream_t st, int ld, int lin_ld) {
+    return launch_advance<true>(K, rows, emb, s0, s1, lin, l0, l1, nullptr, ts, state, l2, 1, target_offset, sumsq_emb, sumsq_lin, st, ld, lin_ld);
 }
 
 int lag_stamp(uint8_t* ts, int64_t rows, const StepState* state, hipStream_t st) {

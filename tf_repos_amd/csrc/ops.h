@@ -61,12 +61,12 @@ inline int64_t group_capacity(const Group* g) { return g->max_entries; }
 int group_create(int64_t rows, int64_t max_entries, int K, Group** out);
 int group_destroy(Group* g);
 int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st, bool zero_gemb = true);
-int group_clear_slots(Group* g, hipStream_t st);     // slot words of the last grouped batch back to 0 (a table step that was told to keep them)
 int embed_scatter_apply(Group* g, int kind, const Hyper* hdev, const Hyper& hval, float* emb, float* e0, float* e1, float* lin,
                         float* l0, float* l1, float l2, float* sumsq_emb, float* sumsq_lin, const float* dE, int de_ld,
                         const float* e, int e_ld, const float* S, const float* coef, const float* dy, const float* vals, int B, int F,
                         int K, int mode, hipStream_t st, int dy_ld = 1, const int32_t* entry_row = nullptr, uint8_t* lag_ts = nullptr,
-                        const StepState* lag_state = nullptr, bool keep_slots = false);     // keep_slots: the grouping's slot words stay (something reads them beside this launch)
+                        const StepState* lag_state = nullptr,
+                        int tab_ld = 0, int tab_lin_ld = 1);     // row strides (floats) of emb / e0 / e1 and lin / l0 / l1: 0 / 1 = dense [rows, K] / [rows] arrays
 int embed_scatter_bwd(Group* g, const float* dE, int de_ld, const float* e, int e_ld, const float* S,
                       const float* coef, const float* dy, const float* vals, int B, int F, int K, int mode,
                       float* gemb, float* glin, hipStream_t st, int dy_ld = 1,     // dy_ld: stride (floats) between examples in dy
@@ -84,7 +84,7 @@ int embed_gather_strided(const float* emb, int emb_ld, const float* lin, int lin
 
 // ---- shard.hip: packed [K+4]-float row records for the row-sharded exchange
 int pack_table_rows(const float* emb, const float* lin, int64_t rows, int K, const int32_t* rows_idx, int n, float* out,
-                    int32_t* status, hipStream_t st, const LagView* lag = nullptr);
+                    int32_t* status, hipStream_t st, const LagView* lag = nullptr, int tab_ld = 0, int tab_lin_ld = 1);
 int pack_unique_grads(const Group* g, const float* glin, const int32_t* upos, float* out, hipStream_t st);
 
 // ---- K6 (gemm.hip)
@@ -150,7 +150,8 @@ int opt_dense_flat(int kind, const Hyper* hdev, const Hyper& hval, float* theta,
 int opt_table(int kind, const Hyper* hdev, const Hyper& hval, int table_mode, int64_t rows, int K, float* emb, float* e0,
               float* e1, float* lin, float* l0, float* l1, const int32_t* slot, const int32_t* uniq,
               const int32_t* counters, int64_t max_entries, const float* gemb, const float* glin, float l2,
-              float* sumsq_emb, float* sumsq_lin, hipStream_t st, hipStream_t st_lin = nullptr, int pass = 0);
+              float* sumsq_emb, float* sumsq_lin, hipStream_t st, hipStream_t st_lin = nullptr, int pass = 0,
+              int tab_ld = 0, int tab_lin_ld = 1);      // row strides (floats) of emb / e0 / e1 and lin / l0 / l1: 0 / 1 = dense [rows, K] / [rows] arrays
 enum { OPT_PASS_ALL = 0, OPT_PASS_UNTOUCHED = 1, OPT_PASS_TOUCHED = 2 };
 int step_state_advance(StepState* s, float* zero, int n_zero, hipStream_t st, uint64_t row0 = 0);
 int step_state_next(const StepState* cur, StepState* nxt, float* zero, int n_zero, hipStream_t st);

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void entry_index_kernel(const int32_t* __restr
 // owner side: out[i] = { emb[rows_idx[i], :], lin[rows_idx[i]], 0, 0, 0 }
 __global__ __launch_bounds__(256) void pack_table_rows_kernel(const float4* __restrict__ emb, const float* __restrict__ lin,
                                                              int64_t rows, const int32_t* __restrict__ rows_idx, int n, int KQ,
-                                                             float4* __restrict__ out, int32_t* __restrict__ status) {
+                                                             float4* __restrict__ out, int32_t* __restrict__ status, int ld4, int lin_ld) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int Q = KQ + 1;
     const int i = (int)(t / Q), q = (int)(t % Q);
@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void pack_table_rows_kernel(const float4* __re
     if (!ok && q == 0) { atomicExch(&status[1], r); atomicExch(&status[0], 1); }
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ok) {
-        if (q < KQ) v = emb[(size_t)r * KQ + q];
-        else if (lin != nullptr) v.x = lin[r];
+        if (q < KQ) v = emb[(size_t)r * ld4 + q];
+        else if (lin != nullptr) v.x = lin[(size_t)r * lin_ld];
     }
     out[(size_t)i * Q + q] = v;
 }
@@ -120,15 +120,15 @@ __global__ __launch_bounds__(256) void pack_table_rows_lag_kernel(const float4* 
         const int nl = lag_behind(T, L.ts[r]);
         const Hyper h = L.state->hyper;
         if (q < KQ) {
-            v = emb[(size_t)r * KQ + q];
+            v = emb[(size_t)r * L.ld4 + q];
             if (nl > 0) {
-                float4 m = L.s0[(size_t)r * KQ + q], vv = L.s1[(size_t)r * KQ + q];
+                float4 m = L.s0[(size_t)r * L.ld4 + q], vv = L.s1[(size_t)r * L.ld4 + q];
                 lag_catch_up4(L.state, h, L.l2, T - nl + 1, nl, v, m, vv);
             }
         } else if (lin != nullptr) {
-            v.x = lin[r];
+            v.x = lin[(size_t)r * L.lin_ld];
             if (nl > 0) {
-                float m = L.l0[r], vv = L.l1[r];
+                float m = L.l0[(size_t)r * L.lin_ld], vv = L.l1[(size_t)r * L.lin_ld];
                 lag_catch_up1(L.state, h, L.l2, T - nl + 1, nl, v.x, m, vv);
             }
         }
@@ -151,17 +151,20 @@ __global__ __launch_bounds__(256) void pack_unique_grads_kernel(const float4* __
 }
 
 int pack_table_rows(const float* emb, const float* lin, int64_t rows, int K, const int32_t* rows_idx, int n, float* out,
-                    int32_t* status, hipStream_t st, const LagView* lag) {
+                    int32_t* status, hipStream_t st, const LagView* lag, int tab_ld, int tab_lin_ld) {
     if (n <= 0) return DCTR_OK;
     const int KQ = K / 4;
+    const int ld4 = tab_ld > 0 ? tab_ld / 4 : KQ;
     if (lag != nullptr) {
+        LagView L = *lag;       // (the slots share the table's row strides)
+        L.ld4 = ld4; L.lin_ld = tab_lin_ld;
         pack_table_rows_lag_kernel<<<ceil_div((int64_t)n * (KQ + 1), 256), 256, 0, st>>>(reinterpret_cast<const float4*>(emb), lin, rows, rows_idx,
-                                                                                       n, KQ, reinterpret_cast<float4*>(out), status, *lag);
+                                                                                       n, KQ, reinterpret_cast<float4*>(out), status, L);
         DCTR_LAUNCH_CHECK();
         return DCTR_OK;
     }
     pack_table_rows_kernel<<<ceil_div((int64_t)n * (KQ + 1), 256), 256, 0, st>>>(reinterpret_cast<const float4*>(emb), lin, rows, rows_idx,
-                                                                               n, KQ, reinterpret_cast<float4*>(out), status);
+                                                                               n, KQ, reinterpret_cast<float4*>(out), status, ld4, tab_lin_ld);
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }

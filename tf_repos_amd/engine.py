@@ -371,17 +371,27 @@ class Engine:
         return g.value
 
     def param_tensor(self, name: str):
-        """Zero-copy torch view of a parameter in device memory (dctr_param_device_ptr): device-side initialisation of tables that
-        are too large to stage through the host."""
+        """Zero-copy torch view of a parameter in device memory (dctr_param_device_view): device-side initialisation of tables that
+        are too large to stage through the host.  A table kept as row records (include/deepctr_hip.h) comes back as a STRIDED view
+        (`.is_contiguous()` False: index it by rows, do not `.view(-1)` it)."""
         import torch
         p = C.c_void_p()
-        capi.check(self._lib.dctr_param_device_ptr(self._h, name.encode(), C.byref(p)))
+        ld = C.c_int64()
+        capi.check(self._lib.dctr_param_device_view(self._h, name.encode(), C.byref(p), C.byref(ld)))
         shape = tuple(int(d) for d in self.param_shapes[name])
+        iface = {"shape": shape, "typestr": "<f4", "data": (p.value, False), "version": 2}
+        inner = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+        if len(shape) >= 1 and ld.value != inner:
+            strides, acc = [], 4
+            for d in reversed(shape[1:]):
+                strides.insert(0, acc)
+                acc *= d
+            iface["strides"] = tuple([4 * ld.value] + strides)
 
         class _A:
             pass
         a = _A()
-        a.__cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (p.value, False), "version": 2}
+        a.__cuda_array_interface__ = iface
         return torch.as_tensor(a, device=torch.device("cuda", torch.cuda.current_device()))
 
     def debug_tensor(self, name: str):
