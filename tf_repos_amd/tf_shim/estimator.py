@@ -209,14 +209,15 @@ class Estimator:
             live.close()
         extra = {"max_entries": int(max_entries)} if cfg_src.slots is not None else {}
         if cfg_src.slots is None:
-            # small batches (the reference's default 256): the step is ~25 launches of a few microseconds each, and enqueueing them
-            # one by one costs the host 0.2-0.3 ms per step -- more than the GPU needs.  One captured hipGraph per (batch size, input
-            # slot) is 13 % slower on the GPU and immune to the host (measured through DeepFM.py, B = 256, same box: 0.79 M
-            # examples/s eager, 1.18 M replayed).  Large batches keep the eager path and its next-batch id grouping.
-            # (decided ONCE per Estimator, from the first engine it builds: a later evaluate() with a larger batch must not flip the
-            #  training path between rebuilds)
+            # Eager steps at every batch size.  Rounds 2-3 replayed one captured hipGraph per (batch size, input slot) for small
+            # batches (the reference's default 256), when enqueueing ~25 launches one by one cost this loop 0.2-0.3 ms per step.  Since
+            # the loop runs on the engine's own stream with the slot handshake inside the library it costs ~0.13 ms, and the eager step
+            # keeps what a captured one cannot have: lagging table rows (csrc/lag.h) and the next-batch grouping hint.  Measured
+            # through this Estimator at BASELINE configs[0] (B = 256, V = 117 581, K = 8; tools/e2e_probe.py c1, same box): replayed
+            # 0.186-0.189 ms per step = 1.36 M examples/s, eager 0.136-0.148 = 1.72-1.88 M.  A/B knob DCTR_EST_GRAPH=1: the replay.
+            # (decided ONCE per Estimator: a later evaluate() must not flip the training path between rebuilds)
             if getattr(self, "_use_graph", None) is None:
-                self._use_graph = int(batch_size) * int(cfg_src.config_kwargs.get("field_size", 0)) < 65536
+                self._use_graph = os.environ.get("DCTR_EST_GRAPH") == "1"
             extra["use_graph"] = self._use_graph
         cfg = cfg_src.engine_config(max_batch=batch_size, table_mode=self.table_mode,
                                     seed=int(self._config.tf_random_seed or 0), **extra)
