@@ -140,6 +140,50 @@ __global__ __launch_bounds__(256) void colsum_scaled_v4_kernel(const float* __re
     }
 }
 
+// several column sums of one shape in ONE launch (blockIdx.z = job): DCN's 2 L cross-parameter gradients were 2 L launches of 6-16 us
+// each in a row on the weight-gradient stream (c3: 56 us, the end of the step waited for them); side by side they take the longest one
+__global__ __launch_bounds__(256) void colsum_scaled_v4_batch_kernel(ColsumJobs J, int ldy, int M, int N, int rows_per_split, int64_t split_stride) {
+    __shared__ float4 red[16][17];
+    const float* __restrict__ Y = J.Y[blockIdx.z];
+    const float* __restrict__ rs = J.rs[blockIdx.z];
+    float* __restrict__ out = J.out[blockIdx.z];
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cg * 4;
+    const int rbeg = blockIdx.y * rows_per_split, rend = min(M, rbeg + rows_per_split);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < N) {
+        for (int r = rbeg + rl; r < rend; r += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(Y + (size_t)r * ldy + c);
+            const float k = rs ? rs[r] : 1.0f;
+            s.x += k * v.x; s.y += k * v.y; s.z += k * v.z; s.w += k * v.w;
+        }
+    }
+    red[rl][cg] = s;
+    __syncthreads();
+    if (rl == 0 && c < N) {
+        float4 a = red[0][cg];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) { const float4 b = red[j][cg]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        *reinterpret_cast<float4*>(out + (size_t)blockIdx.y * split_stride + c) = a;
+    }
+}
+
+int colsum_partials_batch(const ColsumJobs& J, int ldy, int M, int N, int splits, int64_t split_stride, hipStream_t st) {
+    if (N <= 0 || J.n <= 0) return DCTR_OK;
+    DCTR_REQUIRE(J.n <= COLSUM_MAX_JOBS, "colsum: %d jobs in one launch (at most %d)", J.n, COLSUM_MAX_JOBS);
+    bool v4 = (N % 4 == 0) && (ldy % 4 == 0) && (split_stride % 4 == 0);
+    for (int j = 0; j < J.n; ++j)
+        v4 = v4 && ((reinterpret_cast<uintptr_t>(J.Y[j]) | reinterpret_cast<uintptr_t>(J.out[j])) & 15) == 0;
+    if (!v4) {          // (odd shapes: one launch per job, as before)
+        for (int j = 0; j < J.n; ++j) DCTR_TRY(colsum_partials(J.Y[j], ldy, J.rs[j], M, N, splits, J.out[j], split_stride, st));
+        return DCTR_OK;
+    }
+    dim3 grid(ceil_div(N, 64), splits, J.n), block(256);
+    colsum_scaled_v4_batch_kernel<<<grid, block, 0, st>>>(J, ldy, M, N, ceil_div(M, splits), split_stride);
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
 int colsum_partials(const float* Y, int ldy, const float* rs, int M, int N, int splits, float* out,
                     int64_t split_stride, hipStream_t st) {
     if (N <= 0) return DCTR_OK;

@@ -1084,16 +1084,26 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     // fork serves -- one more record here is one more barrier packet (~5 us) in front of the scatter
     if (!E->cfg.use_graph && E->last_fork_ev != nullptr) { E->ev_tail = E->last_fork_ev; E->have_tail = true; }
     if (fused_opt) {
-        // what is left of the dense arena: cross_w / cross_b (DCN), and the output layer + bias if they were not stepped above
+        // what is left of the dense arena: cross_w / cross_b (DCN), and the output layer + bias if they were not stepped above --
+        // neighbours in the arena in one launch (c3: cross_w, cross_b were two 6-us launches at the very end of the step)
+        int run_first = -1, run_last = -1;
+        auto flush_run = [&]() -> int {
+            if (run_first >= 0) DCTR_TRY(opt_dense_range(E, run_first, run_last, sw));
+            run_first = run_last = -1;
+            return DCTR_OK;
+        };
         for (int i = 0; i < (int)E->params.size(); ++i) {
             const Param& p = E->params[i];
             if (p.is_table) continue;
             bool is_mlp = false;
             for (auto& fc : E->mlp) is_mlp = is_mlp || (i >= fc.w && i <= fc.last);
-            if (is_mlp) continue;
-            if (out_done && (i == E->p_out_w || i == E->p_out_b || i == E->p_bias)) continue;
-            DCTR_TRY(opt_dense_range(E, i, i, sw));
+            const bool skip = is_mlp || (out_done && (i == E->p_out_w || i == E->p_out_b || i == E->p_bias));
+            if (skip) { DCTR_TRY(flush_run()); continue; }
+            if (run_first >= 0 && E->params[run_last].arena_off + E->params[run_last].padded != p.arena_off) DCTR_TRY(flush_run());
+            if (run_first < 0) run_first = i;
+            run_last = i;
         }
+        DCTR_TRY(flush_run());
     } else {
         DCTR_TRY(opt_dense_arena(E->cfg.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->parts, E->meta,
                                  E->n_blocks, nullptr, 1, E->scalars + 3 * SUMSQ_SHARDS, sw));

@@ -435,10 +435,15 @@ int dcn_cross_param_grads(const float* xs, int B, int D, int L, float* dw_part, 
     if (B <= 0) return DCTR_OK;
     const float* G = scratch;                          // [L,B,D]
     const float* T = scratch + (size_t)L * B * D;      // [L,B]
+    ColsumJobs J{};
     for (int l = 0; l < L; ++l) {
         // partial slabs: slab s of layer l at part + s*part_stride + l*D
-        DCTR_TRY(colsum_partials(G + (size_t)l * B * D, D, nullptr, B, D, splits, db_part + (size_t)l * D, part_stride, st));
-        DCTR_TRY(colsum_partials(xs + (size_t)l * B * D, D, T + (size_t)l * B, B, D, splits, dw_part + (size_t)l * D, part_stride, st));
+        J.Y[J.n] = G + (size_t)l * B * D; J.rs[J.n] = nullptr; J.out[J.n] = db_part + (size_t)l * D; ++J.n;
+        J.Y[J.n] = xs + (size_t)l * B * D; J.rs[J.n] = T + (size_t)l * B; J.out[J.n] = dw_part + (size_t)l * D; ++J.n;
+        if (J.n + 2 > COLSUM_MAX_JOBS || l == L - 1) {
+            DCTR_TRY(colsum_partials_batch(J, D, B, D, splits, part_stride, st));
+            J.n = 0;
+        }
     }
     return DCTR_OK;
 }

@@ -137,6 +137,10 @@ int rank1_bwd(const float* dy, const float* w, int M, int n, const float* act, i
               int lddx, int accumulate, hipStream_t st);
 int colsum_partials(const float* Y, int ldy, const float* rs, int M, int N, int splits, float* out,
                     int64_t split_stride, hipStream_t st);
+// the same for up to COLSUM_MAX_JOBS (Y, rs, out) triples of ONE shape, in one launch
+constexpr int COLSUM_MAX_JOBS = 16;
+struct ColsumJobs { const float* Y[COLSUM_MAX_JOBS]; const float* rs[COLSUM_MAX_JOBS]; float* out[COLSUM_MAX_JOBS]; int n; };
+int colsum_partials_batch(const ColsumJobs& J, int ldy, int M, int N, int splits, int64_t split_stride, hipStream_t st);
 int out_layer_bwd(const float* x, int ldx, const float* dy, const float* w, int M, int n, int splits, int masked,
                   float keep, float* dx, int lddx, float* dw_part, int64_t dw_stride, float* db_part, int64_t db_stride,
                   hipStream_t st);
