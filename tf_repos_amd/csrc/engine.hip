@@ -93,6 +93,13 @@ static int add_param(dctr_engine* E, const std::string& name, std::initializer_l
     return engine_add_param(E, name, dims, table, n_part, l2);
 }
 
+// DCN's cross network in a step: the lean forward / fused backward pair of interact.hip (A/B knob DCTR_DCN_LEAN=0: the op-level
+// kernels, which keep every x_l and leave the parameter gradients to column-sum launches)
+bool dcn_lean(const dctr_engine* E) {
+    static const bool off = [] { const char* v = getenv("DCTR_DCN_LEAN"); return v != nullptr && v[0] == '0'; }();
+    return !off && E->cfg.model == DCTR_MODEL_DCN && dcn_cross_lean_ok(E->D, E->cfg.cross_layers) && E->Din_ld % 4 == 0;
+}
+
 int gather_mode(const dctr_engine* E) {
     switch (E->cfg.model) {
         case DCTR_MODEL_DEEPFM: return DCTR_GATHER_FM;
@@ -575,7 +582,18 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::f
     if (c.model == DCTR_MODEL_OPNN && !E->opnn_fused) DCTR_TRY(pnn_outer_fwd(E->e, E->e_ld, B, F, K, E->x_in + D, E->Din_ld, st));
     if (c.model == DCTR_MODEL_NFM && train) DCTR_TRY(dropout_inplace(E->x_in, (int64_t)B * K, K, c.keep_prob[0], seedp, DCTR_DROPOUT_SITE_NFM_BI, st));   // NFM.py:136-137
     if (c.model == DCTR_MODEL_DCN)
+    {
+        if (dcn_lean(E)) {
+            // (interact.hip: x_L and s only; a training step's forward also zeroes the cross parameters' gradient slabs, which its
+            //  backward adds into)
+            const Param& cw = E->params[E->p_cross_w];
+            const Param& cb = E->params[E->p_cross_b];
+            DCTR_TRY(dcn_cross_fwd_lean(E->x_in, E->Din_ld, E->pp(E->p_cross_w), E->pp(E->p_cross_b), B, D, c.cross_layers,
+                                        E->xs + (size_t)c.cross_layers * B * D, E->xlw, train ? E->part(E->p_cross_w) : nullptr,
+                                        train ? cw.padded * cw.n_part : 0, train ? E->part(E->p_cross_b) : nullptr, train ? cb.padded * cb.n_part : 0, st));
+        } else
         DCTR_TRY(dcn_cross_fwd(E->x_in, E->Din_ld, E->pp(E->p_cross_w), E->pp(E->p_cross_b), B, D, c.cross_layers, E->xs, E->xlw, st));
+    }
     if (c.model == DCTR_MODEL_MVM) DCTR_TRY(mvm_fwd(E->e, E->e_ld, E->pp(E->p_mvm_b), B, F, K, E->xmvm, st));
     const float* x = E->x_in;
     int ldx = E->Din_ld;
@@ -831,6 +849,10 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
         const Param& cw = E->params[E->p_cross_w];
         // (fused_opt: the cross parameters' 2 L column-sum launches go to the side stream behind the fork below -- 37 us of small
         //  kernels that stood between the cross backward and the table step at c3)
+        if (dcn_lean(E))
+            DCTR_TRY(dcn_cross_bwd_fused(E->x_in, E->Din_ld, E->xlw, E->pp(E->p_cross_w), E->pp(E->p_cross_b), E->dxL, D, B, D, c.cross_layers,
+                                         E->dx_in, E->Din_ld, E->part(E->p_cross_w), E->part(E->p_cross_b), cw.n_part, cw.padded, st));
+        else
         DCTR_TRY(dcn_cross_bwd(E->xs, E->xlw, E->pp(E->p_cross_w), E->dxL, D, B, D, c.cross_layers, E->dx_in, E->Din_ld,
                                fused_opt && sw != st ? nullptr : E->part(E->p_cross_w), E->part(E->p_cross_b), cw.n_part, cw.padded, E->cross_scratch, st));
     }
@@ -838,7 +860,7 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
         // everything the dense side reads or writes on st is enqueued: the first layer's step (its dgrad is done) and, for the
         // caller, the cross-network / output-layer partial slabs
         DCTR_TRY(stop_fork(E, st, sw));
-        if (c.model == DCTR_MODEL_DCN && sw != st) {
+        if (c.model == DCTR_MODEL_DCN && sw != st && !dcn_lean(E)) {
             const Param& cw = E->params[E->p_cross_w];
             DCTR_TRY(dcn_cross_param_grads(E->xs, B, D, c.cross_layers, E->part(E->p_cross_w), E->part(E->p_cross_b), cw.n_part, cw.padded, E->cross_scratch, sw));
         }

@@ -468,6 +468,231 @@ int dcn_cross_bwd(const float* xs, const float* xlw, const float* w, const float
     return dcn_cross_param_grads(xs, B, D, L, dw_part, db_part, splits, part_stride, scratch, st);
 }
 
+// ---- DCN cross network, the TRAINING STEP's pair of kernels (DCN.py:150-158 and its gradient).  The op-level kernels above keep every
+// x_l ([L+1, B, D]) and hand dL/dx_{l+1} ([L, B, D]) to column-sum launches; at c3 that is 40 MB written by the forward and 30 MB
+// written + 60 MB re-read behind the backward, for values that cost two FMAs to form.  Here
+//   * the forward writes x_L and s_l = x_l . w_l only (and zeroes the cross parameters' gradient slabs for the backward);
+//   * the backward re-forms x_1 .. x_{L-1} from x_0, s_l, b_l in registers, walks the layers down, and accumulates
+//     db_l = sum_b g_l and dw_l = sum_b t_l x_l in registers over the examples of its block; blocks meet in the parameter's n_part
+//     partial slabs by float atomics (slab = block mod n_part).
+// One group of GS lanes per example, float4 per lane (D % 4 == 0), NR float4 per lane: D <= 4 GS NR.
+template <int GS>
+__device__ __forceinline__ float dcn_group_sum_u(float v) {       // every thread of the block calls it (uniform control flow)
+    v = wsum(v);
+    if (GS == 64) return v;
+    __shared__ float part[4];
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (GS == 128) { const int w = (threadIdx.x >> 6) & ~1; return part[w] + part[w + 1]; }
+    return part[0] + part[1] + part[2] + part[3];
+}
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ float4 fma4(const float4 a, float s, const float4 c) {        // a * s + c
+    return make_float4(a.x * s + c.x, a.y * s + c.y, a.z * s + c.z, a.w * s + c.w);
+}
+__device__ __forceinline__ float4 add4(const float4 a, const float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+template <int NR, int GS, int L>
+__global__ __launch_bounds__(256) void dcn_cross_fwd_lean_kernel(const float* __restrict__ x0, int x0_ld, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, int B, int D, float* __restrict__ xL,
+                                                                float* __restrict__ xlw, float* __restrict__ z0, int nz0,
+                                                                float* __restrict__ z1, int nz1) {
+    constexpr int NG = 256 / GS;
+    {   // the backward's gradient slabs start from zero (the previous step's optimizer launch has consumed them: stream order)
+        const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t i = t; i < nz0 / 4; i += (int64_t)gridDim.x * 256) reinterpret_cast<float4*>(z0)[i] = z;
+        for (int64_t i = t; i < nz1 / 4; i += (int64_t)gridDim.x * 256) reinterpret_cast<float4*>(z1)[i] = z;
+    }
+    const int lig = threadIdx.x % GS, grp = threadIdx.x / GS;
+    const int D4 = D / 4;
+    for (int row0 = blockIdx.x * NG; row0 < B; row0 += gridDim.x * NG) {
+        const int b = row0 + grp;
+        const bool live = b < B;
+        float4 a0[NR], xl[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int d4 = lig + GS * r;
+            a0[r] = (live && d4 < D4) ? reinterpret_cast<const float4*>(x0 + (size_t)b * x0_ld)[d4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            xl[r] = a0[r];
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const float4* wl = reinterpret_cast<const float4*>(w + (size_t)l * D);
+            const float4* bl = reinterpret_cast<const float4*>(bias + (size_t)l * D);
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int d4 = lig + GS * r;
+                if (d4 < D4) s += dot4(xl[r], wl[d4]);
+            }
+            s = dcn_group_sum_u<GS>(s);
+            if (live && lig == 0) xlw[(size_t)l * B + b] = s;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int d4 = lig + GS * r;
+                if (d4 < D4) xl[r] = add4(fma4(a0[r], s, xl[r]), bl[d4]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int d4 = lig + GS * r;
+            if (live && d4 < D4) reinterpret_cast<float4*>(xL + (size_t)b * D)[d4] = xl[r];
+        }
+    }
+}
+
+template <int NR, int GS, int L>
+__global__ __launch_bounds__(256) void dcn_cross_bwd_fused_kernel(const float* __restrict__ x0, int x0_ld, const float* __restrict__ xlw,
+                                                                 const float* __restrict__ w, const float* __restrict__ bias,
+                                                                 const float* __restrict__ dxL, int dxl_ld, int B, int D,
+                                                                 float* __restrict__ dx0, int dx0_ld, float* __restrict__ dw_part,
+                                                                 float* __restrict__ db_part, int n_part, int64_t part_stride) {
+    constexpr int NG = 256 / GS;
+    const int lig = threadIdx.x % GS, grp = threadIdx.x / GS;
+    const int D4 = D / 4;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 dw[L][NR], db[L][NR];
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) dw[l][r] = db[l][r] = zero;
+    for (int row0 = blockIdx.x * NG; row0 < B; row0 += gridDim.x * NG) {
+        const int b = row0 + grp;
+        const bool live = b < B;
+        float4 x[L][NR], g[NR], acc0[NR];     // x[l] = x_l (x[0] = x_0)
+        float sl[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) sl[l] = live ? xlw[(size_t)l * B + b] : 0.f;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int d4 = lig + GS * r;
+            const bool ok = live && d4 < D4;
+            x[0][r] = ok ? reinterpret_cast<const float4*>(x0 + (size_t)b * x0_ld)[d4] : zero;
+            g[r] = ok ? reinterpret_cast<const float4*>(dxL + (size_t)b * dxl_ld)[d4] : zero;
+            acc0[r] = zero;
+        }
+#pragma unroll
+        for (int l = 0; l + 1 < L; ++l) {       // x_{l+1} = x_0 s_l + x_l + b_l, as the forward formed it
+            const float4* bl = reinterpret_cast<const float4*>(bias + (size_t)l * D);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int d4 = lig + GS * r;
+                x[l + 1][r] = (live && d4 < D4) ? add4(fma4(x[0][r], sl[l], x[l][r]), bl[d4]) : zero;
+            }
+        }
+#pragma unroll
+        for (int l = L - 1; l >= 0; --l) {
+            const float4* wl = reinterpret_cast<const float4*>(w + (size_t)l * D);
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) t += dot4(g[r], x[0][r]);
+            t = dcn_group_sum_u<GS>(t);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int d4 = lig + GS * r;
+                if (live && d4 < D4) {
+                    db[l][r] = add4(db[l][r], g[r]);
+                    dw[l][r] = fma4(x[l][r], t, dw[l][r]);
+                    acc0[r] = fma4(g[r], sl[l], acc0[r]);
+                    g[r] = fma4(wl[d4], t, g[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int d4 = lig + GS * r;
+            if (live && d4 < D4) {
+                float4* p = reinterpret_cast<float4*>(dx0 + (size_t)b * dx0_ld) + d4;
+                const float4 o = *p;
+                *p = make_float4(o.x + acc0[r].x + g[r].x, o.y + acc0[r].y + g[r].y, o.z + acc0[r].z + g[r].z, o.w + acc0[r].w + g[r].w);
+            }
+        }
+    }
+    // the block's column sums -> its slab (groups of one block first, through LDS)
+    __shared__ float4 red[256];
+    float* wslab = dw_part + (size_t)(blockIdx.x % n_part) * part_stride;
+    float* bslab = db_part + (size_t)(blockIdx.x % n_part) * part_stride;
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                float4 v = which ? db[l][r] : dw[l][r];
+                if (NG > 1) {
+                    __syncthreads();
+                    red[threadIdx.x] = v;
+                    __syncthreads();
+                    if (grp == 0)
+                        for (int q = 1; q < NG; ++q) v = add4(v, red[q * GS + lig]);
+                }
+                const int d4 = lig + GS * r;
+                if (grp == 0 && d4 < D4) {
+                    float* o = (which ? bslab : wslab) + (size_t)l * D + (size_t)d4 * 4;
+                    atomicAdd(o + 0, v.x); atomicAdd(o + 1, v.y); atomicAdd(o + 2, v.z); atomicAdd(o + 3, v.w);
+                }
+            }
+}
+
+// -> false: shape outside what the pair covers (the caller keeps the op-level kernels)
+bool dcn_cross_lean_ok(int D, int L) { return D % 4 == 0 && D <= 4 * 256 * 3 && L >= 1 && L <= 4; }
+
+template <int NR, int GS>
+static int dcn_lean_fwd_L(const float* x0, int x0_ld, const float* w, const float* b, int B, int D, int L, float* xL, float* xlw,
+                          float* z0, int nz0, float* z1, int nz1, hipStream_t st) {
+    const int grid = std::min(ceil_div(B, 256 / GS), 2048);
+    switch (L) {
+#define DCTR_L(LL) case LL: dcn_cross_fwd_lean_kernel<NR, GS, LL><<<grid, 256, 0, st>>>(x0, x0_ld, w, b, B, D, xL, xlw, z0, nz0, z1, nz1); break
+        DCTR_L(1); DCTR_L(2); DCTR_L(3); DCTR_L(4);
+#undef DCTR_L
+        default: set_error("dcn_cross (lean): %d layers", L); return DCTR_ERR_UNSUPPORTED;
+    }
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+template <int NR, int GS>
+static int dcn_lean_bwd_L(const float* x0, int x0_ld, const float* xlw, const float* w, const float* bias, const float* dxL, int dxl_ld,
+                          int B, int D, int L, float* dx0, int dx0_ld, float* dw_part, float* db_part, int n_part, int64_t part_stride,
+                          hipStream_t st) {
+    // (512 blocks: two per CU; each sums its examples in registers and pays 2 L D atomics once)
+    const int grid = std::min(ceil_div(B, 256 / GS), 512);
+    switch (L) {
+#define DCTR_L(LL) case LL: dcn_cross_bwd_fused_kernel<NR, GS, LL><<<grid, 256, 0, st>>>(x0, x0_ld, xlw, w, bias, dxL, dxl_ld, B, D, dx0, dx0_ld, dw_part, db_part, n_part, part_stride); break
+        DCTR_L(1); DCTR_L(2); DCTR_L(3); DCTR_L(4);
+#undef DCTR_L
+        default: set_error("dcn_cross (lean): %d layers", L); return DCTR_ERR_UNSUPPORTED;
+    }
+    DCTR_LAUNCH_CHECK();
+    return DCTR_OK;
+}
+
+// forward of a TRAINING or inference step: x_L [B, D] and s [L, B] only; z0 / z1: float ranges zeroed on the way (the cross
+// parameters' gradient slabs, multiples of 4 floats, 16-byte aligned; nullptr / 0: nothing)
+int dcn_cross_fwd_lean(const float* x0, int x0_ld, const float* w, const float* b, int B, int D, int L, float* xL, float* xlw,
+                       float* z0, int64_t nz0, float* z1, int64_t nz1, hipStream_t st) {
+    if (B <= 0) return DCTR_OK;
+    DCTR_REQUIRE(dcn_cross_lean_ok(D, L) && x0_ld % 4 == 0 && nz0 % 4 == 0 && nz1 % 4 == 0, "dcn_cross (lean): D=%d L=%d ld=%d", D, L, x0_ld);
+    const int D4 = D / 4;
+    if (D4 <= 64 * 3) return dcn_lean_fwd_L<3, 64>(x0, x0_ld, w, b, B, D, L, xL, xlw, z0, (int)nz0, z1, (int)nz1, st);
+    if (D4 <= 128 * 3) return dcn_lean_fwd_L<3, 128>(x0, x0_ld, w, b, B, D, L, xL, xlw, z0, (int)nz0, z1, (int)nz1, st);
+    return dcn_lean_fwd_L<3, 256>(x0, x0_ld, w, b, B, D, L, xL, xlw, z0, (int)nz0, z1, (int)nz1, st);
+}
+
+// backward: dx0 += dL/dx_0 through the cross network, and the cross parameters' gradients ADDED into their (zeroed) n_part slabs
+// (slab s of layer l at part + s * part_stride + l * D)
+int dcn_cross_bwd_fused(const float* x0, int x0_ld, const float* xlw, const float* w, const float* bias, const float* dxL, int dxl_ld, int B,
+                        int D, int L, float* dx0, int dx0_ld, float* dw_part, float* db_part, int n_part, int64_t part_stride, hipStream_t st) {
+    if (B <= 0) return DCTR_OK;
+    DCTR_REQUIRE(dcn_cross_lean_ok(D, L) && x0_ld % 4 == 0 && dxl_ld % 4 == 0 && dx0_ld % 4 == 0 && n_part >= 1,
+                 "dcn_cross (lean): D=%d L=%d", D, L);
+    const int D4 = D / 4;
+    if (D4 <= 64 * 3) return dcn_lean_bwd_L<3, 64>(x0, x0_ld, xlw, w, bias, dxL, dxl_ld, B, D, L, dx0, dx0_ld, dw_part, db_part, n_part, part_stride, st);
+    if (D4 <= 128 * 3) return dcn_lean_bwd_L<3, 128>(x0, x0_ld, xlw, w, bias, dxL, dxl_ld, B, D, L, dx0, dx0_ld, dw_part, db_part, n_part, part_stride, st);
+    return dcn_lean_bwd_L<3, 256>(x0, x0_ld, xlw, w, bias, dxL, dxl_ld, B, D, L, dx0, dx0_ld, dw_part, db_part, n_part, part_stride, st);
+}
+
 // ---- DeepMVM "all-order" product (DeepMVM.py:144-150): x_mvm[b,k] = prod_f (e[b,f,k] + mvm_b[f,k]) -----------------------------
 // One lane per (example, k): the F factors of a lane are strided K apart in e, consecutive lanes read consecutive k.
 constexpr int MVM_MAXF = 64;
