@@ -550,7 +550,8 @@ int build(dctr_engine* E) {
         DCTR_TRY(dmalloc(&E->xs, (size_t)(L + 1) * MB * D));
         DCTR_TRY(dmalloc(&E->xlw, (size_t)L * MB));
         DCTR_TRY(dmalloc(&E->dxL, (size_t)MB * D));
-        DCTR_TRY(dmalloc(&E->cross_scratch, (size_t)L * MB * D + (size_t)L * MB));
+        // ([L, B, D] + [L, B] for the op-level backward; the step's fused backward wants two [512, L D] row blocks)
+        DCTR_TRY(dmalloc(&E->cross_scratch, std::max((size_t)L * MB * D + (size_t)L * MB, (size_t)2 * 512 * L * D)));
     }
     DCTR_HIP_CHECK(hipDeviceSynchronize());     // the zero-fills above ran on the null stream; callers use non-blocking streams
     return DCTR_OK;
@@ -584,13 +585,9 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::f
     if (c.model == DCTR_MODEL_DCN)
     {
         if (dcn_lean(E)) {
-            // (interact.hip: x_L and s only; a training step's forward also zeroes the cross parameters' gradient slabs, which its
-            //  backward adds into)
-            const Param& cw = E->params[E->p_cross_w];
-            const Param& cb = E->params[E->p_cross_b];
+            // (interact.hip: x_L and s only)
             DCTR_TRY(dcn_cross_fwd_lean(E->x_in, E->Din_ld, E->pp(E->p_cross_w), E->pp(E->p_cross_b), B, D, c.cross_layers,
-                                        E->xs + (size_t)c.cross_layers * B * D, E->xlw, train ? E->part(E->p_cross_w) : nullptr,
-                                        train ? cw.padded * cw.n_part : 0, train ? E->part(E->p_cross_b) : nullptr, train ? cb.padded * cb.n_part : 0, st));
+                                        E->xs + (size_t)c.cross_layers * B * D, E->xlw, st));
         } else
         DCTR_TRY(dcn_cross_fwd(E->x_in, E->Din_ld, E->pp(E->p_cross_w), E->pp(E->p_cross_b), B, D, c.cross_layers, E->xs, E->xlw, st));
     }
@@ -849,10 +846,16 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
         const Param& cw = E->params[E->p_cross_w];
         // (fused_opt: the cross parameters' 2 L column-sum launches go to the side stream behind the fork below -- 37 us of small
         //  kernels that stood between the cross backward and the table step at c3)
-        if (dcn_lean(E))
+        if (dcn_lean(E)) {
+            // (the blocks' rows of parameter-gradient sums land in the cross scratch -- two [512, L D] blocks, build() sizes it for
+            //  them --, folded into the slabs on the side stream, or here when there is none)
+            float* rows_w = E->cross_scratch;
+            float* rows_b = E->cross_scratch + (size_t)512 * c.cross_layers * D;
             DCTR_TRY(dcn_cross_bwd_fused(E->x_in, E->Din_ld, E->xlw, E->pp(E->p_cross_w), E->pp(E->p_cross_b), E->dxL, D, B, D, c.cross_layers,
-                                         E->dx_in, E->Din_ld, E->part(E->p_cross_w), E->part(E->p_cross_b), cw.n_part, cw.padded, st));
-        else
+                                         E->dx_in, E->Din_ld, rows_w, rows_b, st));
+            if (!(fused_opt && sw != st))
+                DCTR_TRY(dcn_cross_param_slabs(rows_w, rows_b, B, D, c.cross_layers, E->part(E->p_cross_w), E->part(E->p_cross_b), cw.n_part, cw.padded, st));
+        } else
         DCTR_TRY(dcn_cross_bwd(E->xs, E->xlw, E->pp(E->p_cross_w), E->dxL, D, B, D, c.cross_layers, E->dx_in, E->Din_ld,
                                fused_opt && sw != st ? nullptr : E->part(E->p_cross_w), E->part(E->p_cross_b), cw.n_part, cw.padded, E->cross_scratch, st));
     }
@@ -860,7 +863,11 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
         // everything the dense side reads or writes on st is enqueued: the first layer's step (its dgrad is done) and, for the
         // caller, the cross-network / output-layer partial slabs
         DCTR_TRY(stop_fork(E, st, sw));
-        if (c.model == DCTR_MODEL_DCN && sw != st && !dcn_lean(E)) {
+        if (c.model == DCTR_MODEL_DCN && sw != st && dcn_lean(E)) {
+            const Param& cw = E->params[E->p_cross_w];
+            DCTR_TRY(dcn_cross_param_slabs(E->cross_scratch, E->cross_scratch + (size_t)512 * c.cross_layers * D, B, D, c.cross_layers,
+                                           E->part(E->p_cross_w), E->part(E->p_cross_b), cw.n_part, cw.padded, sw));
+        } else if (c.model == DCTR_MODEL_DCN && sw != st) {
             const Param& cw = E->params[E->p_cross_w];
             DCTR_TRY(dcn_cross_param_grads(E->xs, B, D, c.cross_layers, E->part(E->p_cross_w), E->part(E->p_cross_b), cw.n_part, cw.padded, E->cross_scratch, sw));
         }

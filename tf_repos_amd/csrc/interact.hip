@@ -471,10 +471,12 @@ int dcn_cross_bwd(const float* xs, const float* xlw, const float* w, const float
 // ---- DCN cross network, the TRAINING STEP's pair of kernels (DCN.py:150-158 and its gradient).  The op-level kernels above keep every
 // x_l ([L+1, B, D]) and hand dL/dx_{l+1} ([L, B, D]) to column-sum launches; at c3 that is 40 MB written by the forward and 30 MB
 // written + 60 MB re-read behind the backward, for values that cost two FMAs to form.  Here
-//   * the forward writes x_L and s_l = x_l . w_l only (and zeroes the cross parameters' gradient slabs for the backward);
+//   * the forward writes x_L and s_l = x_l . w_l only;
 //   * the backward re-forms x_1 .. x_{L-1} from x_0, s_l, b_l in registers, walks the layers down, and accumulates
-//     db_l = sum_b g_l and dw_l = sum_b t_l x_l in registers over the examples of its block; blocks meet in the parameter's n_part
-//     partial slabs by float atomics (slab = block mod n_part).
+//     db_l = sum_b g_l and dw_l = sum_b t_l x_l in registers over the examples of its block; every block leaves ONE row of sums
+//     ([blocks, L D] per parameter, <= 512 rows), which a column-sum launch on the side stream folds into the parameter's n_part
+//     partial slabs.  (Blocks meeting in the slabs by float atomics was tried first: 1.9 M device-scope atomics from 512 blocks took
+//     the kernel from ~20 to 60 us -- across XCDs they are performed at the memory side.)
 // One group of GS lanes per example, float4 per lane (D % 4 == 0), NR float4 per lane: D <= 4 GS NR.
 template <int GS>
 __device__ __forceinline__ float dcn_group_sum_u(float v) {       // every thread of the block calls it (uniform control flow)
@@ -496,15 +498,8 @@ __device__ __forceinline__ float4 add4(const float4 a, const float4 b) { return 
 template <int NR, int GS, int L>
 __global__ __launch_bounds__(256) void dcn_cross_fwd_lean_kernel(const float* __restrict__ x0, int x0_ld, const float* __restrict__ w,
                                                                 const float* __restrict__ bias, int B, int D, float* __restrict__ xL,
-                                                                float* __restrict__ xlw, float* __restrict__ z0, int nz0,
-                                                                float* __restrict__ z1, int nz1) {
+                                                                float* __restrict__ xlw) {
     constexpr int NG = 256 / GS;
-    {   // the backward's gradient slabs start from zero (the previous step's optimizer launch has consumed them: stream order)
-        const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t i = t; i < nz0 / 4; i += (int64_t)gridDim.x * 256) reinterpret_cast<float4*>(z0)[i] = z;
-        for (int64_t i = t; i < nz1 / 4; i += (int64_t)gridDim.x * 256) reinterpret_cast<float4*>(z1)[i] = z;
-    }
     const int lig = threadIdx.x % GS, grp = threadIdx.x / GS;
     const int D4 = D / 4;
     for (int row0 = blockIdx.x * NG; row0 < B; row0 += gridDim.x * NG) {
@@ -547,8 +542,8 @@ template <int NR, int GS, int L>
 __global__ __launch_bounds__(256) void dcn_cross_bwd_fused_kernel(const float* __restrict__ x0, int x0_ld, const float* __restrict__ xlw,
                                                                  const float* __restrict__ w, const float* __restrict__ bias,
                                                                  const float* __restrict__ dxL, int dxl_ld, int B, int D,
-                                                                 float* __restrict__ dx0, int dx0_ld, float* __restrict__ dw_part,
-                                                                 float* __restrict__ db_part, int n_part, int64_t part_stride) {
+                                                                 float* __restrict__ dx0, int dx0_ld, float* __restrict__ dw_rows,
+                                                                 float* __restrict__ db_rows) {
     constexpr int NG = 256 / GS;
     const int lig = threadIdx.x % GS, grp = threadIdx.x / GS;
     const int D4 = D / 4;
@@ -610,10 +605,10 @@ __global__ __launch_bounds__(256) void dcn_cross_bwd_fused_kernel(const float* _
             }
         }
     }
-    // the block's column sums -> its slab (groups of one block first, through LDS)
+    // the block's column sums -> its row of [blocks, L D] (groups of one block first, through LDS)
     __shared__ float4 red[256];
-    float* wslab = dw_part + (size_t)(blockIdx.x % n_part) * part_stride;
-    float* bslab = db_part + (size_t)(blockIdx.x % n_part) * part_stride;
+    float* wslab = dw_rows + (size_t)blockIdx.x * L * D;
+    float* bslab = db_rows + (size_t)blockIdx.x * L * D;
 #pragma unroll
     for (int l = 0; l < L; ++l)
 #pragma unroll
@@ -629,22 +624,23 @@ __global__ __launch_bounds__(256) void dcn_cross_bwd_fused_kernel(const float* _
                         for (int q = 1; q < NG; ++q) v = add4(v, red[q * GS + lig]);
                 }
                 const int d4 = lig + GS * r;
-                if (grp == 0 && d4 < D4) {
-                    float* o = (which ? bslab : wslab) + (size_t)l * D + (size_t)d4 * 4;
-                    atomicAdd(o + 0, v.x); atomicAdd(o + 1, v.y); atomicAdd(o + 2, v.z); atomicAdd(o + 3, v.w);
-                }
+                if (grp == 0 && d4 < D4) reinterpret_cast<float4*>((which ? bslab : wslab) + (size_t)l * D)[d4] = v;
             }
 }
 
 // -> false: shape outside what the pair covers (the caller keeps the op-level kernels)
 bool dcn_cross_lean_ok(int D, int L) { return D % 4 == 0 && D <= 4 * 256 * 3 && L >= 1 && L <= 4; }
+// blocks of the backward = rows of its two [rows, L D] outputs (two blocks per CU at most)
+int dcn_cross_bwd_rows(int B, int D) {
+    const int gs = D / 4 <= 64 * 3 ? 64 : (D / 4 <= 128 * 3 ? 128 : 256);
+    return std::min(ceil_div(B, 256 / gs), 512);
+}
 
 template <int NR, int GS>
-static int dcn_lean_fwd_L(const float* x0, int x0_ld, const float* w, const float* b, int B, int D, int L, float* xL, float* xlw,
-                          float* z0, int nz0, float* z1, int nz1, hipStream_t st) {
+static int dcn_lean_fwd_L(const float* x0, int x0_ld, const float* w, const float* b, int B, int D, int L, float* xL, float* xlw, hipStream_t st) {
     const int grid = std::min(ceil_div(B, 256 / GS), 2048);
     switch (L) {
-#define DCTR_L(LL) case LL: dcn_cross_fwd_lean_kernel<NR, GS, LL><<<grid, 256, 0, st>>>(x0, x0_ld, w, b, B, D, xL, xlw, z0, nz0, z1, nz1); break
+#define DCTR_L(LL) case LL: dcn_cross_fwd_lean_kernel<NR, GS, LL><<<grid, 256, 0, st>>>(x0, x0_ld, w, b, B, D, xL, xlw); break
         DCTR_L(1); DCTR_L(2); DCTR_L(3); DCTR_L(4);
 #undef DCTR_L
         default: set_error("dcn_cross (lean): %d layers", L); return DCTR_ERR_UNSUPPORTED;
@@ -654,12 +650,10 @@ static int dcn_lean_fwd_L(const float* x0, int x0_ld, const float* w, const floa
 }
 template <int NR, int GS>
 static int dcn_lean_bwd_L(const float* x0, int x0_ld, const float* xlw, const float* w, const float* bias, const float* dxL, int dxl_ld,
-                          int B, int D, int L, float* dx0, int dx0_ld, float* dw_part, float* db_part, int n_part, int64_t part_stride,
-                          hipStream_t st) {
-    // (512 blocks: two per CU; each sums its examples in registers and pays 2 L D atomics once)
-    const int grid = std::min(ceil_div(B, 256 / GS), 512);
+                          int B, int D, int L, float* dx0, int dx0_ld, float* dw_rows, float* db_rows, hipStream_t st) {
+    const int grid = dcn_cross_bwd_rows(B, D);
     switch (L) {
-#define DCTR_L(LL) case LL: dcn_cross_bwd_fused_kernel<NR, GS, LL><<<grid, 256, 0, st>>>(x0, x0_ld, xlw, w, bias, dxL, dxl_ld, B, D, dx0, dx0_ld, dw_part, db_part, n_part, part_stride); break
+#define DCTR_L(LL) case LL: dcn_cross_bwd_fused_kernel<NR, GS, LL><<<grid, 256, 0, st>>>(x0, x0_ld, xlw, w, bias, dxL, dxl_ld, B, D, dx0, dx0_ld, dw_rows, db_rows); break
         DCTR_L(1); DCTR_L(2); DCTR_L(3); DCTR_L(4);
 #undef DCTR_L
         default: set_error("dcn_cross (lean): %d layers", L); return DCTR_ERR_UNSUPPORTED;
@@ -668,29 +662,37 @@ static int dcn_lean_bwd_L(const float* x0, int x0_ld, const float* xlw, const fl
     return DCTR_OK;
 }
 
-// forward of a TRAINING or inference step: x_L [B, D] and s [L, B] only; z0 / z1: float ranges zeroed on the way (the cross
-// parameters' gradient slabs, multiples of 4 floats, 16-byte aligned; nullptr / 0: nothing)
-int dcn_cross_fwd_lean(const float* x0, int x0_ld, const float* w, const float* b, int B, int D, int L, float* xL, float* xlw,
-                       float* z0, int64_t nz0, float* z1, int64_t nz1, hipStream_t st) {
+// forward of a training or inference step: x_L [B, D] and s [L, B] only
+int dcn_cross_fwd_lean(const float* x0, int x0_ld, const float* w, const float* b, int B, int D, int L, float* xL, float* xlw, hipStream_t st) {
     if (B <= 0) return DCTR_OK;
-    DCTR_REQUIRE(dcn_cross_lean_ok(D, L) && x0_ld % 4 == 0 && nz0 % 4 == 0 && nz1 % 4 == 0, "dcn_cross (lean): D=%d L=%d ld=%d", D, L, x0_ld);
+    DCTR_REQUIRE(dcn_cross_lean_ok(D, L) && x0_ld % 4 == 0, "dcn_cross (lean): D=%d L=%d ld=%d", D, L, x0_ld);
     const int D4 = D / 4;
-    if (D4 <= 64 * 3) return dcn_lean_fwd_L<3, 64>(x0, x0_ld, w, b, B, D, L, xL, xlw, z0, (int)nz0, z1, (int)nz1, st);
-    if (D4 <= 128 * 3) return dcn_lean_fwd_L<3, 128>(x0, x0_ld, w, b, B, D, L, xL, xlw, z0, (int)nz0, z1, (int)nz1, st);
-    return dcn_lean_fwd_L<3, 256>(x0, x0_ld, w, b, B, D, L, xL, xlw, z0, (int)nz0, z1, (int)nz1, st);
+    if (D4 <= 64 * 3) return dcn_lean_fwd_L<3, 64>(x0, x0_ld, w, b, B, D, L, xL, xlw, st);
+    if (D4 <= 128 * 3) return dcn_lean_fwd_L<3, 128>(x0, x0_ld, w, b, B, D, L, xL, xlw, st);
+    return dcn_lean_fwd_L<3, 256>(x0, x0_ld, w, b, B, D, L, xL, xlw, st);
 }
 
-// backward: dx0 += dL/dx_0 through the cross network, and the cross parameters' gradients ADDED into their (zeroed) n_part slabs
-// (slab s of layer l at part + s * part_stride + l * D)
+// backward: dx0 += dL/dx_0 through the cross network; every block's sums of the cross parameters' gradients go to row `block` of
+// dw_rows / db_rows [dcn_cross_bwd_rows(B, D), L D]
 int dcn_cross_bwd_fused(const float* x0, int x0_ld, const float* xlw, const float* w, const float* bias, const float* dxL, int dxl_ld, int B,
-                        int D, int L, float* dx0, int dx0_ld, float* dw_part, float* db_part, int n_part, int64_t part_stride, hipStream_t st) {
+                        int D, int L, float* dx0, int dx0_ld, float* dw_rows, float* db_rows, hipStream_t st) {
     if (B <= 0) return DCTR_OK;
-    DCTR_REQUIRE(dcn_cross_lean_ok(D, L) && x0_ld % 4 == 0 && dxl_ld % 4 == 0 && dx0_ld % 4 == 0 && n_part >= 1,
-                 "dcn_cross (lean): D=%d L=%d", D, L);
+    DCTR_REQUIRE(dcn_cross_lean_ok(D, L) && x0_ld % 4 == 0 && dxl_ld % 4 == 0 && dx0_ld % 4 == 0, "dcn_cross (lean): D=%d L=%d", D, L);
     const int D4 = D / 4;
-    if (D4 <= 64 * 3) return dcn_lean_bwd_L<3, 64>(x0, x0_ld, xlw, w, bias, dxL, dxl_ld, B, D, L, dx0, dx0_ld, dw_part, db_part, n_part, part_stride, st);
-    if (D4 <= 128 * 3) return dcn_lean_bwd_L<3, 128>(x0, x0_ld, xlw, w, bias, dxL, dxl_ld, B, D, L, dx0, dx0_ld, dw_part, db_part, n_part, part_stride, st);
-    return dcn_lean_bwd_L<3, 256>(x0, x0_ld, xlw, w, bias, dxL, dxl_ld, B, D, L, dx0, dx0_ld, dw_part, db_part, n_part, part_stride, st);
+    if (D4 <= 64 * 3) return dcn_lean_bwd_L<3, 64>(x0, x0_ld, xlw, w, bias, dxL, dxl_ld, B, D, L, dx0, dx0_ld, dw_rows, db_rows, st);
+    if (D4 <= 128 * 3) return dcn_lean_bwd_L<3, 128>(x0, x0_ld, xlw, w, bias, dxL, dxl_ld, B, D, L, dx0, dx0_ld, dw_rows, db_rows, st);
+    return dcn_lean_bwd_L<3, 256>(x0, x0_ld, xlw, w, bias, dxL, dxl_ld, B, D, L, dx0, dx0_ld, dw_rows, db_rows, st);
+}
+
+// ... and those rows folded into the parameters' partial slabs (slab s of layer l at part + s * part_stride + l * D): one launch
+int dcn_cross_param_slabs(const float* dw_rows, const float* db_rows, int B, int D, int L, float* dw_part, float* db_part, int n_part,
+                          int64_t part_stride, hipStream_t st) {
+    if (B <= 0) return DCTR_OK;
+    ColsumJobs J{};
+    J.Y[0] = dw_rows; J.rs[0] = nullptr; J.out[0] = dw_part;
+    J.Y[1] = db_rows; J.rs[1] = nullptr; J.out[1] = db_part;
+    J.n = 2;
+    return colsum_partials_batch(J, L * D, dcn_cross_bwd_rows(B, D), L * D, n_part, part_stride, st);
 }
 
 // ---- DeepMVM "all-order" product (DeepMVM.py:144-150): x_mvm[b,k] = prod_f (e[b,f,k] + mvm_b[f,k]) -----------------------------

@@ -204,10 +204,12 @@ int dcn_cross_param_grads(const float* xs, int B, int D, int L, float* dw_part, 
                           const float* scratch, hipStream_t st);
 // the training step's pair (interact.hip): forward keeps x_L and s only, backward re-forms the x_l and sums the parameter gradients itself
 bool dcn_cross_lean_ok(int D, int L);
-int dcn_cross_fwd_lean(const float* x0, int x0_ld, const float* w, const float* b, int B, int D, int L, float* xL, float* xlw,
-                       float* z0, int64_t nz0, float* z1, int64_t nz1, hipStream_t st);
+int dcn_cross_bwd_rows(int B, int D);       // rows of the backward's two [rows, L D] outputs
+int dcn_cross_fwd_lean(const float* x0, int x0_ld, const float* w, const float* b, int B, int D, int L, float* xL, float* xlw, hipStream_t st);
 int dcn_cross_bwd_fused(const float* x0, int x0_ld, const float* xlw, const float* w, const float* bias, const float* dxL, int dxl_ld, int B,
-                        int D, int L, float* dx0, int dx0_ld, float* dw_part, float* db_part, int n_part, int64_t part_stride, hipStream_t st);
+                        int D, int L, float* dx0, int dx0_ld, float* dw_rows, float* db_rows, hipStream_t st);
+int dcn_cross_param_slabs(const float* dw_rows, const float* db_rows, int B, int D, int L, float* dw_part, float* db_part, int n_part,
+                          int64_t part_stride, hipStream_t st);
 
 // sparse.hip / mtl.hip: the CSR (multi-hot) models DIN / ESMM
 int lookup_sparse_slots_fwd(const float* emb, int64_t rows, int K, const int32_t* offsets, const int32_t* ids, const float* weights,
