@@ -519,6 +519,26 @@ def test_dcn_cross_wider_than_2560(K, dev):
     eng.close()
 
 
+@pytest.mark.parametrize("K,cross", [(16, 3), (16, 1), (32, 4), (32, 2), (64, 3)])
+def test_dcn_cross_step_pair(K, cross, dev):
+    """The step's own cross-network kernels (interact.hip: a forward that keeps x_L and s_l only, a backward that re-forms the x_l and
+    sums the cross parameters' gradients per block) at their three group sizes -- F*K = 624 (one wave per example), 1248 (two waves),
+    2496 (a block) -- with 1..4 cross layers (DCN.py:150-158) and a batch that does not fill the last block: four Adam steps against
+    the oracle, every variable, cross_w / cross_b included."""
+    F, V, B = 39, 3000, 70
+    ocfg, params, eng = make_pair("dcn", B=B, F=F, V=V, K=K, layers=(32, 16), cross=cross, opt="Adam", lr=1e-3, l2=1e-4, scale=0.02)
+    oopt = O.Optimizer(ocfg, params)
+    for step in range(4):
+        ids, vals, labels = O.synth_batch(B if step != 2 else 37, F, V, seed=700 + step)
+        ref_loss, _ = O.train_step(ocfg, params, oopt, ids, vals, labels)
+        loss = eng.train_step(*dev_batch(ids, vals, labels, dev))
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (step, loss, ref_loss)
+    got = eng.get_params()
+    for name, ref_p in params.items():
+        assert np.abs(got[name] - ref_p.numpy()).max() <= 3e-6, (name, float(np.abs(got[name] - ref_p.numpy()).max()))
+    eng.close()
+
+
 @pytest.mark.parametrize("model", MODELS)
 @pytest.mark.parametrize("K", [10, 12, 24])
 def test_any_embedding_size(model, K, dev):
