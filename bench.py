@@ -134,9 +134,17 @@ def pmc_traffic_bytes(kernel_name):
 
 
 def profile_is_stale(rel):
-    """a committed profile older than the built library describes other kernels than the ones that just ran"""
+    """a committed profile made from other sources than the library's present ones describes other kernels than the ones that just
+    ran.  tools/profile_round.sh stamps its summaries with the sha256 of csrc/ + the header (tf_repos_amd.build.sources_hash); a summary
+    without a stamp is judged by file times, as in round 3."""
     a, b = os.path.join(ROOT, rel), os.path.join(ROOT, LIB_FILE)
-    return os.path.exists(a) and os.path.exists(b) and os.path.getmtime(a) < os.path.getmtime(b)
+    if not os.path.exists(a):
+        return False
+    for line in open(a):
+        if line.startswith("# sources sha256:"):
+            from tf_repos_amd.build import sources_hash
+            return line.split(":", 1)[1].strip() != sources_hash()
+    return os.path.exists(b) and os.path.getmtime(a) < os.path.getmtime(b)
 
 
 def rocprof_avg_us(kernel_name):

@@ -56,3 +56,18 @@ def test_bench_kernel_names_exist_in_the_committed_pmc_summary():
         if "gemm_f32_mfma" in n or "opt_table_kernel" in n:      # (A/B alternatives -- DCTR_GEMM=lds, the classic sweep: not in the default step, so not in its PMC summary)
             continue
         assert bench.pmc_traffic_bytes(n) is not None, n
+
+
+def test_profile_staleness_goes_by_the_sources_stamp(tmp_path, monkeypatch):
+    """A committed rocprof summary is stale when the library's sources have changed since tools/profile_round.sh made it -- by the
+    stamp it carries, not by file times (a rebuild of unchanged sources must not raise the bench line's `profile_warning`)."""
+    import bench
+    from tf_repos_amd.build import sources_hash
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "tf_repos_amd" / "_lib").mkdir(parents=True)
+    (tmp_path / "p.txt").write_text("kernel  calls\n# sources sha256: %s\n" % sources_hash())
+    (tmp_path / "tf_repos_amd" / "_lib" / "libdeepctr_hip.so").write_text("newer than the profile")
+    assert not bench.profile_is_stale("p.txt")
+    (tmp_path / "q.txt").write_text("kernel  calls\n# sources sha256: %s\n" % ("0" * 64))
+    assert bench.profile_is_stale("q.txt")
+    assert not bench.profile_is_stale("absent.txt")

@@ -26,6 +26,18 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
 
+def sources_hash() -> str:
+    """sha256 over the library's sources (csrc/*, include/deepctr_hip.h): names a build independently of when it was made -- what the
+    committed profiles are stamped with (tools/profile_round.sh) and bench.py compares against."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".cpp", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(INCLUDE, "deepctr_hip.h"), "rb").read())
+    return h.hexdigest()
+
+
 def _headers_mtime():
     m = os.path.getmtime(os.path.join(INCLUDE, "deepctr_hip.h"))
     for f in os.listdir(CSRC):

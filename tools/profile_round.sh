@@ -17,5 +17,8 @@ python tools/prof_summary.py stats $OUT/trace/${TAG}_results.db > $OUT/${TAG}_ke
 python tools/prof_summary.py timeline $OUT/trace/${TAG}_results.db > $OUT/${TAG}_step_timeline.txt 2>&1
 python tools/prof_summary.py pmc $OUT/pmc_fetch/${TAG}_results.db $OUT/pmc_write/${TAG}_results.db > $OUT/${TAG}_pmc_traffic.txt 2>&1
 python tools/prof_summary.py pmc $OUT/pmc_sq/${TAG}_results.db > $OUT/${TAG}_pmc_sq.txt 2>&1
+# stamp: which sources these summaries describe (bench.py: profile_is_stale)
+stamp="# sources sha256: $(python -c 'from tf_repos_amd.build import sources_hash; print(sources_hash())')"
+for f in $OUT/${TAG}_kernel_stats.txt $OUT/${TAG}_step_timeline.txt $OUT/${TAG}_pmc_traffic.txt $OUT/${TAG}_pmc_sq.txt; do echo "$stamp" >> $f; done
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
 cat $OUT/${TAG}_step_timeline.txt | head -60
