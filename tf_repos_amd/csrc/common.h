@@ -1,6 +1,7 @@
 // Shared helpers for libdeepctr_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -21,6 +22,14 @@ hipEvent_t take_stop_event();          // the armed event (and disarms), or null
 bool stop_event_pending();             // still armed: nobody took it (the caller records it the ordinary way and disarms)
 void disarm_stop_event();
 const char* get_error();
+// a launch that carries the armed event, if there is one (kernel templates with commas in their argument list go in parentheses)
+#define DCTR_LAUNCH_RIDE(kern, grid, block, lds, st, ...)                                                                     \
+    do {                                                                                                                      \
+        if (hipEvent_t stop_ = ::dctr::take_stop_event())                                                                     \
+            hipExtLaunchKernelGGL(kern, grid, block, lds, st, nullptr, stop_, 0, __VA_ARGS__);                                \
+        else                                                                                                                  \
+            hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                                      \
+    } while (0)
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

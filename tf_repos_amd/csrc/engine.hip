@@ -125,7 +125,7 @@ __global__ void dropout_inplace_kernel(float* __restrict__ x, int64_t n, int wid
 
 int dropout_inplace(float* x, int64_t n, int width, float keep, const uint64_t* seed_ptr, uint64_t salt, hipStream_t st) {
     if (n <= 0 || keep >= 1.f) return DCTR_OK;
-    dropout_inplace_kernel<<<ceil_div(n, 256), 256, 0, st>>>(x, n, width, keep, seed_ptr, salt);
+    DCTR_LAUNCH_RIDE(dropout_inplace_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0u, st, x, n, width, keep, seed_ptr, salt);
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
 }
@@ -835,6 +835,12 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
         }
     }
     const uint64_t* seedp = &E->state->seed_t;
+    // the interaction backward is the LAST kernel on st the fork below depends on: where its launch site can carry the record
+    // (common.h DCTR_LAUNCH_RIDE), the record rides on it like the MLP models' on their last dgrad
+    static const bool ride_off = [] { const char* v = getenv("DCTR_RIDE_LAST"); return v != nullptr && v[0] == '0'; }();      // A/B knob
+    const bool ride_last = !ride_off && fused_opt && sw != st && !wgrad_late && late_layers == 0 && !E->bn &&
+                           (c.model == DCTR_MODEL_IPNN || c.model == DCTR_MODEL_NFM || (c.model == DCTR_MODEL_DCN && dcn_lean(E)));
+    if (ride_last) stop_arm(E);
     if (c.model == DCTR_MODEL_IPNN) DCTR_TRY(pnn_inner_bwd(E->e, E->e_ld, E->dx_in + D, E->Din_ld, B, F, K, E->dx_in, E->Din_ld, st));
     if (c.model == DCTR_MODEL_OPNN && !E->opnn_fused) DCTR_TRY(pnn_outer_bwd(E->e, E->e_ld, E->dx_in + D, E->Din_ld, B, F, K, E->dx_in, E->Din_ld, st));
     if (c.model == DCTR_MODEL_NFM) DCTR_TRY(dropout_inplace(E->dx_in, (int64_t)B * K, K, c.keep_prob[0], seedp, DCTR_DROPOUT_SITE_NFM_BI, st));

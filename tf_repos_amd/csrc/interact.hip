@@ -244,7 +244,7 @@ int pnn_inner_bwd(const float* e, int e_ld, const float* dip, int dip_ld, int B,
     if (F == 39 && !generic) {                          // the Criteo field count (compile-time sizes for the register arrays)
         constexpr int P2 = 39 * 38 / 2, GS = 41;
         const size_t ldsm = (((size_t)2 * P2 * sizeof(int16_t) + 15) / 16) * 16 + (size_t)4 * 64 * GS * sizeof(float);
-        pnn_inner_bwd_mfma_kernel<39><<<std::min(ceil_div(B, 4), 256 * 3), 256, ldsm, st>>>(e, e_ld, dip, dip_ld, B, K, dE, de_ld);
+        DCTR_LAUNCH_RIDE(pnn_inner_bwd_mfma_kernel<39>, dim3(std::min(ceil_div(B, 4), 256 * 3)), dim3(256), (uint32_t)ldsm, st, e, e_ld, dip, dip_ld, B, K, dE, de_ld);
         DCTR_LAUNCH_CHECK();
         return DCTR_OK;
     }
@@ -653,7 +653,7 @@ static int dcn_lean_bwd_L(const float* x0, int x0_ld, const float* xlw, const fl
                           int B, int D, int L, float* dx0, int dx0_ld, float* dw_rows, float* db_rows, hipStream_t st) {
     const int grid = dcn_cross_bwd_rows(B, D);
     switch (L) {
-#define DCTR_L(LL) case LL: dcn_cross_bwd_fused_kernel<NR, GS, LL><<<grid, 256, 0, st>>>(x0, x0_ld, xlw, w, bias, dxL, dxl_ld, B, D, dx0, dx0_ld, dw_rows, db_rows); break
+#define DCTR_L(LL) case LL: DCTR_LAUNCH_RIDE((dcn_cross_bwd_fused_kernel<NR, GS, LL>), dim3(grid), dim3(256), 0u, st, x0, x0_ld, xlw, w, bias, dxL, dxl_ld, B, D, dx0, dx0_ld, dw_rows, db_rows); break
         DCTR_L(1); DCTR_L(2); DCTR_L(3); DCTR_L(4);
 #undef DCTR_L
         default: set_error("dcn_cross (lean): %d layers", L); return DCTR_ERR_UNSUPPORTED;
