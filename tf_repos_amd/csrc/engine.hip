@@ -1060,6 +1060,9 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
                             : ((int64_t)E->mlp[0].in * E->mlp[0].out >= (1 << 16) ? 1 : 0);
     hipEvent_t tables_ev = nullptr;
     bool have_tables_ev = false;
+    bool sg_joined_by_tables_ev = false;
+    hipEvent_t sg_done_ev = nullptr;
+    bool have_sg_done = false;
     // A/B knob DCTR_SWEEP_AFTER_HEAD=1: with the ids grouped ahead the grouping stream has only the background sweep to start, and the
     // fork that starts it behind the last forward layer is a record on st -- a barrier packet between that GEMM and the head (~5 us in
     // the timeline).  Here the sweep starts behind the record the head needs anyway (head_ev below).
@@ -1101,6 +1104,14 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
         if (split_table && bg_late) DCTR_TRY(step_untouched_rows(E, sg));
         DCTR_TRY(opt_dense_range(E, E->p_out_w, E->p_out_b, sg));
         if (E->p_bias >= 0) DCTR_TRY(opt_dense_range(E, E->p_bias, E->p_bias, sg));
+        // The end of the step used to join BOTH side streams on st: two waits in front of the next gather.  This stream's work of
+        // the step ends here, long before the step does: the weight-gradient stream waits for it (in front of its last kernel) and st
+        // joins that stream only -- c2 0.2648 -> 0.2624 ms/step, c4 NFM 0.2188 -> 0.2154, PNN-inner 0.500 -> 0.495.  (=1: the table
+        // step waits for it instead -- as good at c2 / c3, but NFM's short backward reaches the table step before this stream is done:
+        // 0.221 -> 0.252.  =0: both joins, as before.)
+        static const int one_join = getenv("DCTR_ONE_SG_JOIN") ? atoi(getenv("DCTR_ONE_SG_JOIN")) : 2;
+        if (one_join == 1 && have_tables_ev && sg != st) { DCTR_TRY(record_on(E, sg, &tables_ev)); sg_joined_by_tables_ev = true; }
+        if (one_join == 2 && have_tables_ev && sg != st && sw != st) { DCTR_TRY(record_on(E, sg, &sg_done_ev)); have_sg_done = true; }
     }
     if (late_sweep && !have_tables_ev) {      // (no fused head on this model: the ordinary fork)
         DCTR_TRY(fork(E, st, sg));
@@ -1151,11 +1162,12 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     if (!E->cfg.use_graph && !no_state_ahead && sw != st) {
         // the next step's state (global_step + 1, Adam's lr_t, dropout seed, zeroed loss scalars) into the second StepState, on
         // the weight-gradient stream beside scatter / table step: it only READS the live state, and the join below orders it
+        if (have_sg_done) { DCTR_HIP_CHECK(hipStreamWaitEvent(sw, sg_done_ev, 0)); sg_joined_by_tables_ev = true; }
         DCTR_TRY(step_state_next(E->state, E->state_alt, E->scalars_alt, 4 * SUMSQ_SHARDS, sw));
         E->state_ready = true;
     }
     DCTR_TRY(fork(E, sw, st));
-    if (have_tables_ev) DCTR_TRY(fork(E, sg, st));      // (the output layer's step on sg: long finished, joined for the next forward)
+    if (have_tables_ev && !sg_joined_by_tables_ev) DCTR_TRY(fork(E, sg, st));      // (the output layer's step on sg: long finished, joined for the next forward)
     if (E->opt_pending) { DCTR_TRY(fork(E, E->s_opt, st)); E->opt_pending = false; }
     return DCTR_OK;
 }
