@@ -578,9 +578,12 @@ int dctr_dist_predict(dctr_dist_t d, const int32_t* d_ids, const float* d_vals, 
  * launches of the named kernel on the engine's current buffers between two hipEvents recorded on
  * `stream`, returns the average milliseconds per launch. */
 int dctr_time_kernel(dctr_handle h, const char* kernel, int iters, float* h_ms_per_launch, void* stream);
-/* in-step duration of the first MLP layer's forward GEMM: enable=1 arms hipEvent pairs around that launch inside every train
- * step; enable=0 stops and returns the average milliseconds and the number of timed launches */
+/* in-step duration of the MLP's forward GEMMs, by hipEvents on the step's stream, every 32nd train step.  enable=1: a pair of records
+ * around the FIRST layer's launch (a bracket: two barrier packets sit inside the interval); enable=2: every forward layer's launch
+ * carries its own start / stop events (the dispatch alone -- what rocprofv3's kernel trace reports); enable=0 stops and returns the
+ * average milliseconds over all timed launches and their number.  dctr_step_timer_layer: the same for one layer, after the stop. */
 int dctr_step_timer(dctr_handle h, int enable, float* h_avg_ms, int* h_count);
+int dctr_step_timer_layer(dctr_handle h, int layer, float* h_avg_ms, int* h_count);
 /* measured HBM roofline: GB/s (read + write) of a streaming float4 copy of `nbytes` (use >> 256 MB so the Infinity Cache does
  * not serve it), averaged over `iters` launches between two hipEvents on `stream` */
 int dctr_measure_copy_bw(size_t nbytes, int iters, float* h_gbps, void* stream);

@@ -125,6 +125,7 @@ _SIGS = {
     "dctr_slot_get": ([_P, C.c_char_p, C.c_int, _P, C.c_size_t], C.c_int),
     "dctr_slot_set": ([_P, C.c_char_p, C.c_int, _P, C.c_size_t], C.c_int),
     "dctr_param_device_ptr": ([_P, C.c_char_p, C.POINTER(_P)], C.c_int),
+    "dctr_step_timer_layer": ([_P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)], C.c_int),
     "dctr_param_device_view": ([_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int64)], C.c_int),
     "dctr_set_global_step": ([_P, C.c_int64], C.c_int),
     "dctr_get_global_step": ([_P, C.POINTER(C.c_int64)], C.c_int),

@@ -21,6 +21,12 @@ void arm_stop_event(hipEvent_t ev);
 hipEvent_t take_stop_event();          // the armed event (and disarms), or nullptr
 bool stop_event_pending();             // still armed: nobody took it (the caller records it the ordinary way and disarms)
 void disarm_stop_event();
+// ... and a launch's own START and STOP events for timing it (dctr_step_timer mode 2): the pair brackets exactly the dispatch, with no
+// barrier packet inside the interval.  Armed by the engine right before the op; a launch site that supports it takes both.
+void arm_timer_events(hipEvent_t start, hipEvent_t stop);
+bool take_timer_events(hipEvent_t* start, hipEvent_t* stop);      // true: taken (and disarmed)
+bool timer_events_pending();
+void disarm_timer_events();
 const char* get_error();
 // a launch that carries the armed event, if there is one (kernel templates with commas in their argument list go in parentheses)
 #define DCTR_LAUNCH_RIDE(kern, grid, block, lds, st, ...)                                                                     \

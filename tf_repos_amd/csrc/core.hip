@@ -8,6 +8,16 @@ void arm_stop_event(hipEvent_t ev) { g_stop_event = ev; }
 hipEvent_t take_stop_event() { hipEvent_t e = g_stop_event; g_stop_event = nullptr; return e; }
 bool stop_event_pending() { return g_stop_event != nullptr; }
 void disarm_stop_event() { g_stop_event = nullptr; }
+static thread_local hipEvent_t g_timer_start = nullptr, g_timer_stop = nullptr;
+void arm_timer_events(hipEvent_t start, hipEvent_t stop) { g_timer_start = start; g_timer_stop = stop; }
+bool take_timer_events(hipEvent_t* start, hipEvent_t* stop) {
+    if (g_timer_start == nullptr) return false;
+    *start = g_timer_start; *stop = g_timer_stop;
+    g_timer_start = g_timer_stop = nullptr;
+    return true;
+}
+bool timer_events_pending() { return g_timer_start != nullptr; }
+void disarm_timer_events() { g_timer_start = g_timer_stop = nullptr; }
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);

@@ -597,11 +597,17 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::f
     for (size_t i = 0; i < E->mlp.size(); ++i) {
         const Fc& fc = E->mlp[i];
         // relu(x W + b) [-> batch_norm] -> dropout (DeepFM.py:156-162): without BN the dropout rides in the GEMM epilogue
-        // (every 8th step only: the two extra event records cost the step ~15 us, which the bench's `value` should not carry)
-        const bool timed = E->timer_on && train && i == 0 && E->timer_n + 2 <= E->timer_ev.size() && (E->timer_tick++ % 8) == 0;
+        // (every 32nd step only: a timed step costs ~15 us more -- event records, or launches with completion signals -- which the
+        //  bench's `value` should not carry: 0.5 us per step on average)
+        if (i == 0) E->timer_step = E->timer_on && train && (E->timer_tick++ % 32) == 0;
+        const bool room = E->timer_n + 2 <= E->timer_ev.size();
+        const bool timed = E->timer_step && room && E->timer_mode == 1 && i == 0;
+        // mode 2: the launch carries its own start / stop events (common.h arm_timer_events) -- the interval is the dispatch alone
+        const bool timed2 = E->timer_step && room && E->timer_mode == 2 && !E->bn && !(i == 0 && E->opnn_fused);
         if (timed) DCTR_HIP_CHECK(hipEventRecord(E->timer_ev[E->timer_n], st));
         const bool fork_here = (int)i == std::min(after_idx, (int)E->mlp.size() - 1) && after_layer0 != nullptr;
-        if (fork_here && !E->bn && !(i == 0 && E->opnn_fused)) stop_arm(E);      // (the fork behind this layer rides on its GEMM launch)
+        if (fork_here && !E->bn && !(i == 0 && E->opnn_fused) && !timed2) stop_arm(E);      // (the fork behind this layer rides on its GEMM launch)
+        if (timed2) arm_timer_events(E->timer_ev[E->timer_n], E->timer_ev[E->timer_n + 1]);
         if (i == 0 && E->opnn_fused) {
             // flat rows of W0 as an ordinary product (raw sums), then the pair-product rows with A formed in registers + bias/ReLU/dropout
             DCTR_TRY(fc_fwd(x, ldx, E->pp(fc.w), nullptr, E->h[0], fc.out, B, D, fc.out, 0, 1.f, nullptr, 0, st, 1));
@@ -610,7 +616,11 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::f
         } else
         DCTR_TRY(fc_fwd(x, ldx, E->pp(fc.w), E->pp(fc.b), E->h[i], fc.out, B, fc.in, fc.out, 1, (train && !E->bn) ? fc.keep : 1.f,
                         seedp, fc.salt, st, 1));
-        if (timed) { DCTR_HIP_CHECK(hipEventRecord(E->timer_ev[E->timer_n + 1], st)); E->timer_n += 2; }
+        if (timed) { DCTR_HIP_CHECK(hipEventRecord(E->timer_ev[E->timer_n + 1], st)); E->timer_layer.push_back(0); E->timer_n += 2; }
+        if (timed2) {
+            if (timer_events_pending()) disarm_timer_events();          // (a launch site that does not carry events: this launch is not timed)
+            else { E->timer_layer.push_back((int)i); E->timer_n += 2; }
+        }
         if (fork_here) DCTR_TRY((*after_layer0)());
         x = E->h[i]; ldx = fc.out;
         if (E->bn) {
@@ -1958,24 +1968,16 @@ int dctr_input_slot(dctr_handle E, int slot, int32_t** d_ids, float** d_vals, fl
     return DCTR_OK;
 }
 
-// In-step duration of the first MLP layer's forward GEMM (the `roofline` kernel of bench.py): hipEvents recorded on the step's
-// own stream right around that launch, so the figure is the kernel as it runs INSIDE the step (beside the grouping / background
-// table pass), comparable with rocprofv3's per-kernel trace.  enable=1 arms up to 4096 steps; the read averages and disarms.
-int dctr_step_timer(dctr_handle E, int enable, float* h_avg_ms, int* h_count) {
-    DCTR_REQUIRE(E, "null handle");
-    if (enable) {
-        if (E->timer_ev.empty()) {
-            E->timer_ev.resize(8192);
-            for (auto& ev : E->timer_ev) DCTR_HIP_CHECK(hipEventCreate(&ev));
-        }
-        E->timer_n = 0;
-        E->timer_on = true;
-        return DCTR_OK;
-    }
-    E->timer_on = false;
+// In-step duration of the MLP's forward GEMMs (the `roofline` kernel of bench.py), by hipEvents on the step's own stream, so the figure
+// is the kernel as it runs INSIDE the step (beside the grouping / background table pass), comparable with rocprofv3's per-kernel trace.
+// enable=1: two records around the first layer's launch (a bracket: the interval holds two barrier packets besides the kernel);
+// enable=2: every forward layer's launch carries its own start / stop events (hipExtLaunchKernel): the dispatch alone.  Every 32nd step
+// is timed, up to 4096 launches; enable=0 stops and returns the average over all timed launches; dctr_step_timer_layer reads one layer.
+static int timer_average(dctr_handle E, int layer, float* h_avg_ms, int* h_count) {
     double tot = 0.0;
     int n = 0;
     for (size_t i = 0; i + 1 < E->timer_n; i += 2) {
+        if (layer >= 0 && (i / 2 >= E->timer_layer.size() || E->timer_layer[i / 2] != layer)) continue;
         DCTR_HIP_CHECK(hipEventSynchronize(E->timer_ev[i + 1]));
         float ms = 0.f;
         DCTR_HIP_CHECK(hipEventElapsedTime(&ms, E->timer_ev[i], E->timer_ev[i + 1]));
@@ -1984,6 +1986,26 @@ int dctr_step_timer(dctr_handle E, int enable, float* h_avg_ms, int* h_count) {
     if (h_avg_ms) *h_avg_ms = n ? (float)(tot / n) : 0.f;
     if (h_count) *h_count = n;
     return DCTR_OK;
+}
+int dctr_step_timer(dctr_handle E, int enable, float* h_avg_ms, int* h_count) {
+    DCTR_REQUIRE(E && enable >= 0 && enable <= 2, "dctr_step_timer: enable is 0, 1 or 2");
+    if (enable) {
+        if (E->timer_ev.empty()) {
+            E->timer_ev.resize(8192);
+            for (auto& ev : E->timer_ev) DCTR_HIP_CHECK(hipEventCreate(&ev));
+        }
+        E->timer_n = 0;
+        E->timer_layer.clear();
+        E->timer_mode = enable;
+        E->timer_on = true;
+        return DCTR_OK;
+    }
+    E->timer_on = false;
+    return timer_average(E, -1, h_avg_ms, h_count);
+}
+int dctr_step_timer_layer(dctr_handle E, int layer, float* h_avg_ms, int* h_count) {
+    DCTR_REQUIRE(E && layer >= 0 && !E->timer_on, "dctr_step_timer_layer: after dctr_step_timer(h, 0, ..), layer >= 0");
+    return timer_average(E, layer, h_avg_ms, h_count);
 }
 
 int dctr_set_dense_input(dctr_handle E, const float* d_dense) {

@@ -70,7 +70,12 @@ int dr_launch(const float* A, int lda, const float* B, int ldb, float* C, int ld
     DCTR_HIP_CHECK(attr);
     const int nbm = ceil_div(M, 16 * TM), nbn = ceil_div(N, 16 * TN);
     const int kchunk = (int)round_up(ceil_div(K, splits), 16);
-    if (hipEvent_t stop = take_stop_event()) {      // (the engine's next cross-stream record rides on this launch: common.h)
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (take_timer_events(&t0, &t1)) {              // (dctr_step_timer mode 2: this dispatch's own start / stop events; a launch has ONE stop event -- the
+                                                    //  engine does not arm a fork on a launch it times)
+        hipExtLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn), (unsigned)splits), dim3(256), (uint32_t)lds, st, t0, t1, 0, A, lda, B, ldb, C, ldc, M, N, K,
+                              kchunk, nbn, ep, DrOuter{});
+    } else if (hipEvent_t stop = take_stop_event()) {      // (the engine's next cross-stream record rides on this launch: common.h)
         hipExtLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn), (unsigned)splits), dim3(256), (uint32_t)lds, st, nullptr, stop, 0, A, lda, B, ldb, C, ldc, M, N, K,
                               kchunk, nbn, ep, DrOuter{});
     } else {

@@ -356,11 +356,18 @@ class Engine:
         capi.check(self._lib.dctr_time_kernel(self._h, stage.encode(), iters, C.byref(ms), st))
         return ms.value
 
-    def step_timer(self, enable: bool):
-        """Arms (True) / reads (False -> (avg_ms, count)) the in-step timer of the first MLP layer's forward GEMM."""
+    def step_timer(self, enable):
+        """Arms (True / 1: a bracket around the first MLP layer's forward GEMM; 2: every forward layer's own dispatch events) /
+        reads (False -> (avg_ms, count) over all timed launches) the in-step timer (dctr_step_timer)."""
         ms, n = C.c_float(), C.c_int()
         capi.check(self._lib.dctr_step_timer(self._h, int(enable), C.byref(ms), C.byref(n)))
         return None if enable else (ms.value, n.value)
+
+    def step_timer_layer(self, layer: int):
+        """(avg_ms, count) of one MLP layer's timed forward launches, after step_timer(False)."""
+        ms, n = C.c_float(), C.c_int()
+        capi.check(self._lib.dctr_step_timer_layer(self._h, int(layer), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     @staticmethod
     def measure_copy_bandwidth(nbytes: int = 1 << 30, iters: int = 20, stream=None) -> float:

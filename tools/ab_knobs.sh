@@ -10,7 +10,7 @@ while IFS='|' read -r label envs; do
 import sys, json
 d = json.loads(sys.stdin.readline())
 s = d['stage_ms']
-print('%.4f ms/step | host %.3f | L0 fwd in-step %.2f us | alone fwd %.1f dgrad %.1f wgrad %.1f' % (d['ms_per_step'], d['host_enqueue_ms_per_step'], 1e3 * d['roofline']['ms'], 1e3 * s['mlp0_fwd'], 1e3 * s['mlp0_dgrad'], 1e3 * s['mlp0_wgrad']))")
+print('%.4f ms/step | host %.3f | L0 fwd in-step %.2f us | alone fwd %.1f dgrad %.1f wgrad %.1f' % (d['ms_per_step'], d['host_enqueue_ms_per_step'], 1e3 * (d['roofline']['layers'][0]['ms'] if 'layers' in d['roofline'] else d['roofline']['ms']), 1e3 * s['mlp0_fwd'], 1e3 * s['mlp0_dgrad'], 1e3 * s['mlp0_wgrad']))")
     echo "$label: $r" | tee -a $out
   done
 done
