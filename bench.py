@@ -430,7 +430,7 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     in_ms, in_n = eng.step_timer(False)
-    in_layers = [eng.step_timer_layer(i) for i in range(len(w["deep_layers"]))] if (timer_mode == 2 and not sharded) else []
+    in_layers = [eng.step_timer_layer(i) for i in range(len(w["deep_layers"]))] if timer_mode == 2 else []
     if sharded:
         import torch.distributed as dist
         t = torch.tensor([el], device=dev, dtype=torch.float64)
@@ -506,7 +506,7 @@ def main():
         r["kernel"] = "%s (%s, layer 0: %dx%dx%d)" % (dom, gemm_name.replace("void dctr::", ""), B, F * K, w["deep_layers"][0])
         dims_ = [F * K] + list(w["deep_layers"])
         layer_flops = [2.0 * B * dims_[i] * dims_[i + 1] for i in range(len(dims_) - 1)]
-        if in_n > 0 and timer_mode == 2 and all(n > 0 for _ms, n in in_layers):
+        if in_n > 0 and timer_mode == 2 and in_layers and all(n > 0 for _ms, n in in_layers):
             # the kernel SYMBOL's launches in the timed steps -- the three forward layers share it -- each by its own dispatch events:
             # mean flops / mean duration, the figure rocprofv3's per-kernel average of the same command is comparable with
             r["kernel"] = "mlp forward GEMMs (%s; layers %s)" % (gemm_name.replace("void dctr::", ""), ", ".join("%dx%dx%d" % (B, dims_[i], dims_[i + 1]) for i in range(len(dims_) - 1)))
