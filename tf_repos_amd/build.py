@@ -22,6 +22,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-I", INCLUDE]
 
 
+# per-file flags.  gemm_dr3.hip: hipcc's SLP pass pairs the split's f32 subtractions into v_pk_add_f32, slower beside MFMAs than two
+# v_sub_f32 (see the file's header)
+FILE_FLAGS = {"gemm_dr3.hip": ["-fno-slp-vectorize"]}
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
@@ -51,7 +56,7 @@ def _compile(src: str, hdr_m: float, force: bool, verbose: bool, objdir: str = O
     path = os.path.join(CSRC, src)
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), hdr_m)):
         return obj
-    cmd = [HIPCC] + FLAGS + list(extra) + ["-x", "hip", "-c", path, "-o", obj]
+    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + list(extra) + ["-x", "hip", "-c", path, "-o", obj]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -46,7 +46,7 @@ class Config(C.Structure):
         ("use_graph", C.c_int32), ("dense_size", C.c_int32), ("lin_optimizer", C.c_int32),
         ("lin_learning_rate", C.c_float), ("loss_sum", C.c_int32), ("max_entries", C.c_int32), ("ctr_task_wgt", C.c_float),
         ("n_att_pairs", C.c_int32), ("att_user_slot", C.c_int32 * 8), ("att_ad_slot", C.c_int32 * 8),
-        ("table_sweep_period", C.c_int32), ("batch_norm_biased_moving_variance", C.c_int32),
+        ("table_sweep_period", C.c_int32), ("batch_norm_biased_moving_variance", C.c_int32), ("gemm_mode", C.c_int32),
     ]
 
 
@@ -194,6 +194,12 @@ class Transport(C.Structure):
 
 _SIGS["dctr_dropout_mask"] = ([C.c_uint64, C.c_int64, C.c_uint64, C.c_int64, C.c_float, _P], C.c_int)
 _SIGS["dctr_gemm_plan"] = ([C.c_char, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int], C.c_int)
+_SIGS["dctr_gemm_split_plane_bytes"] = ([C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)], C.c_int)
+_SIGS["dctr_gemm_wsplit"] = ([_P, C.c_int, C.c_int, _P, _P, _P], C.c_int)
+_SIGS["dctr_fc_fwd_split"] = ([_P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, _P], C.c_int)
+_SIGS["dctr_fc_bwd_data_split"] = ([_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_float, _P], C.c_int)
+_SIGS["dctr_fc_bwd_weights_split"] = ([_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P], C.c_int)
+_SIGS["dctr_gemm_split_launches"] = ([], C.c_int64)
 _SIGS["dctr_set_stat_sync"] = ([_P, ALL_REDUCE_F32_FN, _P, C.c_int], C.c_int)
 
 DECLARED_SYMBOLS = tuple(_SIGS)

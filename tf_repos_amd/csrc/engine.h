@@ -44,6 +44,12 @@ struct Fc {
     int splits = 1;
     int bn_beta = -1, bn_gamma = -1, bn_mm = -1, bn_mv = -1;   // batch_norm after this layer's ReLU (DeepFM.py:159-160)
     int last = -1;               // last parameter index of this layer (biases, or the BN moving variance)
+    // dctr_config.gemm_mode = 1: the weight pre-split into three bf16 planes in the forms the forward and the dgrad product read
+    // (gemm_dr3.hip); rewritten behind every optimizer step of the layer.  w_epoch counts writes of the weight, p_epoch is the
+    // epoch the planes were made from: a product that finds them different refreshes first (parameter writes from the host).
+    unsigned *wp_fwd = nullptr, *wp_dgr = nullptr;
+    int64_t fwd_plane = 0, dgr_plane = 0;
+    uint64_t w_epoch = 1, p_epoch = 0;
 };
 
 }  // namespace dctr
@@ -66,6 +72,7 @@ struct dctr_engine {
     std::vector<Fc> mlp;
     int p_out_w = -1, p_out_b = -1, p_bias = -1, p_cross_w = -1, p_cross_b = -1;
     int out_splits = 128;
+    int gemm_mode = 0;                   // dctr_config.gemm_mode after the DCTR_GEMM_MODE override
 
     // tables
     float *emb = nullptr, *emb_s0 = nullptr, *emb_s1 = nullptr, *lin = nullptr, *lin_s0 = nullptr, *lin_s1 = nullptr;

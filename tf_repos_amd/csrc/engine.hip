@@ -560,6 +560,54 @@ int build(dctr_engine* E) {
 // ---- forward (train=true: dropout on, DeepFM.py:161-162) ------------------------------------------------
 // the gather reads (emb, lin, rows, ids): the engine's own tables, or -- in the row-sharded path -- the buffer of rows
 // received from their owners with ids = positions in that buffer
+// ---- dctr_config.gemm_mode = 1: the MLP weights' pre-split planes (gemm_dr3.hip) ------------------------------------------------
+// fresh planes of one layer on `st` (behind whatever wrote the weight on that stream)
+int wplanes_refresh(dctr_engine* E, Fc& fc, hipStream_t st) {
+    if (fc.wp_fwd == nullptr) return DCTR_OK;
+    DCTR_TRY(dr3_wsplit(E->pp(fc.w), fc.out, fc.in, fc.out, fc.wp_fwd, fc.wp_dgr, st));
+    fc.p_epoch = fc.w_epoch;
+    return DCTR_OK;
+}
+// ... if the weight was written since they were made (parameter writes from the host; the step's own optimizer launches refresh eagerly)
+int wplanes_ensure(dctr_engine* E, Fc& fc, hipStream_t st) {
+    return fc.wp_fwd != nullptr && fc.p_epoch != fc.w_epoch ? wplanes_refresh(E, fc, st) : DCTR_OK;
+}
+// the parameters [p_first, p_last] were just written on `st` (an optimizer launch): their layers' planes follow on the same stream
+int wplanes_written(dctr_engine* E, int p_first, int p_last, hipStream_t st) {
+    for (std::vector<Fc>* tower : {&E->mlp, &E->mlp2})
+        for (Fc& fc : *tower)
+            if (fc.w >= p_first && fc.w <= p_last) {
+                fc.w_epoch++;
+                DCTR_TRY(wplanes_refresh(E, fc, st));
+            }
+    return DCTR_OK;
+}
+// the host wrote parameters: the next product that reads a layer's planes refreshes them first
+void wplanes_invalidate(dctr_engine* E) {
+    for (std::vector<Fc>* tower : {&E->mlp, &E->mlp2})
+        for (Fc& fc : *tower) fc.w_epoch++;
+}
+GemmOpt gemm_opt(const dctr_engine* E, const Fc& fc) {
+    GemmOpt g;
+    if (E->gemm_mode == 1 && fc.wp_fwd != nullptr) { g.mode = 1; g.w_fwd = fc.wp_fwd; g.fwd_plane = fc.fwd_plane; g.w_dgr = fc.wp_dgr; g.dgr_plane = fc.dgr_plane; }
+    else if (E->gemm_mode == 1) g.mode = 1;               // (no planes: the weight gradient may still take the split kernel)
+    return g;
+}
+static int wplanes_alloc(dctr_engine* E) {
+    if (E->gemm_mode != 1) return DCTR_OK;
+    for (std::vector<Fc>* tower : {&E->mlp, &E->mlp2})
+        for (size_t i = 0; i < tower->size(); ++i) {
+            Fc& fc = (*tower)[i];
+            if (tower == &E->mlp && i == 0 && E->opnn_fused) continue;          // (its products run over sub-ranges of the weight's rows)
+            if (!dr3_shape_ok(E->MB, fc.in, fc.out)) continue;
+            fc.fwd_plane = dr3_fwd_plane_bytes(fc.in, fc.out);
+            fc.dgr_plane = dr3_dgr_plane_bytes(fc.in, fc.out);
+            DCTR_HIP_CHECK(hipMalloc(&fc.wp_fwd, (size_t)(3 * fc.fwd_plane)));
+            DCTR_HIP_CHECK(hipMalloc(&fc.wp_dgr, (size_t)(3 * fc.dgr_plane)));
+        }
+    return DCTR_OK;
+}
+
 int gather_from(dctr_engine* E, const float* emb, const float* lin, int64_t rows, const int32_t* ids, int B, hipStream_t st, const LagView* lag = nullptr) {
     const int F = E->F, K = E->K;
     const int mode = gather_mode(E);
@@ -595,7 +643,9 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::f
     const float* x = E->x_in;
     int ldx = E->Din_ld;
     for (size_t i = 0; i < E->mlp.size(); ++i) {
-        const Fc& fc = E->mlp[i];
+        Fc& fc = E->mlp[i];
+        DCTR_TRY(wplanes_ensure(E, fc, st));
+        const GemmOpt go = gemm_opt(E, fc);
         // relu(x W + b) [-> batch_norm] -> dropout (DeepFM.py:156-162): without BN the dropout rides in the GEMM epilogue
         // (every 32nd step only: a timed step costs ~15 us more -- event records, or launches with completion signals -- which the
         //  bench's `value` should not carry: 0.5 us per step on average)
@@ -615,7 +665,7 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::f
                                     (train && !E->bn) ? fc.keep : 1.f, seedp, fc.salt, E->opnn_ws, st));
         } else
         DCTR_TRY(fc_fwd(x, ldx, E->pp(fc.w), E->pp(fc.b), E->h[i], fc.out, B, fc.in, fc.out, 1, (train && !E->bn) ? fc.keep : 1.f,
-                        seedp, fc.salt, st, 1));
+                        seedp, fc.salt, st, 1, &go));
         if (timed) { DCTR_HIP_CHECK(hipEventRecord(E->timer_ev[E->timer_n + 1], st)); E->timer_layer.push_back(0); E->timer_n += 2; }
         if (timed2) {
             if (timer_events_pending()) disarm_timer_events();          // (a launch site that does not carry events: this launch is not timed)
@@ -719,9 +769,10 @@ int opt_dense_range(dctr_engine* E, int p_first, int p_last, hipStream_t st, boo
     const int64_t off = a.arena_off;
     const int nb = (int)((b.arena_off + b.padded - off) / OPT_BLOCK);
     const int kind = lin_side ? E->cfg.lin_optimizer : E->cfg.optimizer;
-    return opt_dense_arena(kind, lin_side ? &E->state->hyper_lin : &E->state->hyper, lin_side ? E->h_state.hyper_lin : E->h_state.hyper,
-                           E->theta + off, E->as0 + off, E->as1 + off, E->parts, E->meta + off / OPT_BLOCK, nb, nullptr, 1,
-                           E->scalars + 3 * SUMSQ_SHARDS, st);
+    DCTR_TRY(opt_dense_arena(kind, lin_side ? &E->state->hyper_lin : &E->state->hyper, lin_side ? E->h_state.hyper_lin : E->h_state.hyper,
+                             E->theta + off, E->as0 + off, E->as1 + off, E->parts, E->meta + off / OPT_BLOCK, nb, nullptr, 1,
+                             E->scalars + 3 * SUMSQ_SHARDS, st));
+    return E->gemm_mode == 1 ? wplanes_written(E, p_first, p_last, st) : DCTR_OK;
 }
 
 // d(pair products) -> dL/de for the fused Outer-PNN first layer: dOP[b][(p,a,c)] = sum_h dh0[b][h] W0[F K + (p,a,c)][h], then
@@ -777,7 +828,9 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
     static const int late_layers_env = getenv("DCTR_WGRAD_LATE_LAYERS") ? atoi(getenv("DCTR_WGRAD_LATE_LAYERS")) : 0;
     const int late_layers = (!wgrad_late && fused_opt && sw != st && !E->opnn_fused && !E->bn) ? std::min(late_layers_env, nl) : 0;
     for (int i = nl - 1; i >= 0; --i) {
-        const Fc& fc = E->mlp[i];
+        Fc& fc = E->mlp[i];
+        DCTR_TRY(wplanes_ensure(E, fc, st));
+        const GemmOpt go = gemm_opt(E, fc);
         const float* x = i > 0 ? (E->bn ? E->hbn[i - 1] : E->h[i - 1]) : E->x_in;
         const int ldx = i > 0 ? E->mlp[i - 1].out : E->Din_ld;
         const Param& w = E->params[fc.w];
@@ -805,7 +858,7 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
                 }
             }
             DCTR_TRY(fc_bwd_weights_partials(x, ldx, E->dh[i], fc.out, E->part(fc.w), w.padded, E->part(fc.b), b.padded, B,
-                                             (i == 0 && E->opnn_fused) ? D : fc.in, fc.out, fc.splits, sw, 1));
+                                             (i == 0 && E->opnn_fused) ? D : fc.in, fc.out, fc.splits, sw, 1, &go));
             if (i == 0 && E->opnn_fused)
                 DCTR_TRY(opnn_outer_wgrad(E->e, E->e_ld, B, F, K, E->opnn_pairs, E->dh[0], fc.out, fc.out, E->part(fc.w) + (size_t)D * fc.out, sw));
         }
@@ -817,12 +870,12 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
         if (!wgrad_late && late_layers == 0 && !E->bn && !E->opnn_fused && sw != st && (i > 0 || (fused_opt && tail_plain))) stop_arm(E);
         if (i > 0)
             DCTR_TRY(fc_bwd_data(E->dh[i], fc.out, E->pp(fc.w), E->dh[i - 1], E->mlp[i - 1].out, B, fc.in, fc.out,
-                                 E->bn ? nullptr : E->h[i - 1], E->mlp[i - 1].out, E->bn ? 1.f : E->mlp[i - 1].keep, st, 1));
+                                 E->bn ? nullptr : E->h[i - 1], E->mlp[i - 1].out, E->bn ? 1.f : E->mlp[i - 1].keep, st, 1, &go));
         else if (E->opnn_fused) {
             DCTR_TRY(fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w), E->dx_in, E->Din_ld, B, D, fc.out, nullptr, 0, 1.f, st, 1));
             DCTR_TRY(opnn_outer_dgrad(E, B, st));
         } else
-            DCTR_TRY(fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w), E->dx_in, E->Din_ld, B, fc.in, fc.out, nullptr, 0, 1.f, st, 1));
+            DCTR_TRY(fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w), E->dx_in, E->Din_ld, B, fc.in, fc.out, nullptr, 0, 1.f, st, 1, &go));
     }
     if (wgrad_late) {
         // (experiment) the weight gradients AFTER the whole dgrad chain, beside the interaction backward, the scatter and the
@@ -1163,6 +1216,7 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     } else {
         DCTR_TRY(opt_dense_arena(E->cfg.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->parts, E->meta,
                                  E->n_blocks, nullptr, 1, E->scalars + 3 * SUMSQ_SHARDS, sw));
+        if (E->gemm_mode == 1) DCTR_TRY(wplanes_written(E, 0, (int)E->params.size() - 1, sw));
     }
     if (have_tables_ev) DCTR_HIP_CHECK(hipStreamWaitEvent(st, tables_ev, 0));
     else DCTR_TRY(fork(E, sg, st));
@@ -1335,8 +1389,14 @@ int dctr_create(const dctr_config* cfg, dctr_handle* h) {
             E->cfg.embedding_size = kp;
         }
     }
+    E->gemm_mode = E->cfg.gemm_mode == 1 ? 1 : 0;
+    if (const char* gm = getenv("DCTR_GEMM_MODE")) {       // (runs a whole test suite in the other mode)
+        if (!strcmp(gm, "split") || !strcmp(gm, "1")) E->gemm_mode = 1;
+        else if (!strcmp(gm, "exact") || !strcmp(gm, "0")) E->gemm_mode = 0;
+    }
     int rc = build(E);
     if (rc == DCTR_OK) rc = build_k_layouts(E);
+    if (rc == DCTR_OK) rc = wplanes_alloc(E);
     if (rc != DCTR_OK) { dctr_destroy(E); return rc; }
     *h = E;
     return DCTR_OK;
@@ -1359,6 +1419,8 @@ int dctr_destroy(dctr_handle E) {
     for (float* p : E->h2) hipFree(p);
     for (float* p : E->dh2) hipFree(p);
     { float* f2[] = {E->dx_in2, E->dy2, E->y2, E->prob2, E->prob3}; for (float* p : f2) if (p) hipFree(p); }
+    for (std::vector<Fc>* tower : {&E->mlp, &E->mlp2})
+        for (Fc& fc : *tower) { if (fc.wp_fwd) hipFree(fc.wp_fwd); if (fc.wp_dgr) hipFree(fc.wp_dgr); }
     if (E->opnn_pairs) hipFree(E->opnn_pairs);
     if (E->opnn_ws) hipFree(E->opnn_ws);
     if (E->opnn_dop) hipFree(E->opnn_dop);
@@ -1429,6 +1491,7 @@ static int copy_param(dctr_handle E, const char* name, int which, void* host, si
     DCTR_REQUIRE(nbytes == (size_t)p->log_n * sizeof(float), "parameter '%s' holds %lld floats, caller passed %zu bytes", name,
                  (long long)p->log_n, nbytes);
     float* d = which < 0 ? p->ptr : (which == 0 ? p->s0 : p->s1);
+    if (to_device && which < 0 && !p->is_table) wplanes_invalidate(E);       // (gemm_mode 1: the next product re-splits the layer's weight)
     if (which == 2) {           // the gradient of a dense variable: its partial slabs of the last backward pass, summed
         DCTR_REQUIRE(!p->is_table && !to_device, "dctr_param_grad_get: dense variables only (a table's gradient lives in the compact rows of the grouping)");
         DCTR_HIP_CHECK(hipDeviceSynchronize());
@@ -1521,6 +1584,7 @@ static int param_device_view(dctr_handle E, const char* name, float** d_ptr, int
         DCTR_TRY(lag_flush_tables(E, nullptr, 0, false));
         DCTR_HIP_CHECK(hipDeviceSynchronize());
     }
+    if (!p->is_table) wplanes_invalidate(E);        // (gemm_mode 1: the caller may write through the pointer)
     *d_ptr = p->ptr;
     if (row_stride != nullptr)      // floats between consecutive rows of the variable's first dimension
         *row_stride = p->is_table ? (p->name == "emb" ? E->tab_ld : E->lin_ld) : (p->rank > 0 ? p->log_n / std::max<int64_t>(p->log_dims[0], 1) : 1);
@@ -1836,6 +1900,7 @@ int dctr_train_step_csr(dctr_handle E, const int32_t* d_offsets, const int32_t* 
     DCTR_TRY(fork(E, st, sw));
     DCTR_TRY(opt_dense_arena(c.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->parts, E->meta, E->n_blocks,
                              nullptr, 1, E->scalars + 3 * SUMSQ_SHARDS, sw));
+    if (E->gemm_mode == 1) DCTR_TRY(wplanes_written(E, 0, (int)E->params.size() - 1, sw));
     // table: per-entry gradient = weight * dL/dx[slot], segment-summed per distinct id, then the optimizer (DIN.py:222: the
     // l2_loss(Feat_Emb) term makes the table gradient dense, as for the fixed-field models)
     DCTR_TRY(fork(E, sg, st));
@@ -2200,8 +2265,9 @@ int dctr_dense_grads(dctr_handle E, float** d_flat, int64_t* n, void* stream) {
 
 int dctr_dense_apply(dctr_handle E, void* stream) {
     DCTR_REQUIRE(E, "null handle");
-    return opt_dense_arena(E->cfg.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->gflat, E->meta_flat,
-                           E->n_blocks, nullptr, 1, E->scalars + 3 * SUMSQ_SHARDS, as_stream(stream));
+    DCTR_TRY(opt_dense_arena(E->cfg.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->gflat, E->meta_flat,
+                             E->n_blocks, nullptr, 1, E->scalars + 3 * SUMSQ_SHARDS, as_stream(stream)));
+    return E->gemm_mode == 1 ? wplanes_written(E, 0, (int)E->params.size() - 1, as_stream(stream)) : DCTR_OK;
 }
 
 int dctr_read_scalars(dctr_handle E, float h_out[4], void* stream) {
@@ -2284,9 +2350,11 @@ int dctr_time_kernel(dctr_handle E, const char* kernel, int iters, float* h_ms_p
                              E->emb_s1, E->lin, E->lin_s0, E->lin_s1, E->group->slot, E->group->uniq, E->group->counters,
                              E->group->max_entries, E->group->gemb, E->group->glin, c.l2_reg, E->scalars + SUMSQ_SHARDS, E->scalars + 2 * SUMSQ_SHARDS, cs,
                              nullptr, OPT_PASS_ALL, E->tab_ld, E->lin_ld);
-        if (s == "opt_dense")
-            return opt_dense_arena(c.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->parts, E->meta,
-                                   E->n_blocks, nullptr, 1, E->scalars + 3 * SUMSQ_SHARDS, cs);
+        if (s == "opt_dense") {
+            DCTR_TRY(opt_dense_arena(c.optimizer, &E->state->hyper, E->h_state.hyper, E->theta, E->as0, E->as1, E->parts, E->meta,
+                                     E->n_blocks, nullptr, 1, E->scalars + 3 * SUMSQ_SHARDS, cs));
+            return E->gemm_mode == 1 ? wplanes_written(E, 0, (int)E->params.size() - 1, cs) : DCTR_OK;
+        }
         if (s == "mlp0_fwd" || s == "mlp0_dgrad" || s == "mlp0_wgrad") {
             if (E->opnn_fused) { set_error("dctr_time_kernel: the fused Outer-PNN first layer is not one product (time it with rocprofv3)"); return DCTR_ERR_UNSUPPORTED; }
             const Fc& fc = E->mlp[0];

@@ -303,8 +303,12 @@ static int launch_gemm(const float* A, int lda, const float* B, int ldb, float* 
 
 // ---- public (namespace-level) entry points used by the engine -------------------------------------
 int fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N,
-           int relu, float keep, const uint64_t* seed_ptr, uint64_t seed, hipStream_t st, int over) {
+           int relu, float keep, const uint64_t* seed_ptr, uint64_t seed, hipStream_t st, int over, const GemmOpt* go) {
     bool done = false;
+    if (go != nullptr && go->mode == 1 && !ws_takes(M, K, N)) {       // split-precision mode: the layer's pre-split weight (gemm_dr3.hip)
+        DCTR_TRY(dr3_fc_fwd(x, ldx, go->w_fwd, go->fwd_plane, b, y, ldy, M, K, N, relu, keep, seed_ptr, seed, st, &done));
+        if (done) return DCTR_OK;
+    }
     DCTR_TRY(ws_fc_fwd(x, ldx, w, b, y, ldy, M, K, N, relu, keep, seed_ptr, seed, st, &done));      // tall operands: the weights stay in LDS (gemm_ws.hip)
     if (done) return DCTR_OK;
     // small products: the direct-to-register kernel family (gemm_dr.h) when one of its tiles fits the shape
@@ -316,9 +320,13 @@ int fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y, in
 }
 
 int fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int K, int N,
-                const float* act, int ldact, float keep_prev, hipStream_t st, int over) {
+                const float* act, int ldact, float keep_prev, hipStream_t st, int over, const GemmOpt* go) {
     // dX[M,K] = dY[M,N] * W[K,N]^T : reduction over N; "B" = W^T[N,K] stored as W[K,N] => k(N)-contiguous
     bool done = false;
+    if (go != nullptr && go->mode == 1 && !ws_takes(M, N, K)) {
+        DCTR_TRY(dr3_fc_bwd_data(dy, lddy, go->w_dgr, go->dgr_plane, dx, lddx, M, K, N, act, ldact, keep_prev, st, &done));
+        if (done) return DCTR_OK;
+    }
     DCTR_TRY(ws_fc_bwd_data(dy, lddy, w, dx, lddx, M, K, N, act, ldact, keep_prev, st, &done));
     if (done) return DCTR_OK;
     DCTR_TRY(dr_fc_bwd_data(dy, lddy, w, dx, lddx, M, K, N, act, ldact, keep_prev, st, &done));
@@ -333,8 +341,12 @@ int fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, 
 
 // dW partials: out[s][K*N] for s < splits (split over the batch dimension M), db partials: outb[s][N]
 int fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int lddy, float* dw_part, int64_t dw_stride,
-                            float* db_part, int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, int over) {
+                            float* db_part, int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, int over, const GemmOpt* go) {
     bool done = false;
+    if (go != nullptr && go->mode == 1) {
+        DCTR_TRY(dr3_fc_bwd_weights_partials(x, ldx, dy, lddy, dw_part, dw_stride, db_part, db_stride, M, K, N, splits, st, &done));
+        if (done) return DCTR_OK;
+    }
     DCTR_TRY(dr_fc_bwd_weights_partials(x, ldx, dy, lddy, dw_part, dw_stride, db_part, db_stride, M, K, N, splits, st, &done));
     if (done) return DCTR_OK;
     Epilogue ep{};

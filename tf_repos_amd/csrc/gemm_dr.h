@@ -24,6 +24,7 @@
 
 #include <cstdint>
 #include <type_traits>
+#include <utility>
 
 #ifdef DR_STAMPS            // tools/gemm_dr_probe.hip only: cycle stamps per wave at the phase boundaries
 #define DR_STAMP(i) do { if (lane == 0) dr_stamps[((blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
@@ -143,6 +144,137 @@ __device__ __forceinline__ void dr_reduce_tiles(f32x4 (&acc)[TM][TN], float* lds
             if (dr_owner<TN, B_RC>(i, j) == W) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) lds[dr_row<TM, A_RC>(i, 4 * q + r) * LDS_ + dr_col<TN, B_RC>(j, c)] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// Everything behind the main loop, shared by the exact kernel and the split-precision one (gemm_dr3_kernel): bias-gradient column
+// sums, cross-wave reduction, row-major staging, epilogue (bias / ReLU / dropout, ReLU mask, column scale) and the coalesced stores.
+template <int TM, int TN, bool A_PLAIN, bool B_RC, bool CS, int EPI, bool GATE>
+__device__ __forceinline__ void dr_finish(f32x4 (&acc)[TM][TN], float (&cs)[TN], float (&cs2)[GATE ? TN : 1], const DrEpilogue& ep, float* __restrict__ C, int ldc,
+                                          int M, int N, int m0, int n0, int bm, int split, uint32_t keep_lo, uint32_t keep_hi, float* dr_lds) {
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    // ---- wgrad: bias gradient = column sums of B (= dY) over this block's reduction range, first row of tiles only
+    if (CS && ep.colsum != nullptr && bm == 0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float v = cs[j];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (q == 0) dr_lds[w * 16 * TN + dr_col<TN, B_RC>(j, c)] = v;
+        }
+        __syncthreads();
+        if (t < 16 * TN && n0 + t < N)
+            ep.colsum[(size_t)split * ep.colsum_stride + n0 + t] = (dr_lds[t] + dr_lds[16 * TN + t] + dr_lds[32 * TN + t] + dr_lds[48 * TN + t]) *
+                                                                     (GATE ? ep.colscale[n0 + t] : 1.f);
+        __syncthreads();
+    }
+    if constexpr (GATE) {
+        if (ep.colsum2 != nullptr && bm == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float v = cs2[j];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (q == 0) dr_lds[w * 16 * TN + dr_col<TN, B_RC>(j, c)] = v;
+            }
+            __syncthreads();
+            if (t < 16 * TN && n0 + t < N)
+                ep.colsum2[(size_t)split * ep.colsum2_stride + n0 + t] = dr_lds[t] + dr_lds[16 * TN + t] + dr_lds[32 * TN + t] + dr_lds[48 * TN + t];
+            __syncthreads();
+        }
+    }
+
+    // this thread's output column (store phase below) and its bias, loaded here so that the latency hides behind the reduction
+    constexpr int C4 = 4 * TN;                  // float4s per tile row
+    constexpr int RPI = 256 / C4;               // tile rows stored per pass of the block
+    const int tr = t / C4, tc = t - tr * C4;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == DR_BIAS_ACT && ep.bias != nullptr && t < RPI * C4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n0 + 4 * tc + e < N) bias4[e] = ep.bias[n0 + 4 * tc + e];
+    }
+    float cscale4[4] = {1.f, 1.f, 1.f, 1.f};
+    if (GATE && t < RPI * C4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n0 + 4 * tc + e < N) cscale4[e] = ep.colscale[n0 + 4 * tc + e];
+    }
+    // ---- cross-wave reduction + row-major staging (dr_reduce_tiles), one instantiation per wave id
+    constexpr int LDS_ = 16 * TN + 4;           // staged row stride
+    switch (w) {
+        case 0: dr_reduce_tiles<TM, TN, A_PLAIN, B_RC, 0>(acc, dr_lds, lane); break;
+        case 1: dr_reduce_tiles<TM, TN, A_PLAIN, B_RC, 1>(acc, dr_lds, lane); break;
+        case 2: dr_reduce_tiles<TM, TN, A_PLAIN, B_RC, 2>(acc, dr_lds, lane); break;
+        default: dr_reduce_tiles<TM, TN, A_PLAIN, B_RC, 3>(acc, dr_lds, lane); break;
+    }
+    DR_STAMP(3);
+    __syncthreads();
+    DR_STAMP(4);
+
+    // ---- coalesced row-major stores: a thread keeps ONE float4 column of the tile and walks down the rows (its bias was loaded
+    // before the reduction; the ReLU-mask reads of all its rows are issued together ahead of the stores).  Bias / ReLU /
+    // dropout or the ReLU mask are applied here.
+    constexpr int NIT = (16 * TM + RPI - 1) / RPI;
+    const int gn = n0 + 4 * tc;
+    float* Cz = C + (EPI == DR_STORE ? (size_t)split * ep.split_stride : 0);
+    uint64_t seed = 0;
+    if (EPI == DR_BIAS_ACT) seed = ep.seed ^ (ep.seed_ptr ? *ep.seed_ptr : 0ull);
+    // fast path: every float4 of the tile is either whole or absent, and 16-byte aligned on both sides
+    const bool fast = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cz) & 15) == 0) && ((N & 3) == 0) &&
+                      (EPI != DR_MASK || (((ep.ldact & 3) == 0) && ((reinterpret_cast<uintptr_t>(ep.act) & 15) == 0)));
+    if (fast) {
+        const bool col_on = t < RPI * C4 && gn < N;
+        float4 am[NIT];
+        if (EPI == DR_MASK) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int row = tr + RPI * it, gm = m0 + row;
+                am[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (col_on && row < 16 * TM && gm < M) am[it] = *reinterpret_cast<const float4*>(ep.act + (size_t)gm * ep.ldact + gn);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = tr + RPI * it, gm = m0 + row;
+            if (col_on && row < 16 * TM && gm < M) {
+                const float4 v4 = *reinterpret_cast<const float4*>(&dr_lds[row * LDS_ + 4 * tc]);
+                float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                const float a[4] = {am[it].x, am[it].y, am[it].z, am[it].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (EPI == DR_BIAS_ACT) {
+                        v[e] += bias4[e];
+                        if (ep.relu) v[e] = fmaxf(v[e], 0.f);
+                        if (ep.keep < 1.0f) v[e] *= (((it * 4 + e < 32 ? keep_lo : keep_hi) >> ((it * 4 + e) & 31)) & 1u) ? 1.0f / ep.keep : 0.0f;
+                    } else if (EPI == DR_MASK) {
+                        v[e] = (a[e] > 0.f) ? v[e] * ep.inv_keep : 0.f;
+                    } else if (GATE) {
+                        v[e] *= cscale4[e];
+                    }
+                }
+                *reinterpret_cast<float4*>(Cz + (size_t)gm * ldc + gn) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    } else {                     // odd strides / widths: element by element (not a tuned path)
+        for (int idx = t; idx < 16 * TM * 16 * TN; idx += 256) {
+            const int row = idx / (16 * TN), col = idx - row * (16 * TN);
+            const int gm = m0 + row, gc = n0 + col;
+            if (gm < M && gc < N) {
+                float v = dr_lds[row * LDS_ + col];
+                if (EPI == DR_BIAS_ACT) {
+                    if (ep.bias != nullptr) v += ep.bias[gc];
+                    if (ep.relu) v = fmaxf(v, 0.f);
+                    if (ep.keep < 1.0f) v *= dr_dropout_scale(seed, ((ep.seed_ptr ? ep.seed_ptr[1] : 0ull) + (uint64_t)gm) * (uint64_t)N + gc, ep.keep);
+                } else if (EPI == DR_MASK) {
+                    v = (ep.act[(size_t)gm * ep.ldact + gc] > 0.f) ? v * ep.inv_keep : 0.f;
+                } else if (GATE) {
+                    v *= ep.colscale[gc];
+                }
+                Cz[(size_t)gm * ldc + gc] = v;
             }
         }
     }
@@ -490,129 +622,406 @@ __global__ __launch_bounds__(256, DR_MIN_WAVES(TM, TN, CS, AGEN)) void gemm_dr_k
     }
     DR_STAMP(2);
 
-    // ---- wgrad: bias gradient = column sums of B (= dY) over this block's reduction range, first row of tiles only
-    if (CS && ep.colsum != nullptr && bm == 0) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float v = cs[j];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            if (q == 0) dr_lds[w * 16 * TN + dr_col<TN, B_RC>(j, c)] = v;
-        }
-        __syncthreads();
-        if (t < 16 * TN && n0 + t < N)
-            ep.colsum[(size_t)split * ep.colsum_stride + n0 + t] = (dr_lds[t] + dr_lds[16 * TN + t] + dr_lds[32 * TN + t] + dr_lds[48 * TN + t]) *
-                                                                     (GATE ? ep.colscale[n0 + t] : 1.f);
-        __syncthreads();
-    }
-    if constexpr (GATE) {
-        if (ep.colsum2 != nullptr && bm == 0) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                float v = cs2[j];
-                v += __shfl_xor(v, 16);
-                v += __shfl_xor(v, 32);
-                if (q == 0) dr_lds[w * 16 * TN + dr_col<TN, B_RC>(j, c)] = v;
-            }
-            __syncthreads();
-            if (t < 16 * TN && n0 + t < N)
-                ep.colsum2[(size_t)split * ep.colsum2_stride + n0 + t] = dr_lds[t] + dr_lds[16 * TN + t] + dr_lds[32 * TN + t] + dr_lds[48 * TN + t];
-            __syncthreads();
-        }
-    }
+    dr_finish<TM, TN, A_PLAIN, B_RC, CS, EPI, GATE>(acc, cs, cs2, ep, C, ldc, M, N, m0, n0, bm, split, keep_lo, keep_hi, dr_lds);
+    DR_STAMP(5);
+}
 
-    // this thread's output column (store phase below) and its bias, loaded here so that the latency hides behind the reduction
-    constexpr int C4 = 4 * TN;                  // float4s per tile row
-    constexpr int RPI = 256 / C4;               // tile rows stored per pass of the block
-    const int tr = t / C4, tc = t - tr * C4;
-    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (EPI == DR_BIAS_ACT && ep.bias != nullptr && t < RPI * C4) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (n0 + 4 * tc + e < N) bias4[e] = ep.bias[n0 + 4 * tc + e];
-    }
-    float cscale4[4] = {1.f, 1.f, 1.f, 1.f};
-    if (GATE && t < RPI * C4) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (n0 + 4 * tc + e < N) cscale4[e] = ep.colscale[n0 + 4 * tc + e];
-    }
-    // ---- cross-wave reduction + row-major staging (dr_reduce_tiles), one instantiation per wave id
-    constexpr int LDS_ = 16 * TN + 4;           // staged row stride
-    switch (w) {
-        case 0: dr_reduce_tiles<TM, TN, A_PLAIN, B_RC, 0>(acc, dr_lds, lane); break;
-        case 1: dr_reduce_tiles<TM, TN, A_PLAIN, B_RC, 1>(acc, dr_lds, lane); break;
-        case 2: dr_reduce_tiles<TM, TN, A_PLAIN, B_RC, 2>(acc, dr_lds, lane); break;
-        default: dr_reduce_tiles<TM, TN, A_PLAIN, B_RC, 3>(acc, dr_lds, lane); break;
-    }
-    DR_STAMP(3);
-    __syncthreads();
-    DR_STAMP(4);
+// ---------------------------------------------------------------------------------------------------------------------------
+// Split-precision variant (dctr_config.gemm_mode = 1): the same direct-to-register wave-split-K product with every f32 operand
+// element split IN REGISTERS into three bf16 planes  x = h + m + l  (round-to-nearest-even each time: h = bf16(x), m = bf16(x - h),
+// l = bf16(x - h - m); the two differences are exact in f32 and after two 8-bit roundings at most 8 significant bits are left, so
+// the three planes carry all 24 bits of x) and the six leading plane products
+//     h h,  h m,  m h,  h l,  l h,  m m
+// accumulated in f32 by v_mfma_f32_16x16x32_bf16 (products of two 8-bit significands are exact; the accumulator is f32).  The
+// three dropped products (m l, l m, l l) are below 2^-24 |x y| each: the result is an f32 dot product to within the rounding of
+// its f32 accumulation, like the exact kernel's -- NOT a bf16 product.  Why: the f32-input MFMA runs at 1/16 of the bf16 rate
+// (MI355X_MICROARCH.md), so six bf16 products cost 6/16 of the matrix-pipe time of one f32 product.  What it costs instead is
+// VALU: 11 ops per PAIR of elements (3 v_cvt_pk_bf16_f32, 2 shifts, 2 ands, 4 subtractions), once per element and wave because
+// the waves split the reduction and each element enters the CU once -- 44 (TM + TN) VALU ops against 6 TM TN MFMAs per 32 k, which
+// wants the squarer tiles (4 x 7, 4 x 10) rather than 2 x 13.
+//
+// k assignment: a group is 32 consecutive k; lane (c, q) holds k = 8 q + e, e = 0..7, of row / column c -- the A and B fragments
+// of one 16x16x32 MFMA (any consistent order of k is a dot product).  A reduction-contiguous operand gives a lane its 8 values as
+// two dwordx4; the other kind one dword (or a dwordx4 over four tiles) per e.  The raw f32 registers of a tile are free again as
+// soon as the tile is split, and are refilled THEN with the next group's values: one raw set, a whole group of latency slack.
+// Replaces the same TF ops as gemm_dr_kernel (DeepFM.py:156-158,165-166,213).
+typedef __bf16 dr_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 dr_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float dr_f32x2 __attribute__((ext_vector_type(2)));
 
-    // ---- coalesced row-major stores: a thread keeps ONE float4 column of the tile and walks down the rows (its bias was loaded
-    // before the reduction; the ReLU-mask reads of all its rows are issued together ahead of the stores).  Bias / ReLU /
-    // dropout or the ReLU mask are applied here.
-    constexpr int NIT = (16 * TM + RPI - 1) / RPI;
-    const int gn = n0 + 4 * tc;
-    float* Cz = C + (EPI == DR_STORE ? (size_t)split * ep.split_stride : 0);
-    uint64_t seed = 0;
-    if (EPI == DR_BIAS_ACT) seed = ep.seed ^ (ep.seed_ptr ? *ep.seed_ptr : 0ull);
-    // fast path: every float4 of the tile is either whole or absent, and 16-byte aligned on both sides
-    const bool fast = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cz) & 15) == 0) && ((N & 3) == 0) &&
-                      (EPI != DR_MASK || (((ep.ldact & 3) == 0) && ((reinterpret_cast<uintptr_t>(ep.act) & 15) == 0)));
-    if (fast) {
-        const bool col_on = t < RPI * C4 && gn < N;
-        float4 am[NIT];
-        if (EPI == DR_MASK) {
+template <class F, int... I>
+__device__ __forceinline__ void dr_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void dr_static_for(F&& f) { dr_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
+struct DrPlanes { u32x4 h, m, l; };
+
+__device__ __forceinline__ unsigned dr_pk_bf16(float a, float b) {          // v_cvt_pk_bf16_f32: a -> low half, b -> high half, RNE
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(dr_f32x2{a, b}, dr_bf16x2));
+}
+// (plain v_sub_f32: hipcc's SLP pass would pair them into v_pk_add_f32, which costs more issue time beside MFMAs than two subs)
+__device__ __forceinline__ float dr_sub(float a, float b) {
+#ifdef DR3_PK_SUB
+    return a - b;
+#else
+    float r;
+    asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#endif
+}
+__device__ __forceinline__ void dr_split3(const float (&x)[8], DrPlanes& p) {
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int row = tr + RPI * it, gm = m0 + row;
-                am[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (col_on && row < 16 * TM && gm < M) am[it] = *reinterpret_cast<const float4*>(ep.act + (size_t)gm * ep.ldact + gn);
+    for (int t = 0; t < 4; ++t) {
+        const float x0 = x[2 * t], x1 = x[2 * t + 1];
+        const unsigned h = dr_pk_bf16(x0, x1);
+        const float r0 = dr_sub(x0, __uint_as_float(h << 16)), r1 = dr_sub(x1, __uint_as_float(h & 0xffff0000u));
+        const unsigned m = dr_pk_bf16(r0, r1);
+        const float s0 = dr_sub(r0, __uint_as_float(m << 16)), s1 = dr_sub(r1, __uint_as_float(m & 0xffff0000u));
+        p.h[t] = h;
+        p.m[t] = m;
+        p.l[t] = dr_pk_bf16(s0, s1);
+    }
+}
+__device__ __forceinline__ f32x4 dr_mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dr_bf16x8, a), __builtin_bit_cast(dr_bf16x8, b), c, 0, 0, 0);
+}
+
+// Tiles of up to 14 accumulators (2 x 7: 32 x 112) are compiled for TWO blocks per CU (<= 256 registers, 42 KB of LDS): one wave
+// per SIMD issues about one instruction per 5 cycles (MI355X_MICROARCH.md: <= 5 fillers per 32-cycle MFMA), which makes the
+// ~2.9 split VALU ops per 17-cycle MFMA the bound; with a second block's wave on the same SIMD the two streams fill each other's
+// issue gaps.  (The exact kernel gains nothing from that -- DESIGN 5b, DR_WAVES2 -- because its VALU stream is nearly empty.)
+#define DR3_MIN_WAVES(TM, TN) ((TM) * (TN) <= 14 ? 2 : 1)
+// B_PRE: the B operand (the layer's WEIGHT in the forward and dgrad products) arrives already split -- three bf16 planes laid out
+// [plane][k / 8][column][8] (dr_wsplit_kernel writes them once per optimizer step; `B` points at plane 0, `ldb` = columns of a plane
+// row, `bplane` = bytes from one plane to the next).  Every CU of a row block needs every weight element, so splitting weights
+// in the product costs 64 x the VALU work of splitting them where they are written; the activations (A) are still split here.
+template <int TM, int TN, bool A_RC, bool B_RC, bool CS, int EPI, bool B_PRE = false>
+__global__ __launch_bounds__(256, DR3_MIN_WAVES(TM, TN)) void gemm_dr3_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                          float* __restrict__ C, int ldc, int M, int N, int K, int kchunk, int nbn, DrEpilogue ep,
+                                                          int64_t bplane) {
+    static_assert(!B_PRE || (B_RC && !CS), "pre-split B: tiles cover plain column blocks (B_RC = true for the epilogue's column map); not a weight gradient");
+    constexpr int TQ = B_RC ? 0 : TN / 4;                    // quads of B tiles sharing one dwordx4 per lane (NC only)
+    constexpr int VA = A_RC ? 1 : (TM % 4 == 0 ? 4 : (TM % 2 == 0 ? 2 : 1));
+    constexpr int AG = TM / VA;                              // A load groups per e (NC only)
+    extern __shared__ __attribute__((aligned(16))) float dr_lds[];
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    int bm, bn, split;
+    {   // XCD-aware order, as gemm_dr_kernel
+        const int nwg = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+        const int qq = nwg / 8, r = nwg % 8, xcd = b % 8, idx = b / 8;
+        const int lb = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+        split = __builtin_amdgcn_readfirstlane(lb / (int)gridDim.x);
+        const int tile = lb - split * (int)gridDim.x;
+        bn = tile % nbn;
+        bm = tile / nbn;
+    }
+    DR_STAMP(0);
+    __builtin_amdgcn_s_setprio(3);
+    const int m0 = bm * 16 * TM, n0 = bn * 16 * TN;
+    const int kb0 = split * kchunk, kb1 = min(K, kb0 + kchunk);            // (kchunk: a multiple of 32)
+    const int kw = ((max(kb1 - kb0, 0) + 31) / 32) * 8;                    // k per wave, a multiple of 8
+    const int kbeg = __builtin_amdgcn_readfirstlane(min(kb0 + w * kw, kb1));
+    const int kend = __builtin_amdgcn_readfirstlane(min(kb1, kbeg + kw));  // (a multiple of 4 for a reduction-contiguous operand: the host requires K % 4 == 0)
+    const int G = __builtin_amdgcn_readfirstlane((kend - kbeg + 31) / 32); // groups of 32 k, the last one possibly partial
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const float* Ab = A + (A_RC ? (size_t)m0 * lda + kbeg : (size_t)kbeg * lda + m0);
+    // (pre-split: plane rows of 8 k, 16 bytes per (k-block, column); kbeg is a multiple of 8)
+    const float* Bb = B_PRE ? B + ((size_t)(kbeg / 8) * ldb + n0) * 4 : B + (B_RC ? (size_t)n0 * ldb + kbeg : (size_t)kbeg * ldb + n0);
+    auto clip31 = [](int64_t floats) -> int {
+        const int hi = (int)(floats >> 32);
+        const unsigned top = (unsigned)((uint64_t)floats >> 29);
+        return hi < 0 ? 0 : (top != 0u ? 0x7ffffff0 : (int)((unsigned)floats * 4u));
+    };
+    // num_records: an operand whose rows ARE the reduction ends at this wave's last row -- whatever a partial or surplus group
+    // addresses beyond it reads as 0 without touching memory; a reduction-contiguous operand ends at the end of the matrix and
+    // its k beyond kend (the next wave's) are masked by lane offsets below
+    const int bytesA = clip31(A_RC ? (int64_t)(min(M - m0, 16 * TM) - 1) * lda + (K - kbeg) : (int64_t)(kend - kbeg - 1) * lda + (M - m0));
+    const int bytesB = B_PRE ? clip31(((int64_t)((kend - kbeg + 7) / 8 - 1) * ldb + (ldb - n0)) * 4)        // this wave's k-blocks of ONE plane (in floats: 4 per entry)
+                       : clip31(B_RC ? (int64_t)(min(N - n0, 16 * TN) - 1) * ldb + (K - kbeg) : (int64_t)(kend - kbeg - 1) * ldb + (N - n0));
+    auto uni_ptr = [](const float* p) {
+        const uint64_t v = reinterpret_cast<uint64_t>(p);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+    };
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(Ab), 0, __builtin_amdgcn_readfirstlane(kend > kbeg ? bytesA : 0), 0x00020000);
+    const auto rb = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(Bb), 0, __builtin_amdgcn_readfirstlane(kend > kbeg ? bytesB : 0), 0x00020000);
+    // (pre-split: one descriptor per plane, so that each plane ends at this wave's last k-block)
+    const float* Bb1 = B_PRE ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(Bb) + bplane) : Bb;
+    const float* Bb2 = B_PRE ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(Bb) + 2 * bplane) : Bb;
+    const auto rb1 = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(Bb1), 0, __builtin_amdgcn_readfirstlane(kend > kbeg ? bytesB : 0), 0x00020000);
+    const auto rb2 = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(Bb2), 0, __builtin_amdgcn_readfirstlane(kend > kbeg ? bytesB : 0), 0x00020000);
+    constexpr int NA = A_RC ? TM : AG, NB = B_PRE ? 1 : (B_RC ? TN : TQ + (TN - 4 * TQ));         // lane offsets per operand
+    int aoff[NA], boff[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) aoff[i] = 4 * (A_RC ? (16 * i + c) * lda + 8 * q : 8 * q * lda + 16 * VA * i + VA * c);
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+        boff[j] = B_PRE ? 16 * (q * ldb + c)                 // (tile j: + 256 j bytes, group g: + 64 g ldb bytes -- scalar)
+                  : 4 * (B_RC ? (16 * j + c) * ldb + 8 * q : 8 * q * ldb + (j < TQ ? 64 * j + 4 * c : 64 * TQ + 16 * (j - TQ) + c));
+    const unsigned strideA = 4u * (unsigned)lda, strideB = 4u * (unsigned)ldb;    // bytes per k of an NC operand
+    // reduction-contiguous pieces (k = 32 g + 8 q + 4 p .. + 3, p = 0, 1) are real while 32 g < lim[p]
+    const int lim0 = (kend - kbeg) - 8 * q, lim1 = lim0 - 4;
+
+    struct Raw { float a[TM][8]; float b[B_PRE ? 1 : TN][8]; };
+    auto ld4 = [](auto rs, int voff, unsigned soff_, float* d, int stride) {
+        const unsigned soff = __builtin_amdgcn_readfirstlane(soff_);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e * stride] = __uint_as_float(v[e]);
+    };
+    auto ld2 = [](auto rs, int voff, unsigned soff_, float* d, int stride) {
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const unsigned soff = __builtin_amdgcn_readfirstlane(soff_);
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+        d[0] = __uint_as_float(v[0]);
+        d[stride] = __uint_as_float(v[1]);
+    };
+    auto ld1 = [](auto rs, int voff, unsigned soff_, float* d) {
+        const unsigned soff = __builtin_amdgcn_readfirstlane(soff_);
+        d[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+    };
+    // the loads of group g: A tile / load group i, B unit u
+    auto loadA = [&](Raw& f, int g) {
+        if constexpr (A_RC) {
+            const bool ok0 = 32 * g < lim0, ok1 = 32 * g < lim1;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ld4(ra, ok0 ? aoff[i] : 0x7ffffff0, 128u * g, &f.a[i][0], 1);
+                ld4(ra, ok1 ? aoff[i] + 16 : 0x7ffffff0, 128u * g, &f.a[i][4], 1);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < AG; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned so = (32u * g + e) * strideA;
+                    if constexpr (VA == 4) ld4(ra, aoff[i], so, &f.a[4 * i][e], 8);
+                    else if constexpr (VA == 2) ld2(ra, aoff[i], so, &f.a[2 * i][e], 8);
+                    else ld1(ra, aoff[i], so, &f.a[i][e]);
+                }
+        }
+    };
+    auto loadB = [&](Raw& f, int u, int g) {
+        if constexpr (B_RC) {
+            const bool ok0 = 32 * g < lim0, ok1 = 32 * g < lim1;
+            ld4(rb, ok0 ? boff[u] : 0x7ffffff0, 128u * g, &f.b[u][0], 1);
+            ld4(rb, ok1 ? boff[u] + 16 : 0x7ffffff0, 128u * g, &f.b[u][4], 1);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned so = (32u * g + e) * strideB;
+                if (u < TQ) ld4(rb, boff[u], so, &f.b[4 * u][e], 8);
+                else ld1(rb, boff[u], so, &f.b[4 * TQ + (u - TQ)][e]);
             }
         }
+    };
+    float cs[TN];                                            // wgrad: column sums of B (= dY), first row of tiles only
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int row = tr + RPI * it, gm = m0 + row;
-            if (col_on && row < 16 * TM && gm < M) {
-                const float4 v4 = *reinterpret_cast<const float4*>(&dr_lds[row * LDS_ + 4 * tc]);
-                float v[4] = {v4.x, v4.y, v4.z, v4.w};
-                const float a[4] = {am[it].x, am[it].y, am[it].z, am[it].w};
+    for (int j = 0; j < TN; ++j) cs[j] = 0.f;
+    auto mma = [&](const DrPlanes (&pa)[TM], const DrPlanes& pb, int j) {
+        // six products; consecutive MFMAs go to different accumulators (i varies fastest)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = dr_mfma_bf16(pa[i].m, pb.m, acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = dr_mfma_bf16(pa[i].l, pb.h, acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = dr_mfma_bf16(pa[i].h, pb.l, acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = dr_mfma_bf16(pa[i].m, pb.h, acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = dr_mfma_bf16(pa[i].h, pb.m, acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = dr_mfma_bf16(pa[i].h, pb.h, acc[i][j]);
+    };
+    // B tile -> the load unit it belongs to and whether it is the unit's last tile (the unit's raw registers are free after it)
+    auto unit_of = [](int j) constexpr { return B_RC ? j : (j < 4 * TQ ? j / 4 : TQ + (j - 4 * TQ)); };
+    auto last_of_unit = [](int j) constexpr { return B_RC || j >= 4 * TQ || (j & 3) == 3; };
+
+    Raw f;
+    DrPlanes pa[TM], pan[TM], pb0, pb1;
+    DrPlanes pw[B_PRE ? TN : 1];                              // pre-split: the planes of every B tile, refilled tile by tile
+    auto loadW = [&](int j, int g) {
+        const unsigned so = __builtin_amdgcn_readfirstlane(64u * g * (unsigned)ldb + 256u * j);
+        pw[j].h = __builtin_amdgcn_raw_buffer_load_b128(rb, boff[0], so, 0);
+        pw[j].m = __builtin_amdgcn_raw_buffer_load_b128(rb1, boff[0], so, 0);
+        pw[j].l = __builtin_amdgcn_raw_buffer_load_b128(rb2, boff[0], so, 0);
+    };
+    if (G > 0) {
+        loadA(f, 0);
+        if constexpr (B_PRE) {
+#pragma unroll
+            for (int j = 0; j < TN - 1; ++j) loadW(j, 0);     // (tile TN - 1 is loaded in the first region of the first group)
+        } else {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) loadB(f, u, 0);
+        }
+    }
+    // ---- dropout keep bits of the elements this thread will store, while the first loads are in flight (as gemm_dr_kernel)
+    constexpr int C4_ = 4 * TN, RPI_ = 256 / C4_, NIT_ = (16 * TM + RPI_ - 1) / RPI_;
+    static_assert(NIT_ * 4 <= 64, "keep bits of a thread's output elements fit two words");
+    uint32_t keep_lo = 0xffffffffu, keep_hi = 0xffffffffu;
+    if constexpr (EPI == DR_BIAS_ACT) {
+        if (ep.keep < 1.0f) {
+            const uint64_t sd = ep.seed ^ (ep.seed_ptr ? *ep.seed_ptr : 0ull);
+            const uint64_t row0 = ep.seed_ptr ? ep.seed_ptr[1] : 0ull;
+            const int tr_ = t / C4_, tc_ = t - tr_ * C4_;
+            keep_lo = keep_hi = 0u;
+#pragma unroll
+            for (int it = 0; it < NIT_; ++it) {
+                const uint64_t base = (row0 + (uint64_t)(m0 + tr_ + RPI_ * it)) * (uint64_t)N + (uint64_t)(n0 + 4 * tc_);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (EPI == DR_BIAS_ACT) {
-                        v[e] += bias4[e];
-                        if (ep.relu) v[e] = fmaxf(v[e], 0.f);
-                        if (ep.keep < 1.0f) v[e] *= (((it * 4 + e < 32 ? keep_lo : keep_hi) >> ((it * 4 + e) & 31)) & 1u) ? 1.0f / ep.keep : 0.0f;
-                    } else if (EPI == DR_MASK) {
-                        v[e] = (a[e] > 0.f) ? v[e] * ep.inv_keep : 0.f;
-                    } else if (GATE) {
-                        v[e] *= cscale4[e];
-                    }
+                    const uint32_t bit = dr_dropout_scale(sd, base + e, ep.keep) != 0.f ? 1u : 0u;
+                    if (it * 4 + e < 32) keep_lo |= bit << ((it * 4 + e) & 31);
+                    else keep_hi |= bit << ((it * 4 + e) & 31);
                 }
-                *reinterpret_cast<float4*>(Cz + (size_t)gm * ldc + gn) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        }
-    } else {                     // odd strides / widths: element by element (not a tuned path)
-        for (int idx = t; idx < 16 * TM * 16 * TN; idx += 256) {
-            const int row = idx / (16 * TN), col = idx - row * (16 * TN);
-            const int gm = m0 + row, gc = n0 + col;
-            if (gm < M && gc < N) {
-                float v = dr_lds[row * LDS_ + col];
-                if (EPI == DR_BIAS_ACT) {
-                    if (ep.bias != nullptr) v += ep.bias[gc];
-                    if (ep.relu) v = fmaxf(v, 0.f);
-                    if (ep.keep < 1.0f) v *= dr_dropout_scale(seed, ((ep.seed_ptr ? ep.seed_ptr[1] : 0ull) + (uint64_t)gm) * (uint64_t)N + gc, ep.keep);
-                } else if (EPI == DR_MASK) {
-                    v = (ep.act[(size_t)gm * ep.ldact + gc] > 0.f) ? v * ep.inv_keep : 0.f;
-                } else if (GATE) {
-                    v *= ep.colscale[gc];
-                }
-                Cz[(size_t)gm * ldc + gc] = v;
             }
         }
     }
+    DR_STAMP(1);
+    auto split_b = [&](int j, DrPlanes& p) {
+        dr_split3(f.b[j], p);
+        if constexpr (CS) {                                   // (unconditional: a branch would cut the scheduling region in two)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[j] += f.b[j][e];
+        }
+    };
+    // A refill of the raw registers of A tile i / load group i for group g (its values of the group before have all been split)
+    auto loadA_unit = [&](int i, int g) {
+        if constexpr (A_RC) {
+            const bool ok0 = 32 * g < lim0, ok1 = 32 * g < lim1;
+            ld4(ra, ok0 ? aoff[i] : 0x7ffffff0, 128u * g, &f.a[i][0], 1);
+            ld4(ra, ok1 ? aoff[i] + 16 : 0x7ffffff0, 128u * g, &f.a[i][4], 1);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned so = (32u * g + e) * strideA;
+                if constexpr (VA == 4) ld4(ra, aoff[i], so, &f.a[4 * i][e], 8);
+                else if constexpr (VA == 2) ld2(ra, aoff[i], so, &f.a[2 * i][e], 8);
+                else ld1(ra, aoff[i], so, &f.a[i][e]);
+            }
+        }
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    if (G > 0) {                                              // group 0's A planes and first B tile, exposed once
+#pragma unroll
+        for (int i = 0; i < TM; ++i) dr_split3(f.a[i], pa[i]);
+        if constexpr (!B_PRE) {
+            split_b(0, pb0);
+            if (last_of_unit(0)) loadB(f, unit_of(0), 1);     // (a group beyond the wave's range is all out of range: zeros, no traffic)
+        }
+        loadA(f, 1);
+    }
+    // One group = TN tile regions fenced by sched_barrier(0) (nothing crosses a fence: the loads stay where they are written, next
+    // to the split that frees their registers -- left alone, hipcc sinks every load without a user in the block to its end).  Region j:
+    //   the 6 TM MFMAs of B tile j  ||  the split of B tile j + 1 (tile 0 of the next group in the last region), 1 / TN of the next
+    //   group's A splits (pair by pair), and the refills of whatever raw registers those splits freed.
+    // The A planes alternate between two sets (cur, nxt); pb0 / pb1 alternate by tile parity (TN odd: they swap roles per group,
+    // which is why `par` is a parameter).
+    constexpr int NPA = 4 * TM;                               // A pairs of a group
+    auto body = [&](DrPlanes (&cur)[TM], DrPlanes (&nxt)[TM], int g, auto parc) {
+        constexpr int PAR = decltype(parc)::value;            // parity of (tile index -> pb set) at tile 0 of this group
+        dr_static_for<TN>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            DrPlanes& pc = ((j + PAR) & 1) ? pb1 : pb0;
+            DrPlanes& pn = ((j + PAR) & 1) ? pb0 : pb1;
+            constexpr int jn = (j + 1) % TN;                              // the B tile split in this region (next group's when it wraps)
+            constexpr bool LB = !B_PRE && last_of_unit(jn);               // ... completes a load unit: refill it
+            if constexpr (B_PRE) {
+                // the planes of the tile whose MFMAs the region before issued are free: refill them (tile TN - 1's for THIS group)
+                loadW((j + TN - 1) % TN, j > 0 ? g + 1 : g);
+            } else {
+                split_b(jn, pn);
+                if constexpr (LB) loadB(f, unit_of(jn), j + 1 < TN ? g + 1 : g + 2);
+            }
+            // the next group's A pairs p0 .. p1 - 1
+            constexpr int p0 = j * NPA / TN, p1 = (j + 1) * NPA / TN;
+#pragma unroll
+            for (int p = p0; p < p1; ++p) {
+                const int i = p / 4, tt = p % 4;
+                const float x0 = f.a[i][2 * tt], x1 = f.a[i][2 * tt + 1];
+                const unsigned h = dr_pk_bf16(x0, x1);
+                const float r0 = dr_sub(x0, __uint_as_float(h << 16)), r1 = dr_sub(x1, __uint_as_float(h & 0xffff0000u));
+                const unsigned m = dr_pk_bf16(r0, r1);
+                const float s0 = dr_sub(r0, __uint_as_float(m << 16)), s1 = dr_sub(r1, __uint_as_float(m & 0xffff0000u));
+                nxt[i].h[tt] = h;
+                nxt[i].m[tt] = m;
+                nxt[i].l[tt] = dr_pk_bf16(s0, s1);
+                // raw registers complete: RC per tile, NC per load group of VA tiles
+                if (tt == 3 && (A_RC || (i % VA) == VA - 1)) loadA_unit(A_RC ? i : i / VA, g + 2);
+            }
+            if constexpr (B_PRE) mma(cur, pw[j], j);
+            else mma(cur, pc, j);
+            constexpr int NVAL = (B_PRE ? 0 : 44 + (CS ? 8 : 0)) + 11 * (p1 - p0) + (LB && B_RC ? 2 : 0) + (A_RC ? 4 : 0);
+            constexpr int NM = 6 * TM;
+            constexpr int PER = (NVAL + NM - 1) / NM;
+#pragma unroll
+            for (int k = 0; k < NM; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, PER, 0);
+                if (k < 16) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, TN & 1>;
+    {
+        int g = 0;
+        for (; g + 1 < G; g += 2) {            // pairs: the A planes alternate between pa and pan without a copy
+            body(pa, pan, g, P0{});
+            body(pan, pa, g + 1, P1{});
+        }
+        if (g < G) body(pa, pan, g, P0{});
+    }
+    DR_STAMP(2);
+    float cs2[1] = {0.f};
+    dr_finish<TM, TN, A_RC, B_RC, CS, EPI, false>(acc, cs, cs2, ep, C, ldc, M, N, m0, n0, bm, split, keep_lo, keep_hi, dr_lds);     // (B_PRE: B_RC = true -> plain column blocks)
     DR_STAMP(5);
+}
+
+// W [K][N] (row stride ldw) -> the two pre-split forms the forward and the dgrad product read (B_PRE above):
+//   fwd:   [plane][K / 8][N][8]   (reduction over k: the 8 k of a block side by side)
+//   dgrad: [plane][N / 8][K][8]   (reduction over n)
+// planes h, m, l as in dr_split3; K8 = ceil(K / 8), N8 = ceil(N / 8): the last block of a ragged dimension is padded with zeros.
+// One thread per 16-byte entry of each form; launched behind the layer's optimizer step.
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void dr_wsplit_kernel(const float* __restrict__ W, int ldw, int K, int N, unsigned* __restrict__ fwd, unsigned* __restrict__ dgr) {
+    const int K8 = (K + 7) / 8, N8 = (N + 7) / 8;
+    const int64_t nf = (int64_t)K8 * N, nd = (int64_t)N8 * K;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float x[8];
+    u32x4* out;
+    int64_t plane;
+    if (idx < nf) {                                           // entry (kb, n): W[8 kb + e][n]
+        const int kb = (int)(idx / N), n = (int)(idx - (int64_t)kb * N);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = 8 * kb + e < K ? W[(size_t)(8 * kb + e) * ldw + n] : 0.f;
+        out = reinterpret_cast<u32x4*>(fwd) + idx;
+        plane = nf;
+    } else if (idx < nf + nd) {                               // entry (nb, k): W[k][8 nb + e]
+        const int64_t i2 = idx - nf;
+        const int nb = (int)(i2 / K), k = (int)(i2 - (int64_t)nb * K);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = 8 * nb + e < N ? W[(size_t)k * ldw + 8 * nb + e] : 0.f;
+        out = reinterpret_cast<u32x4*>(dgr) + i2;
+        plane = nd;
+    } else {
+        return;
+    }
+    DrPlanes p;
+    dr_split3(x, p);
+    out[0] = p.h;
+    out[plane] = p.m;
+    out[2 * plane] = p.l;
 }
 
 // LDS bytes of one block: the register dump of the reduction (3 KB per 16x16 tile) or the row-major stage, whichever is larger

@@ -88,12 +88,32 @@ int pack_table_rows(const float* emb, const float* lin, int64_t rows, int K, con
 int pack_unique_grads(const Group* g, const float* glin, const int32_t* upos, float* out, hipStream_t st);
 
 // ---- K6 (gemm.hip)
+// dctr_config.gemm_mode = 1 (gemm_dr3.hip): the product may take the split-precision kernels; w_fwd / w_dgr are the layer's weight
+// pre-split into three bf16 planes in the two forms the forward and the dgrad product read (null: that product stays exact)
+struct GemmOpt {
+    int mode = 0;
+    const unsigned* w_fwd = nullptr;
+    int64_t fwd_plane = 0;
+    const unsigned* w_dgr = nullptr;
+    int64_t dgr_plane = 0;
+};
 int fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N,
-           int relu, float keep, const uint64_t* seed_ptr, uint64_t seed, hipStream_t st, int over = 0);
+           int relu, float keep, const uint64_t* seed_ptr, uint64_t seed, hipStream_t st, int over = 0, const GemmOpt* go = nullptr);
 int fc_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int K, int N,
-                const float* act, int ldact, float keep_prev, hipStream_t st, int over = 0);
+                const float* act, int ldact, float keep_prev, hipStream_t st, int over = 0, const GemmOpt* go = nullptr);
 int fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int lddy, float* dw_part, int64_t dw_stride,
-                            float* db_part, int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, int over = 0);
+                            float* db_part, int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, int over = 0, const GemmOpt* go = nullptr);
+// gemm_dr3.hip: *done = false -> not taken
+bool dr3_shape_ok(int M, int K, int N);
+int64_t dr3_fwd_plane_bytes(int K, int N);
+int64_t dr3_dgr_plane_bytes(int K, int N);
+int dr3_wsplit(const float* w, int ldw, int K, int N, unsigned* fwd, unsigned* dgr, hipStream_t st);
+int dr3_fc_fwd(const float* x, int ldx, const unsigned* wp, int64_t plane, const float* b, float* y, int ldy, int M, int K, int N, int relu, float keep,
+               const uint64_t* seed_ptr, uint64_t seed, hipStream_t st, bool* done);
+int dr3_fc_bwd_data(const float* dy, int lddy, const unsigned* wp, int64_t plane, float* dx, int lddx, int M, int K, int N, const float* act, int ldact,
+                    float keep_prev, hipStream_t st, bool* done);
+int dr3_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int lddy, float* dw_part, int64_t dw_stride, float* db_part,
+                                int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, bool* done);
 // `over` = 1: both operands are followed by GEMM_SLACK_ROWS rows (64 * ld floats) of readable memory, edge tiles may over-read
 constexpr int GEMM_SLACK_ROWS = 64;
 int sum_partials(const float* part, int64_t stride, int splits, int64_t n, float* out, hipStream_t st);

@@ -31,7 +31,7 @@ __global__ void ref_gemm(const float* A, int lda, bool a_rc, const float* B, int
     C[(size_t)m * N + n] = (relu && v < 0) ? 0 : v;
 }
 
-template <int TM, int TN, bool A_RC, bool B_RC, bool CS>
+template <int TM, int TN, bool A_RC, bool B_RC, bool CS, bool P3 = false, bool BP = false>
 void run(const char* name, int M, int N, int K, int splits = 1) {
     std::vector<float> hA((size_t)M * K), hB((size_t)K * N), hb(N);
     srand(1);
@@ -47,14 +47,33 @@ void run(const char* name, int M, int N, int K, int splits = 1) {
     const int nbm = (M + 16 * TM - 1) / (16 * TM), nbn = (N + 16 * TN - 1) / (16 * TN);
     const size_t lds = gemm_dr_lds_bytes<TM, TN>();
     constexpr int EPI = CS ? DR_STORE : DR_BIAS_ACT;
-    auto k = gemm_dr_kernel<TM, TN, A_RC, B_RC, CS, EPI>;
-    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const void* kfn;
+    // pre-split B (weights): both plane forms of the B matrix as stored ([K][N] for fwd, [N][K] for dgrad), the product reads one
+    unsigned *pf = nullptr, *pd = nullptr;
+    const int Wr = B_RC ? N : K, Wc = B_RC ? K : N;          // B as a row-major matrix [Wr][Wc]
+    const int64_t nfe = (int64_t)((Wr + 7) / 8) * Wc, nde = (int64_t)((Wc + 7) / 8) * Wr;
+    if constexpr (BP) {
+        CK(hipMalloc(&pf, nfe * 48)); CK(hipMalloc(&pd, nde * 48));
+        dr_wsplit_kernel<0><<<(unsigned)((nfe + nde + 255) / 256), 256>>>(B, Wc, Wr, Wc, pf, pd);
+        CK(hipDeviceSynchronize());
+    }
+    if constexpr (BP) kfn = (const void*)gemm_dr3_kernel<TM, TN, A_RC, true, CS, EPI, true>;
+    else if constexpr (P3) kfn = (const void*)gemm_dr3_kernel<TM, TN, A_RC, B_RC, CS, EPI>;
+    else kfn = (const void*)gemm_dr_kernel<TM, TN, A_RC, B_RC, CS, EPI>;
+    CK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     DrEpilogue ep{};
     ep.bias = bias; ep.relu = 1; ep.keep = 1.f;
     ep.split_stride = (int64_t)M * N;
     ep.colsum = CS ? cs : nullptr; ep.colsum_stride = N;
-    const int kchunk = ((K + splits - 1) / splits + 15) / 16 * 16;
-    auto launch = [&]() { k<<<dim3(nbm * nbn, splits), 256, lds, 0>>>(A, lda, B, ldb, C, N, M, N, K, kchunk, nbn, ep); };
+    const int kr = P3 ? 32 : 16;
+    const int kchunk = ((K + splits - 1) / splits + kr - 1) / kr * kr;
+    auto launch = [&]() {
+        // fwd (B = W [K][N]): the k-blocked form of W, plane rows of N columns; dgrad (B stored [N][K], reduction over its columns): the
+        // column-blocked form, plane rows of N entries
+        if constexpr (BP) gemm_dr3_kernel<TM, TN, A_RC, true, CS, EPI, true><<<dim3(nbm * nbn, splits), 256, lds, 0>>>(A, lda, (const float*)(B_RC ? pd : pf), N, C, N, M, N, K, kchunk, nbn, ep, (B_RC ? nde : nfe) * 16);
+        else if constexpr (P3) gemm_dr3_kernel<TM, TN, A_RC, B_RC, CS, EPI><<<dim3(nbm * nbn, splits), 256, lds, 0>>>(A, lda, B, ldb, C, N, M, N, K, kchunk, nbn, ep, 0);
+        else gemm_dr_kernel<TM, TN, A_RC, B_RC, CS, EPI><<<dim3(nbm * nbn, splits), 256, lds, 0>>>(A, lda, B, ldb, C, N, M, N, K, kchunk, nbn, ep, DrOuter{});
+    };
     launch();
     CK(hipDeviceSynchronize());
     const bool plain = EPI == DR_STORE;
@@ -85,7 +104,7 @@ void run(const char* name, int M, int N, int K, int splits = 1) {
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / it;
-    printf("%-14s M=%d N=%d K=%d  TM=%d TN=%d splits=%d blocks=%d lds=%zuKB  %.2f us  %.1f TF  (%.3f of 157.3)  maxerr %.2e colsum err %.2e\n", name, M, N, K, TM, TN, splits,
+    printf("%s%-14s M=%d N=%d K=%d  TM=%d TN=%d splits=%d blocks=%d lds=%zuKB  %.2f us  %.1f TF  (%.3f of 157.3)  maxerr %.2e colsum err %.2e\n", BP ? "[bf16x3 W pre-split] " : P3 ? "[bf16x3] " : "[exact]  ", name, M, N, K, TM, TN, splits,
            nbm * nbn * splits, lds / 1024, us, 2.0 * M * N * K / us / 1e6, 2.0 * M * N * K / us / 1e6 / 157.3, worst, worst_cs);
     {
         const int nw = std::min(nbm * nbn * splits, 1024) * 4;
@@ -105,17 +124,17 @@ void run(const char* name, int M, int N, int K, int splits = 1) {
 }
 
 int main(int argc, char** argv) {
+    // exact f32 MFMA and the three-plane bf16 split side by side: time, and max |error| against an fp64 product
     run<2, 13, true, false, false>("fwd L0", 4096, 400, 624);
-    run<2, 13, true, false, false>("fwd K=640", 4096, 400, 640);
-    run<2, 13, true, false, false>("fwd L1", 4096, 400, 400);
-    run<4, 7, true, false, false>("fwd L0", 4096, 400, 624);
-    run<2, 13, true, false, false>("fwd odd", 4001, 397, 613);
-    run<2, 13, true, true, false>("dgrad L1", 4096, 400, 400);
-    run<4, 10, true, true, false>("dgrad L0", 4096, 624, 400);
-    run<2, 20, true, true, false>("dgrad L0", 4096, 624, 400);
-    run<2, 13, false, false, true>("wgrad L0", 624, 400, 4096, 6);
-    run<3, 13, false, false, true>("wgrad L0", 624, 400, 4096, 9);
-    run<2, 13, false, false, true>("wgrad L1", 400, 400, 4096, 9);
-    run<2, 13, false, false, true>("wgrad L1", 400, 400, 4096, 10);
+    run<4, 7, true, false, false, true>("fwd L0", 4096, 400, 624);
+    run<4, 7, true, false, false, true, true>("fwd L0", 4096, 400, 624);
+    run<2, 13, true, false, false, true, true>("fwd L0", 4096, 400, 624);
+    run<2, 7, true, false, false, true, true>("fwd L0", 4096, 400, 624);
+    run<4, 7, true, false, false, true, true>("fwd L1", 4096, 400, 400);
+    run<4, 7, true, false, false, true, true>("fwd odd", 4001, 396, 612);
+    run<4, 10, true, true, false, true, true>("dgrad L0", 4096, 624, 400);
+    run<4, 7, true, true, false, true, true>("dgrad L1", 4096, 400, 400);
+    run<4, 7, false, false, true, true>("wgrad L0", 624, 400, 4096, 6);
+    run<4, 7, false, false, true, true>("wgrad L1", 400, 400, 4096, 9);
     return 0;
 }
