@@ -147,12 +147,23 @@ def _lag_vs_classic(kw, B, steps, dev, tol=1e-6):
         unit = max(float(np.abs(v).max()) / 5e-4, 1e-30) if k.endswith(("/m", "/v")) else 1.0        # (Adam's slots are gradient-sized)
         noise = float(np.abs(v - b[k]).max()) / unit
         err = np.abs(v - c[k]) / unit
-        n_off = int((err > tol).sum())
-        print("%-16s lagging + hint vs classic: max %.2e (two classic runs: %.2e), elements > %.0e: %d of %d" % (k, err.max(), noise, tol, n_off, err.size))
-        # a ReLU decision at |z| ~ 1e-10 that the atomics' noise flips moves one weight-gradient column by ~1e-5 (see the module docstring):
-        # such columns show up between two classic runs just as often -- everything else must agree to 1e-6
-        if float(err.max()) > max(tol, 4 * noise) or (noise <= tol and n_off > 0):
-            bad[k] = (float(err.max()), noise, n_off)
+        off = err > tol
+        n_off = int(off.sum())
+        # A ReLU decision at |z| ~ 1e-9 -- the size of the atomics' noise between ANY two runs -- that falls the other way moves one unit's
+        # weight-gradient column, its bias and the 39 embedding rows of one example by up to ~lr / 10 (module docstring; ~0.7 such events
+        # are expected per pair of 17-step runs at this size).  So: everything agrees to 1e-6 EXCEPT elements confined to at most 3
+        # units' columns (dense variables) / 3 examples' rows (tables), none of them beyond 5e-5.  A wrong replayed step is everywhere.
+        where = ""
+        if n_off:
+            if v.ndim == 2 and v.shape[0] != V:
+                groups = np.unique(np.nonzero(off)[1])                 # units (columns of [in, out])
+            else:
+                groups = np.unique(np.nonzero(off)[0])                 # table rows / vector elements
+            limit = 3 * F if (v.shape[0] == V) else 3
+            where = " in %d %s" % (len(groups), "rows" if v.shape[0] == V or v.ndim == 1 else "columns")
+            if len(groups) > limit or float(err.max()) > 5e-5:
+                bad[k] = (float(err.max()), noise, n_off, len(groups))
+        print("%-16s lagging + hint vs classic: max %.2e (two classic runs: %.2e), elements > %.0e: %d of %d%s" % (k, err.max(), noise, tol, n_off, err.size, where))
     assert not bad, bad
 
 

@@ -112,6 +112,13 @@ struct dctr_engine {
     std::atomic<int> slot_feed_ready = {0};
     hipEvent_t ev_tail = nullptr;   // = the event of the main stream's last fork when the dense backward was enqueued (ring of 64: one step uses ~12)
     hipEvent_t last_fork_ev = nullptr;
+    // The step's LAST cross-stream join, deferred (record_train): the dense side of step t -- the first layer's weight gradient, its
+    // optimizer step, the re-split of its weight -- is awaited by step t + 1 behind its GATHER (forward_rest), not in front of it: the
+    // gather needs the tables and the step state, not the MLP.  x_in alternates between two buffers so that the gather of step t + 1
+    // does not overwrite what the weight gradient of step t is still reading.
+    hipEvent_t ev_dense = nullptr;
+    bool dense_pending = false;
+    float* x_in_alt = nullptr;
     hipEvent_t armed_ev = nullptr;  // stop_arm: the ring event armed for the next launch (engine.hip stop_arm / stop_fork)
     bool have_tail = false;
     // arena

@@ -453,6 +453,7 @@ int build(dctr_engine* E) {
     }
     E->ids = E->slot_ids[0]; E->vals = E->slot_vals[0]; E->labels = E->slot_labels[0];
     DCTR_TRY(dmalloc(&E->x_in, (size_t)(MB + GEMM_SLACK_ROWS) * E->Din_ld));      // (+ slack rows: see gemm.hip `over`)
+    if (!c.use_graph && !E->csr) DCTR_TRY(dmalloc(&E->x_in_alt, (size_t)(MB + GEMM_SLACK_ROWS) * E->Din_ld));     // (engine.h: ev_dense)
     if (E->opnn_fused) {
         std::vector<int> pairs;
         for (int i = 0; i < F; ++i)
@@ -622,7 +623,17 @@ int gather_from(dctr_engine* E, const float* emb, const float* lin, int64_t rows
 }
 
 // after_layer0: called once the first MLP layer has been enqueued (the step uses it to start the id grouping there)
+// the deferred end-of-step join (engine.h ev_dense): whatever reads a dense variable on `st` waits here first
+int join_deferred(dctr_engine* E, hipStream_t st) {
+    if (E->dense_pending) {
+        DCTR_HIP_CHECK(hipStreamWaitEvent(st, E->ev_dense, 0));
+        E->dense_pending = false;
+    }
+    return DCTR_OK;
+}
+
 int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::function<int()>* after_layer0 = nullptr, int after_idx = 0) {
+    DCTR_TRY(join_deferred(E, st));
     const dctr_config& c = E->cfg;
     const int F = E->F, K = E->K, D = E->D;
     if (c.model == DCTR_MODEL_AFM) return afm_forward(E, B, train, st);
@@ -1087,6 +1098,17 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     // ids grouped ahead (dctr_prefetch_ids, during the tail of the previous step)
     const bool pregrouped = E->pre_valid && E->pre_ids == E->ids && E->pre_B == B && E->group_alt != nullptr && !E->cfg.use_graph &&
                             E->pre_gen == E->slot_gen[E->pre_slot].load();     // (the slot still holds what was grouped)
+    if (E->x_in_alt != nullptr && !E->cfg.use_graph) {       // (engine.h ev_dense: the step before may still be reading its x_in on the side stream)
+        const bool e_is_x = E->e == E->x_in;
+        std::swap(E->x_in, E->x_in_alt);
+        if (e_is_x) E->e = E->x_in;
+    }
+    // the next step's state is prepared EARLY in this step, on the grouping stream in front of the record the table step waits for
+    // (it only READS the live state): the step's last join can then be deferred past the next gather (below)
+    static const bool no_state_ahead = getenv("DCTR_NO_STATE_AHEAD") != nullptr;       // A/B knob
+    static const bool defer_off = [] { const char* v = getenv("DCTR_DEFER_JOIN"); return v != nullptr && v[0] == '0'; }();     // A/B knob
+    const bool state_early_ok = !defer_off && !E->cfg.use_graph && !no_state_ahead && sw != st && sg != st && E->cfg.shard_world == 1;
+    bool state_early = false;
     if (E->state_ready) {
         // prepared under the tail of the previous step (below): the two states / scalar sets change roles
         std::swap(E->state, E->state_alt);
@@ -1140,7 +1162,14 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
         if (split_table && !bg_late) DCTR_TRY(step_untouched_rows(E, sg));
         // what the scatter needs from this stream ends here: it waits for THIS record, not for the output layer's optimizer
         // launches that follow on sg (two latency-bound kernels, ~80 us in the step: they used to hold the scatter back ~10 us)
-        if (!bg_late) { DCTR_TRY(record_on(E, sg, &tables_ev)); have_tables_ev = true; }
+        if (!bg_late) {
+            if (state_early_ok) {
+                DCTR_TRY(step_state_next(E->state, E->state_alt, E->scalars_alt, 4 * SUMSQ_SHARDS, sg));
+                E->state_ready = state_early = true;
+            }
+            DCTR_TRY(record_on(E, sg, &tables_ev));
+            have_tables_ev = true;
+        }
         return DCTR_OK;
     };
     const bool have_mlp = !E->mlp.empty() && E->cfg.model != DCTR_MODEL_AFM;
@@ -1222,15 +1251,30 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     else DCTR_TRY(fork(E, sg, st));
     if (split_table) DCTR_TRY(scatter_and_step_tables(E, B, st, nullptr, OPT_PASS_TOUCHED));
     else DCTR_TRY(scatter_and_step_tables(E, B, st, sg));  // the grouping stream is idle by now: linear table beside the embedding table
-    static const bool no_state_ahead = getenv("DCTR_NO_STATE_AHEAD") != nullptr;       // A/B knob
     if (!E->cfg.use_graph && !no_state_ahead && sw != st) {
         // the next step's state (global_step + 1, Adam's lr_t, dropout seed, zeroed loss scalars) into the second StepState, on
         // the weight-gradient stream beside scatter / table step: it only READS the live state, and the join below orders it
+        // (state_early: already enqueued on the grouping stream, in front of the record the table step waited for)
         if (have_sg_done) { DCTR_HIP_CHECK(hipStreamWaitEvent(sw, sg_done_ev, 0)); sg_joined_by_tables_ev = true; }
-        DCTR_TRY(step_state_next(E->state, E->state_alt, E->scalars_alt, 4 * SUMSQ_SHARDS, sw));
-        E->state_ready = true;
+        if (!state_early) {
+            DCTR_TRY(step_state_next(E->state, E->state_alt, E->scalars_alt, 4 * SUMSQ_SHARDS, sw));
+            E->state_ready = true;
+        }
     }
-    DCTR_TRY(fork(E, sw, st));
+    // The step's last join.  What the weight-gradient stream still holds -- the first layer's weight gradient, its optimizer step, the
+    // re-split of its weight (gemm_mode 1) and the joined grouping stream's output-layer steps -- is needed by the next FORWARD
+    // PRODUCTS, not by the next gather (tables: this stream; step state: prepared early): with the state in place the join is
+    // left to the next reader of a dense variable (join_deferred, behind the next step's gather).  A step that reports its loss
+    // reads the l2 sums those optimizer launches add, so it joins here.  A/B knob DCTR_DEFER_JOIN=0.
+    const bool defer = state_early && E->x_in_alt != nullptr && !E->want_loss && !E->opt_pending && fused_opt &&
+                       (!have_tables_ev || sg_joined_by_tables_ev) && E->bn_sync.world <= 1;
+    if (defer) {
+        if (E->ev_dense == nullptr) DCTR_HIP_CHECK(hipEventCreateWithFlags(&E->ev_dense, hipEventDisableTiming | hipEventDisableSystemFence));
+        DCTR_HIP_CHECK(hipEventRecord(E->ev_dense, sw));
+        E->dense_pending = true;
+    } else {
+        DCTR_TRY(fork(E, sw, st));
+    }
     if (have_tables_ev && !sg_joined_by_tables_ev) DCTR_TRY(fork(E, sg, st));      // (the output layer's step on sg: long finished, joined for the next forward)
     if (E->opt_pending) { DCTR_TRY(fork(E, E->s_opt, st)); E->opt_pending = false; }
     return DCTR_OK;
@@ -1454,6 +1498,8 @@ int dctr_destroy(dctr_handle E) {
     group_destroy(E->group);
     afm_free(E);
     for (auto& ev : E->events) if (ev) hipEventDestroy(ev);
+    if (E->ev_dense) hipEventDestroy(E->ev_dense);
+    if (E->x_in_alt) hipFree(E->x_in_alt);
     if (E->s_group) hipStreamDestroy(E->s_group);
     if (E->s_wgrad) hipStreamDestroy(E->s_wgrad);
     if (E->s_opt) hipStreamDestroy(E->s_opt);
