@@ -27,6 +27,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFS = 157.3  # f32-input MFMA peak
+MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF figure includes 2:1 sparsity)
+# gemm_mode "split": one f32 multiply-add = six bf16 plane products on the bf16 pipe -> the matrix-pipe ceiling in f32-equivalent flops
+MFMA_SPLIT_PEAK_TFS = MFMA_BF16_PEAK_TFS / 6.0
+DTYPE = {"exact": "f32", "split": "f32 (3-plane bf16 split, 6 products, f32 accumulate)"}
 
 CONFIGS = {
     "c2": dict(model="deepfm", field_size=39, feature_size=1_000_000, embedding_size=16, batch=4096,
@@ -37,8 +41,8 @@ CONFIGS = {
                name="DeepFM 39 fields, vocab 1e8 row-sharded, emb_dim 32, batch 8192/GPU (65536 at 8 GPUs), MLP 400-400-400 keep 0.5, "
                     "Adam (BASELINE configs[4])"),
 }
-PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.txt")
-STATS_FILE = os.path.join("profiles", "r04_kernel_stats.txt")     # rocprofv3 --kernel-trace --stats of this same command
+PMC_FILE = os.path.join("profiles", "r05_pmc_traffic.txt")
+STATS_FILE = os.path.join("profiles", "r05_kernel_stats.txt")     # rocprofv3 --kernel-trace --stats of this same command
 LIB_FILE = os.path.join("tf_repos_amd", "_lib", "libdeepctr_hip.so")
 
 
@@ -162,6 +166,24 @@ def rocprof_avg_us(kernel_name):
     return None
 
 
+def rocprof_family(prefix):
+    """(total microseconds, calls) per kernel template whose demangled name starts with `prefix`, from the committed rocprofv3 --stats
+    summary of `python bench.py`: {template name: (total_us, calls)}; {} if the summary is absent"""
+    path = os.path.join(ROOT, STATS_FILE)
+    out = {}
+    if not os.path.exists(path):
+        return out
+    for line in open(path):
+        if line.startswith(prefix):
+            name = line[:line.index("(")] if "(" in line else line.split()[0]
+            f = line.split()
+            try:
+                out[name] = (float(f[-3]), int(f[-4]))           # ... calls total_us avg_us pct
+            except (ValueError, IndexError):
+                pass
+    return out
+
+
 def fill_normal_(t, scale, seed):
     """In-place N(0, scale) on the device, in chunks (c5's 12.8 GB table never exists on the host)."""
     import torch
@@ -215,10 +237,12 @@ def hbm_resident_gather(dev, K=16, V=64 * 1024 * 1024, B=4096, F=39, iters=200):
 
 def end_to_end(w, epochs=40, lines=32768 * 12):
     """What a user of the reference runs: `tf.estimator.Estimator(model_fn, ...).train(input_fn)` over a libsvm TEXT file
-    (examples/ctr_estimator.py: the model_fn / input_fn of DeepFM.py:63-221 written against the tensorflow surface of tf_shim) --
-    parse (C parser, threads), batching, H2D through the engine's input slots, train steps, checkpoint save; one short call first so
-    that the timed one does not carry the first-use costs (library load, engine allocation).  examples/s = examples / wall time
-    of the whole train() call.  Never `value`: a reported product-level rate beside it."""
+    (examples/ctr_estimator.py: the model_fn / input_fn of DeepFM.py:63-221 written against the tensorflow surface of tf_shim).
+    One short call first: it pays the first-use costs (library load, engine allocation) AND parses the file's text (C parser,
+    threads), leaving the parsed rows in memory and in a .dctr.npz beside the file -- so the timed multi-epoch call measures batching,
+    H2D through the engine's input slots, the train steps and the checkpoint save, not text parsing; `cold_text_one_epoch` is one
+    epoch of a file seen for the first time, parse included.  examples/s = examples / wall time of the whole train() call.  Never
+    `value`: reported product-level rates beside it."""
     import importlib.util
     import tempfile
     import torch
@@ -254,13 +278,26 @@ def end_to_end(w, epochs=40, lines=32768 * 12):
     dt_short, dt = timed(short), timed(epochs)
     steps, steps_short = n_lines * epochs // B, n_lines * short // B
     per_step = (dt - dt_short) / max(1, steps - steps_short)          # what a step costs once the call's fixed costs are paid
+    # ... and ONE epoch over a file no call has seen (a copy under another name: no parsed copy in memory, no .dctr.npz beside it): the
+    # text really is parsed inside this call -- what TextLineDataset.map(decode_libsvm) pays on every epoch of the reference
     import shutil
+    cold = os.path.join(d, "cold.libsvm")
+    shutil.copyfile(path, cold)
+    t0 = time.perf_counter()
+    est.train(input_fn=lambda: mod.input_fn([cold], num_epochs=1, batch_size=B))
+    torch.cuda.synchronize()
+    dt_cold = time.perf_counter() - t0
     shutil.rmtree(d, ignore_errors=True)
     return {"examples_per_sec": round(n_lines * epochs / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps, "wall_s": round(dt, 3),
             "steady_examples_per_sec": round(B / per_step, 1), "steady_ms_per_step": round(1e3 * per_step, 4),
             "fixed_cost_s": round(dt - per_step * steps, 3),
-            "what": "tf.estimator.Estimator.train (tf_shim) over a %d-line libsvm text file x %d epochs, batch %d: text parse + batching + H2D into the "
-                    "engine's input slots + train steps + checkpoint save (204 MB of variables and Adam slots); examples_per_sec = wall time of the "
+            "cold_text_one_epoch": {"examples_per_sec": round(n_lines / dt_cold, 1), "wall_s": round(dt_cold, 3), "steps": n_lines // B,
+                                    "what": "one epoch of a libsvm file seen for the first time: the text IS parsed in the call (C parser, thread team), "
+                                            "plus batching, H2D, the steps and the call's fixed costs (graph trace, lowering, 204 MB checkpoint)"},
+            "what": "tf.estimator.Estimator.train (tf_shim) over a %d-line libsvm text file x %d epochs, batch %d.  The file's text is parsed ONCE, by "
+                    "the short call before the timed one (which also writes the .dctr.npz binary cache beside it): the timed call loads the parsed "
+                    "rows and replays its epochs from memory -- batching + H2D into the engine's input slots + train steps + checkpoint save (204 MB "
+                    "of variables and Adam slots), NO text parse per epoch (cold_text_one_epoch has that).  examples_per_sec = wall time of the "
                     "whole call, steady_* = the slope between a %d-epoch and a %d-epoch call (the per-call fixed costs -- graph trace, lowering, "
                     "checkpoint -- cancel)" % (n_lines, epochs, B, short, epochs)}
 
@@ -286,6 +323,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=200)
     ap.add_argument("--uniform-ids", action="store_true", help="uniform ids instead of Zipf (cache-worst case)")
     ap.add_argument("--feature-size", type=int, default=0, help="override the config's vocabulary (tools/c5_shard_projection.py: ONE shard of c5's table, V / 8 rows, on one GPU)")
+    ap.add_argument("--gemm-mode", default=os.environ.get("DCTR_BENCH_GEMM_MODE", "split"), choices=["split", "exact"],
+                    help="arithmetic of the MLP products (dctr_config.gemm_mode): split = three bf16 planes, six products, f32 accumulate (f32-equivalent, "
+                         "the whole GPU suite passes in it at the exact mode's tolerances); exact = f32-input MFMA.  The line reports the other mode's step time too")
     ap.add_argument("--sweep-period", type=int, default=0, help="dense_exact + Adam: period of the time-blocked table sweep (0 = library default, 1 = classic: every row every step)")
     args = ap.parse_args()
 
@@ -312,6 +352,7 @@ def main():
     big = V * (K + 1) * 4 > (2 << 30)           # tables that must be initialised on the device
 
     sharded = world > 1 or bool(os.environ.get("DCTR_FORCE_SHARDED"))     # the env var exercises the RCCL path on one GPU
+    os.environ["DCTR_GEMM_MODE"] = args.gemm_mode        # (every engine of this process, the row-sharded trainer's included)
     if sharded:
         import torch.distributed as dist
         from tf_repos_amd.distributed import ShardedTrainer
@@ -343,7 +384,7 @@ def main():
         eng = Engine(EngineConfig(model=w["model"], field_size=F, feature_size=V, embedding_size=K, deep_layers=w["deep_layers"],
                                   dropout=w["dropout"], l2_reg=w["l2_reg"], learning_rate=w["learning_rate"], optimizer=w["optimizer"],
                                   table_mode=args.table_mode, max_batch=B, seed=1, table_sweep_period=args.sweep_period,
-                                  use_graph=os.environ.get("DCTR_USE_GRAPH", "0") == "1"))
+                                  gemm_mode=args.gemm_mode, use_graph=os.environ.get("DCTR_USE_GRAPH", "0") == "1"))
         rng = np.random.default_rng(1)
         for name, shp in eng.param_shapes.items():
             if big and name in ("emb", "linear"):
@@ -413,6 +454,9 @@ def main():
         dist.destroy_process_group()
         sys.exit(0 if ok else 1)
 
+    # (the in-step timer's event pool is created by its first enable: here, not between the warm-up and the timed region, where the
+    #  milliseconds it takes would leave the GPU idle long enough to drop its clocks)
+    eng.step_timer(1 if os.environ.get("DCTR_BENCH_TIMER") == "1" else 2)
     for s in range(args.warmup):
         step(*batches[s % nb], batches[(s + 1) % nb][0])
     barrier()
@@ -430,7 +474,21 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     in_ms, in_n = eng.step_timer(False)
-    in_layers = [eng.step_timer_layer(i) for i in range(len(w["deep_layers"]))] if timer_mode == 2 else []
+    nl = len(w["deep_layers"])
+    in_layers = [eng.step_timer_layer(i) for i in range(3 * nl)] if timer_mode == 2 else []      # forward, dgrad, wgrad of every layer
+    # the run's fixed part: a second, longer block of the same loop gives the slope (steady state) and, by difference, what the
+    # closing flush of the lagging rows costs -- the driver's 20-step number and a 200-step number then agree by construction
+    steady_ms, flush_ms = None, None
+    if not sharded:
+        n2 = max(5 * args.steps, 200)
+        t1 = time.perf_counter()
+        for s in range(n2):
+            step(*batches[(args.warmup + s) % nb], batches[(args.warmup + s + 1) % nb][0])
+        eng.sync_tables()
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t1
+        steady_ms = 1e3 * (el2 - el) / (n2 - args.steps)
+        flush_ms = 1e3 * el - args.steps * steady_ms
     if sharded:
         import torch.distributed as dist
         t = torch.tensor([el], device=dev, dtype=torch.float64)
@@ -444,14 +502,20 @@ def main():
             "unit": "examples/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * el / args.steps, 4), "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 4),
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic Criteo-shaped (Zipf categorical ids), random-init weights",
+            "vs_baseline": None, "dtype": DTYPE[args.gemm_mode], "data": "synthetic Criteo-shaped (Zipf categorical ids), random-init weights",
             "config": {"workload": w["name"], "config": args.config, "global_batch": B * world, "table_mode": args.table_mode,
                        "parallelism": "single GPU" if world == 1 else "row-sharded tables (id %% %d) + data-parallel dense" % world,
                        "driver": ("single-GPU engine" if not sharded else (driver_note or (args.driver + (" (C++ step driver over RCCL)" if args.driver == "native" else " (torch.distributed orchestration)")))),
-                       "ids": "uniform" if args.uniform_ids else "zipf",
+                       "ids": "uniform" if args.uniform_ids else "zipf", "gemm_mode": args.gemm_mode,
                        "next_batch_hint": bool(not sharded and os.environ.get("DCTR_BENCH_PREFETCH", "1") == "1"),
                        "table_sweep_period": (args.sweep_period or int(os.environ.get("DCTR_SWEEP_PERIOD", "8"))) if (args.table_mode == "dense_exact" and (not sharded or args.driver == "native")) else 1},
         }
+        if steady_ms is not None:
+            # ms_per_step = (steps x steady_ms_per_step + final_flush_ms) / steps: the timed region closes with the flush that brings every
+            # lagging table row to the present (its deferred updates are paid inside the region)
+            out["steady_ms_per_step"] = round(steady_ms, 4)
+            out["final_flush_ms"] = round(flush_ms, 4)
+            out["steady_examples_per_sec"] = round(B * world / (steady_ms * 1e-3), 1)
         # ---- per-stage timing (hipEvents around a graph of back-to-back launches, on torch's current stream)
         e = eng
         rows = (V + world - 1) // world                            # rows of this rank's table shard
@@ -496,48 +560,100 @@ def main():
             k["frac"] = round(k["achieved"] / k["peak"], 4)
             k["achieved"] = round(k["achieved"], 2)
             k["ms"] = round(k["ms"], 5)
-        # the dominant kernel family of the step is the MLP GEMM (half of the kernel time; the dense-exact table pass runs as a
-        # background kernel under the GEMMs).  `roofline` is the first layer's forward GEMM (B x F*K x 400) AS IT RUNS IN THE
-        # TIMED STEPS: hipEvents on the step's stream around that launch (dctr_step_timer); `kernels` holds the same kernels
-        # timed alone, back to back.
-        dom = "mlp0_fwd_gemm"
-        r = dict(kernels[dom])
-        gemm_name = "void dctr::gemm_dr_kernel<2, 13, true, false, false, 1, 0>" if os.environ.get("DCTR_GEMM", "fdw").find("f") >= 0 and os.environ.get("DCTR_GEMM") != "lds" else "void dctr::gemm_f32_mfma<true, true, 1>"
-        r["kernel"] = "%s (%s, layer 0: %dx%dx%d)" % (dom, gemm_name.replace("void dctr::", ""), B, F * K, w["deep_layers"][0])
-        dims_ = [F * K] + list(w["deep_layers"])
-        layer_flops = [2.0 * B * dims_[i] * dims_[i + 1] for i in range(len(dims_) - 1)]
-        if in_n > 0 and timer_mode == 2 and in_layers and all(n > 0 for _ms, n in in_layers):
-            # the kernel SYMBOL's launches in the timed steps -- the three forward layers share it -- each by its own dispatch events:
-            # mean flops / mean duration, the figure rocprofv3's per-kernel average of the same command is comparable with
-            r["kernel"] = "mlp forward GEMMs (%s; layers %s)" % (gemm_name.replace("void dctr::", ""), ", ".join("%dx%dx%d" % (B, dims_[i], dims_[i + 1]) for i in range(len(dims_) - 1)))
-            r["ms_alone_layer0"] = r["ms"]
-            r["ms"] = round(in_ms, 5)
-            r["achieved"] = round(sum(layer_flops) / len(layer_flops) / in_ms / 1e9, 2)
-            r["frac"] = round(r["achieved"] / r["peak"], 4)
-            r["launches_timed"] = in_n
-            r["method"] = "hipExtLaunchKernel start/stop events on each timed dispatch (every 32nd step), mean flops / mean duration over the symbol's launches"
-            r["layers"] = [{"shape": "%dx%dx%d" % (B, dims_[i], dims_[i + 1]), "ms": round(ms_i, 5), "launches": n_i,
-                            "frac": round(layer_flops[i] / ms_i / 1e9 / r["peak"], 4)} for i, (ms_i, n_i) in enumerate(in_layers)]
+        # The dominant kernel family of the step is the MLP GEMM: nine products per step (forward, dgrad, weight gradient of three
+        # layers).  `roofline` is the kernel TEMPLATE with the most time in the timed steps -- every product's launch carries its own
+        # start / stop events (dctr_step_timer mode 2, every 32nd step) -- and `roofline.family` all nine; `kernels` holds layer 0's
+        # products timed alone, back to back.
+        split = args.gemm_mode == "split"
+        peak = MFMA_SPLIT_PEAK_TFS if split else MFMA_F32_PEAK_TFS
+        for kn in ("mlp0_fwd_gemm", "mlp0_dgrad_gemm", "mlp0_wgrad_gemm"):
+            kernels[kn]["peak"] = round(peak, 1)
+            kernels[kn]["frac"] = round(kernels[kn]["achieved"] / peak, 4)
+            kernels[kn]["frac_of_f32_mfma_peak"] = round(kernels[kn]["achieved"] / MFMA_F32_PEAK_TFS, 4)
+        dims = [F * K] + list(w["deep_layers"])
+        layer_flops = [2.0 * B * dims[i] * dims[i + 1] for i in range(nl)]
+
+        def template(kind, i):          # (the names c2's shapes take; other configs: labels only)
+            if split:
+                return {"fwd": "void dctr::gemm_dr3_kernel<4, 7, true, true, false, 1, true>",
+                        "dgrad": "void dctr::gemm_dr3_kernel<4, 7, true, true, false, 2, true>" if i > 0 else "void dctr::gemm_dr3_kernel<4, 10, true, true, false, 0, true>",
+                        "wgrad": "void dctr::gemm_dr3_kernel<4, 7, false, false, true, 0, false>"}[kind]
+            return {"fwd": "void dctr::gemm_dr_kernel<2, 13, true, false, false, 1, 0>",
+                    "dgrad": "void dctr::gemm_dr_kernel<2, 13, true, true, false, 2, 0>" if i > 0 else "void dctr::gemm_dr_kernel<4, 10, true, true, false, 0, 0>",
+                    "wgrad": "void dctr::gemm_dr_kernel<2, 13, false, false, true, 0, 0>"}[kind]
+
+        def product_bytes(kind, i):     # what one launch must move: both operands once, the result once (split: the weight as 3 bf16 planes)
+            wb = 6 if split else 4
+            if kind == "wgrad":
+                return 4 * B * dims[i] + 4 * B * dims[i + 1] + 4 * dims[i] * dims[i + 1]
+            return 4 * B * dims[i] + wb * dims[i] * dims[i + 1] + 4 * B * dims[i + 1]
+        products = []
+        if in_n > 0 and timer_mode == 2 and len(in_layers) == 3 * nl:
+            for ki, kind in enumerate(("fwd", "dgrad", "wgrad")):
+                for i in range(nl):
+                    ms_i, n_i = in_layers[ki * nl + i]
+                    if n_i > 0:
+                        products.append({"product": "%s layer %d" % (kind, i), "shape": "%dx%dx%d" % (B, dims[i], dims[i + 1]), "template": template(kind, i).replace("void dctr::", ""),
+                                         "ms": round(ms_i, 5), "launches": n_i, "flops": layer_flops[i], "bytes": product_bytes(kind, i)})
+        r = dict(kernels["mlp0_fwd_gemm"])
+        gemm_name = template("fwd", 1)
+        r["ms_alone_layer0_fwd"] = r.pop("ms")
+        if products:
+            groups = {}
+            for pr in products:
+                groups.setdefault(pr["template"], []).append(pr)
+            # (per launch-weighted: sum_i n_i flops_i / sum_i n_i ms_i -- the launch counts of the products may differ when the event pool fills)
+            def agg(prs):
+                nn = sum(p_["launches"] for p_ in prs)
+                tf = sum(p_["launches"] * p_["flops"] for p_ in prs) / sum(p_["launches"] * p_["ms"] for p_ in prs) / 1e9
+                return nn, tf, sum(p_["ms"] for p_ in prs), sum(p_["launches"] * p_["ms"] for p_ in prs) / nn
+            dom_t = max(groups, key=lambda t: sum(p_["ms"] for p_ in groups[t]))
+            nn, tf, ms_step, ms_mean = agg(groups[dom_t])
+            gemm_name = "void dctr::" + dom_t
+            r.update({"kernel": "%s -- %s: the template with the most time in the timed steps (%.1f us of the nine products' %.1f us per step)" % (
+                          dom_t, ", ".join(p_["product"] for p_ in groups[dom_t]), 1e3 * ms_step, 1e3 * sum(p_["ms"] for p_ in products)),
+                      "ms": round(ms_mean, 5), "achieved": round(tf, 2), "peak": round(peak, 1), "frac": round(tf / peak, 4),
+                      "frac_of_f32_mfma_peak": round(tf / MFMA_F32_PEAK_TFS, 4), "launches_timed": nn,
+                      "method": "hipExtLaunchKernel start/stop events on each timed dispatch (every 32nd step), launch-weighted flops / duration over the template's launches",
+                      "algorithmic_bytes": int(sum(p_["bytes"] for p_ in groups[dom_t]) / len(groups[dom_t]))})
+            an, atf, ams, _ = agg(products)
+            r["family"] = {"what": "all nine MLP products of the step (%s)" % ("gemm_dr3_kernel: split precision" if split else "gemm_dr_kernel: exact f32 MFMA"),
+                           "achieved": round(atf, 2), "peak": round(peak, 1), "frac": round(atf / peak, 4), "frac_of_f32_mfma_peak": round(atf / MFMA_F32_PEAK_TFS, 4),
+                           "us_per_step_sum_of_dispatches": round(1e3 * ams, 2), "launches_timed": an,
+                           "by_template": {t: {"products": [p_["product"] for p_ in g], "us_per_step": round(1e3 * sum(p_["ms"] for p_ in g), 2),
+                                               "achieved": round(agg(g)[1], 2), "frac": round(agg(g)[1] / peak, 4)} for t, g in groups.items()}}
+            r["layers"] = [{k_: v_ for k_, v_ in pr.items() if k_ not in ("flops", "bytes")} | {"frac": round(pr["flops"] / pr["ms"] / 1e9 / peak, 4)} for pr in products]
+            if split:
+                r["peak_note"] = ("f32-equivalent flops against the dense bf16 MFMA peak / 6 (%.0f / 6 = %.1f TF): one f32 multiply-add is six bf16 plane "
+                                  "products; frac_of_f32_mfma_peak is the same rate against the f32-input MFMA's %.1f TF" % (MFMA_BF16_PEAK_TFS, peak, MFMA_F32_PEAK_TFS))
         elif in_n > 0:
-            r["ms_alone"] = r["ms"]
+            r["kernel"] = "mlp0_fwd_gemm (layer 0: %dx%dx%d)" % (B, F * K, w["deep_layers"][0])
             r["ms"] = round(in_ms, 5)
             r["achieved"] = round(mlp0_flops / in_ms / 1e9, 2)
-            r["frac"] = round(r["achieved"] / r["peak"], 4)
+            r["frac"] = round(r["achieved"] / peak, 4)
             r["launches_timed"] = in_n
             r["method"] = "two hipEvent records around layer 0's launch (a bracket: holds two barrier packets)"
-        # HBM bytes per launch of exactly this kernel (PMC passes of tools/profile_round.sh, committed under profiles/)
+            r["algorithmic_bytes"] = product_bytes("fwd", 0)
+        else:
+            r["kernel"] = "mlp0_fwd_gemm alone (no in-step timer on this path)"
+            r["ms"] = r["ms_alone_layer0_fwd"]
+            r["algorithmic_bytes"] = product_bytes("fwd", 0)
+        # HBM bytes per launch of exactly this kernel template (PMC passes of tools/profile_round.sh, committed under profiles/)
         r["traffic"] = pmc_traffic_bytes(gemm_name) if (not sharded and args.config == "c2") else None
-        # the PMC mean covers EVERY launch of this kernel template -- all three forward layers -- so the like-for-like algorithmic
-        # figure is their mean (X + W + Y of each layer), not layer 0's
-        dims = [F * K] + list(w["deep_layers"])
-        r["algorithmic_bytes_mean_of_the_launches_in_traffic"] = int(sum(4 * (B * dims[i] + dims[i] * dims[i + 1] + B * dims[i + 1]) for i in range(len(dims) - 1)) / (len(dims) - 1))
-        r["algorithmic_bytes_layer0"] = int(4 * (B * F * K + F * K * w["deep_layers"][0] + B * w["deep_layers"][0]))
-        r["algorithmic_bytes"] = r["algorithmic_bytes_mean_of_the_launches_in_traffic"] if "layers" in r else r["algorithmic_bytes_layer0"]
-        us = rocprof_avg_us(gemm_name) if (not sharded and args.config == "c2") else None
-        if us:      # the same launch by rocprofv3's kernel timestamps (no barrier packets inside the bracket): the optimistic reading
-            mean_flops = sum(2.0 * B * dims[i] * dims[i + 1] for i in range(len(dims) - 1)) / (len(dims) - 1)
-            r["frac_rocprof"] = round(mean_flops / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFS, 4)      # mean flops / mean duration of the three forward layers
-            r["rocprof_avg_us_all_layers"] = us
+        fam = rocprof_family("void dctr::gemm_dr3_kernel" if split else "void dctr::gemm_dr_kernel") if (not sharded and args.config == "c2") else {}
+        if fam and products:
+            # the same figures by rocprofv3's kernel timestamps of this command (its launches include the ~100 alone-timed ones of layer 0)
+            mean_flops = {}
+            for pr in products:
+                mean_flops.setdefault("void dctr::" + pr["template"], []).append(pr["flops"])
+            tot_us = sum(us_ for nm, (us_, _c) in fam.items() if nm in mean_flops)
+            tot_fl = sum(c_ * sum(mean_flops[nm]) / len(mean_flops[nm]) for nm, (_u, c_) in fam.items() if nm in mean_flops)
+            if tot_us > 0:
+                r["family"]["frac_rocprof"] = round(tot_fl / (tot_us * 1e-6) / 1e12 / peak, 4)
+            if gemm_name in fam and fam[gemm_name][1] > 0:
+                us = fam[gemm_name][0] / fam[gemm_name][1]
+                r["rocprof_avg_us"] = round(us, 2)
+                r["frac_rocprof"] = round(sum(mean_flops[gemm_name]) / len(mean_flops[gemm_name]) / (us * 1e-6) / 1e12 / peak, 4)
         stale = [f for f in (PMC_FILE, STATS_FILE) if profile_is_stale(f)]
         if stale:
             r["profile_warning"] = "older than the built library, re-run tools/profile_round.sh: " + ", ".join(stale)
@@ -553,15 +669,21 @@ def main():
                   "us_in_step": sweep_us, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "achieved": round(sweep_bytes / sweep_us / 1e3, 2) if sweep_us else None,
                   "frac": round(sweep_bytes / sweep_us / 1e3 / HBM_PEAK_GBS, 4) if sweep_us else None,
-                  "note": "ALU-bound, not HBM-bound: every row replays up to %d Adam steps in registers (V (K+1) element-updates per step however "
-                          "scheduled); it runs under the backward GEMMs.  The classic sweep it replaces: kernels.opt_table_dense_adam_classic" % period}
+                  "element_updates_per_launch": int(rows * (K + 1)),
+                  "alu_floor_us": round(rows * (K + 1) * 23.0 / (256 * 128) / 2.1e3, 2),
+                  "note": "NOT an HBM-bound kernel (frac is its traffic against HBM for reference only): every swept row replays %d Adam steps in "
+                          "registers -- V (K+1) element-updates per launch however scheduled, ~15 VALU + 2 quarter-rate (sqrt, rcp) ops each = "
+                          "alu_floor_us at full VALU issue on 256 CUs; the measured time above that floor is the dependent chain of each update "
+                          "(4 rows interleaved per lane under a 96-VGPR cap so that it shares SIMDs with the backward GEMMs it runs under).  The "
+                          "classic sweep it replaces: kernels.opt_table_dense_adam_classic" % period}
         else:
             hk = dict(kernels["opt_table_dense_adam_classic"])
             hk["traffic"] = pmc_traffic_bytes("void dctr::opt_table_kernel<0, 4, true>") if (not sharded and args.config == "c2") else None
         r["hbm_kernel"] = hk
         # the whole step against the matrix pipes: forward + dgrad + wgrad flops of the MLP over ms_per_step
         step_flops = 3 * sum(2.0 * B * dims[i] * dims[i + 1] for i in range(len(dims) - 1))
-        r["step_mfma_frac"] = round(step_flops / (out["ms_per_step"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFS, 4)
+        r["step_mfma_frac"] = round(step_flops / (out["ms_per_step"] * 1e-3) / 1e12 / peak, 4)
+        r["step_mfma_frac_of_f32_peak"] = round(step_flops / (out["ms_per_step"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFS, 4)
         r["step_gemm_gflop"] = round(step_flops / 1e9, 3)
         r["traffic_source"] = PMC_FILE + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch of the exactly named kernel (gfx950 FETCH_SIZE counts 1/2 of 16-B/lane streams; MI355X_MICROARCH.md HBM section)"
         out["roofline"] = r
@@ -588,6 +710,33 @@ def main():
                 ref.prefetch_ids(rb[(s_ + 1) % nb][0])
             torch.cuda.synchronize()
             out["classic_sweep_ms_per_step"] = round(1e3 * (time.perf_counter() - tr0) / 200, 4)
+            ref.close()
+        if not sharded and not big and not args.no_classic_reference:
+            # the same loop in the OTHER arithmetic of the MLP products (dctr_config.gemm_mode), for reference beside `value`
+            other = "exact" if args.gemm_mode == "split" else "split"
+            os.environ["DCTR_GEMM_MODE"] = other
+            ref = Engine(EngineConfig(model=w["model"], field_size=F, feature_size=V, embedding_size=K, deep_layers=w["deep_layers"],
+                                      dropout=w["dropout"], l2_reg=w["l2_reg"], learning_rate=w["learning_rate"], optimizer=w["optimizer"],
+                                      table_mode=args.table_mode, max_batch=B, seed=1, table_sweep_period=args.sweep_period, gemm_mode=other))
+            os.environ["DCTR_GEMM_MODE"] = args.gemm_mode
+            r1 = np.random.default_rng(1)
+            for name, shp in ref.param_shapes.items():
+                ref.set_param(name, r1.normal(0, 0.01, size=shp).astype(np.float32))
+            rb = []
+            for i in range(nb):
+                si, sv, sl = ref.input_slot(i)
+                si[:B].copy_(batches[i][0]); sv[:B].copy_(batches[i][1]); sl[:B].copy_(batches[i][2])
+                rb.append((si[:B], sv[:B], sl[:B]))
+            for s_ in range(20 + 200):
+                if s_ == 20:
+                    torch.cuda.synchronize()
+                    tr0 = time.perf_counter()
+                ref.train_step(*rb[s_ % nb], want_loss=False)
+                ref.prefetch_ids(rb[(s_ + 1) % nb][0])
+            ref.sync_tables()
+            torch.cuda.synchronize()
+            out["gemm_mode_%s_ms_per_step" % other] = round(1e3 * (time.perf_counter() - tr0) / 200, 4)
+            out["gemm_mode_%s_dtype" % other] = DTYPE[other]
             ref.close()
         if not sharded and not big and not args.no_end_to_end:
             try:

@@ -606,7 +606,8 @@ int dctr_time_kernel(dctr_handle h, const char* kernel, int iters, float* h_ms_p
 /* in-step duration of the MLP's forward GEMMs, by hipEvents on the step's stream, every 32nd train step.  enable=1: a pair of records
  * around the FIRST layer's launch (a bracket: two barrier packets sit inside the interval); enable=2: every forward layer's launch
  * carries its own start / stop events (the dispatch alone -- what rocprofv3's kernel trace reports); enable=0 stops and returns the
- * average milliseconds over all timed launches and their number.  dctr_step_timer_layer: the same for one layer, after the stop. */
+ * average milliseconds over all timed launches and their number.  dctr_step_timer_layer: the same for one product, after the stop:
+ * layer = i the forward product of MLP layer i, n_layers + i its dgrad, 2 n_layers + i its weight gradient (mode 2 times all three). */
 int dctr_step_timer(dctr_handle h, int enable, float* h_avg_ms, int* h_count);
 int dctr_step_timer_layer(dctr_handle h, int layer, float* h_avg_ms, int* h_count);
 /* measured HBM roofline: GB/s (read + write) of a streaming float4 copy of `nbytes` (use >> 256 MB so the Infinity Cache does

@@ -575,13 +575,18 @@ int wplanes_ensure(dctr_engine* E, Fc& fc, hipStream_t st) {
 }
 // the parameters [p_first, p_last] were just written on `st` (an optimizer launch): their layers' planes follow on the same stream
 int wplanes_written(dctr_engine* E, int p_first, int p_last, hipStream_t st) {
+    WsplitJob jobs[8];
+    int n = 0;
     for (std::vector<Fc>* tower : {&E->mlp, &E->mlp2})
         for (Fc& fc : *tower)
             if (fc.w >= p_first && fc.w <= p_last) {
                 fc.w_epoch++;
-                DCTR_TRY(wplanes_refresh(E, fc, st));
+                if (fc.wp_fwd == nullptr) continue;
+                if (n == 8) { DCTR_TRY(dr3_wsplit_multi(jobs, n, st)); n = 0; }          // (one launch per 8 layers)
+                jobs[n++] = WsplitJob{E->pp(fc.w), fc.out, fc.in, fc.out, fc.wp_fwd, fc.wp_dgr};
+                fc.p_epoch = fc.w_epoch;
             }
-    return DCTR_OK;
+    return dr3_wsplit_multi(jobs, n, st);
 }
 // the host wrote parameters: the next product that reads a layer's planes refreshes them first
 void wplanes_invalidate(dctr_engine* E) {
@@ -838,6 +843,12 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
     // chain, beside the table step, with no per-layer record on st; the others stay beside their layer's dgrad
     static const int late_layers_env = getenv("DCTR_WGRAD_LATE_LAYERS") ? atoi(getenv("DCTR_WGRAD_LATE_LAYERS")) : 0;
     const int late_layers = (!wgrad_late && fused_opt && sw != st && !E->opnn_fused && !E->bn) ? std::min(late_layers_env, nl) : 0;
+    // The MLP's optimizer steps as ONE launch behind the last weight gradient (and one re-split of the weights, gemm_mode 1) instead of
+    // each layer's in front of the weight gradient of the layer below: with the step's last join deferred past the next gather
+    // (record_train) the end of this stream is off the critical path, and two to four small launches leave the chain of full-chip
+    // products.  A/B knob DCTR_OPT_TAIL=0 (the round-2 placement).  The layers' parameters are neighbours in the arena.
+    static const bool opt_tail_off = [] { const char* v = getenv("DCTR_OPT_TAIL"); return v != nullptr && v[0] == '0'; }();
+    const bool opt_tail = !opt_tail_off && fused_opt && sw != st && !E->cfg.use_graph && !wgrad_late && late_layers == 0 && E->cfg.shard_world == 1;
     for (int i = nl - 1; i >= 0; --i) {
         Fc& fc = E->mlp[i];
         DCTR_TRY(wplanes_ensure(E, fc, st));
@@ -859,7 +870,7 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
             // layer's weight gradient (measured at c2: 0.3052 vs 0.3062 ms/step -- nothing; every kernel here fills the chip, the
             // step is the sum of their solo times whatever the order)
             static const bool opt_side = getenv("DCTR_OPT_SIDE") != nullptr;
-            if (fused_opt && i < nl - 1) {
+            if (fused_opt && i < nl - 1 && !opt_tail) {
                 if (opt_side && E->s_opt != nullptr && sw != st) {
                     DCTR_TRY(fork(E, sw, E->s_opt));
                     DCTR_TRY(opt_dense_range(E, E->mlp[i + 1].w, E->mlp[i + 1].last, E->s_opt));
@@ -868,8 +879,15 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
                     DCTR_TRY(opt_dense_range(E, E->mlp[i + 1].w, E->mlp[i + 1].last, sw));
                 }
             }
+            // (dctr_step_timer mode 2: the backward products carry their own dispatch events too -- layer ids nl + i dgrad, 2 nl + i wgrad)
+            const bool tw = E->timer_step && E->timer_mode == 2 && E->timer_n + 2 <= E->timer_ev.size() && !E->bn && !(i == 0 && E->opnn_fused);
+            if (tw) arm_timer_events(E->timer_ev[E->timer_n], E->timer_ev[E->timer_n + 1]);
             DCTR_TRY(fc_bwd_weights_partials(x, ldx, E->dh[i], fc.out, E->part(fc.w), w.padded, E->part(fc.b), b.padded, B,
                                              (i == 0 && E->opnn_fused) ? D : fc.in, fc.out, fc.splits, sw, 1, &go));
+            if (tw) {
+                if (timer_events_pending()) disarm_timer_events();
+                else { E->timer_layer.push_back(2 * nl + i); E->timer_n += 2; }
+            }
             if (i == 0 && E->opnn_fused)
                 DCTR_TRY(opnn_outer_wgrad(E->e, E->e_ld, B, F, K, E->opnn_pairs, E->dh[0], fc.out, fc.out, E->part(fc.w) + (size_t)D * fc.out, sw));
         }
@@ -878,7 +896,9 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
         // when an interaction backward follows the last dgrad)
         const bool tail_plain = c.model == DCTR_MODEL_DEEPFM || c.model == DCTR_MODEL_FNN || c.model == DCTR_MODEL_WIDE || c.model == DCTR_MODEL_DEEP ||
                                 c.model == DCTR_MODEL_WND;
-        if (!wgrad_late && late_layers == 0 && !E->bn && !E->opnn_fused && sw != st && (i > 0 || (fused_opt && tail_plain))) stop_arm(E);
+        const bool td = E->timer_step && E->timer_mode == 2 && E->timer_n + 2 <= E->timer_ev.size() && !E->bn && !E->opnn_fused;
+        if (td) arm_timer_events(E->timer_ev[E->timer_n], E->timer_ev[E->timer_n + 1]);       // (a launch has ONE stop event: a timed dgrad does not carry the fork's record)
+        else if (!wgrad_late && late_layers == 0 && !E->bn && !E->opnn_fused && sw != st && (i > 0 || (fused_opt && tail_plain))) stop_arm(E);
         if (i > 0)
             DCTR_TRY(fc_bwd_data(E->dh[i], fc.out, E->pp(fc.w), E->dh[i - 1], E->mlp[i - 1].out, B, fc.in, fc.out,
                                  E->bn ? nullptr : E->h[i - 1], E->mlp[i - 1].out, E->bn ? 1.f : E->mlp[i - 1].keep, st, 1, &go));
@@ -887,6 +907,10 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
             DCTR_TRY(opnn_outer_dgrad(E, B, st));
         } else
             DCTR_TRY(fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w), E->dx_in, E->Din_ld, B, fc.in, fc.out, nullptr, 0, 1.f, st, 1, &go));
+        if (td) {
+            if (timer_events_pending()) disarm_timer_events();
+            else { E->timer_layer.push_back(nl + i); E->timer_n += 2; }
+        }
     }
     if (wgrad_late) {
         // (experiment) the weight gradients AFTER the whole dgrad chain, beside the interaction backward, the scatter and the
@@ -959,7 +983,7 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
             DCTR_TRY(fc_bwd_weights_partials(x, ldx, E->dh[i], fc.out, E->part(fc.w), E->params[fc.w].padded, E->part(fc.b), E->params[fc.b].padded, B,
                                              fc.in, fc.out, fc.splits, sw, 1));
         }
-        if (!wgrad_late) DCTR_TRY(opt_dense_range(E, E->mlp[0].w, E->mlp[0].last, sw));
+        if (!wgrad_late) DCTR_TRY(opt_dense_range(E, E->mlp[0].w, opt_tail ? E->mlp[nl - 1].last : E->mlp[0].last, sw));
     }
     return DCTR_OK;
 }
@@ -2367,6 +2391,7 @@ int dctr_time_kernel(dctr_handle E, const char* kernel, int iters, float* h_ms_p
     const dctr_config& c = E->cfg;
     // the stages are captured once and REPLAYED: a grouping in them must not rely on what this enqueue knows about the slot words
     E->group->slots_clean = false;
+    DCTR_TRY(join_deferred(E, st));                    // (the stages are captured on a stream of their own: nothing of the last step may be pending)
     DCTR_TRY(lag_flush_tables(E, st, 0, false));       // (lagging rows: the classic stages below assume every row is current)
     E->lag_suspended = s != "train_step";              // (a replayed single stage does not advance global_step: classic kernels)
     auto stage = [&](hipStream_t cs) -> int {
@@ -2404,13 +2429,14 @@ int dctr_time_kernel(dctr_handle E, const char* kernel, int iters, float* h_ms_p
         if (s == "mlp0_fwd" || s == "mlp0_dgrad" || s == "mlp0_wgrad") {
             if (E->opnn_fused) { set_error("dctr_time_kernel: the fused Outer-PNN first layer is not one product (time it with rocprofv3)"); return DCTR_ERR_UNSUPPORTED; }
             const Fc& fc = E->mlp[0];
+            const GemmOpt go = gemm_opt(E, fc);          // (the mode the steps run in; the planes are current: the caller synchronised)
             if (s == "mlp0_fwd")
                 return fc_fwd(E->x_in, E->Din_ld, E->pp(fc.w), E->pp(fc.b), E->h[0], fc.out, B, fc.in, fc.out, 1, fc.keep,
-                              &E->state->seed_t, fc.salt, cs, 1);
+                              &E->state->seed_t, fc.salt, cs, 1, &go);
             if (s == "mlp0_dgrad")
-                return fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w), E->dx_in, E->Din_ld, B, fc.in, fc.out, nullptr, 0, 1.f, cs, 1);
+                return fc_bwd_data(E->dh[0], fc.out, E->pp(fc.w), E->dx_in, E->Din_ld, B, fc.in, fc.out, nullptr, 0, 1.f, cs, 1, &go);
             return fc_bwd_weights_partials(E->x_in, E->Din_ld, E->dh[0], fc.out, E->part(fc.w), E->params[fc.w].padded,
-                                           E->part(fc.b), E->params[fc.b].padded, B, fc.in, fc.out, fc.splits, cs, 1);
+                                           E->part(fc.b), E->params[fc.b].padded, B, fc.in, fc.out, fc.splits, cs, 1, &go);
         }
         if (s == "train_step") return record_train(E, B, cs);
         set_error("unknown stage '%s'", kernel);

@@ -993,11 +993,23 @@ __global__ __launch_bounds__(256, DR3_MIN_WAVES(TM, TN)) void gemm_dr3_kernel(co
 //   dgrad: [plane][N / 8][K][8]   (reduction over n)
 // planes h, m, l as in dr_split3; K8 = ceil(K / 8), N8 = ceil(N / 8): the last block of a ragged dimension is padded with zeros.
 // One thread per 16-byte entry of each form; launched behind the layer's optimizer step.
+struct DrWsplitJob { const float* W; int ldw, K, N; unsigned* fwd; unsigned* dgr; int64_t first; };     // first: this job's first entry in the launch
+struct DrWsplitJobs { DrWsplitJob j[8]; int n; int64_t total; };
+// (several weights per launch: the MLP's layers are re-split together behind the step's last optimizer launch)
 template <int UNUSED = 0>
-__global__ __launch_bounds__(256) void dr_wsplit_kernel(const float* __restrict__ W, int ldw, int K, int N, unsigned* __restrict__ fwd, unsigned* __restrict__ dgr) {
+__global__ __launch_bounds__(256) void dr_wsplit_kernel(DrWsplitJobs jobs) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= jobs.total) return;
+    int ji = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+        if (k < jobs.n && idx >= jobs.j[k].first) ji = k;
+    const DrWsplitJob& jb = jobs.j[ji];
+    idx -= jb.first;
+    const float* __restrict__ W = jb.W;
+    const int ldw = jb.ldw, K = jb.K, N = jb.N;
     const int K8 = (K + 7) / 8, N8 = (N + 7) / 8;
     const int64_t nf = (int64_t)K8 * N, nd = (int64_t)N8 * K;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float x[8];
     u32x4* out;
     int64_t plane;
@@ -1005,14 +1017,14 @@ __global__ __launch_bounds__(256) void dr_wsplit_kernel(const float* __restrict_
         const int kb = (int)(idx / N), n = (int)(idx - (int64_t)kb * N);
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = 8 * kb + e < K ? W[(size_t)(8 * kb + e) * ldw + n] : 0.f;
-        out = reinterpret_cast<u32x4*>(fwd) + idx;
+        out = reinterpret_cast<u32x4*>(jb.fwd) + idx;
         plane = nf;
     } else if (idx < nf + nd) {                               // entry (nb, k): W[k][8 nb + e]
         const int64_t i2 = idx - nf;
         const int nb = (int)(i2 / K), k = (int)(i2 - (int64_t)nb * K);
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = 8 * nb + e < N ? W[(size_t)k * ldw + 8 * nb + e] : 0.f;
-        out = reinterpret_cast<u32x4*>(dgr) + i2;
+        out = reinterpret_cast<u32x4*>(jb.dgr) + i2;
         plane = nd;
     } else {
         return;

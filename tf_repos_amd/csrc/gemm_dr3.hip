@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <string>
 
 #include <hip/hip_ext.h>
 
@@ -56,17 +57,15 @@ int dr3_launch(const float* A, int lda, const float* B, int ldb, int64_t bplane,
 // One round of the chip or nothing: the tile (index) whose grid fills the most of <= 256 blocks with the least padded work.
 struct Tile3 { int tm, tn; };
 constexpr Tile3 FWD3[] = {{4, 7}, {4, 8}, {4, 10}};
-template <size_t NT>
-int pick3(const Tile3 (&list)[NT], int Mo, int No, int splits) {
-    int best = -1;
-    double best_cost = 0.0;
-    for (size_t i = 0; i < NT; ++i) {
-        const int64_t blocks = (int64_t)ceil_div(Mo, 16 * list[i].tm) * ceil_div(No, 16 * list[i].tn) * splits;
-        if (blocks > CUS) continue;
-        const double cost = (double)list[i].tm * list[i].tn;            // MFMAs per block and group: the blocks run side by side
-        if (best < 0 || cost < best_cost) { best = (int)i; best_cost = cost; }
-    }
-    return best;
+// The forward and dgrad products of a 4096 x 400 output take the 2 x 7 tile at TWO blocks per CU (512 blocks) rather than 4 x 7 at one:
+// alone the two are equal (18.0 us, tools/gemm_dr_probe), in the step the small tile wins -- a CU holds blocks of two products side by
+// side (a dgrad's beside the weight gradient's of the layer above), one block's prologue / cross-wave reduction / stores under the
+// other's MFMAs, and co-resident blocks of one product share their weight planes in L1 (same column block, XCD-aware order): c2
+// 0.2271 -> 0.2172 ms/step with "fd", 0.2185 with "fdw" (the weight gradient splits BOTH operands in registers: 4.7 VALU ops per MFMA at
+// 2 x 7 against 2.9 at 4 x 7), 0.2206 "f", 0.2188 "d", 0.2316 "w" (profiles/r05_ab_small_tiles.txt).  A/B knob DCTR_DR3_SMALL=<subset of fdw> | none.
+bool small_tile(char op, int Mo, int No, int splits) {
+    static const std::string ops = [] { const char* e = getenv("DCTR_DR3_SMALL"); return std::string(e ? e : "fd"); }();
+    return ops != "none" && ops.find(op) != std::string::npos && (int64_t)ceil_div(Mo, 32) * ceil_div(No, 112) * splits <= 2 * CUS;
 }
 
 }  // namespace
@@ -79,11 +78,25 @@ bool dr3_shape_ok(int M, int K, int N) { return M >= 1024 && K >= 64 && N >= 64 
 int64_t dr3_fwd_plane_bytes(int K, int N) { return (int64_t)ceil_div(K, 8) * N * 16; }
 int64_t dr3_dgr_plane_bytes(int K, int N) { return (int64_t)ceil_div(N, 8) * K * 16; }
 
-int dr3_wsplit(const float* w, int ldw, int K, int N, unsigned* fwd, unsigned* dgr, hipStream_t st) {
-    const int64_t n = (int64_t)ceil_div(K, 8) * N + (int64_t)ceil_div(N, 8) * K;
-    dr_wsplit_kernel<0><<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(w, ldw, K, N, fwd, dgr);
+// up to 8 weights in one launch
+int dr3_wsplit_multi(const WsplitJob* jobs, int n, hipStream_t st) {
+    DrWsplitJobs J{};
+    DCTR_REQUIRE(n >= 0 && n <= 8, "dr3_wsplit_multi: at most 8 weights per launch");
+    if (n == 0) return DCTR_OK;
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        J.j[i] = DrWsplitJob{jobs[i].w, jobs[i].ldw, jobs[i].K, jobs[i].N, jobs[i].fwd, jobs[i].dgr, total};
+        total += (int64_t)ceil_div(jobs[i].K, 8) * jobs[i].N + (int64_t)ceil_div(jobs[i].N, 8) * jobs[i].K;
+    }
+    J.n = n;
+    J.total = total;
+    dr_wsplit_kernel<0><<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(J);
     DCTR_LAUNCH_CHECK();
     return DCTR_OK;
+}
+int dr3_wsplit(const float* w, int ldw, int K, int N, unsigned* fwd, unsigned* dgr, hipStream_t st) {
+    const WsplitJob j{w, ldw, K, N, fwd, dgr};
+    return dr3_wsplit_multi(&j, 1, st);
 }
 
 // ---- Y = act(X W + b): A = X [M,K] split in registers, B = the k-blocked planes of W [K,N]
@@ -97,6 +110,7 @@ int dr3_fc_fwd(const float* x, int ldx, const unsigned* wp, int64_t plane, const
     ep.bias = b; ep.relu = relu; ep.keep = keep; ep.seed = seed; ep.seed_ptr = seed_ptr;
     *done = true;
     const float* B = reinterpret_cast<const float*>(wp);
+    if (small_tile('f', M, N, 1)) return dr3_launch<2, 7, true, true, false, DR_BIAS_ACT, true>(x, ldx, B, N, plane, y, ldy, M, N, K, 1, ep, st);
     switch (t) {
         case 0: return dr3_launch<4, 7, true, true, false, DR_BIAS_ACT, true>(x, ldx, B, N, plane, y, ldy, M, N, K, 1, ep, st);
         case 1: return dr3_launch<4, 8, true, true, false, DR_BIAS_ACT, true>(x, ldx, B, N, plane, y, ldy, M, N, K, 1, ep, st);
@@ -115,6 +129,7 @@ int dr3_fc_bwd_data(const float* dy, int lddy, const unsigned* wp, int64_t plane
     ep.act = act; ep.ldact = ldact; ep.inv_keep = act ? 1.0f / keep_prev : 1.f;
     *done = true;
     const float* B = reinterpret_cast<const float*>(wp);
+    if (act != nullptr && small_tile('d', M, K, 1)) return dr3_launch<2, 7, true, true, false, DR_MASK, true>(dy, lddy, B, K, plane, dx, lddx, M, K, N, 1, ep, st);
     if (act != nullptr) {
         switch (t) {
             case 0: return dr3_launch<4, 7, true, true, false, DR_MASK, true>(dy, lddy, B, K, plane, dx, lddx, M, K, N, 1, ep, st);
@@ -144,6 +159,7 @@ int dr3_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int ld
     ep.colsum = db_part;
     ep.colsum_stride = db_stride;
     *done = true;
+    if (small_tile('w', K, N, splits)) return dr3_launch<2, 7, false, false, true, DR_STORE, false>(x, ldx, dy, lddy, 0, dw_part, N, K, N, M, splits, ep, st);
     return dr3_launch<4, 7, false, false, true, DR_STORE, false>(x, ldx, dy, lddy, 0, dw_part, N, K, N, M, splits, ep, st);
 }
 

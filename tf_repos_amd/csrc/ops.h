@@ -108,6 +108,8 @@ bool dr3_shape_ok(int M, int K, int N);
 int64_t dr3_fwd_plane_bytes(int K, int N);
 int64_t dr3_dgr_plane_bytes(int K, int N);
 int dr3_wsplit(const float* w, int ldw, int K, int N, unsigned* fwd, unsigned* dgr, hipStream_t st);
+struct WsplitJob { const float* w; int ldw, K, N; unsigned* fwd; unsigned* dgr; };
+int dr3_wsplit_multi(const WsplitJob* jobs, int n, hipStream_t st);
 int dr3_fc_fwd(const float* x, int ldx, const unsigned* wp, int64_t plane, const float* b, float* y, int ldy, int M, int K, int N, int relu, float keep,
                const uint64_t* seed_ptr, uint64_t seed, hipStream_t st, bool* done);
 int dr3_fc_bwd_data(const float* dy, int lddy, const unsigned* wp, int64_t plane, float* dx, int lddx, int M, int K, int N, const float* act, int ldact,

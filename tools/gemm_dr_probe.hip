@@ -54,7 +54,12 @@ void run(const char* name, int M, int N, int K, int splits = 1) {
     const int64_t nfe = (int64_t)((Wr + 7) / 8) * Wc, nde = (int64_t)((Wc + 7) / 8) * Wr;
     if constexpr (BP) {
         CK(hipMalloc(&pf, nfe * 48)); CK(hipMalloc(&pd, nde * 48));
-        dr_wsplit_kernel<0><<<(unsigned)((nfe + nde + 255) / 256), 256>>>(B, Wc, Wr, Wc, pf, pd);
+        {
+            DrWsplitJobs J{};
+            J.j[0] = DrWsplitJob{B, Wc, Wr, Wc, pf, pd, 0};
+            J.n = 1; J.total = nfe + nde;
+            dr_wsplit_kernel<0><<<(unsigned)((nfe + nde + 255) / 256), 256>>>(J);
+        }
         CK(hipDeviceSynchronize());
     }
     if constexpr (BP) kfn = (const void*)gemm_dr3_kernel<TM, TN, A_RC, true, CS, EPI, true>;
