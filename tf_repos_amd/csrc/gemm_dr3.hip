@@ -67,6 +67,18 @@ bool small_tile(char op, int Mo, int No, int splits) {
     static const std::string ops = [] { const char* e = getenv("DCTR_DR3_SMALL"); return std::string(e ? e : "fd"); }();
     return ops != "none" && ops.find(op) != std::string::npos && (int64_t)ceil_div(Mo, 32) * ceil_div(No, 112) * splits <= 2 * CUS;
 }
+template <size_t NT>
+int pick3(const Tile3 (&list)[NT], int Mo, int No, int splits) {
+    int best = -1;
+    double best_cost = 0.0;
+    for (size_t i = 0; i < NT; ++i) {
+        const int64_t blocks = (int64_t)ceil_div(Mo, 16 * list[i].tm) * ceil_div(No, 16 * list[i].tn) * splits;
+        if (blocks > CUS) continue;
+        const double cost = (double)list[i].tm * list[i].tn;            // MFMAs per block and group: the blocks run side by side
+        if (best < 0 || cost < best_cost) { best = (int)i; best_cost = cost; }
+    }
+    return best;
+}
 
 }  // namespace
 
