@@ -554,6 +554,14 @@ def main():
                                                        "note": "c5's row shape: K = 32 (a row = one 128-byte granule), 32 M-row table (4.4 GB), uniform ids; layouts compared in profiles/r03_gather_layouts.txt"}
         copy_gbps = e.measure_copy_bandwidth(1 << 30, 20)          # this box's measured HBM roofline (1 GiB float4 copy, read + write)
         out["hbm_measured_copy_GBps"] = round(copy_gbps, 1)
+        # the gathers, memory side: a random access costs a 128-byte granule whatever it asks for (profiles/r02_gather_hbm_pmc.txt: 41.2 MB
+        # fetched per launch at K = 16 AND at K = 32) -- one per row piece of <= 128 B and one per 4-byte linear weight -- plus e written
+        for kn, kk in (("embed_gather_fwd", K), ("embed_gather_fwd_k32_hbm", 32)):
+            if kn in kernels:
+                ms_side = B * F * (128 * ((4 * kk + 127) // 128) + 128) + B * F * 4 * kk
+                kernels[kn]["memory_side_bytes"] = int(ms_side)
+                kernels[kn]["memory_side_GBps"] = round(ms_side / kernels[kn]["ms"] / 1e6, 1)
+                kernels[kn]["frac_memory_side_of_measured_copy"] = round(ms_side / kernels[kn]["ms"] / 1e6 / copy_gbps, 4)
         for k in kernels.values():
             if k["bound"] == "hbm":
                 k["frac_of_measured_copy"] = round(k["achieved"] / copy_gbps, 4)

@@ -36,7 +36,7 @@ def _planes(lib, w, K, N, dev):
     return pf, pd
 
 
-SHAPES = [(4096, 624, 400), (4096, 400, 400), (4001, 616, 392), (8192, 256, 128), (1024, 64, 72), (2048, 1000, 640)]
+SHAPES = [(4096, 624, 400), (4096, 400, 400), (4001, 616, 392), (8192, 512, 128), (1024, 640, 712), (2048, 1000, 640)]
 
 
 @pytest.mark.parametrize("M,K,N", SHAPES)
@@ -94,12 +94,13 @@ def test_split_products_are_f32_equivalent(M, K, N, dev):
 
 def test_split_ops_refuse_shapes_they_do_not_take(dev):
     lib = capi.lib()
-    x = torch.zeros(256, 400, device=dev)
-    w = torch.zeros(400, 400, device=dev)
-    pf, _ = _planes(lib, w, 400, 400, dev)
-    y = torch.empty(256, 400, device=dev)
-    with pytest.raises(errors.UnimplementedError):          # c1's batch: the exact small-batch tiles keep it
-        capi.check(lib.dctr_fc_fwd_split(capi.ptr(x), 400, capi.ptr(pf), None, capi.ptr(y), 400, 256, 400, 400, 1, 1.0, 0, capi.current_stream()))
+    for M, K, N in ((256, 400, 400), (8192, 256, 128), (4096, 404, 400)):     # c1's batch; c4's second layer (0.27 GFLOP); a width not a multiple of 8
+        x = torch.zeros(M, K, device=dev)
+        w = torch.zeros(K, N, device=dev)
+        pf, _ = _planes(lib, w, K, N, dev)
+        y = torch.empty(M, N, device=dev)
+        with pytest.raises(errors.UnimplementedError):          # the exact kernels keep these
+            capi.check(lib.dctr_fc_fwd_split(capi.ptr(x), K, capi.ptr(pf), None, capi.ptr(y), N, M, K, N, 1, 1.0, 0, capi.current_stream()))
 
 
 F, V = 39, 1_000_000

@@ -167,7 +167,7 @@ struct dctr_engine {
     std::vector<hipEvent_t> timer_ev;   // pairs
     std::vector<int> timer_layer;       // MLP layer of every recorded pair
     int timer_mode = 1;                 // 1: two records around layer 0 (a bracket), 2: every forward layer's own dispatch events
-    bool timer_step = false;            // this step is a timed one (every 8th)
+    bool timer_step = false;            // this step is a timed one (every 32nd)
     size_t timer_n = 0;
     uint64_t timer_tick = 0;
     hipStream_t s_group = nullptr, s_wgrad = nullptr;   // side streams of the step DAG

@@ -1113,6 +1113,10 @@ int record_train_wnd(dctr_engine* E, int B, hipStream_t st) {
 }
 
 int record_train(dctr_engine* E, int B, hipStream_t st) {
+    // (an event armed for a launch that an error path never reached must not ride on this step's first launch: common.h arm_stop_event)
+    if (stop_event_pending()) disarm_stop_event();
+    if (timer_events_pending()) disarm_timer_events();
+    E->armed_ev = nullptr;
     if (E->wnd) return record_train_wnd(E, B, st);
     hipStream_t sg = E->s_group, sw = E->s_wgrad;
     // per-step state (loss scalars, global_step, Adam lr_t, dropout seed) off the critical path: the gather does not need it
@@ -2152,9 +2156,17 @@ int dctr_set_dense_input(dctr_handle E, const float* d_dense) {
 
 int dctr_check_ids(dctr_handle E, void* stream) {
     DCTR_REQUIRE(E, "null handle");
-    int32_t s[2] = {0, 0};
+    int32_t s[2] = {0, 0}, lag_over = 0;
     DCTR_HIP_CHECK(hipMemcpyAsync(s, E->status, sizeof(s), hipMemcpyDeviceToHost, as_stream(stream)));
+    if (E->lag_period > 1)
+        DCTR_HIP_CHECK(hipMemcpyAsync(&lag_over, reinterpret_cast<const char*>(E->state) + offsetof(StepState, lag_overflow), sizeof(lag_over),
+                                      hipMemcpyDeviceToHost, as_stream(stream)));
     DCTR_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+    if (lag_over != 0) {         // (lag.h lag_replay_rows: a row further behind than the replay loop reaches -- never under the engine's own schedule)
+        set_error("a table row was found more than %d steps behind global_step: the time-blocked sweep's invariant is broken (stamps wrapped, or the "
+                  "owner-side table API was driven without its sweep)", LAG_MAX_PERIOD);
+        return DCTR_ERR_INVALID_ARG;
+    }
     if (s[0] != 0) {
         DCTR_HIP_CHECK(hipMemsetAsync(E->status, 0, sizeof(s), as_stream(stream)));
         set_error("indices = %d is not in [0, %lld)", s[1], (long long)E->rows);   // GatherOp's message [TF-1.4]

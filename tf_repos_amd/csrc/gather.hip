@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(
     const float4* __restrict__ emb, const float* __restrict__ lin, int64_t rows, int emb_ld4, int lin_ld,
     const int32_t* __restrict__ ids, const float* __restrict__ vals, int B, int F,
     float* __restrict__ e_out, int e_ld, float* __restrict__ yw_out, float* __restrict__ sum_out,
-    float* __restrict__ red_out, int32_t* __restrict__ status, LagView L) {
+    float* __restrict__ red_out, int32_t* __restrict__ status, LagView L, int nt) {
     constexpr int TPE = KQ * FS;           // lanes per example (power of two, <= 64)
     constexpr int EPB = 256 / TPE;         // examples per block
     const int tid = threadIdx.x;
@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(
                 if (f < F) {
                     float4 e;
                     e.x = r[u].x * v[u]; e.y = r[u].y * v[u]; e.z = r[u].z * v[u]; e.w = r[u].w * v[u];
-                    er[(size_t)f * KQ + kq] = e;
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    if (nt) __builtin_nontemporal_store(f4v{e.x, e.y, e.z, e.w}, reinterpret_cast<f4v*>(&er[(size_t)f * KQ + kq]));
+                    else er[(size_t)f * KQ + kq] = e;
                     s.x += e.x; s.y += e.y; s.z += e.z; s.w += e.w;
                     q.x += e.x * e.x; q.y += e.y * e.y; q.z += e.z * e.z; q.w += e.w * e.w;
                     yw += w[u] * v[u];
@@ -130,9 +132,12 @@ static int launch_gather(const float* emb, const float* lin, int64_t rows, int e
     const float4* emb4 = reinterpret_cast<const float4*>(emb);
     LagView L = lag ? *lag : LagView{};
     if (L.ld4 == 0) L.ld4 = KQ;
+    // A/B knob DCTR_GATHER_NT=1: nontemporal stores of e.  Measured SLOWER on the HBM-resident tables it was meant for (K = 32, 32 M rows:
+    // 13.25 -> 13.89 us; K = 16, 64 M rows: 11.51 -> 11.92; profiles/r05_gather_k32_variants.txt): off.
+    static const int nt = getenv("DCTR_GATHER_NT") ? atoi(getenv("DCTR_GATHER_NT")) : 0;
 #define DCTR_GK(MODE_)                                                                                                                  \
-    if (lag) gather_fwd_kernel<KQ, FS, MODE_, U, true><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status, L); \
-    else gather_fwd_kernel<KQ, FS, MODE_, U, false><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status, L)
+    if (lag) gather_fwd_kernel<KQ, FS, MODE_, U, true><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status, L, nt); \
+    else gather_fwd_kernel<KQ, FS, MODE_, U, false><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status, L, nt)
     switch (mode) {
         case DCTR_GATHER_RAW: DCTR_GK(DCTR_GATHER_RAW); break;
         case DCTR_GATHER_FM: DCTR_GK(DCTR_GATHER_FM); break;

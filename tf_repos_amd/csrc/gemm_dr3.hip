@@ -84,7 +84,11 @@ int pick3(const Tile3 (&list)[NT], int Mo, int No, int splits) {
 
 // (reduction lengths up to 16 384: what the error measurements against fp64 cover -- layer widths; a reduction over hundreds of
 //  thousands of terms, like the materialised Outer-PNN first layer's 760 032, stays on the exact kernels, and so do its 1.2 GB of planes)
-bool dr3_shape_ok(int M, int K, int N) { return M >= 1024 && K >= 64 && N >= 64 && K <= 16384 && N <= 16384 && (K & 7) == 0 && (N & 7) == 0; }
+// (and products of at least 0.8 GFLOP: below that the kernels' fixed costs dominate either way and the re-split launch behind the
+//  optimizer is a net loss -- c4's 8192 x 256 x 128 layer: NFM 0.226 -> 0.236 ms/step with it, profiles/r05_configs.txt)
+bool dr3_shape_ok(int M, int K, int N) {
+    return M >= 1024 && K >= 64 && N >= 64 && K <= 16384 && N <= 16384 && (K & 7) == 0 && (N & 7) == 0 && (int64_t)M * K * N >= (int64_t)400 * 1000 * 1000;
+}
 
 // bytes of ONE plane of each pre-split form of a [K][N] weight (three planes each)
 int64_t dr3_fwd_plane_bytes(int K, int N) { return (int64_t)ceil_div(K, 8) * N * 16; }
@@ -161,7 +165,8 @@ int dr3_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int ld
                                 int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, bool* done) {
     *done = false;
     if (splits < 1 || M < 1024 || K < 64 || N < 64 || (N & 3) || (K & 3) || !al16(x) || !al16(dy) || (ldx & 3) || (lddy & 3) || !al16(dw_part) ||
-        (dw_stride & 3) || (int64_t)ceil_div(M, splits) < 128 || (int64_t)ceil_div(M, splits) > 65536 || K > 16384 || N > 16384)
+        (dw_stride & 3) || (int64_t)ceil_div(M, splits) < 128 || (int64_t)ceil_div(M, splits) > 65536 || K > 16384 || N > 16384 ||
+        (int64_t)M * K * N < (int64_t)400 * 1000 * 1000)
         return DCTR_OK;
     const int64_t rows_w = round_up(ceil_div(M, splits), 32) / 4 + 64;            // a wave's rows (+ the groups it prefetches beyond its range)
     if (!fits31(rows_w, ldx) || !fits31(rows_w, lddy)) return DCTR_OK;

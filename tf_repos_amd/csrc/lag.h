@@ -129,6 +129,9 @@ __device__ __forceinline__ void lag_replay_rows(const StepState* __restrict__ S,
     }
     const int kmax = lag_wave_max_lag(nmax);
     if (kmax == 0) return;
+    // (a row further behind than the loop can replay would be stamped current after LAG_MAX_PERIOD updates: never by the engine's own
+    //  schedule -- the sweep bounds every row's lag by the period -- so it is a broken invariant, flagged instead of silently wrong)
+    if (__any(nmax > LAG_MAX_PERIOD) && nmax > LAG_MAX_PERIOD) const_cast<StepState*>(S)->lag_overflow = 1;
     // (`last` is the same on every lane -- callers derive it from StepState::t; readfirstlane says so to the compiler, which would
     //  otherwise index the ring per lane: a vector load.  The ring index needs the low bits only.)
     const int ilast = __builtin_amdgcn_readfirstlane((int)last);

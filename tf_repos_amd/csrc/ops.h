@@ -20,6 +20,8 @@ struct StepState {
     Hyper hyper;
     Hyper hyper_lin;    // canned-estimator models: the linear side's optimizer (wide_n_deep.py:144-149); else a copy of hyper
     float lr_hist[LR_HIST];     // lr_hist[s % LR_HIST] = hyper.lr_t of step s
+    int32_t lag_overflow;       // set (and kept: the next step's state is a copy) by a replay that met a row further behind than LAG_MAX_PERIOD steps --
+    int32_t pad_;               // a broken invariant (stamp wrap, a direct caller of the owner-side API): dctr_check_ids reports it
 };
 
 // sum-of-squares outputs (the l2_loss part of the reported loss) are SUMSQ_SHARDS-way sharded by block index: thousands of

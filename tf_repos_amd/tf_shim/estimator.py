@@ -372,7 +372,15 @@ class Estimator:
                 self._side_ctx.__enter__()
             feeder = DeviceFeeder(e, pipeline.numpy_batches())
         try:
-            return self._train_loop(e, csr, feeder, pipeline, steps, max_steps, start_step, log_every)
+            self._train_loop(e, csr, feeder, pipeline, steps, max_steps, start_step, log_every)
+            if feeder is not None:                    # (before the id check and the checkpoint save: no H2D copy into an input slot, no pending
+                feeder.close()                        #  next-batch grouping may run beside them)
+                feeder = None
+            e.check_ids()
+            path = self._save()
+            from . import logging as L
+            L.info("Saving checkpoints for %d into %s." % (e.global_step, path))
+            return self
         finally:
             if feeder is not None:                    # (also on an exception in train_step / check_ids: the thread stops, its pending hint is dropped)
                 feeder.close()
@@ -412,9 +420,6 @@ class Estimator:
                 dt = time.time() - t0
                 L.info("global_step/sec: %.4g  examples/sec: %.4g  loss = %.7g, step = %d" % (log_every / dt, n0 / dt, loss, start_step + done))
                 t0, n0 = time.time(), 0
-        e.check_ids()
-        path = self._save()
-        L.info("Saving checkpoints for %d into %s." % (e.global_step, path))
         return self
 
     def evaluate(self, input_fn, steps=None, hooks=None, checkpoint_path=None, name=None):
