@@ -330,8 +330,8 @@ int dctr_fc_bwd_weights(const float* d_x, int ldx, const float* d_dy, int lddy, 
  * planes, six plane products, f32 accumulation -- f32-equivalent results on the bf16 matrix pipe.  The weight is pre-split once
  * (dctr_gemm_wsplit, after every change of W) into the two forms the forward and the dgrad product read; their sizes come from
  * dctr_gemm_split_plane_bytes.  Same arguments and epilogues as the exact ops above with the plane buffer in W's place;
- * DCTR_ERR_UNSUPPORTED when no split kernel takes the shape (M >= 1024, K and N multiples of 8 and >= 64, one round of the chip): the
- * caller then uses the exact op.  dctr_fc_bwd_weights_split needs a workspace (as dctr_fc_bwd_weights with splits).
+ * DCTR_ERR_UNSUPPORTED when no split kernel takes the shape (M >= 1024; K and N multiples of 8 in [64, 16384]; at least 0.8 GFLOP; one
+ * round of the chip): the caller then uses the exact op.  dctr_fc_bwd_weights_split needs a workspace (as dctr_fc_bwd_weights with splits).
  * dctr_gemm_split_launches: split-kernel launches so far in this process (tests: the mode is really on). */
 int dctr_gemm_split_plane_bytes(int K, int N, int64_t* fwd_bytes, int64_t* dgr_bytes);
 int dctr_gemm_wsplit(const float* d_w, int K, int N, void* d_fwd_planes, void* d_dgr_planes, void* stream);

@@ -665,7 +665,7 @@ int forward_rest(dctr_engine* E, int B, bool train, hipStream_t st, const std::f
         // relu(x W + b) [-> batch_norm] -> dropout (DeepFM.py:156-162): without BN the dropout rides in the GEMM epilogue
         // (every 32nd step only: a timed step costs ~15 us more -- event records, or launches with completion signals -- which the
         //  bench's `value` should not carry: 0.5 us per step on average)
-        if (i == 0) E->timer_step = E->timer_on && train && (E->timer_tick++ % 32) == 0;
+        if (i == 0) E->timer_step = E->timer_on && train && (E->timer_tick++ % 32) == 3;      // (not the very first step after the enable: it fills the pipeline)
         const bool room = E->timer_n + 2 <= E->timer_ev.size();
         const bool timed = E->timer_step && room && E->timer_mode == 1 && i == 0;
         // mode 2: the launch carries its own start / stop events (common.h arm_timer_events) -- the interval is the dispatch alone
@@ -2134,6 +2134,7 @@ int dctr_step_timer(dctr_handle E, int enable, float* h_avg_ms, int* h_count) {
             for (auto& ev : E->timer_ev) DCTR_HIP_CHECK(hipEventCreate(&ev));
         }
         E->timer_n = 0;
+        E->timer_tick = 0;
         E->timer_layer.clear();
         E->timer_mode = enable;
         E->timer_on = true;
