@@ -126,14 +126,25 @@ def _shard_worker(rank, world, port, model, overlap, driver, ret):
                                                   ("deepfm+dropout", True, "native"), ("nfm+dropout", False, "native"),
                                                   ("dcn+dropout", True, "python")])
 def test_two_ranks_equal_one_rank(model, overlap, driver, dev):
+    _n_ranks_equal_one_rank(2, model, overlap, driver, dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,overlap,driver", [("deepfm+dropout", True, "native"), ("dcn+lag", False, "native"), ("nfm", True, "python")])
+def test_four_ranks_equal_one_rank(model, overlap, driver, dev):
+    """the same with FOUR ranks sharing the GPU (id mod 4 row shards, four quarter batches; round-4 verdict, item 8): every all-to-all has
+    three remote peers per rank, the dropout rows of rank r start at r * 32"""
+    _n_ranks_equal_one_rank(4, model, overlap, driver, dev)
+
+
+def _n_ranks_equal_one_rank(world, model, overlap, driver, dev):
     from oracle import deepctr_oracle as O
     from tests.util import dev_batch, make_pair
-    world = 2
     with mp.Manager() as m:
         ret = m.dict()
         mp.spawn(_shard_worker, args=(world, _free_port(), model, overlap, driver, ret), nprocs=world, join=True)
         got, losses = dict(ret["params"]), list(ret["losses"])
-        probs = np.concatenate([ret["prob0"], ret["prob1"]])
+        probs = np.concatenate([ret["prob%d" % r] for r in range(world)])
     F, V, K, Bg = 39, 2003, 8, 128
     ocfg, params, eng = make_pair(model.split("+")[0], B=Bg, F=F, V=V, K=K, layers=(32, 16), cross=2,
                                   opt="Momentum" if model.endswith("+bn") else "Adam", l2=1e-3, lr=1e-2, seed=4, batch_norm=model.endswith("+bn"),
