@@ -583,9 +583,12 @@ def main():
 
         def template(kind, i):          # (the names c2's shapes take; other configs: labels only)
             if split:
-                return {"fwd": "void dctr::gemm_dr3_kernel<4, 7, true, true, false, 1, true>",
-                        "dgrad": "void dctr::gemm_dr3_kernel<4, 7, true, true, false, 2, true>" if i > 0 else "void dctr::gemm_dr3_kernel<4, 10, true, true, false, 0, true>",
-                        "wgrad": "void dctr::gemm_dr3_kernel<4, 7, false, false, true, 0, false>"}[kind]
+                # (forward and the 400-wide dgrads: 2 x 7 tiles at two blocks per CU unless DCTR_DR3_SMALL says otherwise -- csrc/gemm_dr3.hip)
+                sm = os.environ.get("DCTR_DR3_SMALL", "fd")
+                f_t, d_t, w_t = ("2, 7" if c_ in sm and sm != "none" else "4, 7" for c_ in "fdw")
+                return {"fwd": "void dctr::gemm_dr3_kernel<%s, true, true, false, 1, true>" % f_t,
+                        "dgrad": ("void dctr::gemm_dr3_kernel<%s, true, true, false, 2, true>" % d_t) if i > 0 else "void dctr::gemm_dr3_kernel<4, 10, true, true, false, 0, true>",
+                        "wgrad": "void dctr::gemm_dr3_kernel<%s, false, false, true, 0, false>" % w_t}[kind]
             return {"fwd": "void dctr::gemm_dr_kernel<2, 13, true, false, false, 1, 0>",
                     "dgrad": "void dctr::gemm_dr_kernel<2, 13, true, true, false, 2, 0>" if i > 0 else "void dctr::gemm_dr_kernel<4, 10, true, true, false, 0, 0>",
                     "wgrad": "void dctr::gemm_dr_kernel<2, 13, false, false, true, 0, 0>"}[kind]
