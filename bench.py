@@ -457,6 +457,12 @@ def main():
     # (the in-step timer's event pool is created by its first enable: here, not between the warm-up and the timed region, where the
     #  milliseconds it takes would leave the GPU idle long enough to drop its clocks)
     eng.step_timer(1 if os.environ.get("DCTR_BENCH_TIMER") == "1" else 2)
+    # this box's HBM roofline (1 GiB float4 copy, read + write; reported as hbm_measured_copy_GBps) is measured HERE, right before the
+    # warm-up steps, not after the timed region: building the engine and loading its 1e6-row tables leaves the GPU idle for seconds, and
+    # a GPU that has idled for >= 50 ms runs its next few milliseconds below its working clocks (tools/fixed_cost_probe.py: +0.33 ms on a
+    # 20-step block) -- the driver's invocation is 5 + 20 steps, 6 ms in all.  7 ms of copy kernels put the clocks where any run longer
+    # than that finds them; nothing inside the timed region changes.
+    copy_gbps = eng.measure_copy_bandwidth(1 << 30, 20)
     for s in range(args.warmup):
         step(*batches[s % nb], batches[(s + 1) % nb][0])
     barrier()
@@ -552,8 +558,7 @@ def main():
                 g_ms, g_bytes = hbm_resident_gather(dev, K=32, V=32 * 1024 * 1024, B=B, F=F)
                 kernels["embed_gather_fwd_k32_hbm"] = {"bound": "hbm", "ms": g_ms, "achieved": g_bytes / g_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                        "note": "c5's row shape: K = 32 (a row = one 128-byte granule), 32 M-row table (4.4 GB), uniform ids; layouts compared in profiles/r03_gather_layouts.txt"}
-        copy_gbps = e.measure_copy_bandwidth(1 << 30, 20)          # this box's measured HBM roofline (1 GiB float4 copy, read + write)
-        out["hbm_measured_copy_GBps"] = round(copy_gbps, 1)
+        out["hbm_measured_copy_GBps"] = round(copy_gbps, 1)        # (measured before the warm-up steps, see there)
         # the gathers, memory side: a random access costs a 128-byte granule whatever it asks for (profiles/r02_gather_hbm_pmc.txt: 41.2 MB
         # fetched per launch at K = 16 AND at K = 32) -- one per row piece of <= 128 B and one per 4-byte linear weight -- plus e written
         for kn, kk in (("embed_gather_fwd", K), ("embed_gather_fwd_k32_hbm", 32)):

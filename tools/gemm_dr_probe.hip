@@ -129,17 +129,12 @@ void run(const char* name, int M, int N, int K, int splits = 1) {
 }
 
 int main(int argc, char** argv) {
-    // exact f32 MFMA and the three-plane bf16 split side by side: time, and max |error| against an fp64 product
-    run<2, 13, true, false, false>("fwd L0", 4096, 400, 624);
-    run<4, 7, true, false, false, true>("fwd L0", 4096, 400, 624);
-    run<4, 7, true, false, false, true, true>("fwd L0", 4096, 400, 624);
-    run<2, 13, true, false, false, true, true>("fwd L0", 4096, 400, 624);
-    run<2, 7, true, false, false, true, true>("fwd L0", 4096, 400, 624);
-    run<4, 7, true, false, false, true, true>("fwd L1", 4096, 400, 400);
-    run<4, 7, true, false, false, true, true>("fwd odd", 4001, 396, 612);
-    run<4, 10, true, true, false, true, true>("dgrad L0", 4096, 624, 400);
-    run<4, 7, true, true, false, true, true>("dgrad L1", 4096, 400, 400);
+    // weight-gradient tiles in split precision (both operands split in registers): VALU ops per MFMA fall with squarer tiles
     run<4, 7, false, false, true, true>("wgrad L0", 624, 400, 4096, 6);
+    run<5, 7, false, false, true, true>("wgrad L0", 624, 400, 4096, 8);
     run<4, 7, false, false, true, true>("wgrad L1", 400, 400, 4096, 9);
+    run<5, 7, false, false, true, true>("wgrad L1", 400, 400, 4096, 12);
+    run<5, 5, false, false, true, true>("wgrad L1", 400, 400, 4096, 10);
+    run<5, 5, false, false, true, true>("wgrad L0", 624, 400, 4096, 6);
     return 0;
 }
