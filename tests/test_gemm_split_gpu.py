@@ -109,12 +109,12 @@ def test_split_ops_refuse_shapes_they_do_not_take(dev):
 F, V = 39, 1_000_000
 
 
-def _c2(mode, B=4096, keep=(1.0, 1.0, 1.0), seed=0, period=0):
+def _c2(mode, B=4096, keep=(1.0, 1.0, 1.0), seed=0, period=0, use_graph=False):
     kw = dict(model="deepfm", field_size=F, feature_size=V, embedding_size=16, deep_layers=(400, 400, 400), dropout=keep, l2_reg=1e-4,
               learning_rate=5e-4, optimizer="Adam")
     ocfg = O.Config(**kw)
     params = O.init_params(ocfg, seed=seed + 1, scale=0.01)
-    eng = Engine(EngineConfig(max_batch=B, seed=seed, use_graph=False, gemm_mode=mode, table_sweep_period=period, **kw))
+    eng = Engine(EngineConfig(max_batch=B, seed=seed, use_graph=use_graph, gemm_mode=mode, table_sweep_period=period, **kw))
     eng.set_params(params)
     return ocfg, params, eng
 
@@ -143,11 +143,13 @@ def test_c2_one_step_in_split_mode_at_the_exact_tolerances(dev):
     eng.close()
 
 
-def test_split_equals_exact_over_steps_and_host_writes_resplit(dev):
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_split_equals_exact_over_steps_and_host_writes_resplit(use_graph, dev):
+    """(use_graph: a replayed hipGraph runs no host logic -- the re-split behind a host write happens at the write)"""
     B = 4096
     states = {}
     for mode in ("exact", "split"):
-        ocfg, params, eng = _c2(mode, keep=(0.5, 0.5, 0.5), seed=3, period=1)
+        ocfg, params, eng = _c2(mode, keep=(0.5, 0.5, 0.5), seed=3, period=1, use_graph=use_graph)
         for s in range(5):
             ids, vals, labels = O.synth_batch(B, F, V, seed=400 + s)
             eng.train_step(*dev_batch(ids, vals, labels, dev), want_loss=(s == 4))

@@ -1558,7 +1558,7 @@ __global__ void strided_copy_kernel(float* __restrict__ strided, float* __restri
     }
 }
 
-static int copy_param(dctr_handle E, const char* name, int which, void* host, size_t nbytes, bool to_device) {
+static int copy_param_impl(dctr_handle E, const char* name, int which, void* host, size_t nbytes, bool to_device) {
     DCTR_REQUIRE(E && host, "null argument");
     Param* p = find_param(E, name);
     if (!p) return DCTR_ERR_NOT_FOUND;
@@ -1621,6 +1621,17 @@ static int copy_param(dctr_handle E, const char* name, int which, void* host, si
     return DCTR_OK;
 }
 
+static int copy_param(dctr_handle E, const char* name, int which, void* host, size_t nbytes, bool to_device) {
+    DCTR_TRY(copy_param_impl(E, name, which, host, nbytes, to_device));
+    // gemm_mode 1 with captured steps: a replayed graph runs no host logic, so the "re-split before the next product" of the eager path
+    // (wplanes_ensure) would never happen -- the planes are refreshed here, once per write
+    if (to_device && which < 0 && E->gemm_mode == 1 && E->cfg.use_graph) {
+        for (std::vector<Fc>* tower : {&E->mlp, &E->mlp2})
+            for (Fc& fc : *tower) DCTR_TRY(wplanes_ensure(E, fc, nullptr));
+        DCTR_HIP_CHECK(hipDeviceSynchronize());
+    }
+    return DCTR_OK;
+}
 int dctr_param_set(dctr_handle h, const char* name, const float* h_src, size_t nbytes) {
     return copy_param(h, name, -1, const_cast<float*>(h_src), nbytes, true);
 }
