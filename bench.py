@@ -470,7 +470,10 @@ def main():
     # hipEvents on the roofline kernel inside the timed steps: every forward layer's launch carries its own start / stop events
     # (DCTR_BENCH_TIMER=1: rounds 1-3's bracket of two records around layer 0 -- two barrier packets inside the interval)
     timer_mode = 1 if os.environ.get("DCTR_BENCH_TIMER") == "1" else 2
-    eng.step_timer(timer_mode)
+    if os.environ.get("DCTR_BENCH_TIMER") == "0":          # (A/B: what the in-step timer's sampled steps cost the timed region)
+        eng.step_timer(False)
+    else:
+        eng.step_timer(timer_mode)
     t0 = time.perf_counter()
     for s in range(args.steps):
         step(*batches[(args.warmup + s) % nb], batches[(args.warmup + s + 1) % nb][0])
