@@ -3,9 +3,10 @@
 # without an 8-GPU node.  What one GPU CAN measure: ONE rank's share of the step -- its shard of the table (V / 8 = 1.25e7 rows), its
 # 8192 examples, the whole row-sharded code path (routing, packing, RCCL at world 1, owner-side segment sum + time-blocked sweep) with
 # every exchange staying on the device.  The xGMI time is then ADDED from a stated model -- a projection, labelled as such.
-# usage (GPU box): bash tools/c5_shard_projection.sh     -> gpurun_out/r04_c5_shard_w1.json
+# usage (GPU box): bash tools/c5_shard_projection.sh     -> gpurun_out/${TAG}_c5_shard_w1.json
 set -u
-out=gpurun_out/r04_c5_shard_w1.json
+TAG=${TAG:-r05}
+export TAG
 DCTR_FORCE_SHARDED=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 \
     --config c5 --feature-size 12500000 --steps 100 --warmup 10 --no-cpu-baseline --no-end-to-end > gpurun_out/c5_shard_bench.json 2> gpurun_out/c5_shard_bench.err
 tail -2 gpurun_out/c5_shard_bench.err
@@ -37,7 +38,8 @@ out = {
                                      "assumes": "perfect overlap of nothing: measured one-rank step + both all-to-alls in full; no load imbalance between owners "
                                                 "(ids are dealt id mod 8); RCCL reaching the 7-link rate"},
 }
-json.dump(out, open("gpurun_out/r04_c5_shard_w1.json", "w"), indent=1)
+import os
+json.dump(out, open("gpurun_out/%s_c5_shard_w1.json" % os.environ.get("TAG", "r05"), "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("xgmi_model", "PROJECTION_not_a_measurement")}))
 print("measured one-rank ms/step:", ms)
 PY
