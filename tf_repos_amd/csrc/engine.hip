@@ -201,6 +201,8 @@ int build(dctr_engine* E) {
     const bool has_lin = E->wnd ? E->wnd_wide : (c.model != DCTR_MODEL_DCN && !mvm && !E->csr);
 
     // ---- parameters (engine names, tf_repos_amd.checkpoint maps them to TF names)
+    // A/B knob DCTR_OUT_SPLITS: slabs of the output layer's gradient = blocks of the fused head kernel (rows per block = batch / slabs)
+    if (const char* v = getenv("DCTR_OUT_SPLITS")) { const int n = atoi(v); if (n >= 32 && n <= 1024) E->out_splits = n; }
     if (c.model == DCTR_MODEL_DCN) {
         E->p_cross_b = add_param(E, "cross_b", {c.cross_layers, D}, false, 32, c.l2_reg);
         E->p_cross_w = add_param(E, "cross_w", {c.cross_layers, D}, false, 32, c.l2_reg);
