@@ -312,3 +312,18 @@ def test_round_robin_pair_schedule_covers_every_pair_once():
                 seen.add((lo, hi))
                 fields.update((lo, hi))
         assert len(seen) == F * (F - 1) // 2
+
+
+def test_knob_list_names_every_knob_the_sources_read():
+    """tools/KNOBS.txt (python tools/list_knobs.py > tools/KNOBS.txt) is the documentation of the DCTR_* A/B switches: a knob added to
+    the sources and not to the list is a setting nobody can find.  Names only -- the line numbers in the file move with every edit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "list_knobs.py")], capture_output=True, text=True, check=True).stdout
+
+    def names(text):
+        return {ln.strip() for ln in text.split("\n") if ln.startswith("DCTR_")}
+    listed = names(open(os.path.join(root, "tools", "KNOBS.txt")).read())
+    assert names(out) == listed, sorted(names(out) ^ listed)
