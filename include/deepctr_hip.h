@@ -134,13 +134,14 @@ typedef struct dctr_config {
      * 1 = the biased variance in the moving average too (the non-fused nn.moments path). */
     int32_t batch_norm_biased_moving_variance;
     /* Arithmetic of the MLP's three matrix products (contrib.layers.fully_connected and its MatMul gradients, DeepFM.py:156-158,
-     * 165-166,213).  0 (default) = exact f32 MFMA (bitwise an fmaf chain).  1 = split precision: every f32 operand element is
-     * carried as THREE bf16 planes (x = h + m + l exactly: 3 x 8 = 24 significand bits) and the six leading plane products (hh, hm,
-     * mh, hl, lh, mm) are accumulated in f32 on the bf16 matrix pipe, which runs 16x the f32 MFMA's rate; the three dropped products
-     * are below 2^-24 of the element product, so the result is an f32 dot product to within the rounding of its f32 accumulation
-     * (measured against an fp64 product: at or below the exact kernel's error, tools/gemm_dr_probe.hip).  Shapes the split kernels
-     * do not take (small batches, widths not a multiple of 8) run the exact kernels in either mode.  The environment variable
-     * DCTR_GEMM_MODE=exact|split overrides this field when the handle is created. */
+     * 165-166,213).  1 = split precision: every f32 operand element is carried as THREE bf16 planes (x = h + m + l exactly: 3 x 8 =
+     * 24 significand bits) and the six leading plane products (hh, hm, mh, hl, lh, mm) are accumulated in f32 on the bf16 matrix
+     * pipe, which runs 16x the f32 MFMA's rate; the three dropped products are below 2^-24 of the element product, so the result is
+     * an f32 dot product to within the rounding of its f32 accumulation (measured against an fp64 product: at or below the exact
+     * kernel's error, tests/test_gemm_split_gpu.py).  2 = exact f32 MFMA (bitwise an fmaf chain).  0 = the library's default: what
+     * the environment variable DCTR_GEMM_MODE=split|exact names, else split (round 6: the mode bench.py times is the mode a
+     * zero-initialised dctr_config gets, and the mode the GPU test suite runs in).  Shapes the split kernels do not take (small
+     * batches, widths not a multiple of 8) run the exact kernels in either mode. */
     int32_t gemm_mode;
 } dctr_config;
 

@@ -1,4 +1,4 @@
-"""Split-precision mode of the MLP products (dctr_config.gemm_mode = 1, csrc/gemm_dr3.hip): every f32 operand element as three bf16
+"""Split-precision mode of the MLP products (dctr_config.gemm_mode = 1 and, since round 6, the library's default; csrc/gemm_dr3.hip): every f32 operand element as three bf16
 planes, six plane products, f32 accumulation -- replaces contrib.layers.fully_connected and its MatMul gradients (DeepFM.py:156-158,
 165-166,213) like the exact kernels do.
 
@@ -8,11 +8,14 @@ What is checked.
     number here, not a name;  bias / ReLU / dropout and ReLU-mask epilogues included (same mask bits as the exact op: bit-equal
     zero patterns);
   * engine level, c2 at full size with gemm_mode = "split": one step against the oracle at the exact mode's tolerances (logits 1e-4,
-    loss 1e-5 rel, every variable 2e-6), the steady-state bench path (lag + hint + slots + keep 0.5, 17 steps, fp64 oracle) at the exact
-    mode's bounds, and split == exact of the same engine to 2e-6 after 5 steps;
+    loss 1e-5 rel, every variable 2e-6), and split == exact of the same engine to 2e-6 after 5 steps -- with the classic sweep and with
+    the default time-blocked one.  The steady-state bench path (lag + hint + slots + keep 0.5 + deferred join, 17 steps, fp64 oracle) in
+    this mode is tests/test_bench_path_gpu.py::test_bench_path_matches_oracle[c2_deepfm-split] / [c3_dcn-split], and lag == classic at
+    full c2 size ::test_lag_equals_classic_at_c2_size[split];
   * the mode is really on (dctr_gemm_split_launches counts 9 launches per c2 step) and parameter writes from the host re-split the
     weights (a stale plane would keep the old weight in the forward product).
-The whole GPU suite also runs green with DCTR_GEMM_MODE=split in the environment (profiles/r05_suite_split_mode.txt)."""
+Since round 6 split is what a handle gets by default, so the whole GPU suite runs in it; DCTR_GEMM_MODE=exact in the environment runs
+every handle that does not name a mode in the exact one (profiles/r06_suite_exact_mode.txt)."""
 import ctypes as C
 
 import numpy as np
@@ -143,13 +146,14 @@ def test_c2_one_step_in_split_mode_at_the_exact_tolerances(dev):
     eng.close()
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_split_equals_exact_over_steps_and_host_writes_resplit(use_graph, dev):
-    """(use_graph: a replayed hipGraph runs no host logic -- the re-split behind a host write happens at the write)"""
+@pytest.mark.parametrize("use_graph,period", [(False, 1), (True, 1), (False, 0)])
+def test_split_equals_exact_over_steps_and_host_writes_resplit(use_graph, period, dev):
+    """(use_graph: a replayed hipGraph runs no host logic -- the re-split behind a host write happens at the write; period 0: the default
+    time-blocked table sweep with its deferred end-of-step join, the schedule bench.py times)"""
     B = 4096
     states = {}
     for mode in ("exact", "split"):
-        ocfg, params, eng = _c2(mode, keep=(0.5, 0.5, 0.5), seed=3, period=1, use_graph=use_graph)
+        ocfg, params, eng = _c2(mode, keep=(0.5, 0.5, 0.5), seed=3, period=period, use_graph=use_graph)
         for s in range(5):
             ids, vals, labels = O.synth_batch(B, F, V, seed=400 + s)
             eng.train_step(*dev_batch(ids, vals, labels, dev), want_loss=(s == 4))

@@ -1066,6 +1066,9 @@ __global__ void step_state_next_kernel(const StepState* __restrict__ cur, StepSt
     for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero[i] = 0.f;
     if (threadIdx.x != 0) return;
     StepState s = *cur;
+    // (prepared EARLY in the step: a replay later in that step sets lag_overflow in `cur` after this copy was made -- it then sits in the
+    //  state this kernel overwrites one step later: keep what is there)
+    s.lag_overflow |= nxt->lag_overflow;
     s.t += 1;
     const double t = (double)s.t;
     for (Hyper* hp : {&s.hyper, &s.hyper_lin}) {

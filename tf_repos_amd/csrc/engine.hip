@@ -720,6 +720,9 @@ int forward_gather_train(dctr_engine* E, int B, hipStream_t st) {
 }
 
 int forward(dctr_engine* E, int B, bool train, hipStream_t st) {
+    // (predict / eval right behind a train step: the gather below writes x_in, which that step's deferred first-layer weight gradient may
+    //  still be reading on the side stream -- record_train alternates the buffer, this path does not)
+    DCTR_TRY(join_deferred(E, st));
     DCTR_TRY(forward_gather(E, B, st));
     return forward_rest(E, B, train, st);
 }
@@ -1137,7 +1140,9 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     // (it only READS the live state): the step's last join can then be deferred past the next gather (below)
     static const bool no_state_ahead = getenv("DCTR_NO_STATE_AHEAD") != nullptr;       // A/B knob
     static const bool defer_off = [] { const char* v = getenv("DCTR_DEFER_JOIN"); return v != nullptr && v[0] == '0'; }();     // A/B knob
-    const bool state_early_ok = !defer_off && !E->cfg.use_graph && !no_state_ahead && sw != st && sg != st && E->cfg.shard_world == 1;
+    // (not while the step is being CAPTURED -- dctr_time_kernel("train_step"): the deferred join would leave sw unjoined at EndCapture and
+    //  dense_pending pointing at an event of the capture)
+    const bool state_early_ok = !defer_off && !E->cfg.use_graph && !E->capturing && !no_state_ahead && sw != st && sg != st && E->cfg.shard_world == 1;
     bool state_early = false;
     if (E->state_ready) {
         // prepared under the tail of the previous step (below): the two states / scalar sets change roles
@@ -1194,6 +1199,9 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
         // launches that follow on sg (two latency-bound kernels, ~80 us in the step: they used to hold the scatter back ~10 us)
         if (!bg_late) {
             if (state_early_ok) {
+                // (started BEFORE forward_rest's join -- a small first layer, ids not grouped ahead: state_alt / scalars_alt are the live
+                //  state of the step before, which that step's deferred optimizer tail on sw may still read and add its l2 sums to)
+                if (E->dense_pending) DCTR_HIP_CHECK(hipStreamWaitEvent(sg, E->ev_dense, 0));
                 DCTR_TRY(step_state_next(E->state, E->state_alt, E->scalars_alt, 4 * SUMSQ_SHARDS, sg));
                 E->state_ready = state_early = true;
             }
@@ -1463,10 +1471,13 @@ int dctr_create(const dctr_config* cfg, dctr_handle* h) {
             E->cfg.embedding_size = kp;
         }
     }
-    E->gemm_mode = E->cfg.gemm_mode == 1 ? 1 : 0;
-    if (const char* gm = getenv("DCTR_GEMM_MODE")) {       // (runs a whole test suite in the other mode)
-        if (!strcmp(gm, "split") || !strcmp(gm, "1")) E->gemm_mode = 1;
-        else if (!strcmp(gm, "exact") || !strcmp(gm, "0")) E->gemm_mode = 0;
+    // dctr_config.gemm_mode: 0 = the library's default (DCTR_GEMM_MODE, else split), 1 = split, 2 = exact.  Internally 1 = split, 0 = exact.
+    E->gemm_mode = E->cfg.gemm_mode == 2 ? 0 : 1;
+    if (E->cfg.gemm_mode == 0) {
+        if (const char* gm = getenv("DCTR_GEMM_MODE")) {   // (runs a whole test suite in the other mode: handles that do not name one)
+            if (!strcmp(gm, "split") || !strcmp(gm, "1")) E->gemm_mode = 1;
+            else if (!strcmp(gm, "exact") || !strcmp(gm, "2")) E->gemm_mode = 0;
+        }
     }
     int rc = build(E);
     if (rc == DCTR_OK) rc = build_k_layouts(E);
@@ -1671,7 +1682,12 @@ static int param_device_view(dctr_handle E, const char* name, float** d_ptr, int
         DCTR_TRY(lag_flush_tables(E, nullptr, 0, false));
         DCTR_HIP_CHECK(hipDeviceSynchronize());
     }
-    if (!p->is_table) wplanes_invalidate(E);        // (gemm_mode 1: the caller may write through the pointer)
+    if (!p->is_table) {
+        // (the step's deferred tail -- last weight gradient, the MLP's optimizer launch -- may still be running on the side stream: the
+        //  caller reads or writes through the pointer on a stream of its own)
+        if (E->dense_pending) { DCTR_HIP_CHECK(hipEventSynchronize(E->ev_dense)); E->dense_pending = false; }
+        wplanes_invalidate(E);                      // (gemm_mode 1: the caller may write through the pointer)
+    }
     *d_ptr = p->ptr;
     if (row_stride != nullptr)      // floats between consecutive rows of the variable's first dimension
         *row_stride = p->is_table ? (p->name == "emb" ? E->tab_ld : E->lin_ld) : (p->rank > 0 ? p->log_n / std::max<int64_t>(p->log_dims[0], 1) : 1);
@@ -2172,10 +2188,17 @@ int dctr_check_ids(dctr_handle E, void* stream) {
     DCTR_REQUIRE(E, "null handle");
     int32_t s[2] = {0, 0}, lag_over = 0;
     DCTR_HIP_CHECK(hipMemcpyAsync(s, E->status, sizeof(s), hipMemcpyDeviceToHost, as_stream(stream)));
-    if (E->lag_period > 1)
+    int32_t lag_over_alt = 0;
+    if (E->lag_period > 1) {
         DCTR_HIP_CHECK(hipMemcpyAsync(&lag_over, reinterpret_cast<const char*>(E->state) + offsetof(StepState, lag_overflow), sizeof(lag_over),
                                       hipMemcpyDeviceToHost, as_stream(stream)));
+        // (the other StepState too: a flag raised late in the last step sits in the state that step ran on, which may be either by now)
+        if (E->state_alt != nullptr)
+            DCTR_HIP_CHECK(hipMemcpyAsync(&lag_over_alt, reinterpret_cast<const char*>(E->state_alt) + offsetof(StepState, lag_overflow), sizeof(lag_over_alt),
+                                          hipMemcpyDeviceToHost, as_stream(stream)));
+    }
     DCTR_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+    lag_over |= lag_over_alt;
     if (lag_over != 0) {         // (lag.h lag_replay_rows: a row further behind than the replay loop reaches -- never under the engine's own schedule)
         set_error("a table row was found more than %d steps behind global_step: the time-blocked sweep's invariant is broken (stamps wrapped, or the "
                   "owner-side table API was driven without its sweep)", LAG_MAX_PERIOD);
@@ -2473,7 +2496,9 @@ int dctr_time_kernel(dctr_handle E, const char* kernel, int iters, float* h_ms_p
     DCTR_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     DCTR_HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
     int rc = DCTR_OK;
+    E->capturing = true;
     for (int i = 0; i < iters && rc == DCTR_OK; ++i) rc = stage(cs);
+    E->capturing = false;
     hipError_t e = hipStreamEndCapture(cs, &graph);
     hipStreamDestroy(cs);
     E->lag_suspended = false;

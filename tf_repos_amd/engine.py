@@ -52,8 +52,9 @@ class EngineConfig:
     # from attention_layers and its keep_probs from dropout[i]
     att_pairs: Sequence[Tuple[int, int]] = ()
     table_sweep_period: int = 0                # dense_exact + Adam: period of the time-blocked table sweep (include/deepctr_hip.h); 0 = default, 1 = classic
-    gemm_mode: str = "exact"                   # MLP products: "exact" f32 MFMA, or "split" (three bf16 planes, six products, f32 accumulate:
-                                               # f32-equivalent results on the bf16 matrix pipe; include/deepctr_hip.h dctr_config.gemm_mode)
+    gemm_mode: str = "default"                 # MLP products: "split" (three bf16 planes, six products, f32 accumulate: f32-equivalent results on
+                                               # the bf16 matrix pipe), "exact" (f32 MFMA), or "default" = the library's (DCTR_GEMM_MODE, else split;
+                                               # include/deepctr_hip.h dctr_config.gemm_mode)
     use_graph: bool = False                    # False: eager launches on 3 HIP streams (measured faster: each stream keeps its own
                                                # hardware queue); True: one captured hipGraph per (batch size, input slot)
 
@@ -101,9 +102,9 @@ class EngineConfig:
         c.max_entries = int(self.max_entries)
         c.ctr_task_wgt = float(self.ctr_task_wgt)
         c.table_sweep_period = int(self.table_sweep_period)
-        if self.gemm_mode not in ("exact", "split"):
-            raise errors.InvalidArgumentError("gemm_mode must be 'exact' or 'split', got %r" % (self.gemm_mode,))
-        c.gemm_mode = 1 if self.gemm_mode == "split" else 0
+        if self.gemm_mode not in ("default", "exact", "split"):
+            raise errors.InvalidArgumentError("gemm_mode must be 'default', 'exact' or 'split', got %r" % (self.gemm_mode,))
+        c.gemm_mode = {"default": 0, "split": 1, "exact": 2}[self.gemm_mode]
         c.n_att_pairs = len(self.att_pairs)
         for i, (u, a) in enumerate(list(self.att_pairs)[:8]):
             c.att_user_slot[i], c.att_ad_slot[i] = int(u), int(a)
