@@ -390,6 +390,7 @@ int build(dctr_engine* E) {
     DCTR_TRY(dmalloc(&E->state, 1, false));
     DCTR_HIP_CHECK(hipMemcpy(E->state, &s, sizeof(s), hipMemcpyHostToDevice));
     DCTR_TRY(dmalloc(&E->state_alt, 1, false));
+    DCTR_HIP_CHECK(hipMemcpy(E->state_alt, &s, sizeof(s), hipMemcpyHostToDevice));      // (step_state_next keeps the destination's lag_overflow: not uninitialised memory)
     DCTR_TRY(dmalloc(&E->scalars_alt, 4 * SUMSQ_SHARDS));
     DCTR_TRY(dmalloc(&E->scalars, 4 * SUMSQ_SHARDS));   // [0..63] xent shards; [64..127] emb^2 shards; [128..191] linear^2; [192..255] dense l2 params
     DCTR_TRY(dmalloc(&E->status, 2));

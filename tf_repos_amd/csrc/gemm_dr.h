@@ -73,9 +73,65 @@ struct DrEpilogue {
     const float* colscale;      // DR_BGATE_WGRAD: [N]
     float* colsum2;             // DR_BGATE_WGRAD: -> colsum2[y * colsum2_stride + n]
     int64_t colsum2_stride;
+    // Producer-side split (round 6): besides C, the STORED output (bias / ReLU / dropout or the ReLU mask applied) leaves as three bf16
+    // planes blocked along its ROWS, cf[plane][row / 8][N][8] -- the form a weight-gradient product reads both of its operands in (the
+    // reduction runs over the batch rows: a lane's 8 k of an MFMA fragment are one 16-byte load, dr3 A_PRE / B_PRE) -- so that the split
+    // happens ONCE per element here instead of once per element and consuming block there (x was re-split by 4 column-tile blocks, dy by
+    // 10 row-tile blocks).  Rows >= M of the last row block are written as zeros (they enter the consumer's reduction).
+    unsigned* cf;               // plane 0, or null
+    int64_t cf_plane;           // bytes from one plane to the next
+    // ... and its column sums over this block's rows (the bias gradient the weight-gradient kernel used to take from its raw B operand):
+    // csp[bm * csp_stride + n]; the blocks of the LAST row tile also zero the slabs bm + 1 .. csp_slabs - 1 (a shorter batch than the one
+    // the slab count was sized for)
+    float* csp;
+    int64_t csp_stride;
+    int csp_slabs;
 };
 
 __device__ __forceinline__ float dr_dropout_scale(uint64_t seed, uint64_t idx, float keep);   // = dropout_scale of common.h (defined by the includer)
+
+// ---- the three-plane bf16 split of an f32 value (the split-precision kernel further down; dr_finish emits planes too)
+typedef __bf16 dr_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 dr_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float dr_f32x2 __attribute__((ext_vector_type(2)));
+
+template <class F, int... I>
+__device__ __forceinline__ void dr_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void dr_static_for(F&& f) { dr_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
+struct DrPlanes { u32x4 h, m, l; };
+
+__device__ __forceinline__ unsigned dr_pk_bf16(float a, float b) {          // v_cvt_pk_bf16_f32: a -> low half, b -> high half, RNE
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(dr_f32x2{a, b}, dr_bf16x2));
+}
+// (plain v_sub_f32: hipcc's SLP pass would pair them into v_pk_add_f32, which costs more issue time beside MFMAs than two subs)
+__device__ __forceinline__ float dr_sub(float a, float b) {
+#ifdef DR3_PK_SUB
+    return a - b;
+#else
+    float r;
+    asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#endif
+}
+__device__ __forceinline__ void dr_split3(const float (&x)[8], DrPlanes& p) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float x0 = x[2 * t], x1 = x[2 * t + 1];
+        const unsigned h = dr_pk_bf16(x0, x1);
+        const float r0 = dr_sub(x0, __uint_as_float(h << 16)), r1 = dr_sub(x1, __uint_as_float(h & 0xffff0000u));
+        const unsigned m = dr_pk_bf16(r0, r1);
+        const float s0 = dr_sub(r0, __uint_as_float(m << 16)), s1 = dr_sub(r1, __uint_as_float(m & 0xffff0000u));
+        p.h[t] = h;
+        p.m[t] = m;
+        p.l[t] = dr_pk_bf16(s0, s1);
+    }
+}
+__device__ __forceinline__ f32x4 dr_mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dr_bf16x8, a), __builtin_bit_cast(dr_bf16x8, b), c, 0, 0, 0);
+}
+
 
 // Row / column of the tile that MFMA output row rho (= A-fragment lane) of A tile i / output column c (= B-fragment lane) of B
 // tile j stands for.  An operand whose NON-reduction dimension is contiguous ("NC") is loaded with one dwordx4 (dwordx2) per
@@ -257,6 +313,38 @@ __device__ __forceinline__ void dr_finish(f32x4 (&acc)[TM][TN], float (&cs)[TN],
                     }
                 }
                 *reinterpret_cast<float4*>(Cz + (size_t)gm * ldc + gn) = make_float4(v[0], v[1], v[2], v[3]);
+                if (ep.cf != nullptr || ep.csp != nullptr) *reinterpret_cast<float4*>(&dr_lds[row * LDS_ + 4 * tc]) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        if (ep.cf != nullptr || ep.csp != nullptr) {
+            __syncthreads();          // the stage holds the stored values
+            if (ep.cf != nullptr) {
+                // entry (rb, col): rows 8 rb .. 8 rb + 7 of tile column col -> 16 bytes per plane; consecutive threads take consecutive columns
+                // (LDS: conflict-free; global: 16 TN x 16 contiguous bytes per row block and plane)
+                char* cfb = reinterpret_cast<char*>(ep.cf);
+                for (int idx = t; idx < 2 * TM * 16 * TN; idx += 256) {
+                    const int rb = idx / (16 * TN), col = idx - rb * (16 * TN);
+                    const int gm0 = m0 + 8 * rb, gc = n0 + col;
+                    if (gc < N && gm0 < M) {
+                        float x[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = gm0 + e < M ? dr_lds[(8 * rb + e) * LDS_ + col] : 0.f;
+                        DrPlanes pl;
+                        dr_split3(x, pl);
+                        char* o = cfb + ((size_t)(gm0 >> 3) * N + gc) * 16;
+                        *reinterpret_cast<u32x4*>(o) = pl.h;
+                        *reinterpret_cast<u32x4*>(o + ep.cf_plane) = pl.m;
+                        *reinterpret_cast<u32x4*>(o + 2 * ep.cf_plane) = pl.l;
+                    }
+                }
+            }
+            if (ep.csp != nullptr && t < 16 * TN && n0 + t < N) {
+                float sum = 0.f;
+#pragma unroll 8
+                for (int row = 0; row < 16 * TM; ++row) sum += m0 + row < M ? dr_lds[row * LDS_ + t] : 0.f;
+                ep.csp[(size_t)bm * ep.csp_stride + n0 + t] = sum;
+                if (m0 + 16 * TM >= M)
+                    for (int sl = bm + 1; sl < ep.csp_slabs; ++sl) ep.csp[(size_t)sl * ep.csp_stride + n0 + t] = 0.f;
             }
         }
     } else {                     // odd strides / widths: element by element (not a tuned path)
@@ -645,47 +733,6 @@ __global__ __launch_bounds__(256, DR_MIN_WAVES(TM, TN, CS, AGEN)) void gemm_dr_k
 // two dwordx4; the other kind one dword (or a dwordx4 over four tiles) per e.  The raw f32 registers of a tile are free again as
 // soon as the tile is split, and are refilled THEN with the next group's values: one raw set, a whole group of latency slack.
 // Replaces the same TF ops as gemm_dr_kernel (DeepFM.py:156-158,165-166,213).
-typedef __bf16 dr_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 dr_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float dr_f32x2 __attribute__((ext_vector_type(2)));
-
-template <class F, int... I>
-__device__ __forceinline__ void dr_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, class F>
-__device__ __forceinline__ void dr_static_for(F&& f) { dr_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
-
-struct DrPlanes { u32x4 h, m, l; };
-
-__device__ __forceinline__ unsigned dr_pk_bf16(float a, float b) {          // v_cvt_pk_bf16_f32: a -> low half, b -> high half, RNE
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(dr_f32x2{a, b}, dr_bf16x2));
-}
-// (plain v_sub_f32: hipcc's SLP pass would pair them into v_pk_add_f32, which costs more issue time beside MFMAs than two subs)
-__device__ __forceinline__ float dr_sub(float a, float b) {
-#ifdef DR3_PK_SUB
-    return a - b;
-#else
-    float r;
-    asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-#endif
-}
-__device__ __forceinline__ void dr_split3(const float (&x)[8], DrPlanes& p) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const float x0 = x[2 * t], x1 = x[2 * t + 1];
-        const unsigned h = dr_pk_bf16(x0, x1);
-        const float r0 = dr_sub(x0, __uint_as_float(h << 16)), r1 = dr_sub(x1, __uint_as_float(h & 0xffff0000u));
-        const unsigned m = dr_pk_bf16(r0, r1);
-        const float s0 = dr_sub(r0, __uint_as_float(m << 16)), s1 = dr_sub(r1, __uint_as_float(m & 0xffff0000u));
-        p.h[t] = h;
-        p.m[t] = m;
-        p.l[t] = dr_pk_bf16(s0, s1);
-    }
-}
-__device__ __forceinline__ f32x4 dr_mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dr_bf16x8, a), __builtin_bit_cast(dr_bf16x8, b), c, 0, 0, 0);
-}
-
 // Tiles of up to 14 accumulators (2 x 7: 32 x 112) are compiled for TWO blocks per CU (<= 256 registers, 42 KB of LDS): one wave
 // per SIMD issues about one instruction per 5 cycles (MI355X_MICROARCH.md: <= 5 fillers per 32-cycle MFMA), which makes the
 // ~2.9 split VALU ops per 17-cycle MFMA the bound; with a second block's wave on the same SIMD the two streams fill each other's
@@ -695,24 +742,31 @@ __device__ __forceinline__ f32x4 dr_mfma_bf16(const u32x4& a, const u32x4& b, co
 // [plane][k / 8][column][8] (dr_wsplit_kernel writes them once per optimizer step; `B` points at plane 0, `ldb` = columns of a plane
 // row, `bplane` = bytes from one plane to the next).  Every CU of a row block needs every weight element, so splitting weights
 // in the product costs 64 x the VALU work of splitting them where they are written; the activations (A) are still split here.
-template <int TM, int TN, bool A_RC, bool B_RC, bool CS, int EPI, bool B_PRE = false>
-__global__ __launch_bounds__(256, DR3_MIN_WAVES(TM, TN)) void gemm_dr3_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                          float* __restrict__ C, int ldc, int M, int N, int K, int kchunk, int nbn, DrEpilogue ep,
-                                                          int64_t bplane) {
-    static_assert(!B_PRE || (B_RC && !CS), "pre-split B: tiles cover plain column blocks (B_RC = true for the epilogue's column map); not a weight gradient");
+// A_PRE (round 6): the A operand arrives as planes too, [plane][k / 8][row][8] (`lda` = rows of a plane row, `aplane` = bytes between
+// planes): the weight-gradient product dW = X^T dY reduces over the BATCH rows, and both of its operands leave their producers'
+// epilogues blocked along those rows (DrEpilogue::cf) -- the main loop is then loads and MFMAs only, 3 (TM + TN) 16-byte loads per 6 TM TN
+// MFMAs, and a 2 x 7 tile fits two blocks per CU beside the dgrad blocks of the layer below.  Hybrid (A f32, reduction rows, split in
+// registers; B planes) is the first layer's weight gradient: its A is the gathered embeddings, which nobody's epilogue writes.
+//
+// The kernel body is a device function of a VIRTUAL block index (vb of gx tiles x gy reduction splits) so that two products can share
+// one launch (gemm_dr3_pair_kernel: a layer's weight gradient and the dgrad of the layer below read the same dY and are independent).
+template <int TM, int TN, bool A_RC, bool B_RC, bool CS, int EPI, bool B_PRE = false, bool A_PRE = false>
+__device__ __forceinline__ void gemm_dr3_body(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc, int M, int N,
+                                              int K, int kchunk, int nbn, const DrEpilogue& ep, int64_t bplane, int64_t aplane, int vb, int gx, int gy, float* dr_lds) {
+    static_assert(!B_PRE || (B_RC && !CS), "pre-split B: tiles cover plain column blocks (B_RC = true for the epilogue's column map); no column sums from raw registers");
+    static_assert(!A_PRE || (A_RC && B_PRE), "pre-split A: plain row blocks (A_RC = true for the epilogue's row map), with pre-split B");
     constexpr int TQ = B_RC ? 0 : TN / 4;                    // quads of B tiles sharing one dwordx4 per lane (NC only)
     constexpr int VA = A_RC ? 1 : (TM % 4 == 0 ? 4 : (TM % 2 == 0 ? 2 : 1));
     constexpr int AG = TM / VA;                              // A load groups per e (NC only)
-    extern __shared__ __attribute__((aligned(16))) float dr_lds[];
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int c = lane & 15, q = lane >> 4;
     int bm, bn, split;
     {   // XCD-aware order, as gemm_dr_kernel
-        const int nwg = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+        const int nwg = gx * gy, b = vb;
         const int qq = nwg / 8, r = nwg % 8, xcd = b % 8, idx = b / 8;
         const int lb = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
-        split = __builtin_amdgcn_readfirstlane(lb / (int)gridDim.x);
-        const int tile = lb - split * (int)gridDim.x;
+        split = __builtin_amdgcn_readfirstlane(lb / gx);
+        const int tile = lb - split * gx;
         bn = tile % nbn;
         bm = tile / nbn;
     }
@@ -731,8 +785,8 @@ __global__ __launch_bounds__(256, DR3_MIN_WAVES(TM, TN)) void gemm_dr3_kernel(co
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const float* Ab = A + (A_RC ? (size_t)m0 * lda + kbeg : (size_t)kbeg * lda + m0);
-    // (pre-split: plane rows of 8 k, 16 bytes per (k-block, column); kbeg is a multiple of 8)
+    // (pre-split: plane rows of 8 k, 16 bytes per (k-block, row / column); kbeg is a multiple of 8)
+    const float* Ab = A_PRE ? A + ((size_t)(kbeg / 8) * lda + m0) * 4 : A + (A_RC ? (size_t)m0 * lda + kbeg : (size_t)kbeg * lda + m0);
     const float* Bb = B_PRE ? B + ((size_t)(kbeg / 8) * ldb + n0) * 4 : B + (B_RC ? (size_t)n0 * ldb + kbeg : (size_t)kbeg * ldb + n0);
     auto clip31 = [](int64_t floats) -> int {
         const int hi = (int)(floats >> 32);
@@ -742,8 +796,9 @@ __global__ __launch_bounds__(256, DR3_MIN_WAVES(TM, TN)) void gemm_dr3_kernel(co
     // num_records: an operand whose rows ARE the reduction ends at this wave's last row -- whatever a partial or surplus group
     // addresses beyond it reads as 0 without touching memory; a reduction-contiguous operand ends at the end of the matrix and
     // its k beyond kend (the next wave's) are masked by lane offsets below
-    const int bytesA = clip31(A_RC ? (int64_t)(min(M - m0, 16 * TM) - 1) * lda + (K - kbeg) : (int64_t)(kend - kbeg - 1) * lda + (M - m0));
-    const int bytesB = B_PRE ? clip31(((int64_t)((kend - kbeg + 7) / 8 - 1) * ldb + (ldb - n0)) * 4)        // this wave's k-blocks of ONE plane (in floats: 4 per entry)
+    const int bytesA = A_PRE ? clip31(((int64_t)((kend - kbeg + 7) / 8 - 1) * lda + (lda - m0)) * 4)        // this wave's k-blocks of ONE plane (in floats: 4 per entry)
+                       : clip31(A_RC ? (int64_t)(min(M - m0, 16 * TM) - 1) * lda + (K - kbeg) : (int64_t)(kend - kbeg - 1) * lda + (M - m0));
+    const int bytesB = B_PRE ? clip31(((int64_t)((kend - kbeg + 7) / 8 - 1) * ldb + (ldb - n0)) * 4)
                        : clip31(B_RC ? (int64_t)(min(N - n0, 16 * TN) - 1) * ldb + (K - kbeg) : (int64_t)(kend - kbeg - 1) * ldb + (N - n0));
     auto uni_ptr = [](const float* p) {
         const uint64_t v = reinterpret_cast<uint64_t>(p);
@@ -757,10 +812,16 @@ __global__ __launch_bounds__(256, DR3_MIN_WAVES(TM, TN)) void gemm_dr3_kernel(co
     const float* Bb2 = B_PRE ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(Bb) + 2 * bplane) : Bb;
     const auto rb1 = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(Bb1), 0, __builtin_amdgcn_readfirstlane(kend > kbeg ? bytesB : 0), 0x00020000);
     const auto rb2 = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(Bb2), 0, __builtin_amdgcn_readfirstlane(kend > kbeg ? bytesB : 0), 0x00020000);
-    constexpr int NA = A_RC ? TM : AG, NB = B_PRE ? 1 : (B_RC ? TN : TQ + (TN - 4 * TQ));         // lane offsets per operand
+    const float* Ab1 = A_PRE ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(Ab) + aplane) : Ab;
+    const float* Ab2 = A_PRE ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(Ab) + 2 * aplane) : Ab;
+    const auto ra1 = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(Ab1), 0, __builtin_amdgcn_readfirstlane(kend > kbeg ? bytesA : 0), 0x00020000);
+    const auto ra2 = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(Ab2), 0, __builtin_amdgcn_readfirstlane(kend > kbeg ? bytesA : 0), 0x00020000);
+    constexpr int NA = A_PRE ? 1 : (A_RC ? TM : AG), NB = B_PRE ? 1 : (B_RC ? TN : TQ + (TN - 4 * TQ));         // lane offsets per operand
     int aoff[NA], boff[NB];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) aoff[i] = 4 * (A_RC ? (16 * i + c) * lda + 8 * q : 8 * q * lda + 16 * VA * i + VA * c);
+    for (int i = 0; i < NA; ++i)
+        aoff[i] = A_PRE ? 16 * (q * lda + c)                 // (tile i: + 256 i bytes, group g: + 64 g lda bytes -- scalar)
+                  : 4 * (A_RC ? (16 * i + c) * lda + 8 * q : 8 * q * lda + 16 * VA * i + VA * c);
 #pragma unroll
     for (int j = 0; j < NB; ++j)
         boff[j] = B_PRE ? 16 * (q * ldb + c)                 // (tile j: + 256 j bytes, group g: + 64 g ldb bytes -- scalar)
@@ -769,7 +830,7 @@ __global__ __launch_bounds__(256, DR3_MIN_WAVES(TM, TN)) void gemm_dr3_kernel(co
     // reduction-contiguous pieces (k = 32 g + 8 q + 4 p .. + 3, p = 0, 1) are real while 32 g < lim[p]
     const int lim0 = (kend - kbeg) - 8 * q, lim1 = lim0 - 4;
 
-    struct Raw { float a[TM][8]; float b[B_PRE ? 1 : TN][8]; };
+    struct Raw { float a[A_PRE ? 1 : TM][8]; float b[B_PRE ? 1 : TN][8]; };
     auto ld4 = [](auto rs, int voff, unsigned soff_, float* d, int stride) {
         const unsigned soff = __builtin_amdgcn_readfirstlane(soff_);
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
@@ -789,7 +850,8 @@ __global__ __launch_bounds__(256, DR3_MIN_WAVES(TM, TN)) void gemm_dr3_kernel(co
     };
     // the loads of group g: A tile / load group i, B unit u
     auto loadA = [&](Raw& f, int g) {
-        if constexpr (A_RC) {
+        if constexpr (A_PRE) {
+        } else if constexpr (A_RC) {
             const bool ok0 = 32 * g < lim0, ok1 = 32 * g < lim1;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -809,7 +871,8 @@ __global__ __launch_bounds__(256, DR3_MIN_WAVES(TM, TN)) void gemm_dr3_kernel(co
         }
     };
     auto loadB = [&](Raw& f, int u, int g) {
-        if constexpr (B_RC) {
+        if constexpr (B_PRE) {
+        } else if constexpr (B_RC) {
             const bool ok0 = 32 * g < lim0, ok1 = 32 * g < lim1;
             ld4(rb, ok0 ? boff[u] : 0x7ffffff0, 128u * g, &f.b[u][0], 1);
             ld4(rb, ok1 ? boff[u] + 16 : 0x7ffffff0, 128u * g, &f.b[u][4], 1);
@@ -853,8 +916,18 @@ __global__ __launch_bounds__(256, DR3_MIN_WAVES(TM, TN)) void gemm_dr3_kernel(co
         pw[j].m = __builtin_amdgcn_raw_buffer_load_b128(rb1, boff[0], so, 0);
         pw[j].l = __builtin_amdgcn_raw_buffer_load_b128(rb2, boff[0], so, 0);
     };
+    // pre-split A: the planes of A tile i of group g (a group beyond the wave's range is all out of range: zeros, no traffic)
+    auto loadAP = [&](DrPlanes& d, int i, int g) {
+        const unsigned so = __builtin_amdgcn_readfirstlane(64u * g * (unsigned)lda + 256u * i);
+        d.h = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff[0], so, 0);
+        d.m = __builtin_amdgcn_raw_buffer_load_b128(ra1, aoff[0], so, 0);
+        d.l = __builtin_amdgcn_raw_buffer_load_b128(ra2, aoff[0], so, 0);
+    };
     if (G > 0) {
-        loadA(f, 0);
+        if constexpr (A_PRE) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) loadAP(pa[i], i, 0);
+        } else loadA(f, 0);
         if constexpr (B_PRE) {
 #pragma unroll
             for (int j = 0; j < TN - 1; ++j) loadW(j, 0);     // (tile TN - 1 is loaded in the first region of the first group)
@@ -895,7 +968,8 @@ __global__ __launch_bounds__(256, DR3_MIN_WAVES(TM, TN)) void gemm_dr3_kernel(co
     };
     // A refill of the raw registers of A tile i / load group i for group g (its values of the group before have all been split)
     auto loadA_unit = [&](int i, int g) {
-        if constexpr (A_RC) {
+        if constexpr (A_PRE) {
+        } else if constexpr (A_RC) {
             const bool ok0 = 32 * g < lim0, ok1 = 32 * g < lim1;
             ld4(ra, ok0 ? aoff[i] : 0x7ffffff0, 128u * g, &f.a[i][0], 1);
             ld4(ra, ok1 ? aoff[i] + 16 : 0x7ffffff0, 128u * g, &f.a[i][4], 1);
@@ -911,20 +985,23 @@ __global__ __launch_bounds__(256, DR3_MIN_WAVES(TM, TN)) void gemm_dr3_kernel(co
     };
     __builtin_amdgcn_sched_barrier(0);
     if (G > 0) {                                              // group 0's A planes and first B tile, exposed once
+        if constexpr (!A_PRE) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) dr_split3(f.a[i], pa[i]);
+            for (int i = 0; i < TM; ++i) dr_split3(f.a[i], pa[i]);
+        }
         if constexpr (!B_PRE) {
             split_b(0, pb0);
             if (last_of_unit(0)) loadB(f, unit_of(0), 1);     // (a group beyond the wave's range is all out of range: zeros, no traffic)
         }
-        loadA(f, 1);
+        if constexpr (!A_PRE) loadA(f, 1);
     }
     // One group = TN tile regions fenced by sched_barrier(0) (nothing crosses a fence: the loads stay where they are written, next
     // to the split that frees their registers -- left alone, hipcc sinks every load without a user in the block to its end).  Region j:
     //   the 6 TM MFMAs of B tile j  ||  the split of B tile j + 1 (tile 0 of the next group in the last region), 1 / TN of the next
     //   group's A splits (pair by pair), and the refills of whatever raw registers those splits freed.
     // The A planes alternate between two sets (cur, nxt); pb0 / pb1 alternate by tile parity (TN odd: they swap roles per group,
-    // which is why `par` is a parameter).
+    // which is why `par` is a parameter).  Pre-split A: the next group's A planes are REQUESTED in the first regions of the group (one tile
+    // per region: a whole group of latency slack) straight into the other set.
     constexpr int NPA = 4 * TM;                               // A pairs of a group
     auto body = [&](DrPlanes (&cur)[TM], DrPlanes (&nxt)[TM], int g, auto parc) {
         constexpr int PAR = decltype(parc)::value;            // parity of (tile index -> pb set) at tile 0 of this group
@@ -942,6 +1019,9 @@ __global__ __launch_bounds__(256, DR3_MIN_WAVES(TM, TN)) void gemm_dr3_kernel(co
                 split_b(jn, pn);
                 if constexpr (LB) loadB(f, unit_of(jn), j + 1 < TN ? g + 1 : g + 2);
             }
+            if constexpr (A_PRE) {
+                if constexpr (j < TM) loadAP(nxt[j], j, g + 1);
+            } else {
             // the next group's A pairs p0 .. p1 - 1
             constexpr int p0 = j * NPA / TN, p1 = (j + 1) * NPA / TN;
 #pragma unroll
@@ -958,16 +1038,19 @@ __global__ __launch_bounds__(256, DR3_MIN_WAVES(TM, TN)) void gemm_dr3_kernel(co
                 // raw registers complete: RC per tile, NC per load group of VA tiles
                 if (tt == 3 && (A_RC || (i % VA) == VA - 1)) loadA_unit(A_RC ? i : i / VA, g + 2);
             }
+            }
             if constexpr (B_PRE) mma(cur, pw[j], j);
             else mma(cur, pc, j);
-            constexpr int NVAL = (B_PRE ? 0 : 44 + (CS ? 8 : 0)) + 11 * (p1 - p0) + (LB && B_RC ? 2 : 0) + (A_RC ? 4 : 0);
+            constexpr int NPAIR = A_PRE ? 0 : ((j + 1) * NPA / TN - j * NPA / TN);
+            constexpr int NVAL = (B_PRE ? 0 : 44 + (CS ? 8 : 0)) + 11 * NPAIR + (LB && B_RC ? 2 : 0) + (A_RC && !A_PRE ? 4 : 0);
             constexpr int NM = 6 * TM;
             constexpr int PER = (NVAL + NM - 1) / NM;
+            constexpr int NLD = A_PRE ? 3 + (j < TM ? 3 : 0) : 16;       // pre-split: spread the region's 16-byte loads over its first MFMAs
 #pragma unroll
             for (int k = 0; k < NM; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x2, PER, 0);
-                if (k < 16) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+                if constexpr (PER > 0) __builtin_amdgcn_sched_group_barrier(0x2, PER, 0);
+                if (k < NLD) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
             }
         });
         __builtin_amdgcn_sched_barrier(0);
@@ -986,6 +1069,43 @@ __global__ __launch_bounds__(256, DR3_MIN_WAVES(TM, TN)) void gemm_dr3_kernel(co
     float cs2[1] = {0.f};
     dr_finish<TM, TN, A_RC, B_RC, CS, EPI, false>(acc, cs, cs2, ep, C, ldc, M, N, m0, n0, bm, split, keep_lo, keep_hi, dr_lds);     // (B_PRE: B_RC = true -> plain column blocks)
     DR_STAMP(5);
+}
+
+template <int TM, int TN, bool A_RC, bool B_RC, bool CS, int EPI, bool B_PRE = false, bool A_PRE = false>
+__global__ __launch_bounds__(256, DR3_MIN_WAVES(TM, TN)) void gemm_dr3_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                          float* __restrict__ C, int ldc, int M, int N, int K, int kchunk, int nbn, DrEpilogue ep,
+                                                          int64_t bplane, int64_t aplane) {
+    extern __shared__ __attribute__((aligned(16))) float dr_lds[];
+    gemm_dr3_body<TM, TN, A_RC, B_RC, CS, EPI, B_PRE, A_PRE>(A, lda, B, ldb, C, ldc, M, N, K, kchunk, nbn, ep, bplane, aplane,
+                                                             (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.x, (int)gridDim.y, dr_lds);
+}
+
+// Two products in ONE launch: blocks [0, n1) run product 1 (x tiles, then reduction splits), blocks [n1, n1 + n2) product 2.  A layer's
+// weight gradient dW_l = X_l^T dY_l and the dgrad of the layer below dX_l = dY_l W_l^T (the input gradient through the SAME layer) read the
+// same dY_l and nothing of each other: launched as one grid they need no cross-stream record on the critical stream (an event is a
+// barrier packet: ~5 us of drained pipeline each, round-6 timeline), the dispatcher hands a CU that finishes a block of one the next block
+// of either, and with both tiles at two blocks per CU a block's prologue / cross-wave reduction / stores run under another's MFMAs.
+// Both bodies must be compiled for the same occupancy (the launch bounds are the pair's).
+template <int TM_, int TN_, bool A_RC_, bool B_RC_, bool CS_, int EPI_, bool B_PRE_, bool A_PRE_>
+struct Dr3Cfg {
+    static constexpr int TM = TM_, TN = TN_, EPI = EPI_;
+    static constexpr bool A_RC = A_RC_, B_RC = B_RC_, CS = CS_, B_PRE = B_PRE_, A_PRE = A_PRE_;
+};
+struct Dr3Arg {
+    const float* A; int lda; const float* B; int ldb; float* C; int ldc; int M, N, K, kchunk, nbn; DrEpilogue ep; int64_t bplane, aplane;
+    int gx, gy;                 // tiles, reduction splits
+};
+template <class P1, class P2>
+__global__ __launch_bounds__(256, 2) void gemm_dr3_pair_kernel(Dr3Arg a, Dr3Arg b, int n1) {
+    static_assert(P1::TM * P1::TN <= 14 && P2::TM * P2::TN <= 14, "both products at two blocks per CU");
+    extern __shared__ __attribute__((aligned(16))) float dr_lds[];
+    const int hb = (int)blockIdx.x;
+    if (hb < n1)
+        gemm_dr3_body<P1::TM, P1::TN, P1::A_RC, P1::B_RC, P1::CS, P1::EPI, P1::B_PRE, P1::A_PRE>(a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.M, a.N, a.K, a.kchunk, a.nbn, a.ep,
+                                                                                                  a.bplane, a.aplane, hb, a.gx, a.gy, dr_lds);
+    else
+        gemm_dr3_body<P2::TM, P2::TN, P2::A_RC, P2::B_RC, P2::CS, P2::EPI, P2::B_PRE, P2::A_PRE>(b.A, b.lda, b.B, b.ldb, b.C, b.ldc, b.M, b.N, b.K, b.kchunk, b.nbn, b.ep,
+                                                                                                  b.bplane, b.aplane, hb - n1, b.gx, b.gy, dr_lds);
 }
 
 // W [K][N] (row stride ldw) -> the two pre-split forms the forward and the dgrad product read (B_PRE above):

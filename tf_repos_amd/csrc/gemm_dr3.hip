@@ -43,11 +43,11 @@ int dr3_launch(const float* A, int lda, const float* B, int ldb, int64_t bplane,
     const dim3 grid((unsigned)(nbm * nbn), (unsigned)splits);
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (take_timer_events(&t0, &t1)) {              // (dctr_step_timer mode 2: this dispatch's own start / stop events)
-        hipExtLaunchKernelGGL(kern, grid, dim3(256), (uint32_t)lds, st, t0, t1, 0, A, lda, B, ldb, C, ldc, M, N, K, kchunk, nbn, ep, bplane);
+        hipExtLaunchKernelGGL(kern, grid, dim3(256), (uint32_t)lds, st, t0, t1, 0, A, lda, B, ldb, C, ldc, M, N, K, kchunk, nbn, ep, bplane, (int64_t)0);
     } else if (hipEvent_t stop = take_stop_event()) {      // (the engine's next cross-stream record rides on this launch: common.h)
-        hipExtLaunchKernelGGL(kern, grid, dim3(256), (uint32_t)lds, st, nullptr, stop, 0, A, lda, B, ldb, C, ldc, M, N, K, kchunk, nbn, ep, bplane);
+        hipExtLaunchKernelGGL(kern, grid, dim3(256), (uint32_t)lds, st, nullptr, stop, 0, A, lda, B, ldb, C, ldc, M, N, K, kchunk, nbn, ep, bplane, (int64_t)0);
     } else {
-        kern<<<grid, 256, lds, st>>>(A, lda, B, ldb, C, ldc, M, N, K, kchunk, nbn, ep, bplane);
+        kern<<<grid, 256, lds, st>>>(A, lda, B, ldb, C, ldc, M, N, K, kchunk, nbn, ep, bplane, (int64_t)0);
     }
     DCTR_LAUNCH_CHECK();
     g_dr3_launches.fetch_add(1, std::memory_order_relaxed);

@@ -136,6 +136,7 @@ __device__ __forceinline__ void lag_replay_rows(const StepState* __restrict__ S,
     //  otherwise index the ring per lane: a vector load.  The ring index needs the low bits only.)
     const int ilast = __builtin_amdgcn_readfirstlane((int)last);
     float lr = S->lr_hist[(ilast - kmax + 1) & (LR_HIST - 1)];
+#ifdef DCTR_LAG_SELECT          // (A/B: rounds 4-5 -- every lane takes the update, a lane that is not that far behind selects it away: 3 v_cndmask per ELEMENT and step)
     for (int k = kmax; k >= 1; --k) {                               // step last - k + 1
         const float lr_next = S->lr_hist[(ilast - k + 2) & (LR_HIST - 1)];     // (of step last - k + 2: the next iteration's; k = 1 reads one entry past `last`, unused)
         h.lr_t = lr;
@@ -160,6 +161,40 @@ __device__ __forceinline__ void lag_replay_rows(const StepState* __restrict__ S,
         }
         lr = lr_next;
     }
+#else
+    // Round 6: the replay is VALU-bound (tools/lag_probe.hip: the 1/8 sweep of c2 is 17 M element-updates; per update the ISA of the
+    // select form spent 12 VALU slots of 4 cycles + sqrt and rcp at 16: ~73 cycles per element and wave, of which 12 were the three selects
+    // and 9 register copies around them).  A lane that is not behind that far now runs the step with the IDENTITY's coefficients instead
+    // -- beta = 1, 1 - beta = 0, lr_t = 0: m' = 1 m + 0 g = m, v' = 1 v + (0 g) g = v, theta' = theta - (0 m') rcp(..) = theta, exactly (m, v,
+    // theta finite; sqrt(v) + eps > 0) -- five selects per ROW and step in place of three per element, and the updates go to the rows'
+    // registers in place.  A lane that takes part computes opt_update's Adam expressions, operand for operand.  The rows' linear weights
+    // ride on their row's coefficients: nl[r] is n[r] on the lane that owns the weight and 0 elsewhere, where lt / lm / lv are zeros or
+    // never stored (a zero stays a zero under the update).  PRECONDITION: th / m / v of EVERY lane are finite numbers (zeros where nothing was
+    // loaded), also on lanes with n[r] = 0: 0 x NaN is NaN.
+    const float c1 = 1.0f - h.beta1, c2 = 1.0f - h.beta2;
+    auto step = [&](float& t, float& a, float& b, float b1, float a1, float b2, float a2, float lrk) {
+        const float g = l2 * t;
+        a = b1 * a + a1 * g;
+        b = b2 * b + a2 * g * g;
+        if constexpr (ADAM_TABLES_EXACT) t = t - lrk * a / (sqrtf(b) + h.eps);
+        else t = t - (lrk * a) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(b) + h.eps);
+    };
+    for (int k = kmax; k >= 1; --k) {                               // step last - k + 1
+        const float lr_next = S->lr_hist[(ilast - k + 2) & (LR_HIST - 1)];     // (of step last - k + 2: the next iteration's; k = 1 reads one entry past `last`, unused)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (SKIP && !__any(k <= n[r] || (LIN && k <= nl[r]))) continue;
+            const bool on = k <= n[r];
+            const float b1 = on ? h.beta1 : 1.f, a1 = on ? c1 : 0.f, b2 = on ? h.beta2 : 1.f, a2 = on ? c2 : 0.f, lrk = on ? lr : 0.f;
+            step(th[r].x, m[r].x, v[r].x, b1, a1, b2, a2, lrk);
+            step(th[r].y, m[r].y, v[r].y, b1, a1, b2, a2, lrk);
+            step(th[r].z, m[r].z, v[r].z, b1, a1, b2, a2, lrk);
+            step(th[r].w, m[r].w, v[r].w, b1, a1, b2, a2, lrk);
+            if (LIN) step(lt[r], lm[r], lv[r], b1, a1, b2, a2, lrk);
+        }
+        lr = lr_next;
+    }
+#endif
 }
 // R row pieces, each n[r] steps behind `last` (its steps last - n[r] + 1 .. last are replayed)
 template <int R>

@@ -75,8 +75,8 @@ void run(const char* name, int M, int N, int K, int splits = 1) {
     auto launch = [&]() {
         // fwd (B = W [K][N]): the k-blocked form of W, plane rows of N columns; dgrad (B stored [N][K], reduction over its columns): the
         // column-blocked form, plane rows of N entries
-        if constexpr (BP) gemm_dr3_kernel<TM, TN, A_RC, true, CS, EPI, true><<<dim3(nbm * nbn, splits), 256, lds, 0>>>(A, lda, (const float*)(B_RC ? pd : pf), N, C, N, M, N, K, kchunk, nbn, ep, (B_RC ? nde : nfe) * 16);
-        else if constexpr (P3) gemm_dr3_kernel<TM, TN, A_RC, B_RC, CS, EPI><<<dim3(nbm * nbn, splits), 256, lds, 0>>>(A, lda, B, ldb, C, N, M, N, K, kchunk, nbn, ep, 0);
+        if constexpr (BP) gemm_dr3_kernel<TM, TN, A_RC, true, CS, EPI, true><<<dim3(nbm * nbn, splits), 256, lds, 0>>>(A, lda, (const float*)(B_RC ? pd : pf), N, C, N, M, N, K, kchunk, nbn, ep, (B_RC ? nde : nfe) * 16, 0);
+        else if constexpr (P3) gemm_dr3_kernel<TM, TN, A_RC, B_RC, CS, EPI><<<dim3(nbm * nbn, splits), 256, lds, 0>>>(A, lda, B, ldb, C, N, M, N, K, kchunk, nbn, ep, 0, 0);
         else gemm_dr_kernel<TM, TN, A_RC, B_RC, CS, EPI><<<dim3(nbm * nbn, splits), 256, lds, 0>>>(A, lda, B, ldb, C, N, M, N, K, kchunk, nbn, ep, DrOuter{});
     };
     launch();
