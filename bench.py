@@ -11,8 +11,8 @@ Workloads (--config):
 f32 arithmetic, synthetic Criteo-shaped libsvm-equivalent tensors already resident in HBM, random-init N(0,0.01) weights.
 A "step" = forward + loss + backward + optimizer over one batch, table optimizer in DENSE-EXACT mode (what the reference's TF
 graph does: l2_loss on the tables makes the optimizer stream all V rows every step).
-Prints ONE JSON line (rank 0).  `roofline` is the kernel that dominates the step (the first MLP layer's forward GEMM, timed
-inside the steps); `cpu_baseline` is the torch-CPU restatement of the reference's TF-1.4 graph (oracle/, "port") timed on this
+Prints ONE JSON line (rank 0).  `roofline` is the kernel TEMPLATE with the most time in the timed steps (the weight-gradient product of the MLP;
+every product's dispatch carries its own start / stop events) with `roofline.family` = all nine MLP products; `cpu_baseline` is the torch-CPU restatement of the reference's TF-1.4 graph (oracle/, "port") timed on this
 box's host cores by the protocol of BASELINE.md section 3.
 """
 import argparse
@@ -200,18 +200,25 @@ def fill_normal_(t, scale, seed):
         flat[s:s + step].normal_(0.0, scale, generator=g)
 
 
-def hbm_resident_gather(dev, K=16, V=64 * 1024 * 1024, B=4096, F=39, iters=200):
+def hbm_resident_gather(dev, K=16, V=64 * 1024 * 1024, B=4096, F=39, iters=200, zipf=False):
     """The gather kernel alone on a table far larger than the 256 MB Infinity Cache (V = 64 M rows x K = 16: 4.3 GB) with uniform
-    ids: algorithmic bytes B (F (12 + 8K) + 8) over the hipEvent time of back-to-back launches through the op-level C ABI."""
+    ids -- or (zipf) the workload's own Criteo-shaped ids: 13 always-hit numeric ids, 26 categorical fields with field-disjoint Zipf
+    ranks (tf_repos_amd/synth.py, the generator the timed steps use): algorithmic bytes B (F (12 + 8K) + 8) over the hipEvent time of
+    back-to-back launches through the op-level C ABI."""
+    import numpy as np
     import torch
     from tf_repos_amd import capi
+    from tf_repos_amd.synth import synth_batch
     L = capi.lib()
     emb = torch.zeros(V, K, device=dev)
     lin = torch.zeros(V, device=dev)
     g = torch.Generator(device=dev)
     g.manual_seed(7)
     nb = 8
-    ids = [torch.randint(0, V, (B, F), device=dev, dtype=torch.int32, generator=g) for _ in range(nb)]
+    if zipf:
+        ids = [torch.from_numpy(synth_batch(B, F, V, seed=20260924 + 500 + i)[0]).to(dev) for i in range(nb)]
+    else:
+        ids = [torch.randint(0, V, (B, F), device=dev, dtype=torch.int32, generator=g) for _ in range(nb)]
     vals = torch.rand(B, F, device=dev)
     e = torch.empty(B, F * K, device=dev)
     yw, yv, S = torch.empty(B, device=dev), torch.empty(B, device=dev), torch.empty(B, K, device=dev)
@@ -287,8 +294,47 @@ def end_to_end(w, epochs=40, lines=32768 * 12):
     est.train(input_fn=lambda: mod.input_fn([cold], num_epochs=1, batch_size=B))
     torch.cuda.synchronize()
     dt_cold = time.perf_counter() - t0
+    # ... and the text really STREAMED: LibsvmDataset(streaming=True) (DCTR_INPUT_STREAMING=1) decodes the file in 64-MB chunks of whole
+    # lines, chunk c + 1 on the library's thread team (num_parallel_calls = 10, DeepFM.py:84) while the batches of chunk c go through the
+    # feeder's pinned buffers into the input slots and the steps run -- nothing cached, every epoch decodes the text again, like tf.data.
+    # A file large enough that a pass lasts several hundred steps; steady state = the slope between a 1-epoch and a 3-epoch call.
+    stream = None
+    try:
+        big_path = os.path.join(d, "stream.libsvm")
+        reps = int(os.environ.get("DCTR_BENCH_STREAM_CHUNKS", "128"))            # x 32 768 lines (395 B each): 4.2 M lines, 1.6 GB of text
+        with open(big_path, "w") as f:
+            for _ in range(reps):
+                f.write(chunk)
+        n_big = 32768 * reps
+        os.environ["DCTR_INPUT_STREAMING"] = "1"
+
+        def timed_stream(ep):
+            t0 = time.perf_counter()
+            est.train(input_fn=lambda: mod.input_fn([big_path], num_epochs=ep, batch_size=B))
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        d1, d3 = timed_stream(1), timed_stream(3)
+        per_epoch = (d3 - d1) / 2.0
+        # the parser alone on the same file and thread count (what bounds the stream if it is the slower side)
+        from tf_repos_amd.input_pipeline import parse_file
+        t0 = time.perf_counter()
+        parse_file(big_path, F, threads=10)
+        d_parse = time.perf_counter() - t0
+        stream = {"text_streaming_examples_per_sec": round(n_big / per_epoch, 1), "lines": n_big, "file_GB": round(os.path.getsize(big_path) / 1e9, 2),
+                  "one_epoch_call_s": round(d1, 3), "three_epoch_call_s": round(d3, 3), "steady_ms_per_step": round(1e3 * per_epoch / (n_big // B), 4),
+                  "one_epoch_call_examples_per_sec": round(n_big / d1, 1),
+                  "parser_alone_lines_per_sec_10_threads": round(n_big / d_parse, 1),
+                  "what": "Estimator.train over a %.1f-GB libsvm text file with DCTR_INPUT_STREAMING=1: decode (10 parser threads inside the library, chunk "
+                          "by chunk) + batching + H2D + train steps overlapped, no cache; text_streaming_examples_per_sec = lines / ((3-epoch call - "
+                          "1-epoch call) / 2); parser_alone = dctr_parse_libsvm_mt over the whole file with the same 10 threads, nothing else running"
+                          % (os.path.getsize(big_path) / 1e9,)}
+    except Exception as e:                                                     # noqa: BLE001
+        stream = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    finally:
+        os.environ.pop("DCTR_INPUT_STREAMING", None)
     shutil.rmtree(d, ignore_errors=True)
     return {"examples_per_sec": round(n_lines * epochs / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps, "wall_s": round(dt, 3),
+            "text_streaming": stream,
             "steady_examples_per_sec": round(B / per_step, 1), "steady_ms_per_step": round(1e3 * per_step, 4),
             "fixed_cost_s": round(dt - per_step * steps, 3),
             "cold_text_one_epoch": {"examples_per_sec": round(n_lines / dt_cold, 1), "wall_s": round(dt_cold, 3), "steps": n_lines // B,
@@ -561,12 +607,22 @@ def main():
                 g_ms, g_bytes = hbm_resident_gather(dev, K=32, V=32 * 1024 * 1024, B=B, F=F)
                 kernels["embed_gather_fwd_k32_hbm"] = {"bound": "hbm", "ms": g_ms, "achieved": g_bytes / g_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                        "note": "c5's row shape: K = 32 (a row = one 128-byte granule), 32 M-row table (4.4 GB), uniform ids; layouts compared in profiles/r03_gather_layouts.txt"}
+                # the distribution the path actually sees at c5 (BASELINE configs[4]): ONE shard of the 1e8-row table on a GPU (1.25e7 rows,
+                # K = 32: 1.6 GB + Adam slots elsewhere), 8192 examples per step -- Zipf ids from the workload's generator, and uniform ids
+                # over the same shard as the worst case (round-5 verdict item 6)
+                for tag, zf in (("zipf", True), ("uniform", False)):
+                    g_ms, g_bytes = hbm_resident_gather(dev, K=32, V=12_500_000, B=8192, F=F, iters=100, zipf=zf)
+                    kernels["embed_gather_fwd_c5_shard_%s" % tag] = {
+                        "bound": "hbm", "ms": g_ms, "achieved": g_bytes / g_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "note": "c5's shard shape: 1.25e7 rows x K = 32 (1.6 GB table), B = 8192, %s ids" % ("Criteo-shaped Zipf (synth_batch)" if zf else "uniform")}
         out["hbm_measured_copy_GBps"] = round(copy_gbps, 1)        # (measured before the warm-up steps, see there)
         # the gathers, memory side: a random access costs a 128-byte granule whatever it asks for (profiles/r02_gather_hbm_pmc.txt: 41.2 MB
         # fetched per launch at K = 16 AND at K = 32) -- one per row piece of <= 128 B and one per 4-byte linear weight -- plus e written
-        for kn, kk in (("embed_gather_fwd", K), ("embed_gather_fwd_k32_hbm", 32)):
+        for kn, kk, bb in (("embed_gather_fwd", K, B), ("embed_gather_fwd_k32_hbm", 32, B), ("embed_gather_fwd_c5_shard_zipf", 32, 8192),
+                           ("embed_gather_fwd_c5_shard_uniform", 32, 8192)):
             if kn in kernels:
-                ms_side = B * F * (128 * ((4 * kk + 127) // 128) + 128) + B * F * 4 * kk
+                # (an upper bound for Zipf ids: repeated hot rows are served by the caches, not by a granule each)
+                ms_side = bb * F * (128 * ((4 * kk + 127) // 128) + 128) + bb * F * 4 * kk
                 kernels[kn]["memory_side_bytes"] = int(ms_side)
                 kernels[kn]["memory_side_GBps"] = round(ms_side / kernels[kn]["ms"] / 1e6, 1)
                 kernels[kn]["frac_memory_side_of_measured_copy"] = round(ms_side / kernels[kn]["ms"] / 1e6 / copy_gbps, 4)

@@ -8,13 +8,15 @@ What it is: a torch-CPU (fp32, with an fp64 shadow via ``dtype=``) restatement, 
 op, of the TF-1.4 graph that the reference's ``model_fn``s build.  Each function cites
 the reference file:line it follows (paths relative to /root/reference).
 
-PARITY STATUS: **parity unpinned** for the model math.  The reference delegates all
-arithmetic to TensorFlow 1.4, which is not vendored, not installed and not installable
-here, and the reference ships no tests / golden vectors / checkpoints for this path
-(SURVEY.md section 8c).  The formulas tagged [TF-1.4] below are restated from TF 1.4's
-documented semantics.  The *integer bucketing* side is pinned:
-see ``oracle/bucketing_oracle.py`` (checked bit-for-bit against the reference's own
-``get_criteo_feature.py`` executed in this container; fixtures in tests/golden/).
+PARITY STATUS: pinned to the reference's own SOURCE since round 2, not to TensorFlow.  TensorFlow 1.4 is not vendored, not
+installed and not installable here, and the reference ships no tests / golden vectors / checkpoints for this path (SURVEY.md
+section 8c) -- but every ``tf.*`` call the reference's ``model_fn``s make is recorded as a symbolic graph and evaluated in numpy
+fp64 by ``oracle/graph_eval.py``; ``tests/golden/make_model_golden.py`` writes the results (logits, loss, every gradient, every
+variable after two optimizer steps) as fixtures under ``tests/golden/models/`` and ``tests/test_model_golden.py`` holds THIS module to
+them (1e-9 in fp64, 2e-5 in fp32) for all eight models, the four optimizers, batch-norm and dropout.  What stays ASSUMED (and is
+tagged [TF-1.4] below): the per-op semantics of TF 1.4 itself -- restated from its documentation, never run.
+The *integer bucketing* side is pinned bit for bit: ``oracle/bucketing_oracle.py`` against the reference's own
+``get_criteo_feature.py`` executed in this container (fixtures in tests/golden/).
 """
 from __future__ import annotations
 

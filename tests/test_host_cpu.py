@@ -159,6 +159,27 @@ def test_libsvm_dataset_batches_span_files_and_epochs(tmp_path):
         assert all(s == B for s in sizes[:-1]) and 0 < sizes[-1] <= B, (B, sizes)
 
 
+def test_streaming_dataset_yields_the_batches_of_the_whole_file_parse(tmp_path, monkeypatch):
+    """LibsvmDataset(streaming=True): the file decoded chunk by chunk (chunk c + 1 in a background thread while chunk c is consumed),
+    every epoch again -- the same batches, in the same order, as the whole-file parse, across chunk, file and epoch edges."""
+    from tf_repos_amd.input_pipeline import LibsvmDataset
+    F = 39
+    paths, parts = [], []
+    for i, n in enumerate((9000, 37, 6100)):             # ~3.5 MB, a few lines, ~2.4 MB of text: several 1-MB chunks per large file
+        ids, vals, labels = O.synth_batch(n, F, 1_000_000, seed=20 + i)
+        p = tmp_path / ("s%d.libsvm" % i)
+        p.write_text(O.to_libsvm(ids, vals, labels))
+        paths.append(str(p)); parts.append(ids)
+    monkeypatch.setenv("DCTR_INPUT_CHUNK_MB", "1")
+    for B in (256, 4096):
+        whole = list(LibsvmDataset(paths, F, batch_size=B, num_epochs=2, binary_cache=False, streaming=False))
+        stream = list(LibsvmDataset(paths, F, batch_size=B, num_epochs=2, streaming=True))
+        assert len(whole) == len(stream)
+        for a, b in zip(whole, stream):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert not any(f.endswith(".npz") for f in os.listdir(tmp_path))          # streaming keeps nothing beside the file
+
+
 def test_multithreaded_file_parse_matches_the_serial_parser(tmp_path):
     """dctr_parse_libsvm_mt (thread team inside the library): same rows as the serial decode for any thread count, blank lines
     and CRLF endings included; a malformed line reports the serial parser's message and line number."""

@@ -888,8 +888,13 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
             // (dctr_step_timer mode 2: the backward products carry their own dispatch events too -- layer ids nl + i dgrad, 2 nl + i wgrad)
             const bool tw = E->timer_step && E->timer_mode == 2 && E->timer_n + 2 <= E->timer_ev.size() && !E->bn && !(i == 0 && E->opnn_fused);
             if (tw) arm_timer_events(E->timer_ev[E->timer_n], E->timer_ev[E->timer_n + 1]);
+            // A/B knob DCTR_WGRAD0_LOW_PRIO=1: the first layer's weight gradient -- the one that runs beside the table step the NEXT gather
+            // waits for -- does not raise its waves' issue priority
+            static const bool w0_low = [] { const char* v = getenv("DCTR_WGRAD0_LOW_PRIO"); return v != nullptr && v[0] == '1'; }();
+            GemmOpt gow = go;
+            gow.wgrad_low_prio = (i == 0 && w0_low) ? 1 : 0;
             DCTR_TRY(fc_bwd_weights_partials(x, ldx, E->dh[i], fc.out, E->part(fc.w), w.padded, E->part(fc.b), b.padded, B,
-                                             (i == 0 && E->opnn_fused) ? D : fc.in, fc.out, fc.splits, sw, 1, &go));
+                                             (i == 0 && E->opnn_fused) ? D : fc.in, fc.out, fc.splits, sw, 1, &gow));
             if (tw) {
                 if (timer_events_pending()) disarm_timer_events();
                 else { E->timer_layer.push_back(2 * nl + i); E->timer_n += 2; }

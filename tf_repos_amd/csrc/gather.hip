@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(
     float* __restrict__ red_out, int32_t* __restrict__ status, LagView L, int nt) {
     constexpr int TPE = KQ * FS;           // lanes per example (power of two, <= 64)
     constexpr int EPB = 256 / TPE;         // examples per block
+    if (nt & 2) __builtin_amdgcn_s_setprio(3);      // A/B knob DCTR_GATHER_PRIO=1 (the step's forward waits for this kernel)
     const int tid = threadIdx.x;
     const int sub = tid % TPE;
     const int kq = sub % KQ;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(
                     float4 e;
                     e.x = r[u].x * v[u]; e.y = r[u].y * v[u]; e.z = r[u].z * v[u]; e.w = r[u].w * v[u];
                     typedef float f4v __attribute__((ext_vector_type(4)));
-                    if (nt) __builtin_nontemporal_store(f4v{e.x, e.y, e.z, e.w}, reinterpret_cast<f4v*>(&er[(size_t)f * KQ + kq]));
+                    if (nt & 1) __builtin_nontemporal_store(f4v{e.x, e.y, e.z, e.w}, reinterpret_cast<f4v*>(&er[(size_t)f * KQ + kq]));
                     else er[(size_t)f * KQ + kq] = e;
                     s.x += e.x; s.y += e.y; s.z += e.z; s.w += e.w;
                     q.x += e.x * e.x; q.y += e.y * e.y; q.z += e.z * e.z; q.w += e.w * e.w;
@@ -134,7 +135,7 @@ static int launch_gather(const float* emb, const float* lin, int64_t rows, int e
     if (L.ld4 == 0) L.ld4 = KQ;
     // A/B knob DCTR_GATHER_NT=1: nontemporal stores of e.  Measured SLOWER on the HBM-resident tables it was meant for (K = 32, 32 M rows:
     // 13.25 -> 13.89 us; K = 16, 64 M rows: 11.51 -> 11.92; profiles/r05_gather_k32_variants.txt): off.
-    static const int nt = getenv("DCTR_GATHER_NT") ? atoi(getenv("DCTR_GATHER_NT")) : 0;
+    static const int nt = (getenv("DCTR_GATHER_NT") ? (atoi(getenv("DCTR_GATHER_NT")) & 1) : 0) | ((getenv("DCTR_GATHER_PRIO") && getenv("DCTR_GATHER_PRIO")[0] == '1') ? 2 : 0);
 #define DCTR_GK(MODE_)                                                                                                                  \
     if (lag) gather_fwd_kernel<KQ, FS, MODE_, U, true><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status, L, nt); \
     else gather_fwd_kernel<KQ, FS, MODE_, U, false><<<grid, block, 0, st>>>(emb4, lin, rows, emb_ld / 4, lin_ld, ids, vals, B, F, e, e_ld, yw, sum, red, status, L, nt)

@@ -344,7 +344,7 @@ int fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int lddy, 
                             float* db_part, int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, int over, const GemmOpt* go) {
     bool done = false;
     if (go != nullptr && go->mode == 1) {
-        DCTR_TRY(dr3_fc_bwd_weights_partials(x, ldx, dy, lddy, dw_part, dw_stride, db_part, db_stride, M, K, N, splits, st, &done));
+        DCTR_TRY(dr3_fc_bwd_weights_partials(x, ldx, dy, lddy, dw_part, dw_stride, db_part, db_stride, M, K, N, splits, st, &done, go->wgrad_low_prio));
         if (done) return DCTR_OK;
     }
     DCTR_TRY(dr_fc_bwd_weights_partials(x, ldx, dy, lddy, dw_part, dw_stride, db_part, db_stride, M, K, N, splits, st, &done));

@@ -162,7 +162,7 @@ int dr3_fc_bwd_data(const float* dy, int lddy, const unsigned* wp, int64_t plane
 
 // ---- dW partial slabs (split over the batch) + bias-gradient partials: both operands are activations, both split in registers
 int dr3_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int lddy, float* dw_part, int64_t dw_stride, float* db_part,
-                                int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, bool* done) {
+                                int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, bool* done, int low_prio) {
     *done = false;
     if (splits < 1 || M < 1024 || K < 64 || N < 64 || (N & 3) || (K & 3) || !al16(x) || !al16(dy) || (ldx & 3) || (lddy & 3) || !al16(dw_part) ||
         (dw_stride & 3) || (int64_t)ceil_div(M, splits) < 128 || (int64_t)ceil_div(M, splits) > 65536 || K > 16384 || N > 16384 ||
@@ -175,6 +175,7 @@ int dr3_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int ld
     ep.split_stride = dw_stride;
     ep.colsum = db_part;
     ep.colsum_stride = db_stride;
+    ep.low_prio = low_prio;
     *done = true;
     if (small_tile('w', K, N, splits)) return dr3_launch<2, 7, false, false, true, DR_STORE, false>(x, ldx, dy, lddy, 0, dw_part, N, K, N, M, splits, ep, st);
     return dr3_launch<4, 7, false, false, true, DR_STORE, false>(x, ldx, dy, lddy, 0, dw_part, N, K, N, M, splits, ep, st);

@@ -494,6 +494,7 @@ struct TableStep {
     int32_t* done;                              // [U] completion tickets
     uint8_t* ts; const StepState* state;        // lagging rows (lag.h; Adam): advanced to t-1 before this step's update, stamped t; nullptr = classic
     int ld4; int lin_ld;                        // row strides of emb / s0 / s1 (float4 units) and of lin / l0 / l1 (floats): KQ and 1, or the record stride (engine.h)
+    int hi_prio;                                // A/B knob DCTR_TAIL_PRIO=1: the fused tail's waves raise their issue priority (the next gather waits for this kernel)
 };
 
 // the row's pieces are LOADED as soon as the distinct id is known (before the gradient loads: one latency instead of two) and
@@ -569,6 +570,7 @@ __global__ __launch_bounds__(256) void scatter_apply_kernel(
     const float* __restrict__ vals, int B, int F, float* __restrict__ gemb, float* __restrict__ glin, int dy_ld,
     int short_blocks, int medium_blocks, const int32_t* __restrict__ medium_list, int medium_cap,
     const int32_t* __restrict__ long_list, int long_cap, const int32_t* __restrict__ entry_row, TableStep T) {
+    if (T.hi_prio) __builtin_amdgcn_s_setprio(3);
     const Hyper h = load_hyper(T.hdev, T.hval);
     float sq = 0.f, sql = 0.f;
     __shared__ float4 red[256];
@@ -762,7 +764,9 @@ int embed_scatter_apply(Group* g, int kind, const Hyper* hdev, const Hyper& hval
                  "scatter: FM/BI modes need e, S and coef");
     DCTR_REQUIRE((lin != nullptr) == (dy != nullptr), "scatter_apply: linear weights and their gradient source go together");
     TableStep T{reinterpret_cast<float4*>(emb), reinterpret_cast<float4*>(e0), reinterpret_cast<float4*>(e1), lin, l0, l1, hdev, hval,
-                l2, sumsq_emb, sumsq_lin, g->uniq, g->slot, g->done, lag_ts, lag_state, tab_ld > 0 ? tab_ld / 4 : K / 4, tab_lin_ld};
+                l2, sumsq_emb, sumsq_lin, g->uniq, g->slot, g->done, lag_ts, lag_state, tab_ld > 0 ? tab_ld / 4 : K / 4, tab_lin_ld, 0};
+    static const bool tail_prio = [] { const char* v = getenv("DCTR_TAIL_PRIO"); return v != nullptr && v[0] == '1'; }();
+    T.hi_prio = tail_prio ? 1 : 0;
     g->slots_clean = true;                  // (every distinct id of the grouping is visited exactly once, and each visit clears its slot word)
 #define DCTR_Q(KD, Q) case Q: return launch_scatter_apply<KD, Q>(g, dE, de_ld, e, e_ld, S, coef, dy, vals, B, F, mode, dy_ld, st, entry_row, T)
 #define DCTR_KD(KD) case KD: switch (K / 4) { DCTR_Q(KD, 1); DCTR_Q(KD, 2); DCTR_Q(KD, 4); DCTR_Q(KD, 8); DCTR_Q(KD, 16); DCTR_Q(KD, 32); DCTR_Q(KD, 64); \

@@ -98,6 +98,7 @@ struct GemmOpt {
     int64_t fwd_plane = 0;
     const unsigned* w_dgr = nullptr;
     int64_t dgr_plane = 0;
+    int wgrad_low_prio = 0;     // the weight gradient's waves keep the default issue priority (it runs beside the table step the next gather waits for)
 };
 int fc_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N,
            int relu, float keep, const uint64_t* seed_ptr, uint64_t seed, hipStream_t st, int over = 0, const GemmOpt* go = nullptr);
@@ -117,7 +118,7 @@ int dr3_fc_fwd(const float* x, int ldx, const unsigned* wp, int64_t plane, const
 int dr3_fc_bwd_data(const float* dy, int lddy, const unsigned* wp, int64_t plane, float* dx, int lddx, int M, int K, int N, const float* act, int ldact,
                     float keep_prev, hipStream_t st, bool* done);
 int dr3_fc_bwd_weights_partials(const float* x, int ldx, const float* dy, int lddy, float* dw_part, int64_t dw_stride, float* db_part,
-                                int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, bool* done);
+                                int64_t db_stride, int M, int K, int N, int splits, hipStream_t st, bool* done, int low_prio = 0);
 // `over` = 1: both operands are followed by GEMM_SLACK_ROWS rows (64 * ld floats) of readable memory, edge tiles may over-read
 constexpr int GEMM_SLACK_ROWS = 64;
 int sum_partials(const float* part, int64_t stride, int splits, int64_t n, float* out, hipStream_t st);

@@ -60,12 +60,49 @@ def parse_file(path: str, field_size: int, threads: int = 10):
     return ids[:rows], vals[:rows], labels[:rows]
 
 
+def _line_chunks(buf, size: int, target: int):
+    """(start, end) byte spans of whole lines, ~target bytes each"""
+    pos = 0
+    while pos < size:
+        end = min(size, pos + target)
+        while end < size:                       # extend to the end of the line the cut fell into
+            win = np.asarray(buf[end:min(size, end + 65536)])
+            nl = np.flatnonzero(win == 10)
+            if nl.size:
+                end += int(nl[0]) + 1
+                break
+            end = min(size, end + 65536)
+        yield pos, end
+        pos = end
+
+
+def parse_span(buf, start: int, end: int, field_size: int, threads: int):
+    """bytes [start, end) of a mapped libsvm file (whole lines) through the library's thread team"""
+    lib = capi.lib()
+    view = buf[start:end]
+    n = C.c_int64()
+    capi.check(lib.dctr_parse_libsvm_mt(capi.ptr(view), end - start, field_size, int(threads), None, None, None, 0, C.byref(n)))
+    rows = n.value
+    ids = np.empty((max(rows, 1), field_size), dtype=np.int32)
+    vals = np.empty((max(rows, 1), field_size), dtype=np.float32)
+    labels = np.empty(max(rows, 1), dtype=np.float32)
+    capi.check(lib.dctr_parse_libsvm_mt(capi.ptr(view), end - start, field_size, int(threads), capi.ptr(ids), capi.ptr(vals), capi.ptr(labels), rows,
+                                        C.byref(n)))
+    return ids[:rows], vals[:rows], labels[:rows]
+
+
 class LibsvmDataset:
     """TextLineDataset(filenames).map(decode_libsvm, 10).prefetch().[shuffle(256)].repeat(num_epochs).batch(batch_size)
-    (DeepFM.py:84-92) as a Python iterator of numpy batches; the last batch may be short."""
+    (DeepFM.py:84-92) as a Python iterator of numpy batches; the last batch may be short.
+
+    Two ways through a file.  Default: the whole file is decoded once (thread team inside the library), kept in memory and in a
+    `.dctr.npz` beside it -- later epochs and later calls replay the parsed rows.  `streaming=True` (DCTR_INPUT_STREAMING=1; what
+    tf.data does): the file is decoded in chunks of DCTR_INPUT_CHUNK_MB (64) megabytes of whole lines, chunk c + 1 by a background
+    thread while the batches of chunk c are consumed; nothing is kept, every epoch decodes the text again, memory stays at two chunks
+    whatever the file's size."""
 
     def __init__(self, filenames: Sequence[str], field_size: int, batch_size: int = 32, num_epochs: int = 1,
-                 perform_shuffle: bool = False, threads: int = 10, seed: int = 0, binary_cache: bool = True):
+                 perform_shuffle: bool = False, threads: int = 10, seed: int = 0, binary_cache: bool = True, streaming: Optional[bool] = None):
         self.filenames = [filenames] if isinstance(filenames, str) else list(filenames)
         self.field_size = field_size
         self.batch_size = batch_size
@@ -74,7 +111,35 @@ class LibsvmDataset:
         self.threads = threads
         self.seed = seed
         self.binary_cache = binary_cache
+        self.streaming = (os.environ.get("DCTR_INPUT_STREAMING", "0") == "1") if streaming is None else bool(streaming)
         self._cache = {}
+
+    def _pieces(self, path):
+        """the file's parsed rows, piece by piece: one piece (the whole file) or, streaming, one per chunk"""
+        if not self.streaming:
+            yield self._load(path)
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        st0 = os.stat(path)
+        size = st0.st_size
+        if size == 0:
+            return
+        buf = np.memmap(path, dtype=np.uint8, mode="r")
+        target = max(1, int(os.environ.get("DCTR_INPUT_CHUNK_MB", "64"))) << 20
+        spans = _line_chunks(buf, size, target)
+        with ThreadPoolExecutor(1) as ex:           # the ctypes call releases the GIL: chunk c + 1 is decoded while chunk c is consumed
+            nxt = next(spans, None)
+            fut = ex.submit(parse_span, buf, nxt[0], nxt[1], self.field_size, self.threads) if nxt else None
+            while fut is not None:
+                data = fut.result()
+                nxt = next(spans, None)
+                fut = ex.submit(parse_span, buf, nxt[0], nxt[1], self.field_size, self.threads) if nxt else None
+                yield data
+        del buf
+        st1 = os.stat(path)
+        if (st1.st_size, st1.st_mtime_ns) != (st0.st_size, st0.st_mtime_ns):
+            raise errors.InvalidArgumentError("%s changed while it was being parsed (size %d -> %d): parse a file that is not being written" % (
+                path, st0.st_size, st1.st_size))
 
     def _load(self, path):
         if path in self._cache:
@@ -112,7 +177,7 @@ class LibsvmDataset:
         carry = None
         for _epoch in range(self.num_epochs):
             for path in self.filenames:
-                ids, vals, labels = self._load(path)
+              for ids, vals, labels in self._pieces(path):
                 if self.perform_shuffle:          # shuffle(buffer_size=256): windowed shuffle (DeepFM.py:88)
                     n = len(labels)
                     perm = np.arange(n)

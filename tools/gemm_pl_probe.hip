@@ -145,6 +145,40 @@ static void run_wgrad(const char* name, const Data& d, int splits) {
     stamps_report(nbm * nbn * splits);
 }
 
+// the weight gradient on v_mfma_f32_32x32x16_bf16 (gemm_dr3w_kernel): both operands split in registers under the 8-pass MFMA
+template <int TM, int TN>
+static void run_wgrad32(const char* name, const Data& d, int splits) {
+    const int M = d.Kin, N = d.N, K = d.Mb;
+    const int nbm = (M + 32 * TM - 1) / (32 * TM), nbn = (N + 32 * TN - 1) / (32 * TN);
+    const size_t lds = gemm_dr3w_lds_bytes<TM, TN>();
+    const int kchunk = ((K + splits - 1) / splits + 63) / 64 * 64;
+    DrEpilogue ep{};
+    ep.split_stride = (int64_t)M * N;
+    float* cs; CK(hipMalloc(&cs, (size_t)splits * N * 4)); CK(hipMemset(cs, 0, (size_t)splits * N * 4));
+    ep.colsum = cs; ep.colsum_stride = N;
+    CK(hipMemset(d.part, 0, (size_t)splits * M * N * 4));
+    auto k = gemm_dr3w_kernel<TM, TN>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    auto launch = [&]() { k<<<dim3(nbm * nbn, splits), 256, lds, 0>>>(d.x, M, d.dy, N, d.part, N, M, N, K, kchunk, nbn, ep); };
+    launch();
+    CK(hipDeviceSynchronize());
+    const double err = check_slabs(d, splits);
+    std::vector<float> hc((size_t)splits * N);
+    CK(hipMemcpy(hc.data(), cs, hc.size() * 4, hipMemcpyDeviceToHost));
+    double err_cs = 0;
+    for (int n = 0; n < N; ++n) {
+        double sm = 0, r = 0;
+        for (int z = 0; z < splits; ++z) sm += hc[(size_t)z * N + n];
+        for (int m = 0; m < K; ++m) r += d.hdy[(size_t)m * N + n];
+        err_cs = fmax(err_cs, fabs(sm - r));
+    }
+    const double us = time_us(launch);
+    printf("[wgrad 32x32x16, both in registers] %-10s out %dx%d over %d rows  tile %dx%d splits=%d blocks=%d lds=%zuKB  %.2f us  %.1f TF  maxerr %.2e  colsum err %.2e\n", name, M, N, K, 32 * TM, 32 * TN,
+           splits, nbm * nbn * splits, lds / 1024, us, 2.0 * M * N * K / us / 1e6, err, err_cs);
+    stamps_report(nbm * nbn * splits);
+    hipFree(cs);
+}
+
 // forward / dgrad product (A f32 split in registers, W pre-split) with and without the CF planes + column sums of its output
 template <int TM, int TN, int EPI>
 static void run_fwd(const char* name, int Mb, int K, int N, bool emit) {
@@ -270,6 +304,12 @@ static void run_pair(const Data& d, int splits, bool emit_cf = true) {
 int main(int argc, char** argv) {
     setvbuf(stdout, nullptr, _IONBF, 0);
     Data L0 = make_data(4096, 624, 400), L1 = make_data(4096, 400, 400);
+    printf("# weight gradient on the 8-pass MFMA\n");
+    run_wgrad32<2, 4>("L0", L0, 6);
+    run_wgrad32<2, 4>("L1", L1, 8);
+    run_wgrad32<2, 4>("L1", L1, 9);
+    { Data Rr = make_data(4001, 392, 616); run_wgrad32<2, 4>("ragged", Rr, 5); }
+    if (argc > 1) return 0;
     printf("# weight gradient, c2 layer 0 (624 x 400 over 4096 rows) and layers 1 / 2 (400 x 400)\n");
     run_wgrad<4, 7, 0>("L0", L0, 6);
     run_wgrad<2, 7, 0>("L0", L0, 6);
