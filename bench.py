@@ -475,8 +475,10 @@ def main():
     if args.selftest:
         # N ranks on the global batch of step 0 == ONE rank on the same global batch, over the real transport (the workload's own keep_prob; both
         # sides draw the weights from seed 1).  A check, not a measurement: prints its own JSON line and exits.
-        if not sharded or big:
-            raise SystemExit("--selftest needs --gpus N > 1 (or DCTR_FORCE_SHARDED=1) and a config whose table fits one GPU twice (c2)")
+        if not sharded:
+            raise SystemExit("--selftest needs --gpus N > 1 (or DCTR_FORCE_SHARDED=1)")
+        # (c5: rank 0 also holds the WHOLE 1e8-row table of the one-rank reference engine -- 12.9 GB of parameters + 25.8 GB of Adam slots
+        #  beside its own shard: 288 GB of HBM take it)
         import torch.distributed as dist
         gathered = [None] * world
         dist.all_gather_object(gathered, host_batches[0])
@@ -489,6 +491,16 @@ def main():
                                       optimizer=w["optimizer"], table_mode=args.table_mode, max_batch=B * world, seed=1))
             r1 = np.random.default_rng(1)
             for name, shp in ref.param_shapes.items():
+                if big and name in ("emb", "linear"):
+                    # the shards' own draws (fill_normal_ with seed 1000 + r on a contiguous [rows of shard r, ...] tensor), laid into rows r, r + N, ...
+                    full = ref.param_tensor(name)
+                    for r_ in range(world):
+                        n_r = (V - r_ + world - 1) // world
+                        tmp = torch.empty((n_r,) + tuple(full.shape[1:]), device=dev)
+                        fill_normal_(tmp, 0.01, 1000 + r_)
+                        full[r_::world].copy_(tmp)
+                        del tmp
+                    continue
                 ref.set_param(name, r1.normal(0, 0.01, size=shp).astype(np.float32))
             loss_1 = ref.train_step(torch.from_numpy(gi).to(dev), torch.from_numpy(gv).to(dev), torch.from_numpy(gl).to(dev))
             ref.close()

@@ -137,6 +137,15 @@ def test_four_ranks_equal_one_rank(model, overlap, driver, dev):
     _n_ranks_equal_one_rank(4, model, overlap, driver, dev)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,overlap,driver", [("deepfm+dropout", True, "native"), ("deepfm+lag", True, "native")])
+def test_eight_ranks_equal_one_rank(model, overlap, driver, dev):
+    """... and with EIGHT ranks sharing the GPU -- the world size BASELINE configs[4] (c5) runs at (round-5 verdict, item 8): id mod 8 row
+    shards, eight batches of 16 examples, seven remote peers per all-to-all, the dropout rows of rank r start at 16 r; with lagging owner
+    shards over nine steps."""
+    _n_ranks_equal_one_rank(8, model, overlap, driver, dev)
+
+
 def _n_ranks_equal_one_rank(world, model, overlap, driver, dev):
     from oracle import deepctr_oracle as O
     from tests.util import dev_batch, make_pair
