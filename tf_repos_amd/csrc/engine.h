@@ -118,6 +118,7 @@ struct dctr_engine {
     // does not overwrite what the weight gradient of step t is still reading.
     hipEvent_t ev_dense = nullptr;
     bool dense_pending = false;
+    bool lean_step = false;         // record_train: a small-batch step with the fewest enqueue calls (one optimizer launch for every dense variable)
     bool capturing = false;         // a step is being captured into a graph by dctr_time_kernel: no deferred join (nothing may stay unjoined at EndCapture)
     float* x_in_alt = nullptr;
     hipEvent_t armed_ev = nullptr;  // stop_arm: the ring event armed for the next launch (engine.hip stop_arm / stop_fork)

@@ -848,13 +848,17 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
     // A/B knob DCTR_WGRAD_LATE_LAYERS=k: the weight gradients of layers 0 .. k-1 (and their optimizer steps) start behind the WHOLE dgrad
     // chain, beside the table step, with no per-layer record on st; the others stay beside their layer's dgrad
     static const int late_layers_env = getenv("DCTR_WGRAD_LATE_LAYERS") ? atoi(getenv("DCTR_WGRAD_LATE_LAYERS")) : 0;
-    const int late_layers = (!wgrad_late && fused_opt && sw != st && !E->opnn_fused && !E->bn) ? std::min(late_layers_env, nl) : 0;
+    // (A/B knob DCTR_LEAN_WGRAD_LATE=1: a lean step -- record_train, small batches -- takes ALL its weight gradients behind the dgrad chain: one
+    //  record on st and one wait on sw for the three of them instead of one pair per layer.  Measured at c1: 0.1047 vs 0.1009 ms/step -- four calls
+    //  less, but 18 us of kernels more behind the table step; profiles/r06_ab_c1_lean.txt)
+    static const bool lean_late = [] { const char* v = getenv("DCTR_LEAN_WGRAD_LATE"); return v != nullptr && v[0] == '1'; }();
+    const int late_layers = (!wgrad_late && fused_opt && sw != st && !E->opnn_fused && !E->bn) ? ((E->lean_step && lean_late) ? nl : std::min(late_layers_env, nl)) : 0;
     // The MLP's optimizer steps as ONE launch behind the last weight gradient (and one re-split of the weights, gemm_mode 1) instead of
     // each layer's in front of the weight gradient of the layer below: with the step's last join deferred past the next gather
     // (record_train) the end of this stream is off the critical path, and two to four small launches leave the chain of full-chip
     // products.  A/B knob DCTR_OPT_TAIL=0 (the round-2 placement).  The layers' parameters are neighbours in the arena.
     static const bool opt_tail_off = [] { const char* v = getenv("DCTR_OPT_TAIL"); return v != nullptr && v[0] == '0'; }();
-    const bool opt_tail = !opt_tail_off && fused_opt && sw != st && !E->cfg.use_graph && !wgrad_late && late_layers == 0 && E->cfg.shard_world == 1;
+    const bool opt_tail = (!opt_tail_off || E->lean_step) && fused_opt && sw != st && !E->cfg.use_graph && !wgrad_late && late_layers == 0 && E->cfg.shard_world == 1;
     for (int i = nl - 1; i >= 0; --i) {
         Fc& fc = E->mlp[i];
         DCTR_TRY(wplanes_ensure(E, fc, st));
@@ -876,7 +880,7 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
             // layer's weight gradient (measured at c2: 0.3052 vs 0.3062 ms/step -- nothing; every kernel here fills the chip, the
             // step is the sum of their solo times whatever the order)
             static const bool opt_side = getenv("DCTR_OPT_SIDE") != nullptr;
-            if (fused_opt && i < nl - 1 && !opt_tail) {
+            if (fused_opt && i < nl - 1 && !opt_tail && !E->lean_step) {
                 if (opt_side && E->s_opt != nullptr && sw != st) {
                     DCTR_TRY(fork(E, sw, E->s_opt));
                     DCTR_TRY(opt_dense_range(E, E->mlp[i + 1].w, E->mlp[i + 1].last, E->s_opt));
@@ -990,11 +994,12 @@ int backward_dense(dctr_engine* E, int B, hipStream_t st, hipStream_t sw, bool f
             const Fc& fc = E->mlp[i];
             const float* x = i > 0 ? E->h[i - 1] : E->x_in;
             const int ldx = i > 0 ? E->mlp[i - 1].out : E->Din_ld;
-            if (i + 1 < nl) DCTR_TRY(opt_dense_range(E, E->mlp[i + 1].w, E->mlp[i + 1].last, sw));
+            if (i + 1 < nl && !E->lean_step) DCTR_TRY(opt_dense_range(E, E->mlp[i + 1].w, E->mlp[i + 1].last, sw));
+            const GemmOpt gol = gemm_opt(E, fc);
             DCTR_TRY(fc_bwd_weights_partials(x, ldx, E->dh[i], fc.out, E->part(fc.w), E->params[fc.w].padded, E->part(fc.b), E->params[fc.b].padded, B,
-                                             fc.in, fc.out, fc.splits, sw, 1));
+                                             fc.in, fc.out, fc.splits, sw, 1, &gol));
         }
-        if (!wgrad_late) DCTR_TRY(opt_dense_range(E, E->mlp[0].w, opt_tail ? E->mlp[nl - 1].last : E->mlp[0].last, sw));
+        if (!wgrad_late && !E->lean_step) DCTR_TRY(opt_dense_range(E, E->mlp[0].w, opt_tail ? E->mlp[nl - 1].last : E->mlp[0].last, sw));
     }
     return DCTR_OK;
 }
@@ -1220,11 +1225,20 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     if (!(group_after >= 1 && have_mlp)) DCTR_TRY(start_grouping());
     DCTR_TRY(forward_rest(E, B, true, st, (group_after >= 1 && have_mlp) ? &start_grouping : nullptr, group_after - 1));
     const bool fused_opt = E->cfg.model != DCTR_MODEL_AFM;
-    if (fused_opt) stop_arm(E);             // (the record behind the head rides on the fused head kernel's launch when that path is taken)
+    // Small batches (c1, the reference's own B = 128 / 256: run.sh:11-22) run at the pace of the HOST's enqueue calls -- 34 per step at ~3 us
+    // (profiles/r05_c1_hip_api_stats.txt), the GPU idle between them.  A LEAN step keeps the same kernels on the same three streams but
+    // drops the placements that exist to overlap full-chip kernels: the output layer's optimizer launches on the grouping stream behind a
+    // record of their own, and one optimizer launch per group of parameters -- every dense variable is stepped by ONE launch at the tail
+    // of the weight-gradient stream (the arena is contiguous).  Six enqueue calls less per step.  A/B knob DCTR_LEAN_BATCH=<rows> (0 = off).
+    static const int lean_rows = getenv("DCTR_LEAN_BATCH") ? atoi(getenv("DCTR_LEAN_BATCH")) : 512;
+    const bool lean = fused_opt && B <= lean_rows && !E->cfg.use_graph && sw != st && sg != st && !E->bn && !E->opnn_fused && E->cfg.shard_world == 1 &&
+                      getenv("DCTR_WGRAD_LATE") == nullptr && getenv("DCTR_WGRAD_LATE_LAYERS") == nullptr;
+    E->lean_step = lean;
+    if (fused_opt && !lean) stop_arm(E);    // (the record behind the head rides on the fused head kernel's launch when that path is taken)
     DCTR_TRY(head(E, B, B, true, st, nullptr, true));
     hipEvent_t head_ev = nullptr;
     bool have_head_ev = false;
-    if (fused_opt && E->head_did_out_bwd) {
+    if (fused_opt && E->head_did_out_bwd && !lean) {
         // the output layer (and the global bias, whose gradient aliases the output bias' slabs) is final right after the fused
         // head kernel: step it now, beside the MLP backward, instead of at the end of the step beside the scatter
         // (on the grouping stream, idle since the MLP forward: on the wgrad stream these two latency-bound launches -- 128 slabs
@@ -1256,12 +1270,17 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
         have_tables_ev = true;
     }
     if (E->armed_ev != nullptr) { disarm_stop_event(); E->armed_ev = nullptr; }      // (armed for the head, not used)
-    const bool out_done = fused_opt && E->head_did_out_bwd;
+    const bool out_done = fused_opt && E->head_did_out_bwd && !lean;
+    if (lean && have_tables_ev) sg_joined_by_tables_ev = true;      // (nothing follows that record on the grouping stream in a lean step: st's wait for it joins the stream)
     // A/B knob DCTR_WGRAD_SERIAL=1: the weight gradients (and the per-layer optimizer steps) on the main stream, right behind their
     // layer's dgrad, instead of beside it on sw
     static const bool wgrad_serial = getenv("DCTR_WGRAD_SERIAL") != nullptr;
-    DCTR_TRY(backward_dense(E, B, st, wgrad_serial ? st : sw, fused_opt, have_head_ev ? &head_ev : nullptr));
-    if (!fused_opt) DCTR_TRY(fork(E, st, sw));          // (fused_opt: backward_dense ends with that fork)
+    static const bool lean_serial = [] { const char* v = getenv("DCTR_LEAN_SERIAL"); return v != nullptr && v[0] == '1'; }();      // A/B knob (measured slower: 0.115 vs 0.101)
+    const bool serial = wgrad_serial || (lean && lean_serial);
+    DCTR_TRY(backward_dense(E, B, st, serial ? st : sw, fused_opt, have_head_ev ? &head_ev : nullptr));
+    // (fused_opt: backward_dense ends with that fork -- unless its weight gradients ran on st itself: then the optimizer launches below, on
+    //  sw, are ordered behind them here)
+    if (!fused_opt || (serial && sw != st)) DCTR_TRY(fork(E, st, sw));
     // where a prefetched grouping of the next batch may start (beside scatter + table step): the record of that last st -> sw
     // fork serves -- one more record here is one more barrier packet (~5 us) in front of the scatter
     if (!E->cfg.use_graph && E->last_fork_ev != nullptr) { E->ev_tail = E->last_fork_ev; E->have_tail = true; }
@@ -1279,7 +1298,7 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
             if (p.is_table) continue;
             bool is_mlp = false;
             for (auto& fc : E->mlp) is_mlp = is_mlp || (i >= fc.w && i <= fc.last);
-            const bool skip = is_mlp || (out_done && (i == E->p_out_w || i == E->p_out_b || i == E->p_bias));
+            const bool skip = (is_mlp && !lean) || (out_done && (i == E->p_out_w || i == E->p_out_b || i == E->p_bias));
             if (skip) { DCTR_TRY(flush_run()); continue; }
             if (run_first >= 0 && E->params[run_last].arena_off + E->params[run_last].padded != p.arena_off) DCTR_TRY(flush_run());
             if (run_first < 0) run_first = i;

@@ -314,6 +314,106 @@ __global__ __launch_bounds__(256) void group_fill_kernel(const int32_t* __restri
     }
 }
 
+// Small batches (the reference's own B = 128 / 256: ~10^4 entries): the whole grouping -- counters cleared, distinct ids counted, segments
+// carved, entries filled -- as ONE block of 1024 threads that walks the entries in trips, the three phases separated by __syncthreads()
+// instead of kernel boundaries.  Four enqueue calls (memset + count + segments + fill) become one: at B = 256 the step runs at the pace of
+// the host's HIP calls (engine.hip record_train: lean step).  Every output is what the three kernels leave, up to the ORDER of the distinct
+// ids in `uniq` -- which already depended on which block's atomic came first.
+constexpr int GROUP_ONE_BLOCK_MAX = 16384;      // entries
+__global__ __launch_bounds__(GROUP_BLOCK) void group_one_block_kernel(const int32_t* __restrict__ ids, int B, int F, int64_t rows, int32_t* __restrict__ slot,
+                                                                      int32_t* __restrict__ uniq, int32_t* __restrict__ counters, int32_t* __restrict__ cnt,
+                                                                      int32_t* __restrict__ seg_start, int32_t* __restrict__ cursor, float* __restrict__ glin,
+                                                                      int32_t* __restrict__ long_list, int long_cap, int32_t* __restrict__ done,
+                                                                      int32_t* __restrict__ medium_list, int medium_cap, int LONG_SEGMENT,
+                                                                      int32_t* __restrict__ perm, int32_t* __restrict__ seg_of) {
+    __shared__ int s_U, s_total, s_long, s_med;
+    __shared__ int wsum[GROUP_BLOCK / 64];
+    const int n = B * F;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { s_U = 0; s_total = 0; s_long = 0; s_med = 0; }
+    __syncthreads();
+    // ---- phase 1: count (group_count_kernel's body per trip; the compact index comes from an LDS counter)
+    for (int base = 0; base < n; base += GROUP_BLOCK) {
+        const int i = base + (int)threadIdx.x;
+        int id = -1;
+        bool valid = false;
+        if (i < n) {
+            const int f = i / B, b = i - f * B;
+            id = ids[(size_t)b * F + f];
+            valid = (id >= 0) && ((int64_t)id < rows);
+        }
+        const WaveGroup g = wave_group(id, valid, lane);
+        bool first = false;
+        if (valid && g.leader == lane) first = atomicAdd(&slot[id], g.count) == 0;
+        const unsigned long long fm = __ballot(first);
+        int wbase = 0;
+        if (lane == 0 && fm != 0ull) wbase = atomicAdd(&s_U, __popcll(fm));
+        wbase = __shfl(wbase, 0);
+        if (first) uniq[wbase + __popcll(fm & ((1ull << lane) - 1ull))] = id;
+    }
+    __syncthreads();
+    const int U = s_U;
+    // ---- phase 2: segments (group_segments_kernel's body per trip of 1024 distinct ids)
+    for (int base = 0; base < U; base += GROUP_BLOCK) {
+        const int u = base + (int)threadIdx.x;
+        int c = 0, id = 0;
+        if (u < U) { id = uniq[u]; c = slot[id]; }
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        const int trip_base = s_total;
+        int before = 0, tot = 0;
+        for (int w = 0; w < GROUP_BLOCK / 64; ++w) { if (w < wave) before += wsum[w]; tot += wsum[w]; }
+        if (u < U) {
+            const int s0 = trip_base + before + incl - c;
+            cnt[u] = c;
+            seg_start[u] = s0;
+            cursor[u] = s0;
+            slot[id] = u + 1;
+            glin[u] = 0.f;
+            done[u] = 0;
+            if (c >= LONG_SEGMENT) {
+                const int k = atomicAdd(&s_long, 1);
+                if (k < long_cap) long_list[k] = u;
+            } else if (c > SHORT_SEGMENT) {
+                const int k = atomicAdd(&s_med, 1);
+                if (k < medium_cap) medium_list[k] = u;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_total = trip_base + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { counters[0] = U; counters[1] = s_total; counters[2] = s_long; counters[3] = 0; counters[4] = s_med; }
+    __syncthreads();          // (slot / cursor written above are read below by other waves of THIS block: workgroup-scope ordering)
+    // ---- phase 3: fill (group_fill_kernel's body per trip)
+    for (int base = 0; base < n; base += GROUP_BLOCK) {
+        const int i = base + (int)threadIdx.x;
+        int id = -1;
+        bool valid = false;
+        if (i < n) {
+            const int f = i / B, b = i - f * B;
+            id = ids[(size_t)b * F + f];
+            valid = (id >= 0) && ((int64_t)id < rows);
+        }
+        const WaveGroup g = wave_group(id, valid, lane);
+        int u = 0, pos0 = 0;
+        if (valid) u = slot[id] - 1;
+        if (valid && g.leader == lane) pos0 = atomicAdd(&cursor[u], g.count);
+        pos0 = __shfl(pos0, g.leader);
+        if (valid) {
+            const int pos = pos0 + g.rank;
+            perm[pos] = i;
+            seg_of[pos] = u;
+        }
+    }
+}
+
 // grouped positions per walker: 8 measured best on c2 once the long segments have their own blocks (6: 20.2 us, 8: 20.0, 12: 22.6,
 // 16: 27.0); A/B knob DCTR_SCATTER_RUN
 
@@ -824,6 +924,15 @@ int group_ids(Group* g, const int32_t* ids, int B, int F, hipStream_t st, bool z
     DCTR_REQUIRE(n <= g->max_entries, "group_ids: B*F=%lld exceeds capacity %lld", (long long)n, (long long)g->max_entries);
     // always forget the previous batch (slot words back to 0, U = 0), even for an empty one -- unless the fused scatter + table step
     // has already put every slot word back (then only the counters are cleared)
+    // small batches: ONE launch for the whole grouping (group_one_block_kernel clears the counters itself).  A/B knob DCTR_GROUP_ONE_BLOCK=0
+    static const bool one_block_on = [] { const char* v = getenv("DCTR_GROUP_ONE_BLOCK"); return v == nullptr || v[0] != '0'; }();
+    if (one_block_on && g->slots_clean && !zero_gemb && g->gemb_clean && n > 0 && n <= GROUP_ONE_BLOCK_MAX) {
+        g->slots_clean = false;
+        group_one_block_kernel<<<1, GROUP_BLOCK, 0, st>>>(ids, B, F, g->rows, g->slot, g->uniq, g->counters, g->cnt, g->seg_start, g->cursor, g->glin, g->long_list,
+                                                          (int)g->long_cap, g->done, g->medium_list, (int)g->medium_cap, long_segment(g->K / 4), g->perm, g->seg_of);
+        DCTR_LAUNCH_CHECK();
+        return DCTR_OK;
+    }
     if (g->slots_clean) DCTR_HIP_CHECK(hipMemsetAsync(g->counters, 0, 32, st));
     else group_reset_kernel<<<ceil_div(g->max_entries, 256), 256, 0, st>>>(g->slot, g->uniq, g->counters, (int)g->max_entries);
     if (n <= 0) { DCTR_LAUNCH_CHECK(); return DCTR_OK; }
