@@ -41,8 +41,8 @@ CONFIGS = {
                name="DeepFM 39 fields, vocab 1e8 row-sharded, emb_dim 32, batch 8192/GPU (65536 at 8 GPUs), MLP 400-400-400 keep 0.5, "
                     "Adam (BASELINE configs[4])"),
 }
-PMC_FILE = os.path.join("profiles", "r05_pmc_traffic.txt")
-STATS_FILE = os.path.join("profiles", "r05_kernel_stats.txt")     # rocprofv3 --kernel-trace --stats of this same command
+PMC_FILE = os.path.join("profiles", "r06_pmc_traffic.txt")
+STATS_FILE = os.path.join("profiles", "r06_kernel_stats.txt")     # rocprofv3 --kernel-trace --stats of this same command
 LIB_FILE = os.path.join("tf_repos_amd", "_lib", "libdeepctr_hip.so")
 
 
@@ -662,9 +662,10 @@ def main():
                 # (forward and the 400-wide dgrads: 2 x 7 tiles at two blocks per CU unless DCTR_DR3_SMALL says otherwise -- csrc/gemm_dr3.hip)
                 sm = os.environ.get("DCTR_DR3_SMALL", "fd")
                 f_t, d_t, w_t = ("2, 7" if c_ in sm and sm != "none" else "4, 7" for c_ in "fdw")
-                return {"fwd": "void dctr::gemm_dr3_kernel<%s, true, true, false, 1, true>" % f_t,
-                        "dgrad": ("void dctr::gemm_dr3_kernel<%s, true, true, false, 2, true>" % d_t) if i > 0 else "void dctr::gemm_dr3_kernel<4, 10, true, true, false, 0, true>",
-                        "wgrad": "void dctr::gemm_dr3_kernel<%s, false, false, true, 0, false>" % w_t}[kind]
+                # (template arguments: TM, TN, A_RC, B_RC, CS, EPI, B_PRE, A_PRE -- csrc/gemm_dr.h)
+                return {"fwd": "void dctr::gemm_dr3_kernel<%s, true, true, false, 1, true, false>" % f_t,
+                        "dgrad": ("void dctr::gemm_dr3_kernel<%s, true, true, false, 2, true, false>" % d_t) if i > 0 else "void dctr::gemm_dr3_kernel<4, 10, true, true, false, 0, true, false>",
+                        "wgrad": "void dctr::gemm_dr3_kernel<%s, false, false, true, 0, false, false>" % w_t}[kind]
             return {"fwd": "void dctr::gemm_dr_kernel<2, 13, true, false, false, 1, 0>",
                     "dgrad": "void dctr::gemm_dr_kernel<2, 13, true, true, false, 2, 0>" if i > 0 else "void dctr::gemm_dr_kernel<4, 10, true, true, false, 0, 0>",
                     "wgrad": "void dctr::gemm_dr_kernel<2, 13, false, false, true, 0, 0>"}[kind]
@@ -747,21 +748,24 @@ def main():
         # the step's largest HBM stream AS THE TIMED STEPS RUN IT: the background sweep over 1/N of the table per step (csrc/lag.h),
         # by rocprofv3's in-step duration and PMC bytes of exactly that kernel (committed summaries of this same command)
         period = out["config"]["table_sweep_period"]
-        sweep_name = "void dctr::(anonymous namespace)::lag_advance_kernel<%d, false, 4>" % (K // 4)
+        sweep_name = "void dctr::(anonymous namespace)::lag_advance_kernel<%d, false, 4, 1>" % (K // 4)
         if period > 1 and not sharded:
             sweep_bytes = (6 * (K + 1) * 4 + 4 + 1) * ((rows + period - 1) // period)      # theta, m, v read + write of 1/N of the rows, slot word, stamp
             sweep_us = rocprof_avg_us(sweep_name) if args.config == "c2" else None
-            hk = {"kernel": "lag_advance_kernel<%d, false, 4> (background sweep of 1/%d of the table per step, lagging rows replayed in registers)" % (K // 4, period),
+            hk = {"kernel": "lag_advance_kernel<%d, false, 4, 1> (background sweep of 1/%d of the table per step, lagging rows replayed in registers)" % (K // 4, period),
                   "bound": "hbm", "algorithmic_bytes": int(sweep_bytes), "traffic": pmc_traffic_bytes(sweep_name) if args.config == "c2" else None,
                   "us_in_step": sweep_us, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "achieved": round(sweep_bytes / sweep_us / 1e3, 2) if sweep_us else None,
                   "frac": round(sweep_bytes / sweep_us / 1e3 / HBM_PEAK_GBS, 4) if sweep_us else None,
                   "element_updates_per_launch": int(rows * (K + 1)),
-                  "alu_floor_us": round(rows * (K + 1) * 23.0 / (256 * 128) / 2.1e3, 2),
+                  # (a VALU op takes a wave 4 cycles on a SIMD, sqrt / rcp 16: ~9.5 + 2 per element-update with the identity-coefficient replay loop)
+                  "alu_floor_us": round(rows * (K + 1) * (9.5 * 4 + 2 * 16) / 64.0 / 1024 / 2.1e3, 2),
                   "note": "NOT an HBM-bound kernel (frac is its traffic against HBM for reference only): every swept row replays %d Adam steps in "
-                          "registers -- V (K+1) element-updates per launch however scheduled, ~15 VALU + 2 quarter-rate (sqrt, rcp) ops each = "
-                          "alu_floor_us at full VALU issue on 256 CUs; the measured time above that floor is the dependent chain of each update "
-                          "(4 rows interleaved per lane under a 96-VGPR cap so that it shares SIMDs with the backward GEMMs it runs under).  The "
+                          "registers -- V (K+1) element-updates per launch however scheduled, ~9.5 VALU issue slots of 4 cycles + sqrt and rcp at 16 per "
+                          "element-update and wave = alu_floor_us on the chip's 1024 SIMDs (PMC, profiles/r06_lag_pmc.txt: SQ_ACTIVE_INST_VALU 4.2 M quad-"
+                          "cycles per launch = 7.8 us); the rest is memory latency the replay does not cover (SQ_WAIT_ANY 44 %% of the wave cycles).  "
+                          "Round 6 measured a software-pipelined kernel, a <= 64-register one-row-per-lane kernel and 1 / 4 / 8 blocks per CU, alone "
+                          "(profiles/r06_lag_probe.txt: 18-22 us whatever the shape) and in the step (r06_ab_schedule_and_sweep_knobs.txt): none faster.  The "
                           "classic sweep it replaces: kernels.opt_table_dense_adam_classic" % period}
         else:
             hk = dict(kernels["opt_table_dense_adam_classic"])

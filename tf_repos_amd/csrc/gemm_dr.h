@@ -984,6 +984,20 @@ __device__ __forceinline__ void gemm_dr3_body(const float* __restrict__ A, int l
             }
         }
     };
+    // ... of an NC operand: the two k rows (2 tt, 2 tt + 1) of every load group
+    auto loadA_krows = [&](int tt, int g) {
+        if constexpr (!A_PRE && !A_RC) {
+#pragma unroll
+            for (int u = 0; u < AG; ++u)
+#pragma unroll
+                for (int e = 2 * tt; e < 2 * tt + 2; ++e) {
+                    const unsigned so = (32u * g + e) * strideA;
+                    if constexpr (VA == 4) ld4(ra, aoff[u], so, &f.a[4 * u][e], 8);
+                    else if constexpr (VA == 2) ld2(ra, aoff[u], so, &f.a[2 * u][e], 8);
+                    else ld1(ra, aoff[u], so, &f.a[u][e]);
+                }
+        }
+    };
     __builtin_amdgcn_sched_barrier(0);
     if (G > 0) {                                              // group 0's A planes and first B tile, exposed once
         if constexpr (!A_PRE) {
@@ -1023,11 +1037,16 @@ __device__ __forceinline__ void gemm_dr3_body(const float* __restrict__ A, int l
             if constexpr (A_PRE) {
                 if constexpr (j < TM) loadAP(nxt[j], j, g + 1);
             } else {
-            // the next group's A pairs p0 .. p1 - 1
+            // the next group's A pairs p0 .. p1 - 1.  Order: a reduction-contiguous operand tile by tile (a tile's two loads hold its 8 k: it is
+            // refilled after its four pairs); an NC operand k-pair by k-pair ACROSS the tiles (one load holds ONE k of every tile of a load
+            // group: once the pair (2 tt, 2 tt + 1) of every tile is split those two rows of registers are refilled for group g + 2.  Round 6:
+            // refilled tile by tile, a one-group operand (TM = VA = 4: the weight gradient) got its registers back only behind the LAST pair, a
+            // region ahead of their next use; measured, the k-pair order changes nothing -- 33.7 k cycles either way: the loop is issue-bound,
+            // tools/mfma32_mix.hip -- it is kept because the slack is real)
             constexpr int p0 = j * NPA / TN, p1 = (j + 1) * NPA / TN;
 #pragma unroll
             for (int p = p0; p < p1; ++p) {
-                const int i = p / 4, tt = p % 4;
+                const int i = A_RC ? p / 4 : p % TM, tt = A_RC ? p % 4 : p / TM;
                 const float x0 = f.a[i][2 * tt], x1 = f.a[i][2 * tt + 1];
                 const unsigned h = dr_pk_bf16(x0, x1);
                 const float r0 = dr_sub(x0, __uint_as_float(h << 16)), r1 = dr_sub(x1, __uint_as_float(h & 0xffff0000u));
@@ -1036,8 +1055,8 @@ __device__ __forceinline__ void gemm_dr3_body(const float* __restrict__ A, int l
                 nxt[i].h[tt] = h;
                 nxt[i].m[tt] = m;
                 nxt[i].l[tt] = dr_pk_bf16(s0, s1);
-                // raw registers complete: RC per tile, NC per load group of VA tiles
-                if (tt == 3 && (A_RC || (i % VA) == VA - 1)) loadA_unit(A_RC ? i : i / VA, g + 2);
+                if constexpr (A_RC) { if (tt == 3) loadA_unit(i, g + 2); }
+                else { if (i == TM - 1) loadA_krows(tt, g + 2); }
             }
             }
             if constexpr (B_PRE) mma(cur, pw[j], j);
