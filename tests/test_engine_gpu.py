@@ -574,3 +574,34 @@ def test_unsupported_embedding_sizes_say_so(dev):
         Engine(EngineConfig(model="opnn", field_size=6, feature_size=100, embedding_size=10, deep_layers=(8,), dropout=(1.0,), max_batch=8))
     with pytest.raises(errors.InvalidArgumentError):
         Engine(EngineConfig(model="deepfm", field_size=6, feature_size=100, embedding_size=300, deep_layers=(8,), dropout=(1.0,), max_batch=8))
+
+
+@pytest.mark.parametrize("B", [256, 4096])
+def test_predict_and_stage_timing_right_behind_a_train_step(B, dev):
+    """(round-5 ADVICE) The step's last join is deferred: the first layer's weight gradient, the MLP's optimizer launch and the weight re-split
+    of step t may still be running on the side stream when the call returns.  A predict enqueued right behind it writes the gathered
+    embeddings the deferred weight gradient reads (forward() joins first); dctr_time_kernel("train_step") CAPTURES steps (no deferred join
+    inside a capture).  Both must leave the variables where an engine that synchronises after every call leaves them.
+    B = 256: the lean small-batch step; B = 4096: the split-precision products with their planes."""
+    F, V, K, layers = 39, 50_000, 16, (400, 400)
+    kw = dict(model="deepfm", B=B, F=F, V=V, K=K, layers=layers, l2=1e-4, lr=5e-4, keep=(0.5, 0.5), use_graph=False, scale=0.01)
+    batches = [dev_batch(*O.synth_batch(B, F, V, seed=70 + i), dev) for i in range(4)]
+    states = []
+    for sync in (True, False):
+        _, _, eng = make_pair(**kw)
+        prob = torch.empty(B, device=dev)
+        for s in range(6):
+            eng.train_step(*batches[s % 4], want_loss=False)
+            if sync:
+                torch.cuda.synchronize()
+            eng.predict(batches[(s + 1) % 4][0], batches[(s + 1) % 4][1], prob, None)      # (writes x_in, reads every dense variable)
+            if sync:
+                torch.cuda.synchronize()
+        states.append((dict(eng.get_params()), prob.cpu().numpy()))
+        if not sync:
+            assert eng.time_stage("train_step", iters=3) > 0.0          # captured steps: no unjoined stream at EndCapture
+            eng.train_step(*batches[0], want_loss=True)                  # ... and the engine goes on
+        eng.close()
+    for k, v in states[0][0].items():
+        assert np.abs(v - states[1][0][k]).max() <= 1e-6, k              # (the hot ids' float atomics: two runs differ by ~1e-8)
+    assert np.abs(states[0][1] - states[1][1]).max() <= 1e-6

@@ -12,6 +12,7 @@
 #define DR_STAMPS
 __device__ long long dr_stamps[16384 * 8];
 #include "../tf_repos_amd/csrc/gemm_dr.h"
+#include "gemm_dr3w_experiment.h"
 
 namespace dctr {
 __device__ __forceinline__ float dr_dropout_scale(uint64_t, uint64_t, float) { return 1.f; }
