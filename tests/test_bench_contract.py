@@ -1,4 +1,4 @@
-"""The bench line's contract, checked on the committed line of the round (profiles/r05_bench.json, produced by `python bench.py`
+"""The bench line's contract, checked on the committed line of the round (profiles/r06_bench.json, produced by `python bench.py`
 on the GPU box): the keys the driver and the judge read, their types, and the internal consistency of the derived figures."""
 import json
 import os
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_honours_the_contract():
-    lines = [l for l in open(os.path.join(ROOT, "profiles", "r05_bench.json")).read().splitlines() if l.strip()]
+    lines = [l for l in open(os.path.join(ROOT, "profiles", "r06_bench.json")).read().splitlines() if l.strip()]
     assert len(lines) == 1                                  # ONE JSON line on stdout
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -51,6 +51,14 @@ def test_committed_bench_line_honours_the_contract():
     assert d["end_to_end"]["cold_text_one_epoch"]["examples_per_sec"] < d["end_to_end"]["steady_examples_per_sec"]
     for kn in ("embed_gather_fwd", "embed_gather_fwd_k32_hbm"):
         assert d["kernels"][kn]["frac_memory_side_of_measured_copy"] > d["kernels"][kn]["frac_of_measured_copy"]
+    # round 6: the mode the line is timed in is the library's default; the gather on c5's shard shape (Zipf and uniform ids) and the
+    # streamed-text rate of the input pipeline sit in the line
+    assert d["config"]["gemm_mode"] == "split"
+    for kn in ("embed_gather_fwd_c5_shard_zipf", "embed_gather_fwd_c5_shard_uniform"):
+        assert d["kernels"][kn]["ms"] > 0 and d["kernels"][kn]["frac_of_measured_copy"] > 0
+    assert d["kernels"]["embed_gather_fwd_c5_shard_zipf"]["ms"] < d["kernels"]["embed_gather_fwd_c5_shard_uniform"]["ms"]
+    ts = d["end_to_end"]["text_streaming"]
+    assert ts["text_streaming_examples_per_sec"] > 0 and ts["lines"] >= 4_000_000 and ts["parser_alone_lines_per_sec_10_threads"] > 0
 
 
 def test_bench_kernel_names_exist_in_the_committed_pmc_summary():
@@ -64,10 +72,11 @@ def test_bench_kernel_names_exist_in_the_committed_pmc_summary():
     names = set(re.findall(r'"(void dctr::(?:gemm_dr3_kernel|gemm_dr_kernel|gemm_f32_mfma|opt_table_kernel)<[^"%]*>)"', src))
     assert any("gemm_dr3_kernel" in n for n in names) and any("gemm_dr_kernel" in n for n in names) and any("opt_table_kernel" in n for n in names)
     # (the split-mode templates of the default step: forward / 400-wide dgrads 2 x 7, the first layer's dgrad 4 x 10, weight gradients 4 x 7)
-    names |= {"void dctr::gemm_dr3_kernel<2, 7, true, true, false, 1, true>", "void dctr::gemm_dr3_kernel<2, 7, true, true, false, 2, true>",
-              "void dctr::gemm_dr3_kernel<4, 7, false, false, true, 0, false>"}
-    names.add("void dctr::(anonymous namespace)::lag_advance_kernel<4, false, 4>")         # roofline.hbm_kernel: the in-step table kernel at c2
-    assert bench.rocprof_avg_us("void dctr::(anonymous namespace)::lag_advance_kernel<4, false, 4>") is not None
+    # (template arguments since round 6: TM, TN, A_RC, B_RC, CS, EPI, B_PRE, A_PRE)
+    names |= {"void dctr::gemm_dr3_kernel<2, 7, true, true, false, 1, true, false>", "void dctr::gemm_dr3_kernel<2, 7, true, true, false, 2, true, false>",
+              "void dctr::gemm_dr3_kernel<4, 7, false, false, true, 0, false, false>"}
+    names.add("void dctr::(anonymous namespace)::lag_advance_kernel<4, false, 4, 1>")         # roofline.hbm_kernel: the in-step table kernel at c2
+    assert bench.rocprof_avg_us("void dctr::(anonymous namespace)::lag_advance_kernel<4, false, 4, 1>") is not None
     for n in names:
         if "gemm_f32_mfma" in n or "opt_table_kernel" in n or "gemm_dr_kernel" in n:      # (alternatives -- DCTR_GEMM=lds, the classic sweep, --gemm-mode exact: not in the default step, so not in its PMC summary)
             continue
