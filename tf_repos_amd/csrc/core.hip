@@ -71,7 +71,7 @@ int dctr_dropout_mask(uint64_t seed, int64_t global_step, uint64_t site, int64_t
     return DCTR_OK;
 }
 
-int dctr_version(void) { return 100; }
+int dctr_version(void) { return 106; }          // (106: dctr_config.gemm_mode 0 = the library default = split, 2 = exact)
 const char* dctr_last_error(void) { return get_error(); }
 
 int dctr_device_count(int* n) {

@@ -1314,6 +1314,14 @@ int record_train(dctr_engine* E, int B, hipStream_t st) {
     else DCTR_TRY(fork(E, sg, st));
     if (split_table) DCTR_TRY(scatter_and_step_tables(E, B, st, nullptr, OPT_PASS_TOUCHED));
     else DCTR_TRY(scatter_and_step_tables(E, B, st, sg));  // the grouping stream is idle by now: linear table beside the embedding table
+    // A/B knob DCTR_PREGROUP_WAIT=end: the next batch's grouping (dctr_prefetch_ids) starts BEHIND the table step -- beside the next gather and
+    // first forward product -- instead of beside it: one more record on st (in front of the next gather)
+    static const bool pregroup_end = [] { const char* v = getenv("DCTR_PREGROUP_WAIT"); return v != nullptr && strcmp(v, "end") == 0; }();
+    if (pregroup_end && !E->cfg.use_graph) {
+        hipEvent_t ev_end = nullptr;
+        DCTR_TRY(record_on(E, st, &ev_end));
+        E->ev_tail = ev_end; E->have_tail = true;
+    }
     if (!E->cfg.use_graph && !no_state_ahead && sw != st) {
         // the next step's state (global_step + 1, Adam's lr_t, dropout seed, zeroed loss scalars) into the second StepState, on
         // the weight-gradient stream beside scatter / table step: it only READS the live state, and the join below orders it
