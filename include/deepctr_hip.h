@@ -343,6 +343,19 @@ int dctr_fc_bwd_data_split(const float* d_dy, int lddy, const void* d_dgr_planes
 int dctr_fc_bwd_weights_split(const float* d_x, int ldx, const float* d_dy, int lddy, float* d_dw, float* d_db,
                               int M, int K, int N, float* d_workspace, size_t workspace_bytes, void* stream);
 int64_t dctr_gemm_split_launches(void);
+/* The products of a layer over a TALL operand (M rows in the millions, K and N of 128 or 256: AFM's attention layer over the B * P
+ * pair rows, AFM.py:142-147) in split precision (csrc/gemm_ts.h) -- what dctr_create's AFM handle runs under gemm_mode = 1, as ops:
+ *   dctr_fc_fwd_dot_split       Y[M,N] = relu(X[M,K] W[K,N] + b) and, from the same accumulators, dot_out[row] = <Y[row,:], dot_w>
+ *                               (the score of the (N -> 1) layer that follows, AFM.py:147; d_dot_out may be null);
+ *   dctr_fc_bwd_data_gate_split dX[M,K] = (rowscale (x) kscale . 1[H > 0]) W[K,N]^T for the layer's stored output H [M,N]: the input
+ *                               gradient when the output gradient is rank one under the ReLU mask (d H = d score (x) w_out . 1[H > 0]).
+ * d_planes_ws: dctr_ts_plane_bytes(K, N) bytes of device memory the call overwrites (the weight's bf16 planes).  DCTR_ERR_UNSUPPORTED when
+ * the shape or the alignment (16-byte pointers, leading dimensions multiples of 4) is not taken: the caller uses the exact ops. */
+int dctr_ts_plane_bytes(int R, int N, int64_t* bytes);
+int dctr_fc_fwd_dot_split(const float* d_x, int ldx, const float* d_w, const float* d_b, float* d_y, int ldy, int64_t M, int K, int N,
+                          const float* d_dot_w, float* d_dot_out, void* d_planes_ws, void* stream);
+int dctr_fc_bwd_data_gate_split(const float* d_h, int ldh, const float* d_rowscale, const float* d_kscale, const float* d_w, float* d_dx,
+                                int lddx, int64_t M, int K, int N, void* d_planes_ws, void* stream);
 
 /* ---- K3/K5/K4: interaction layers ------------------------------------------------------ */
 /* AFM's attention-weighted pairwise interaction (AFM.py:127-158) as an op.  It needs the attention network's variables and ~B P (K + A)

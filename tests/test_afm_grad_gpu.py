@@ -52,6 +52,12 @@ def test_afm_gradients_at_the_run_sh_operating_point(dev):
         err_eng = float(np.abs(g_eng - truth).max())
         err_o32 = float(np.abs(g32[name].double().numpy() - truth).max())
         report[name] = (err_eng / scale, err_o32 / scale)
+        if scale < 1e-18:
+            # attention_out/biases: the softmax over the pairs is shift-invariant, so this gradient is identically zero (fp64: 4e-23) and what
+            # an fp32 evaluation returns is the rounding residue of sum(d score) over the 94 848 pair rows (|d score| ~ 1e-9: eps * 1e-9 *
+            # sqrt(rows) ~ 2e-14) -- a property of the summation order, not of the model: bounded, not compared with the oracle's own residue
+            assert err_eng <= 1e-12, (name, err_eng, err_o32, scale)
+            continue
         assert err_eng <= max(4.0 * err_o32, 1e-6 * scale), (name, err_eng, err_o32, scale)
         if name not in ("emb", "linear"):       # the same gradient read directly (dctr_param_grad_get: the partial slabs of the backward, summed)
             g_direct = eng.get_grad(name).astype(np.float64).reshape(truth.shape)

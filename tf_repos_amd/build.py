@@ -22,9 +22,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-I", INCLUDE]
 
 
-# per-file flags.  gemm_dr3.hip: hipcc's SLP pass pairs the split's f32 subtractions into v_pk_add_f32, slower beside MFMAs than two
+# per-file flags.  gemm_dr3.hip, gemm_ts.hip: hipcc's SLP pass pairs the split's f32 subtractions into v_pk_add_f32, slower beside MFMAs than two
 # v_sub_f32 (see the file's header)
-FILE_FLAGS = {"gemm_dr3.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"gemm_dr3.hip": ["-fno-slp-vectorize"], "gemm_ts.hip": ["-fno-slp-vectorize"]}
 
 
 def _sources():

@@ -20,6 +20,7 @@ _VARIANT = os.environ.get("DCTR_LIB_VARIANT") or ("ieee" if os.environ.get("DCTR
 LIB_PATH = os.path.join(_HERE, "_lib", "libdeepctr_hip%s.so" % ("_" + _VARIANT if _VARIANT else ""))
 
 DCTR_OK = 0
+DCTR_ERR_UNSUPPORTED = -6
 MODELS = {"deepfm": 0, "fnn": 1, "ipnn": 2, "opnn": 3, "nfm": 4, "afm": 5, "dcn": 6, "wide": 7, "deep": 8, "wide_n_deep": 9, "mvm": 10,
           "din": 11, "esmm": 12}
 OPTIMIZERS = {"Adam": 0, "Adagrad": 1, "Momentum": 2, "ftrl": 3}
@@ -200,6 +201,9 @@ _SIGS["dctr_fc_fwd_split"] = ([_P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_in
 _SIGS["dctr_fc_bwd_data_split"] = ([_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_float, _P], C.c_int)
 _SIGS["dctr_fc_bwd_weights_split"] = ([_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P], C.c_int)
 _SIGS["dctr_gemm_split_launches"] = ([], C.c_int64)
+_SIGS["dctr_ts_plane_bytes"] = ([C.c_int, C.c_int, _P], C.c_int)
+_SIGS["dctr_fc_fwd_dot_split"] = ([_P, C.c_int, _P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int)
+_SIGS["dctr_fc_bwd_data_gate_split"] = ([_P, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P], C.c_int)
 _SIGS["dctr_set_stat_sync"] = ([_P, ALL_REDUCE_F32_FN, _P, C.c_int], C.c_int)
 
 DECLARED_SYMBOLS = tuple(_SIGS)

@@ -598,6 +598,14 @@ using namespace dctr;
 
 // A/B knob DCTR_AFM_IN_PRODUCTS=0: the score dot, the ReLU-masked rank-one gradient of the last attention layer and attention_out's
 // weight gradient as passes of their own (rowdot / out_layer_bwd) instead of inside the three products
+// Below this many pair rows the tall split-precision products (gemm_ts.hip) are NOT used although they take the shape: their blocks own a
+// whole CU (one wave per SIMD with all 512 registers, 96 KB of LDS), so nothing of the step's other streams (table sweep, next batch's
+// grouping, weight gradient) shares a CU with them, and at the reference's B = 128 (95 k rows, 371 row tiles for 256 CUs) the step lost
+// 0.17 ms to that while the two products gained 0.07 (0.75 -> 0.92 ms); at B = 4096 (3.0 M rows) it gains 2.7 ms of 11.4.
+static int64_t afm_ts_min_rows() {
+    static const int64_t v = getenv("DCTR_AFM_TS_MIN_ROWS") ? atoll(getenv("DCTR_AFM_TS_MIN_ROWS")) : 262144;     // A/B knob
+    return v;
+}
 static bool afm_in_products() {
     static const bool off = [] { const char* v = getenv("DCTR_AFM_IN_PRODUCTS"); return v != nullptr && v[0] == '0'; }();
     return !off;
@@ -683,6 +691,8 @@ int afm_alloc(dctr_engine* E) {
         E->dah = E->dahs.back();
         DCTR_HIP_CHECK(hipStreamCreateWithFlags(&E->s_afm, hipStreamNonBlocking));
         DCTR_TRY(dm(&E->sc_parts, 2 * MB * P));
+        // split-precision mode: the attention weight's bf16 planes for the tall products (gemm_ts.hip), [forward | input gradient]
+        DCTR_HIP_CHECK(hipMalloc(&E->ts_planes, 2 * ts_plane_bytes(256, 256)));
     }
     (void)A;
     DCTR_TRY(dm(&E->sc, MB * P));
@@ -704,6 +714,7 @@ void afm_free(dctr_engine* E) {
     for (float* p : fl) if (p) hipFree(p);
     for (float* p : E->ahs) hipFree(p);
     for (float* p : E->dahs) hipFree(p);
+    if (E->ts_planes) hipFree(E->ts_planes);
     if (E->pair_i) hipFree(E->pair_i);
     if (E->pair_j) hipFree(E->pair_j);
     if (E->s_afm) hipStreamDestroy(E->s_afm);
@@ -813,7 +824,18 @@ int afm_forward(dctr_engine* E, int B, bool train, hipStream_t st) {
             bool done = false;
             // the last layer's product also takes the score dot <ah[row, :], w_o> (AFM.py:147) from its accumulators, one part per
             // 128-column slab, when it is the tall-operand kernel with at most two slabs (a two-term sum is order-free)
-            if (l + 1 == E->att_fc.size() && fc.out <= 256 && afm_in_products())
+            const bool in_products = l + 1 == E->att_fc.size() && fc.out <= 256 && afm_in_products();
+            // split-precision mode: the tall product on the bf16 matrix pipe (gemm_ts.hip), the whole score from one wave's accumulators
+            if (in_products && nc == 1 && E->gemm_mode == 1 && E->ts_planes != nullptr && (int64_t)n * P >= afm_ts_min_rows()) {
+                // (one launch writes the weight's planes for this product and for the backward's gated input gradient)
+                const bool both = E->afm_gate_slabs && ts_takes((int64_t)n * P, fc.out, fc.in);
+                if (both) DCTR_TRY(ts_prepare(E->pp(fc.w), fc.in, fc.out, E->pp(E->p_ao_w), E->ts_planes, static_cast<char*>(E->ts_planes) + ts_plane_bytes(256, 256), s));
+                DCTR_TRY(ts_fc_fwd_dot(x, fc.in, E->pp(fc.w), E->pp(fc.b), y, fc.out, (int64_t)n * P, fc.in, fc.out, E->pp(E->p_ao_w), E->sc_parts + r0,
+                                       E->ts_planes, !both, s, &done));
+                E->ts_dgr_ready = both && done;
+                if (done) score_parts = 1;
+            }
+            if (!done && in_products)
                 DCTR_TRY(ws_fc_fwd_dot(x, fc.in, E->pp(fc.w), E->pp(fc.b), y, fc.out, n * P, fc.in, fc.out, 1, E->pp(E->p_ao_w), E->sc_parts + r0,
                                        (int64_t)E->MB * P, &score_parts, s, &done));
             if (!done) DCTR_TRY(fc_fwd(x, fc.in, E->pp(fc.w), E->pp(fc.b), y, fc.out, n * P, fc.in, fc.out, 1, 1.f, nullptr, 0, s));
@@ -916,7 +938,10 @@ int afm_interaction_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t 
             };
             if (beside) DCTR_TRY(wgrad());
             if (!beside || wdone) {
-                DCTR_TRY(ws_fc_bwd_data_gate(E->ah, A, E->dsc, E->pp(E->p_ao_w), E->pp(fc.w), E->dpairp2, K, n * P, K, A, st, &ddone));
+                if (E->gemm_mode == 1 && E->ts_planes != nullptr && (int64_t)n * P >= afm_ts_min_rows())     // split-precision mode: the gate is ONE exact bf16 plane (gemm_ts.hip)
+                    DCTR_TRY(ts_fc_bwd_data_gate(E->ah, A, E->dsc, E->pp(E->p_ao_w), E->pp(fc.w), E->dpairp2, K, (int64_t)n * P, K, A,
+                                                 static_cast<char*>(E->ts_planes) + ts_plane_bytes(256, 256), !E->ts_dgr_ready, st, &ddone));
+                if (!ddone) DCTR_TRY(ws_fc_bwd_data_gate(E->ah, A, E->dsc, E->pp(E->p_ao_w), E->pp(fc.w), E->dpairp2, K, n * P, K, A, st, &ddone));
                 DCTR_REQUIRE(ddone, "AFM: the gated input gradient was not taken for a shape ws_takes() accepts");
                 if (!beside) DCTR_TRY(wgrad());
                 if (wdone) {

@@ -143,6 +143,14 @@ int ws_fc_fwd_dot(const float* x, int ldx, const float* w, const float* b, float
                   const float* dot_w, float* dot_parts, int64_t dot_stride, int* n_parts, hipStream_t st, bool* done);
 int ws_fc_bwd_data_gate(const float* h, int ldh, const float* rowscale, const float* kscale, const float* w, float* dx, int lddx, int M, int K,
                         int N, hipStream_t st, bool* done);
+// tall operands in split precision (gemm_ts.hip; DCTR_GEMM_TS=0 turns it off): *done = false -> not taken.  planes_ws: ts_plane_bytes(R, N)
+bool ts_takes(int64_t M, int R, int N);
+size_t ts_plane_bytes(int R, int N);
+int ts_fc_fwd_dot(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int64_t M, int K, int N, const float* dot_w,
+                  float* dot_out, void* planes_ws, bool split_here, hipStream_t st, bool* done);
+int ts_fc_bwd_data_gate(const float* h, int ldh, const float* rowscale, const float* kscale, const float* w, float* dx, int lddx, int64_t M, int K,
+                        int N, void* planes_ws, bool split_here, hipStream_t st, bool* done);
+int ts_prepare(const float* w, int K, int N, const float* kscale, void* fwd_planes, void* dgr_planes, hipStream_t st);
 int dr_wgrad_splits(int M, int K, int N);
 // Outer-PNN first layer with the pair products formed in the MFMA fragments (gemm_dr.hip)
 bool opnn_fused_ok(int F, int K, int H);
