@@ -349,6 +349,13 @@ int64_t dctr_gemm_split_launches(void);
  *                               (the score of the (N -> 1) layer that follows, AFM.py:147; d_dot_out may be null);
  *   dctr_fc_bwd_data_gate_split dX[M,K] = (rowscale (x) kscale . 1[H > 0]) W[K,N]^T for the layer's stored output H [M,N]: the input
  *                               gradient when the output gradient is rank one under the ReLU mask (d H = d score (x) w_out . 1[H > 0]).
+ *   dctr_fc_bwd_weights_gate_split  the same layer's weight gradient under that rank-one output gradient, dW[K,N] = X^T (rowscale (x) colscale . 1[H > 0]),
+ *                               with db[N] (its bias gradient) and dwo[N] = sum_r rowscale[r] H[r,:] (the (N -> 1) layer's weight gradient);
+ *                               workspace: at least (K N + 2 N) floats, 256 x that for full speed (partial slabs over row ranges).
+ *   dctr_pairs_fc_fwd_dot_split / dctr_pairs_fc_bwd_weights_gate_split  the first and the third with X never stored: row b P + p of X is the
+ *                               element-wise product e[b, pair_i[p], :] . e[b, pair_j[p], :] of two gathered embeddings (AFM.py:130-139; d_e
+ *                               [examples, e_ld] floats, field f at f * K; d_pair_i / d_pair_j: P int16 field indices), formed in the registers --
+ *                               bit-identical to the same op over the materialised products.
  * d_planes_ws: dctr_ts_plane_bytes(K, N) bytes of device memory the call overwrites (the weight's bf16 planes).  DCTR_ERR_UNSUPPORTED when
  * the shape or the alignment (16-byte pointers, leading dimensions multiples of 4) is not taken: the caller uses the exact ops. */
 int dctr_ts_plane_bytes(int R, int N, int64_t* bytes);
@@ -356,6 +363,15 @@ int dctr_fc_fwd_dot_split(const float* d_x, int ldx, const float* d_w, const flo
                           const float* d_dot_w, float* d_dot_out, void* d_planes_ws, void* stream);
 int dctr_fc_bwd_data_gate_split(const float* d_h, int ldh, const float* d_rowscale, const float* d_kscale, const float* d_w, float* d_dx,
                                 int lddx, int64_t M, int K, int N, void* d_planes_ws, void* stream);
+int dctr_fc_bwd_weights_gate_split(const float* d_x, int ldx, const float* d_h, int ldh, const float* d_rowscale, const float* d_colscale,
+                                   float* d_dw, float* d_db, float* d_dwo, int64_t M, int K, int N, float* d_workspace, size_t workspace_bytes,
+                                   void* stream);
+int dctr_pairs_fc_fwd_dot_split(const float* d_e, int e_ld, int examples, const int16_t* d_pair_i, const int16_t* d_pair_j, int P, const float* d_w,
+                                const float* d_b, float* d_y, int ldy, int64_t M, int K, int N, const float* d_dot_w, float* d_dot_out,
+                                void* d_planes_ws, void* stream);
+int dctr_pairs_fc_bwd_weights_gate_split(const float* d_e, int e_ld, int examples, const int16_t* d_pair_i, const int16_t* d_pair_j, int P,
+                                         const float* d_h, int ldh, const float* d_rowscale, const float* d_colscale, float* d_dw, float* d_db,
+                                         float* d_dwo, int64_t M, int K, int N, float* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K3/K5/K4: interaction layers ------------------------------------------------------ */
 /* AFM's attention-weighted pairwise interaction (AFM.py:127-158) as an op.  It needs the attention network's variables and ~B P (K + A)

@@ -1,5 +1,6 @@
 """Tall split-precision products (csrc/gemm_ts.h, round 6): AFM's attention layer over the B * P pair rows and its input gradient
-(AFM.py:142-147: fully_connected(relu) over [B * P, K], the (A -> 1) score, and their gradients) on the bf16 matrix pipe with every f32
+(AFM.py:142-147: fully_connected(relu) over [B * P, K], the (A -> 1) score, and their gradients: forward + score, gated input gradient,
+gated weight gradient with the two bias / score-weight sums) on the bf16 matrix pipe with every f32
 value as three bf16 planes -- what an AFM handle at the reference's K = 256 (run.sh:18) runs by default (gemm_mode split).
 
 Checked through the C ABI against an fp64 product of the same f32 inputs, on ragged row counts (the last block tile, wave and 16-row
@@ -72,6 +73,76 @@ def test_tall_products_are_f32_equivalent(M, K, N, dev):
     es, ee = float((gs.double() - ref).abs().max()), float((g32.double() - ref).abs().max())
     print("gate  %6d x %3d x %3d: split max err %.2e, an f32 product %.2e" % (M, K, N, es, ee))
     assert es <= 2 * ee + 1e-9, (es, ee)
+    # ---- gated weight gradient: dW = X^T (rs (x) wo . 1[H > 0]), db = its column sums, dwo = sum_r rs[r] H[r, :]
+    gate = (ys > 0).double()
+    xs = x.double() * rs.double()[:, None]
+    ref_w = (xs.t() @ gate) * wo.double()[None, :]
+    ref_b = (gate * rs.double()[:, None]).sum(0) * wo.double()
+    ref_o = (ys.double() * rs.double()[:, None]).sum(0)
+    per = K * N + 2 * N
+    wsp = torch.zeros(256 * per, device=dev)
+    dw, db, dwo = torch.empty(K, N, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev)
+    capi.check(lib.dctr_fc_bwd_weights_gate_split(capi.ptr(dx_), K, capi.ptr(h), N, capi.ptr(drs_), capi.ptr(dwo_), capi.ptr(dw), capi.ptr(db), capi.ptr(dwo),
+                                                  M, K, N, capi.ptr(wsp), wsp.numel() * 4, st))
+    d32 = (h > 0).float() * drs_[:, None] * dwo_[None, :]                       # the gradient the exact path forms on its operand loads
+    w32 = torch.empty(K, N, device=dev); b32 = torch.empty(N, device=dev)
+    wse = torch.zeros(64 * (K * N + N), device=dev)
+    capi.check(lib.dctr_fc_bwd_weights(capi.ptr(dx_), K, capi.ptr(d32), N, capi.ptr(w32), capi.ptr(b32), M, K, N, capi.ptr(wse), wse.numel() * 4, st))
+    es, ee = float((dw.cpu().double() - ref_w).abs().max()), float((w32.cpu().double() - ref_w).abs().max())
+    print("wgrad %6d x %3d x %3d: split max err %.2e, exact (on the materialised gradient) %.2e, values to %.1f" % (M, K, N, es, ee, float(ref_w.abs().max())))
+    assert es <= 2 * ee + 1e-9, (es, ee)
+    eb, eeb = float((db.cpu().double() - ref_b).abs().max()), float((b32.cpu().double() - ref_b).abs().max())
+    assert eb <= 2 * eeb + 1e-6 * float(ref_b.abs().max()), (eb, eeb)
+    eo = float((dwo.cpu().double() - ref_o).abs().max())
+    o32 = float(((h * drs_[:, None]).sum(0).cpu().double() - ref_o).abs().max())
+    assert eo <= 2 * o32 + 1e-6 * float(ref_o.abs().max()), (eo, o32)
+    # a workspace of ONE slab: the same sums from a single block
+    capi.check(lib.dctr_fc_bwd_weights_gate_split(capi.ptr(dx_[:4096]), K, capi.ptr(h[:4096]), N, capi.ptr(drs_), capi.ptr(dwo_), capi.ptr(dw), capi.ptr(db), capi.ptr(dwo),
+                                                  4096, K, N, capi.ptr(wsp), per * 4, st))
+    ref1 = (xs[:4096].t() @ gate[:4096]) * wo.double()[None, :]
+    assert float((dw.cpu().double() - ref1).abs().max()) <= 1e-5 * max(1.0, float(ref1.abs().max()))
+
+
+@pytest.mark.parametrize("B,F,K,N", [(96, 39, 256, 256), (300, 23, 128, 256), (130, 39, 256, 128)])
+def test_rows_formed_from_the_embeddings_give_the_same_bits(B, F, K, N, dev):
+    """AFM.py:130-139's element-wise products e_i . e_j as the tall operand WITHOUT the [B P, K] tensor: the forward product and the gated weight
+    gradient read the gathered embeddings and multiply in the registers -- every output word equal to the op over the materialised rows."""
+    lib = capi.lib()
+    st = capi.current_stream()
+    P = F * (F - 1) // 2
+    M = B * P - 5                                            # (the last example's last pairs are not rows: a ragged end)
+    g = torch.Generator().manual_seed(B + F + K + N)
+    e = (torch.rand(B, F * K, generator=g) * 2 - 1).to(dev)
+    pi = torch.tensor([i for i in range(F - 1) for j in range(i + 1, F)], dtype=torch.int16)
+    pj = torch.tensor([j for i in range(F - 1) for j in range(i + 1, F)], dtype=torch.int16)
+    dpi, dpj = pi.to(dev), pj.to(dev)
+    ev = e.view(B, F, K)
+    x = (ev[:, pi.long(), :] * ev[:, pj.long(), :]).reshape(B * P, K)[:M].contiguous()
+    w = ((torch.rand(K, N, generator=g) * 2 - 1) * 0.08).to(dev)
+    b = ((torch.rand(N, generator=g) * 2 - 1) * 0.1).to(dev)
+    wo = ((torch.rand(N, generator=g) * 2 - 1) * 0.3).to(dev)
+    rs = (torch.rand(M, generator=g) * 2 - 1).to(dev)
+    ws = _ws(lib, 256, 256, dev)
+    y1, y2 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    d1, d2 = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    capi.check(lib.dctr_fc_fwd_dot_split(capi.ptr(x), K, capi.ptr(w), capi.ptr(b), capi.ptr(y1), N, M, K, N, capi.ptr(wo), capi.ptr(d1), capi.ptr(ws), st))
+    capi.check(lib.dctr_pairs_fc_fwd_dot_split(capi.ptr(e), F * K, B, capi.ptr(dpi), capi.ptr(dpj), P, capi.ptr(w), capi.ptr(b), capi.ptr(y2), N, M, K, N,
+                                               capi.ptr(wo), capi.ptr(d2), capi.ptr(ws), st))
+    assert torch.equal(y1, y2) and torch.equal(d1, d2)
+    per = K * N + 2 * N
+    wsp = torch.zeros(256 * per, device=dev)
+    out1 = [torch.empty(K, N, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev)]
+    out2 = [torch.empty(K, N, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev)]
+    capi.check(lib.dctr_fc_bwd_weights_gate_split(capi.ptr(x), K, capi.ptr(y1), N, capi.ptr(rs), capi.ptr(wo), *[capi.ptr(t) for t in out1], M, K, N,
+                                                  capi.ptr(wsp), wsp.numel() * 4, st))
+    capi.check(lib.dctr_pairs_fc_bwd_weights_gate_split(capi.ptr(e), F * K, B, capi.ptr(dpi), capi.ptr(dpj), P, capi.ptr(y1), N, capi.ptr(rs), capi.ptr(wo),
+                                                        *[capi.ptr(t) for t in out2], M, K, N, capi.ptr(wsp), wsp.numel() * 4, st))
+    for a, b2 in zip(out1, out2):
+        assert torch.equal(a, b2)
+    # more rows than the embeddings hold pairs for: refused
+    rc = lib.dctr_pairs_fc_fwd_dot_split(capi.ptr(e), F * K, B - 1, capi.ptr(dpi), capi.ptr(dpj), P, capi.ptr(w), capi.ptr(b), capi.ptr(y2), N, M, K, N,
+                                         capi.ptr(wo), capi.ptr(d2), capi.ptr(ws), st)
+    assert rc == capi.DCTR_ERR_UNSUPPORTED
 
 
 def test_shapes_not_taken_are_refused(dev):

@@ -641,6 +641,10 @@ int afm_declare_params(dctr_engine* E) {
         // (the unfused path runs in up to AFM_MAX_CHUNKS chunks of examples, each with a full set of weight-gradient slabs)
         const int nc_max = afm_chunks_wanted(E->MB, E->P);
         fc.splits = E->afm_fused ? AFM_SLABS : nc_max * choose_wgrad_splits(ceil_div(E->MB, nc_max) * E->P, fc.in, fc.out);
+        // split-precision mode at a batch the tall products pay for: the gated weight gradient is gemm_ts.hip's, one slab per CU
+        E->afm_ts_wgrad = nl == 1 && !E->afm_fused && nc_max == 1 && E->gemm_mode == 1 && afm_in_products() && ts_takes((int64_t)E->MB * E->P, fc.in, fc.out) &&
+                          ws_takes((int64_t)E->MB * E->P, fc.out, fc.in) && (int64_t)E->MB * E->P >= afm_ts_min_rows();
+        if (E->afm_ts_wgrad) fc.splits = TS_WGRAD_SLABS;
         char nm[64];
         snprintf(nm, sizeof(nm), "att_mlp%d/weights", l);
         fc.w = add(E, nm, {fc.in, fc.out}, false, fc.splits, 0.f);
@@ -754,6 +758,23 @@ static int afm_chunks(const dctr_engine* E, int B) {
     return nc;
 }
 
+// can this step run without the pair tensor?  Everything the forward product, the weight gradient and the two pooling kernels check, in one place
+static bool afm_pairs_in_registers(dctr_engine* E, int n, const TsPairs* tp) {
+    static const bool off = getenv("DCTR_AFM_PP") != nullptr && atoi(getenv("DCTR_AFM_PP")) == 1;                    // A/B knob
+    static const bool pool_knobs = getenv("DCTR_AFM_POOL_FWD_LOOP") != nullptr || getenv("DCTR_AFM_POOL_BWD_PP") != nullptr;
+    const int F = E->F, K = E->K, P = E->P;
+    if (off || pool_knobs || !afm_in_products() || !E->afm_ts_wgrad || E->att_fc.size() != 1 || E->gemm_mode != 1 || E->ts_planes == nullptr || afm_chunks(E, n) != 1) return false;
+    const Fc& fc = E->att_fc[0];
+    const Param& w = E->params[fc.w];
+    if ((int64_t)n * P < afm_ts_min_rows() || !ts_takes((int64_t)n * P, fc.in, fc.out) || !ts_pairs_ok(tp, (int64_t)n * P, K) || fc.in != K) return false;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!al16(E->ah) || !al16(E->dsc) || !al16(E->parts + w.part_off) || (w.padded & 3) || !al16(E->pp(fc.w)) || !al16(E->pp(fc.b)) || !al16(E->pp(E->p_ao_w))) return false;
+    // forward pooling: the MFMA kernel (n >= 2048) or the LDS rebuild, both from e; backward pooling: the MFMA kernel
+    const bool kf = (K == 64 || K == 128 || K == 256) && F <= 48 && E->e_ld % 4 == 0;
+    const bool fwd_e = (n >= 2048 && kf) || ((size_t)(((P + 3) & ~3) + F * K) * sizeof(float) <= 128 * 1024 && E->e_ld % 4 == 0);
+    return fwd_e && kf && E->Din_ld % 4 == 0;
+}
+
 static int afm_pool_fwd(dctr_engine* E, int b0, int n, bool train, hipStream_t st, int score_parts = 0) {
     const int F = E->F, K = E->K, P = E->P;
     static const bool no_mfma = getenv("DCTR_AFM_POOL_FWD_LOOP") != nullptr;       // A/B knob: the per-pair loop
@@ -813,9 +834,19 @@ int afm_forward(dctr_engine* E, int B, bool train, hipStream_t st) {
         // nontemporal stores once the pair tensor cannot stay in the caches anyway (3.1 GB at the reference point: 13.52 -> 13.42 ms/step)
         static const bool nt_off = getenv("DCTR_AFM_PAIR_FWD_NT") != nullptr && atoi(getenv("DCTR_AFM_PAIR_FWD_NT")) == 0;       // A/B knob
         const bool nt = !nt_off && (size_t)n * P * K * sizeof(float) > ((size_t)512 << 20);
-        (nt ? afm_pair_fwd_kernel<true> : afm_pair_fwd_kernel<false>)<<<dim3(ceil_div(P * KQ, 256 * PAIR_FWD_U), n), 256, 0, s>>>(reinterpret_cast<const float4*>(E->e + (size_t)b0 * E->e_ld), E->e_ld / 4, E->pair_i,
-                                                               E->pair_j, n, P, KQ, reinterpret_cast<float4*>(E->pairp + r0 * K));
-        DCTR_LAUNCH_CHECK();
+        auto materialise = [&]() -> int {
+            (nt ? afm_pair_fwd_kernel<true> : afm_pair_fwd_kernel<false>)<<<dim3(ceil_div(P * KQ, 256 * PAIR_FWD_U), n), 256, 0, s>>>(reinterpret_cast<const float4*>(E->e + (size_t)b0 * E->e_ld), E->e_ld / 4, E->pair_i,
+                                                                   E->pair_j, n, P, KQ, reinterpret_cast<float4*>(E->pairp + r0 * K));
+            DCTR_LAUNCH_CHECK();
+            return DCTR_OK;
+        };
+        // The pair tensor [B P, K] (3.1 GB at the reference point) is NOT written when everything that reads it can form its rows from the
+        // gathered embeddings instead: the attention product and its weight gradient (gemm_ts.hip with TsPairs: e_i . e_j in the registers,
+        // bit-identical) and the two pooling kernels (which already work from the embeddings at this shape).  DCTR_AFM_PP=1: written as before.
+        const TsPairs tp{E->e + (size_t)b0 * E->e_ld, E->e_ld, n, E->pair_i, E->pair_j, P};
+        bool gen = afm_pairs_in_registers(E, n, &tp);
+        E->afm_pp_skipped = false;
+        if (!gen) DCTR_TRY(materialise());
         const float* x = E->pairp + r0 * K;
         int score_parts = 0;
         for (size_t l = 0; l < E->att_fc.size(); ++l) {     // relu(x W_l + b_l) over the chunk's pair rows
@@ -831,7 +862,12 @@ int afm_forward(dctr_engine* E, int B, bool train, hipStream_t st) {
                 const bool both = E->afm_gate_slabs && ts_takes((int64_t)n * P, fc.out, fc.in);
                 if (both) DCTR_TRY(ts_prepare(E->pp(fc.w), fc.in, fc.out, E->pp(E->p_ao_w), E->ts_planes, static_cast<char*>(E->ts_planes) + ts_plane_bytes(256, 256), s));
                 DCTR_TRY(ts_fc_fwd_dot(x, fc.in, E->pp(fc.w), E->pp(fc.b), y, fc.out, (int64_t)n * P, fc.in, fc.out, E->pp(E->p_ao_w), E->sc_parts + r0,
-                                       E->ts_planes, !both, s, &done));
+                                       E->ts_planes, !both, s, &done, gen ? &tp : nullptr));
+                if (gen && !done) {                     // (not taken after all: the rows are written and the product below reads them)
+                    gen = false;
+                    DCTR_TRY(materialise());
+                }
+                E->afm_pp_skipped = gen;
                 E->ts_dgr_ready = both && done;
                 if (done) score_parts = 1;
             }
@@ -932,8 +968,15 @@ int afm_interaction_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t 
                 // db_o = sum of d score, from the per-example sums the backward pooling left (B values, not B P)
                 vec_sum_partials_kernel<<<ab.n_part, 256, 0, sw>>>(E->sc_parts, n, ceil_div(n, ab.n_part), E->part(E->p_ao_b), ab.padded);
                 DCTR_LAUNCH_CHECK();
-                DCTR_TRY(dr_fc_bwd_weights_partials_gate(E->pairp, K, E->ah, A, E->dsc, E->pp(E->p_ao_w), E->part(fc.w), w.padded, E->part(fc.b),
-                                                         bb.padded, E->part(E->p_ao_w), aw.padded, n * P, K, A, fc.splits, sw, &wdone));
+                if (E->afm_ts_wgrad) {      // (declared with TS_WGRAD_SLABS slabs: every batch of this handle, whatever its size)
+                    const TsPairs tp{E->e, E->e_ld, n, E->pair_i, E->pair_j, P};
+                    DCTR_TRY(ts_fc_bwd_weights_gate(E->pairp, K, E->ah, A, E->dsc, E->pp(E->p_ao_w), E->part(fc.w), w.padded, E->part(fc.b), bb.padded,
+                                                    E->part(E->p_ao_w), aw.padded, (int64_t)n * P, K, A, fc.splits, sw, &wdone, E->afm_pp_skipped ? &tp : nullptr));
+                }
+                DCTR_REQUIRE(wdone || !E->afm_pp_skipped, "AFM: the forward left the pair tensor unwritten and the weight gradient that forms it in registers was not taken");
+                if (!wdone)
+                    DCTR_TRY(dr_fc_bwd_weights_partials_gate(E->pairp, K, E->ah, A, E->dsc, E->pp(E->p_ao_w), E->part(fc.w), w.padded, E->part(fc.b),
+                                                             bb.padded, E->part(E->p_ao_w), aw.padded, n * P, K, A, fc.splits, sw, &wdone));
                 return DCTR_OK;
             };
             if (beside) DCTR_TRY(wgrad());

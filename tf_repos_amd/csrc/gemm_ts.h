@@ -11,7 +11,7 @@
 //     path (global_load_lds, 1 KB per wave instruction, no registers, no ds_write) -- the four waves of a block share every
 //     fragment they read;
 //   * the ReLU gate of the input gradient (d ah = dsc (x) w_o . 1[ah > 0]) is ONE exact bf16 plane: three products, no split.
-// A block = 4 waves (one per SIMD) = 256 rows of the tall operand per pass, persistent over the row tiles (grid = CUs).
+// A block = 256 rows of the tall operand per pass (4 waves of 64 rows, one per SIMD, or 8 waves of 32), persistent over the row tiles (grid = CUs).
 // Operands are SWAPPED at the MFMA (srcA = weight planes, srcB = rows): lane (c, q) then holds 4 consecutive output columns
 // (16 tt + 4 q ..+3) of row c -- the epilogue stores float4s, no LDS staging.
 //
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void ts_wsplit_kernel(const float* __restrict_
 }
 
 struct TsArgs {
-    const float* A;             // the tall operand [M, 32 KG], row-major
+    const float* A;             // the tall operand [M, 32 KG], row-major (GEN: unused)
     int lda;
     const u32x4* planes;        // ts_wsplit_kernel's output for the small operand
     float* C;                   // [M, 16 NT]
@@ -76,6 +76,15 @@ struct TsArgs {
     const float* dot_w;         // forward: dot_out[row] = sum_n C[row, n] dot_w[n] ([N], never null; dot_out may be)
     float* dot_out;
     const float* rowscale;      // gate: C[row, :] *= rowscale[row]
+    // GEN (forward): row r = (example b = r / P, pair p = r % P) of the tall operand is e[b, pair_i[p], :] . e[b, pair_j[p], :], formed in
+    // the registers from the gathered embeddings e [examples, e_ld] (field f at f * 32 KG) -- AFM.py:130-139's element-wise products
+    // without the [B P, K] tensor
+    const float* e;
+    int e_ld;
+    int64_t e_floats;           // examples * e_ld
+    const int16_t* pair_i;
+    const int16_t* pair_j;
+    int P;
 };
 
 enum { TS_FWD = 0, TS_GATE = 1 };
@@ -85,8 +94,15 @@ typedef __attribute__((address_space(3))) void ts_lds_ptr;
 // KG: reduction length / 32; NT: output columns / 16.
 //   TS_FWD : C = relu(A W + bias), dot_out = C . dot_w        (A split in registers: 6 products)
 //   TS_GATE: C = rowscale (x) (1[A > 0] Wt')                  (A is a ReLU output: one exact plane, 3 products)
-template <int KG, int NT, int MODE>
-__global__ __launch_bounds__(256, 1) void gemm_ts_kernel(TsArgs a) {
+// TM: 16-row tiles per wave; a block is 16 / TM waves = 256 rows.  TM = 4: four waves, one per SIMD, 256 accumulator registers each (the
+// AGPR half of the file).  TM = 2: EIGHT waves, two per SIMD with 256 registers each -- one wave's row loads, split and epilogue stores run
+// under the other's MFMAs (with one wave per SIMD every one of them idles the matrix pipe), at twice the LDS fragment traffic: fine for the
+// six-product forward (LDS 50 % busy), not for the three-product gate (100 %).
+template <int KG, int NT, int MODE, bool GEN = false, int TM = 4>
+__global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
+    static_assert(!GEN || MODE == TS_FWD, "generated rows: the forward product");
+    static_assert(TM == 4 || TM == 2, "four or eight waves");
+    constexpr int NW = 16 / TM;
     constexpr int N = 16 * NT;
     constexpr int PLANE = 4 * N * 16;                  // bytes of one plane of one group
     constexpr int BUF = 3 * PLANE;
@@ -103,14 +119,14 @@ __global__ __launch_bounds__(256, 1) void gemm_ts_kernel(TsArgs a) {
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
         return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
     };
-    // the planes of group g -> LDS image `buf`, contiguous in both: wave w takes the 1 KB pieces w, w + 4, ...  (buffer form: the lane part
+    // the planes of group g -> LDS image `buf`, contiguous in both: wave w takes the 1 KB pieces w, w + NW, ...  (buffer form: the lane part
     // of the address is ONE register, lane x 16, and the piece is a scalar offset -- with global_load_lds hipcc hoisted a 64-bit per-lane
     // address per piece and group out of the loop: 192 registers, spills)
     const auto rp = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.planes), 0, 3 * KG * PLANE, 0x00020000);
     auto stage = [&](int g, int buf) {
 #pragma unroll
-        for (int j = 0; j < PIECES / 4; ++j) {
-            const int piece = 4 * j + w;
+        for (int j = 0; j < PIECES / NW; ++j) {
+            const int piece = NW * j + w;
             const int p = piece / (PLANE / 1024), o = piece - p * (PLANE / 1024);
             const int so = __builtin_amdgcn_readfirstlane((p * KG + g) * PLANE + o * 1024);
 #if defined(__HIP_DEVICE_COMPILE__)     // (hipcc's HOST pass drops the kernel's stub without a diagnostic when it meets this builtin)
@@ -121,45 +137,76 @@ __global__ __launch_bounds__(256, 1) void gemm_ts_kernel(TsArgs a) {
         }
     };
     // the rows of one block tile behind a per-wave base (rows beyond M: num_records ends at the last real row -> zeros, no traffic)
-    auto rows_of = [&](int64_t tl) { const int64_t m0 = tl * 256 + 64 * w; return (int)(a.M - m0 < 64 ? (a.M - m0 > 0 ? a.M - m0 : 0) : 64); };
+    auto rows_of = [&](int64_t tl) { const int64_t m0 = tl * 256 + 16 * TM * w; return (int)(a.M - m0 < 16 * TM ? (a.M - m0 > 0 ? a.M - m0 : 0) : 16 * TM); };
     auto a_rsrc = [&](int64_t tl) {
-        const int rows = rows_of(tl);
-        return __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.A + (size_t)(tl * 256 + 64 * w) * a.lda), 0,
-                                                 __builtin_amdgcn_readfirstlane(rows > 0 ? ((rows - 1) * a.lda + 32 * KG) * 4 : 0), 0x00020000);
+        if constexpr (GEN) {        // (one descriptor over all of e: the rows of a tile are anywhere in it)
+            return __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.e), 0, __builtin_amdgcn_readfirstlane((int)(a.e_floats * 4)), 0x00020000);
+        } else {
+            const int rows = rows_of(tl);
+            return __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.A + (size_t)(tl * 256 + 16 * TM * w) * a.lda), 0,
+                                                     __builtin_amdgcn_readfirstlane(rows > 0 ? ((rows - 1) * a.lda + 32 * KG) * 4 : 0), 0x00020000);
+        }
     };
-    int aoff[4], coff[4];
+    // lane offsets of the row tiles: into the tile's rows, or (GEN) into e for the two factors of each row's pair
+    struct Offs { int i[TM]; int j[GEN ? TM : 1]; };
+    auto offs_of = [&](int64_t tl, Offs& o) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        aoff[i] = 4 * ((16 * i + c) * a.lda + 4 * q);
-        coff[i] = 4 * ((16 * i + c) * a.ldc + 4 * q);
-    }
-    auto loadA = [&](float (&raw)[4][8], decltype(a_rsrc(0)) rs, int g) {
+        for (int i = 0; i < TM; ++i) {
+            if constexpr (GEN) {
+                int64_t row = tl * 256 + 16 * TM * w + 16 * i + c;
+                if (row >= a.M) row = a.M - 1;          // (a row past the end: any real pair -- nobody stores it)
+                const unsigned b = (unsigned)row / (unsigned)a.P, p = (unsigned)row - b * (unsigned)a.P;
+                o.i[i] = 4 * ((int)b * a.e_ld + a.pair_i[p] * 32 * KG + 4 * q);
+                o.j[i] = 4 * ((int)b * a.e_ld + a.pair_j[p] * 32 * KG + 4 * q);
+            } else {
+                o.i[i] = 4 * ((16 * i + c) * a.lda + 4 * q);
+            }
+        }
+    };
+    int coff[TM];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, aoff[i], 128 * g, 0);
-            const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, aoff[i] + 64, 128 * g, 0);
+    for (int i = 0; i < TM; ++i) coff[i] = 4 * ((16 * i + c) * a.ldc + 4 * q);
+    struct Raw { float a[TM][8]; float b[GEN ? TM : 1][8]; };
+    auto loadA = [&](Raw& raw, decltype(a_rsrc(0)) rs, const Offs& o, int g) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { raw[i][e] = __uint_as_float(v0[e]); raw[i][4 + e] = __uint_as_float(v1[e]); }
+        for (int i = 0; i < TM; ++i) {
+            const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, o.i[i], 128 * g, 0);
+            const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, o.i[i] + 64, 128 * g, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { raw.a[i][e] = __uint_as_float(v0[e]); raw.a[i][4 + e] = __uint_as_float(v1[e]); }
+            if constexpr (GEN) {
+                const u32x4 u0 = __builtin_amdgcn_raw_buffer_load_b128(rs, o.j[i], 128 * g, 0);
+                const u32x4 u1 = __builtin_amdgcn_raw_buffer_load_b128(rs, o.j[i] + 64, 128 * g, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { raw.b[i][e] = __uint_as_float(u0[e]); raw.b[i][4 + e] = __uint_as_float(u1[e]); }
+            }
         }
     };
     // raw -> the MFMA operand(s) of the rows
-    struct Ops { u32x4 h[4], m[MODE == TS_FWD ? 4 : 1], l[MODE == TS_FWD ? 4 : 1]; };
-    auto convert = [&](const float (&raw)[4][8], Ops& o) {
+    struct Ops { u32x4 h[TM], m[MODE == TS_FWD ? TM : 1], l[MODE == TS_FWD ? TM : 1]; };
+    auto convert = [&](const Raw& raw, Ops& o) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TM; ++i) {
             if constexpr (MODE == TS_FWD) {
                 DrPlanes p;
-                dr_split3(raw[i], p);
+                if constexpr (GEN) {
+                    float x[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = raw.a[i][e] * raw.b[i][e];       // (the product afm_pair_fwd_kernel stores: one f32 multiply)
+                    dr_split3(x, p);
+                } else {
+                    dr_split3(raw.a[i], p);
+                }
                 o.h[i] = p.h; o.m[i] = p.m; o.l[i] = p.l;
             } else {
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt)
-                    o.h[i][tt] = (raw[i][2 * tt] > 0.f ? 0x3f80u : 0u) | (raw[i][2 * tt + 1] > 0.f ? 0x3f800000u : 0u);
+                    o.h[i][tt] = (raw.a[i][2 * tt] > 0.f ? 0x3f80u : 0u) | (raw.a[i][2 * tt + 1] > 0.f ? 0x3f800000u : 0u);
             }
         }
     };
     const int boff = (q * N + c) * 16;                  // this lane's fragment of (plane 0, column tile 0)
-    f32x4 acc[4][NT];
+    f32x4 acc[TM][NT];
     // One region per column tile, fenced: the three fragments of tile tt + 1 are asked for ahead of tile tt's MFMAs and nothing else moves
     // across (left alone, hipcc hoists all 3 NT fragment reads of a group to its top: 192 registers, spills).
     auto products = [&](const Ops& o, int buf) {
@@ -176,34 +223,40 @@ __global__ __launch_bounds__(256, 1) void gemm_ts_kernel(TsArgs a) {
             const u32x4 bh = fb[tt & 1][0], bm = fb[tt & 1][1], bl = fb[tt & 1][2];
             if constexpr (MODE == TS_FWD) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][tt] = dr_mfma_bf16(bm, o.m[i], acc[i][tt]);
+                for (int i = 0; i < TM; ++i) acc[i][tt] = dr_mfma_bf16(bm, o.m[i], acc[i][tt]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][tt] = dr_mfma_bf16(bh, o.l[i], acc[i][tt]);
+                for (int i = 0; i < TM; ++i) acc[i][tt] = dr_mfma_bf16(bh, o.l[i], acc[i][tt]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][tt] = dr_mfma_bf16(bl, o.h[i], acc[i][tt]);
+                for (int i = 0; i < TM; ++i) acc[i][tt] = dr_mfma_bf16(bl, o.h[i], acc[i][tt]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][tt] = dr_mfma_bf16(bh, o.m[i], acc[i][tt]);
+                for (int i = 0; i < TM; ++i) acc[i][tt] = dr_mfma_bf16(bh, o.m[i], acc[i][tt]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][tt] = dr_mfma_bf16(bm, o.h[i], acc[i][tt]);
+                for (int i = 0; i < TM; ++i) acc[i][tt] = dr_mfma_bf16(bm, o.h[i], acc[i][tt]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][tt] = dr_mfma_bf16(bh, o.h[i], acc[i][tt]);
+                for (int i = 0; i < TM; ++i) acc[i][tt] = dr_mfma_bf16(bh, o.h[i], acc[i][tt]);
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][tt] = dr_mfma_bf16(bl, o.h[i], acc[i][tt]);
+                for (int i = 0; i < TM; ++i) acc[i][tt] = dr_mfma_bf16(bl, o.h[i], acc[i][tt]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][tt] = dr_mfma_bf16(bm, o.h[i], acc[i][tt]);
+                for (int i = 0; i < TM; ++i) acc[i][tt] = dr_mfma_bf16(bm, o.h[i], acc[i][tt]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][tt] = dr_mfma_bf16(bh, o.h[i], acc[i][tt]);
+                for (int i = 0; i < TM; ++i) acc[i][tt] = dr_mfma_bf16(bh, o.h[i], acc[i][tt]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    float raw[4][8];
+    // The rows of group g + 1 are asked for at the top of group g and waited for at its end, one group (3-6 k cycles of MFMAs) later.
+    // (Two groups ahead -- a second raw set -- changed nothing: 1.55 ms either way for the input gradient, tools/gemm_ts_probe; what the
+    // kernel waits for is not the row loads.)
+    Raw raw;
     Ops cur, nxt;
+    Offs off, noff;
     auto rs = a_rsrc(bt);
+    offs_of(bt, off);
+    noff = off;
     stage(0, 0);
-    loadA(raw, rs, 0);
+    loadA(raw, rs, off, 0);
     __syncthreads();                                    // (drains the LDS-DMA queue: vmcnt(0) before the barrier)
     convert(raw, cur);
     int buf = 0;
@@ -212,25 +265,27 @@ __global__ __launch_bounds__(256, 1) void gemm_ts_kernel(TsArgs a) {
         const bool more = next < nbt;
         auto rs_next = a_rsrc(more ? next : bt);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) acc[i][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int64_t m0 = bt * 256 + 64 * w;
+        const int64_t m0 = bt * 256 + 16 * TM * w;
         // the per-row scalars of the epilogue, asked for before the products (in the epilogue they would queue behind the next tile's loads)
-        float rsc[4];
+        float rsc[TM];
         if constexpr (MODE == TS_GATE) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rsc[i] = m0 + 16 * i + c < a.M ? a.rowscale[m0 + 16 * i + c] : 0.f;
+            for (int i = 0; i < TM; ++i) rsc[i] = m0 + 16 * i + c < a.M ? a.rowscale[m0 + 16 * i + c] : 0.f;
         }
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
-            // everything asked for here lands under this group's MFMAs (3-6 k cycles) and is waited for at its end
+            // everything asked for here lands under this group's MFMAs and is waited for at its end
             if (g + 1 < KG) {
                 if (!(TS_SKIP & 2)) stage(g + 1, buf ^ 1);
-                if (!(TS_SKIP & 1)) loadA(raw, rs, g + 1);
+                if (!(TS_SKIP & 1)) loadA(raw, rs, off, g + 1);
+                // (GEN: the next tile's pair lookups, two loads per row, a group ahead of the offsets' first use)
+                if (GEN && g + 2 == KG) offs_of(more ? next : bt, noff);
             } else {
                 if (more && !(TS_SKIP & 2)) stage(0, buf ^ 1);
-                if (!(TS_SKIP & 1)) loadA(raw, rs_next, 0);                 // (the last tile re-reads its own first group: nobody consumes it)
+                if (!(TS_SKIP & 1)) loadA(raw, rs_next, GEN ? noff : off, 0);     // (the last tile re-reads its own first group: nobody consumes it)
             }
             products(cur, buf);
             convert(raw, nxt);
@@ -242,7 +297,9 @@ __global__ __launch_bounds__(256, 1) void gemm_ts_kernel(TsArgs a) {
         const int rows = rows_of(bt);
         const auto rc = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.C + (size_t)m0 * a.ldc), 0,
                                                           __builtin_amdgcn_readfirstlane(rows > 0 ? ((rows - 1) * a.ldc + N) * 4 : 0), 0x00020000);
-        float dot[4] = {0.f, 0.f, 0.f, 0.f};
+        float dot[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) dot[i] = 0.f;
         auto ld4 = [&](const float* p, int tt) { return *reinterpret_cast<const f32x4*>(p + 16 * tt + 4 * q); };
         f32x4 bc = f32x4{0.f, 0.f, 0.f, 0.f}, dc = bc;
         if constexpr (MODE == TS_FWD) { bc = ld4(a.bias, 0); dc = ld4(a.dot_w, 0); }
@@ -253,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ts_kernel(TsArgs a) {
                 if (tt + 1 < NT) { bn = ld4(a.bias, tt + 1); dn = ld4(a.dot_w, tt + 1); }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < TM; ++i) {
                 f32x4 v = acc[i][tt];
                 if constexpr (MODE == TS_FWD) {
 #pragma unroll
@@ -274,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ts_kernel(TsArgs a) {
         if constexpr (MODE == TS_FWD) {
             if (a.dot_out != nullptr) {                 // (uniform) the four q-lanes of a row hold its four column quarters
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < TM; ++i) {
                     float d = dot[i];
                     d += __shfl_xor(d, 16);
                     d += __shfl_xor(d, 32);
@@ -285,6 +342,234 @@ __global__ __launch_bounds__(256, 1) void gemm_ts_kernel(TsArgs a) {
         if (!more) break;
         bt = next;
         rs = rs_next;
+        if constexpr (GEN) off = noff;
+    }
+}
+
+// ---- the weight gradient of the same layer under its rank-one output gradient (gemm_dr.h DR_BGATE_WGRAD, in split precision) ----------------
+//   dW[k, a] = colscale[a] * sum_r (rowscale[r] X[r, k]) * 1[H[r, a] > 0]       (X = the pair products, H = the layer's ReLU output)
+//   db[a]    = colscale[a] * sum_r rowscale[r] 1[H[r, a] > 0]
+//   dwo[a]   = sum_r rowscale[r] H[r, a]                                         (the weight gradient of the (A -> 1) layer behind H)
+// The row scale moves to the X side (one multiply per element), which leaves the gate as the B operand: ONE exact bf16 plane, three
+// products per tile pair instead of six.  The reduction runs over the ROWS, so a block owns the whole [Kd, A] output for a
+// contiguous range of rows (one partial slab per block: grid slabs) and the product is HBM-bound (each operand row is read once: 6.2 GB at
+// the reference point against 0.5 ms of matrix pipe) -- the schedule is the simple one: convert, barrier, multiply, with the loads of two
+// groups (32 rows each) in flight.  Wave w splits X's columns [16 TK w, 16 TK (w + 1)) in registers and turns H's columns
+// [16 TA w, 16 TA (w + 1)) into gate fragments that all the waves read from LDS (16 KB per group at A = 256, double-buffered); it also owns those
+// columns' two sums.  Both operands are read with one 16-byte (TK, TA = 4) or 8-byte (= 2) load per lane and row: lane (c, q) takes columns
+// T c .. T c + T - 1 of rows 8 q .. 8 q + 7, i.e. element i of the load belongs to tile i, whose fragment column c is matrix column T c + i.
+struct TswArgs {
+    const float* X; int ldx;            // [M, Kd] (GEN: unused)
+    const float* H; int ldh;            // [M, A]
+    const float* rowscale;              // [M]
+    const float* colscale;              // [A]
+    float* dw; int64_t dw_stride;       // slab b: dw + b * dw_stride, row-major [Kd, A]
+    float* db; int64_t db_stride;       // slab b: db + b * db_stride, [A]
+    float* dwo; int64_t dwo_stride;
+    int64_t M;
+    int rows_per_block;                 // a multiple of 32; gridDim.x * rows_per_block >= M
+    // GEN: X[r, :] = e[b, pair_i[p], :] . e[b, pair_j[p], :] for r = b P + p, formed in the registers from the gathered embeddings
+    // (as TsArgs; field f at f * Kd of an example's e_ld floats)
+    const float* e;
+    int e_ld;
+    int64_t e_floats;
+    const int16_t* pair_i;
+    const int16_t* pair_j;
+    int P;
+};
+
+// NW waves per block: X has 16 TK NW columns, H has 16 TA NW.  At 256 x 256 the block is EIGHT waves of a [32, 256] output strip each (two
+// per SIMD, 128 accumulator registers): with four waves of [64, 256] the 256 accumulators fill the AGPR half of the register file and the
+// two raw sets + planes no longer fit the other half (355 registers spilled) -- and two waves per SIMD overlap one's conversion with the
+// other's MFMAs for free.
+template <int NW, int TK, int TA, bool GEN = false>
+__global__ __launch_bounds__(64 * NW, 1) void gemm_tsw_kernel(TswArgs a) {
+    static_assert((TK == 2 || TK == 4) && (TA == 2 || TA == 4) && (NW == 4 || NW == 8), "two or four 16-column tiles per wave and operand");
+    constexpr int NJ = NW * TA;                         // gate tiles of the block
+    constexpr int KD = 16 * TK * NW;
+    extern __shared__ __attribute__((aligned(16))) char ts_lds[];          // [2][NJ][64 lanes] x 16 bytes (+ GEN: the pair table, P words)
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
+    const int rows = (int)(a.M - r0 < a.rows_per_block ? (a.M - r0 > 0 ? a.M - r0 : 0) : a.rows_per_block);
+    const int G = __builtin_amdgcn_readfirstlane((rows + 31) / 32);
+    auto uni_ptr = [](const void* p) {
+        const uint64_t v = reinterpret_cast<uint64_t>(p);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+    };
+    // this block's rows behind per-block bases: whatever a partial or surplus group addresses beyond them reads as 0 without touching memory
+    const auto rx = GEN ? __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.e), 0, __builtin_amdgcn_readfirstlane((int)(a.e_floats * 4)), 0x00020000)
+                        : __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.X + (size_t)r0 * a.ldx), 0, __builtin_amdgcn_readfirstlane(rows > 0 ? ((rows - 1) * a.ldx + KD) * 4 : 0), 0x00020000);
+    const auto rh = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.H + (size_t)r0 * a.ldh), 0, __builtin_amdgcn_readfirstlane(rows > 0 ? ((rows - 1) * a.ldh + 16 * TA * NW) * 4 : 0), 0x00020000);
+    const auto rr = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.rowscale + r0), 0, __builtin_amdgcn_readfirstlane(rows * 4), 0x00020000);
+    const int xoff = 4 * ((GEN ? 0 : 8 * q * a.ldx) + 16 * TK * w + TK * c), hoff = 4 * (8 * q * a.ldh + 16 * TA * w + TA * c);
+    const unsigned sx = 4u * (unsigned)a.ldx, sh = 4u * (unsigned)a.ldh;
+    // GEN: pair p -> the two fields' offsets inside an example (floats, 16 bits each), in LDS; this lane's (example, pair) of the first of
+    // its 8 rows in the next group to load, advanced by 32 rows per group (P > 32: at most one carry)
+    unsigned* tab = reinterpret_cast<unsigned*>(ts_lds + 2 * NJ * 1024);
+    int bx = 0, px = 0;
+    const int nex = GEN ? (int)(a.e_floats / a.e_ld) : 0;
+    if constexpr (GEN) {
+        for (int p = t; p < a.P; p += 64 * NW) tab[p] = (unsigned)(a.pair_i[p] * KD) | ((unsigned)(a.pair_j[p] * KD) << 16);
+        const unsigned row = (unsigned)(r0 + 8 * q);
+        bx = (int)(row / (unsigned)a.P);
+        px = (int)(row - (unsigned)bx * (unsigned)a.P);
+        __syncthreads();
+    }
+
+    struct RawH { float h[8][TA]; float rs[8]; };
+    struct RawX { float x[8][TK]; float y[GEN ? 8 : 1][TK]; };
+    auto ldn = [](auto rs, int voff, unsigned soff_, auto nt, float* d) {
+        constexpr int NV = decltype(nt)::value;
+        const unsigned soff = __builtin_amdgcn_readfirstlane(soff_);
+        if constexpr (NV == 4) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = __uint_as_float(v[e]);
+        } else {
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+            d[0] = __uint_as_float(v[0]);
+            d[1] = __uint_as_float(v[1]);
+        }
+    };
+    using ITK = std::integral_constant<int, TK>;
+    using ITA = std::integral_constant<int, TA>;
+    using I4 = std::integral_constant<int, 4>;
+    auto loadH = [&](RawH& f, int g) {
+        ldn(rr, 32 * q, 128u * g, I4{}, &f.rs[0]);
+        ldn(rr, 32 * q + 16, 128u * g, I4{}, &f.rs[4]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ldn(rh, hoff, (32u * g + e) * sh, ITA{}, &f.h[e][0]);
+    };
+    auto loadX = [&](RawX& f, int g) {
+        if constexpr (GEN) {
+            (void)g;                                    // (the rows of the group after the one loaded last: bx, px)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int pe = px + e, be = bx;
+                if (pe >= a.P) { pe -= a.P; ++be; }
+                if (be >= nex) be = nex - 1;            // (rows past the end: any real pair; their row scale and gate are zero)
+                const unsigned tw = tab[pe];
+                const int base = be * a.e_ld;
+                ldn(rx, xoff + 4 * (base + (int)(tw & 0xffffu)), 0u, ITK{}, &f.x[e][0]);
+                ldn(rx, xoff + 4 * (base + (int)(tw >> 16)), 0u, ITK{}, &f.y[e][0]);
+            }
+            px += 32;
+            if (px >= a.P) { px -= a.P; ++bx; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ldn(rx, xoff, (32u * g + e) * sx, ITK{}, &f.x[e][0]);
+        }
+    };
+    f32x4 acc[TK][NJ];
+#pragma unroll
+    for (int i = 0; i < TK; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float cs[TA], cs2[TA];
+#pragma unroll
+    for (int j = 0; j < TA; ++j) cs[j] = cs2[j] = 0.f;
+    DrPlanes px_[TK];
+    // raw -> X planes (registers), gate fragments (LDS image `buf`), the two column sums
+    auto convert = [&](const RawX& fx, const RawH& f, int buf) {
+#pragma unroll
+        for (int i = 0; i < TK; ++i) {
+            float xs[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xs[e] = (GEN ? fx.x[e][i] * fx.y[e][i] : fx.x[e][i]) * f.rs[e];      // (GEN: the f32 product afm_pair_fwd_kernel stores, then the scale)
+            dr_split3(xs, px_[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < TA; ++j) {
+            u32x4 gw;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const float h0 = f.h[2 * tt][j], h1 = f.h[2 * tt + 1][j];
+                gw[tt] = (h0 > 0.f ? 0x3f80u : 0u) | (h1 > 0.f ? 0x3f800000u : 0u);
+                cs[j] += (h0 > 0.f ? f.rs[2 * tt] : 0.f) + (h1 > 0.f ? f.rs[2 * tt + 1] : 0.f);
+                cs2[j] = fmaf(h0, f.rs[2 * tt], cs2[j]);
+                cs2[j] = fmaf(h1, f.rs[2 * tt + 1], cs2[j]);
+            }
+            *reinterpret_cast<u32x4*>(ts_lds + ((buf * NJ + TA * w + j) * 64 + lane) * 16) = gw;
+        }
+    };
+    auto products = [&](int buf) {
+        const char* base = ts_lds + (buf * NJ * 64 + lane) * 16;
+        u32x4 fg[2];
+        fg[0] = *reinterpret_cast<const u32x4*>(base);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j + 1 < NJ) fg[(j + 1) & 1] = *reinterpret_cast<const u32x4*>(base + 1024 * (j + 1));
+            const u32x4 gq = fg[j & 1];
+#pragma unroll
+            for (int i = 0; i < TK; ++i) acc[i][j] = dr_mfma_bf16(px_[i].l, gq, acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < TK; ++i) acc[i][j] = dr_mfma_bf16(px_[i].m, gq, acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < TK; ++i) acc[i][j] = dr_mfma_bf16(px_[i].h, gq, acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // H and the row scales (HBM) two groups ahead in two sets; X beside them -- or, generated from the cache-resident embeddings, ONE group
+    // ahead in one set (twice the registers per row)
+    RawH h0, h1;
+    RawX x0, x1;
+    if (G > 0) { loadH(h0, 0); loadX(x0, 0); }
+    if (G > 1) { loadH(h1, 1); if (!GEN) loadX(x1, 1); }
+    for (int g = 0; g < G; g += 2) {
+        convert(x0, h0, 0);
+        loadH(h0, g + 2);                               // (beyond the block's rows: zeros, no traffic)
+        loadX(GEN ? x0 : x0, GEN ? g + 1 : g + 2);
+        __syncthreads();
+        products(0);
+        if (g + 1 < G) {                                // (uniform)
+            convert(GEN ? x0 : x1, h1, 1);
+            loadH(h1, g + 3);
+            loadX(GEN ? x0 : x1, GEN ? g + 2 : g + 3);
+            __syncthreads();
+            products(1);
+        }
+    }
+    // ---- epilogue: register r of lane (c, q), tile (i, j = TA wj + jj) is dW[16 TK w + TK (4 q + r) + i][16 TA wj + TA c + jj]
+    constexpr int A_ = 16 * TA * NW;
+    // (buffer stores: the lane part of the address is one register, tile and row are a scalar offset)
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.dw + (size_t)blockIdx.x * a.dw_stride), 0, 16 * TK * NW * A_ * 4, 0x00020000);
+    const int woff = 4 * (TK * 4 * q * A_ + TA * c);
+#pragma unroll
+    for (int wj = 0; wj < NW; ++wj) {
+        float sc[TA];
+#pragma unroll
+        for (int jj = 0; jj < TA; ++jj) sc[jj] = a.colscale[16 * TA * wj + TA * c + jj];
+#pragma unroll
+        for (int i = 0; i < TK; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned so = __builtin_amdgcn_readfirstlane(4u * (unsigned)((16 * TK * w + TK * r + i) * A_ + 16 * TA * wj));
+                if constexpr (TA == 4) {
+                    const f32x4 v = f32x4{acc[i][4 * wj][r] * sc[0], acc[i][4 * wj + 1][r] * sc[1], acc[i][4 * wj + 2][r] * sc[2], acc[i][4 * wj + 3][r] * sc[3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rw, woff, so, 0);
+                } else {
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 v = f32x2{acc[i][2 * wj][r] * sc[0], acc[i][2 * wj + 1][r] * sc[1]};
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rw, woff, so, 0);
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the column sums of this wave's H columns: the four q hold different rows of the same columns
+#pragma unroll
+    for (int j = 0; j < TA; ++j) {
+        float s1 = cs[j], s2 = cs2[j];
+        s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+        const int col = 16 * TA * w + TA * c + j;
+        if (q == 0) {
+            if (a.db != nullptr) a.db[(size_t)blockIdx.x * a.db_stride + col] = s1 * a.colscale[col];
+            if (a.dwo != nullptr) a.dwo[(size_t)blockIdx.x * a.dwo_stride + col] = s2;
+        }
     }
 }
 

@@ -146,10 +146,18 @@ int ws_fc_bwd_data_gate(const float* h, int ldh, const float* rowscale, const fl
 // tall operands in split precision (gemm_ts.hip; DCTR_GEMM_TS=0 turns it off): *done = false -> not taken.  planes_ws: ts_plane_bytes(R, N)
 bool ts_takes(int64_t M, int R, int N);
 size_t ts_plane_bytes(int R, int N);
+// the tall operand as pair products of gathered embeddings (AFM.py:130-139), never stored: row b P + p = e[b, pair_i[p], :] . e[b, pair_j[p], :]
+// with e [examples, e_ld], field f at f * K
+struct TsPairs { const float* e; int e_ld; int examples; const int16_t* pair_i; const int16_t* pair_j; int P; };
+bool ts_pairs_ok(const TsPairs* g, int64_t M, int K);
 int ts_fc_fwd_dot(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int64_t M, int K, int N, const float* dot_w,
-                  float* dot_out, void* planes_ws, bool split_here, hipStream_t st, bool* done);
+                  float* dot_out, void* planes_ws, bool split_here, hipStream_t st, bool* done, const TsPairs* pairs = nullptr);
 int ts_fc_bwd_data_gate(const float* h, int ldh, const float* rowscale, const float* kscale, const float* w, float* dx, int lddx, int64_t M, int K,
                         int N, void* planes_ws, bool split_here, hipStream_t st, bool* done);
+int ts_fc_bwd_weights_gate(const float* x, int ldx, const float* h, int ldh, const float* rowscale, const float* colscale, float* dw_part,
+                           int64_t dw_stride, float* db_part, int64_t db_stride, float* dwo_part, int64_t dwo_stride, int64_t M, int K, int N, int splits,
+                           hipStream_t st, bool* done, const TsPairs* pairs = nullptr);
+constexpr int TS_WGRAD_SLABS = 256;         // one block per slab and CU
 int ts_prepare(const float* w, int K, int N, const float* kscale, void* fwd_planes, void* dgr_planes, hipStream_t st);
 int dr_wgrad_splits(int M, int K, int N);
 // Outer-PNN first layer with the pair products formed in the MFMA fragments (gemm_dr.hip)

@@ -29,6 +29,21 @@ __global__ void fill_kernel(float* p, int64_t n, uint32_t seed, float scale, int
     }
 }
 
+__global__ void pair_kernel(const float* e, int e_ld, const int16_t* pi, const int16_t* pj, int P, int K, int64_t M, float* X) {
+    for (int64_t idx = blockIdx.x * 256ll + threadIdx.x; idx < M * K; idx += gridDim.x * 256ll) {
+        const int64_t r = idx / K; const int k = (int)(idx - r * K);
+        const int64_t b = r / P; const int p = (int)(r - b * P);
+        X[idx] = e[b * e_ld + pi[p] * K + k] * e[b * e_ld + pj[p] * K + k];
+    }
+}
+static size_t diff_words(const void* a, const void* b, size_t n) {
+    std::vector<uint32_t> x(n), y(n);
+    CK(hipMemcpy(x.data(), a, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(y.data(), b, n * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    for (size_t i = 0; i < n; ++i) bad += x[i] != y[i];
+    return bad;
+}
+
 template <int KG, int NT>
 static void run(int64_t M, int reps) {
     constexpr int R = 32 * KG, N = 16 * NT;
@@ -39,7 +54,18 @@ static void run(int64_t M, int reps) {
     CK(hipMalloc(&W, R * N * 4)); CK(hipMalloc(&b, N * 4)); CK(hipMalloc(&wo, N * 4)); CK(hipMalloc(&rsc, (M + guard) * 4)); CK(hipMalloc(&dot, (M + guard) * 4));
     u32x4 *pf, *pg;
     CK(hipMalloc(&pf, 3 * R * N * 2)); CK(hipMalloc(&pg, 3 * R * N * 2));
-    fill_kernel<<<4096, 256>>>(X, M * R, 1, 1.f, 0);
+    // X = the pair products of F = 39 gathered embeddings per example (AFM.py:130-139), so that the generated-operand kernels can be compared
+    const int F = 39, P = F * (F - 1) / 2, e_ld = F * R;
+    const int64_t nex = (M + P - 1) / P;
+    float* E_; int16_t *pi, *pj;
+    CK(hipMalloc(&E_, nex * e_ld * 4)); CK(hipMalloc(&pi, P * 2)); CK(hipMalloc(&pj, P * 2));
+    {
+        std::vector<int16_t> hi, hj;
+        for (int i = 0; i < F - 1; ++i) for (int j = i + 1; j < F; ++j) { hi.push_back((int16_t)i); hj.push_back((int16_t)j); }
+        CK(hipMemcpy(pi, hi.data(), P * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(pj, hj.data(), P * 2, hipMemcpyHostToDevice));
+    }
+    fill_kernel<<<4096, 256>>>(E_, nex * e_ld, 1, 1.f, 0);
+    pair_kernel<<<8192, 256>>>(E_, e_ld, pi, pj, P, R, M, X);
     fill_kernel<<<64, 256>>>(W, R * N, 2, 0.08f, 0);
     fill_kernel<<<1, 256>>>(b, N, 3, 0.1f, 0);
     fill_kernel<<<1, 256>>>(wo, N, 4, 0.3f, 0);
@@ -75,6 +101,48 @@ static void run(int64_t M, int reps) {
     CK(hipGetLastError());
     const double gf = 2.0 * M * R * N * 1e-9;
     printf("forward  (6 products): %.3f ms  %.1f TF-equivalent  %.2f TB/s algorithmic\n", best, gf / best, (double)M * (R + N) * 4 / best * 1e-9);
+    {   // the same product with its rows generated from the embeddings: bit-identical output
+        float *Y2, *dot2;
+        CK(hipMalloc(&Y2, (M * N) * 4)); CK(hipMalloc(&dot2, M * 4));
+        TsArgs ag2 = af; ag2.C = Y2; ag2.dot_out = dot2; ag2.e = E_; ag2.e_ld = e_ld; ag2.e_floats = nex * e_ld; ag2.pair_i = pi; ag2.pair_j = pj; ag2.P = P;
+        auto kfg = gemm_ts_kernel<KG, NT, TS_FWD, true>;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfg), hipFuncAttributeMaxDynamicSharedMemorySize, ldsf));
+        best = 1e9f;
+        for (int r = 0; r < reps; ++r) {
+            CK(hipEventRecord(e0));
+            kfg<<<grid, 256, ldsf>>>(ag2);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            best = std::min(best, ms);
+        }
+        CK(hipGetLastError());
+        printf("forward, rows generated from the embeddings: %.3f ms  %.1f TF-equivalent; words differing from the product over the stored rows: %zu (+ %zu of the scores)\n",
+               best, gf / best, M <= 200000 ? diff_words(Y, Y2, M * N) : diff_words(Y, Y2, 1 << 24), diff_words(dot, dot2, M));
+        CK(hipFree(Y2)); CK(hipFree(dot2));
+    }
+    {   // eight waves of 32 rows (two per SIMD)
+        float *Y2, *dot2;
+        CK(hipMalloc(&Y2, (M * N) * 4)); CK(hipMalloc(&dot2, M * 4));
+        TsArgs a8 = af; a8.C = Y2; a8.dot_out = dot2; a8.e = E_; a8.e_ld = e_ld; a8.e_floats = nex * e_ld; a8.pair_i = pi; a8.pair_j = pj; a8.P = P;
+        auto k8 = gemm_ts_kernel<KG, NT, TS_FWD, false, 2>;
+        auto k8g = gemm_ts_kernel<KG, NT, TS_FWD, true, 2>;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, ldsf));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k8g), hipFuncAttributeMaxDynamicSharedMemorySize, ldsf));
+        for (int gen = 0; gen < 2; ++gen) {
+            best = 1e9f;
+            for (int r = 0; r < reps; ++r) {
+                CK(hipEventRecord(e0));
+                if (gen) k8g<<<grid, 512, ldsf>>>(a8); else k8<<<grid, 512, ldsf>>>(a8);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                best = std::min(best, ms);
+            }
+            CK(hipGetLastError());
+            printf("forward, 8 waves%s: %.3f ms  %.1f TF-equivalent; words differing: %zu (+ %zu of the scores)\n", gen ? ", rows generated" : "", best, gf / best,
+                   M <= 200000 ? diff_words(Y, Y2, M * N) : diff_words(Y, Y2, 1 << 24), diff_words(dot, dot2, M));
+        }
+        CK(hipFree(Y2)); CK(hipFree(dot2));
+    }
     // ---- gate
     TsArgs ag{}; ag.A = Y; ag.lda = N; ag.planes = pg; ag.C = DX; ag.ldc = R; ag.M = M; ag.rowscale = rsc;
     best = 1e9f;
@@ -84,6 +152,19 @@ static void run(int64_t M, int reps) {
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         best = std::min(best, ms);
+    }
+    {
+        auto kg8 = gemm_ts_kernel<NT / 2, 2 * KG, TS_GATE, false, 2>;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kg8), hipFuncAttributeMaxDynamicSharedMemorySize, ldsg));
+        float b8 = 1e9f;
+        for (int r = 0; r < reps; ++r) {
+            CK(hipEventRecord(e0));
+            kg8<<<grid, 512, ldsg>>>(ag);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            b8 = std::min(b8, ms);
+        }
+        printf("gate dgrad, 8 waves: %.3f ms  %.1f TF-equivalent\n", b8, 2.0 * M * R * N * 1e-9 / b8);
     }
     CK(hipGetLastError());
     printf("gate dgrad (3 products): %.3f ms  %.1f TF-equivalent  %.2f TB/s algorithmic\n", best, gf / best, (double)M * (R + N) * 4 / best * 1e-9);
@@ -119,7 +200,78 @@ static void run(int64_t M, int reps) {
     CK(hipMemcpy(gd.data(), DX + M * R, guard * 4, hipMemcpyDeviceToHost)); for (auto v : gd) bad += v != 0xffffffffu;
     CK(hipMemcpy(gd.data(), dot + M, guard * 4, hipMemcpyDeviceToHost)); for (auto v : gd) bad += v != 0xffffffffu;
     printf("  max |err| forward %.3e (values to %.2f), score dot %.3e, gate dgrad %.3e (values to %.2f); words written past the ends: %zu\n", ef, sf, ed, eg, sg, bad);
-    CK(hipFree(X)); CK(hipFree(Y)); CK(hipFree(DX)); CK(hipFree(W)); CK(hipFree(b)); CK(hipFree(wo)); CK(hipFree(rsc)); CK(hipFree(dot)); CK(hipFree(pf)); CK(hipFree(pg));
+    // ---- gated weight gradient: dW[k, a] = wo[a] sum_r (rsc[r] X[r, k]) 1[Y[r, a] > 0], partial slabs per block
+    {
+        constexpr int NW = (R == 256 && N == 256) ? 8 : 4, TK = R / (16 * NW), TA = N / (16 * NW);
+        const int grid_w = 256;
+        const int rpb = (int)(((M + grid_w - 1) / grid_w + 31) / 32 * 32);
+        float *dw, *db, *dwo;
+        CK(hipMalloc(&dw, (size_t)grid_w * R * N * 4)); CK(hipMalloc(&db, grid_w * N * 4)); CK(hipMalloc(&dwo, grid_w * N * 4));
+        TswArgs aw{}; aw.X = X; aw.ldx = R; aw.H = Y; aw.ldh = N; aw.rowscale = rsc; aw.colscale = wo; aw.dw = dw; aw.dw_stride = R * N; aw.db = db; aw.db_stride = N;
+        aw.dwo = dwo; aw.dwo_stride = N; aw.M = M; aw.rows_per_block = rpb;
+        auto kw = gemm_tsw_kernel<NW, TK, TA>;
+        const int ldsw = 2 * NW * TA * 1024;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw));
+        best = 1e9f;
+        for (int r = 0; r < reps; ++r) {
+            CK(hipEventRecord(e0));
+            kw<<<grid_w, 64 * NW, ldsw>>>(aw);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            best = std::min(best, ms);
+        }
+        CK(hipGetLastError());
+        printf("gate wgrad (3 products): %.3f ms  %.1f TF-equivalent  %.2f TB/s algorithmic (%d rows per block)\n", best, gf / best, (double)M * (R + N) * 4 / best * 1e-9, rpb);
+        if (M <= 200000) {
+            std::vector<float> hx((size_t)M * R), hy((size_t)M * N), hr(M), hdw((size_t)grid_w * R * N), hdb(grid_w * N), hdwo(grid_w * N);
+            CK(hipMemcpy(hx.data(), X, hx.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hy.data(), Y, hy.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hr.data(), rsc, M * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hdw.data(), dw, hdw.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hdb.data(), db, hdb.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hdwo.data(), dwo, hdwo.size() * 4, hipMemcpyDeviceToHost));
+            double ew = 0, sw = 0, eb = 0, sb = 0, eo = 0, so = 0;
+            for (int kk = 0; kk < 24; ++kk) {
+                const int k = (kk * 37 + 5) % R;
+                for (int aa = 0; aa < 24; ++aa) {
+                    const int an = (aa * 29 + 3) % N;
+                    double v = 0;
+                    for (int64_t r = 0; r < M; ++r) if (hy[r * N + an] > 0.f) v += (double)(hr[r] * hx[r * R + k]);
+                    v *= hwo[an];
+                    double got = 0;
+                    for (int b2 = 0; b2 < grid_w; ++b2) got += hdw[(size_t)b2 * R * N + (size_t)k * N + an];
+                    ew = std::max(ew, std::fabs(v - got)); sw = std::max(sw, std::fabs(v));
+                }
+            }
+            for (int an = 0; an < N; ++an) {
+                double v1 = 0, v2 = 0, g1 = 0, g2 = 0;
+                for (int64_t r = 0; r < M; ++r) { if (hy[r * N + an] > 0.f) v1 += hr[r]; v2 += (double)hr[r] * hy[r * N + an]; }
+                v1 *= hwo[an];
+                for (int b2 = 0; b2 < grid_w; ++b2) { g1 += hdb[b2 * N + an]; g2 += hdwo[b2 * N + an]; }
+                eb = std::max(eb, std::fabs(v1 - g1)); sb = std::max(sb, std::fabs(v1));
+                eo = std::max(eo, std::fabs(v2 - g2)); so = std::max(so, std::fabs(v2));
+            }
+            printf("  max |err| gate wgrad %.3e (values to %.2f), bias grad %.3e (to %.2f), second column sums %.3e (to %.2f)\n", ew, sw, eb, sb, eo, so);
+        }
+        {   // generated X
+            float *dw2, *db2, *dwo2;
+            CK(hipMalloc(&dw2, (size_t)grid_w * R * N * 4)); CK(hipMalloc(&db2, grid_w * N * 4)); CK(hipMalloc(&dwo2, grid_w * N * 4));
+            TswArgs a2 = aw; a2.dw = dw2; a2.db = db2; a2.dwo = dwo2; a2.e = E_; a2.e_ld = e_ld; a2.e_floats = nex * e_ld; a2.pair_i = pi; a2.pair_j = pj; a2.P = P;
+            auto kwg = gemm_tsw_kernel<NW, TK, TA, true>;
+            const int ldsg2 = ldsw + P * 4;
+            best = 1e9f;
+            for (int r = 0; r < reps; ++r) {
+                CK(hipEventRecord(e0));
+                kwg<<<grid_w, 64 * NW, ldsg2>>>(a2);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                best = std::min(best, ms);
+            }
+            CK(hipGetLastError());
+            printf("gate wgrad, X generated from the embeddings: %.3f ms  %.1f TF-equivalent; words differing: %zu of dW, %zu of db, %zu of dwo\n", best, gf / best,
+                   diff_words(dw, dw2, (size_t)grid_w * R * N), diff_words(db, db2, grid_w * N), diff_words(dwo, dwo2, grid_w * N));
+            CK(hipFree(dw2)); CK(hipFree(db2)); CK(hipFree(dwo2));
+        }
+        CK(hipFree(dw)); CK(hipFree(db)); CK(hipFree(dwo));
+    }
+    CK(hipFree(X)); CK(hipFree(Y)); CK(hipFree(DX)); CK(hipFree(W)); CK(hipFree(b)); CK(hipFree(wo)); CK(hipFree(rsc)); CK(hipFree(dot)); CK(hipFree(pf)); CK(hipFree(pg)); CK(hipFree(E_)); CK(hipFree(pi)); CK(hipFree(pj));
 }
 
 int main() {
