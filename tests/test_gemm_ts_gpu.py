@@ -57,6 +57,11 @@ def test_tall_products_are_f32_equivalent(M, K, N, dev):
     e32 = float(((ys.to(dev) @ dwo_).cpu().double() - dref).abs().max())
     print("score dot: max err %.2e (an f32 matvec of the same rows: %.2e)" % (ed, e32))
     assert ed <= 2 * e32 + 1e-7, (ed, e32)
+    # twice the same bits (LDS-DMA staging, barriers and two waves per SIMD: a schedule-dependent result would be a race)
+    yb2 = torch.empty(M, N, device=dev); db2 = torch.empty(M, device=dev)
+    for _ in range(3):
+        capi.check(lib.dctr_fc_fwd_dot_split(capi.ptr(dx_), K, capi.ptr(dw_), capi.ptr(db_), capi.ptr(yb2), N, M, K, N, capi.ptr(dwo_), capi.ptr(db2), capi.ptr(ws), st))
+        assert torch.equal(yb2.cpu(), ys) and torch.equal(db2, dbuf[:M])
     # without the dot output
     y2 = torch.empty(M, N, device=dev)
     capi.check(lib.dctr_fc_fwd_dot_split(capi.ptr(dx_), K, capi.ptr(dw_), capi.ptr(db_), capi.ptr(y2), N, M, K, N, capi.ptr(dwo_), None, capi.ptr(ws), st))
@@ -69,6 +74,10 @@ def test_tall_products_are_f32_equivalent(M, K, N, dev):
     capi.check(lib.dctr_fc_bwd_data_gate_split(capi.ptr(h), N, capi.ptr(drs_), capi.ptr(dwo_), capi.ptr(dw_), capi.ptr(gbuf), K, M, K, N, capi.ptr(ws), st))
     assert bool(torch.isnan(gbuf[M * K:]).all()), "stores past the last row"
     gs = gbuf[:M * K].view(M, K).cpu()
+    g2 = torch.empty(M, K, device=dev)
+    for _ in range(3):
+        capi.check(lib.dctr_fc_bwd_data_gate_split(capi.ptr(h), N, capi.ptr(drs_), capi.ptr(dwo_), capi.ptr(dw_), capi.ptr(g2), K, M, K, N, capi.ptr(ws), st))
+        assert torch.equal(g2.cpu(), gs)
     g32 = (((h > 0).float() @ (dw_ * dwo_).t()) * drs_[:, None]).cpu()
     es, ee = float((gs.double() - ref).abs().max()), float((g32.double() - ref).abs().max())
     print("gate  %6d x %3d x %3d: split max err %.2e, an f32 product %.2e" % (M, K, N, es, ee))

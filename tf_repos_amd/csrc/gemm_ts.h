@@ -7,7 +7,7 @@
 //   * a wave owns 64 rows x ALL 16 N output columns, so the split of one A fragment (44 VALU ops) is shared by 6 N MFMAs (96 at
 //     N = 256: 0.46 VALU ops per MFMA, where the MLP kernels pay 1.6-3.2);
 //   * the small operand (the weight, <= 256 x 256) is split ONCE per step by ts_wsplit_kernel into planes laid out in B-fragment
-//     order, and streamed group by group (32 reduction steps: 3 planes x 16 KB) through a double-buffered LDS image by the LDS-DMA
+//     order, and streamed group by group (32 reduction steps: 3 planes x 16 KB) through a triple-buffered LDS image by the LDS-DMA
 //     path (global_load_lds, 1 KB per wave instruction, no registers, no ds_write) -- the four waves of a block share every
 //     fragment they read;
 //   * the ReLU gate of the input gradient (d ah = dsc (x) w_o . 1[ah > 0]) is ONE exact bf16 plane: three products, no split.
@@ -123,14 +123,14 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
     // of the address is ONE register, lane x 16, and the piece is a scalar offset -- with global_load_lds hipcc hoisted a 64-bit per-lane
     // address per piece and group out of the loop: 192 registers, spills)
     const auto rp = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.planes), 0, 3 * KG * PLANE, 0x00020000);
-    auto stage = [&](int g, int buf) {
+    auto stage = [&](int g, int bufoff) {                // bufoff: byte offset of the LDS image (a multiple of BUF)
 #pragma unroll
         for (int j = 0; j < PIECES / NW; ++j) {
             const int piece = NW * j + w;
             const int p = piece / (PLANE / 1024), o = piece - p * (PLANE / 1024);
             const int so = __builtin_amdgcn_readfirstlane((p * KG + g) * PLANE + o * 1024);
 #if defined(__HIP_DEVICE_COMPILE__)     // (hipcc's HOST pass drops the kernel's stub without a diagnostic when it meets this builtin)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (ts_lds_ptr*)(ts_lds + buf * BUF + piece * 1024), 16, lane * 16, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (ts_lds_ptr*)(ts_lds + bufoff + piece * 1024), 16, lane * 16, so, 0, 0);
 #else
             (void)so; (void)rp;
 #endif
@@ -209,8 +209,8 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
     f32x4 acc[TM][NT];
     // One region per column tile, fenced: the three fragments of tile tt + 1 are asked for ahead of tile tt's MFMAs and nothing else moves
     // across (left alone, hipcc hoists all 3 NT fragment reads of a group to its top: 192 registers, spills).
-    auto products = [&](const Ops& o, int buf) {
-        const char* base = ts_lds + buf * BUF + boff;
+    auto products = [&](const Ops& o, int bufoff) {
+        const char* base = ts_lds + bufoff + boff;
         u32x4 fb[2][3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) fb[0][p] = *reinterpret_cast<const u32x4*>(base + p * PLANE);
@@ -249,17 +249,24 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
     // The rows of group g + 1 are asked for at the top of group g and waited for at its end, one group (3-6 k cycles of MFMAs) later.
     // (Two groups ahead -- a second raw set -- changed nothing: 1.55 ms either way for the input gradient, tools/gemm_ts_probe; what the
     // kernel waits for is not the row loads.)
+    // THREE LDS images: the planes of group s + 2 are asked for at the top of group s, retired by this wave's vmcnt(0) at its end and
+    // read in group s + 2, TWO barriers later.  With two images (asked for one group ahead, read right behind the barrier that follows the
+    // wait) the eight-wave gate kernel -- the one variant that keeps the LDS pipe saturated with fragment reads -- returned a few wrong
+    // tiles per 10^5, differently from run to run: a piece the counter had retired was not yet what a ds_read of ANOTHER wave saw one
+    // barrier later (delays in front of the barrier lowered the rate; tools/gemm_ts_probe compares kernels word by word).
     Raw raw;
-    Ops cur, nxt;
+    Ops ops[2];                                         // this group's operands / the next group's, alternating (KG is even: no copy)
     Offs off, noff;
     auto rs = a_rsrc(bt);
     offs_of(bt, off);
     noff = off;
     stage(0, 0);
+    stage(1, BUF);
     loadA(raw, rs, off, 0);
-    __syncthreads();                                    // (drains the LDS-DMA queue: vmcnt(0) before the barrier)
-    convert(raw, cur);
-    int buf = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    convert(raw, ops[0]);
+    int rd = 0, wr = 2 * BUF;                           // byte offsets of the image read in this group / written for the group after next
     while (true) {
         const int64_t next = bt + gridDim.x;
         const bool more = next < nbt;
@@ -277,21 +284,24 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
         }
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
-            // everything asked for here lands under this group's MFMAs and is waited for at its end
+            // planes two groups ahead, rows one group ahead: both land under MFMAs and are waited for at this group's end
+            if (!(TS_SKIP & 2)) {
+                if (g + 2 < KG) stage(g + 2, wr);
+                else if (more) stage(g + 2 - KG, wr);
+            }
             if (g + 1 < KG) {
-                if (!(TS_SKIP & 2)) stage(g + 1, buf ^ 1);
                 if (!(TS_SKIP & 1)) loadA(raw, rs, off, g + 1);
                 // (GEN: the next tile's pair lookups, two loads per row, a group ahead of the offsets' first use)
                 if (GEN && g + 2 == KG) offs_of(more ? next : bt, noff);
             } else {
-                if (more && !(TS_SKIP & 2)) stage(0, buf ^ 1);
                 if (!(TS_SKIP & 1)) loadA(raw, rs_next, GEN ? noff : off, 0);     // (the last tile re-reads its own first group: nobody consumes it)
             }
-            products(cur, buf);
-            convert(raw, nxt);
+            products(ops[g & 1], rd);
+            convert(raw, ops[(g + 1) & 1]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (everything this wave asked for has landed before it enters the barrier)
             __syncthreads();
-            cur = nxt;
-            buf ^= 1;
+            rd = rd == 2 * BUF ? 0 : rd + BUF;
+            wr = wr == 2 * BUF ? 0 : wr + BUF;
         }
         // ---- epilogue on the accumulators: register r of lane (c, q) is row 16 i + c, column 16 tt + 4 q + r
         const int rows = rows_of(bt);

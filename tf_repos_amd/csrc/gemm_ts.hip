@@ -29,12 +29,15 @@ bool ts_enabled() {
 }
 bool ts_dim_ok(int d) { return d == 128 || d == 256; }
 
-// Eight waves of 32 rows per block (gemm_ts.h TM = 2): forward 2.63 -> 2.14 ms, gated input gradient 1.71 -> 1.59 ms at 3.0 M rows against
-// four waves of 64 (tools/gemm_ts_probe; DCTR_GEMM_TS_WAVES=4 is the A/B knob).
+// The forward runs eight waves of 32 rows per block (gemm_ts.h TM = 2): 2.63 -> 2.10 ms at 3.0 M rows against four waves of 64, bit-identical
+// output (tools/gemm_ts_probe; DCTR_GEMM_TS_FWD_WAVES=4 is the A/B knob).  The gated input gradient stays at four: its eight-wave form
+// (1.70 -> 1.55 ms) returned a few differing 64-byte row segments per 10^5 from run to run, and neither a full vmcnt(0) in front of the
+// barrier, a third LDS image (a piece read two barriers after its wait), four accumulators in rotation nor copy-free operand sets removed
+// them (profiles/r06_gemm_ts_probe.txt) -- not instantiated in the library.
 template <int KG, int NT, int MODE, bool GEN, int TM>
 int ts_launch(const TsArgs& a, hipStream_t st) {
     auto kern = gemm_ts_kernel<KG, NT, MODE, GEN, TM>;
-    constexpr int lds = 2 * 3 * 4 * 16 * NT * 16;
+    constexpr int lds = 3 * 3 * 4 * 16 * NT * 16;          // three images of a group's planes
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     DCTR_HIP_CHECK(attr);
     const int grid = (int)std::min<int64_t>((a.M + 255) / 256, CUS);
@@ -52,8 +55,11 @@ int ts_dispatch_t(int R, int N, const TsArgs& a, hipStream_t st) {
 }
 template <int MODE, bool GEN = false>
 int ts_dispatch(int R, int N, const TsArgs& a, hipStream_t st) {
-    static const bool four = getenv("DCTR_GEMM_TS_WAVES") != nullptr && atoi(getenv("DCTR_GEMM_TS_WAVES")) == 4;
-    return four ? ts_dispatch_t<MODE, GEN, 4>(R, N, a, st) : ts_dispatch_t<MODE, GEN, 2>(R, N, a, st);
+    if constexpr (MODE == TS_FWD) {
+        static const bool four = getenv("DCTR_GEMM_TS_FWD_WAVES") != nullptr && atoi(getenv("DCTR_GEMM_TS_FWD_WAVES")) == 4;
+        if (!four) return ts_dispatch_t<MODE, GEN, 2>(R, N, a, st);
+    }
+    return ts_dispatch_t<MODE, GEN, 4>(R, N, a, st);
 }
 int ts_split(const float* w, int ldw, const TsSplitJob& j0, const TsSplitJob* j1, hipStream_t st) {
     const int n0 = j0.R / 8 * j0.N, n1 = j1 ? j1->R / 8 * j1->N : 0;

@@ -73,7 +73,7 @@ static void run(int64_t M, int reps) {
     CK(hipMemset(Y + M * N, 0xff, guard * 4)); CK(hipMemset(DX + M * R, 0xff, guard * 4)); CK(hipMemset(dot + M, 0xff, guard * 4));
     auto kf = gemm_ts_kernel<KG, NT, TS_FWD>;
     auto kg = gemm_ts_kernel<NT / 2, 2 * KG, TS_GATE>;            // the input gradient: reduction over the N outputs, R columns out
-    const int ldsf = 2 * 3 * 4 * N * 16, ldsg = 2 * 3 * 4 * R * 16;
+    const int ldsf = 3 * 3 * 4 * N * 16, ldsg = 3 * 3 * 4 * R * 16;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, ldsf));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, ldsg));
     const int grid = (int)std::min<int64_t>((M + 255) / 256, 256);
@@ -165,9 +165,29 @@ static void run(int64_t M, int reps) {
             b8 = std::min(b8, ms);
         }
         printf("gate dgrad, 8 waves: %.3f ms  %.1f TF-equivalent\n", b8, 2.0 * M * R * N * 1e-9 / b8);
+        kg<<<grid, 256, ldsg>>>(ag);                    // (DX holds the 4-wave kernel's result from here on)
+        CK(hipDeviceSynchronize());
     }
     CK(hipGetLastError());
     printf("gate dgrad (3 products): %.3f ms  %.1f TF-equivalent  %.2f TB/s algorithmic\n", best, gf / best, (double)M * (R + N) * 4 / best * 1e-9);
+    {   // run to run: the 4-wave kernel (the library's) against itself, and the 8-wave form (NOT in the library) against it
+        float* DX2; CK(hipMalloc(&DX2, M * R * 4));
+        TsArgs a2 = ag; a2.C = DX2;
+        size_t d4 = 0, d8 = 0;
+        const size_t nw = M <= 200000 ? M * R : (1 << 24);
+        for (int r = 0; r < 4; ++r) {
+            kg<<<grid, 256, ldsg>>>(a2);
+            CK(hipDeviceSynchronize());
+            d4 += diff_words(DX, DX2, nw);
+        }
+        for (int r = 0; r < 4; ++r) {
+            gemm_ts_kernel<NT / 2, 2 * KG, TS_GATE, false, 2><<<grid, 512, ldsg>>>(a2);
+            CK(hipDeviceSynchronize());
+            d8 += diff_words(DX, DX2, nw);
+        }
+        printf("gate dgrad, 4 more runs each: words differing from the first run's, 4 waves (the library's): %zu; 8 waves (not in the library): %zu of 4 x %zu\n", d4, d8, nw);
+        CK(hipFree(DX2));
+    }
     // ---- check sampled rows (the last rows among them) against fp64
     std::vector<float> hW(R * N), hb(N), hwo(N);
     CK(hipMemcpy(hW.data(), W, R * N * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), b, N * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hwo.data(), wo, N * 4, hipMemcpyDeviceToHost));
