@@ -381,6 +381,51 @@ def test_afm_attention_out_inside_the_products(K, A, F, B, dev):
     eng.close()
 
 
+@pytest.mark.parametrize("K,A,F,B", [(128, 128, 12, 4001), (256, 256, 9, 7300), (256, 128, 10, 5900)])
+def test_afm_tall_split_precision_products_in_the_step(K, A, F, B, dev):
+    """From 262144 pair rows on, a handle in the default (split) gemm mode runs the attention layer's three products on the bf16 matrix
+    pipe (csrc/gemm_ts.h): forward + score with the pair rows e_i . e_j formed in the registers (the [B P, K] tensor of AFM.py:130-139 is
+    never written), gated input gradient, gated weight gradient from 256 partial slabs -- against the fp64-free oracle at the tolerances
+    of the exact path.  Then two smaller batches on the same handle: below the threshold the forward and the input gradient go back to
+    the f32 kernels while the weight gradient keeps its 256 slabs; below 65536 rows everything takes the materialising passes."""
+    import os
+    from tf_repos_amd import capi
+    V = 3000
+    P = F * (F - 1) // 2
+    assert B * P >= 262144
+    ocfg, params, eng = make_pair("afm", B=B, F=F, V=V, K=K, layers=(1,), att=(A,), opt="Adagrad", lr=1e-2, l2=1e-3)
+    oopt = O.Optimizer(ocfg, params)
+    lib = capi.lib()
+    n0 = lib.dctr_gemm_split_launches()
+    for step in range(2):
+        ids, vals, labels = O.synth_batch(B, F, V, seed=900 + step)
+        ref_loss, _ = O.train_step(ocfg, params, oopt, ids, vals, labels)
+        loss = eng.train_step(*dev_batch(ids, vals, labels, dev))
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (step, loss, ref_loss)
+    if os.environ.get("DCTR_GEMM_MODE", "split") not in ("exact", "2"):
+        assert lib.dctr_gemm_split_launches() - n0 >= 3, "the tall split-precision kernels did not run"      # (3 per step; a captured step enqueues them once)
+    got = eng.get_params()
+    for name, ref in params.items():
+        diff = np.abs(got[name] - ref.numpy()).max()
+        assert diff <= 3e-6, (name, diff)
+    for b2, seed in ((max(70000 // P + 1, 300), 902), (150, 903)):
+        ids, vals, labels = O.synth_batch(b2, F, V, seed=seed)
+        ref_loss, _ = O.train_step(ocfg, params, oopt, ids, vals, labels)
+        loss = eng.train_step(*dev_batch(ids, vals, labels, dev))
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (b2, loss, ref_loss)
+        got = eng.get_params()
+        for name, ref in params.items():
+            diff = np.abs(got[name] - ref.numpy()).max()
+            assert diff <= 4e-6, (name, b2, diff)
+    # inference on the big batch (the forward alone: no backward follows the unwritten pair tensor)
+    ids, vals, labels = O.synth_batch(B, F, V, seed=904)
+    d = dev_batch(ids, vals, labels, dev)
+    logit, prob = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    eng.predict(d[0], d[1], prob, logit)
+    assert np.abs(logit.cpu().numpy() - O.forward(ocfg, params, ids, vals)["y"].numpy()).max() <= 1e-4
+    eng.close()
+
+
 @pytest.mark.parametrize("K,F,B", [(64, 13, 37), (64, 12, 520), (128, 9, 513), (256, 39, 37), (256, 6, 600), (72, 7, 530), (64, 6, 2100), (128, 20, 2050)])
 def test_afm_wide_embeddings_pair_backward(K, F, B, dev):
     """K >= 64 (the reference runs AFM at K = 256, run.sh:18).  From 512 examples on the pair backward walks the pairs of an example
