@@ -598,12 +598,13 @@ using namespace dctr;
 
 // A/B knob DCTR_AFM_IN_PRODUCTS=0: the score dot, the ReLU-masked rank-one gradient of the last attention layer and attention_out's
 // weight gradient as passes of their own (rowdot / out_layer_bwd) instead of inside the three products
-// Below this many pair rows the tall split-precision products (gemm_ts.hip) are NOT used although they take the shape: their blocks own a
-// whole CU (one wave per SIMD with all 512 registers, 96 KB of LDS), so nothing of the step's other streams (table sweep, next batch's
-// grouping, weight gradient) shares a CU with them, and at the reference's B = 128 (95 k rows, 371 row tiles for 256 CUs) the step lost
-// 0.17 ms to that while the two products gained 0.07 (0.75 -> 0.92 ms); at B = 4096 (3.0 M rows) it gains 2.7 ms of 11.4.
+// From this many pair rows on, a handle in split mode runs the attention layer's products on the tall split-precision kernels (gemm_ts.hip).
+// Their blocks own a whole CU (512 registers per lane of a SIMD, 72-144 KB of LDS), so nothing of the step's other streams shares a CU with
+// them: with only the forward and the input gradient on them (four waves each) the reference's B = 128 (95 k rows, 371 row tiles for
+// 256 CUs) LOST 0.17 ms to that; with all three products, the eight-wave forward and no pair tensor it gains 0.3 of 0.9 ms, so the bound
+// is the kernels' own (ts_takes: 65536 rows).
 static int64_t afm_ts_min_rows() {
-    static const int64_t v = getenv("DCTR_AFM_TS_MIN_ROWS") ? atoll(getenv("DCTR_AFM_TS_MIN_ROWS")) : 262144;     // A/B knob
+    static const int64_t v = getenv("DCTR_AFM_TS_MIN_ROWS") ? atoll(getenv("DCTR_AFM_TS_MIN_ROWS")) : 65536;     // A/B knob
     return v;
 }
 static bool afm_in_products() {
