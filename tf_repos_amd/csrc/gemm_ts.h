@@ -76,6 +76,11 @@ struct TsArgs {
     const float* dot_w;         // forward: dot_out[row] = sum_n C[row, n] dot_w[n] ([N], never null; dot_out may be)
     float* dot_out;
     const float* rowscale;      // gate: C[row, :] *= rowscale[row]
+    // the tall operand's SIGN bits, one u64 per (row, lane quarter q): bit 4 tt + r = 1[C[row, 16 tt + 4 q + r] > 0] -- exactly the 8 reduction
+    // slots per group the gate kernel's lane (row, q) feeds its MFMAs with (ts_k), so the input gradient of the layer reads 32 bytes per row
+    // instead of the row (1 KB at N = 256): written by the forward (bits_out, may be null), read by TS_GATE with GEN = true (bits_in)
+    unsigned long long* bits_out;
+    const unsigned long long* bits_in;
     // GEN (forward): row r = (example b = r / P, pair p = r % P) of the tall operand is e[b, pair_i[p], :] . e[b, pair_j[p], :], formed in
     // the registers from the gathered embeddings e [examples, e_ld] (field f at f * 32 KG) -- AFM.py:130-139's element-wise products
     // without the [B P, K] tensor
@@ -93,14 +98,13 @@ typedef __attribute__((address_space(3))) void ts_lds_ptr;
 
 // KG: reduction length / 32; NT: output columns / 16.
 //   TS_FWD : C = relu(A W + bias), dot_out = C . dot_w        (A split in registers: 6 products)
-//   TS_GATE: C = rowscale (x) (1[A > 0] Wt')                  (A is a ReLU output: one exact plane, 3 products)
+//   TS_GATE: C = rowscale (x) (1[A > 0] Wt')                  (A is a ReLU output: one exact plane, 3 products; GEN: its sign bits are read, not A)
 // TM: 16-row tiles per wave; a block is 16 / TM waves = 256 rows.  TM = 4: four waves, one per SIMD, 256 accumulator registers each (the
 // AGPR half of the file).  TM = 2: EIGHT waves, two per SIMD with 256 registers each -- one wave's row loads, split and epilogue stores run
 // under the other's MFMAs (with one wave per SIMD every one of them idles the matrix pipe), at twice the LDS fragment traffic: fine for the
 // six-product forward (LDS 50 % busy), not for the three-product gate (100 %).
 template <int KG, int NT, int MODE, bool GEN = false, int TM = 4>
 __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
-    static_assert(!GEN || MODE == TS_FWD, "generated rows: the forward product");
     static_assert(TM == 4 || TM == 2, "four or eight waves");
     constexpr int NW = 16 / TM;
     constexpr int N = 16 * NT;
@@ -139,7 +143,10 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
     // the rows of one block tile behind a per-wave base (rows beyond M: num_records ends at the last real row -> zeros, no traffic)
     auto rows_of = [&](int64_t tl) { const int64_t m0 = tl * 256 + 16 * TM * w; return (int)(a.M - m0 < 16 * TM ? (a.M - m0 > 0 ? a.M - m0 : 0) : 16 * TM); };
     auto a_rsrc = [&](int64_t tl) {
-        if constexpr (GEN) {        // (one descriptor over all of e: the rows of a tile are anywhere in it)
+        if constexpr (GEN && MODE == TS_GATE) {          // the tile's sign words: 32 bytes per row
+            const int rows = rows_of(tl);
+            return __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.bits_in + (size_t)(tl * 256 + 16 * TM * w) * 4), 0, __builtin_amdgcn_readfirstlane(rows * 32), 0x00020000);
+        } else if constexpr (GEN) {        // (one descriptor over all of e: the rows of a tile are anywhere in it)
             return __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.e), 0, __builtin_amdgcn_readfirstlane((int)(a.e_floats * 4)), 0x00020000);
         } else {
             const int rows = rows_of(tl);
@@ -152,7 +159,10 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
     auto offs_of = [&](int64_t tl, Offs& o) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            if constexpr (GEN) {
+            if constexpr (GEN && MODE == TS_GATE) {
+                o.i[i] = (16 * i + c) * 32 + 8 * q;
+                o.j[i] = 0;
+            } else if constexpr (GEN) {
                 int64_t row = tl * 256 + 16 * TM * w + 16 * i + c;
                 if (row >= a.M) row = a.M - 1;          // (a row past the end: any real pair -- nobody stores it)
                 const unsigned b = (unsigned)row / (unsigned)a.P, p = (unsigned)row - b * (unsigned)a.P;
@@ -202,6 +212,28 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt)
                     o.h[i][tt] = (raw.a[i][2 * tt] > 0.f ? 0x3f80u : 0u) | (raw.a[i][2 * tt + 1] > 0.f ? 0x3f800000u : 0u);
+            }
+        }
+    };
+    // sign-bit form of the gate operand: a tile's words (one u64 per lane and row tile) and the expansion of group g's byte into the fragment
+    struct Bits { unsigned lo[TM], hi[TM]; };
+    auto loadBits = [&](Bits& b, decltype(a_rsrc(0)) rs, const Offs& o) {
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, o.i[i], 0, 0);
+            b.lo[i] = v[0];
+            b.hi[i] = v[1];
+        }
+    };
+    auto expand = [&](const Bits& b, int g, Ops& o) {    // g: compile-time after unrolling
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const unsigned byte = g < 4 ? b.lo[i] >> (8 * g) : b.hi[i] >> (8 * (g - 4));
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const unsigned m0_ = (unsigned)((int)(byte << (31 - 2 * tt)) >> 31), m1_ = (unsigned)((int)(byte << (30 - 2 * tt)) >> 31);
+                o.h[i][tt] = (m0_ & 0x3f80u) | (m1_ & 0x3f800000u);
             }
         }
     };
@@ -260,12 +292,14 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
     auto rs = a_rsrc(bt);
     offs_of(bt, off);
     noff = off;
+    constexpr bool BITS = GEN && MODE == TS_GATE;
+    Bits cb, nb;                                        // (BITS) this tile's sign words / the next tile's, asked for a whole tile ahead
     stage(0, 0);
     stage(1, BUF);
-    loadA(raw, rs, off, 0);
+    if constexpr (BITS) { loadBits(cb, rs, off); nb = cb; } else loadA(raw, rs, off, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    convert(raw, ops[0]);
+    if constexpr (BITS) expand(cb, 0, ops[0]); else convert(raw, ops[0]);
     int rd = 0, wr = 2 * BUF;                           // byte offsets of the image read in this group / written for the group after next
     while (true) {
         const int64_t next = bt + gridDim.x;
@@ -282,6 +316,7 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) rsc[i] = m0 + 16 * i + c < a.M ? a.rowscale[m0 + 16 * i + c] : 0.f;
         }
+        if constexpr (BITS) loadBits(nb, rs_next, off);  // (the last tile re-reads its own words: nobody consumes them)
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
             // planes two groups ahead, rows one group ahead: both land under MFMAs and are waited for at this group's end
@@ -289,15 +324,22 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
                 if (g + 2 < KG) stage(g + 2, wr);
                 else if (more) stage(g + 2 - KG, wr);
             }
-            if (g + 1 < KG) {
-                if (!(TS_SKIP & 1)) loadA(raw, rs, off, g + 1);
-                // (GEN: the next tile's pair lookups, two loads per row, a group ahead of the offsets' first use)
-                if (GEN && g + 2 == KG) offs_of(more ? next : bt, noff);
-            } else {
-                if (!(TS_SKIP & 1)) loadA(raw, rs_next, GEN ? noff : off, 0);     // (the last tile re-reads its own first group: nobody consumes it)
+            if constexpr (!BITS) {
+                if (g + 1 < KG) {
+                    if (!(TS_SKIP & 1)) loadA(raw, rs, off, g + 1);
+                    // (GEN: the next tile's pair lookups, two loads per row, a group ahead of the offsets' first use)
+                    if (GEN && g + 2 == KG) offs_of(more ? next : bt, noff);
+                } else {
+                    if (!(TS_SKIP & 1)) loadA(raw, rs_next, GEN ? noff : off, 0);     // (the last tile re-reads its own first group: nobody consumes it)
+                }
             }
             products(ops[g & 1], rd);
-            convert(raw, ops[(g + 1) & 1]);
+            if constexpr (BITS) {
+                if (g + 1 < KG) expand(cb, g + 1, ops[(g + 1) & 1]);
+                else expand(nb, 0, ops[(g + 1) & 1]);
+            } else {
+                convert(raw, ops[(g + 1) & 1]);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (everything this wave asked for has landed before it enters the barrier)
             __syncthreads();
             rd = rd == 2 * BUF ? 0 : rd + BUF;
@@ -308,8 +350,9 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
         const auto rc = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.C + (size_t)m0 * a.ldc), 0,
                                                           __builtin_amdgcn_readfirstlane(rows > 0 ? ((rows - 1) * a.ldc + N) * 4 : 0), 0x00020000);
         float dot[TM];
+        unsigned sgn_lo[TM], sgn_hi[TM];                 // forward: the sign words of this lane's 4 NT outputs per row tile
 #pragma unroll
-        for (int i = 0; i < TM; ++i) dot[i] = 0.f;
+        for (int i = 0; i < TM; ++i) { dot[i] = 0.f; sgn_lo[i] = sgn_hi[i] = 0u; }
         auto ld4 = [&](const float* p, int tt) { return *reinterpret_cast<const f32x4*>(p + 16 * tt + 4 * q); };
         f32x4 bc = f32x4{0.f, 0.f, 0.f, 0.f}, dc = bc;
         if constexpr (MODE == TS_FWD) { bc = ld4(a.bias, 0); dc = ld4(a.dot_w, 0); }
@@ -328,6 +371,9 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
                         v[r] = fmaxf(v[r] + bc[r], 0.f);
                         dot[i] += v[r] * dc[r];
                     }
+                    const unsigned sm = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+                    if (tt < 8) sgn_lo[i] |= sm << (4 * (tt & 7));
+                    else sgn_hi[i] |= sm << (4 * (tt & 7));
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] *= rsc[i];
@@ -339,6 +385,12 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (MODE == TS_FWD) {
+            if (a.bits_out != nullptr) {                // (uniform)
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const auto rb = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.bits_out + (size_t)m0 * 4), 0, __builtin_amdgcn_readfirstlane(rows * 32), 0x00020000);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) __builtin_amdgcn_raw_buffer_store_b64(u32x2{sgn_lo[i], sgn_hi[i]}, rb, (16 * i + c) * 32 + 8 * q, 0, 0);
+            }
             if (a.dot_out != nullptr) {                 // (uniform) the four q-lanes of a row hold its four column quarters
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
@@ -352,7 +404,8 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
         if (!more) break;
         bt = next;
         rs = rs_next;
-        if constexpr (GEN) off = noff;
+        if constexpr (BITS) cb = nb;
+        else if constexpr (GEN) off = noff;
     }
 }
 

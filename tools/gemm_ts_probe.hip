@@ -79,7 +79,8 @@ static void run(int64_t M, int reps) {
     const int grid = (int)std::min<int64_t>((M + 255) / 256, 256);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     // ---- forward
-    TsArgs af{}; af.A = X; af.lda = R; af.planes = pf; af.C = Y; af.ldc = N; af.M = M; af.bias = b; af.dot_w = wo; af.dot_out = dot;
+    unsigned long long* SB; CK(hipMalloc(&SB, (M + 4096) * 32)); CK(hipMemset(SB + M * 4, 0xff, 4096 * 32));
+    TsArgs af{}; af.A = X; af.lda = R; af.planes = pf; af.C = Y; af.ldc = N; af.M = M; af.bias = b; af.dot_w = wo; af.dot_out = dot; af.bits_out = SB;
     {   // both plane sets in one launch, timed
         const TsSplitJob j0{0, nullptr, R, N, pf}, j1{1, wo, N, R, pg};
         for (int r = 0; r < 3; ++r) {
@@ -170,6 +171,27 @@ static void run(int64_t M, int reps) {
     }
     CK(hipGetLastError());
     printf("gate dgrad (3 products): %.3f ms  %.1f TF-equivalent  %.2f TB/s algorithmic\n", best, gf / best, (double)M * (R + N) * 4 / best * 1e-9);
+    {   // the same gradient from the forward's sign bits (32 bytes per row instead of the row)
+        float* DX2; CK(hipMalloc(&DX2, M * R * 4));
+        TsArgs a2 = ag; a2.C = DX2; a2.bits_in = SB; a2.A = nullptr;
+        auto kgb = gemm_ts_kernel<NT / 2, 2 * KG, TS_GATE, true, 4>;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kgb), hipFuncAttributeMaxDynamicSharedMemorySize, ldsg));
+        float bb = 1e9f;
+        for (int r = 0; r < reps; ++r) {
+            CK(hipEventRecord(e0));
+            kgb<<<grid, 256, ldsg>>>(a2);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            bb = std::min(bb, ms);
+        }
+        CK(hipGetLastError());
+        std::vector<uint32_t> gd2(4096 * 8);
+        CK(hipMemcpy(gd2.data(), SB + M * 4, 4096 * 32, hipMemcpyDeviceToHost));
+        size_t badb = 0; for (auto v : gd2) badb += v != 0xffffffffu;
+        printf("gate dgrad from the sign bits: %.3f ms  %.1f TF-equivalent  %.2f TB/s algorithmic; words differing from the gradient read from the rows: %zu; sign words written past the end: %zu\n",
+               bb, gf / bb, ((double)M * R * 4 + M * 32.0) / bb * 1e-9, diff_words(DX, DX2, M <= 200000 ? M * R : (1 << 24)), badb);
+        CK(hipFree(DX2));
+    }
     {   // run to run: the 4-wave kernel (the library's) against itself, and the 8-wave form (NOT in the library) against it
         float* DX2; CK(hipMalloc(&DX2, M * R * 4));
         TsArgs a2 = ag; a2.C = DX2;
@@ -291,7 +313,7 @@ static void run(int64_t M, int reps) {
         }
         CK(hipFree(dw)); CK(hipFree(db)); CK(hipFree(dwo));
     }
-    CK(hipFree(X)); CK(hipFree(Y)); CK(hipFree(DX)); CK(hipFree(W)); CK(hipFree(b)); CK(hipFree(wo)); CK(hipFree(rsc)); CK(hipFree(dot)); CK(hipFree(pf)); CK(hipFree(pg)); CK(hipFree(E_)); CK(hipFree(pi)); CK(hipFree(pj));
+    CK(hipFree(X)); CK(hipFree(Y)); CK(hipFree(DX)); CK(hipFree(W)); CK(hipFree(b)); CK(hipFree(wo)); CK(hipFree(rsc)); CK(hipFree(dot)); CK(hipFree(SB)); CK(hipFree(pf)); CK(hipFree(pg)); CK(hipFree(E_)); CK(hipFree(pi)); CK(hipFree(pj));
 }
 
 int main() {
