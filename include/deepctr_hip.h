@@ -349,6 +349,8 @@ int64_t dctr_gemm_split_launches(void);
  *                               (the score of the (N -> 1) layer that follows, AFM.py:147; d_dot_out may be null);
  *   dctr_fc_bwd_data_gate_split dX[M,K] = (rowscale (x) kscale . 1[H > 0]) W[K,N]^T for the layer's stored output H [M,N]: the input
  *                               gradient when the output gradient is rank one under the ReLU mask (d H = d score (x) w_out . 1[H > 0]).
+ *   d_sign_bits (both, may be null): 32 M bytes the forward fills with the SIGN bits of Y (one 64-bit word per row and quarter of its columns);
+ *                               the gradient given them reads 32 bytes per row instead of the row of H (d_h may then be null) -- same result.
  *   dctr_fc_bwd_weights_gate_split  the same layer's weight gradient under that rank-one output gradient, dW[K,N] = X^T (rowscale (x) colscale . 1[H > 0]),
  *                               with db[N] (its bias gradient) and dwo[N] = sum_r rowscale[r] H[r,:] (the (N -> 1) layer's weight gradient);
  *                               workspace: at least (K N + 2 N) floats, 256 x that for full speed (partial slabs over row ranges).
@@ -360,15 +362,15 @@ int64_t dctr_gemm_split_launches(void);
  * the shape or the alignment (16-byte pointers, leading dimensions multiples of 4) is not taken: the caller uses the exact ops. */
 int dctr_ts_plane_bytes(int R, int N, int64_t* bytes);
 int dctr_fc_fwd_dot_split(const float* d_x, int ldx, const float* d_w, const float* d_b, float* d_y, int ldy, int64_t M, int K, int N,
-                          const float* d_dot_w, float* d_dot_out, void* d_planes_ws, void* stream);
-int dctr_fc_bwd_data_gate_split(const float* d_h, int ldh, const float* d_rowscale, const float* d_kscale, const float* d_w, float* d_dx,
-                                int lddx, int64_t M, int K, int N, void* d_planes_ws, void* stream);
+                          const float* d_dot_w, float* d_dot_out, void* d_sign_bits, void* d_planes_ws, void* stream);
+int dctr_fc_bwd_data_gate_split(const float* d_h, int ldh, const void* d_sign_bits, const float* d_rowscale, const float* d_kscale, const float* d_w,
+                                float* d_dx, int lddx, int64_t M, int K, int N, void* d_planes_ws, void* stream);
 int dctr_fc_bwd_weights_gate_split(const float* d_x, int ldx, const float* d_h, int ldh, const float* d_rowscale, const float* d_colscale,
                                    float* d_dw, float* d_db, float* d_dwo, int64_t M, int K, int N, float* d_workspace, size_t workspace_bytes,
                                    void* stream);
 int dctr_pairs_fc_fwd_dot_split(const float* d_e, int e_ld, int examples, const int16_t* d_pair_i, const int16_t* d_pair_j, int P, const float* d_w,
                                 const float* d_b, float* d_y, int ldy, int64_t M, int K, int N, const float* d_dot_w, float* d_dot_out,
-                                void* d_planes_ws, void* stream);
+                                void* d_sign_bits, void* d_planes_ws, void* stream);
 int dctr_pairs_fc_bwd_weights_gate_split(const float* d_e, int e_ld, int examples, const int16_t* d_pair_i, const int16_t* d_pair_j, int P,
                                          const float* d_h, int ldh, const float* d_rowscale, const float* d_colscale, float* d_dw, float* d_db,
                                          float* d_dwo, int64_t M, int K, int N, float* d_workspace, size_t workspace_bytes, void* stream);

@@ -44,13 +44,18 @@ def test_tall_products_are_f32_equivalent(M, K, N, dev):
     ybuf = torch.full((M * N + guard,), float("nan"), device=dev)
     dbuf = torch.full((M + guard,), float("nan"), device=dev)
     ye = torch.empty(M, N, device=dev)
+    sbuf = torch.full((M * 4 + guard,), -1, dtype=torch.int64, device=dev)          # the sign words of the output, 32 bytes per row
     capi.check(lib.dctr_fc_fwd_dot_split(capi.ptr(dx_), K, capi.ptr(dw_), capi.ptr(db_), capi.ptr(ybuf), N, M, K, N, capi.ptr(dwo_), capi.ptr(dbuf),
-                                         capi.ptr(ws), st))
+                                         capi.ptr(sbuf), capi.ptr(ws), st))
     capi.check(lib.dctr_fc_fwd(capi.ptr(dx_), K, capi.ptr(dw_), capi.ptr(db_), capi.ptr(ye), N, M, K, N, 1, 1.0, 0, st))
     ys = ybuf[:M * N].view(M, N).cpu()
-    assert bool(torch.isnan(ybuf[M * N:]).all()) and bool(torch.isnan(dbuf[M:]).all()), "stores past the last row"
+    assert bool(torch.isnan(ybuf[M * N:]).all()) and bool(torch.isnan(dbuf[M:]).all()) and bool((sbuf[M * 4:] == -1).all()), "stores past the last row"
     es, ee = float((ys.double() - ref).abs().max()), float((ye.cpu().double() - ref).abs().max())
     print("fwd   %6d x %3d x %3d: split max err %.2e, exact %.2e" % (M, K, N, es, ee))
+    # the sign words: bit 4 tt + r of word (row, q) = 1[y[row, 16 tt + 4 q + r] > 0]
+    pos = (ys > 0).view(M, N // 16, 4, 4).permute(0, 2, 1, 3).reshape(M, 4, N // 4).to(torch.int64)     # [row, q, 4 tt + r]
+    want = (pos << torch.arange(N // 4, dtype=torch.int64)).sum(-1)
+    assert torch.equal(sbuf[:M * 4].view(M, 4).cpu(), want)
     assert es <= 2 * ee + 1e-9, (es, ee)
     dref = ys.double() @ wo.double()
     ed = float((dbuf[:M].cpu().double() - dref).abs().max())
@@ -60,24 +65,29 @@ def test_tall_products_are_f32_equivalent(M, K, N, dev):
     # twice the same bits (LDS-DMA staging, barriers and two waves per SIMD: a schedule-dependent result would be a race)
     yb2 = torch.empty(M, N, device=dev); db2 = torch.empty(M, device=dev)
     for _ in range(3):
-        capi.check(lib.dctr_fc_fwd_dot_split(capi.ptr(dx_), K, capi.ptr(dw_), capi.ptr(db_), capi.ptr(yb2), N, M, K, N, capi.ptr(dwo_), capi.ptr(db2), capi.ptr(ws), st))
+        capi.check(lib.dctr_fc_fwd_dot_split(capi.ptr(dx_), K, capi.ptr(dw_), capi.ptr(db_), capi.ptr(yb2), N, M, K, N, capi.ptr(dwo_), capi.ptr(db2), None, capi.ptr(ws), st))
         assert torch.equal(yb2.cpu(), ys) and torch.equal(db2, dbuf[:M])
     # without the dot output
     y2 = torch.empty(M, N, device=dev)
-    capi.check(lib.dctr_fc_fwd_dot_split(capi.ptr(dx_), K, capi.ptr(dw_), capi.ptr(db_), capi.ptr(y2), N, M, K, N, capi.ptr(dwo_), None, capi.ptr(ws), st))
+    capi.check(lib.dctr_fc_fwd_dot_split(capi.ptr(dx_), K, capi.ptr(dw_), capi.ptr(db_), capi.ptr(y2), N, M, K, N, capi.ptr(dwo_), None, None, capi.ptr(ws), st))
     assert torch.equal(y2.cpu(), ys)
     # ---- gated input gradient: dX = (rs (x) wo . 1[H > 0]) W^T, H = the forward's output
     h = ys.to(dev)
     wk = (w * wo).double()                                   # (the kernels round W[k, a] wo[a] to f32 once, like this product)
     ref = ((ys > 0).double() @ wk.t()) * rs.double()[:, None]
     gbuf = torch.full((M * K + guard,), float("nan"), device=dev)
-    capi.check(lib.dctr_fc_bwd_data_gate_split(capi.ptr(h), N, capi.ptr(drs_), capi.ptr(dwo_), capi.ptr(dw_), capi.ptr(gbuf), K, M, K, N, capi.ptr(ws), st))
+    capi.check(lib.dctr_fc_bwd_data_gate_split(capi.ptr(h), N, None, capi.ptr(drs_), capi.ptr(dwo_), capi.ptr(dw_), capi.ptr(gbuf), K, M, K, N, capi.ptr(ws), st))
     assert bool(torch.isnan(gbuf[M * K:]).all()), "stores past the last row"
     gs = gbuf[:M * K].view(M, K).cpu()
     g2 = torch.empty(M, K, device=dev)
     for _ in range(3):
-        capi.check(lib.dctr_fc_bwd_data_gate_split(capi.ptr(h), N, capi.ptr(drs_), capi.ptr(dwo_), capi.ptr(dw_), capi.ptr(g2), K, M, K, N, capi.ptr(ws), st))
+        capi.check(lib.dctr_fc_bwd_data_gate_split(capi.ptr(h), N, None, capi.ptr(drs_), capi.ptr(dwo_), capi.ptr(dw_), capi.ptr(g2), K, M, K, N, capi.ptr(ws), st))
         assert torch.equal(g2.cpu(), gs)
+    # ... and from the forward's sign words instead of the rows (two column halves, two blocks per CU): the same bits, run after run
+    gb = torch.full((M * K + guard,), float("nan"), device=dev)
+    for _ in range(3):
+        capi.check(lib.dctr_fc_bwd_data_gate_split(None, 0, capi.ptr(sbuf), capi.ptr(drs_), capi.ptr(dwo_), capi.ptr(dw_), capi.ptr(gb), K, M, K, N, capi.ptr(ws), st))
+        assert torch.equal(gb[:M * K].view(M, K).cpu(), gs) and bool(torch.isnan(gb[M * K:]).all())
     g32 = (((h > 0).float() @ (dw_ * dwo_).t()) * drs_[:, None]).cpu()
     es, ee = float((gs.double() - ref).abs().max()), float((g32.double() - ref).abs().max())
     print("gate  %6d x %3d x %3d: split max err %.2e, an f32 product %.2e" % (M, K, N, es, ee))
@@ -134,10 +144,11 @@ def test_rows_formed_from_the_embeddings_give_the_same_bits(B, F, K, N, dev):
     ws = _ws(lib, 256, 256, dev)
     y1, y2 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
     d1, d2 = torch.empty(M, device=dev), torch.empty(M, device=dev)
-    capi.check(lib.dctr_fc_fwd_dot_split(capi.ptr(x), K, capi.ptr(w), capi.ptr(b), capi.ptr(y1), N, M, K, N, capi.ptr(wo), capi.ptr(d1), capi.ptr(ws), st))
+    s1, s2 = torch.zeros(M * 4, dtype=torch.int64, device=dev), torch.zeros(M * 4, dtype=torch.int64, device=dev)
+    capi.check(lib.dctr_fc_fwd_dot_split(capi.ptr(x), K, capi.ptr(w), capi.ptr(b), capi.ptr(y1), N, M, K, N, capi.ptr(wo), capi.ptr(d1), capi.ptr(s1), capi.ptr(ws), st))
     capi.check(lib.dctr_pairs_fc_fwd_dot_split(capi.ptr(e), F * K, B, capi.ptr(dpi), capi.ptr(dpj), P, capi.ptr(w), capi.ptr(b), capi.ptr(y2), N, M, K, N,
-                                               capi.ptr(wo), capi.ptr(d2), capi.ptr(ws), st))
-    assert torch.equal(y1, y2) and torch.equal(d1, d2)
+                                               capi.ptr(wo), capi.ptr(d2), capi.ptr(s2), capi.ptr(ws), st))
+    assert torch.equal(y1, y2) and torch.equal(d1, d2) and torch.equal(s1, s2)
     per = K * N + 2 * N
     wsp = torch.zeros(256 * per, device=dev)
     out1 = [torch.empty(K, N, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev)]
@@ -150,7 +161,7 @@ def test_rows_formed_from_the_embeddings_give_the_same_bits(B, F, K, N, dev):
         assert torch.equal(a, b2)
     # more rows than the embeddings hold pairs for: refused
     rc = lib.dctr_pairs_fc_fwd_dot_split(capi.ptr(e), F * K, B - 1, capi.ptr(dpi), capi.ptr(dpj), P, capi.ptr(w), capi.ptr(b), capi.ptr(y2), N, M, K, N,
-                                         capi.ptr(wo), capi.ptr(d2), capi.ptr(ws), st)
+                                         capi.ptr(wo), capi.ptr(d2), None, capi.ptr(ws), st)
     assert rc == capi.DCTR_ERR_UNSUPPORTED
 
 
@@ -160,8 +171,8 @@ def test_shapes_not_taken_are_refused(dev):
     ws = _ws(lib, 256, 256, dev)
     for M, K, N in [(4096, 256, 256), (70000, 64, 256), (70000, 256, 192)]:
         x = torch.zeros(M, K, device=dev); w = torch.zeros(K, N, device=dev); b = torch.zeros(N, device=dev); y = torch.zeros(M, N, device=dev)
-        rc = lib.dctr_fc_fwd_dot_split(capi.ptr(x), K, capi.ptr(w), capi.ptr(b), capi.ptr(y), N, M, K, N, capi.ptr(b), None, capi.ptr(ws), st)
+        rc = lib.dctr_fc_fwd_dot_split(capi.ptr(x), K, capi.ptr(w), capi.ptr(b), capi.ptr(y), N, M, K, N, capi.ptr(b), None, None, capi.ptr(ws), st)
         assert rc == capi.DCTR_ERR_UNSUPPORTED, (M, K, N, rc)
         r = torch.zeros(M, device=dev)
-        rc = lib.dctr_fc_bwd_data_gate_split(capi.ptr(y), N, capi.ptr(r), capi.ptr(b), capi.ptr(w), capi.ptr(x), K, M, K, N, capi.ptr(ws), st)
+        rc = lib.dctr_fc_bwd_data_gate_split(capi.ptr(y), N, None, capi.ptr(r), capi.ptr(b), capi.ptr(w), capi.ptr(x), K, M, K, N, capi.ptr(ws), st)
         assert rc == capi.DCTR_ERR_UNSUPPORTED, (M, K, N, rc)

@@ -698,6 +698,8 @@ int afm_alloc(dctr_engine* E) {
         DCTR_TRY(dm(&E->sc_parts, 2 * MB * P));
         // split-precision mode: the attention weight's bf16 planes for the tall products (gemm_ts.hip), [forward | input gradient]
         DCTR_HIP_CHECK(hipMalloc(&E->ts_planes, 2 * ts_plane_bytes(256, 256)));
+        // ... and the sign words of the attention layer's output (32 bytes per pair row), what its input gradient reads instead of the rows
+        DCTR_HIP_CHECK(hipMalloc(&E->ts_sign, ts_sign_bytes((int64_t)MB * P)));
     }
     (void)A;
     DCTR_TRY(dm(&E->sc, MB * P));
@@ -720,6 +722,7 @@ void afm_free(dctr_engine* E) {
     for (float* p : E->ahs) hipFree(p);
     for (float* p : E->dahs) hipFree(p);
     if (E->ts_planes) hipFree(E->ts_planes);
+    if (E->ts_sign) hipFree(E->ts_sign);
     if (E->pair_i) hipFree(E->pair_i);
     if (E->pair_j) hipFree(E->pair_j);
     if (E->s_afm) hipStreamDestroy(E->s_afm);
@@ -847,6 +850,7 @@ int afm_forward(dctr_engine* E, int B, bool train, hipStream_t st) {
         const TsPairs tp{E->e + (size_t)b0 * E->e_ld, E->e_ld, n, E->pair_i, E->pair_j, P};
         bool gen = afm_pairs_in_registers(E, n, &tp);
         E->afm_pp_skipped = false;
+        E->ts_sign_ready = false;
         if (!gen) DCTR_TRY(materialise());
         const float* x = E->pairp + r0 * K;
         int score_parts = 0;
@@ -863,7 +867,8 @@ int afm_forward(dctr_engine* E, int B, bool train, hipStream_t st) {
                 const bool both = E->afm_gate_slabs && ts_takes((int64_t)n * P, fc.out, fc.in);
                 if (both) DCTR_TRY(ts_prepare(E->pp(fc.w), fc.in, fc.out, E->pp(E->p_ao_w), E->ts_planes, static_cast<char*>(E->ts_planes) + ts_plane_bytes(256, 256), s));
                 DCTR_TRY(ts_fc_fwd_dot(x, fc.in, E->pp(fc.w), E->pp(fc.b), y, fc.out, (int64_t)n * P, fc.in, fc.out, E->pp(E->p_ao_w), E->sc_parts + r0,
-                                       E->ts_planes, !both, s, &done, gen ? &tp : nullptr));
+                                       E->ts_planes, !both, s, &done, gen ? &tp : nullptr, E->ts_sign ? static_cast<char*>(E->ts_sign) + ts_sign_bytes(r0) : nullptr));
+                E->ts_sign_ready = done && E->ts_sign != nullptr;
                 if (gen && !done) {                     // (not taken after all: the rows are written and the product below reads them)
                     gen = false;
                     DCTR_TRY(materialise());
@@ -984,7 +989,8 @@ int afm_interaction_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t 
             if (!beside || wdone) {
                 if (E->gemm_mode == 1 && E->ts_planes != nullptr && (int64_t)n * P >= afm_ts_min_rows())     // split-precision mode: the gate is ONE exact bf16 plane (gemm_ts.hip)
                     DCTR_TRY(ts_fc_bwd_data_gate(E->ah, A, E->dsc, E->pp(E->p_ao_w), E->pp(fc.w), E->dpairp2, K, (int64_t)n * P, K, A,
-                                                 static_cast<char*>(E->ts_planes) + ts_plane_bytes(256, 256), !E->ts_dgr_ready, st, &ddone));
+                                                 static_cast<char*>(E->ts_planes) + ts_plane_bytes(256, 256), !E->ts_dgr_ready, st, &ddone,
+                                                 E->ts_sign_ready ? E->ts_sign : nullptr));
                 if (!ddone) DCTR_TRY(ws_fc_bwd_data_gate(E->ah, A, E->dsc, E->pp(E->p_ao_w), E->pp(fc.w), E->dpairp2, K, n * P, K, A, st, &ddone));
                 DCTR_REQUIRE(ddone, "AFM: the gated input gradient was not taken for a shape ws_takes() accepts");
                 if (!beside) DCTR_TRY(wgrad());

@@ -219,6 +219,8 @@ struct dctr_engine {
     float keep_att = 1.f, keep_emb = 1.f;
     float* sc_parts = nullptr;      // AFM: per-column-slab partial score dots out of the last attention product's epilogue [2][MB * P]
     void* ts_planes = nullptr;      // AFM, gemm_mode split: the attention weight's bf16 planes for the tall products (gemm_ts.hip), forward | input gradient
+    void* ts_sign = nullptr;        // ... the sign words of the attention layer's output (gemm_ts.h bits_out), [MB * P] x 32 bytes
+    bool ts_sign_ready = false;     // ... written by this step's forward
     bool afm_ts_wgrad = false;      // ... and the gated weight gradient is gemm_ts.hip's (the attention layer declared TS_WGRAD_SLABS slabs)
     bool afm_pp_skipped = false;    // ... this step's forward did not write the pair tensor (its readers form the rows from the embeddings)
     bool ts_dgr_ready = false;      // ... the input gradient's planes were written by this step's forward (ts_prepare)

@@ -103,10 +103,16 @@ typedef __attribute__((address_space(3))) void ts_lds_ptr;
 // AGPR half of the file).  TM = 2: EIGHT waves, two per SIMD with 256 registers each -- one wave's row loads, split and epilogue stores run
 // under the other's MFMAs (with one wave per SIMD every one of them idles the matrix pipe), at twice the LDS fragment traffic: fine for the
 // six-product forward (LDS 50 % busy), not for the three-product gate (100 %).
-template <int KG, int NT, int MODE, bool GEN = false, int TM = 4>
-__global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
+// NTF: column tiles of the whole output when a block pass covers only NT of them (NTF = 2 NT: two column HALVES, each a tile of the block
+// loop of its own).  Half the accumulators (128 registers at TM = 4) and half the LDS images (72 KB) let TWO blocks share a CU: they are not
+// in step with each other, so one block's epilogue stores (3.1 GB at the reference point: 0.5-0.6 ms that no MFMA covers when all waves of
+// a CU reach their epilogue together) run under the other's MFMAs.  Only where the row operand is cheap to form twice: the gate from sign bits.
+template <int KG, int NT, int MODE, bool GEN = false, int TM = 4, int NTF = NT>
+__global__ __launch_bounds__(64 * (16 / TM), NTF == NT ? 1 : 2) void gemm_ts_kernel(TsArgs a) {
     static_assert(TM == 4 || TM == 2, "four or eight waves");
+    static_assert(NTF == NT || (NTF == 2 * NT && MODE == TS_GATE && GEN), "column halves: the gate from sign bits");
     constexpr int NW = 16 / TM;
+    constexpr int H = NTF / NT, NF = 16 * NTF;
     constexpr int N = 16 * NT;
     constexpr int PLANE = 4 * N * 16;                  // bytes of one plane of one group
     constexpr int BUF = 3 * PLANE;
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
     extern __shared__ __attribute__((aligned(16))) char ts_lds[];
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int c = lane & 15, q = lane >> 4;
-    const int64_t nbt = (a.M + 255) / 256;
+    const int64_t nbt = (a.M + 255) / 256 * H;          // block tiles: (row tile, column half), the half fastest
     int64_t bt = blockIdx.x;
     if (bt >= nbt) return;
 
@@ -126,13 +132,15 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
     // the planes of group g -> LDS image `buf`, contiguous in both: wave w takes the 1 KB pieces w, w + NW, ...  (buffer form: the lane part
     // of the address is ONE register, lane x 16, and the piece is a scalar offset -- with global_load_lds hipcc hoisted a 64-bit per-lane
     // address per piece and group out of the loop: 192 registers, spills)
-    const auto rp = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.planes), 0, 3 * KG * PLANE, 0x00020000);
-    auto stage = [&](int g, int bufoff) {                // bufoff: byte offset of the LDS image (a multiple of BUF)
+    const auto rp = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.planes), 0, 3 * KG * PLANE * H, 0x00020000);
+    auto stage = [&](int g, int bufoff, int h) {         // bufoff: byte offset of the LDS image (a multiple of BUF); h: column half
+        constexpr int PR = N * 16 / 1024;               // 1 KB pieces per (plane, q) row of this pass's columns
 #pragma unroll
         for (int j = 0; j < PIECES / NW; ++j) {
             const int piece = NW * j + w;
-            const int p = piece / (PLANE / 1024), o = piece - p * (PLANE / 1024);
-            const int so = __builtin_amdgcn_readfirstlane((p * KG + g) * PLANE + o * 1024);
+            const int pq = piece / PR, o = piece - pq * PR;           // pq = 4 p + q
+            const int p = pq >> 2, qq = pq & 3;
+            const int so = __builtin_amdgcn_readfirstlane((((p * KG + g) * 4 + qq) * NF + h * N) * 16 + o * 1024);
 #if defined(__HIP_DEVICE_COMPILE__)     // (hipcc's HOST pass drops the kernel's stub without a diagnostic when it meets this builtin)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (ts_lds_ptr*)(ts_lds + bufoff + piece * 1024), 16, lane * 16, so, 0, 0);
 #else
@@ -289,13 +297,13 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
     Raw raw;
     Ops ops[2];                                         // this group's operands / the next group's, alternating (KG is even: no copy)
     Offs off, noff;
-    auto rs = a_rsrc(bt);
-    offs_of(bt, off);
+    auto rs = a_rsrc(bt / H);
+    offs_of(bt / H, off);
     noff = off;
     constexpr bool BITS = GEN && MODE == TS_GATE;
     Bits cb, nb;                                        // (BITS) this tile's sign words / the next tile's, asked for a whole tile ahead
-    stage(0, 0);
-    stage(1, BUF);
+    stage(0, 0, (int)(bt % H));
+    stage(1, BUF, (int)(bt % H));
     if constexpr (BITS) { loadBits(cb, rs, off); nb = cb; } else loadA(raw, rs, off, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -304,12 +312,14 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
     while (true) {
         const int64_t next = bt + gridDim.x;
         const bool more = next < nbt;
-        auto rs_next = a_rsrc(more ? next : bt);
+        const int64_t rt = bt / H, rt_next = (more ? next : bt) / H;           // row tiles
+        const int hh = (int)(bt % H), hh_next = (int)((more ? next : bt) % H);
+        auto rs_next = a_rsrc(rt_next);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) acc[i][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int64_t m0 = bt * 256 + 16 * TM * w;
+        const int64_t m0 = rt * 256 + 16 * TM * w;
         // the per-row scalars of the epilogue, asked for before the products (in the epilogue they would queue behind the next tile's loads)
         float rsc[TM];
         if constexpr (MODE == TS_GATE) {
@@ -321,14 +331,14 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
         for (int g = 0; g < KG; ++g) {
             // planes two groups ahead, rows one group ahead: both land under MFMAs and are waited for at this group's end
             if (!(TS_SKIP & 2)) {
-                if (g + 2 < KG) stage(g + 2, wr);
-                else if (more) stage(g + 2 - KG, wr);
+                if (g + 2 < KG) stage(g + 2, wr, hh);
+                else if (more) stage(g + 2 - KG, wr, hh_next);
             }
             if constexpr (!BITS) {
                 if (g + 1 < KG) {
                     if (!(TS_SKIP & 1)) loadA(raw, rs, off, g + 1);
                     // (GEN: the next tile's pair lookups, two loads per row, a group ahead of the offsets' first use)
-                    if (GEN && g + 2 == KG) offs_of(more ? next : bt, noff);
+                    if (GEN && g + 2 == KG) offs_of(rt_next, noff);
                 } else {
                     if (!(TS_SKIP & 1)) loadA(raw, rs_next, GEN ? noff : off, 0);     // (the last tile re-reads its own first group: nobody consumes it)
                 }
@@ -346,8 +356,8 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
             wr = wr == 2 * BUF ? 0 : wr + BUF;
         }
         // ---- epilogue on the accumulators: register r of lane (c, q) is row 16 i + c, column 16 tt + 4 q + r
-        const int rows = rows_of(bt);
-        const auto rc = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.C + (size_t)m0 * a.ldc), 0,
+        const int rows = rows_of(rt);
+        const auto rc = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.C + (size_t)m0 * a.ldc + hh * N), 0,
                                                           __builtin_amdgcn_readfirstlane(rows > 0 ? ((rows - 1) * a.ldc + N) * 4 : 0), 0x00020000);
         float dot[TM];
         unsigned sgn_lo[TM], sgn_hi[TM];                 // forward: the sign words of this lane's 4 NT outputs per row tile
@@ -378,8 +388,16 @@ __global__ __launch_bounds__(64 * (16 / TM), 1) void gemm_ts_kernel(TsArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] *= rsc[i];
                 }
-                // (the column tile as the SCALAR offset: written into the lane offset, hipcc precomputes all 4 NT of them outside the loop)
-                if (!(TS_SKIP & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, coff[i], 64 * tt, 0);
+                // The column tile goes into the LANE offset, computed right here (the empty asm keeps hipcc from precomputing all 4 NT offsets
+                // outside the loop: 64 registers).  NOT into the scalar offset: a 16-byte buffer store whose soffset SGPR is rewritten for the
+                // next store right behind it put part of its data (the first register of lanes 12-15 of every 16) at the NEXT store's offset
+                // whenever two waves shared the SIMD -- the eight-wave and two-blocks-per-CU gate kernels returned a few wrong 64-byte row
+                // segments per 10^5, differently run to run, until the scalar offset went (8-byte stores with it are fine; tools/gemm_ts_probe).
+                if (!(TS_SKIP & 4)) {
+                    int vo = coff[i] + 64 * tt;
+                    asm volatile("" : "+v"(vo));
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, vo, 0, 0);
+                }
             }
             bc = bn; dc = dn;
             __builtin_amdgcn_sched_barrier(0);
@@ -611,8 +629,11 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_tsw_kernel(TswArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const unsigned so = __builtin_amdgcn_readfirstlane(4u * (unsigned)((16 * TK * w + TK * r + i) * A_ + 16 * TA * wj));
                 if constexpr (TA == 4) {
+                    // (16-byte stores: no scalar offset -- see gemm_ts_kernel's epilogue)
                     const f32x4 v = f32x4{acc[i][4 * wj][r] * sc[0], acc[i][4 * wj + 1][r] * sc[1], acc[i][4 * wj + 2][r] * sc[2], acc[i][4 * wj + 3][r] * sc[3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rw, woff, so, 0);
+                    int vo = woff + (int)so;
+                    asm volatile("" : "+v"(vo));
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rw, vo, 0, 0);
                 } else {
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
                     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));

@@ -29,18 +29,17 @@ bool ts_enabled() {
 }
 bool ts_dim_ok(int d) { return d == 128 || d == 256; }
 
-// The forward runs eight waves of 32 rows per block (gemm_ts.h TM = 2): 2.63 -> 2.10 ms at 3.0 M rows against four waves of 64, bit-identical
-// output (tools/gemm_ts_probe; DCTR_GEMM_TS_FWD_WAVES=4 is the A/B knob).  The gated input gradient stays at four: its eight-wave form
-// (1.70 -> 1.55 ms) returned a few differing 64-byte row segments per 10^5 from run to run, and neither a full vmcnt(0) in front of the
-// barrier, a third LDS image (a piece read two barriers after its wait), four accumulators in rotation nor copy-free operand sets removed
-// them (profiles/r06_gemm_ts_probe.txt) -- not instantiated in the library.
-template <int KG, int NT, int MODE, bool GEN, int TM>
+// Eight waves of 32 rows per block (gemm_ts.h TM = 2) for the products over stored / generated rows: forward 2.63 -> 2.10 ms, gated input
+// gradient 1.70 -> 1.55 ms at 3.0 M rows against four waves of 64, bit-identical (tools/gemm_ts_probe; DCTR_GEMM_TS_WAVES=4 is the A/B
+// knob).  The gate from the forward's sign bits runs in two column halves at two blocks per CU: 1.20 ms.
+template <int KG, int NT, int MODE, bool GEN, int TM, int NTF = NT>
 int ts_launch(const TsArgs& a, hipStream_t st) {
-    auto kern = gemm_ts_kernel<KG, NT, MODE, GEN, TM>;
-    constexpr int lds = 3 * 3 * 4 * 16 * NT * 16;          // three images of a group's planes
+    auto kern = gemm_ts_kernel<KG, NT, MODE, GEN, TM, NTF>;
+    constexpr int lds = 3 * 3 * 4 * 16 * NT * 16;          // three images of a group's planes (of this pass's columns)
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     DCTR_HIP_CHECK(attr);
-    const int grid = (int)std::min<int64_t>((a.M + 255) / 256, CUS);
+    constexpr int H = NTF / NT;                             // column halves: two blocks per CU
+    const int grid = (int)std::min<int64_t>((a.M + 255) / 256 * H, CUS * H);
     kern<<<grid, 64 * (16 / TM), lds, st>>>(a);
     DCTR_LAUNCH_CHECK();
     g_dr3_launches.fetch_add(1, std::memory_order_relaxed);
@@ -55,11 +54,15 @@ int ts_dispatch_t(int R, int N, const TsArgs& a, hipStream_t st) {
 }
 template <int MODE, bool GEN = false>
 int ts_dispatch(int R, int N, const TsArgs& a, hipStream_t st) {
-    if constexpr (MODE == TS_FWD) {
-        static const bool four = getenv("DCTR_GEMM_TS_FWD_WAVES") != nullptr && atoi(getenv("DCTR_GEMM_TS_FWD_WAVES")) == 4;
-        if (!four) return ts_dispatch_t<MODE, GEN, 2>(R, N, a, st);
-    }
-    return ts_dispatch_t<MODE, GEN, 4>(R, N, a, st);
+    static const bool four = getenv("DCTR_GEMM_TS_WAVES") != nullptr && atoi(getenv("DCTR_GEMM_TS_WAVES")) == 4;
+    return four ? ts_dispatch_t<MODE, GEN, 4>(R, N, a, st) : ts_dispatch_t<MODE, GEN, 2>(R, N, a, st);
+}
+// the gate from the forward's sign bits, in two column halves at two blocks per CU (gemm_ts.h NTF)
+int ts_dispatch_bits(int R, int N, const TsArgs& a, hipStream_t st) {
+    if (R == 128 && N == 128) return ts_launch<4, 4, TS_GATE, true, 4, 8>(a, st);
+    if (R == 128 && N == 256) return ts_launch<4, 8, TS_GATE, true, 4, 16>(a, st);
+    if (R == 256 && N == 128) return ts_launch<8, 4, TS_GATE, true, 4, 8>(a, st);
+    return ts_launch<8, 8, TS_GATE, true, 4, 16>(a, st);
 }
 int ts_split(const float* w, int ldw, const TsSplitJob& j0, const TsSplitJob* j1, hipStream_t st) {
     const int n0 = j0.R / 8 * j0.N, n1 = j1 ? j1->R / 8 * j1->N : 0;
@@ -100,7 +103,7 @@ bool ts_pairs_ok(const TsPairs* g, int64_t M, int K) {
 // Y[M,N] = relu(X[M,K] W[K,N] + b), dot_out[row] = <Y[row,:], dot_w> (dot_out may be null).  pairs != null: X is not read -- row b P + p is
 // e[b, pair_i[p], :] . e[b, pair_j[p], :] (TsPairs), formed in the registers.
 int ts_fc_fwd_dot(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int64_t M, int K, int N, const float* dot_w,
-                  float* dot_out, void* planes_ws, bool split_here, hipStream_t st, bool* done, const TsPairs* pairs) {
+                  float* dot_out, void* planes_ws, bool split_here, hipStream_t st, bool* done, const TsPairs* pairs, void* sign_bits_out) {
     *done = false;
     if (pairs != nullptr && !ts_pairs_ok(pairs, M, K)) return DCTR_OK;
     if (pairs != nullptr) { x = pairs->e; ldx = 4; }
@@ -110,6 +113,7 @@ int ts_fc_fwd_dot(const float* x, int ldx, const float* w, const float* b, float
     if (split_here) DCTR_TRY(ts_split(w, N, TsSplitJob{0, nullptr, K, N, static_cast<u32x4*>(planes_ws)}, nullptr, st));
     TsArgs a{};
     a.A = x; a.lda = ldx; a.planes = static_cast<const u32x4*>(planes_ws); a.C = y; a.ldc = ldy; a.M = M; a.bias = b; a.dot_w = dot_w; a.dot_out = dot_out;
+    a.bits_out = static_cast<unsigned long long*>(sign_bits_out);
     *done = true;
     if (pairs != nullptr) {
         a.e = pairs->e; a.e_ld = pairs->e_ld; a.e_floats = (int64_t)pairs->examples * pairs->e_ld; a.pair_i = pairs->pair_i; a.pair_j = pairs->pair_j; a.P = pairs->P;
@@ -118,10 +122,12 @@ int ts_fc_fwd_dot(const float* x, int ldx, const float* w, const float* b, float
     return ts_dispatch<TS_FWD>(K, N, a, st);
 }
 
-// dX[M,K] = (rowscale (x) kscale . 1[H > 0]) W[K,N]^T with H [M,N] the layer's ReLU output (gemm_ws.hip WS_GATE, three bf16 products)
+// dX[M,K] = (rowscale (x) kscale . 1[H > 0]) W[K,N]^T with H [M,N] the layer's ReLU output (gemm_ws.hip WS_GATE, three bf16 products).
+// sign_bits: the words ts_fc_fwd_dot wrote beside H (32 bytes per row) -- read instead of H when given (h may then be null... of the same forward)
 int ts_fc_bwd_data_gate(const float* h, int ldh, const float* rowscale, const float* kscale, const float* w, float* dx, int lddx, int64_t M, int K,
-                        int N, void* planes_ws, bool split_here, hipStream_t st, bool* done) {
+                        int N, void* planes_ws, bool split_here, hipStream_t st, bool* done, const void* sign_bits) {
     *done = false;
+    if (sign_bits != nullptr && h == nullptr) { h = rowscale; ldh = 4; }      // (the rows are not read: any aligned pointer passes the checks below)
     if (!ts_takes(M, N, K) || planes_ws == nullptr || !al16(w) || !al16(h) || (ldh & 3) || !al16(dx) || (lddx & 3) || rowscale == nullptr || kscale == nullptr ||
         ldh > (1 << 20) || lddx > (1 << 20))
         return DCTR_OK;
@@ -129,6 +135,11 @@ int ts_fc_bwd_data_gate(const float* h, int ldh, const float* rowscale, const fl
     TsArgs a{};
     a.A = h; a.lda = ldh; a.planes = static_cast<const u32x4*>(planes_ws); a.C = dx; a.ldc = lddx; a.M = M; a.rowscale = rowscale;
     *done = true;
+    static const bool no_bits = getenv("DCTR_GEMM_TS_BITS") != nullptr && atoi(getenv("DCTR_GEMM_TS_BITS")) == 0;      // A/B knob
+    if (sign_bits != nullptr && !no_bits && (reinterpret_cast<uintptr_t>(sign_bits) & 7) == 0) {
+        a.bits_in = static_cast<const unsigned long long*>(sign_bits);
+        return ts_dispatch_bits(N, K, a, st);
+    }
     return ts_dispatch<TS_GATE>(N, K, a, st);
 }
 
@@ -177,17 +188,17 @@ int dctr_ts_plane_bytes(int R, int N, int64_t* bytes) {
 }
 
 int dctr_fc_fwd_dot_split(const float* d_x, int ldx, const float* d_w, const float* d_b, float* d_y, int ldy, int64_t M, int K, int N,
-                          const float* d_dot_w, float* d_dot_out, void* d_planes_ws, void* stream) {
+                          const float* d_dot_w, float* d_dot_out, void* d_sign_bits, void* d_planes_ws, void* stream) {
     bool done = false;
-    DCTR_TRY(ts_fc_fwd_dot(d_x, ldx, d_w, d_b, d_y, ldy, M, K, N, d_dot_w, d_dot_out, d_planes_ws, true, as_stream(stream), &done, nullptr));
+    DCTR_TRY(ts_fc_fwd_dot(d_x, ldx, d_w, d_b, d_y, ldy, M, K, N, d_dot_w, d_dot_out, d_planes_ws, true, as_stream(stream), &done, nullptr, d_sign_bits));
     if (!done) { set_error("dctr_fc_fwd_dot_split: no tall split-precision kernel takes M=%lld K=%d N=%d with these pointers", (long long)M, K, N); return DCTR_ERR_UNSUPPORTED; }
     return DCTR_OK;
 }
 
-int dctr_fc_bwd_data_gate_split(const float* d_h, int ldh, const float* d_rowscale, const float* d_kscale, const float* d_w, float* d_dx, int lddx,
-                                int64_t M, int K, int N, void* d_planes_ws, void* stream) {
+int dctr_fc_bwd_data_gate_split(const float* d_h, int ldh, const void* d_sign_bits, const float* d_rowscale, const float* d_kscale, const float* d_w,
+                                float* d_dx, int lddx, int64_t M, int K, int N, void* d_planes_ws, void* stream) {
     bool done = false;
-    DCTR_TRY(ts_fc_bwd_data_gate(d_h, ldh, d_rowscale, d_kscale, d_w, d_dx, lddx, M, K, N, d_planes_ws, true, as_stream(stream), &done));
+    DCTR_TRY(ts_fc_bwd_data_gate(d_h, ldh, d_rowscale, d_kscale, d_w, d_dx, lddx, M, K, N, d_planes_ws, true, as_stream(stream), &done, d_sign_bits));
     if (!done) { set_error("dctr_fc_bwd_data_gate_split: no tall split-precision kernel takes M=%lld K=%d N=%d with these pointers", (long long)M, K, N); return DCTR_ERR_UNSUPPORTED; }
     return DCTR_OK;
 }
@@ -218,11 +229,11 @@ int dctr_fc_bwd_weights_gate_split(const float* d_x, int ldx, const float* d_h, 
 }
 
 int dctr_pairs_fc_fwd_dot_split(const float* d_e, int e_ld, int examples, const int16_t* d_pair_i, const int16_t* d_pair_j, int P, const float* d_w,
-                                const float* d_b, float* d_y, int ldy, int64_t M, int K, int N, const float* d_dot_w, float* d_dot_out, void* d_planes_ws,
-                                void* stream) {
+                                const float* d_b, float* d_y, int ldy, int64_t M, int K, int N, const float* d_dot_w, float* d_dot_out, void* d_sign_bits,
+                                void* d_planes_ws, void* stream) {
     const TsPairs pairs{d_e, e_ld, examples, d_pair_i, d_pair_j, P};
     bool done = false;
-    DCTR_TRY(ts_fc_fwd_dot(nullptr, 0, d_w, d_b, d_y, ldy, M, K, N, d_dot_w, d_dot_out, d_planes_ws, true, as_stream(stream), &done, &pairs));
+    DCTR_TRY(ts_fc_fwd_dot(nullptr, 0, d_w, d_b, d_y, ldy, M, K, N, d_dot_w, d_dot_out, d_planes_ws, true, as_stream(stream), &done, &pairs, d_sign_bits));
     if (!done) { set_error("dctr_pairs_fc_fwd_dot_split: no tall split-precision kernel takes M=%lld K=%d N=%d over these embeddings", (long long)M, K, N); return DCTR_ERR_UNSUPPORTED; }
     return DCTR_OK;
 }

@@ -151,9 +151,10 @@ size_t ts_plane_bytes(int R, int N);
 struct TsPairs { const float* e; int e_ld; int examples; const int16_t* pair_i; const int16_t* pair_j; int P; };
 bool ts_pairs_ok(const TsPairs* g, int64_t M, int K);
 int ts_fc_fwd_dot(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int64_t M, int K, int N, const float* dot_w,
-                  float* dot_out, void* planes_ws, bool split_here, hipStream_t st, bool* done, const TsPairs* pairs = nullptr);
+                  float* dot_out, void* planes_ws, bool split_here, hipStream_t st, bool* done, const TsPairs* pairs = nullptr, void* sign_bits_out = nullptr);
 int ts_fc_bwd_data_gate(const float* h, int ldh, const float* rowscale, const float* kscale, const float* w, float* dx, int lddx, int64_t M, int K,
-                        int N, void* planes_ws, bool split_here, hipStream_t st, bool* done);
+                        int N, void* planes_ws, bool split_here, hipStream_t st, bool* done, const void* sign_bits = nullptr);
+inline size_t ts_sign_bytes(int64_t M) { return (size_t)M * 32; }      // the forward's sign words: one u64 per row and lane quarter
 int ts_fc_bwd_weights_gate(const float* x, int ldx, const float* h, int ldh, const float* rowscale, const float* colscale, float* dw_part,
                            int64_t dw_stride, float* db_part, int64_t db_stride, float* dwo_part, int64_t dwo_stride, int64_t M, int K, int N, int splits,
                            hipStream_t st, bool* done, const TsPairs* pairs = nullptr);
