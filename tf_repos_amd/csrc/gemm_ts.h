@@ -75,6 +75,7 @@ struct TsArgs {
     const float* bias;          // forward: [N]
     const float* dot_w;         // forward: dot_out[row] = sum_n C[row, n] dot_w[n] ([N], never null; dot_out may be)
     float* dot_out;
+    int64_t dot_stride;         // column halves (NTF = 2 NT): half h writes its part of the dot to dot_out[h * dot_stride + row] (the caller adds the two)
     const float* rowscale;      // gate: C[row, :] *= rowscale[row]
     // the tall operand's SIGN bits, one u64 per (row, lane quarter q): bit 4 tt + r = 1[C[row, 16 tt + 4 q + r] > 0] -- exactly the 8 reduction
     // slots per group the gate kernel's lane (row, q) feeds its MFMAs with (ts_k), so the input gradient of the layer reads 32 bytes per row
@@ -106,11 +107,13 @@ typedef __attribute__((address_space(3))) void ts_lds_ptr;
 // NTF: column tiles of the whole output when a block pass covers only NT of them (NTF = 2 NT: two column HALVES, each a tile of the block
 // loop of its own).  Half the accumulators (128 registers at TM = 4) and half the LDS images (72 KB) let TWO blocks share a CU: they are not
 // in step with each other, so one block's epilogue stores (3.1 GB at the reference point: 0.5-0.6 ms that no MFMA covers when all waves of
-// a CU reach their epilogue together) run under the other's MFMAs.  Only where the row operand is cheap to form twice: the gate from sign bits.
+// a CU reach their epilogue together) run under the other's MFMAs.  It pays only where the row operand is cheap to form twice -- the gate
+// from sign bits: 1.45 -> 1.20 ms; the forward (rows split twice) LOSES, 2.30 -> 2.77 ms stored rows / 2.37 -> 3.74 ms generated, and is not
+// dispatched that way (tools/gemm_ts_probe measures both).
 template <int KG, int NT, int MODE, bool GEN = false, int TM = 4, int NTF = NT>
 __global__ __launch_bounds__(64 * (16 / TM), NTF == NT ? 1 : 2) void gemm_ts_kernel(TsArgs a) {
     static_assert(TM == 4 || TM == 2, "four or eight waves");
-    static_assert(NTF == NT || (NTF == 2 * NT && MODE == TS_GATE && GEN), "column halves: the gate from sign bits");
+    static_assert(NTF == NT || NTF == 2 * NT, "whole rows or two column halves");
     constexpr int NW = 16 / TM;
     constexpr int H = NTF / NT, NF = 16 * NTF;
     constexpr int N = 16 * NT;
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(64 * (16 / TM), NTF == NT ? 1 : 2) void gemm_ts_ker
         unsigned sgn_lo[TM], sgn_hi[TM];                 // forward: the sign words of this lane's 4 NT outputs per row tile
 #pragma unroll
         for (int i = 0; i < TM; ++i) { dot[i] = 0.f; sgn_lo[i] = sgn_hi[i] = 0u; }
-        auto ld4 = [&](const float* p, int tt) { return *reinterpret_cast<const f32x4*>(p + 16 * tt + 4 * q); };
+        auto ld4 = [&](const float* p, int tt) { return *reinterpret_cast<const f32x4*>(p + hh * N + 16 * tt + 4 * q); };
         f32x4 bc = f32x4{0.f, 0.f, 0.f, 0.f}, dc = bc;
         if constexpr (MODE == TS_FWD) { bc = ld4(a.bias, 0); dc = ld4(a.dot_w, 0); }
 #pragma unroll
@@ -393,11 +396,15 @@ __global__ __launch_bounds__(64 * (16 / TM), NTF == NT ? 1 : 2) void gemm_ts_ker
                 // next store right behind it put part of its data (the first register of lanes 12-15 of every 16) at the NEXT store's offset
                 // whenever two waves shared the SIMD -- the eight-wave and two-blocks-per-CU gate kernels returned a few wrong 64-byte row
                 // segments per 10^5, differently run to run, until the scalar offset went (8-byte stores with it are fine; tools/gemm_ts_probe).
+#ifdef TS_STORE_SOFFSET         // tools/gemm_ts_probe.hip -DTS_STORE_SOFFSET: the scalar-offset form, to show the effect (profiles/r06_store_soffset_ab.txt)
+                if (!(TS_SKIP & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, coff[i], 64 * tt, 0);
+#else
                 if (!(TS_SKIP & 4)) {
                     int vo = coff[i] + 64 * tt;
                     asm volatile("" : "+v"(vo));
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, vo, 0, 0);
                 }
+#endif
             }
             bc = bn; dc = dn;
             __builtin_amdgcn_sched_barrier(0);
@@ -407,7 +414,11 @@ __global__ __launch_bounds__(64 * (16 / TM), NTF == NT ? 1 : 2) void gemm_ts_ker
                 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                 const auto rb = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.bits_out + (size_t)m0 * 4), 0, __builtin_amdgcn_readfirstlane(rows * 32), 0x00020000);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) __builtin_amdgcn_raw_buffer_store_b64(u32x2{sgn_lo[i], sgn_hi[i]}, rb, (16 * i + c) * 32 + 8 * q, 0, 0);
+                for (int i = 0; i < TM; ++i) {
+                    if constexpr (H == 1) __builtin_amdgcn_raw_buffer_store_b64(u32x2{sgn_lo[i], sgn_hi[i]}, rb, (16 * i + c) * 32 + 8 * q, 0, 0);
+                    else if constexpr (NT == 8) __builtin_amdgcn_raw_buffer_store_b32(sgn_lo[i], rb, (16 * i + c) * 32 + 8 * q + 4 * hh, 0, 0);       // (half h = bits 32 h ..)
+                    else __builtin_amdgcn_raw_buffer_store_b16((unsigned short)sgn_lo[i], rb, (16 * i + c) * 32 + 8 * q + 2 * hh, 0, 0);          // (NT = 4: bits 16 h ..)
+                }
             }
             if (a.dot_out != nullptr) {                 // (uniform) the four q-lanes of a row hold its four column quarters
 #pragma unroll
@@ -415,7 +426,7 @@ __global__ __launch_bounds__(64 * (16 / TM), NTF == NT ? 1 : 2) void gemm_ts_ker
                     float d = dot[i];
                     d += __shfl_xor(d, 16);
                     d += __shfl_xor(d, 32);
-                    if (q == 0 && m0 + 16 * i + c < a.M) a.dot_out[m0 + 16 * i + c] = d;
+                    if (q == 0 && m0 + 16 * i + c < a.M) a.dot_out[hh * a.dot_stride + m0 + 16 * i + c] = d;
                 }
             }
         }
