@@ -607,6 +607,13 @@ static int64_t afm_ts_min_rows() {
     static const int64_t v = getenv("DCTR_AFM_TS_MIN_ROWS") ? atoll(getenv("DCTR_AFM_TS_MIN_ROWS")) : 65536;     // A/B knob
     return v;
 }
+// ... and from this many multiply-adds per product (rows x K x A): the reference's own run.sh:18 point (B = 128, K = 256, A = 128: 3.1 G) is
+// faster on the f32 kernels (0.58 against 0.65-0.75 ms/step, alternated), its script default A = 256 at the same batch (6.2 G) on these
+// (0.395 against 0.59) -- the 256 partial slabs and whole-CU blocks are a fixed cost that 371 row tiles of half the width do not repay.
+static bool afm_ts_worth(int64_t rows, int K, int A) {
+    static const double v = getenv("DCTR_AFM_TS_MIN_MACS") ? atof(getenv("DCTR_AFM_TS_MIN_MACS")) : 5e9;          // A/B knob
+    return rows >= afm_ts_min_rows() && (double)rows * K * A >= v;
+}
 static bool afm_in_products() {
     static const bool off = [] { const char* v = getenv("DCTR_AFM_IN_PRODUCTS"); return v != nullptr && v[0] == '0'; }();
     return !off;
@@ -644,7 +651,7 @@ int afm_declare_params(dctr_engine* E) {
         fc.splits = E->afm_fused ? AFM_SLABS : nc_max * choose_wgrad_splits(ceil_div(E->MB, nc_max) * E->P, fc.in, fc.out);
         // split-precision mode at a batch the tall products pay for: the gated weight gradient is gemm_ts.hip's, one slab per CU
         E->afm_ts_wgrad = nl == 1 && !E->afm_fused && nc_max == 1 && E->gemm_mode == 1 && afm_in_products() && ts_takes((int64_t)E->MB * E->P, fc.in, fc.out) &&
-                          ws_takes((int64_t)E->MB * E->P, fc.out, fc.in) && (int64_t)E->MB * E->P >= afm_ts_min_rows();
+                          ws_takes((int64_t)E->MB * E->P, fc.out, fc.in) && afm_ts_worth((int64_t)E->MB * E->P, fc.in, fc.out);
         if (E->afm_ts_wgrad) fc.splits = TS_WGRAD_SLABS;
         char nm[64];
         snprintf(nm, sizeof(nm), "att_mlp%d/weights", l);
@@ -770,7 +777,7 @@ static bool afm_pairs_in_registers(dctr_engine* E, int n, const TsPairs* tp) {
     if (off || pool_knobs || !afm_in_products() || !E->afm_ts_wgrad || E->att_fc.size() != 1 || E->gemm_mode != 1 || E->ts_planes == nullptr || afm_chunks(E, n) != 1) return false;
     const Fc& fc = E->att_fc[0];
     const Param& w = E->params[fc.w];
-    if ((int64_t)n * P < afm_ts_min_rows() || !ts_takes((int64_t)n * P, fc.in, fc.out) || !ts_pairs_ok(tp, (int64_t)n * P, K) || fc.in != K) return false;
+    if (!afm_ts_worth((int64_t)n * P, fc.in, fc.out) || !ts_takes((int64_t)n * P, fc.in, fc.out) || !ts_pairs_ok(tp, (int64_t)n * P, K) || fc.in != K) return false;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!al16(E->ah) || !al16(E->dsc) || !al16(E->parts + w.part_off) || (w.padded & 3) || !al16(E->pp(fc.w)) || !al16(E->pp(fc.b)) || !al16(E->pp(E->p_ao_w))) return false;
     // forward pooling: the MFMA kernel (n >= 2048) or the LDS rebuild, both from e; backward pooling: the MFMA kernel
@@ -862,7 +869,7 @@ int afm_forward(dctr_engine* E, int B, bool train, hipStream_t st) {
             // 128-column slab, when it is the tall-operand kernel with at most two slabs (a two-term sum is order-free)
             const bool in_products = l + 1 == E->att_fc.size() && fc.out <= 256 && afm_in_products();
             // split-precision mode: the tall product on the bf16 matrix pipe (gemm_ts.hip), the whole score from one wave's accumulators
-            if (in_products && nc == 1 && E->gemm_mode == 1 && E->ts_planes != nullptr && (int64_t)n * P >= afm_ts_min_rows()) {
+            if (in_products && nc == 1 && E->gemm_mode == 1 && E->ts_planes != nullptr && afm_ts_worth((int64_t)n * P, fc.in, fc.out)) {
                 // (one launch writes the weight's planes for this product and for the backward's gated input gradient)
                 const bool both = E->afm_gate_slabs && ts_takes((int64_t)n * P, fc.out, fc.in);
                 if (both) DCTR_TRY(ts_prepare(E->pp(fc.w), fc.in, fc.out, E->pp(E->p_ao_w), E->ts_planes, static_cast<char*>(E->ts_planes) + ts_plane_bytes(256, 256), s));
@@ -987,7 +994,7 @@ int afm_interaction_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t 
             };
             if (beside) DCTR_TRY(wgrad());
             if (!beside || wdone) {
-                if (E->gemm_mode == 1 && E->ts_planes != nullptr && (int64_t)n * P >= afm_ts_min_rows())     // split-precision mode: the gate is ONE exact bf16 plane (gemm_ts.hip)
+                if (E->gemm_mode == 1 && E->ts_planes != nullptr && afm_ts_worth((int64_t)n * P, K, A))     // split-precision mode: the gate is ONE exact bf16 plane (gemm_ts.hip)
                     DCTR_TRY(ts_fc_bwd_data_gate(E->ah, A, E->dsc, E->pp(E->p_ao_w), E->pp(fc.w), E->dpairp2, K, (int64_t)n * P, K, A,
                                                  static_cast<char*>(E->ts_planes) + ts_plane_bytes(256, 256), !E->ts_dgr_ready, st, &ddone,
                                                  E->ts_sign_ready ? E->ts_sign : nullptr));

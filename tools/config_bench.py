@@ -27,6 +27,10 @@ CONFIGS = {
     "DeepMVM B=4096 V=1e6 K=16 MLP 400x3": dict(model="mvm", B=4096, V=1_000_000, K=16, layers=(400, 400, 400)),
     # the reference's own AFM operating point (AFM.py:44,52 / run.sh:18): K = 256, attention 256 -- the unfused attention path
     "AFM reference point B=128 V=117581 K=256 att 256": dict(model="afm", B=128, V=117581, K=256, layers=(1,), att=(256,)),
+    "AFM run.sh:18 point B=128 V=117581 K=256 att 128": dict(model="afm", B=128, V=117581, K=256, layers=(1,), att=(128,)),
+    "AFM run.sh:18 point B=256 V=117581 K=256 att 128": dict(model="afm", B=256, V=117581, K=256, layers=(1,), att=(128,)),
+    "AFM run.sh:18 point B=512 V=117581 K=256 att 128": dict(model="afm", B=512, V=117581, K=256, layers=(1,), att=(128,)),
+    "AFM run.sh:18 point B=4096 V=117581 K=256 att 128": dict(model="afm", B=4096, V=117581, K=256, layers=(1,), att=(128,), steps=30),
     "AFM reference point B=512 V=117581 K=256 att 256": dict(model="afm", B=512, V=117581, K=256, layers=(1,), att=(256,)),
     "AFM reference point B=1024 V=117581 K=256 att 256": dict(model="afm", B=1024, V=117581, K=256, layers=(1,), att=(256,), steps=30),
     "AFM reference point B=4096 V=117581 K=256 att 256": dict(model="afm", B=4096, V=117581, K=256, layers=(1,), att=(256,), steps=10),
