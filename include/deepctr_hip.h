@@ -349,7 +349,10 @@ int64_t dctr_gemm_split_launches(void);
  *                               (the score of the (N -> 1) layer that follows, AFM.py:147; d_dot_out may be null);
  *   dctr_fc_bwd_data_gate_split dX[M,K] = (rowscale (x) kscale . 1[H > 0]) W[K,N]^T for the layer's stored output H [M,N]: the input
  *                               gradient when the output gradient is rank one under the ReLU mask (d H = d score (x) w_out . 1[H > 0]).
- *   d_sign_bits (both, may be null): 32 M bytes the forward fills with the SIGN bits of Y (one 64-bit word per row and quarter of its columns);
+ *   Given d_sign_bits, d_w [K,N] and d_b [N], dctr_pairs_fc_bwd_weights_gate_split does not read H either (d_h may be null): the gate comes
+ *                               from the sign words and dwo from the product itself, dwo[n] = sum_k W[k,n] dWraw[k,n] + b[n] dbraw[n] -- then Y
+ *                               of the forward has no reader left and dctr_pairs_fc_fwd_dot_split / dctr_fc_fwd_dot_split accept d_y = null.
+ *   d_sign_bits (forward and input gradient, may be null): 32 M bytes the forward fills with the SIGN bits of Y (one 64-bit word per row and quarter of its columns);
  *                               the gradient given them reads 32 bytes per row instead of the row of H (d_h may then be null) -- same result.
  *   dctr_fc_bwd_weights_gate_split  the same layer's weight gradient under that rank-one output gradient, dW[K,N] = X^T (rowscale (x) colscale . 1[H > 0]),
  *                               with db[N] (its bias gradient) and dwo[N] = sum_r rowscale[r] H[r,:] (the (N -> 1) layer's weight gradient);
@@ -372,8 +375,9 @@ int dctr_pairs_fc_fwd_dot_split(const float* d_e, int e_ld, int examples, const 
                                 const float* d_b, float* d_y, int ldy, int64_t M, int K, int N, const float* d_dot_w, float* d_dot_out,
                                 void* d_sign_bits, void* d_planes_ws, void* stream);
 int dctr_pairs_fc_bwd_weights_gate_split(const float* d_e, int e_ld, int examples, const int16_t* d_pair_i, const int16_t* d_pair_j, int P,
-                                         const float* d_h, int ldh, const float* d_rowscale, const float* d_colscale, float* d_dw, float* d_db,
-                                         float* d_dwo, int64_t M, int K, int N, float* d_workspace, size_t workspace_bytes, void* stream);
+                                         const float* d_h, int ldh, const void* d_sign_bits, const float* d_w, const float* d_b,
+                                         const float* d_rowscale, const float* d_colscale, float* d_dw, float* d_db, float* d_dwo, int64_t M, int K,
+                                         int N, float* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K3/K5/K4: interaction layers ------------------------------------------------------ */
 /* AFM's attention-weighted pairwise interaction (AFM.py:127-158) as an op.  It needs the attention network's variables and ~B P (K + A)

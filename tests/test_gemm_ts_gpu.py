@@ -155,10 +155,24 @@ def test_rows_formed_from_the_embeddings_give_the_same_bits(B, F, K, N, dev):
     out2 = [torch.empty(K, N, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev)]
     capi.check(lib.dctr_fc_bwd_weights_gate_split(capi.ptr(x), K, capi.ptr(y1), N, capi.ptr(rs), capi.ptr(wo), *[capi.ptr(t) for t in out1], M, K, N,
                                                   capi.ptr(wsp), wsp.numel() * 4, st))
-    capi.check(lib.dctr_pairs_fc_bwd_weights_gate_split(capi.ptr(e), F * K, B, capi.ptr(dpi), capi.ptr(dpj), P, capi.ptr(y1), N, capi.ptr(rs), capi.ptr(wo),
-                                                        *[capi.ptr(t) for t in out2], M, K, N, capi.ptr(wsp), wsp.numel() * 4, st))
+    capi.check(lib.dctr_pairs_fc_bwd_weights_gate_split(capi.ptr(e), F * K, B, capi.ptr(dpi), capi.ptr(dpj), P, capi.ptr(y1), N, None, None, None, capi.ptr(rs),
+                                                        capi.ptr(wo), *[capi.ptr(t) for t in out2], M, K, N, capi.ptr(wsp), wsp.numel() * 4, st))
     for a, b2 in zip(out1, out2):
         assert torch.equal(a, b2)
+    # ... and without reading the layer's output at all: the gate from the forward's sign words (same dW and db, bit for bit), the second column
+    # sums as sum_k W[k, n] dWraw[k, n] + b[n] dbraw[n] (the same number in another summation order) -- and a forward that stores only scores + signs
+    out3 = [torch.empty(K, N, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev)]
+    capi.check(lib.dctr_pairs_fc_bwd_weights_gate_split(capi.ptr(e), F * K, B, capi.ptr(dpi), capi.ptr(dpj), P, None, 0, capi.ptr(s1), capi.ptr(w), capi.ptr(b),
+                                                        capi.ptr(rs), capi.ptr(wo), *[capi.ptr(t) for t in out3], M, K, N, capi.ptr(wsp), wsp.numel() * 4, st))
+    assert torch.equal(out1[0], out3[0]) and torch.equal(out1[1], out3[1])
+    ref_o = (y1.double() * rs.double()[:, None]).sum(0)
+    e1, e3 = float((out1[2].double() - ref_o).abs().max()), float((out3[2].double() - ref_o).abs().max())
+    print("second column sums: over H max err %.2e, from the product %.2e (values to %.1f)" % (e1, e3, float(ref_o.abs().max())))
+    assert e3 <= 4 * e1 + 2e-6 * float(ref_o.abs().max()), (e1, e3)
+    d3, s3 = torch.empty(M, device=dev), torch.zeros(M * 4, dtype=torch.int64, device=dev)
+    capi.check(lib.dctr_pairs_fc_fwd_dot_split(capi.ptr(e), F * K, B, capi.ptr(dpi), capi.ptr(dpj), P, capi.ptr(w), capi.ptr(b), None, N, M, K, N,
+                                               capi.ptr(wo), capi.ptr(d3), capi.ptr(s3), capi.ptr(ws), st))
+    assert torch.equal(d3, d1) and torch.equal(s3, s1)
     # more rows than the embeddings hold pairs for: refused
     rc = lib.dctr_pairs_fc_fwd_dot_split(capi.ptr(e), F * K, B - 1, capi.ptr(dpi), capi.ptr(dpj), P, capi.ptr(w), capi.ptr(b), capi.ptr(y2), N, M, K, N,
                                          capi.ptr(wo), capi.ptr(d2), None, capi.ptr(ws), st)

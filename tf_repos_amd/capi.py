@@ -205,8 +205,8 @@ _SIGS["dctr_ts_plane_bytes"] = ([C.c_int, C.c_int, _P], C.c_int)
 _SIGS["dctr_fc_fwd_dot_split"] = ([_P, C.c_int, _P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P, _P], C.c_int)
 _SIGS["dctr_fc_bwd_weights_gate_split"] = ([_P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, C.c_size_t, _P], C.c_int)
 _SIGS["dctr_pairs_fc_fwd_dot_split"] = ([_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P, _P], C.c_int)
-_SIGS["dctr_pairs_fc_bwd_weights_gate_split"] = ([_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, _P,
-                                                  C.c_size_t, _P], C.c_int)
+_SIGS["dctr_pairs_fc_bwd_weights_gate_split"] = ([_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int,
+                                                  _P, C.c_size_t, _P], C.c_int)
 _SIGS["dctr_fc_bwd_data_gate_split"] = ([_P, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P], C.c_int)
 _SIGS["dctr_set_stat_sync"] = ([_P, ALL_REDUCE_F32_FN, _P, C.c_int], C.c_int)
 

@@ -858,6 +858,7 @@ int afm_forward(dctr_engine* E, int B, bool train, hipStream_t st) {
         bool gen = afm_pairs_in_registers(E, n, &tp);
         E->afm_pp_skipped = false;
         E->ts_sign_ready = false;
+        E->afm_ah_skipped = false;
         if (!gen) DCTR_TRY(materialise());
         const float* x = E->pairp + r0 * K;
         int score_parts = 0;
@@ -873,8 +874,14 @@ int afm_forward(dctr_engine* E, int B, bool train, hipStream_t st) {
                 // (one launch writes the weight's planes for this product and for the backward's gated input gradient)
                 const bool both = E->afm_gate_slabs && ts_takes((int64_t)n * P, fc.out, fc.in);
                 if (both) DCTR_TRY(ts_prepare(E->pp(fc.w), fc.in, fc.out, E->pp(E->p_ao_w), E->ts_planes, static_cast<char*>(E->ts_planes) + ts_plane_bytes(256, 256), s));
-                DCTR_TRY(ts_fc_fwd_dot(x, fc.in, E->pp(fc.w), E->pp(fc.b), y, fc.out, (int64_t)n * P, fc.in, fc.out, E->pp(E->p_ao_w), E->sc_parts + r0,
+                // With the rows generated and the sign words written, NOBODY reads the layer's output ah [B P, A] (3.1 GB): the input gradient takes
+                // its gate from the sign words, the weight gradient too (and the score-weight gradient from its own product) -- it is not stored.
+                // DCTR_AFM_AH=1: stored as before (and read by the weight gradient).
+                static const bool keep_ah = getenv("DCTR_AFM_AH") != nullptr && atoi(getenv("DCTR_AFM_AH")) == 1;           // A/B knob
+                const bool no_ah = gen && both && !keep_ah && E->ts_sign != nullptr && ts_bits_enabled();
+                DCTR_TRY(ts_fc_fwd_dot(x, fc.in, E->pp(fc.w), E->pp(fc.b), no_ah ? nullptr : y, fc.out, (int64_t)n * P, fc.in, fc.out, E->pp(E->p_ao_w), E->sc_parts + r0,
                                        E->ts_planes, !both, s, &done, gen ? &tp : nullptr, E->ts_sign ? static_cast<char*>(E->ts_sign) + ts_sign_bytes(r0) : nullptr));
+                E->afm_ah_skipped = done && no_ah;
                 E->ts_sign_ready = done && E->ts_sign != nullptr;
                 if (gen && !done) {                     // (not taken after all: the rows are written and the product below reads them)
                     gen = false;
@@ -983,8 +990,11 @@ int afm_interaction_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t 
                 DCTR_LAUNCH_CHECK();
                 if (E->afm_ts_wgrad) {      // (declared with TS_WGRAD_SLABS slabs: every batch of this handle, whatever its size)
                     const TsPairs tp{E->e, E->e_ld, n, E->pair_i, E->pair_j, P};
+                    const bool hb = E->afm_pp_skipped && E->ts_sign_ready && ts_bits_enabled();
                     DCTR_TRY(ts_fc_bwd_weights_gate(E->pairp, K, E->ah, A, E->dsc, E->pp(E->p_ao_w), E->part(fc.w), w.padded, E->part(fc.b), bb.padded,
-                                                    E->part(E->p_ao_w), aw.padded, (int64_t)n * P, K, A, fc.splits, sw, &wdone, E->afm_pp_skipped ? &tp : nullptr));
+                                                    E->part(E->p_ao_w), aw.padded, (int64_t)n * P, K, A, fc.splits, sw, &wdone, E->afm_pp_skipped ? &tp : nullptr,
+                                                    hb ? E->ts_sign : nullptr, E->pp(fc.w), E->pp(fc.b)));
+                    DCTR_REQUIRE(!E->afm_ah_skipped || (wdone && hb), "AFM: the forward did not store the attention layer's output and the weight gradient that works without it was not taken");
                 }
                 DCTR_REQUIRE(wdone || !E->afm_pp_skipped, "AFM: the forward left the pair tensor unwritten and the weight gradient that forms it in registers was not taken");
                 if (!wdone)
@@ -998,6 +1008,7 @@ int afm_interaction_backward(dctr_engine* E, int B, hipStream_t st, hipStream_t 
                     DCTR_TRY(ts_fc_bwd_data_gate(E->ah, A, E->dsc, E->pp(E->p_ao_w), E->pp(fc.w), E->dpairp2, K, (int64_t)n * P, K, A,
                                                  static_cast<char*>(E->ts_planes) + ts_plane_bytes(256, 256), !E->ts_dgr_ready, st, &ddone,
                                                  E->ts_sign_ready ? E->ts_sign : nullptr));
+                DCTR_REQUIRE(ddone || !E->afm_ah_skipped, "AFM: the forward did not store the attention layer's output and the input gradient that reads its sign words was not taken");
                 if (!ddone) DCTR_TRY(ws_fc_bwd_data_gate(E->ah, A, E->dsc, E->pp(E->p_ao_w), E->pp(fc.w), E->dpairp2, K, n * P, K, A, st, &ddone));
                 DCTR_REQUIRE(ddone, "AFM: the gated input gradient was not taken for a shape ws_takes() accepts");
                 if (!beside) DCTR_TRY(wgrad());

@@ -222,6 +222,7 @@ struct dctr_engine {
     void* ts_sign = nullptr;        // ... the sign words of the attention layer's output (gemm_ts.h bits_out), [MB * P] x 32 bytes
     bool ts_sign_ready = false;     // ... written by this step's forward
     bool afm_ts_wgrad = false;      // ... and the gated weight gradient is gemm_ts.hip's (the attention layer declared TS_WGRAD_SLABS slabs)
+    bool afm_ah_skipped = false;    // ... nor the attention layer's output: both gradient products work from the sign words
     bool afm_pp_skipped = false;    // ... this step's forward did not write the pair tensor (its readers form the rows from the embeddings)
     bool ts_dgr_ready = false;      // ... the input gradient's planes were written by this step's forward (ts_prepare)
     bool afm_gate_slabs = false;    // AFM: attention_out's gradient slabs are laid out for the gated weight gradient (one per batch split)

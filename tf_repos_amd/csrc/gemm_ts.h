@@ -69,7 +69,7 @@ struct TsArgs {
     const float* A;             // the tall operand [M, 32 KG], row-major (GEN: unused)
     int lda;
     const u32x4* planes;        // ts_wsplit_kernel's output for the small operand
-    float* C;                   // [M, 16 NT]
+    float* C;                   // [M, 16 NT] (forward: may be null -- the output itself is not stored)
     int ldc;
     int64_t M;
     const float* bias;          // forward: [N]
@@ -360,8 +360,9 @@ __global__ __launch_bounds__(64 * (16 / TM), NTF == NT ? 1 : 2) void gemm_ts_ker
         }
         // ---- epilogue on the accumulators: register r of lane (c, q) is row 16 i + c, column 16 tt + 4 q + r
         const int rows = rows_of(rt);
-        const auto rc = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.C + (size_t)m0 * a.ldc + hh * N), 0,
-                                                          __builtin_amdgcn_readfirstlane(rows > 0 ? ((rows - 1) * a.ldc + N) * 4 : 0), 0x00020000);
+        // (C == null -- the forward when nobody reads its output, only the score and the sign words: an empty descriptor, every store is dropped)
+        const auto rc = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.C != nullptr ? a.C + (size_t)m0 * a.ldc + hh * N : a.bias), 0,
+                                                          __builtin_amdgcn_readfirstlane(rows > 0 && a.C != nullptr ? ((rows - 1) * a.ldc + N) * 4 : 0), 0x00020000);
         float dot[TM];
         unsigned sgn_lo[TM], sgn_hi[TM];                 // forward: the sign words of this lane's 4 NT outputs per row tile
 #pragma unroll
@@ -468,13 +469,20 @@ struct TswArgs {
     const int16_t* pair_i;
     const int16_t* pair_j;
     int P;
+    // HB: H is not read.  Its signs come from the forward's sign words (TsArgs::bits_out: 32 bytes per row), and the second column sums
+    // follow from the product itself:  sum_r rowscale[r] H[r, a] = sum_r rs[r] 1[H > 0] (sum_k X[r, k] W[k, a] + b[a])
+    //                                                            = sum_k W[k, a] dWraw[k, a] + b[a] dbraw[a]
+    // with dWraw / dbraw this kernel's accumulators before the column scale -- 32 bytes per row instead of 1 KB, and nobody reads H any more.
+    const unsigned long long* bits;
+    const float* W;             // [Kd, A] row-major: the layer's weight
+    const float* bias;          // [A]
 };
 
 // NW waves per block: X has 16 TK NW columns, H has 16 TA NW.  At 256 x 256 the block is EIGHT waves of a [32, 256] output strip each (two
 // per SIMD, 128 accumulator registers): with four waves of [64, 256] the 256 accumulators fill the AGPR half of the register file and the
 // two raw sets + planes no longer fit the other half (355 registers spilled) -- and two waves per SIMD overlap one's conversion with the
 // other's MFMAs for free.
-template <int NW, int TK, int TA, bool GEN = false>
+template <int NW, int TK, int TA, bool GEN = false, bool HB = false>
 __global__ __launch_bounds__(64 * NW, 1) void gemm_tsw_kernel(TswArgs a) {
     static_assert((TK == 2 || TK == 4) && (TA == 2 || TA == 4) && (NW == 4 || NW == 8), "two or four 16-column tiles per wave and operand");
     constexpr int NJ = NW * TA;                         // gate tiles of the block
@@ -493,10 +501,15 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_tsw_kernel(TswArgs a) {
     // this block's rows behind per-block bases: whatever a partial or surplus group addresses beyond them reads as 0 without touching memory
     const auto rx = GEN ? __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.e), 0, __builtin_amdgcn_readfirstlane((int)(a.e_floats * 4)), 0x00020000)
                         : __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.X + (size_t)r0 * a.ldx), 0, __builtin_amdgcn_readfirstlane(rows > 0 ? ((rows - 1) * a.ldx + KD) * 4 : 0), 0x00020000);
-    const auto rh = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.H + (size_t)r0 * a.ldh), 0, __builtin_amdgcn_readfirstlane(rows > 0 ? ((rows - 1) * a.ldh + 16 * TA * NW) * 4 : 0), 0x00020000);
+    const auto rh = HB ? __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.bits + (size_t)r0 * 4), 0, __builtin_amdgcn_readfirstlane(rows * 32), 0x00020000)
+                       : __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.H + (size_t)r0 * a.ldh), 0, __builtin_amdgcn_readfirstlane(rows > 0 ? ((rows - 1) * a.ldh + 16 * TA * NW) * 4 : 0), 0x00020000);
+    // HB: this lane's TA columns 16 TA w + TA c .. are bits sh0 .. sh0 + TA - 1 of one 32-bit half of the sign word (row, q' = column quarter)
+    const int col0 = 16 * TA * w + TA * c;
+    const int sh0 = 4 * ((col0 >> 4) & 7) + (col0 & 3);
+    const int hbo = 8 * q * 32 + ((col0 & 15) >> 2) * 8 + ((col0 >> 4) >= 8 ? 4 : 0);          // byte offset of (row 8 q, that word half)
     const auto rr = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.rowscale + r0), 0, __builtin_amdgcn_readfirstlane(rows * 4), 0x00020000);
-    const int xoff = 4 * ((GEN ? 0 : 8 * q * a.ldx) + 16 * TK * w + TK * c), hoff = 4 * (8 * q * a.ldh + 16 * TA * w + TA * c);
-    const unsigned sx = 4u * (unsigned)a.ldx, sh = 4u * (unsigned)a.ldh;
+    const int xoff = 4 * ((GEN ? 0 : 8 * q * a.ldx) + 16 * TK * w + TK * c), hoff = HB ? hbo : 4 * (8 * q * a.ldh + 16 * TA * w + TA * c);
+    const unsigned sx = 4u * (unsigned)a.ldx, sh = HB ? 32u : 4u * (unsigned)a.ldh;
     // GEN: pair p -> the two fields' offsets inside an example (floats, 16 bits each), in LDS; this lane's (example, pair) of the first of
     // its 8 rows in the next group to load, advanced by 32 rows per group (P > 32: at most one carry)
     unsigned* tab = reinterpret_cast<unsigned*>(ts_lds + 2 * NJ * 1024);
@@ -510,7 +523,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_tsw_kernel(TswArgs a) {
         __syncthreads();
     }
 
-    struct RawH { float h[8][TA]; float rs[8]; };
+    struct RawH { float h[HB ? 1 : 8][TA]; unsigned hb[HB ? 8 : 1]; float rs[8]; };
     struct RawX { float x[8][TK]; float y[GEN ? 8 : 1][TK]; };
     auto ldn = [](auto rs, int voff, unsigned soff_, auto nt, float* d) {
         constexpr int NV = decltype(nt)::value;
@@ -533,7 +546,10 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_tsw_kernel(TswArgs a) {
         ldn(rr, 32 * q, 128u * g, I4{}, &f.rs[0]);
         ldn(rr, 32 * q + 16, 128u * g, I4{}, &f.rs[4]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ldn(rh, hoff, (32u * g + e) * sh, ITA{}, &f.h[e][0]);
+        for (int e = 0; e < 8; ++e) {
+            if constexpr (HB) f.hb[e] = __builtin_amdgcn_raw_buffer_load_b32(rh, hoff, __builtin_amdgcn_readfirstlane((32u * g + e) * sh), 0);
+            else ldn(rh, hoff, (32u * g + e) * sh, ITA{}, &f.h[e][0]);
+        }
     };
     auto loadX = [&](RawX& f, int g) {
         if constexpr (GEN) {
@@ -578,11 +594,17 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_tsw_kernel(TswArgs a) {
             u32x4 gw;
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
-                const float h0 = f.h[2 * tt][j], h1 = f.h[2 * tt + 1][j];
-                gw[tt] = (h0 > 0.f ? 0x3f80u : 0u) | (h1 > 0.f ? 0x3f800000u : 0u);
-                cs[j] += (h0 > 0.f ? f.rs[2 * tt] : 0.f) + (h1 > 0.f ? f.rs[2 * tt + 1] : 0.f);
-                cs2[j] = fmaf(h0, f.rs[2 * tt], cs2[j]);
-                cs2[j] = fmaf(h1, f.rs[2 * tt + 1], cs2[j]);
+                if constexpr (HB) {
+                    const bool g0 = (f.hb[2 * tt] >> (sh0 + j)) & 1u, g1 = (f.hb[2 * tt + 1] >> (sh0 + j)) & 1u;
+                    gw[tt] = (g0 ? 0x3f80u : 0u) | (g1 ? 0x3f800000u : 0u);
+                    cs[j] += (g0 ? f.rs[2 * tt] : 0.f) + (g1 ? f.rs[2 * tt + 1] : 0.f);
+                } else {
+                    const float h0 = f.h[2 * tt][j], h1 = f.h[2 * tt + 1][j];
+                    gw[tt] = (h0 > 0.f ? 0x3f80u : 0u) | (h1 > 0.f ? 0x3f800000u : 0u);
+                    cs[j] += (h0 > 0.f ? f.rs[2 * tt] : 0.f) + (h1 > 0.f ? f.rs[2 * tt + 1] : 0.f);
+                    cs2[j] = fmaf(h0, f.rs[2 * tt], cs2[j]);
+                    cs2[j] = fmaf(h1, f.rs[2 * tt + 1], cs2[j]);
+                }
             }
             *reinterpret_cast<u32x4*>(ts_lds + ((buf * NJ + TA * w + j) * 64 + lane) * 16) = gw;
         }
@@ -626,6 +648,47 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_tsw_kernel(TswArgs a) {
     }
     // ---- epilogue: register r of lane (c, q), tile (i, j = TA wj + jj) is dW[16 TK w + TK (4 q + r) + i][16 TA wj + TA c + jj]
     constexpr int A_ = 16 * TA * NW;
+    if constexpr (HB) {
+        // the second column sums from the raw accumulators: this wave's share sum_{k in its strip} W[k, a] dWraw[k, a] for all A columns,
+        // summed over the four q in the wave and over the NW waves through LDS (the gate images are free now)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(ts_lds);           // [NW + 1][A_]: the waves' shares, then the raw first sums
+#pragma unroll
+        for (int wj = 0; wj < NW; ++wj) {
+            float sw[TA];
+#pragma unroll
+            for (int jj = 0; jj < TA; ++jj) sw[jj] = 0.f;
+#pragma unroll
+            for (int i = 0; i < TK; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* wp = a.W + (size_t)(16 * TK * w + TK * (4 * q + r) + i) * A_ + 16 * TA * wj + TA * c;
+#pragma unroll
+                    for (int jj = 0; jj < TA; ++jj) sw[jj] = fmaf(wp[jj], acc[i][TA * wj + jj][r], sw[jj]);
+                }
+#pragma unroll
+            for (int jj = 0; jj < TA; ++jj) {
+                float v = sw[jj];
+                v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+                if (q == 0) red[w * A_ + 16 * TA * wj + TA * c + jj] = v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TA; ++j) {
+            float s1 = cs[j];
+            s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+            cs[j] = s1;
+            if (q == 0) red[NW * A_ + 16 * TA * w + TA * c + j] = s1;
+        }
+        __syncthreads();
+        for (int col = t; col < A_; col += 64 * NW) {
+            float v = a.bias[col] * red[NW * A_ + col];
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) v += red[ww * A_ + col];
+            if (a.dwo != nullptr) a.dwo[(size_t)blockIdx.x * a.dwo_stride + col] = v;
+            if (a.db != nullptr) a.db[(size_t)blockIdx.x * a.db_stride + col] = red[NW * A_ + col] * a.colscale[col];
+        }
+    }
     // (buffer stores: the lane part of the address is one register, tile and row are a scalar offset)
     const auto rw = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.dw + (size_t)blockIdx.x * a.dw_stride), 0, 16 * TK * NW * A_ * 4, 0x00020000);
     const int woff = 4 * (TK * 4 * q * A_ + TA * c);
@@ -655,6 +718,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_tsw_kernel(TswArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     }
     // the column sums of this wave's H columns: the four q hold different rows of the same columns
+    if constexpr (!HB)
 #pragma unroll
     for (int j = 0; j < TA; ++j) {
         float s1 = cs[j], s2 = cs2[j];

@@ -71,9 +71,9 @@ int ts_split(const float* w, int ldw, const TsSplitJob& j0, const TsSplitJob* j1
     return DCTR_OK;
 }
 
-template <int NW, int TK, int TA, bool GEN = false>
+template <int NW, int TK, int TA, bool GEN = false, bool HB = false>
 int tsw_launch(const TswArgs& a, int grid, hipStream_t st) {
-    auto kern = gemm_tsw_kernel<NW, TK, TA, GEN>;
+    auto kern = gemm_tsw_kernel<NW, TK, TA, GEN, HB>;
     const int lds = 2 * NW * TA * 1024 + (GEN ? a.P * 4 : 0);
     kern<<<grid, 64 * NW, lds, st>>>(a);
     DCTR_LAUNCH_CHECK();
@@ -85,6 +85,11 @@ int tsw_launch(const TswArgs& a, int grid, hipStream_t st) {
 
 // host logic: would a product over M rows with a reduction of R and N output columns take these kernels (alignment permitting)?
 bool ts_takes(int64_t M, int R, int N) { return ts_enabled() && M >= 65536 && ts_dim_ok(R) && ts_dim_ok(N); }
+// are the forward's sign words used by the two gradient products (DCTR_GEMM_TS_BITS=0: they read the layer's output itself)?
+bool ts_bits_enabled() {
+    static const bool off = getenv("DCTR_GEMM_TS_BITS") != nullptr && atoi(getenv("DCTR_GEMM_TS_BITS")) == 0;      // A/B knob
+    return !off;
+}
 size_t ts_plane_bytes(int R, int N) { return (size_t)3 * R * N * 2; }
 
 // both plane sets of one layer weight W [K, N] in one launch: the forward's into fwd_planes, the gated input gradient's (x kscale) into dgr_planes
@@ -108,7 +113,7 @@ int ts_fc_fwd_dot(const float* x, int ldx, const float* w, const float* b, float
     if (pairs != nullptr && !ts_pairs_ok(pairs, M, K)) return DCTR_OK;
     if (pairs != nullptr) { x = pairs->e; ldx = 4; }
     if (!ts_takes(M, K, N) || planes_ws == nullptr || !al16(w) || !al16(x) || (ldx & 3) || !al16(y) || (ldy & 3) || !al16(b) || !al16(dot_w) || b == nullptr ||
-        dot_w == nullptr || ldx > (1 << 20) || ldy > (1 << 20))
+        dot_w == nullptr || ldx > (1 << 20) || ldy > (1 << 20) || (y == nullptr && sign_bits_out == nullptr))
         return DCTR_OK;
     if (split_here) DCTR_TRY(ts_split(w, N, TsSplitJob{0, nullptr, K, N, static_cast<u32x4*>(planes_ws)}, nullptr, st));
     TsArgs a{};
@@ -135,8 +140,7 @@ int ts_fc_bwd_data_gate(const float* h, int ldh, const float* rowscale, const fl
     TsArgs a{};
     a.A = h; a.lda = ldh; a.planes = static_cast<const u32x4*>(planes_ws); a.C = dx; a.ldc = lddx; a.M = M; a.rowscale = rowscale;
     *done = true;
-    static const bool no_bits = getenv("DCTR_GEMM_TS_BITS") != nullptr && atoi(getenv("DCTR_GEMM_TS_BITS")) == 0;      // A/B knob
-    if (sign_bits != nullptr && !no_bits && (reinterpret_cast<uintptr_t>(sign_bits) & 7) == 0) {
+    if (sign_bits != nullptr && ts_bits_enabled() && (reinterpret_cast<uintptr_t>(sign_bits) & 7) == 0) {
         a.bits_in = static_cast<const unsigned long long*>(sign_bits);
         return ts_dispatch_bits(N, K, a, st);
     }
@@ -149,10 +153,13 @@ int ts_fc_bwd_data_gate(const float* h, int ldh, const float* rowscale, const fl
 // (slabs beyond the rows are written as zeros); one block per slab: 256 slabs fill the chip.
 int ts_fc_bwd_weights_gate(const float* x, int ldx, const float* h, int ldh, const float* rowscale, const float* colscale, float* dw_part,
                            int64_t dw_stride, float* db_part, int64_t db_stride, float* dwo_part, int64_t dwo_stride, int64_t M, int K, int N, int splits,
-                           hipStream_t st, bool* done, const TsPairs* pairs) {
+                           hipStream_t st, bool* done, const TsPairs* pairs, const void* sign_bits, const float* w, const float* bias) {
     *done = false;
     if (pairs != nullptr && !ts_pairs_ok(pairs, M, K)) return DCTR_OK;
     if (pairs != nullptr) { x = pairs->e; ldx = 4; }
+    // the gate from the forward's sign words, the second sums from the product (gemm_ts.h HB): with generated rows only (what the engine runs)
+    const bool hb = sign_bits != nullptr && pairs != nullptr && w != nullptr && bias != nullptr && ts_bits_enabled() && (reinterpret_cast<uintptr_t>(sign_bits) & 7) == 0;
+    if (hb && h == nullptr) { h = rowscale; ldh = 4; }
     if (!ts_enabled() || !ts_dim_ok(K) || !ts_dim_ok(N) || splits < 1 || splits > 65535 || M < 0 || !al16(x) || !al16(h) || (ldx & 3) || (ldh & 3) ||
         !al16(rowscale) || colscale == nullptr || !al16(dw_part) || (dw_stride & 3) || ldx > (1 << 16) || ldh > (1 << 16))
         return DCTR_OK;
@@ -162,6 +169,14 @@ int ts_fc_bwd_weights_gate(const float* x, int ldx, const float* h, int ldh, con
     a.X = x; a.ldx = ldx; a.H = h; a.ldh = ldh; a.rowscale = rowscale; a.colscale = colscale; a.dw = dw_part; a.dw_stride = dw_stride;
     a.db = db_part; a.db_stride = db_stride; a.dwo = dwo_part; a.dwo_stride = dwo_stride; a.M = M; a.rows_per_block = (int)rpb;
     *done = true;
+    if (hb) {
+        a.e = pairs->e; a.e_ld = pairs->e_ld; a.e_floats = (int64_t)pairs->examples * pairs->e_ld; a.pair_i = pairs->pair_i; a.pair_j = pairs->pair_j; a.P = pairs->P;
+        a.bits = static_cast<const unsigned long long*>(sign_bits); a.W = w; a.bias = bias; a.H = nullptr;
+        if (K == 256 && N == 256) return tsw_launch<8, 2, 2, true, true>(a, splits, st);
+        if (K == 256 && N == 128) return tsw_launch<4, 4, 2, true, true>(a, splits, st);
+        if (K == 128 && N == 256) return tsw_launch<4, 2, 4, true, true>(a, splits, st);
+        return tsw_launch<4, 2, 2, true, true>(a, splits, st);
+    }
     if (pairs != nullptr) {
         a.e = pairs->e; a.e_ld = pairs->e_ld; a.e_floats = (int64_t)pairs->examples * pairs->e_ld; a.pair_i = pairs->pair_i; a.pair_j = pairs->pair_j; a.P = pairs->P;
         if (K == 256 && N == 256) return tsw_launch<8, 2, 2, true>(a, splits, st);
@@ -203,8 +218,9 @@ int dctr_fc_bwd_data_gate_split(const float* d_h, int ldh, const void* d_sign_bi
     return DCTR_OK;
 }
 
-static int bwd_weights_gate_split(const float* d_x, int ldx, const TsPairs* pairs, const float* d_h, int ldh, const float* d_rowscale, const float* d_colscale,
-                                  float* d_dw, float* d_db, float* d_dwo, int64_t M, int K, int N, float* d_workspace, size_t workspace_bytes, void* stream) {
+static int bwd_weights_gate_split(const float* d_x, int ldx, const TsPairs* pairs, const float* d_h, int ldh, const void* sign_bits, const float* d_w, const float* d_bias,
+                                  const float* d_rowscale, const float* d_colscale, float* d_dw, float* d_db, float* d_dwo, int64_t M, int K, int N, float* d_workspace,
+                                  size_t workspace_bytes, void* stream) {
     hipStream_t st = as_stream(stream);
     DCTR_REQUIRE(d_dw != nullptr && d_db != nullptr && d_dwo != nullptr, "fc_bwd_weights_gate_split: three outputs");
     const size_t per = ((size_t)K * N + 2 * (size_t)N) * sizeof(float);
@@ -215,7 +231,7 @@ static int bwd_weights_gate_split(const float* d_x, int ldx, const TsPairs* pair
     float* bpart = wpart + (size_t)splits * K * N;
     float* opart = bpart + (size_t)splits * N;
     bool done = false;
-    DCTR_TRY(ts_fc_bwd_weights_gate(d_x, ldx, d_h, ldh, d_rowscale, d_colscale, wpart, (int64_t)K * N, bpart, N, opart, N, M, K, N, splits, st, &done, pairs));
+    DCTR_TRY(ts_fc_bwd_weights_gate(d_x, ldx, d_h, ldh, d_rowscale, d_colscale, wpart, (int64_t)K * N, bpart, N, opart, N, M, K, N, splits, st, &done, pairs, sign_bits, d_w, d_bias));
     if (!done) { set_error("fc_bwd_weights_gate_split: no tall split-precision kernel takes M=%lld K=%d N=%d with these pointers", (long long)M, K, N); return DCTR_ERR_UNSUPPORTED; }
     DCTR_TRY(sum_partials(wpart, (int64_t)K * N, splits, (int64_t)K * N, d_dw, st));
     DCTR_TRY(sum_partials(bpart, N, splits, N, d_db, st));
@@ -225,7 +241,7 @@ static int bwd_weights_gate_split(const float* d_x, int ldx, const TsPairs* pair
 
 int dctr_fc_bwd_weights_gate_split(const float* d_x, int ldx, const float* d_h, int ldh, const float* d_rowscale, const float* d_colscale, float* d_dw,
                                    float* d_db, float* d_dwo, int64_t M, int K, int N, float* d_workspace, size_t workspace_bytes, void* stream) {
-    return bwd_weights_gate_split(d_x, ldx, nullptr, d_h, ldh, d_rowscale, d_colscale, d_dw, d_db, d_dwo, M, K, N, d_workspace, workspace_bytes, stream);
+    return bwd_weights_gate_split(d_x, ldx, nullptr, d_h, ldh, nullptr, nullptr, nullptr, d_rowscale, d_colscale, d_dw, d_db, d_dwo, M, K, N, d_workspace, workspace_bytes, stream);
 }
 
 int dctr_pairs_fc_fwd_dot_split(const float* d_e, int e_ld, int examples, const int16_t* d_pair_i, const int16_t* d_pair_j, int P, const float* d_w,
@@ -239,10 +255,11 @@ int dctr_pairs_fc_fwd_dot_split(const float* d_e, int e_ld, int examples, const 
 }
 
 int dctr_pairs_fc_bwd_weights_gate_split(const float* d_e, int e_ld, int examples, const int16_t* d_pair_i, const int16_t* d_pair_j, int P, const float* d_h,
-                                         int ldh, const float* d_rowscale, const float* d_colscale, float* d_dw, float* d_db, float* d_dwo, int64_t M, int K,
-                                         int N, float* d_workspace, size_t workspace_bytes, void* stream) {
+                                         int ldh, const void* d_sign_bits, const float* d_w, const float* d_b, const float* d_rowscale, const float* d_colscale,
+                                         float* d_dw, float* d_db, float* d_dwo, int64_t M, int K, int N, float* d_workspace, size_t workspace_bytes, void* stream) {
     const TsPairs pairs{d_e, e_ld, examples, d_pair_i, d_pair_j, P};
-    return bwd_weights_gate_split(nullptr, 0, &pairs, d_h, ldh, d_rowscale, d_colscale, d_dw, d_db, d_dwo, M, K, N, d_workspace, workspace_bytes, stream);
+    return bwd_weights_gate_split(nullptr, 0, &pairs, d_h, ldh, d_sign_bits, d_w, d_b, d_rowscale, d_colscale, d_dw, d_db, d_dwo, M, K, N, d_workspace, workspace_bytes,
+                                  stream);
 }
 
 }  // extern "C"

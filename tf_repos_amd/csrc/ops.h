@@ -157,7 +157,9 @@ int ts_fc_bwd_data_gate(const float* h, int ldh, const float* rowscale, const fl
 inline size_t ts_sign_bytes(int64_t M) { return (size_t)M * 32; }      // the forward's sign words: one u64 per row and lane quarter
 int ts_fc_bwd_weights_gate(const float* x, int ldx, const float* h, int ldh, const float* rowscale, const float* colscale, float* dw_part,
                            int64_t dw_stride, float* db_part, int64_t db_stride, float* dwo_part, int64_t dwo_stride, int64_t M, int K, int N, int splits,
-                           hipStream_t st, bool* done, const TsPairs* pairs = nullptr);
+                           hipStream_t st, bool* done, const TsPairs* pairs = nullptr, const void* sign_bits = nullptr, const float* w = nullptr,
+                           const float* bias = nullptr);
+bool ts_bits_enabled();
 constexpr int TS_WGRAD_SLABS = 256;         // one block per slab and CU
 int ts_prepare(const float* w, int K, int N, const float* kscale, void* fwd_planes, void* dgr_planes, hipStream_t st);
 int dr_wgrad_splits(int M, int K, int N);

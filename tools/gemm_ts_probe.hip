@@ -372,6 +372,35 @@ static void run(int64_t M, int reps) {
                    diff_words(dw, dw2, (size_t)grid_w * R * N), diff_words(db, db2, grid_w * N), diff_words(dwo, dwo2, grid_w * N));
             CK(hipFree(dw2)); CK(hipFree(db2)); CK(hipFree(dwo2));
         }
+        {   // gate from the forward's sign words, second sums from the product itself; X generated
+            float *dw2, *db2, *dwo2;
+            CK(hipMalloc(&dw2, (size_t)grid_w * R * N * 4)); CK(hipMalloc(&db2, grid_w * N * 4)); CK(hipMalloc(&dwo2, grid_w * N * 4));
+            TswArgs a2 = aw; a2.dw = dw2; a2.db = db2; a2.dwo = dwo2; a2.e = E_; a2.e_ld = e_ld; a2.e_floats = nex * e_ld; a2.pair_i = pi; a2.pair_j = pj; a2.P = P;
+            a2.bits = SB; a2.W = W; a2.bias = b; a2.H = nullptr;
+            auto kwb = gemm_tsw_kernel<NW, TK, TA, true, true>;
+            const int ldsg2 = ldsw + P * 4;
+            best = 1e9f;
+            for (int r = 0; r < reps; ++r) {
+                CK(hipEventRecord(e0));
+                kwb<<<grid_w, 64 * NW, ldsg2>>>(a2);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                best = std::min(best, ms);
+            }
+            CK(hipGetLastError());
+            // second sums: compare the slab totals with the H-reading kernel's
+            std::vector<float> o1(grid_w * N), o2(grid_w * N);
+            CK(hipMemcpy(o1.data(), dwo, o1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(o2.data(), dwo2, o2.size() * 4, hipMemcpyDeviceToHost));
+            double em = 0, sm = 0;
+            for (int an = 0; an < N; ++an) {
+                double t1 = 0, t2 = 0;
+                for (int b2 = 0; b2 < grid_w; ++b2) { t1 += o1[b2 * N + an]; t2 += o2[b2 * N + an]; }
+                em = std::max(em, std::fabs(t1 - t2)); sm = std::max(sm, std::fabs(t1));
+            }
+            printf("gate wgrad from the sign bits, X generated: %.3f ms  %.1f TF-equivalent; words differing: %zu of dW, %zu of db; second column sums (W . dW + b db) against the sums over H: max |diff| %.3e (values to %.2f)\n",
+                   best, gf / best, diff_words(dw, dw2, (size_t)grid_w * R * N), diff_words(db, db2, grid_w * N), em, sm);
+            CK(hipFree(dw2)); CK(hipFree(db2)); CK(hipFree(dwo2));
+        }
         CK(hipFree(dw)); CK(hipFree(db)); CK(hipFree(dwo));
     }
     CK(hipFree(X)); CK(hipFree(Y)); CK(hipFree(DX)); CK(hipFree(W)); CK(hipFree(b)); CK(hipFree(wo)); CK(hipFree(rsc)); CK(hipFree(dot)); CK(hipFree(SB)); CK(hipFree(pf)); CK(hipFree(pg)); CK(hipFree(E_)); CK(hipFree(pi)); CK(hipFree(pj));
