@@ -626,6 +626,72 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_tsw_kernel(TswArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // PIPE (the engine's form: sign bits, generated rows, eight waves): the conversion of group g + 1 is cut into NJ pieces -- one pair of
+    // rows of one X tile (product, scale, three-plane split) or of one gate tile (bit tests, the first column sum) -- and piece j sits in
+    // region j of group g's multiplication, between that column tile's six MFMAs: the VALU stream runs under the matrix pipe instead of in
+    // front of the barrier (measured before: 0.67 ms of MFMAs + 0.65 ms of everything else, no overlap).  A second plane set takes the
+    // conversion while the first feeds the MFMAs; the gate images alternate as before; one barrier per group.
+    constexpr bool PIPE = HB && GEN && NW == 8 && TK == 2 && TA == 2;
+    if constexpr (PIPE) {
+        static_assert(NJ == 16, "eight X pieces + eight gate pieces");
+        RawH hh;
+        RawX xx;
+        DrPlanes pq[2][TK];                             // [g & 1]: planes of group g
+        u32x4 gwt;                                      // the gate tile being assembled
+        // piece j of the conversion of (xx, hh) into pq[pn] / gate image `img`
+        auto piece = [&](auto jc, int pn, int img) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j < 8) {
+                constexpr int i = j / 4, tt = j % 4;
+                const float x0 = xx.x[2 * tt][i] * xx.y[2 * tt][i] * hh.rs[2 * tt], x1 = xx.x[2 * tt + 1][i] * xx.y[2 * tt + 1][i] * hh.rs[2 * tt + 1];
+                const unsigned h = dr_pk_bf16(x0, x1);
+                const float r0_ = dr_sub(x0, __uint_as_float(h << 16)), r1_ = dr_sub(x1, __uint_as_float(h & 0xffff0000u));
+                const unsigned m = dr_pk_bf16(r0_, r1_);
+                const float s0 = dr_sub(r0_, __uint_as_float(m << 16)), s1 = dr_sub(r1_, __uint_as_float(m & 0xffff0000u));
+                pq[pn][i].h[tt] = h; pq[pn][i].m[tt] = m; pq[pn][i].l[tt] = dr_pk_bf16(s0, s1);
+            } else {
+                constexpr int jj = (j - 8) / 4, tt = (j - 8) % 4;
+                const bool g0 = (hh.hb[2 * tt] >> (sh0 + jj)) & 1u, g1 = (hh.hb[2 * tt + 1] >> (sh0 + jj)) & 1u;
+                gwt[tt] = (g0 ? 0x3f80u : 0u) | (g1 ? 0x3f800000u : 0u);
+                cs[jj] += (g0 ? hh.rs[2 * tt] : 0.f) + (g1 ? hh.rs[2 * tt + 1] : 0.f);
+                if constexpr (tt == 3) *reinterpret_cast<u32x4*>(ts_lds + ((img * NJ + TA * w + jj) * 64 + lane) * 16) = gwt;
+            }
+        };
+        if (G > 0) {
+            loadH(hh, 0); loadX(xx, 0);
+            dr_static_for<NJ>([&](auto jc) { piece(jc, 0, 0); });
+            loadH(hh, 1); loadX(xx, 1);                 // (beyond the block's rows: zeros, no traffic)
+        }
+        __syncthreads();
+        auto group = [&](int g, auto pc) {
+            constexpr int pcur = decltype(pc)::value, pnxt = pcur ^ 1;
+            const char* base = ts_lds + (pcur * NJ * 64 + lane) * 16;
+            u32x4 fg[2];
+            fg[0] = *reinterpret_cast<const u32x4*>(base);
+            dr_static_for<NJ>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (j + 1 < NJ) fg[(j + 1) & 1] = *reinterpret_cast<const u32x4*>(base + 1024 * (j + 1));
+                const u32x4 gq = fg[j & 1];
+#pragma unroll
+                for (int i = 0; i < TK; ++i) acc[i][j] = dr_mfma_bf16(pq[pcur][i].l, gq, acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < TK; ++i) acc[i][j] = dr_mfma_bf16(pq[pcur][i].m, gq, acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < TK; ++i) acc[i][j] = dr_mfma_bf16(pq[pcur][i].h, gq, acc[i][j]);
+                piece(jc, pnxt, pnxt);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // (asking for the X rows of group g + 2 pair by pair from region 8 on, as their registers free up, costs 151 spilled registers: 2.4 ms)
+            loadH(hh, g + 2); loadX(xx, g + 2);
+            __syncthreads();
+        };
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        for (int g = 0; g < G; g += 2) {
+            group(g, P0{});
+            if (g + 1 < G) group(g + 1, P1{});          // (uniform)
+        }
+    } else {
     // H and the row scales (HBM) two groups ahead in two sets; X beside them -- or, generated from the cache-resident embeddings, ONE group
     // ahead in one set (twice the registers per row)
     RawH h0, h1;
@@ -645,6 +711,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_tsw_kernel(TswArgs a) {
             __syncthreads();
             products(1);
         }
+    }
     }
     // ---- epilogue: register r of lane (c, q), tile (i, j = TA wj + jj) is dW[16 TK w + TK (4 q + r) + i][16 TA wj + TA c + jj]
     constexpr int A_ = 16 * TA * NW;
