@@ -165,6 +165,11 @@ def test_rows_formed_from_the_embeddings_give_the_same_bits(B, F, K, N, dev):
     capi.check(lib.dctr_pairs_fc_bwd_weights_gate_split(capi.ptr(e), F * K, B, capi.ptr(dpi), capi.ptr(dpj), P, None, 0, capi.ptr(s1), capi.ptr(w), capi.ptr(b),
                                                         capi.ptr(rs), capi.ptr(wo), *[capi.ptr(t) for t in out3], M, K, N, capi.ptr(wsp), wsp.numel() * 4, st))
     assert torch.equal(out1[0], out3[0]) and torch.equal(out1[1], out3[1])
+    out4 = [torch.empty(K, N, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev)]
+    for _ in range(3):                                   # (the conversion of the next rows runs between the MFMAs of these: same bits every run)
+        capi.check(lib.dctr_pairs_fc_bwd_weights_gate_split(capi.ptr(e), F * K, B, capi.ptr(dpi), capi.ptr(dpj), P, None, 0, capi.ptr(s1), capi.ptr(w), capi.ptr(b),
+                                                            capi.ptr(rs), capi.ptr(wo), *[capi.ptr(t) for t in out4], M, K, N, capi.ptr(wsp), wsp.numel() * 4, st))
+        assert all(torch.equal(a, c) for a, c in zip(out3, out4))
     ref_o = (y1.double() * rs.double()[:, None]).sum(0)
     e1, e3 = float((out1[2].double() - ref_o).abs().max()), float((out3[2].double() - ref_o).abs().max())
     print("second column sums: over H max err %.2e, from the product %.2e (values to %.1f)" % (e1, e3, float(ref_o.abs().max())))
