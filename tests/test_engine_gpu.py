@@ -383,13 +383,13 @@ def test_afm_attention_out_inside_the_products(K, A, F, B, dev):
 
 @pytest.mark.parametrize("K,A,F,B", [(128, 128, 12, 5001), (256, 256, 9, 7300), (256, 128, 10, 5900)])
 def test_afm_tall_split_precision_products_in_the_step(K, A, F, B, dev):
-    """From 65536 pair rows and 5 G multiply-adds per product on, a handle in the default (split) gemm mode runs the attention layer's three
+    """From 65536 pair rows and 2.5 G multiply-adds per product on, a handle in the default (split) gemm mode runs the attention layer's three
     products on the bf16 matrix pipe (csrc/gemm_ts.h): forward + score with the pair rows e_i . e_j formed in the registers (the [B P, K]
     tensor of AFM.py:130-139 is never written) and the sign bits of the output beside it, gated input gradient from those bits, gated weight
     gradient from 256 partial slabs -- against the oracle at the tolerances of the exact path.  Then two smaller batches on the same handle:
-    ~70000 rows (below the work threshold at these shapes: the forward and the input gradient go back to the f32 kernels while the weight
-    gradient keeps the 256 slabs the handle declared -- most of them short or empty), and below 65536 rows, where everything takes the
-    materialising passes."""
+    ~70000 rows (one block per row tile instead of looping blocks; at K = A = 128 below the work threshold: the forward and the input gradient
+    go back to the f32 kernels while the weight gradient keeps the 256 slabs the handle declared -- most of them short or empty), and below
+    65536 rows, where everything takes the materialising passes."""
     import os
     from tf_repos_amd import capi
     V = 3000

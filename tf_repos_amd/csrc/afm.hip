@@ -607,11 +607,11 @@ static int64_t afm_ts_min_rows() {
     static const int64_t v = getenv("DCTR_AFM_TS_MIN_ROWS") ? atoll(getenv("DCTR_AFM_TS_MIN_ROWS")) : 65536;     // A/B knob
     return v;
 }
-// ... and from this many multiply-adds per product (rows x K x A): the reference's own run.sh:18 point (B = 128, K = 256, A = 128: 3.1 G) is
-// faster on the f32 kernels (0.58 against 0.65-0.75 ms/step, alternated), its script default A = 256 at the same batch (6.2 G) on these
-// (0.395 against 0.59) -- the 256 partial slabs and whole-CU blocks are a fixed cost that 371 row tiles of half the width do not repay.
+// ... and from this many multiply-adds per product (rows x K x A): the reference's own run.sh:18 point (B = 128, K = 256, A = 128: 3.1 G) is the
+// smallest shape measured -- 0.58 -> 0.41 ms/step once the tall kernels run one block per row tile there (gemm_ts.hip: with looping blocks that
+// hold every CU until the kernel ends it LOST, 0.73).  Below it the 256 partial slabs and the plane split are not known to be repaid.
 static bool afm_ts_worth(int64_t rows, int K, int A) {
-    static const double v = getenv("DCTR_AFM_TS_MIN_MACS") ? atof(getenv("DCTR_AFM_TS_MIN_MACS")) : 5e9;          // A/B knob
+    static const double v = getenv("DCTR_AFM_TS_MIN_MACS") ? atof(getenv("DCTR_AFM_TS_MIN_MACS")) : 2.5e9;          // A/B knob
     return rows >= afm_ts_min_rows() && (double)rows * K * A >= v;
 }
 static bool afm_in_products() {

@@ -39,7 +39,13 @@ int ts_launch(const TsArgs& a, hipStream_t st) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     DCTR_HIP_CHECK(attr);
     constexpr int H = NTF / NT;                             // column halves: two blocks per CU
-    const int grid = (int)std::min<int64_t>((a.M + 255) / 256 * H, CUS * H);
+    // Persistent blocks (one per CU slot, looping over the row tiles) save the prologue of every tile but hold every CU until the kernel ends;
+    // with few tiles per slot the step's other streams (next batch's grouping, table sweep) pay for that with a wait per product.
+    // AFM at run.sh:18's B = 128, A = 128 (371 row tiles): 0.73 ms/step with looping blocks, 0.41 with one block per tile (the f32 kernels: 0.58).
+    // DCTR_GEMM_TS_PERSIST_TILES: from this many tiles per slot on the blocks loop (default 2); below, one block per tile.
+    static const int persist_from = getenv("DCTR_GEMM_TS_PERSIST_TILES") ? atoi(getenv("DCTR_GEMM_TS_PERSIST_TILES")) : 2;     // A/B knob
+    const int64_t tiles = (a.M + 255) / 256 * H;
+    const int grid = tiles >= (int64_t)persist_from * CUS * H ? CUS * H : (int)std::min<int64_t>(tiles, 1 << 20);
     kern<<<grid, 64 * (16 / TM), lds, st>>>(a);
     DCTR_LAUNCH_CHECK();
     g_dr3_launches.fetch_add(1, std::memory_order_relaxed);
