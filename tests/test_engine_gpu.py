@@ -124,12 +124,14 @@ def test_outer_pnn_first_layer_ops_through_the_c_abi(K, H, B, F, dev):
     assert (dEg.cpu().double() - dE.reshape(B, F * K)).abs().max() <= 1e-5
 
 
-@pytest.mark.parametrize("K,A,B,F,keep", [(16, 32, 96, 39, (1.0, 1.0)), (16, 32, 64, 12, (0.7, 0.6)), (256, 128, 24, 39, (0.5, 0.5)), (8, 16, 50, 10, (1.0, 1.0))])
+@pytest.mark.parametrize("K,A,B,F,keep", [(16, 32, 96, 39, (1.0, 1.0)), (16, 32, 64, 12, (0.7, 0.6)), (256, 128, 24, 39, (0.5, 0.5)), (8, 16, 50, 10, (1.0, 1.0)),
+                                          (256, 256, 128, 39, (0.5, 0.5)), (256, 128, 130, 39, (1.0, 1.0))])
 def test_afm_interaction_ops_through_the_c_abi(K, A, B, F, keep, dev):
     """dctr_afm_fwd / dctr_afm_bwd (AFM.py:127-158: pair products, attention network, softmax over the pairs, both dropouts, pooling)
     against the same lines written out in fp64 with autograd; the attention variables' gradients through dctr_param_grad_get.
     K = 16 takes the fused attention kernels, K = 256 / A = 128 (run.sh:18) the layer-by-layer path with the products carrying
-    attention_out, K = 8 the small-row forms."""
+    attention_out, K = 8 the small-row forms; K = 256 at B = 128 / 130 (95 k pair rows: run.sh:18's own batch) the tall split-precision products in the
+    default gemm mode (csrc/gemm_ts.h: neither the pair tensor nor the attention layer's output is written) and the f32 kernels in the exact one."""
     from tf_repos_amd import capi
     from tf_repos_amd.engine import Engine, EngineConfig
     P = F * (F - 1) // 2
@@ -156,8 +158,10 @@ def test_afm_interaction_ops_through_the_c_abi(K, A, B, F, keep, dev):
     row = [i for i in range(F - 1) for _ in range(i + 1, F)]
     col = [j for i in range(F - 1) for j in range(i + 1, F)]
     pp = e64[:, row, :] * e64[:, col, :]                                        # AFM.py:134-138
-    ah = torch.relu(pp.reshape(-1, K) @ prm[0] + prm[1])                        # AFM.py:142-145
+    z = pp.reshape(-1, K) @ prm[0] + prm[1]
+    ah = torch.relu(z)                                                          # AFM.py:142-145
     sc = (ah @ prm[2] + prm[3]).reshape(B, P, 1)                                # AFM.py:147
+    sc.retain_grad()
     soft = torch.softmax(sc, dim=1)                                             # AFM.py:151
     a_d = soft * m_att / keep[0]                                                # AFM.py:152-153
     y = (a_d * pp).sum(1) * m_emb / keep[1]                                     # AFM.py:156-158
@@ -167,11 +171,20 @@ def test_afm_interaction_ops_through_the_c_abi(K, A, B, F, keep, dev):
     assert (att.cpu().double() - soft.detach().reshape(B, P)).abs().max() <= 1e-6         # (the softmax weights, before their dropout)
     dE = eng.afm_bwd(dy.to(dev))
     assert (dE.cpu().double() - e64.grad.reshape(B, F * K)).abs().max() <= 2e-6 * max(1.0, float(e64.grad.abs().max()))
+    # ReLU decisions at |z| below fp32's resolution of z can fall either way in ANY fp32 evaluation (24 M of them at K = A = 256, B = 128: three
+    # within 1e-7 of zero, one within 3e-8); one that does moves dW[:, a] by d sc[r] w_o[a] pp[r, :] and db[a] by d sc[r] w_o[a].  Budget for exactly
+    # those (tools/afm_relu_flip_diag.py: the one column with such a z carries 4.7e-7 of error in split mode, every other column <= 2e-8).
+    near = (z.detach().abs() < 2e-7).double()
+    dsc = sc.grad.reshape(-1, 1).abs()
+    slack = {"att_mlp0/weights": ((pp.detach().reshape(-1, K).abs() * dsc).t() @ near) * prm[2].detach().abs().reshape(1, -1),
+             "att_mlp0/biases": ((dsc * near).sum(0)) * prm[2].detach().abs().reshape(-1)}
     for name, t in zip(("att_mlp0/weights", "att_mlp0/biases", "attention_out/weights", "attention_out/biases"), prm):
         got = eng.get_grad(name).astype(np.float64).reshape(t.shape)
         scale = max(1e-3, float(t.grad.abs().max()))
         # (attention_out's bias has gradient exactly 0 -- the softmax is shift-invariant -- and fp32 leaves ~1e-8 of rounding there)
-        assert np.abs(got - t.grad.numpy()).max() <= max(3e-6 * scale, 1e-7), (name, np.abs(got - t.grad.numpy()).max(), scale)
+        tol = max(3e-6 * scale, 1e-7) + (slack[name].numpy().reshape(t.shape) if name in slack else 0.0)
+        err = np.abs(got - t.grad.numpy())
+        assert (err <= tol).all(), (name, float(err.max()), scale, int(near.sum()), float(np.max(tol)))
     eng.close()
 
 
